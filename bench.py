@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: passive U-Net separator pair (get_binSepMasks + convert_bin2mono), spectrograms/s.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic 512xTm binaural log-magnitude spectrograms
+already resident in HBM (BASELINE.json configs[1]: batch 256, 512x256).  The path shards by batch with no
+data-path collective, so N ranks each run the full batch: weak scaling, value = all ranks'
+spectrograms / max-over-ranks time.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     dominant kernel family (the MFMA implicit-GEMM conv): algorithmic FLOP / HIP-event time,
+               measured inside the timed region on the launch stream.
+  cpu_baseline the oracle (oracle/m2h_oracle.py, a PyTorch-CPU restatement of the reference) timed on this
+               host's cores on a bounded sample of the same workload (kind "port").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "move2hear-active-av-separation_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--tm", type=int, default=256, help="time frames (32 = reference-native, 256 = headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def make_policy(dev, seed=1):
+    from m2h import synthetic
+    from m2h.common.spaces import move2hear_observation_space
+    from m2h.pretrain.passive.policy import Move2HearPassiveWoMemoryPolicy
+    pol = Move2HearPassiveWoMemoryPolicy(move2hear_observation_space())
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.passive_shapes(), seed).items()}
+    pol.load_state_dict(sd)
+    return pol.to(dev).eval(), sd
+
+
+def make_inputs(dev, batch, tm, seed):
+    """Seeded synthetic spectrograms generated on the device (same distribution as m2h.synthetic: log1p of a
+    Rayleigh magnitude with a per-frequency gain); kept resident in HBM."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    re = torch.randn(batch, 512, tm, 2, device=dev, generator=g)
+    im = torch.randn(batch, 512, tm, 2, device=dev, generator=g)
+    gain = torch.exp(torch.rand(batch, 512, 1, 1, device=dev, generator=g) * 3.0 - 2.0)
+    mix = torch.log1p(torch.sqrt(re * re + im * im) * gain).contiguous()
+    tc = torch.randint(0, 11, (batch, 1), device=dev, generator=g)
+    return mix, tc
+
+
+def cpu_baseline(sd, tm, seconds):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import m2h_oracle as O
+    from m2h import synthetic
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    bs = 8
+    mixed, tc = synthetic.make_passive_inputs(bs, tm, 5)
+    mix, tct = torch.from_numpy(mixed), torch.from_numpy(tc)
+    with torch.no_grad():
+        O.passive_pair(sd, mix, tct)  # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            O.passive_pair(sd, mix, tct)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or n >= 200:
+                break
+    return {"value": bs * n / el, "unit": "spectrograms/s", "cores": cores, "kind": "port",
+            "sample": "%d batches of %d 512x%d spectrograms through oracle.passive_pair (PyTorch-CPU fp32, %d threads), %.1f s"
+                      % (n, bs, tm, cores, el)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the m2h ops have no CPU path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from m2h import ops
+    pol, sd = make_policy(dev)
+    mix, tc = make_inputs(dev, args.batch, args.tm, 1000 + rank)
+    obs = {"mixed_bin_audio_mag": mix, "target_class": tc}
+
+    def step():
+        with torch.no_grad():
+            masks = pol.get_binSepMasks(obs)
+            mono = pol.convert_bin2mono(masks, mixed_audio=mix)
+        return masks, mono
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    sink = None if args.no_kernel_timing else []
+    ops.set_timing(sink)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_timing(None)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel accounting from the HIP events of the timed region
+    roofline = None
+    layers = None
+    if sink:
+        fam = {}
+        per_layer = {}
+        for name, meta, e0, e1 in sink:
+            ms = e0.elapsed_time(e1)
+            k = meta.get("kernel", name)
+            f = fam.setdefault(k, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+            f["ms"] += ms
+            f["flops"] += meta.get("flops", 0.0)
+            f["bytes"] += meta.get("bytes", 0.0)
+            f["launches"] += 1
+            key = "%s M=%s N=%s K=%s" % (name, meta.get("M"), meta.get("N"), meta.get("K"))
+            pl = per_layer.setdefault(key, {"ms": 0.0, "flops": 0.0, "n": 0})
+            pl["ms"] += ms
+            pl["flops"] += meta.get("flops", 0.0)
+            pl["n"] += 1
+        igemm = {k: v for k, v in fam.items() if k.startswith("igemm")}
+        tot_ms = sum(v["ms"] for v in igemm.values())
+        tot_fl = sum(v["flops"] for v in igemm.values())
+        dom = max(igemm.items(), key=lambda kv: kv[1]["ms"])
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roofline = {
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "m2h::igemm_f32_kernel (all instantiations; MFMA f32 32x32x2 implicit-GEMM conv)",
+            "launches_per_step": sum(v["launches"] for v in igemm.values()) // args.steps,
+            "kernel_ms_per_step": round(tot_ms / args.steps, 4),
+            "algorithmic_gflop_per_step": round(tot_fl / args.steps / 1e9, 3),
+            "dominant_instantiation": {
+                "name": dom[0], "avg_launch_us": round(1e3 * dom[1]["ms"] / dom[1]["launches"], 2),
+                "launches_per_step": dom[1]["launches"] // args.steps,
+                "achieved_tflops": round(dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12, 2)},
+            "by_instantiation": {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // args.steps,
+                                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                                     "algorithmic_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                                 for k, v in fam.items()},
+        }
+        layers = {k: {"us": round(1e3 * v["ms"] / v["n"], 1), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None}
+                  for k, v in per_layer.items()}
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(sd, args.tm, args.cpu_seconds)
+
+    value = world * args.batch * args.steps / elapsed
+    line = {
+        "metric": "passive_unet_pair_spectrograms_per_sec",
+        "value": round(value, 1), "unit": "spectrograms/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "passive U-Net separator pair forward (get_binSepMasks + convert_bin2mono, eval-BN), "
+                               "batch %d/GPU of 512x%d binaural log-magnitude spectrograms, inputs resident in HBM" % (args.batch, args.tm),
+                   "batch_per_gpu": args.batch, "n_freq": 512, "time_frames": args.tm, "parallelism": "dp%d (batch-sharded, no collective)" % world,
+                   "weights": "synthetic (m2h.synthetic seed 1), reference architecture 33.47 M params"},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
+        "layers": layers,
+    }
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+/*
+ * m2h.h -- C-ABI of libm2h.so: the MI355X (gfx950) kernels behind Move2Hear's data-parallel hot path.
+ *
+ * The reference (SAGNIKMJR/move2hear-active-AV-separation) has no FFI layer: its hot path is stock
+ * torch.nn ops.  Each entry point below therefore names the reference torch-op sequence it replaces
+ * (file:line relative to the reference root).  A maintainer binds these with ctypes (see
+ * INTEGRATION.md); the shipped binding is move2hear-active-av-separation_amd/m2h/_lib.py.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (the library
+ *     never allocates, frees or retains device memory) unless marked "host".
+ *   - every call only enqueues work on `stream` (a hipStream_t passed as void*); it never synchronises.
+ *   - return value: 0 = OK; negative = argument/shape error, nothing was launched; positive = hipError_t.
+ *     The message is available from m2h_last_error() (thread-local).  No exceptions cross the ABI.
+ *   - activations between kernels are NHWC ("channels-last") fp32: [B][H][W][C], C contiguous.
+ *   - spectrogram tensors at the module boundary keep the reference layout BHWC = [B][F][T][C].
+ */
+#ifndef M2H_H
+#define M2H_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* m2h_stream; /* hipStream_t */
+
+#define M2H_VERSION 100
+
+/* output layouts of m2h_conv_igemm_f32 */
+#define M2H_OUT_NHWC 0     /* dst[((b*Ho+oh)*Wo+ow)*ldc + n]                                   */
+#define M2H_OUT_DESLICE 1  /* n = c*16+s  ->  dst[((b*16*Ho + s*Ho + oh)*Wo + ow)*(N/16) + c]   */
+
+int m2h_version(void);
+const char* m2h_last_error(void);
+
+/*
+ * K1/K2  --  separator input glue.
+ *   masks == NULL : x = mix                                    (separator_cnn.py:82)
+ *   masks != NULL : x = log1p(max(0, masks * (exp(mix) - 1)))  (separator_cnn.py:73-79)
+ * then BHWC -> 16-way frequency slice, written NHWC:            (separator_cnn.py:85-90)
+ *   out[b][h][t][c*16 + s] = x[b][s*(F/16) + h][t][c]
+ * mix, masks: [B][F][T][C] fp32;  out: [B][F/16][T][16*C] fp32.  F % 16 == 0, (16*C) % 4 == 0.
+ * The (target_class + 1) plane of separator_cnn.py:93-99 is not materialised: it enters the first
+ * conv as a border-aware per-channel bias (m2h_unet_class_table + cls_* of m2h_conv_args).
+ */
+int m2h_sep_slice_input(const float* mix, const float* masks, float* out, int B, int F, int T, int C,
+                        m2h_stream stream);
+
+/*
+ * Weight packing (run once per weight version, into caller-owned buffers).
+ *
+ * m2h_pack_conv_weight: torch Conv2d weight [Co][Ci][KH][KW] -> [Co][KH][KW][ci_used] (K contiguous,
+ *   K = KH*KW*ci_used, channel fastest); input channels >= ci_used are dropped (the class plane).
+ * m2h_pack_convT_weight: torch ConvTranspose2d(k=4,s=2,p=1) weight [Ci][Co][4][4] -> 4 sub-pixel phase
+ *   matrices [ph*2+pw][Co][th][tw][Ci]: output pixel (2q+ph, 2r+pw) reads input (q + th*(2ph-1),
+ *   r + tw*(2pw-1)) through kernel tap kh = (ph ? 2 : 1) + th*(ph ? -2 : 2), kw likewise.
+ * m2h_unet_class_table: table[(ch*3+cw)][co] = sum over the taps of channel `plane` that fall inside the
+ *   image for an output pixel of border class (ch, cw) (0 = first row/col, 1 = interior, 2 = last)
+ *   of a 4x4 stride-2 pad-1 conv; w is the torch weight [Co][Ci][4][4].
+ * m2h_fold_bn: eval-mode BatchNorm2d as y = x*scale + shift  (scale = gamma/sqrt(var+eps),
+ *   shift = beta - mean*scale).
+ */
+int m2h_pack_conv_weight(const float* w, float* wp, int Co, int Ci, int KH, int KW, int ci_used, m2h_stream stream);
+int m2h_pack_convT_weight(const float* w, float* wp, int Ci, int Co, m2h_stream stream);
+int m2h_unet_class_table(const float* w, float* table, int Co, int Ci, int plane, m2h_stream stream);
+int m2h_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                float* scale, float* shift, int C, m2h_stream stream);
+
+/*
+ * Implicit-GEMM convolution, fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
+ *   D[m][n] = act( (sum_k A[m][k] * Wp[n][k]) * scale[n] + shift[n] + cls_val[b]*cls_table[cls(m)][n] )
+ * m enumerates (b, q, r) over B x Hq x Wq; k enumerates (th, tw, ci) over taps x (C0 + C1) input
+ * channels, the channels being the concatenation of two NHWC sources (the U-Net skip concat of
+ * separator_cnn.py:160-161 is never materialised); A[m][k] = src[b][q*stride + offh + th*mulh]
+ * [r*stride + offw + tw*mulw][ci], zero outside the image.  The output pixel is (q*os + ph, r*os + pw).
+ * With conv_transpose != 0 the launch covers the 4 sub-pixel phases of a 4x4/s2/p1 transposed conv
+ * (grid z = phase; weights from m2h_pack_convT_weight; mul/off/ph/pw derived per phase).
+ */
+typedef struct m2h_conv_args {
+  const float* src0; /* NHWC [B][Hi][Wi][C0] */
+  const float* src1; /* NHWC [B][Hi][Wi][C1] or NULL (C1 = 0) */
+  int C0, C1;
+  int B, Hi, Wi;
+  int Hq, Wq;  /* GEMM pixel grid: M = B*Hq*Wq */
+  int stride;  /* input step per q/r */
+  int nth, ntw; /* taps along h, w */
+  int mulh, offh, mulw, offw;
+  int conv_transpose; /* 0 | 1 */
+  const float* wp;    /* packed weights [phase][N][K], K = nth*ntw*(C0+C1) */
+  int N;
+  const float* scale; /* [N] or NULL (=1) */
+  const float* shift; /* [N] or NULL (=0) */
+  float slope;        /* y = v > 0 ? v : v*slope  (0 = ReLU, 0.2 = LeakyReLU, 1 = identity) */
+  const float* cls_table; /* [9][N] or NULL */
+  const float* cls_val;   /* [B] (target_class + 1 as float) or NULL */
+  float* dst;
+  int Ho, Wo; /* output spatial size */
+  int os;     /* output step per q/r (1 conv, 2 transposed conv) */
+  int ph, pw; /* output phase offset when conv_transpose == 0 */
+  int ldc;    /* channel count of dst rows (M2H_OUT_NHWC) */
+  int out_mode;
+} m2h_conv_args;
+
+int m2h_conv_igemm_f32(const m2h_conv_args* args /* host */, m2h_stream stream);
+
+/*
+ * Named fused ops of the separator U-Nets; thin argument adapters over m2h_conv_igemm_f32.
+ *
+ * K3  m2h_unet_down_fwd: Conv2d(4x4, s2, p1, no bias) + BatchNorm2d(eval) + LeakyReLU(0.2)
+ *     (separator_cnn.py:5-12,101-105).  x NHWC [B][H][W][Ci] -> y NHWC [B][H/2][W/2][Co].
+ *     cls_table/cls_val non-NULL only for binSep stage 0 (the target-class plane).
+ * K4  m2h_unet_up_fwd: cat(x, skip) + ConvTranspose2d(4x4, s2, p1, no bias) + BatchNorm2d(eval) + ReLU
+ *     (separator_cnn.py:15-24,156-161).  x [B][H][W][C0], skip [B][H][W][C1] or NULL -> y [B][2H][2W][Co].
+ * K5  m2h_unet_head_fwd: Conv2d(1x1, bias) + de-slice + permute to BHWC (separator_cnn.py:134,163-168).
+ *     x NHWC [B][H][W][Ci] -> out BHWC [B][16*H][W][Co/16].
+ */
+int m2h_unet_down_fwd(const float* x, const float* wp, const float* scale, const float* shift,
+                      const float* cls_table, const float* cls_val, float* y,
+                      int B, int H, int W, int Ci, int Co, m2h_stream stream);
+int m2h_unet_up_fwd(const float* x, const float* skip, const float* wp, const float* scale, const float* shift,
+                    float* y, int B, int H, int W, int C0, int C1, int Co, m2h_stream stream);
+int m2h_unet_head_fwd(const float* x, const float* wp, const float* bias, float* out,
+                      int B, int H, int W, int Ci, int Co, m2h_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M2H_H */

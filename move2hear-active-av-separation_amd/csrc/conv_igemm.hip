@@ -1,0 +1,323 @@
+// Implicit-GEMM convolution for gfx950 (MI355X), fp32 in / fp32 accumulate on the matrix cores.
+//
+// Replaces, in the reference, every Conv2d / ConvTranspose2d (+BatchNorm2d(eval) + activation) of the
+// separator U-Nets (audio_separation/rl/models/separator_cnn.py:5-24,46-52,128-135) and, through the same
+// engine, the 3x3 convs of AcousticMem (rl/models/memory_nets.py:11-16).
+//
+// GEMM view:  D[m][n] = sum_k A[m][k] * W[n][k]
+//   m = (b, q, r) over the output pixel grid of one sub-pixel phase, n = output channel,
+//   k = (th, tw, ci): kernel tap x input channel, input channels being the concatenation of two NHWC
+//   sources (the U-Net skip concat is read in place, never materialised).
+// A is gathered on the fly from NHWC activations (channel-contiguous 16-byte segments, zero outside the
+// image); W is pre-packed [n][k] (m2h_pack_conv*_weight).  Both are staged global -> VGPR -> LDS with a
+// register double buffer (one barrier per 32-deep k-tile), LDS rows padded 32 -> 36 floats so that the
+// ds_read_b128 fragment reads are bank-conflict free.  Each wave owns a (TM x TN) sub-tile as FM x FN
+// v_mfma_f32_32x32x2_f32 accumulators: one 16-byte LDS read feeds four MFMAs (lane (i, h) holds
+// k = 8g + 4h + {0..3} of row i; MFMA j of the group contracts k = 8g + j and 8g + 4 + j).  The f32 MFMA
+// is a k-ordered fp32 FMA chain, so results match an fp32 CPU convolution to rounding.
+//
+// Epilogue (fused): optional target-class plane (border-aware bias), BatchNorm(eval) scale/shift,
+// LeakyReLU/ReLU, and the store either NHWC or de-sliced straight into the reference's BHWC layout.
+//
+// Block -> tile map: n-tiles of one m-tile are consecutive on one XCD (blocks b and b+8 share an XCD's
+// L2), so the gathered A panel is fetched from HBM once and re-read from L2 by its sibling n-tiles.
+#include "m2h_internal.h"
+
+namespace m2h {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct IGemmP {
+  const float* src0;
+  const float* src1;
+  int C0, C1, Ctot;
+  int B, Hi, Wi;
+  int Hq, Wq;
+  int stride;
+  int ntw, ntap;
+  int mulh, offh, mulw, offw;
+  int convT;
+  const float* w;
+  int N, K;
+  const float* scale;
+  const float* shift;
+  float slope;
+  const float* cls_table;
+  const float* cls_val;
+  float* dst;
+  int Ho, Wo, os, ph, pw, ldc, out_mode;
+  int M, MT, NT;
+};
+
+constexpr int BK = 32;   // k-tile depth (floats)
+constexpr int LDK = 36;  // padded LDS row (floats): 144 B, keeps 16-B alignment, conflict-free b128 reads
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
+  constexpr int FM = TM / 32, FN = TN / 32;  // 32x32 MFMA fragments per wave
+  constexpr int AR = BM / 32, BR = BN / 32;  // staged rows per thread (256 threads = 32 rows x 8 segments)
+  static_assert(FM >= 1 && FN >= 1, "wave tile must hold at least one 32x32 fragment");
+
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+  __shared__ int ri_qh[BM], ri_rw[BM], ri_bpix[BM], ri_out[BM], ri_bc[BM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int seg = tid & 7;    // 16-byte segment inside the 128-byte k-tile row
+  const int srow = tid >> 3;  // 0..31
+
+  // ---- block -> (m-tile, n-tile): siblings (same m-tile) run back to back on one XCD ----
+  const int L = blockIdx.x;
+  const int xcd = L & 7;
+  const int idx = L >> 3;
+  const int mt = (idx / p.NT) * 8 + xcd;
+  const int nt = idx - (idx / p.NT) * p.NT;
+  if (mt >= p.MT) return;  // whole block leaves before any barrier
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
+
+  int mulh = p.mulh, offh = p.offh, mulw = p.mulw, offw = p.offw, ph = p.ph, pw = p.pw;
+  const float* wbase = p.w;
+  if (p.convT) {
+    const int phase = blockIdx.z;
+    ph = phase >> 1;
+    pw = phase & 1;
+    mulh = 2 * ph - 1;
+    mulw = 2 * pw - 1;
+    offh = 0;
+    offw = 0;
+    wbase += (size_t)phase * p.N * p.K;
+  }
+
+  // ---- per-row (output pixel) bookkeeping, once per block ----
+  for (int r = tid; r < BM; r += 256) {
+    const int m = m0 + r;
+    int qh = -(1 << 24), rw = -(1 << 24), bpix = 0, out = -1, bc = 0;
+    if (m < p.M) {
+      const int rr = m % p.Wq;
+      const int t = m / p.Wq;
+      const int q = t % p.Hq;
+      const int b = t / p.Hq;
+      qh = q * p.stride + offh;
+      rw = rr * p.stride + offw;
+      bpix = b * p.Hi * p.Wi;
+      const int oh = q * p.os + ph, ow = rr * p.os + pw;
+      if (p.out_mode == M2H_OUT_NHWC)
+        out = (b * p.Ho + oh) * p.Wo + ow;
+      else
+        out = b * 16 * p.Ho * p.Wo + oh * p.Wo + ow;
+      const int ch = (oh == 0) ? 0 : ((oh == p.Ho - 1) ? 2 : 1);
+      const int cw = (ow == 0) ? 0 : ((ow == p.Wo - 1) ? 2 : 1);
+      bc = b * 16 + ch * 3 + cw;
+    }
+    ri_qh[r] = qh;
+    ri_rw[r] = rw;
+    ri_bpix[r] = bpix;
+    ri_out[r] = out;
+    ri_bc[r] = bc;
+  }
+  __syncthreads();
+
+  int a_qh[AR], a_rw[AR], a_bpix[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    a_qh[i] = ri_qh[srow + 32 * i];
+    a_rw[i] = ri_rw[srow + 32 * i];
+    a_bpix[i] = ri_bpix[srow + 32 * i];
+  }
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < FN; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  f32x4 ra[AR], rb[BR];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  auto load_tile = [&](int kt) {
+    const int k = kt * BK + seg * 4;
+    const bool kok = k < p.K;
+    int tap = 0, ci = k;
+    if (p.ntap > 1) {
+      tap = (unsigned)k / (unsigned)p.Ctot;
+      ci = k - tap * p.Ctot;
+    }
+    const int th = (unsigned)tap / (unsigned)p.ntw;
+    const int tw = tap - th * p.ntw;
+    const int dh = th * mulh, dw = tw * mulw;
+    const float* src = p.src0;
+    int Cs = p.C0, c = ci;
+    if (ci >= p.C0) {
+      src = p.src1;
+      Cs = p.C1;
+      c = ci - p.C0;
+    }
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int ih = a_qh[i] + dh, iw = a_rw[i] + dw;
+      const bool ok = kok && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+      ra[i] = zero4;
+      if (ok) {
+        const size_t off = ((size_t)(a_bpix[i] + ih * p.Wi + iw)) * (size_t)Cs + (size_t)c;
+        ra[i] = *reinterpret_cast<const f32x4*>(src + off);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      const int n = n0 + srow + 32 * j;
+      rb[j] = zero4;
+      if (kok && n < p.N) rb[j] = *reinterpret_cast<const f32x4*>(wbase + (size_t)n * p.K + k);
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(&As[buf][(srow + 32 * i) * LDK + seg * 4]) = ra[i];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(&Bs[buf][(srow + 32 * j) * LDK + seg * 4]) = rb[j];
+  };
+
+  const int frow = lane & 31;        // fragment row (A: pixel, B: channel)
+  const int fk = (lane >> 5) * 4;    // k offset of this lane half inside an 8-deep group
+
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      f32x4 a[FM], b[FN];
+#pragma unroll
+      for (int mi = 0; mi < FM; ++mi)
+        a[mi] = *reinterpret_cast<const f32x4*>(&As[buf][(wm * TM + mi * 32 + frow) * LDK + g * 8 + fk]);
+#pragma unroll
+      for (int ni = 0; ni < FN; ++ni)
+        b[ni] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wn * TN + ni * 32 + frow) * LDK + g * 8 + fk]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < FN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+    }
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);  // global loads fly under the MFMAs of this tile
+    compute(cur);
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- fused epilogue ----
+  const int col = lane & 31;
+  const int rhalf = (lane >> 5) * 4;
+  float sc[FN], sh[FN];
+  int nn[FN];
+#pragma unroll
+  for (int ni = 0; ni < FN; ++ni) {
+    const int n = n0 + wn * TN + ni * 32 + col;
+    nn[ni] = n;
+    sc[ni] = (p.scale != nullptr && n < p.N) ? p.scale[n] : 1.f;
+    sh[ni] = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
+  }
+  const size_t plane = (size_t)p.Ho * p.Wo;
+  const int Cc = p.N >> 4;
+#pragma unroll
+  for (int mi = 0; mi < FM; ++mi) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int lrow = wm * TM + mi * 32 + (e & 3) + 8 * (e >> 2) + rhalf;
+      const int out = ri_out[lrow];
+      if (out < 0) continue;
+      const int bc = ri_bc[lrow];
+      float cv = 0.f;
+      const float* ctab = nullptr;
+      if (p.cls_table != nullptr) {
+        cv = p.cls_val[bc >> 4];
+        ctab = p.cls_table + (size_t)(bc & 15) * p.N;
+      }
+#pragma unroll
+      for (int ni = 0; ni < FN; ++ni) {
+        const int n = nn[ni];
+        if (n >= p.N) continue;
+        float v = acc[mi][ni][e];
+        if (ctab != nullptr) v += cv * ctab[n];
+        v = v * sc[ni] + sh[ni];
+        v = v > 0.f ? v : v * p.slope;
+        if (p.out_mode == M2H_OUT_NHWC) {
+          p.dst[(size_t)out * p.ldc + n] = v;
+        } else {
+          const int c = n >> 4, s = n & 15;
+          p.dst[((size_t)out + (size_t)s * plane) * Cc + c] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(IGemmP& p, hipStream_t st) {
+  p.MT = (p.M + BM - 1) / BM;
+  p.NT = (p.N + BN - 1) / BN;
+  const long mtpad = ((long)p.MT + 7) / 8 * 8;
+  const long nblk = mtpad * p.NT;
+  if (nblk > 0x7fffffffL) return fail(-1, "conv_igemm: grid too large (%ld blocks)", nblk);
+  dim3 grid((unsigned)nblk, 1, p.convT ? 4 : 1);
+  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, p);
+  return launch_status("conv_igemm_f32");
+}
+
+int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
+  M2H_REQUIRE(a.src0 != nullptr && a.wp != nullptr && a.dst != nullptr, "conv_igemm: null pointer");
+  M2H_REQUIRE(a.B > 0 && a.Hi > 0 && a.Wi > 0 && a.Hq > 0 && a.Wq > 0 && a.N > 0, "conv_igemm: non-positive size");
+  M2H_REQUIRE(a.C0 > 0 && a.C0 % 4 == 0 && a.C1 >= 0 && a.C1 % 4 == 0, "conv_igemm: C0/C1 must be multiples of 4 (got %d, %d)", a.C0, a.C1);
+  M2H_REQUIRE((a.C1 == 0) == (a.src1 == nullptr), "conv_igemm: src1/C1 mismatch");
+  M2H_REQUIRE(a.nth > 0 && a.ntw > 0 && a.stride > 0 && a.os > 0, "conv_igemm: bad taps/stride");
+  M2H_REQUIRE(a.Ho > 0 && a.Wo > 0, "conv_igemm: bad output size");
+  if (a.conv_transpose) {
+    M2H_REQUIRE(a.nth == 2 && a.ntw == 2 && a.stride == 1 && a.os == 2, "conv_igemm: transposed conv is 4x4/s2/p1 (2x2 taps per phase)");
+    M2H_REQUIRE(a.Hq == a.Hi && a.Wq == a.Wi && a.Ho == 2 * a.Hi && a.Wo == 2 * a.Wi, "conv_igemm: transposed conv geometry");
+  } else {
+    M2H_REQUIRE((a.Hq - 1) * a.os + a.ph < a.Ho && (a.Wq - 1) * a.os + a.pw < a.Wo, "conv_igemm: output pixel grid exceeds Ho x Wo");
+  }
+  const long M = (long)a.B * a.Hq * a.Wq;
+  M2H_REQUIRE(M < (1L << 30), "conv_igemm: M too large");
+  M2H_REQUIRE((long)a.B * a.Hi * a.Wi < (1L << 30), "conv_igemm: input pixel count too large");
+  M2H_REQUIRE((long)a.B * 16 * a.Ho * a.Wo < (1L << 31), "conv_igemm: output pixel count too large");
+  if (a.out_mode == M2H_OUT_DESLICE) {
+    M2H_REQUIRE(a.N % 16 == 0, "conv_igemm: de-slice needs N %% 16 == 0");
+  } else {
+    M2H_REQUIRE(a.out_mode == M2H_OUT_NHWC && a.ldc >= a.N, "conv_igemm: bad out_mode/ldc");
+  }
+  M2H_REQUIRE((a.cls_table == nullptr) == (a.cls_val == nullptr), "conv_igemm: cls_table/cls_val mismatch");
+
+  IGemmP p;
+  p.src0 = a.src0; p.src1 = a.src1; p.C0 = a.C0; p.C1 = a.C1; p.Ctot = a.C0 + a.C1;
+  p.B = a.B; p.Hi = a.Hi; p.Wi = a.Wi; p.Hq = a.Hq; p.Wq = a.Wq; p.stride = a.stride;
+  p.ntw = a.ntw; p.ntap = a.nth * a.ntw;
+  p.mulh = a.mulh; p.offh = a.offh; p.mulw = a.mulw; p.offw = a.offw; p.convT = a.conv_transpose ? 1 : 0;
+  p.w = a.wp; p.N = a.N; p.K = p.ntap * p.Ctot;
+  p.scale = a.scale; p.shift = a.shift; p.slope = a.slope; p.cls_table = a.cls_table; p.cls_val = a.cls_val;
+  p.dst = a.dst; p.Ho = a.Ho; p.Wo = a.Wo; p.os = a.os; p.ph = a.ph; p.pw = a.pw; p.ldc = a.ldc; p.out_mode = a.out_mode;
+  p.M = (int)M;
+  M2H_REQUIRE(p.K % 4 == 0, "conv_igemm: K must be a multiple of 4");
+
+  if (p.N > 64) return launch_cfg<128, 128, 2, 2>(p, st);
+  if (p.N > 32) return launch_cfg<128, 64, 2, 2>(p, st);
+  return launch_cfg<128, 32, 4, 1>(p, st);
+}
+
+}  // namespace m2h

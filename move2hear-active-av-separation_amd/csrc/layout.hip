@@ -1,0 +1,155 @@
+// HBM-bound layout / pointwise kernels of the separator path (gfx950).
+//   sep_slice_input  : K1 + K2 of SURVEY section 2.2 (separator_cnn.py:73-90)
+//   pack_conv_weight / pack_convT_weight / unet_class_table / fold_bn : one-off weight preparation
+#include "m2h_internal.h"
+
+namespace m2h {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// out[b][h][t][c*16+s] = f(mix[b][s*Hs+h][t][c])   (Hs = F/16)
+// One thread produces 4 consecutive output channels (same c, s0..s0+3) as one 16-byte store; lanes walk
+// (channel-group, t) so a wave writes 8 x 128-byte pixel rows... reads are 4-byte gathers from 4 frequency
+// rows (served by L2: every 32-byte sector fetched is fully consumed by neighbouring lanes).
+__global__ __launch_bounds__(256) void sep_slice_input_kernel(const float* __restrict__ mix, const float* __restrict__ masks,
+                                                              float* __restrict__ out, int B, int F, int T, int C) {
+  const int Hs = F >> 4;
+  const int CG = (16 * C) >> 2;  // channel groups of 4
+  const size_t total = (size_t)B * Hs * T * CG;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % CG);
+    size_t r = i / CG;
+    const int t = (int)(r % T);
+    r /= T;
+    const int h = (int)(r % Hs);
+    const int b = (int)(r / Hs);
+    const int n0 = cg * 4;
+    const int c = n0 >> 4, s0 = n0 & 15;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t off = (((size_t)b * F + (size_t)(s0 + j) * Hs + h) * T + t) * C + c;
+      float x = mix[off];
+      if (masks != nullptr) {
+        // log1p(clamp(mask * (exp(mix) - 1), min=0))   (separator_cnn.py:77-79)
+        const float e = expf(x) - 1.f;
+        x = log1pf(fmaxf(masks[off] * e, 0.f));
+      }
+      v[j] = x;
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+  }
+}
+
+// [Co][Ci][KH][KW] -> [Co][KH][KW][ci_used]
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int KH, int KW, int cu) {
+  const size_t total = (size_t)Co * KH * KW * cu;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % cu);
+    size_t r = i / cu;
+    const int kw = (int)(r % KW);
+    r /= KW;
+    const int kh = (int)(r % KH);
+    const int co = (int)(r / KH);
+    wp[i] = w[(((size_t)co * Ci + ci) * KH + kh) * KW + kw];
+  }
+}
+
+// [Ci][Co][4][4] -> [phase = ph*2+pw][Co][th][tw][Ci];  kh = (ph ? 2 : 1) + th * (ph ? -2 : 2)
+__global__ void pack_convT_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Ci, int Co) {
+  const size_t total = (size_t)4 * Co * 4 * Ci;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Ci);
+    size_t r = i / Ci;
+    const int tw = (int)(r & 1);
+    const int th = (int)((r >> 1) & 1);
+    r >>= 2;
+    const int co = (int)(r % Co);
+    const int phase = (int)(r / Co);
+    const int ph = phase >> 1, pw = phase & 1;
+    const int kh = (ph ? 2 : 1) + th * (ph ? -2 : 2);
+    const int kw = (pw ? 2 : 1) + tw * (pw ? -2 : 2);
+    wp[i] = w[(((size_t)ci * Co + co) * 4 + kh) * 4 + kw];
+  }
+}
+
+// table[(ch*3+cw)*Co + co] = sum_{kh valid for ch} sum_{kw valid for cw} w[co][plane][kh][kw]
+// 4x4 stride-2 pad-1: the first output row/col misses tap 0, the last misses tap 3.
+__global__ void unet_class_table_kernel(const float* __restrict__ w, float* __restrict__ table, int Co, int Ci, int plane) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * Co) return;
+  const int co = i % Co;
+  const int cls = i / Co;
+  const int ch = cls / 3, cw = cls % 3;
+  const int h0 = (ch == 0) ? 1 : 0, h1 = (ch == 2) ? 3 : 4;
+  const int w0 = (cw == 0) ? 1 : 0, w1 = (cw == 2) ? 3 : 4;
+  float s = 0.f;
+  for (int kh = h0; kh < h1; ++kh)
+    for (int kw = w0; kw < w1; ++kw) s += w[(((size_t)co * Ci + plane) * 4 + kh) * 4 + kw];
+  table[i] = s;
+}
+
+__global__ void fold_bn_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ mean,
+                               const float* __restrict__ var, float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  const float s = g[i] / sqrtf(var[i] + eps);
+  scale[i] = s;
+  shift[i] = b[i] - mean[i] * s;
+}
+
+static inline unsigned grid_for(size_t total, int block = 256, unsigned cap = 256 * 8) {
+  size_t g = (total + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace m2h
+
+using namespace m2h;
+
+extern "C" {
+
+int m2h_sep_slice_input(const float* mix, const float* masks, float* out, int B, int F, int T, int C, m2h_stream stream) {
+  M2H_REQUIRE(mix != nullptr && out != nullptr, "sep_slice_input: null pointer");
+  M2H_REQUIRE(B > 0 && F > 0 && T > 0 && C > 0, "sep_slice_input: non-positive size");
+  M2H_REQUIRE(F % 16 == 0, "sep_slice_input: F (%d) must be a multiple of 16", F);
+  M2H_REQUIRE((16 * C) % 4 == 0, "sep_slice_input: 16*C must be a multiple of 4");
+  const size_t total = (size_t)B * (F / 16) * T * (16 * C / 4);
+  hipLaunchKernelGGL(sep_slice_input_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, as_stream(stream), mix, masks, out, B, F, T, C);
+  return launch_status("sep_slice_input");
+}
+
+int m2h_pack_conv_weight(const float* w, float* wp, int Co, int Ci, int KH, int KW, int ci_used, m2h_stream stream) {
+  M2H_REQUIRE(w != nullptr && wp != nullptr, "pack_conv_weight: null pointer");
+  M2H_REQUIRE(Co > 0 && Ci > 0 && KH > 0 && KW > 0 && ci_used > 0 && ci_used <= Ci, "pack_conv_weight: bad sizes");
+  const size_t total = (size_t)Co * KH * KW * ci_used;
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w, wp, Co, Ci, KH, KW, ci_used);
+  return launch_status("pack_conv_weight");
+}
+
+int m2h_pack_convT_weight(const float* w, float* wp, int Ci, int Co, m2h_stream stream) {
+  M2H_REQUIRE(w != nullptr && wp != nullptr, "pack_convT_weight: null pointer");
+  M2H_REQUIRE(Co > 0 && Ci > 0, "pack_convT_weight: bad sizes");
+  const size_t total = (size_t)16 * Co * Ci;
+  hipLaunchKernelGGL(pack_convT_weight_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w, wp, Ci, Co);
+  return launch_status("pack_convT_weight");
+}
+
+int m2h_unet_class_table(const float* w, float* table, int Co, int Ci, int plane, m2h_stream stream) {
+  M2H_REQUIRE(w != nullptr && table != nullptr, "unet_class_table: null pointer");
+  M2H_REQUIRE(Co > 0 && Ci > 0 && plane >= 0 && plane < Ci, "unet_class_table: bad sizes");
+  hipLaunchKernelGGL(unet_class_table_kernel, dim3((9 * Co + 255) / 256), dim3(256), 0, as_stream(stream), w, table, Co, Ci, plane);
+  return launch_status("unet_class_table");
+}
+
+int m2h_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale,
+                float* shift, int C, m2h_stream stream) {
+  M2H_REQUIRE(gamma && beta && mean && var && scale && shift, "fold_bn: null pointer");
+  M2H_REQUIRE(C > 0, "fold_bn: bad size");
+  hipLaunchKernelGGL(fold_bn_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), gamma, beta, mean, var, eps, scale, shift, C);
+  return launch_status("fold_bn");
+}
+
+}  // extern "C"

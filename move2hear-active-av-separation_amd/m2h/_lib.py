@@ -1,0 +1,119 @@
+"""ctypes binding of libm2h.so (the C-ABI declared in include/m2h.h) and its in-tree build.
+
+The library is built IN-TREE (``m2h/libm2h.so``) with ``hipcc --offload-arch=gfx950`` so that it travels
+with the repository snapshot to the GPU box.  There is no CPU fallback: if the library is missing or does
+not load, every op raises ``RuntimeError``.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG_ROOT = os.path.dirname(_HERE)
+_REPO_ROOT = os.path.dirname(_PKG_ROOT)
+CSRC = os.path.join(_PKG_ROOT, "csrc")
+INCLUDE = os.path.join(_REPO_ROOT, "include")
+LIB_PATH = os.path.join(_HERE, "libm2h.so")
+SOURCES = ["conv_igemm.hip", "layout.hip", "api.hip"]
+
+_lock = threading.Lock()
+_lib = None
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "m2h_internal.h"), os.path.join(INCLUDE, "m2h.h")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    """Compiles csrc/*.hip for gfx950 into m2h/libm2h.so (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, "-I" + CSRC]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+class ConvArgs(ctypes.Structure):
+    """Mirror of ``struct m2h_conv_args`` (include/m2h.h)."""
+    _fields_ = [
+        ("src0", ctypes.c_void_p), ("src1", ctypes.c_void_p),
+        ("C0", ctypes.c_int), ("C1", ctypes.c_int),
+        ("B", ctypes.c_int), ("Hi", ctypes.c_int), ("Wi", ctypes.c_int),
+        ("Hq", ctypes.c_int), ("Wq", ctypes.c_int),
+        ("stride", ctypes.c_int),
+        ("nth", ctypes.c_int), ("ntw", ctypes.c_int),
+        ("mulh", ctypes.c_int), ("offh", ctypes.c_int), ("mulw", ctypes.c_int), ("offw", ctypes.c_int),
+        ("conv_transpose", ctypes.c_int),
+        ("wp", ctypes.c_void_p),
+        ("N", ctypes.c_int),
+        ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
+        ("slope", ctypes.c_float),
+        ("cls_table", ctypes.c_void_p), ("cls_val", ctypes.c_void_p),
+        ("dst", ctypes.c_void_p),
+        ("Ho", ctypes.c_int), ("Wo", ctypes.c_int),
+        ("os", ctypes.c_int), ("ph", ctypes.c_int), ("pw", ctypes.c_int),
+        ("ldc", ctypes.c_int), ("out_mode", ctypes.c_int),
+    ]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+# name -> argtypes; every function returns int except m2h_last_error.  Must list every symbol of include/m2h.h
+SIGNATURES = {
+    "m2h_version": [],
+    "m2h_sep_slice_input": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "m2h_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "m2h_pack_convT_weight": [_P, _P, _I, _I, _P],
+    "m2h_unet_class_table": [_P, _P, _I, _I, _I, _P],
+    "m2h_fold_bn": [_P, _P, _P, _P, _F, _P, _P, _I, _P],
+    "m2h_conv_igemm_f32": [ctypes.POINTER(ConvArgs), _P],
+    "m2h_unet_down_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "m2h_unet_up_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "m2h_unet_head_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+}
+
+
+def load():
+    """Returns the loaded library; raises RuntimeError when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libm2h.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "-- the m2h ops have no CPU/PyTorch fallback." % LIB_PATH)
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise RuntimeError("libm2h.so failed to load: %s" % e)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        lib.m2h_last_error.argtypes = []
+        lib.m2h_last_error.restype = ctypes.c_char_p
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().m2h_last_error().decode("utf-8", "replace")
+        raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, msg))

@@ -1,0 +1,199 @@
+"""Separator U-Nets on MI355X: drop-in for audio_separation/rl/models/separator_cnn.py.
+
+Same class names, constructor arguments, ``forward`` signatures/return conventions and ``state_dict``
+keys as the reference (``cnn.{i}.0.weight``, ``cnn.{i}.1.{weight,bias,running_mean,running_var,
+num_batches_tracked}``, decoder ``cnn.5.0.{weight,bias}``; reference :46-52,128-135), so reference
+checkpoints load unchanged.  The torch.nn layers below are parameter containers only (they also give
+bit-identical default initialisation under the same seed, reference :56-68,139-151); the arithmetic
+runs in libm2h.so:
+
+  encoder  (reference :70-108)  K1/K2 slice kernel -> 5 x fused conv4x4s2+BN(eval)+LeakyReLU (MFMA
+           implicit GEMM, NHWC); the (target_class + 1) plane enters stage 0 as a border-aware bias.
+  decoder  (reference :153-170) 5 x fused [skip-concat]+convT4x4s2+BN(eval)+ReLU (4 sub-pixel phase
+           GEMMs, concat read in place) -> fused conv1x1+bias+de-slice straight into BHWC.
+
+Both stacks are fully convolutional in time: Tm = 32 is the reference-native shape, any multiple of 32
+works (the reference's ``view(B,-1,1,1)`` at :154 pins Tm = 32).
+
+Feature maps cross the module boundary as NCHW-shaped tensors in channels-last memory (zero-copy views of
+the NHWC buffers the kernels use).
+
+Only inference is built so far (eval-mode BatchNorm, no autograd): this is the mode every RL call site
+uses (ppo_trainer.py:557-577, ppo.py:184-195).  Calling forward in training mode, or with gradients
+required, raises NotImplementedError rather than silently computing something else.
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+
+def unet_conv(input_nc, output_nc, norm_layer=nn.BatchNorm2d):
+    # parameter containers: Conv2d(4,2,1,no bias) + BN + LeakyReLU(0.2)   (reference :5-12)
+    return nn.Sequential(nn.Conv2d(input_nc, output_nc, kernel_size=(4, 4), stride=(2, 2), padding=(1, 1), bias=False),
+                         norm_layer(output_nc), nn.LeakyReLU(0.2, True))
+
+
+def unet_upconv(input_nc, output_nc, norm_layer=nn.BatchNorm2d):
+    # parameter containers: ConvTranspose2d(4,2,1,no bias) + BN + ReLU    (reference :15-24, outermost=False)
+    return nn.Sequential(nn.ConvTranspose2d(input_nc, output_nc, kernel_size=(4, 4), stride=(2, 2), padding=(1, 1), bias=False),
+                         norm_layer(output_nc), nn.ReLU(True))
+
+
+def _init_like_reference(cnn, a):
+    # reference :56-68 / :139-151: kaiming_normal_(weight, <gain passed as `a`>), BN weight=1, bias=0
+    for module in cnn:
+        for layer in module:
+            if isinstance(layer, (nn.Conv2d, nn.ConvTranspose2d, nn.Linear)):
+                nn.init.kaiming_normal_(layer.weight, a)
+                if layer.bias is not None:
+                    nn.init.constant_(layer.bias, val=0)
+            elif isinstance(layer, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                if layer.affine:
+                    layer.weight.data.fill_(1)
+                    layer.bias.data.zero_()
+
+
+class _PackedCache:
+    """Packed weights + folded BN, rebuilt when any source tensor is modified in place or replaced."""
+
+    def __init__(self):
+        self.key = None
+        self.val = None
+
+    def get(self, tensors, build):
+        key = tuple((t.data_ptr(), t._version, t.device) for t in tensors)
+        if key != self.key:
+            self.val = build()
+            self.key = key
+        return self.val
+
+
+def _check_inference(module, *tensors):
+    if module.training:
+        raise NotImplementedError(
+            "m2h %s: train-mode BatchNorm / backward is not built yet (inference only); call .eval()"
+            % type(module).__name__)
+    if torch.is_grad_enabled() and (any(p.requires_grad for p in module.parameters())
+                                    or any(t is not None and t.requires_grad for t in tensors)):
+        raise NotImplementedError(
+            "m2h %s: no autograd through the HIP path yet; wrap the call in torch.no_grad() or freeze the "
+            "separator (requires_grad_(False)) as ppo_trainer.py:557-577 does" % type(module).__name__)
+
+
+def _as_nhwc(t):
+    """NCHW-shaped tensor (any strides) -> contiguous NHWC buffer; free for channels-last inputs."""
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+class PassiveSepEncCNN(nn.Module):
+    r"""U-net encoder for passive separation (reference separator_cnn.py:27-108)."""
+
+    def __init__(self, convert_bin2mono=False):
+        super().__init__()
+        self._convert_bin2mono = convert_bin2mono
+        self._slice_factor = 16
+        self._n_input_audio = 2 * self._slice_factor
+        if not convert_bin2mono:
+            self._n_input_audio += 1
+        self.cnn = nn.Sequential(
+            unet_conv(self._n_input_audio, 64),
+            unet_conv(64, 64 * 2),
+            unet_conv(64 * 2, 64 * 4),
+            unet_conv(64 * 4, 64 * 8),
+            unet_conv(64 * 8, 64 * 8),
+        )
+        self.layer_init()
+        self._cache = _PackedCache()
+
+    def layer_init(self):
+        _init_like_reference(self.cnn, nn.init.calculate_gain("leaky_relu", 0.2))
+
+    def _packed(self):
+        srcs = [t for m in self.cnn for t in (m[0].weight, m[1].weight, m[1].bias, m[1].running_mean, m[1].running_var)]
+
+        def build():
+            out = []
+            for i, m in enumerate(self.cnn):
+                conv, bn = m[0], m[1]
+                w = conv.weight.detach().contiguous()
+                ci_used = 32 if (i == 0) else w.shape[1]
+                wp = ops.pack_conv_weight(w, ci_used)
+                table = ops.unet_class_table(w, 32) if (i == 0 and not self._convert_bin2mono) else None
+                scale, shift = ops.fold_bn(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+                out.append((wp, scale, shift, table, w.shape[0]))
+            return out
+
+        return self._cache.get(srcs, build)
+
+    def forward(self, observations, mixed_audio=None):
+        if self._convert_bin2mono:
+            assert mixed_audio is not None
+            _check_inference(self, observations, mixed_audio)
+            x0 = ops.sep_slice_input(mixed_audio.contiguous(), observations.contiguous())
+            cls_val = None
+        else:
+            mix = observations["mixed_bin_audio_mag"]
+            _check_inference(self, mix)
+            x0 = ops.sep_slice_input(mix.contiguous())
+            cls_val = (observations["target_class"].reshape(-1).to(torch.float32) + 1.0).contiguous()  # reference :96
+        feats = []
+        out = x0
+        for (wp, scale, shift, table, co) in self._packed():
+            out = ops.unet_down_fwd(out, wp, scale, shift, co, table, cls_val if table is not None else None)
+            feats.append(out.permute(0, 3, 1, 2))  # NCHW-shaped view of the NHWC buffer
+        bottleneck = feats[-1]
+        return bottleneck.reshape(bottleneck.size(0), -1), feats[:-1][::-1]
+
+
+class PassiveSepDecCNN(nn.Module):
+    r"""U-net decoder for passive separation (reference separator_cnn.py:111-170)."""
+
+    def __init__(self, convert_bin2mono=False):
+        super().__init__()
+        self._slice_factor = 16
+        self._n_out_audio = self._slice_factor
+        if not convert_bin2mono:
+            self._n_out_audio *= 2
+        self.cnn = nn.Sequential(
+            unet_upconv(64 * 8, 64 * 8),
+            unet_upconv(64 * 16, 64 * 4),
+            unet_upconv(64 * 8, 64 * 2),
+            unet_upconv(64 * 4, 64 * 1),
+            unet_upconv(64 * 2, self._n_out_audio),
+            nn.Sequential(nn.Conv2d(self._n_out_audio, self._n_out_audio, kernel_size=(1, 1))),
+        )
+        self.layer_init()
+        self._cache = _PackedCache()
+
+    def layer_init(self):
+        _init_like_reference(self.cnn, nn.init.calculate_gain("relu"))
+
+    def _packed(self):
+        srcs = [t for m in list(self.cnn)[:5] for t in (m[0].weight, m[1].weight, m[1].bias, m[1].running_mean, m[1].running_var)]
+        srcs += [self.cnn[5][0].weight, self.cnn[5][0].bias]
+
+        def build():
+            ups = []
+            for m in list(self.cnn)[:5]:
+                convT, bn = m[0], m[1]
+                w = convT.weight.detach().contiguous()
+                scale, shift = ops.fold_bn(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+                ups.append((ops.pack_convT_weight(w), scale, shift, w.shape[1]))
+            head = self.cnn[5][0]
+            hw = ops.pack_conv_weight(head.weight.detach().contiguous())
+            return ups, (hw, head.bias.detach().contiguous(), head.weight.shape[0])
+
+        return self._cache.get(srcs, build)
+
+    def forward(self, bottleneck_feats, lst_skip_feats):
+        _check_inference(self, bottleneck_feats, *lst_skip_feats)
+        B = bottleneck_feats.size(0)
+        # reference :154 is view(B,-1,1,1) (Tm = 32); in general the bottleneck is [B,512,1,Tm/32]
+        wb = lst_skip_feats[0].size(3) // 2
+        out = _as_nhwc(bottleneck_feats.reshape(B, -1, 1, wb))
+        ups, (hw, hb, hco) = self._packed()
+        for idx, (wp, scale, shift, co) in enumerate(ups):
+            skip = None if idx == 0 else _as_nhwc(lst_skip_feats[idx - 1])
+            out = ops.unet_up_fwd(out, skip, wp, scale, shift, co)
+        return ops.unet_head_fwd(out, hw, hb, hco)  # BHWC, contiguous

@@ -1,0 +1,141 @@
+"""numpy model of the index arithmetic of csrc/conv_igemm.hip + csrc/layout.hip (TEST INFRASTRUCTURE).
+
+It restates, in vectorised numpy, exactly the address/tap/phase/de-slice formulas the HIP kernels use, so
+that the *algorithm* (sub-pixel phase decomposition of the transposed conv, in-place skip concat, class
+plane as border-aware bias, slice/de-slice maps, packed-weight order) can be checked against the oracle on
+a CPU-only machine.  It says nothing about the MFMA lane maps or LDS staging -- those are covered by the
+-m gpu parity tests.
+"""
+import numpy as np
+
+
+def sep_slice_input(mix, masks=None):
+    B, F, T, C = mix.shape
+    Hs = F // 16
+    x = mix if masks is None else np.log1p(np.maximum(masks * (np.exp(mix) - 1.0), 0.0))
+    out = np.empty((B, Hs, T, 16 * C), np.float32)
+    for n in range(16 * C):
+        c, s = n >> 4, n & 15
+        out[:, :, :, n] = x[:, s * Hs:(s + 1) * Hs, :, c]
+    return out
+
+
+def pack_conv_weight(w, ci_used=None):
+    Co, Ci, KH, KW = w.shape
+    cu = Ci if ci_used is None else ci_used
+    return np.ascontiguousarray(w[:, :cu].transpose(0, 2, 3, 1)).reshape(Co, KH * KW * cu)
+
+
+def pack_convT_weight(w):
+    Ci, Co = w.shape[:2]
+    wp = np.empty((4, Co, 2, 2, Ci), np.float32)
+    for phase in range(4):
+        ph, pw = phase >> 1, phase & 1
+        for th in range(2):
+            for tw in range(2):
+                kh = (2 if ph else 1) + th * (-2 if ph else 2)
+                kw = (2 if pw else 1) + tw * (-2 if pw else 2)
+                wp[phase, :, th, tw, :] = w[:, :, kh, kw].T
+    return wp.reshape(4, Co, 4 * Ci)
+
+
+def class_table(w, plane):
+    Co = w.shape[0]
+    t = np.zeros((9, Co), np.float32)
+    for ch in range(3):
+        for cw in range(3):
+            h0, h1 = (1 if ch == 0 else 0), (3 if ch == 2 else 4)
+            w0, w1 = (1 if cw == 0 else 0), (3 if cw == 2 else 4)
+            t[ch * 3 + cw] = w[:, plane, h0:h1, w0:w1].sum(axis=(1, 2))
+    return t
+
+
+def fold_bn(g, b, mean, var, eps):
+    s = g / np.sqrt(var + eps)
+    return s.astype(np.float32), (b - mean * s).astype(np.float32)
+
+
+def conv_igemm(src0, src1, wp, N, Hq, Wq, stride, nth, ntw, mulh, offh, mulw, offw, conv_transpose,
+               scale, shift, slope, cls_table, cls_val, Ho, Wo, os_, ph0, pw0, out_mode):
+    """Mirror of igemm_f32_kernel.  src*: NHWC arrays.  Returns dst (NHWC [B,Ho,Wo,N] or BHWC de-sliced)."""
+    B, Hi, Wi, C0 = src0.shape
+    C1 = 0 if src1 is None else src1.shape[3]
+    Ctot = C0 + C1
+    K = nth * ntw * Ctot
+    if out_mode == 0:
+        dst = np.zeros((B, Ho, Wo, N), np.float32)
+    else:
+        dst = np.zeros((B, 16 * Ho, Wo, N // 16), np.float32)
+    m = np.arange(B * Hq * Wq)
+    r = m % Wq
+    q = (m // Wq) % Hq
+    b = m // (Wq * Hq)
+    for phase in range(4 if conv_transpose else 1):
+        if conv_transpose:
+            ph, pw = phase >> 1, phase & 1
+            mh, mw, oh_, ow_ = 2 * ph - 1, 2 * pw - 1, 0, 0
+            w = wp[phase]
+        else:
+            ph, pw, mh, mw, oh_, ow_ = ph0, pw0, mulh, mulw, offh, offw
+            w = wp
+        A = np.zeros((m.size, K), np.float32)
+        for tap in range(nth * ntw):
+            th, tw = tap // ntw, tap % ntw
+            ih = q * stride + oh_ + th * mh
+            iw = r * stride + ow_ + tw * mw
+            ok = (ih >= 0) & (ih < Hi) & (iw >= 0) & (iw < Wi)
+            ihc, iwc = np.clip(ih, 0, Hi - 1), np.clip(iw, 0, Wi - 1)
+            v0 = src0[b, ihc, iwc, :] * ok[:, None]
+            A[:, tap * Ctot: tap * Ctot + C0] = v0
+            if C1:
+                A[:, tap * Ctot + C0:(tap + 1) * Ctot] = src1[b, ihc, iwc, :] * ok[:, None]
+        D = A @ w.reshape(N, K).T
+        oh = q * os_ + ph
+        ow = r * os_ + pw
+        if cls_table is not None:
+            ch = np.where(oh == 0, 0, np.where(oh == Ho - 1, 2, 1))
+            cw = np.where(ow == 0, 0, np.where(ow == Wo - 1, 2, 1))
+            D = D + cls_val[b][:, None] * cls_table[ch * 3 + cw]
+        if scale is not None:
+            D = D * scale[None, :]
+        if shift is not None:
+            D = D + shift[None, :]
+        D = np.where(D > 0, D, D * slope).astype(np.float32)
+        if out_mode == 0:
+            dst[b, oh, ow, :] = D
+        else:
+            for n in range(N):
+                c, s = n >> 4, n & 15
+                dst[b, s * Ho + oh, ow, c] = D[:, n]
+    return dst
+
+
+def unet_forward(sd, enc_pre, dec_pre, mix, target_class=None, masks=None, eps=1e-5):
+    """Whole U-Net through the kernel model; sd: numpy state dict."""
+    x = sep_slice_input(mix, masks)
+    feats = []
+    for i in range(5):
+        w = sd[enc_pre + "%d.0.weight" % i]
+        first_bin = (i == 0 and masks is None)
+        wp = pack_conv_weight(w, 32 if i == 0 else None)
+        sc, sh = fold_bn(sd[enc_pre + "%d.1.weight" % i], sd[enc_pre + "%d.1.bias" % i],
+                         sd[enc_pre + "%d.1.running_mean" % i], sd[enc_pre + "%d.1.running_var" % i], eps)
+        tab = class_table(w, 32) if first_bin else None
+        cv = (target_class.reshape(-1).astype(np.float32) + 1.0) if first_bin else None
+        B, H, W, _ = x.shape
+        x = conv_igemm(x, None, wp, w.shape[0], H // 2, W // 2, 2, 4, 4, 1, -1, 1, -1, False, sc, sh, 0.2, tab, cv,
+                       H // 2, W // 2, 1, 0, 0, 0)
+        feats.append(x)
+    out = feats[4]
+    skips = feats[:4][::-1]
+    for i in range(5):
+        w = sd[dec_pre + "%d.0.weight" % i]
+        sc, sh = fold_bn(sd[dec_pre + "%d.1.weight" % i], sd[dec_pre + "%d.1.bias" % i],
+                         sd[dec_pre + "%d.1.running_mean" % i], sd[dec_pre + "%d.1.running_var" % i], eps)
+        B, H, W, _ = out.shape
+        out = conv_igemm(out, None if i == 0 else skips[i - 1], pack_convT_weight(w), w.shape[1], H, W, 1, 2, 2,
+                         0, 0, 0, 0, True, sc, sh, 0.0, None, None, 2 * H, 2 * W, 2, 0, 0, 0)
+    hw = sd[dec_pre + "5.0.weight"]
+    B, H, W, _ = out.shape
+    return conv_igemm(out, None, pack_conv_weight(hw), hw.shape[0], H, W, 1, 1, 1, 0, 0, 0, 0, False, None,
+                      sd[dec_pre + "5.0.bias"], 1.0, None, None, H, W, 1, 0, 0, 1), feats

@@ -1,0 +1,195 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C-ABI, against the
+CPU oracle and the committed golden fixtures.  Tolerance: the north-star contract is rel-L1 <= 1e-3 on the
+fp32 separated spectrograms; the fp32 MFMA path is an exact fp32 FMA chain, so we hold it to 2e-5."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import kernel_model as KM
+import m2h_oracle as O
+from m2h import synthetic
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5  # rel-L1, fp32 path (contract: 1e-3)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda", 0)
+
+
+def _policy(seed, dev):
+    from m2h.common.spaces import move2hear_observation_space
+    from m2h.pretrain.passive.policy import Move2HearPassiveWoMemoryPolicy
+    pol = Move2HearPassiveWoMemoryPolicy(move2hear_observation_space())
+    sd_np = synthetic.make_state_dict(synthetic.passive_shapes(), seed)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}
+    pol.load_state_dict(sd, strict=True)
+    return pol.to(dev).eval(), sd
+
+
+def test_library_loads_and_reports_version():
+    from m2h import _lib
+    lib = _lib.load()
+    assert lib.m2h_version() == 100
+
+
+def test_slice_input_matches_model():
+    from m2h import ops
+    dev = _dev()
+    mixed, _ = synthetic.make_passive_inputs(2, 32, 21)
+    masks = np.random.default_rng(0).standard_normal(mixed.shape).astype(np.float32)
+    out = ops.sep_slice_input(torch.from_numpy(mixed).to(dev)).cpu().numpy()
+    assert np.array_equal(out, KM.sep_slice_input(mixed))
+    out2 = ops.sep_slice_input(torch.from_numpy(mixed).to(dev), torch.from_numpy(masks).to(dev)).cpu()
+    ref = O.slice_freq(torch.log1p(torch.clamp(torch.from_numpy(masks) * (torch.exp(torch.from_numpy(mixed)) - 1), min=0)))
+    assert torch.allclose(out2.permute(0, 3, 1, 2), ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 32, 32, 32, 64), (3, 8, 8, 128, 256), (1, 2, 16, 512, 512), (5, 4, 4, 64, 128)])
+def test_down_conv_matches_torch(B, H, W, Ci, Co):
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 4, 4, generator=g) * (2.0 / (Ci * 16)) ** 0.5
+    gamma, beta = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.1
+    mean, var = torch.randn(Co, generator=g) * 0.1, torch.rand(Co, generator=g) + 0.5
+    ref = F.leaky_relu(F.batch_norm(F.conv2d(x, w, None, 2, 1), mean, var, gamma, beta, False, 0.1, 1e-5), 0.2)
+    wp = ops.pack_conv_weight(w.to(dev))
+    sc, sh = ops.fold_bn(gamma.to(dev), beta.to(dev), mean.to(dev), var.to(dev), 1e-5)
+    y = ops.unet_down_fwd(x.permute(0, 2, 3, 1).contiguous().to(dev), wp, sc, sh, Co)
+    assert y.shape == (B, H // 2, W // 2, Co)
+    assert O.rel_l1(y.cpu().permute(0, 3, 1, 2), ref) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,C0,C1,Co", [(2, 1, 1, 512, 0, 512), (2, 2, 2, 512, 512, 256), (3, 8, 8, 128, 128, 64),
+                                            (1, 16, 16, 64, 64, 32), (2, 16, 16, 64, 64, 16), (1, 4, 32, 256, 256, 128)])
+def test_up_conv_matches_torch(B, H, W, C0, C1, Co):
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 100 + H + C1)
+    x = torch.randn(B, C0, H, W, generator=g)
+    s = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    w = torch.randn(C0 + C1, Co, 4, 4, generator=g) * (2.0 / ((C0 + C1) * 4)) ** 0.5
+    gamma, beta = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.1
+    mean, var = torch.randn(Co, generator=g) * 0.1, torch.rand(Co, generator=g) + 0.5
+    xin = x if s is None else torch.cat((x, s), 1)
+    ref = F.relu(F.batch_norm(F.conv_transpose2d(xin, w, None, 2, 1), mean, var, gamma, beta, False, 0.1, 1e-5))
+    wp = ops.pack_convT_weight(w.to(dev))
+    sc, sh = ops.fold_bn(gamma.to(dev), beta.to(dev), mean.to(dev), var.to(dev), 1e-5)
+    y = ops.unet_up_fwd(x.permute(0, 2, 3, 1).contiguous().to(dev),
+                        None if s is None else s.permute(0, 2, 3, 1).contiguous().to(dev), wp, sc, sh, Co)
+    assert y.shape == (B, 2 * H, 2 * W, Co)
+    assert O.rel_l1(y.cpu().permute(0, 3, 1, 2), ref) < TOL
+
+
+@pytest.mark.parametrize("Co", [32, 16])
+def test_head_matches_torch(Co):
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(Co)
+    B, H, W = 2, 32, 32
+    x = torch.randn(B, Co, H, W, generator=g)
+    w = torch.randn(Co, Co, 1, 1, generator=g) * 0.2
+    b = torch.randn(Co, generator=g) * 0.1
+    ref = O.deslice_freq(F.conv2d(x, w, b))
+    out = ops.unet_head_fwd(x.permute(0, 2, 3, 1).contiguous().to(dev), ops.pack_conv_weight(w.to(dev)), b.to(dev), Co)
+    assert out.shape == (B, 512, W, Co // 16)
+    assert O.rel_l1(out.cpu(), ref) < TOL
+
+
+def test_pair_tm32_matches_golden_and_oracle(golden_dir):
+    dev = _dev()
+    g = np.load(os.path.join(golden_dir, "unet_tm32.npz"))
+    pol, sd = _policy(int(g["seed_w"]), dev)
+    mixed, tc = synthetic.make_passive_inputs(int(g["B"]), 32, int(g["seed_x"]))
+    obs = {"mixed_bin_audio_mag": torch.from_numpy(mixed).to(dev), "target_class": torch.from_numpy(tc).to(dev)}
+    with torch.no_grad():
+        bott, skips = pol.binSep_enc(obs)
+        masks = pol.get_binSepMasks(obs)
+        mono = pol.convert_bin2mono(masks, mixed_audio=obs["mixed_bin_audio_mag"])
+    assert masks.shape == (2, 512, 32, 2) and mono.shape == (2, 512, 32, 1)
+    assert bott.shape == (2, 512) and [tuple(s.shape) for s in skips] == [(2, 512, 2, 2), (2, 256, 4, 4), (2, 128, 8, 8), (2, 64, 16, 16)]
+    assert torch.allclose(bott.cpu(), torch.from_numpy(g["bottleneck_binSep"]), atol=2e-5, rtol=1e-4)
+    assert O.rel_l1(skips[3].cpu(), torch.from_numpy(g["binSep_skip3_full"])) < TOL
+    gm, gmono = torch.from_numpy(g["masks"]), torch.from_numpy(g["mono"])
+    assert O.rel_l1(masks.cpu(), gm) < TOL
+    assert O.rel_l1(mono.cpu(), gmono) < TOL
+    # the contract metric: separated spectrograms
+    mix = torch.from_numpy(mixed)
+    assert O.rel_l1(O.pred_bin(masks.cpu(), mix), O.pred_bin(gm, mix)) < TOL
+    # live oracle on the same inputs
+    with torch.no_grad():
+        mo, mono_o = O.passive_pair(sd, mix, torch.from_numpy(tc))
+    assert O.rel_l1(masks.cpu(), mo) < TOL and O.rel_l1(mono.cpu(), mono_o) < TOL
+
+
+def test_pair_tm256_fully_convolutional_matches_golden(golden_dir):
+    dev = _dev()
+    g = np.load(os.path.join(golden_dir, "unet_tm256.npz"))
+    pol, _ = _policy(int(g["seed_w"]), dev)
+    mixed, tc = synthetic.make_passive_inputs(1, 256, int(g["seed_x"]))
+    obs = {"mixed_bin_audio_mag": torch.from_numpy(mixed).to(dev), "target_class": torch.from_numpy(tc).to(dev)}
+    with torch.no_grad():
+        masks = pol.get_binSepMasks(obs)
+        mono = pol.convert_bin2mono(masks, mixed_audio=obs["mixed_bin_audio_mag"])
+    assert O.rel_l1(masks.cpu(), torch.from_numpy(g["masks"])) < TOL
+    assert O.rel_l1(mono.cpu(), torch.from_numpy(g["mono"])) < TOL
+
+
+@pytest.mark.parametrize("B", [1, 7, 14])
+def test_pair_ragged_batches_match_oracle(B):
+    dev = _dev()
+    pol, sd = _policy(2, dev)
+    mixed, tc = synthetic.make_passive_inputs(B, 32, 100 + B)
+    obs = {"mixed_bin_audio_mag": torch.from_numpy(mixed).to(dev), "target_class": torch.from_numpy(tc).to(dev)}
+    with torch.no_grad():
+        masks = pol.get_binSepMasks(obs)
+        mono = pol.convert_bin2mono(masks, mixed_audio=obs["mixed_bin_audio_mag"])
+        mo, mono_o = O.passive_pair(sd, torch.from_numpy(mixed), torch.from_numpy(tc))
+    assert O.rel_l1(masks.cpu(), mo) < TOL and O.rel_l1(mono.cpu(), mono_o) < TOL
+
+
+def test_batch_independence_and_determinism():
+    """Size-independent properties at the full benchmark shape: a sample's result does not depend on its
+    batch neighbours (eval-mode BN) and repeated runs are bit-identical."""
+    dev = _dev()
+    pol, _ = _policy(2, dev)
+    mixed, tc = synthetic.make_passive_inputs(8, 256, 77)
+    mix, tct = torch.from_numpy(mixed).to(dev), torch.from_numpy(tc).to(dev)
+    with torch.no_grad():
+        big = pol.get_binSepMasks({"mixed_bin_audio_mag": mix, "target_class": tct})
+        big2 = pol.get_binSepMasks({"mixed_bin_audio_mag": mix, "target_class": tct})
+        one = pol.get_binSepMasks({"mixed_bin_audio_mag": mix[5:6].contiguous(), "target_class": tct[5:6]})
+    assert torch.equal(big, big2)
+    assert torch.equal(big[5:6], one)
+
+
+def test_weight_update_invalidates_packed_cache():
+    dev = _dev()
+    pol, _ = _policy(2, dev)
+    mixed, tc = synthetic.make_passive_inputs(1, 32, 9)
+    obs = {"mixed_bin_audio_mag": torch.from_numpy(mixed).to(dev), "target_class": torch.from_numpy(tc).to(dev)}
+    with torch.no_grad():
+        a = pol.get_binSepMasks(obs)
+        pol.binSep_dec.passive_sep_decoder.cnn[5][0].bias.add_(1.0)
+        b = pol.get_binSepMasks(obs)
+    assert torch.allclose(b, a + 1.0, atol=1e-5)
+
+
+def test_error_behaviour():
+    from m2h import ops
+    dev = _dev()
+    with pytest.raises(RuntimeError):
+        ops.sep_slice_input(torch.zeros(1, 512, 32, 2))  # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        ops.sep_slice_input(torch.zeros(1, 500, 32, 2, device=dev))  # F % 16 != 0 -> C-ABI argument error
+    pol, _ = _policy(2, dev)
+    pol.train()
+    with pytest.raises(NotImplementedError):
+        pol.get_binSepMasks({"mixed_bin_audio_mag": torch.zeros(1, 512, 32, 2, device=dev), "target_class": torch.zeros(1, 1, device=dev)})
