@@ -67,27 +67,44 @@ def make_inputs(dev, batch, tm, seed):
 
 
 def cpu_baseline(sd, tm, seconds):
+    """The oracle timed on this host's cores.  PyTorch-CPU convs at batch 8 do not scale to hundreds of threads
+    (256 threads ran 40x slower than 32 on the first GPU box), so a short probe picks the fastest thread count
+    among {8,16,32,64,all}; `cores` reports the count actually used."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import m2h_oracle as O
     from m2h import synthetic
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     bs = 8
     mixed, tc = synthetic.make_passive_inputs(bs, tm, 5)
     mix, tct = torch.from_numpy(mixed), torch.from_numpy(tc)
-    with torch.no_grad():
-        O.passive_pair(sd, mix, tct)  # warm-up
-        t0 = time.perf_counter()
-        n = 0
-        while True:
+
+    def once():
+        t = time.perf_counter()
+        with torch.no_grad():
             O.passive_pair(sd, mix, tct)
-            n += 1
-            el = time.perf_counter() - t0
-            if el >= seconds or n >= 200:
-                break
-    return {"value": bs * n / el, "unit": "spectrograms/s", "cores": cores, "kind": "port",
-            "sample": "%d batches of %d 512x%d spectrograms through oracle.passive_pair (PyTorch-CPU fp32, %d threads), %.1f s"
-                      % (n, bs, tm, cores, el)}
+        return time.perf_counter() - t
+
+    best_t, best_n = None, None
+    for n in sorted(set(min(c, ncpu) for c in (8, 16, 32, 64, ncpu))):
+        torch.set_num_threads(n)
+        once()  # warm-up (allocator, oneDNN primitive cache)
+        t = min(once(), once())
+        if best_t is None or t < best_t:
+            best_t, best_n = t, n
+        if t > 4 * best_t:
+            break  # oversubscribed: larger counts only get worse
+    torch.set_num_threads(best_n)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        once()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 400:
+            break
+    return {"value": round(bs * n / el, 2), "unit": "spectrograms/s", "cores": best_n, "kind": "port",
+            "sample": "%d batches of %d 512x%d spectrograms through oracle.passive_pair (PyTorch-CPU fp32, %d of %d host threads), %.1f s"
+                      % (n, bs, tm, best_n, ncpu, el)}
 
 
 def main():
