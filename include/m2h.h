@@ -102,9 +102,21 @@ typedef struct m2h_conv_args {
   int ph, pw; /* output phase offset when conv_transpose == 0 */
   int ldc;    /* channel count of dst rows (M2H_OUT_NHWC) */
   int out_mode;
+  void* workspace;        /* optional split-K scratch (device); NULL = never split */
+  size_t workspace_bytes; /* size of workspace; m2h_conv_igemm_workspace_bytes() says how much the launch can use */
 } m2h_conv_args;
 
 int m2h_conv_igemm_f32(const m2h_conv_args* args /* host */, m2h_stream stream);
+
+/* Bytes of split-K scratch the launch described by args would use (0 = the grid already fills the chip).
+ * Small-M layers (deep U-Net stages, rollout batches) are split along K over up to 32 blocks; partial sums go
+ * to the workspace as [phase][split][M][N] fp32 and a second kernel reduces them in a fixed order
+ * (bit-reproducible) and applies the fused epilogue. */
+size_t m2h_conv_igemm_workspace_bytes(const m2h_conv_args* args /* host */);
+
+/* Tuning/debug knobs (process-wide, not for production use): knob 0 = force split-K factor (0 auto, -1 never),
+ * knob 1 = force LDS stages of the narrow-N tile configs (0 auto, 1, 2). */
+int m2h_debug_set(int knob, int value);
 
 /*
  * Named fused ops of the separator U-Nets; thin argument adapters over m2h_conv_igemm_f32.
@@ -112,6 +124,7 @@ int m2h_conv_igemm_f32(const m2h_conv_args* args /* host */, m2h_stream stream);
  * K3  m2h_unet_down_fwd: Conv2d(4x4, s2, p1, no bias) + BatchNorm2d(eval) + LeakyReLU(0.2)
  *     (separator_cnn.py:5-12,101-105).  x NHWC [B][H][W][Ci] -> y NHWC [B][H/2][W/2][Co].
  *     cls_table/cls_val non-NULL only for binSep stage 0 (the target-class plane).
+ *     workspace: optional split-K scratch (see m2h_conv_igemm_workspace_bytes), NULL allowed.
  * K4  m2h_unet_up_fwd: cat(x, skip) + ConvTranspose2d(4x4, s2, p1, no bias) + BatchNorm2d(eval) + ReLU
  *     (separator_cnn.py:15-24,156-161).  x [B][H][W][C0], skip [B][H][W][C1] or NULL -> y [B][2H][2W][Co].
  * K5  m2h_unet_head_fwd: Conv2d(1x1, bias) + de-slice + permute to BHWC (separator_cnn.py:134,163-168).
@@ -119,9 +132,13 @@ int m2h_conv_igemm_f32(const m2h_conv_args* args /* host */, m2h_stream stream);
  */
 int m2h_unet_down_fwd(const float* x, const float* wp, const float* scale, const float* shift,
                       const float* cls_table, const float* cls_val, float* y,
-                      int B, int H, int W, int Ci, int Co, m2h_stream stream);
+                      int B, int H, int W, int Ci, int Co, void* workspace, size_t workspace_bytes, m2h_stream stream);
 int m2h_unet_up_fwd(const float* x, const float* skip, const float* wp, const float* scale, const float* shift,
-                    float* y, int B, int H, int W, int C0, int C1, int Co, m2h_stream stream);
+                    float* y, int B, int H, int W, int C0, int C1, int Co, void* workspace, size_t workspace_bytes,
+                    m2h_stream stream);
+/* split-K scratch the two ops above can use for these shapes (0 = none needed) */
+size_t m2h_unet_down_workspace_bytes(int B, int H, int W, int Ci, int Co);
+size_t m2h_unet_up_workspace_bytes(int B, int H, int W, int C0, int C1, int Co);
 int m2h_unet_head_fwd(const float* x, const float* wp, const float* bias, float* out,
                       int B, int H, int W, int Ci, int Co, m2h_stream stream);
 

@@ -48,12 +48,30 @@ struct IGemmP {
   float* dst;
   int Ho, Wo, os, ph, pw, ldc, out_mode;
   int M, MT, NT;
+  int S;       // split-K factor (grid y); S > 1: raw partial sums go to `ws`, the epilogue runs in splitk_epilogue_kernel
+  float* ws;   // [phase][S][M][N] fp32 partial slabs (caller-owned workspace)
 };
 
 constexpr int BK = 32;   // k-tile depth (floats)
 constexpr int LDK = 36;  // padded LDS row (floats): 144 B, keeps 16-B alignment, conflict-free b128 reads
 
-template <int BM, int BN, int WM, int WN>
+// Row bookkeeping shared by the main kernel and the split-K epilogue: output pixel offset and class id of GEMM row m.
+__device__ __forceinline__ void decode_row(const IGemmP& p, int m, int ph, int pw, int& q, int& rr, int& b, int& out, int& bc) {
+  rr = m % p.Wq;
+  const int t = m / p.Wq;
+  q = t % p.Hq;
+  b = t / p.Hq;
+  const int oh = q * p.os + ph, ow = rr * p.os + pw;
+  if (p.out_mode == M2H_OUT_NHWC)
+    out = (b * p.Ho + oh) * p.Wo + ow;
+  else
+    out = b * 16 * p.Ho * p.Wo + oh * p.Wo + ow;
+  const int ch = (oh == 0) ? 0 : ((oh == p.Ho - 1) ? 2 : 1);
+  const int cw = (ow == 0) ? 0 : ((ow == p.Wo - 1) ? 2 : 1);
+  bc = b * 16 + ch * 3 + cw;
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
@@ -61,8 +79,8 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
   constexpr int AR = BM / 32, BR = BN / 32;  // staged rows per thread (256 threads = 32 rows x 8 segments)
   static_assert(FM >= 1 && FN >= 1, "wave tile must hold at least one 32x32 fragment");
 
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+  __shared__ __attribute__((aligned(16))) float As[NSTAGE][BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[NSTAGE][BN * LDK];
   __shared__ int ri_qh[BM], ri_rw[BM], ri_bpix[BM], ri_out[BM], ri_bc[BM];
 
   const int tid = threadIdx.x;
@@ -84,8 +102,8 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
 
   int mulh = p.mulh, offh = p.offh, mulw = p.mulw, offw = p.offw, ph = p.ph, pw = p.pw;
   const float* wbase = p.w;
+  const int phase = p.convT ? blockIdx.z : 0;
   if (p.convT) {
-    const int phase = blockIdx.z;
     ph = phase >> 1;
     pw = phase & 1;
     mulh = 2 * ph - 1;
@@ -100,21 +118,11 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
     const int m = m0 + r;
     int qh = -(1 << 24), rw = -(1 << 24), bpix = 0, out = -1, bc = 0;
     if (m < p.M) {
-      const int rr = m % p.Wq;
-      const int t = m / p.Wq;
-      const int q = t % p.Hq;
-      const int b = t / p.Hq;
+      int q, rr, b;
+      decode_row(p, m, ph, pw, q, rr, b, out, bc);
       qh = q * p.stride + offh;
       rw = rr * p.stride + offw;
       bpix = b * p.Hi * p.Wi;
-      const int oh = q * p.os + ph, ow = rr * p.os + pw;
-      if (p.out_mode == M2H_OUT_NHWC)
-        out = (b * p.Ho + oh) * p.Wo + ow;
-      else
-        out = b * 16 * p.Ho * p.Wo + oh * p.Wo + ow;
-      const int ch = (oh == 0) ? 0 : ((oh == p.Ho - 1) ? 2 : 1);
-      const int cw = (ow == 0) ? 0 : ((ow == p.Wo - 1) ? 2 : 1);
-      bc = b * 16 + ch * 3 + cw;
     }
     ri_qh[r] = qh;
     ri_rw[r] = rw;
@@ -209,16 +217,52 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
     }
   };
 
-  const int nk = (p.K + BK - 1) / BK;
-  load_tile(0);
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int split = blockIdx.y;
+  const int kt0 = (int)(((long)nk_all * split) / p.S);
+  const int kt1 = (int)(((long)nk_all * (split + 1)) / p.S);
+  load_tile(kt0);
   store_tile(0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);  // global loads fly under the MFMAs of this tile
-    compute(cur);
-    if (kt + 1 < nk) store_tile(cur ^ 1);
-    __syncthreads();
+  if constexpr (NSTAGE == 2) {
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int cur = (kt - kt0) & 1;
+      if (kt + 1 < kt1) load_tile(kt + 1);  // global loads fly under the MFMAs of this tile
+      compute(cur);
+      if (kt + 1 < kt1) store_tile(cur ^ 1);
+      __syncthreads();
+    }
+  } else {
+    // single LDS stage: half the LDS, twice the resident blocks; other blocks' MFMAs cover the two barriers
+    for (int kt = kt0; kt < kt1; ++kt) {
+      if (kt + 1 < kt1) load_tile(kt + 1);
+      compute(0);
+      if (kt + 1 < kt1) {
+        __syncthreads();
+        store_tile(0);
+        __syncthreads();
+      }
+    }
+  }
+
+  if (p.S > 1) {
+    // split-K: raw partial sums to the slab [phase][split][M][N]; BN/activation/store happen in the reduce kernel
+    float* slab = p.ws + ((size_t)(phase * p.S + split) * p.M) * p.N;
+    const int col = lane & 31;
+    const int rhalf = (lane >> 5) * 4;
+#pragma unroll
+    for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * TM + mi * 32 + (e & 3) + 8 * (e >> 2) + rhalf;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < FN; ++ni) {
+          const int n = n0 + wn * TN + ni * 32 + col;
+          if (n < p.N) slab[(size_t)m * p.N + n] = acc[mi][ni][e];
+        }
+      }
+    return;
   }
 
   // ---- fused epilogue ----
@@ -268,16 +312,105 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_cfg(IGemmP& p, hipStream_t st) {
+// Split-K epilogue: sums the S partial slabs of one output element in a fixed order (deterministic) and applies the
+// same fused epilogue as the main kernel.  One thread = one GEMM row x 4 consecutive channels.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IGemmP p) {
+  const int N4 = p.N >> 2;
+  const long total = (long)p.M * N4;
+  const int phase = blockIdx.y;
+  const int ph = p.convT ? (phase >> 1) : p.ph, pw = p.convT ? (phase & 1) : p.pw;
+  const size_t plane = (size_t)p.Ho * p.Wo;
+  const int Cc = p.N >> 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / N4);
+    const int n = (int)(i - (long)m * N4) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.S; ++s) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(p.ws + ((size_t)(phase * p.S + s) * p.M + m) * p.N + n);
+      v += t;
+    }
+    int q, rr, b, out, bc;
+    decode_row(p, m, ph, pw, q, rr, b, out, bc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x = v[j];
+      if (p.cls_table != nullptr) x += p.cls_val[bc >> 4] * p.cls_table[(size_t)(bc & 15) * p.N + n + j];
+      const float sc = p.scale != nullptr ? p.scale[n + j] : 1.f;
+      const float sh = p.shift != nullptr ? p.shift[n + j] : 0.f;
+      x = x * sc + sh;
+      v[j] = x > 0.f ? x : x * p.slope;
+    }
+    if (p.out_mode == M2H_OUT_NHWC) {
+      *reinterpret_cast<f32x4*>(p.dst + (size_t)out * p.ldc + n) = v;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = (n + j) >> 4, s = (n + j) & 15;
+        p.dst[((size_t)out + (size_t)s * plane) * Cc + c] = v[j];
+      }
+    }
+  }
+}
+
+// Debug/tuning knobs (m2h_debug_set): 0 = automatic.
+int g_force_splitk = 0;   // >0: force this split-K factor (when workspace allows), -1: never split
+int g_force_stages = 0;   // 1 | 2: force the LDS stage count of the narrow-N configs
+
+static int choose_splitk(const IGemmP& p, int BM, int BN, size_t ws_bytes) {
+  if (p.ws == nullptr || g_force_splitk < 0 || (p.N & 3) != 0) return 1;
+  const int phases = p.convT ? 4 : 1;
+  const int nk = (p.K + BK - 1) / BK;
+  const long mt = (p.M + BM - 1) / BM, ntl = (p.N + BN - 1) / BN;
+  const long blocks = mt * ntl * phases;  // working blocks (padding blocks of the XCD map exit at once)
+  int S = 1;
+  if (g_force_splitk > 0) {
+    S = g_force_splitk;
+  } else if (blocks < 512) {
+    S = (int)((512 + blocks - 1) / blocks);  // aim at two resident blocks per CU
+    if (S > 32) S = 32;
+  }
+  if (S > nk / 2) S = nk / 2;  // at least two k-tiles per split
+  while (S > 1 && (size_t)phases * S * p.M * p.N * sizeof(float) > ws_bytes) --S;
+  return S < 1 ? 1 : S;
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   p.MT = (p.M + BM - 1) / BM;
   p.NT = (p.N + BN - 1) / BN;
+  p.S = choose_splitk(p, BM, BN, ws_bytes);
   const long mtpad = ((long)p.MT + 7) / 8 * 8;
   const long nblk = mtpad * p.NT;
   if (nblk > 0x7fffffffL) return fail(-1, "conv_igemm: grid too large (%ld blocks)", nblk);
-  dim3 grid((unsigned)nblk, 1, p.convT ? 4 : 1);
-  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, p);
-  return launch_status("conv_igemm_f32");
+  const int phases = p.convT ? 4 : 1;
+  dim3 grid((unsigned)nblk, (unsigned)p.S, phases);
+  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE>), grid, dim3(256), 0, st, p);
+  int rc = launch_status("conv_igemm_f32");
+  if (rc != 0 || p.S == 1) return rc;
+  const long total = (long)p.M * (p.N >> 2);
+  long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g, phases), dim3(256), 0, st, p);
+  return launch_status("conv_igemm_f32 split-K epilogue");
+}
+
+size_t conv_igemm_workspace_bytes(const m2h_conv_args& a) {
+  // enough for the automatic split-K choice on any tile config: phases * S * M * N floats, S <= 32 and only when the
+  // grid is small (blocks < 512  =>  M*N*phases < 512 * 128 * 128), so cap at 32 * 512 * 128 * 128 * 4 B = 1 GiB worst case;
+  // the exact figure for these arguments:
+  const long M = (long)a.B * a.Hq * a.Wq;
+  const int phases = a.conv_transpose ? 4 : 1;
+  const int K = a.nth * a.ntw * (a.C0 + a.C1);
+  const int BN = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
+  const long mt = (M + 127) / 128, ntl = (a.N + BN - 1) / BN;
+  const long blocks = mt * ntl * phases;
+  if (blocks >= 512 || (a.N & 3) != 0) return 0;
+  long S = (512 + blocks - 1) / blocks;
+  if (S > 32) S = 32;
+  const long nk = (K + BK - 1) / BK;
+  if (S > nk / 2) S = nk / 2;
+  if (S <= 1) return 0;
+  return (size_t)phases * S * M * a.N * sizeof(float);
 }
 
 int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
@@ -315,9 +448,17 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   p.M = (int)M;
   M2H_REQUIRE(p.K % 4 == 0, "conv_igemm: K must be a multiple of 4");
 
-  if (p.N > 64) return launch_cfg<128, 128, 2, 2>(p, st);
-  if (p.N > 32) return launch_cfg<128, 64, 2, 2>(p, st);
-  return launch_cfg<128, 32, 4, 1>(p, st);
+  p.ws = static_cast<float*>(a.workspace);
+  const size_t wsb = a.workspace != nullptr ? a.workspace_bytes : 0;
+  if (p.N > 64) return launch_cfg<128, 128, 2, 2, 2>(p, wsb, st);
+  // narrow-N tiles: one LDS stage doubles the resident blocks; measured better for the transposed-conv phases and the
+  // 32-wide tiles, worse for the short-K stride-2 conv (layer_bench.py, round 1)
+  if (p.N > 32) {
+    const bool one_stage = g_force_stages ? (g_force_stages == 1) : (p.convT != 0);
+    return one_stage ? launch_cfg<128, 64, 2, 2, 1>(p, wsb, st) : launch_cfg<128, 64, 2, 2, 2>(p, wsb, st);
+  }
+  const bool one_stage = g_force_stages != 2;
+  return one_stage ? launch_cfg<128, 32, 4, 1, 1>(p, wsb, st) : launch_cfg<128, 32, 4, 1, 2>(p, wsb, st);
 }
 
 }  // namespace m2h

@@ -65,12 +65,14 @@ class ConvArgs(ctypes.Structure):
         ("Ho", ctypes.c_int), ("Wo", ctypes.c_int),
         ("os", ctypes.c_int), ("ph", ctypes.c_int), ("pw", ctypes.c_int),
         ("ldc", ctypes.c_int), ("out_mode", ctypes.c_int),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
     ]
 
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
+_Z = ctypes.c_size_t
 
 # name -> argtypes; every function returns int except m2h_last_error.  Must list every symbol of include/m2h.h
 SIGNATURES = {
@@ -81,8 +83,12 @@ SIGNATURES = {
     "m2h_unet_class_table": [_P, _P, _I, _I, _I, _P],
     "m2h_fold_bn": [_P, _P, _P, _P, _F, _P, _P, _I, _P],
     "m2h_conv_igemm_f32": [ctypes.POINTER(ConvArgs), _P],
-    "m2h_unet_down_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "m2h_unet_up_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "m2h_conv_igemm_workspace_bytes": [ctypes.POINTER(ConvArgs)],
+    "m2h_debug_set": [_I, _I],
+    "m2h_unet_down_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P],
+    "m2h_unet_up_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P],
+    "m2h_unet_down_workspace_bytes": [_I, _I, _I, _I, _I],
+    "m2h_unet_up_workspace_bytes": [_I, _I, _I, _I, _I, _I],
     "m2h_unet_head_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
 
@@ -106,7 +112,7 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_size_t if name.endswith("workspace_bytes") else ctypes.c_int
         lib.m2h_last_error.argtypes = []
         lib.m2h_last_error.restype = ctypes.c_char_p
         _lib = lib

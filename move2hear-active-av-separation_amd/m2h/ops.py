@@ -39,6 +39,18 @@ def _timed(name, meta, dev, fn):
     return r
 
 
+def _workspace(nbytes, dev):
+    """Split-K scratch from the caching allocator (None when the launch does not split)."""
+    if nbytes == 0:
+        return None, 0
+    ws = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
+    return ws, nbytes
+
+
+def debug_set(knob, value):
+    _lib.check(_lib.load().m2h_debug_set(int(knob), int(value)), "m2h_debug_set")
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -140,12 +152,13 @@ def unet_down_fwd(x, wp, scale, shift, Co, cls_table=None, cls_val=None):
     lib = _lib.load()
     with torch.cuda.device(x.device):
         M = B * (H // 2) * (W // 2)
+        ws, wsb = _workspace(lib.m2h_unet_down_workspace_bytes(B, H, W, Ci, Co), x.device)
         meta = {"kernel": igemm_config(Co), "M": M, "N": Co, "K": 16 * Ci,
                 "flops": 2.0 * M * Co * 16 * (Ci + (1 if cls_table is not None else 0)),
                 "bytes": 4.0 * (x.numel() + y.numel() + wp.numel())}
         _timed("unet_down_fwd", meta, x.device,
                lambda: _lib.check(lib.m2h_unet_down_fwd(_ptr(x), _ptr(wp), _ptr(scale), _ptr(shift), _ptr(cls_table), _ptr(cls_val),
-                                                        _ptr(y), B, H, W, Ci, Co, _stream(x)), "m2h_unet_down_fwd"))
+                                                        _ptr(y), B, H, W, Ci, Co, _ptr(ws), wsb, _stream(x)), "m2h_unet_down_fwd"))
     return y
 
 
@@ -169,11 +182,12 @@ def unet_up_fwd(x, skip, wp, scale, shift, Co):
     lib = _lib.load()
     with torch.cuda.device(x.device):
         M = B * H * W
+        ws, wsb = _workspace(lib.m2h_unet_up_workspace_bytes(B, H, W, C0, C1, Co), x.device)
         meta = {"kernel": igemm_config(Co), "M": 4 * M, "N": Co, "K": 4 * (C0 + C1), "flops": 2.0 * 4 * M * Co * 4 * (C0 + C1),
                 "bytes": 4.0 * (x.numel() + (skip.numel() if skip is not None else 0) + y.numel() + wp.numel())}
         _timed("unet_up_fwd", meta, x.device,
                lambda: _lib.check(lib.m2h_unet_up_fwd(_ptr(x), _ptr(skip), _ptr(wp), _ptr(scale), _ptr(shift), _ptr(y), B, H, W,
-                                                      C0, C1, Co, _stream(x)), "m2h_unet_up_fwd"))
+                                                      C0, C1, Co, _ptr(ws), wsb, _stream(x)), "m2h_unet_up_fwd"))
     return y
 
 
@@ -204,7 +218,7 @@ def conv_igemm_f32(**kw):
     dev_t = kw["src0"]
     for name, _ in _lib.ConvArgs._fields_:
         v = kw.get(name, None)
-        if name in ("src0", "src1", "wp", "scale", "shift", "cls_table", "cls_val", "dst"):
+        if name in ("src0", "src1", "wp", "scale", "shift", "cls_table", "cls_val", "dst", "workspace"):
             _chk(v, "conv_igemm_f32(%s)" % name)
             setattr(a, name, v.data_ptr() if v is not None else None)
         elif v is not None:

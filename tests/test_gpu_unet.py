@@ -156,8 +156,9 @@ def test_pair_ragged_batches_match_oracle(B):
 
 
 def test_batch_independence_and_determinism():
-    """Size-independent properties at the full benchmark shape: a sample's result does not depend on its
-    batch neighbours (eval-mode BN) and repeated runs are bit-identical."""
+    """Size-independent properties at the full benchmark shape: repeated runs are bit-identical (the split-K
+    reduction is ordered, no atomics) and a sample's result does not depend on its batch neighbours (eval-mode
+    BN) beyond fp32 summation order (the split-K factor depends on the batch size)."""
     dev = _dev()
     pol, _ = _policy(2, dev)
     mixed, tc = synthetic.make_passive_inputs(8, 256, 77)
@@ -167,7 +168,7 @@ def test_batch_independence_and_determinism():
         big2 = pol.get_binSepMasks({"mixed_bin_audio_mag": mix, "target_class": tct})
         one = pol.get_binSepMasks({"mixed_bin_audio_mag": mix[5:6].contiguous(), "target_class": tct[5:6]})
     assert torch.equal(big, big2)
-    assert torch.equal(big[5:6], one)
+    assert O.rel_l1(big[5:6].cpu(), one.cpu()) < 1e-6
 
 
 def test_weight_update_invalidates_packed_cache():
