@@ -88,6 +88,8 @@ def fill(name, shape, seed):
     else:
         fan_in = shape[-1]
     std = np.sqrt(2.0 / fan_in)
+    if name.startswith("action_dist") or "state_encoder" in name:
+        std = np.sqrt(1.0 / fan_in)  # keep logits / GRU pre-activations O(1): unsaturated softmax and gates
     return (std * r.standard_normal(size=shape)).astype(np.float32)
 
 
@@ -107,3 +109,60 @@ def make_passive_inputs(batch, tm, seed, n_freq=512):
     mixed = np.log1p(mag).astype(np.float32)
     target = r.integers(0, 11, size=(batch, 1)).astype(np.int64)
     return mixed, target
+
+
+# ------------------------------------------------------------------------------------------------
+# RL policy (Move2HearPolicy, audio_separation/rl/ppo/policy.py:276-326) -- 158-entry state_dict
+# ------------------------------------------------------------------------------------------------
+def policy_shapes(extra_rgb=False, extra_depth=True, hidden=512, n_actions=3):
+    """Ordered (key -> shape) of the full RL policy in the reference's registration order:
+    pol_net (visual, bin, monoNmonoFromMem encoders, GRU), action_dist, critic, 4 separator modules,
+    acoustic_mem (ddppo variant: no BN; rl/models/memory_nets.py:11-16)."""
+    s = OrderedDict()
+    cin_v = (0 if extra_rgb else 3) + (0 if extra_depth else 1)
+    v = "pol_net.visual_encoder.cnn."
+    s[v + "0.weight"], s[v + "0.bias"] = (32, cin_v, 8, 8), (32,)
+    s[v + "2.weight"], s[v + "2.bias"] = (64, 32, 4, 4), (64,)
+    s[v + "4.weight"], s[v + "4.bias"] = (32, 64, 3, 3), (32,)
+    s[v + "6.weight"], s[v + "6.bias"] = (hidden, 32 * 12 * 12), (hidden,)
+    for enc in ("bin_encoder", "monoNmonoFromMem_encoder"):
+        a = "pol_net.%s.cnn." % enc
+        s[a + "0.weight"], s[a + "0.bias"] = (32, 32, 8, 8), (32,)
+        s[a + "2.weight"], s[a + "2.bias"] = (64, 32, 4, 4), (64,)
+        s[a + "4.weight"], s[a + "4.bias"] = (32, 64, 2, 2), (32,)
+        s[a + "7.weight"], s[a + "7.bias"] = (hidden, 32), (hidden,)
+    g = "pol_net.state_encoder.rnn."
+    s[g + "weight_ih_l0"], s[g + "weight_hh_l0"] = (3 * hidden, 3 * hidden), (3 * hidden, hidden)
+    s[g + "bias_ih_l0"], s[g + "bias_hh_l0"] = (3 * hidden,), (3 * hidden,)
+    s["action_dist.linear.weight"], s["action_dist.linear.bias"] = (n_actions, hidden), (n_actions,)
+    s["critic.fc.weight"], s["critic.fc.bias"] = (1, hidden), (1,)
+    for k, shp in passive_shapes().items():
+        s[k] = shp
+    s["acoustic_mem.cnn.0.weight"] = (32, 32, 3, 3)
+    s["acoustic_mem.cnn.2.weight"] = (16, 32, 3, 3)
+    return s
+
+
+def make_rl_observations(n, seed, tm=32, n_freq=512):
+    """One batch of observations with the reference's sensor shapes (config/default.py:130-157):
+    rgb uint8-valued float, depth in [0,1], mixed/gt spectrogram tensors, target_class.
+    gt_bin_comps = per source [mag_l, phase_l, mag_r, phase_r] x 2 sources, gt_mono_comps = [mag, phase] x 2."""
+    r = _rng(seed, "rl_obs_%d_%d" % (n, tm))
+    mixed, tc = make_passive_inputs(n, tm, seed, n_freq)
+    obs = {
+        "rgb": r.integers(0, 256, size=(n, 128, 128, 3)).astype(np.float32),
+        "depth": r.uniform(0.0, 1.0, size=(n, 128, 128, 1)).astype(np.float32),
+        "mixed_bin_audio_mag": mixed,
+        "target_class": tc,
+    }
+    gb = np.empty((n, n_freq, tm, 8), np.float32)
+    gm = np.empty((n, n_freq, tm, 4), np.float32)
+    for j in range(0, 8, 2):
+        gb[..., j] = np.log1p(np.abs(r.standard_normal(size=(n, n_freq, tm))).astype(np.float32))
+        gb[..., j + 1] = r.uniform(-np.pi, np.pi, size=(n, n_freq, tm)).astype(np.float32)
+    for j in range(0, 4, 2):
+        gm[..., j] = np.log1p(np.abs(r.standard_normal(size=(n, n_freq, tm))).astype(np.float32))
+        gm[..., j + 1] = r.uniform(-np.pi, np.pi, size=(n, n_freq, tm)).astype(np.float32)
+    obs["gt_bin_comps"] = gb
+    obs["gt_mono_comps"] = gm
+    return obs

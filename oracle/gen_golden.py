@@ -138,7 +138,144 @@ def gen_init(ref):
     print("init: %d entries" % len(rec))
 
 
-GENS = {"unet_tm32": gen_unet_tm32, "unet_tm256": gen_unet_tm256, "init": gen_init}
+# ----------------------------------------------------------------------------------------------
+# RL path fixtures
+# ----------------------------------------------------------------------------------------------
+def build_ref_rl(ref, seed):
+    """Reference Move2HearPolicy (ppo_trainer.py:168-177 arguments: EXTRA_RGB False, EXTRA_DEPTH True, ddppo)
+    loaded with the synthetic state dict; separators frozen + eval as ppo_trainer.py:557-577."""
+    pol = ref["rl_policy"].Move2HearPolicy(FakeObsSpace(32), FakeActionSpace(), "spectrogram", 512, False, True,
+                                           use_ddppo=True)
+    sd = synthetic.make_state_dict(synthetic.policy_shapes(), seed)
+    res = pol.load_state_dict(_t(sd), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    pol.train()
+    for m in (pol.binSep_enc, pol.binSep_dec, pol.bin2mono_enc, pol.bin2mono_dec):
+        m.eval()
+        for p_ in m.parameters():
+            p_.requires_grad_(False)
+    return pol, sd
+
+
+def _obs_t(obs_np):
+    return {k: torch.from_numpy(v).float() if k != "target_class" else torch.from_numpy(v).float() for k, v in obs_np.items()}
+
+
+def gen_rl_forward(ref):
+    """G3-G7: AcousticMem, VisualCNN, AudioCNN x2, GRU single/seq, act (sampled + deterministic), evaluate_actions."""
+    seed_w, seed_x, N = 2, 31, 6
+    pol, sd = build_ref_rl(ref, seed_w)
+    obs = _obs_t(synthetic.make_rl_observations(N, seed_x))
+    g = torch.Generator().manual_seed(5)
+    prev_mem = torch.rand(N, 512, 32, 1, generator=g)
+    masks = torch.tensor([[1.0], [0.0], [1.0], [1.0], [0.0], [1.0]])
+    h0 = torch.randn(1, N, 512, generator=g) * 0.5
+    out = {"seed_w": seed_w, "seed_x": seed_x, "N": N, "prev_mem": prev_mem.numpy(), "masks": masks.numpy(), "h0": h0.numpy()}
+    with torch.no_grad():
+        pm = pol.get_binSepMasks(obs)
+        mono = pol.convert_bin2mono(pm, mixed_audio=obs["mixed_bin_audio_mag"])
+        prev_masked = prev_mem * masks.unsqueeze(1).unsqueeze(2).repeat(1, *mono.size()[1:])  # ppo_trainer.py:310-314
+        mem = pol.get_monoFromMem(mono, prev_masked)
+        out["pred_binSepMasks"] = pm.contiguous().numpy()
+        out["pred_mono"] = mono.contiguous().numpy()
+        out["pred_monoFromMem"] = mem.contiguous().numpy()
+        out["visual_feats"] = pol.pol_net.visual_encoder(obs).numpy()
+        out["bin_feats"] = pol.pol_net.bin_encoder(obs, pred_binSepMasks=pm).numpy()
+        out["mnm_feats"] = pol.pol_net.monoNmonoFromMem_encoder(obs, pred_monoNmonoFromMem=torch.cat((mono, mem), dim=3)).numpy()
+        feats, h1 = pol.pol_net(obs, h0, masks, pred_binSepMasks=pm, pred_mono=mono, pred_monoFromMem=mem)
+        out["gru_out"], out["h1"] = feats.numpy(), h1.numpy()
+        torch.manual_seed(77)
+        v, a, lp, hh, probs = pol.act(obs, h0, masks, deterministic=False, pred_binSepMasks=pm, pred_mono=mono, pred_monoFromMem=mem)
+        out.update(act_value=v.numpy(), act_action=a.numpy(), act_logp=lp.numpy(), act_probs=probs.numpy(), act_seed=77)
+        v2, a2, lp2, _, _ = pol.act(obs, h0, masks, deterministic=True, pred_binSepMasks=pm, pred_mono=mono, pred_monoFromMem=mem)
+        out.update(det_action=a2.numpy(), det_logp=lp2.numpy())
+        out["get_value"] = pol.get_value(obs, h0, masks, pred_binSepMasks=pm, pred_mono=mono, pred_monoFromMem=mem).numpy()
+        # bit-exact sampling contract: (probs, seed) -> actions alone
+        pr = torch.softmax(torch.randn(64, 3, generator=g), dim=-1)
+        torch.manual_seed(123)
+        out["sample_probs"] = pr.numpy()
+        out["sample_actions"] = ref["utils"].CustomFixedCategorical(probs=pr).sample().numpy()
+        out["sample_seed"] = 123
+        # evaluate_actions as update_pol calls it: T=3 steps x N=2 envs flattened (T*N), masks with a reset at t=1 for env 1
+        T, n = 3, 2
+        obs_seq = {k: v_[:T * n] for k, v_ in obs.items()}
+        masks_seq = torch.tensor([[1.0], [1.0], [1.0], [0.0], [1.0], [1.0]])
+        acts = torch.tensor([[0], [2], [1], [1], [2], [0]])
+        hseq = h0[:, :n]
+        ev, elp, eent, eh = pol.evaluate_actions(obs_seq, hseq, masks_seq, acts, pred_binSepMasks=pm[:T * n],
+                                                 pred_mono=mono[:T * n], pred_monoFromMem=mem[:T * n])
+        out.update(eval_masks=masks_seq.numpy(), eval_actions=acts.numpy(), eval_value=ev.numpy(), eval_logp=elp.numpy(),
+                   eval_entropy=np.array(eent.item()), eval_h=eh.numpy())
+    np.savez_compressed(os.path.join(GOLD, "rl_forward.npz"), meta=json.dumps(META), **out)
+    print("rl_forward: actions", a.reshape(-1).tolist(), "probs[0]", probs[0].tolist(), "mem mean", float(mem.abs().mean()))
+
+
+def gen_rl_scalars(ref):
+    """G8, G9, G13, G14, G15: compute_returns, generator permutations, STFT-L2 / rewards, advantages, LR decay."""
+    RS = ref["rollout_storage"]
+    T, N = 20, 14
+    g = torch.Generator().manual_seed(9)
+    space = FakeObsSpace(32)
+    small = type("S", (), {})()
+    small.spaces = {"gt_mono_comps": space.spaces["gt_mono_comps"], "target_class": space.spaces["target_class"]}
+    out = {"T": T, "N": N}
+    ro = RS.RolloutStoragePol(T, N, small, 512)
+    ro.rewards.copy_(torch.randn(T, N, 1, generator=g))
+    ro.value_preds.copy_(torch.randn(T + 1, N, 1, generator=g))
+    ro.masks.copy_((torch.rand(T + 1, N, 1, generator=g) > 0.15).float())
+    nv = torch.randn(N, 1, generator=g)
+    out.update(rewards=ro.rewards.numpy().copy(), value_preds=ro.value_preds.numpy().copy(), masks=ro.masks.numpy().copy(), next_value=nv.numpy())
+    ro.compute_returns(nv, True, 0.99, 0.95)
+    out["returns_gae"] = ro.returns.numpy().copy()
+    ppo = ref["ppo"].PPO.__new__(ref["ppo"].PPO)
+    ppo.use_normalized_advantage = True
+    out["advantages"] = ref["ppo"].PPO.get_advantages(ppo, ro).numpy().copy()
+    ro2 = RS.RolloutStoragePol(T, N, small, 512)
+    ro2.rewards.copy_(ro.rewards); ro2.masks.copy_(ro.masks)
+    ro2.compute_returns(nv, False, 0.99, 0.95)
+    out["returns_nogae"] = ro2.returns.numpy().copy()
+    # G9: permutation + flattened gather order of the recurrent generators (torch.randperm on the CPU generator)
+    ro.actions.copy_(torch.arange(T * N).reshape(T, N, 1))
+    torch.manual_seed(2024)
+    adv = torch.from_numpy(out["advantages"])
+    batch = next(iter(ro.recurrent_generator(adv, 1)))
+    out["gen_seed"] = 2024
+    out["gen_actions_flat"] = batch[8].numpy().copy()  # actions_batch: value = t*N + env  -> reveals perm and order
+    rs = RS.RolloutStorageSep(6, 5, small)
+    rs.masks.copy_(torch.arange(7 * 5).reshape(7, 5, 1).float())
+    torch.manual_seed(2025)
+    sb = next(iter(rs.recurrent_generator(1)))
+    out["gen_sep_seed"] = 2025
+    out["gen_sep_masks_flat"] = sb[3].numpy().copy()
+    # G13: STFT-L2 distance, reward_util, override_rewards
+    n = 5
+    obs = _obs_t(synthetic.make_rl_observations(n, 41))
+    pm = torch.randn(n, 512, 32, 2, generator=g)
+    pmono = torch.rand(n, 512, 32, 1, generator=g)
+    mem_next = torch.rand(n, 512, 32, 1, generator=g)
+    mem_cur = torch.rand(n, 512, 32, 1, generator=g)
+    d_bin, d_mono = ref["eval_metrics"].STFT_L2_distance(obs["mixed_bin_audio_mag"], pm, obs["gt_bin_comps"].clone(), pmono,
+                                                         obs["gt_mono_comps"].clone())
+    out.update(l2_seed_x=41, l2_masks=pm.numpy(), l2_mono=pmono.numpy(), stft_l2_bin=d_bin.numpy(), stft_l2_mono=d_mono.numpy())
+    # reward_util / override_rewards live in a Habitat-importing file: exec only their source lines (env_utils.py:690-713)
+    src = open(os.path.join("/root/reference", "audio_separation/common/env_utils.py")).read().split("\n")[689:713]
+    ns = {"F": torch.nn.functional, "torch": torch}
+    exec("\n".join(src), ns)
+    gt_mono_mag = obs["gt_mono_comps"][..., 0::2][..., :1]
+    dones = [False, True, False, False, True]
+    out["rew_mem_next"], out["rew_mem_cur"] = mem_next.numpy(), mem_cur.numpy()
+    out["rew_dones"] = np.array(dones)
+    out["rew_quality_improvement"] = np.array(ns["override_rewards"]([0.0] * n, dones, mem_next, gt_mono_mag, reward_type="quality_improvement",
+                                                                     pred_monoFromMem=mem_cur, gt_mono_mag=gt_mono_mag), dtype=np.float64)
+    out["rew_extra"] = np.array(ns["override_rewards"]([0.0] * n, dones, mem_next, gt_mono_mag), dtype=np.float64)
+    # G15: linear decay + LambdaLR
+    out["linear_decay"] = np.array([ref["utils"].linear_decay(e, 100) for e in range(6)])
+    np.savez_compressed(os.path.join(GOLD, "rl_scalars.npz"), meta=json.dumps(META), **out)
+    print("rl_scalars: returns mean", float(out["returns_gae"].mean()), "rew", out["rew_quality_improvement"])
+
+
+GENS = {"unet_tm32": gen_unet_tm32, "unet_tm256": gen_unet_tm256, "init": gen_init,
+        "rl_forward": gen_rl_forward, "rl_scalars": gen_rl_scalars}
 
 
 def main():

@@ -151,3 +151,232 @@ def rel_l1(a, b):
 def pred_bin(masks, mixed_bin_audio_mag):
     """mask * (exp(mix) - 1): the separated binaural magnitude (passive_trainer.py:271-272)."""
     return masks * (torch.exp(mixed_bin_audio_mag) - 1)
+
+
+# ==============================================================================================
+# RL path (forward).  State-dict keys are the reference's, without the "actor_critic." root.
+# ==============================================================================================
+MEM = "acoustic_mem.cnn."
+VIS = "pol_net.visual_encoder.cnn."
+BIN = "pol_net.bin_encoder.cnn."
+MNM = "pol_net.monoNmonoFromMem_encoder.cnn."
+GRU = "pol_net.state_encoder.rnn."
+
+
+# A5: AcousticMem.forward (rl/models/memory_nets.py:40-69), ddppo variant (no BN, :11-16)
+def acoustic_mem(sd, pred_mono, prev_pred_monoFromMem_masked):
+    x = torch.cat((slice_freq(pred_mono), slice_freq(prev_pred_monoFromMem_masked)), dim=1)
+    x = F.relu(F.conv2d(x, sd[MEM + "0.weight"], None, padding=1))
+    x = F.conv2d(x, sd[MEM + "2.weight"], None, padding=1)
+    return deslice_freq(x)
+
+
+def mask_prev_mem(prev_pred_monoFromMem, masks):
+    """prev * masks.unsqueeze(1).unsqueeze(2).repeat(...)  (ppo_trainer.py:310-314; ppo.py:206-209)"""
+    return prev_pred_monoFromMem * masks.reshape(-1, 1, 1, 1)
+
+
+# A6: VisualCNN.forward (rl/models/visual_cnn.py:135-152): /255, NHWC->NCHW, conv8x8s4+ReLU, conv4x4s2+ReLU,
+# conv3x3s1 (no ReLU), flatten (NCHW order), FC+ReLU
+def visual_cnn(sd, rgb, depth=None):
+    x = rgb.permute(0, 3, 1, 2) / 255.0
+    if depth is not None:
+        x = torch.cat((x, depth.permute(0, 3, 1, 2)), dim=1)
+    x = F.relu(F.conv2d(x, sd[VIS + "0.weight"], sd[VIS + "0.bias"], stride=4))
+    x = F.relu(F.conv2d(x, sd[VIS + "2.weight"], sd[VIS + "2.bias"], stride=2))
+    x = F.conv2d(x, sd[VIS + "4.weight"], sd[VIS + "4.bias"], stride=1)
+    x = x.reshape(x.size(0), -1)
+    return F.relu(F.linear(x, sd[VIS + "6.weight"], sd[VIS + "6.bias"]))
+
+
+# A7: AudioCNN.forward (rl/models/audio_cnn.py:117-140)
+def audio_cnn(sd, pre, mixed_bin_audio_mag=None, pred_binSepMasks=None, pred_monoNmonoFromMem=None):
+    if pred_monoNmonoFromMem is not None:
+        x = torch.log1p(torch.clamp(pred_monoNmonoFromMem, min=0))  # :121-122
+    else:
+        x = (torch.exp(mixed_bin_audio_mag) - 1) * pred_binSepMasks  # :125-127
+        x = torch.log1p(torch.clamp(x, min=0))
+    x = slice_freq(x)
+    x = F.relu(F.conv2d(x, sd[pre + "0.weight"], sd[pre + "0.bias"], stride=4))
+    x = F.relu(F.conv2d(x, sd[pre + "2.weight"], sd[pre + "2.bias"], stride=2))
+    x = F.relu(F.conv2d(x, sd[pre + "4.weight"], sd[pre + "4.bias"], stride=1))
+    x = x.reshape(x.size(0), -1)
+    return F.relu(F.linear(x, sd[pre + "7.weight"], sd[pre + "7.bias"]))
+
+
+# A8: RNNStateEncoder (rl/models/rnn_state_encoder.py:74-143), GRU(1536 -> 512), gate order r,z,n
+def gru_cell(sd, x, h):
+    gi = F.linear(x, sd[GRU + "weight_ih_l0"], sd[GRU + "bias_ih_l0"])
+    gh = F.linear(h, sd[GRU + "weight_hh_l0"], sd[GRU + "bias_hh_l0"])
+    H = h.size(1)
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    return (1 - z) * n + z * h
+
+
+def rnn_forward(sd, x, hidden_states, masks):
+    """single_forward when x.size(0) == N (:74-84), else seq_forward (:86-137).  seq_forward's segment
+    trick (run the GRU over stretches without resets, mask h at every stretch start) equals masking h
+    with masks[t] before EVERY step only when masks are 1 inside stretches -- which is the definition of a
+    stretch -- except at t=0 of each segment where the reference applies masks[start]; identical."""
+    n = hidden_states.size(1)
+    h = hidden_states[0]
+    if x.size(0) == n:
+        h = gru_cell(sd, x, h * masks)
+        return h, h.unsqueeze(0)
+    t = x.size(0) // n
+    xs = x.reshape(t, n, -1)
+    ms = masks.reshape(t, n, 1)
+    outs = []
+    for i in range(t):
+        h = gru_cell(sd, xs[i], h * ms[i])
+        outs.append(h)
+    return torch.cat(outs, 0), h.unsqueeze(0)
+
+
+# PolicyNet.forward (rl/ppo/policy.py:98-118)
+def policy_net(sd, obs, hidden_states, masks, pred_binSepMasks, pred_mono, pred_monoFromMem, use_depth=False):
+    feats = [
+        visual_cnn(sd, obs["rgb"], obs["depth"] if use_depth else None),
+        audio_cnn(sd, BIN, mixed_bin_audio_mag=obs["mixed_bin_audio_mag"], pred_binSepMasks=pred_binSepMasks),
+        audio_cnn(sd, MNM, pred_monoNmonoFromMem=torch.cat((pred_mono, pred_monoFromMem), dim=3)),
+    ]
+    x = torch.cat(feats, dim=1)
+    return rnn_forward(sd, x, hidden_states, masks) + (x,)
+
+
+# A9: CategoricalNet / CustomFixedCategorical / CriticHead (common/utils.py:16-50; rl/ppo/policy.py:15-23)
+def heads(sd, feats):
+    logits = F.linear(feats, sd["action_dist.linear.weight"], sd["action_dist.linear.bias"])
+    value = F.linear(feats, sd["critic.fc.weight"], sd["critic.fc.bias"])
+    # torch.distributions.Categorical(logits=x): logits normalised by logsumexp, probs = softmax
+    logp_all = logits - logits.logsumexp(dim=-1, keepdim=True)
+    probs = F.softmax(logits, dim=-1)
+    return value, logp_all, probs
+
+
+def categorical_entropy(logp_all, probs):
+    """Categorical.entropy(): -(clamped logits * probs).sum(-1)"""
+    min_real = torch.finfo(logp_all.dtype).min
+    return -(torch.clamp(logp_all, min=min_real) * probs).sum(-1)
+
+
+def act(sd, obs, hidden_states, masks, pred_binSepMasks, pred_mono, pred_monoFromMem, deterministic=False, generator=None):
+    """Policy.act (rl/ppo/policy.py:198-225).  sample() = torch.multinomial(probs, 1, True) on the probs tensor."""
+    feats, h, _ = policy_net(sd, obs, hidden_states, masks, pred_binSepMasks, pred_mono, pred_monoFromMem)
+    value, logp_all, probs = heads(sd, feats)
+    if deterministic:
+        action = probs.argmax(dim=-1, keepdim=True)
+    else:
+        action = torch.multinomial(probs, 1, True, generator=generator)
+    logp = logp_all.gather(1, action)
+    return value, action, logp, h, probs
+
+
+def evaluate_actions(sd, obs, hidden_states, masks, action, pred_binSepMasks, pred_mono, pred_monoFromMem):
+    """Policy.evaluate_actions (rl/ppo/policy.py:248-273)."""
+    feats, h, _ = policy_net(sd, obs, hidden_states, masks, pred_binSepMasks, pred_mono, pred_monoFromMem)
+    value, logp_all, probs = heads(sd, feats)
+    logp = logp_all.gather(1, action)
+    return value, logp, categorical_entropy(logp_all, probs).mean(), h
+
+
+# A10: RolloutStoragePol.compute_returns (common/rollout_storage.py:155-180)
+def compute_returns(rewards, value_preds, masks, next_value, use_gae, gamma, tau):
+    """rewards [T,N,1], value_preds [T+1,N,1] (last row overwritten by next_value when use_gae), masks [T+1,N,1].
+    Returns (returns [T+1,N,1], value_preds)."""
+    T = rewards.size(0)
+    value_preds = value_preds.clone()
+    returns = torch.zeros_like(value_preds)
+    if use_gae:
+        value_preds[-1] = next_value
+        gae = 0
+        for step in reversed(range(T)):
+            delta = rewards[step] + gamma * value_preds[step + 1] * masks[step + 1] - value_preds[step]
+            gae = delta + gamma * tau * masks[step + 1] * gae
+            returns[step] = gae + value_preds[step]
+    else:
+        returns[-1] = next_value
+        for step in reversed(range(T)):
+            returns[step] = returns[step + 1] * gamma * masks[step + 1] + rewards[step]
+    return returns, value_preds
+
+
+# A14: PPO.get_advantages (rl/ppo/ppo.py:75-80) and the distributed variant (:275-284; ddppo_utils.py:168-190)
+EPS_PPO = 1e-5
+
+
+def get_advantages(returns, value_preds, normalized=True):
+    adv = returns[:-1] - value_preds[:-1]
+    if not normalized:
+        return adv
+    return (adv - adv.mean()) / (adv.std() + EPS_PPO)
+
+
+def get_advantages_distributed(per_rank_adv):
+    """Emulates _get_advantages_distributed over a list of per-rank advantage tensors: global mean, then the
+    mean over ranks of per-rank mean((A - mean)^2) (biased), (A - mean) / (sqrt(var) + eps)."""
+    w = len(per_rank_adv)
+    mean = sum(a.mean() for a in per_rank_adv) / w
+    var = sum((a - mean).pow(2).mean() for a in per_rank_adv) / w
+    return [(a - mean) / (var.sqrt() + EPS_PPO) for a in per_rank_adv]
+
+
+# K15: PPO losses (rl/ppo/ppo.py:125-157)
+def ppo_losses(values, action_log_probs, dist_entropy, value_preds_batch, return_batch, adv_targ, old_action_log_probs,
+               clip_param, value_loss_coef, entropy_coef, use_clipped_value_loss=True):
+    ratio = torch.exp(action_log_probs - old_action_log_probs)
+    surr1 = ratio * adv_targ
+    surr2 = torch.clamp(ratio, 1.0 - clip_param, 1.0 + clip_param) * adv_targ
+    action_loss = -torch.min(surr1, surr2).mean()
+    if use_clipped_value_loss:
+        value_pred_clipped = value_preds_batch + (values - value_preds_batch).clamp(-clip_param, clip_param)
+        value_loss = 0.5 * torch.max((values - return_batch).pow(2), (value_pred_clipped - return_batch).pow(2)).mean()
+    else:
+        value_loss = 0.5 * (return_batch - values).pow(2).mean()
+    total = value_loss * value_loss_coef + action_loss - dist_entropy * entropy_coef
+    return value_loss, action_loss, total
+
+
+# A16: reward_util / override_rewards (common/env_utils.py:690-713)
+def reward_util(pred_monoFromMem, gt_mono_mag):
+    loss = F.mse_loss(pred_monoFromMem, gt_mono_mag)
+    return -loss.item() / torch.mean(torch.pow(gt_mono_mag, 2.0)).item()
+
+
+def override_rewards(rewards, dones, next_pred, next_gt, reward_type=None, pred=None, gt=None, extra_reward_multiplier=10.0):
+    rewards = list(rewards)
+    for idx in range(len(rewards)):
+        if not dones[idx]:
+            rewards[idx] = reward_util(next_pred[idx].unsqueeze(0), next_gt[idx].unsqueeze(0))
+            if reward_type == "quality_improvement":
+                rewards[idx] -= reward_util(pred[idx].unsqueeze(0), gt[idx].unsqueeze(0))
+            else:
+                rewards[idx] *= extra_reward_multiplier
+        else:
+            rewards[idx] = 0.0
+    return rewards
+
+
+# A17: STFT_L2_distance (common/eval_metrics.py:306-366): squared distance of (mag*cos(phi), mag*sin(phi)) using the
+# GT phase for both; mean over (re/im, F, T) per env; binaural = left + right.
+def stft_l2_distance(mixed_audio, pred_binSepMasks, gt_bin_comps, pred_mono, gt_mono_comps):
+    def ri(mag, phase):
+        return torch.stack((mag * torch.cos(phase), mag * torch.sin(phase)), dim=1).reshape(mag.size(0), 1, -1)
+
+    pred_bin_ = (torch.exp(mixed_audio) - 1) * pred_binSepMasks
+    d = 0
+    for ch in range(2):
+        gt_mag, gt_ph = gt_bin_comps[..., 2 * ch], gt_bin_comps[..., 2 * ch + 1]
+        d = d + torch.mean(torch.pow(ri(gt_mag, gt_ph) - ri(pred_bin_[..., ch], gt_ph), 2), dim=2)
+    gm, gp = gt_mono_comps[..., 0], gt_mono_comps[..., 1]
+    dm = torch.mean(torch.pow(ri(gm, gp) - ri(pred_mono[..., 0], gp), 2), dim=2)
+    return d, dm
+
+
+def gt_mags(obs):
+    """gt_mono_mag / gt_bin_mag selections used by the trainers (ppo.py:212,219; ppo_trainer.py:376-383)."""
+    gt_mono_mag = obs["gt_mono_comps"][..., 0::2][..., :1]
+    gt_bin_mag = obs["gt_bin_comps"][..., 0::2][..., :2]
+    return gt_bin_mag, gt_mono_mag
