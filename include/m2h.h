@@ -142,6 +142,79 @@ size_t m2h_unet_up_workspace_bytes(int B, int H, int W, int C0, int C1, int Co);
 int m2h_unet_head_fwd(const float* x, const float* wp, const float* bias, float* out,
                       int B, int H, int W, int Ci, int Co, m2h_stream stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * RL path (forward): layout glue, GRU cell, heads, scans and reductions.  All fp32, all HBM-bound or tiny.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* m2h_pack_conv_weight_ex: as m2h_pack_conv_weight but the packed channel count ci_out >= ci_used is zero-padded
+ * (VisualCNN's 3-channel first conv is packed to 4 channels, visual_cnn.py:65-72).  A Linear weight [Co][C*H*W] applied
+ * to an NCHW-flattened map (visual_cnn.py:140-141, audio_cnn.py:131-132) is packed as the conv weight [Co][C][H][W]. */
+int m2h_pack_conv_weight_ex(const float* w, float* wp, int Co, int Ci, int KH, int KW, int ci_used, int ci_out, m2h_stream stream);
+
+/* Input glue of AcousticMem (memory_nets.py:40-59: cat(slice(pred_mono), slice(prev_mem * mask))) and AudioCNN
+ * (audio_cnn.py:117-133).  Virtual BHWC tensor with channels [a (Ca) | b (Cb)], b optionally scaled per batch row by
+ * bscale[B] (the not-done mask of ppo_trainer.py:310-314), then
+ *   op 0: x          op 1: log1p(max(0, mul * (exp(a) - 1)))  (mul: same shape as a)      op 2: log1p(max(0, x))
+ * and the 16-way frequency slice into NHWC  out[b][h][t][c*16+s].  a,b: [B][F][T][Ca|Cb];  out: [B][F/16][T][16*(Ca+Cb)]. */
+int m2h_slice_concat_input(const float* a, int Ca, const float* b, int Cb, const float* mul, const float* bscale, int op,
+                           float* out, int B, int F, int T, m2h_stream stream);
+
+/* VisualCNN input (visual_cnn.py:135-150): rgb [B][H][W][3] in 0..255 -> out [B][H][W][4] = (rgb/255, depth or 0). */
+int m2h_visual_input(const float* rgb, const float* depth, float* out, int B, int H, int W, m2h_stream stream);
+
+/* GRU cell pointwise part (torch.nn.GRU as used by rnn_state_encoder.py:74-84), gate order r,z,n:
+ *   gi = x W_ih^T + b_ih  [M][3H] (from m2h_conv_igemm_f32),  gh_raw = h W_hh^T (no bias, UNMASKED h) [M][3H],
+ *   mask[M] in {0,1} or NULL: the hidden-state reset h*mask is applied here ((h*m) W^T == m * (h W^T)).
+ *   hout = (1-z)*n + z*(m*h). */
+int m2h_gru_gates(const float* gi, const float* gh_raw, const float* bhh, const float* hprev, const float* mask, float* hout,
+                  int M, int H, m2h_stream stream);
+
+/* CategoricalNet + CriticHead (common/utils.py:16-50, rl/ppo/policy.py:15-23): logits = feats Wa^T + ba (A <= 8),
+ * value = feats Wc^T + bc, logp_all = log_softmax, probs = softmax, entropy = -sum p*logp per row; when actions != NULL
+ * also logp_act[row] = logp_all[row][actions[row]] (CustomFixedCategorical.log_probs).  actions: int64. */
+int m2h_policy_heads(const float* feats, const float* Wa, const float* ba, const float* Wc, const float* bc,
+                     const long long* actions, float* value, float* logp_all, float* probs, float* entropy, float* logp_act,
+                     int M, int H, int A, m2h_stream stream);
+int m2h_gather_logp(const float* logp_all, const long long* actions, float* out, int M, int A, m2h_stream stream);
+
+/* RolloutStoragePol.compute_returns (common/rollout_storage.py:155-180).  rewards [T][N], value_preds [T+1][N] (row T is
+ * overwritten by next_value when use_gae), masks [T+1][N], next_value [N], returns [T+1][N]. */
+int m2h_gae_returns(const float* rewards, float* value_preds, const float* masks, const float* next_value, float* returns, int T,
+                    int N, int use_gae, float gamma, float tau, m2h_stream stream);
+
+/* PPO.get_advantages (ppo.py:75-80): adv = returns - value_preds over n = T*N elements; mode 0 raw, mode 1 local
+ * normalisation (adv-mean)/(std_unbiased+eps); mode 2 raw + stats[0] = local mean (first step of the distributed variant,
+ * ppo.py:275-284 + ddppo_utils.py:168-190: all-reduce the mean, m2h_adv_sqdiff, all-reduce, m2h_adv_apply). */
+int m2h_advantages(const float* returns, const float* value_preds, float* adv, float* stats, int n, int mode, float eps,
+                   m2h_stream stream);
+int m2h_adv_sqdiff(const float* adv, const float* gmean, float* out, int n, m2h_stream stream);
+int m2h_adv_apply(float* adv, const float* gmean, const float* gvar, int n, float eps, m2h_stream stream);
+
+/* PPO losses (ppo.py:125-157) forward and analytic gradients: out[0] = value_loss, out[1] = action_loss;
+ * g_values = d(value_loss_coef*value_loss)/dvalues, g_logp = d(action_loss)/d(action_log_probs) (either may be NULL). */
+int m2h_ppo_loss(const float* values, const float* logp, const float* old_values, const float* returns, const float* adv,
+                 const float* old_logp, float clip, int use_clipped_value_loss, float value_loss_coef, float* out, float* g_values,
+                 float* g_logp, int n, m2h_stream stream);
+
+/* reward_util / override_rewards (common/env_utils.py:690-713).  m2h_sq_stats: per env e, stats[e] = (sum (pred-gt)^2,
+ * sum gt^2) over L elements, gt read with stride/offset from an interleaved components tensor (gt_mono_comps[...,0]).
+ * m2h_rewards_from_stats: done -> 0; else -(mse/mean gt^2) of the next step, minus the same at the current step
+ * (quality_improvement) or times mult. */
+int m2h_sq_stats(const float* pred, const float* gt_comps, int gt_stride, int gt_off, float* stats, int N, int L, m2h_stream stream);
+int m2h_rewards_from_stats(const float* next_stats, const float* cur_stats, const float* not_done, float* rewards, int N, int L,
+                           int quality_improvement, float mult, m2h_stream stream);
+
+/* Minibatch gather of the recurrent generators (common/rollout_storage.py:182-298, 392-457): for a storage tensor
+ * src [T][N][row] and an env permutation perm[Nsel] (int64, device), dst[t][j][:] = src[t][perm[j]][:]; row_bytes % 4 == 0.
+ * The result viewed as [T*Nsel][row] is the reference's stacked + flattened minibatch. */
+int m2h_gather_envs(const void* src, const long long* perm, void* dst, int T, int N, int Nsel, size_t row_bytes, m2h_stream stream);
+
+/* STFT_L2_distance (common/eval_metrics.py:306-366) for nch channels: out[e] = sum_ch mean_{re/im,F,T} of the squared
+ * distance between (gt_mag, pred_mag) x (cos, sin)(gt_phase); pred_mag = pred (use_mix 0) or (exp(mix)-1)*pred (use_mix 1).
+ * pred/mix: [N][L][Cp]; gt_comps: [N][L][Cg] = per channel (mag, phase). */
+int m2h_stft_l2(const float* mix, const float* pred, int Cp, const float* gt_comps, int Cg, int nch, int use_mix, float* out, int N,
+                int L, m2h_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,17 +41,17 @@ __global__ __launch_bounds__(256) void sep_slice_input_kernel(const float* __res
   }
 }
 
-// [Co][Ci][KH][KW] -> [Co][KH][KW][ci_used]
-__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int KH, int KW, int cu) {
-  const size_t total = (size_t)Co * KH * KW * cu;
+// [Co][Ci][KH][KW] -> [Co][KH][KW][cout]; channels >= cu are zero
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int KH, int KW, int cu, int cout) {
+  const size_t total = (size_t)Co * KH * KW * cout;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % cu);
-    size_t r = i / cu;
+    const int ci = (int)(i % cout);
+    size_t r = i / cout;
     const int kw = (int)(r % KW);
     r /= KW;
     const int kh = (int)(r % KH);
     const int co = (int)(r / KH);
-    wp[i] = w[(((size_t)co * Ci + ci) * KH + kh) * KW + kw];
+    wp[i] = ci < cu ? w[(((size_t)co * Ci + ci) * KH + kh) * KW + kw] : 0.f;
   }
 }
 
@@ -121,12 +121,16 @@ int m2h_sep_slice_input(const float* mix, const float* masks, float* out, int B,
   return launch_status("sep_slice_input");
 }
 
-int m2h_pack_conv_weight(const float* w, float* wp, int Co, int Ci, int KH, int KW, int ci_used, m2h_stream stream) {
+int m2h_pack_conv_weight_ex(const float* w, float* wp, int Co, int Ci, int KH, int KW, int ci_used, int ci_out, m2h_stream stream) {
   M2H_REQUIRE(w != nullptr && wp != nullptr, "pack_conv_weight: null pointer");
-  M2H_REQUIRE(Co > 0 && Ci > 0 && KH > 0 && KW > 0 && ci_used > 0 && ci_used <= Ci, "pack_conv_weight: bad sizes");
-  const size_t total = (size_t)Co * KH * KW * ci_used;
-  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w, wp, Co, Ci, KH, KW, ci_used);
+  M2H_REQUIRE(Co > 0 && Ci > 0 && KH > 0 && KW > 0 && ci_used > 0 && ci_used <= Ci && ci_out >= ci_used, "pack_conv_weight: bad sizes");
+  const size_t total = (size_t)Co * KH * KW * ci_out;
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w, wp, Co, Ci, KH, KW, ci_used, ci_out);
   return launch_status("pack_conv_weight");
+}
+
+int m2h_pack_conv_weight(const float* w, float* wp, int Co, int Ci, int KH, int KW, int ci_used, m2h_stream stream) {
+  return m2h_pack_conv_weight_ex(w, wp, Co, Ci, KH, KW, ci_used, ci_used, stream);
 }
 
 int m2h_pack_convT_weight(const float* w, float* wp, int Ci, int Co, m2h_stream stream) {

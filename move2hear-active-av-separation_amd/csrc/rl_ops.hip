@@ -1,0 +1,490 @@
+// HBM-bound / wavefront-reduction kernels of the RL path (gfx950), fp32.
+//   slice_concat_input : AcousticMem / AudioCNN input glue          (memory_nets.py:40-59, audio_cnn.py:117-133)
+//   visual_input       : rgb/255 (+depth) -> NHWC padded to 4 ch     (visual_cnn.py:135-150)
+//   gru_gates          : GRU cell pointwise part, hidden mask fused  (rnn_state_encoder.py:74-84)
+//   policy_heads       : actor/critic linear heads + categorical     (common/utils.py:16-50, rl/ppo/policy.py:15-23)
+//   gae_returns        : GAE / discounted-return scan                (common/rollout_storage.py:155-180)
+//   normalize_adv      : advantage normalisation                     (rl/ppo/ppo.py:75-80; ddppo_utils.py:168-190)
+//   ppo_loss_fwd       : clipped surrogate + clipped value loss      (rl/ppo/ppo.py:125-157)
+//   sep_rewards        : -mse/mean(gt^2) per env (+variants)         (common/env_utils.py:690-713)
+//   stft_l2            : STFT-L2 distance per env                    (common/eval_metrics.py:306-366)
+#include "m2h_internal.h"
+
+namespace m2h {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum (blockDim = 256); result valid in every thread.
+__device__ __forceinline__ float block_sum(float v, float* sh /* >= 4 floats */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// out[b][h][t][c*16+s] = f(virtual[b][s*Hs+h][t][c]),  virtual channel c < Ca -> a[..][c] (times mul[..][c] inside op 1),
+// else b[..][c-Ca] * bscale[batch].   op: 0 none | 1 log1p(max(0, mul*(exp(a)-1))) | 2 log1p(max(0, x))
+__global__ __launch_bounds__(256) void slice_concat_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ bsrc, int Cb,
+                                                           const float* __restrict__ mul, const float* __restrict__ bscale, int op,
+                                                           float* __restrict__ out, int B, int F, int T) {
+  const int C = Ca + Cb;
+  const int Hs = F >> 4;
+  const int CG = (16 * C) >> 2;
+  const size_t total = (size_t)B * Hs * T * CG;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % CG);
+    size_t r = i / CG;
+    const int t = (int)(r % T);
+    r /= T;
+    const int h = (int)(r % Hs);
+    const int b = (int)(r / Hs);
+    const int n0 = cg * 4;
+    const int c = n0 >> 4, s0 = n0 & 15;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t pix = ((size_t)b * F + (size_t)(s0 + j) * Hs + h) * T + t;
+      float x;
+      if (c < Ca) {
+        x = a[pix * Ca + c];
+        if (op == 1) x = log1pf(fmaxf(mul[pix * Ca + c] * (expf(x) - 1.f), 0.f));
+      } else {
+        x = bsrc[pix * Cb + (c - Ca)];
+        if (bscale != nullptr) x *= bscale[b];
+      }
+      if (op == 2) x = log1pf(fmaxf(x, 0.f));
+      v[j] = x;
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+  }
+}
+
+// rgb [B,H,W,3] (0..255) (+ depth [B,H,W,1]) -> out [B,H,W,4] = (r/255, g/255, b/255, depth or 0)
+__global__ __launch_bounds__(256) void visual_input_kernel(const float* __restrict__ rgb, const float* __restrict__ depth,
+                                                           float* __restrict__ out, size_t npix) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 v;
+    v[0] = rgb[i * 3 + 0] / 255.0f;
+    v[1] = rgb[i * 3 + 1] / 255.0f;
+    v[2] = rgb[i * 3 + 2] / 255.0f;
+    v[3] = depth != nullptr ? depth[i] : 0.f;
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// GRU cell pointwise part.  gi = x W_ih^T + b_ih  [M,3H];  gh_raw = h W_hh^T (no bias, UNMASKED h)  [M,3H]
+// mask m[row] in {0,1}: (h*m) W^T = m * (h W^T), so the hidden mask is applied here.  Gate order r,z,n.
+__global__ __launch_bounds__(256) void gru_gates_kernel(const float* __restrict__ gi, const float* __restrict__ gh_raw,
+                                                        const float* __restrict__ bhh, const float* __restrict__ hprev,
+                                                        const float* __restrict__ mask, float* __restrict__ hout, int M, int H) {
+  const int total = M * H;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int row = i / H, j = i - row * H;
+    const float m = mask != nullptr ? mask[row] : 1.f;
+    const float* gir = gi + (size_t)row * 3 * H;
+    const float* ghr = gh_raw + (size_t)row * 3 * H;
+    const float r = sigmoidf_(gir[j] + (m * ghr[j] + bhh[j]));
+    const float z = sigmoidf_(gir[H + j] + (m * ghr[H + j] + bhh[H + j]));
+    const float n = tanhf(gir[2 * H + j] + r * (m * ghr[2 * H + j] + bhh[2 * H + j]));
+    const float hp = m * hprev[i];
+    hout[i] = (1.f - z) * n + z * hp;
+  }
+}
+
+// One wave per row: logits = feats Wa^T + ba (A <= 8 actions), value = feats Wc^T + bc; log-softmax, softmax, entropy,
+// optional log-prob of a given action.  H multiple of 64.
+__global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restrict__ feats, const float* __restrict__ Wa,
+                                                           const float* __restrict__ ba, const float* __restrict__ Wc,
+                                                           const float* __restrict__ bc, const long long* __restrict__ actions,
+                                                           float* __restrict__ value, float* __restrict__ logp_all,
+                                                           float* __restrict__ probs, float* __restrict__ entropy,
+                                                           float* __restrict__ logp_act, int M, int H, int A) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float acc[9];
+#pragma unroll
+  for (int a = 0; a < 9; ++a) acc[a] = 0.f;
+  const float* f = feats + (size_t)row * H;
+  for (int k = lane; k < H; k += 64) {
+    const float x = f[k];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+      if (a < A) acc[a] += x * Wa[a * H + k];
+    acc[8] += x * Wc[k];
+  }
+#pragma unroll
+  for (int a = 0; a < 9; ++a) acc[a] = wave_sum(acc[a]);
+  if (lane == 0) {
+    float mx = -INFINITY;
+    for (int a = 0; a < A; ++a) {
+      acc[a] += ba[a];
+      mx = fmaxf(mx, acc[a]);
+    }
+    float se = 0.f;
+    for (int a = 0; a < A; ++a) se += expf(acc[a] - mx);
+    const float lse = mx + logf(se);
+    float ent = 0.f;
+    for (int a = 0; a < A; ++a) {
+      const float lp = acc[a] - lse;
+      const float p = expf(lp);
+      logp_all[row * A + a] = lp;
+      probs[row * A + a] = p;
+      ent -= lp * p;
+    }
+    value[row] = acc[8] + bc[0];
+    entropy[row] = ent;
+    if (actions != nullptr && logp_act != nullptr) logp_act[row] = logp_all[row * A + (int)actions[row]];
+  }
+}
+
+__global__ void gather_logp_kernel(const float* __restrict__ logp_all, const long long* __restrict__ actions,
+                                   float* __restrict__ out, int M, int A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M) out[i] = logp_all[i * A + (int)actions[i]];
+}
+
+// GAE / discounted-return scan: one thread per env, T steps backwards.  rewards [T,N], value_preds [T+1,N] (row T is
+// overwritten with next_value when use_gae), masks [T+1,N], returns [T+1,N].
+__global__ void gae_returns_kernel(const float* __restrict__ rewards, float* __restrict__ value_preds, const float* __restrict__ masks,
+                                   const float* __restrict__ next_value, float* __restrict__ returns, int T, int N, int use_gae,
+                                   float gamma, float tau) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  if (use_gae) {
+    value_preds[T * N + e] = next_value[e];
+    float gae = 0.f;
+    for (int s = T - 1; s >= 0; --s) {
+      const float m = masks[(s + 1) * N + e];
+      const float delta = rewards[s * N + e] + gamma * value_preds[(s + 1) * N + e] * m - value_preds[s * N + e];
+      gae = delta + gamma * tau * m * gae;
+      returns[s * N + e] = gae + value_preds[s * N + e];
+    }
+  } else {
+    returns[T * N + e] = next_value[e];
+    for (int s = T - 1; s >= 0; --s)
+      returns[s * N + e] = returns[(s + 1) * N + e] * gamma * masks[(s + 1) * N + e] + rewards[s * N + e];
+  }
+}
+
+// adv = returns[:-1] - value_preds[:-1]; stats[0] = sum(adv), stats[1] = sum((adv-mean)^2) for the local n elements.
+// mode 0: adv only.  mode 1 (local): (adv-mean)/(std_unbiased+eps).  mode 2 (distributed step A): write raw adv + local mean
+// to stats[0];  the host all-reduces and calls normalize_apply.  Single block (n = T*N is small).
+__global__ __launch_bounds__(256) void advantages_kernel(const float* __restrict__ returns, const float* __restrict__ value_preds,
+                                                         float* __restrict__ adv, float* __restrict__ stats, int n, int mode, float eps) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float a = returns[i] - value_preds[i];
+    adv[i] = a;
+    s += a;
+  }
+  const float mean = block_sum(s, sh) / (float)n;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = adv[i] - mean;
+    q += d * d;
+  }
+  const float ss = block_sum(q, sh);
+  if (threadIdx.x == 0 && stats != nullptr) {
+    stats[0] = mean;
+    stats[1] = ss / (float)n;  // biased variance around the LOCAL mean (mode 2 recomputes around the global mean)
+  }
+  if (mode == 1) {
+    const float sd = sqrtf(ss / (float)(n - 1));
+    for (int i = threadIdx.x; i < n; i += 256) adv[i] = (adv[i] - mean) / (sd + eps);
+  }
+}
+
+// distributed step B: sqdiff[0] = mean((adv - gmean)^2) locally;  step C: adv = (adv - gmean)/(sqrt(gvar)+eps)
+__global__ __launch_bounds__(256) void adv_sqdiff_kernel(const float* __restrict__ adv, const float* __restrict__ gmean,
+                                                         float* __restrict__ out, int n) {
+  __shared__ float sh[4];
+  const float m = gmean[0];
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = adv[i] - m;
+    q += d * d;
+  }
+  const float ss = block_sum(q, sh);
+  if (threadIdx.x == 0) out[0] = ss / (float)n;
+}
+
+__global__ void adv_apply_kernel(float* __restrict__ adv, const float* __restrict__ gmean, const float* __restrict__ gvar, int n, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) adv[i] = (adv[i] - gmean[0]) / (sqrtf(gvar[0]) + eps);
+}
+
+// PPO losses, forward + analytic gradients w.r.t. values, action_log_probs (and the entropy coefficient is applied by the
+// caller).  out[0] = value_loss, out[1] = action_loss.  Single block.
+__global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__ values, const float* __restrict__ logp,
+                                                       const float* __restrict__ old_values, const float* __restrict__ returns,
+                                                       const float* __restrict__ adv, const float* __restrict__ old_logp,
+                                                       float clip, int use_clipped_value_loss, float* __restrict__ out,
+                                                       float* __restrict__ g_values, float* __restrict__ g_logp,
+                                                       float value_loss_coef, int n) {
+  __shared__ float sh[4];
+  float sv = 0.f, sa = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float ratio = expf(logp[i] - old_logp[i]);
+    const float a = adv[i];
+    const float s1 = ratio * a;
+    const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+    const float s2 = rc * a;
+    sa += fminf(s1, s2);
+    // d(-min(s1,s2))/dlogp: torch.min picks s1 when s1 <= s2 (ties -> first), clamp passes gradient inside [1-c, 1+c]
+    float gl;
+    if (s1 <= s2) gl = -a * ratio;
+    else gl = (ratio >= 1.f - clip && ratio <= 1.f + clip) ? -a * ratio : 0.f;
+    const float v = values[i], ov = old_values[i], R = returns[i];
+    float vl, gv;
+    if (use_clipped_value_loss) {
+      const float dv = v - ov;
+      const float vc = ov + fminf(fmaxf(dv, -clip), clip);
+      const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+      if (l1 >= l2) {  // torch.max picks the first on ties
+        vl = l1;
+        gv = 2.f * (v - R);
+      } else {
+        vl = l2;
+        gv = (dv >= -clip && dv <= clip) ? 2.f * (vc - R) : 0.f;
+      }
+    } else {
+      vl = (R - v) * (R - v);
+      gv = 2.f * (v - R);
+    }
+    sv += vl;
+    if (g_logp != nullptr) g_logp[i] = gl / (float)n;
+    if (g_values != nullptr) g_values[i] = 0.5f * gv / (float)n * value_loss_coef;
+  }
+  const float tv = block_sum(sv, sh);
+  const float ta = block_sum(sa, sh);
+  if (threadIdx.x == 0) {
+    out[0] = 0.5f * tv / (float)n;
+    out[1] = -ta / (float)n;
+  }
+}
+
+// Per-env reductions over L = F*T*C elements (one block per env):
+//   stats[e][0] = sum (p-g)^2, stats[e][1] = sum g^2  -> reward_util = -(s0/L)/(s1/L)
+__global__ __launch_bounds__(256) void sq_stats_kernel(const float* __restrict__ pred, const float* __restrict__ gt_comps, int gt_stride,
+                                                       int gt_off, float* __restrict__ stats, int L) {
+  __shared__ float sh[4];
+  const int e = blockIdx.x;
+  const float* p = pred + (size_t)e * L;
+  const float* g = gt_comps + (size_t)e * L * gt_stride + gt_off;
+  float s0 = 0.f, s1 = 0.f;
+  for (int i = threadIdx.x; i < L; i += 256) {
+    const float gv = g[(size_t)i * gt_stride];
+    const float d = p[i] - gv;
+    s0 += d * d;
+    s1 += gv * gv;
+  }
+  const float t0 = block_sum(s0, sh);
+  const float t1 = block_sum(s1, sh);
+  if (threadIdx.x == 0) {
+    stats[e * 2 + 0] = t0;
+    stats[e * 2 + 1] = t1;
+  }
+}
+
+// rewards[e] per override_rewards:  done -> 0;  else r = -(next0/L)/(next1/L);  quality_improvement: r -= -(cur0/L)/(cur1/L);
+// otherwise r *= mult.
+__global__ void rewards_from_stats_kernel(const float* __restrict__ next_stats, const float* __restrict__ cur_stats,
+                                          const float* __restrict__ not_done, float* __restrict__ rewards, int N, int L, int quality,
+                                          float mult) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  float r = 0.f;
+  if (not_done[e] != 0.f) {
+    r = -(next_stats[2 * e] / (float)L) / (next_stats[2 * e + 1] / (float)L);
+    if (quality) r -= -(cur_stats[2 * e] / (float)L) / (cur_stats[2 * e + 1] / (float)L);
+    else r *= mult;
+  }
+  rewards[e] = r;
+}
+
+// STFT-L2 per env (one block per env): both sides use the GT phase, so with m_g, m_p the magnitudes:
+//   mean over (re, im, F, T) of (m_g cos - m_p cos)^2, (m_g sin - m_p sin)^2, computed term by term as the reference does.
+// pred magnitude p = (exp(mix)-1)*mask for the binaural channels (use_mix=1) or the tensor itself (mono).
+__global__ __launch_bounds__(256) void stft_l2_kernel(const float* __restrict__ mix, const float* __restrict__ pred, int Cp,
+                                                      const float* __restrict__ gt_comps, int Cg, int nch, int use_mix,
+                                                      float* __restrict__ out, int L /* F*T */) {
+  __shared__ float sh[4];
+  const int e = blockIdx.x;
+  float tot = 0.f;
+  for (int ch = 0; ch < nch; ++ch) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < L; i += 256) {
+      const size_t pix = (size_t)e * L + i;
+      const float gm = gt_comps[pix * Cg + 2 * ch];
+      const float ph = gt_comps[pix * Cg + 2 * ch + 1];
+      float pm = pred[pix * Cp + ch];
+      if (use_mix) pm = (expf(mix[pix * Cp + ch]) - 1.f) * pm;
+      const float c = cosf(ph), sn = sinf(ph);
+      const float dr = gm * c - pm * c, di = gm * sn - pm * sn;
+      s += dr * dr + di * di;
+    }
+    tot += block_sum(s, sh) / (float)(2 * L);
+  }
+  if (threadIdx.x == 0) out[e] = tot;
+}
+
+// Minibatch gather of the recurrent generators (common/rollout_storage.py:182-298,392-457):
+// dst[t][j][:] = src[t][perm[j]][:]  for t < T, j < Nsel; rows of L elements (bytes, copied as 16-byte or 4-byte words).
+__global__ __launch_bounds__(256) void gather_envs_kernel(const uint32_t* __restrict__ src, const long long* __restrict__ perm,
+                                                          uint32_t* __restrict__ dst, int T, int N, int Nsel, size_t Lw) {
+  const size_t total = (size_t)T * Nsel * Lw;
+  if ((Lw & 3) == 0) {
+    const size_t L4 = Lw >> 2;
+    const size_t tot4 = (size_t)T * Nsel * L4;
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot4; i += (size_t)gridDim.x * blockDim.x) {
+      const size_t l = i % L4;
+      const size_t r = i / L4;
+      const int j = (int)(r % Nsel);
+      const int t = (int)(r / Nsel);
+      d4[i] = s4[((size_t)t * N + (size_t)perm[j]) * L4 + l];
+    }
+    return;
+  }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t l = i % Lw;
+    const size_t r = i / Lw;
+    const int j = (int)(r % Nsel);
+    const int t = (int)(r / Nsel);
+    dst[i] = src[((size_t)t * N + (size_t)perm[j]) * Lw + l];
+  }
+}
+
+static inline unsigned grid_for(size_t total, unsigned cap = 4096) {
+  size_t g = (total + 255) / 256;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace m2h
+
+using namespace m2h;
+
+extern "C" {
+
+int m2h_slice_concat_input(const float* a, int Ca, const float* b, int Cb, const float* mul, const float* bscale, int op,
+                           float* out, int B, int F, int T, m2h_stream stream) {
+  M2H_REQUIRE(a != nullptr && out != nullptr && Ca > 0 && Cb >= 0, "slice_concat_input: bad arguments");
+  M2H_REQUIRE((Cb == 0) == (b == nullptr), "slice_concat_input: b/Cb mismatch");
+  M2H_REQUIRE(op >= 0 && op <= 2 && (op != 1 || mul != nullptr), "slice_concat_input: bad op");
+  M2H_REQUIRE(B > 0 && F > 0 && T > 0 && F % 16 == 0, "slice_concat_input: bad sizes (F %% 16)");
+  const size_t total = (size_t)B * (F / 16) * T * (16 * (Ca + Cb) / 4);
+  hipLaunchKernelGGL(slice_concat_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), a, Ca, b, Cb, mul, bscale, op, out, B, F, T);
+  return launch_status("slice_concat_input");
+}
+
+int m2h_visual_input(const float* rgb, const float* depth, float* out, int B, int H, int W, m2h_stream stream) {
+  M2H_REQUIRE(rgb != nullptr && out != nullptr && B > 0 && H > 0 && W > 0, "visual_input: bad arguments");
+  const size_t npix = (size_t)B * H * W;
+  hipLaunchKernelGGL(visual_input_kernel, dim3(grid_for(npix)), dim3(256), 0, as_stream(stream), rgb, depth, out, npix);
+  return launch_status("visual_input");
+}
+
+int m2h_gru_gates(const float* gi, const float* gh_raw, const float* bhh, const float* hprev, const float* mask, float* hout,
+                  int M, int H, m2h_stream stream) {
+  M2H_REQUIRE(gi && gh_raw && bhh && hprev && hout && M > 0 && H > 0, "gru_gates: bad arguments");
+  hipLaunchKernelGGL(gru_gates_kernel, dim3(grid_for((size_t)M * H)), dim3(256), 0, as_stream(stream), gi, gh_raw, bhh, hprev, mask, hout, M, H);
+  return launch_status("gru_gates");
+}
+
+int m2h_policy_heads(const float* feats, const float* Wa, const float* ba, const float* Wc, const float* bc,
+                     const long long* actions, float* value, float* logp_all, float* probs, float* entropy, float* logp_act,
+                     int M, int H, int A, m2h_stream stream) {
+  M2H_REQUIRE(feats && Wa && ba && Wc && bc && value && logp_all && probs && entropy, "policy_heads: null pointer");
+  M2H_REQUIRE(M > 0 && H > 0 && H % 64 == 0 && A > 0 && A <= 8, "policy_heads: bad sizes (H %% 64, A <= 8)");
+  hipLaunchKernelGGL(policy_heads_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), feats, Wa, ba, Wc, bc, actions, value,
+                     logp_all, probs, entropy, logp_act, M, H, A);
+  return launch_status("policy_heads");
+}
+
+int m2h_gather_logp(const float* logp_all, const long long* actions, float* out, int M, int A, m2h_stream stream) {
+  M2H_REQUIRE(logp_all && actions && out && M > 0 && A > 0, "gather_logp: bad arguments");
+  hipLaunchKernelGGL(gather_logp_kernel, dim3((M + 255) / 256), dim3(256), 0, as_stream(stream), logp_all, actions, out, M, A);
+  return launch_status("gather_logp");
+}
+
+int m2h_gae_returns(const float* rewards, float* value_preds, const float* masks, const float* next_value, float* returns, int T,
+                    int N, int use_gae, float gamma, float tau, m2h_stream stream) {
+  M2H_REQUIRE(rewards && value_preds && masks && next_value && returns && T > 0 && N > 0, "gae_returns: bad arguments");
+  hipLaunchKernelGGL(gae_returns_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), rewards, value_preds, masks, next_value,
+                     returns, T, N, use_gae, gamma, tau);
+  return launch_status("gae_returns");
+}
+
+int m2h_advantages(const float* returns, const float* value_preds, float* adv, float* stats, int n, int mode, float eps,
+                   m2h_stream stream) {
+  M2H_REQUIRE(returns && value_preds && adv && n > 1 && mode >= 0 && mode <= 2, "advantages: bad arguments");
+  hipLaunchKernelGGL(advantages_kernel, dim3(1), dim3(256), 0, as_stream(stream), returns, value_preds, adv, stats, n, mode, eps);
+  return launch_status("advantages");
+}
+
+int m2h_adv_sqdiff(const float* adv, const float* gmean, float* out, int n, m2h_stream stream) {
+  M2H_REQUIRE(adv && gmean && out && n > 0, "adv_sqdiff: bad arguments");
+  hipLaunchKernelGGL(adv_sqdiff_kernel, dim3(1), dim3(256), 0, as_stream(stream), adv, gmean, out, n);
+  return launch_status("adv_sqdiff");
+}
+
+int m2h_adv_apply(float* adv, const float* gmean, const float* gvar, int n, float eps, m2h_stream stream) {
+  M2H_REQUIRE(adv && gmean && gvar && n > 0, "adv_apply: bad arguments");
+  hipLaunchKernelGGL(adv_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), adv, gmean, gvar, n, eps);
+  return launch_status("adv_apply");
+}
+
+int m2h_ppo_loss(const float* values, const float* logp, const float* old_values, const float* returns, const float* adv,
+                 const float* old_logp, float clip, int use_clipped_value_loss, float value_loss_coef, float* out, float* g_values,
+                 float* g_logp, int n, m2h_stream stream) {
+  M2H_REQUIRE(values && logp && old_values && returns && adv && old_logp && out && n > 0, "ppo_loss: bad arguments");
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), values, logp, old_values, returns, adv, old_logp, clip,
+                     use_clipped_value_loss, out, g_values, g_logp, value_loss_coef, n);
+  return launch_status("ppo_loss");
+}
+
+int m2h_sq_stats(const float* pred, const float* gt_comps, int gt_stride, int gt_off, float* stats, int N, int L, m2h_stream stream) {
+  M2H_REQUIRE(pred && gt_comps && stats && N > 0 && L > 0 && gt_stride > 0 && gt_off >= 0 && gt_off < gt_stride, "sq_stats: bad arguments");
+  hipLaunchKernelGGL(sq_stats_kernel, dim3(N), dim3(256), 0, as_stream(stream), pred, gt_comps, gt_stride, gt_off, stats, L);
+  return launch_status("sq_stats");
+}
+
+int m2h_rewards_from_stats(const float* next_stats, const float* cur_stats, const float* not_done, float* rewards, int N, int L,
+                           int quality_improvement, float mult, m2h_stream stream) {
+  M2H_REQUIRE(next_stats && not_done && rewards && N > 0 && L > 0 && (!quality_improvement || cur_stats), "rewards_from_stats: bad arguments");
+  hipLaunchKernelGGL(rewards_from_stats_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), next_stats, cur_stats, not_done,
+                     rewards, N, L, quality_improvement, mult);
+  return launch_status("rewards_from_stats");
+}
+
+int m2h_gather_envs(const void* src, const long long* perm, void* dst, int T, int N, int Nsel, size_t row_bytes, m2h_stream stream) {
+  M2H_REQUIRE(src && perm && dst && T > 0 && N > 0 && Nsel > 0 && row_bytes > 0 && row_bytes % 4 == 0, "gather_envs: bad arguments (row_bytes %% 4)");
+  const size_t Lw = row_bytes / 4;
+  hipLaunchKernelGGL(gather_envs_kernel, dim3(grid_for((size_t)T * Nsel * ((Lw & 3) ? Lw : Lw / 4), 8192)), dim3(256), 0, as_stream(stream),
+                     static_cast<const uint32_t*>(src), perm, static_cast<uint32_t*>(dst), T, N, Nsel, Lw);
+  return launch_status("gather_envs");
+}
+
+int m2h_stft_l2(const float* mix, const float* pred, int Cp, const float* gt_comps, int Cg, int nch, int use_mix, float* out, int N,
+                int L, m2h_stream stream) {
+  M2H_REQUIRE(pred && gt_comps && out && N > 0 && L > 0 && nch > 0 && Cp >= nch && Cg >= 2 * nch && (!use_mix || mix), "stft_l2: bad arguments");
+  hipLaunchKernelGGL(stft_l2_kernel, dim3(N), dim3(256), 0, as_stream(stream), mix, pred, Cp, gt_comps, Cg, nch, use_mix, out, L);
+  return launch_status("stft_l2");
+}
+
+}  // extern "C"

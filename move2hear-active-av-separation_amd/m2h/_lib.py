@@ -15,7 +15,7 @@ _REPO_ROOT = os.path.dirname(_PKG_ROOT)
 CSRC = os.path.join(_PKG_ROOT, "csrc")
 INCLUDE = os.path.join(_REPO_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libm2h.so")
-SOURCES = ["conv_igemm.hip", "layout.hip", "api.hip"]
+SOURCES = ["conv_igemm.hip", "layout.hip", "rl_ops.hip", "api.hip"]
 
 _lock = threading.Lock()
 _lib = None
@@ -90,6 +90,21 @@ SIGNATURES = {
     "m2h_unet_down_workspace_bytes": [_I, _I, _I, _I, _I],
     "m2h_unet_up_workspace_bytes": [_I, _I, _I, _I, _I, _I],
     "m2h_unet_head_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "m2h_pack_conv_weight_ex": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "m2h_slice_concat_input": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],
+    "m2h_visual_input": [_P, _P, _P, _I, _I, _I, _P],
+    "m2h_gru_gates": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "m2h_policy_heads": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "m2h_gather_logp": [_P, _P, _P, _I, _I, _P],
+    "m2h_gae_returns": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P],
+    "m2h_advantages": [_P, _P, _P, _P, _I, _I, _F, _P],
+    "m2h_adv_sqdiff": [_P, _P, _P, _I, _P],
+    "m2h_adv_apply": [_P, _P, _P, _I, _F, _P],
+    "m2h_ppo_loss": [_P, _P, _P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _I, _P],
+    "m2h_sq_stats": [_P, _P, _I, _I, _P, _I, _I, _P],
+    "m2h_rewards_from_stats": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "m2h_gather_envs": [_P, _P, _P, _I, _I, _I, _Z, _P],
+    "m2h_stft_l2": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
 }
 
 

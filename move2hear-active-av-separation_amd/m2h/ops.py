@@ -226,3 +226,252 @@ def conv_igemm_f32(**kw):
     lib = _lib.load()
     with torch.cuda.device(dev_t.device):
         _lib.check(lib.m2h_conv_igemm_f32(ctypes.byref(a), _stream(dev_t)), "m2h_conv_igemm_f32")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# generic conv / linear on the igemm engine, and the RL-path ops
+# ----------------------------------------------------------------------------------------------------------------
+def conv2d_nhwc(x, wp, n_out, kh, kw, stride=1, pad=0, bias=None, scale=None, slope=1.0, x2=None, deslice=False, name="conv2d"):
+    """Conv2d over NHWC activations through m2h_conv_igemm_f32.  x [B,H,W,C0] (+ x2 [B,H,W,C1] concatenated on channels),
+    wp packed [n_out, kh*kw*(C0+C1)], bias -> epilogue shift, slope: 1 none / 0 ReLU / 0.2 LeakyReLU.
+    Returns NHWC [B,Ho,Wo,n_out], or the de-sliced BHWC [B,16*Ho,Wo,n_out/16] when deslice."""
+    _chk(x, name + "(x)")
+    _chk(x2, name + "(x2)")
+    for t in (wp, bias, scale):
+        _chk(t, name)
+    B, H, W, C0 = x.shape
+    C1 = x2.shape[3] if x2 is not None else 0
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    if wp.numel() != n_out * kh * kw * (C0 + C1):
+        raise RuntimeError("m2h.%s: packed weight has %d elements, expected %d" % (name, wp.numel(), n_out * kh * kw * (C0 + C1)))
+    if deslice:
+        out = torch.empty((B, 16 * Ho, Wo, n_out // 16), device=x.device, dtype=torch.float32)
+    else:
+        out = torch.empty((B, Ho, Wo, n_out), device=x.device, dtype=torch.float32)
+    a = _lib.ConvArgs()
+    a.src0, a.src1, a.C0, a.C1 = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), C0, C1
+    a.B, a.Hi, a.Wi, a.Hq, a.Wq = B, H, W, Ho, Wo
+    a.stride, a.nth, a.ntw, a.mulh, a.offh, a.mulw, a.offw = stride, kh, kw, 1, -pad, 1, -pad
+    a.conv_transpose, a.wp, a.N = 0, wp.data_ptr(), n_out
+    a.scale = scale.data_ptr() if scale is not None else None
+    a.shift = bias.data_ptr() if bias is not None else None
+    a.slope = float(slope)
+    a.cls_table, a.cls_val = None, None
+    a.dst, a.Ho, a.Wo, a.os, a.ph, a.pw, a.ldc = out.data_ptr(), Ho, Wo, 1, 0, 0, n_out
+    a.out_mode = OUT_DESLICE if deslice else OUT_NHWC
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        ws, wsb = _workspace(lib.m2h_conv_igemm_workspace_bytes(ctypes.byref(a)), x.device)
+        a.workspace, a.workspace_bytes = (ws.data_ptr() if ws is not None else None), wsb
+        M = B * Ho * Wo
+        meta = {"kernel": igemm_config(n_out), "M": M, "N": n_out, "K": kh * kw * (C0 + C1), "flops": 2.0 * M * n_out * kh * kw * (C0 + C1),
+                "bytes": 4.0 * (x.numel() + (x2.numel() if x2 is not None else 0) + out.numel() + wp.numel())}
+        _timed(name, meta, x.device, lambda: _lib.check(lib.m2h_conv_igemm_f32(ctypes.byref(a), _stream(x)), "m2h_conv_igemm_f32"))
+    return out
+
+
+def linear(x, w, bias=None, slope=1.0, name="linear"):
+    """y = act(x W^T + b): x [M,K], w [N,K] (torch Linear layout == packed [N][K])."""
+    M, K = x.shape
+    y = conv2d_nhwc(x.reshape(M, 1, 1, K), w, w.shape[0], 1, 1, bias=bias, slope=slope, name=name)
+    return y.reshape(M, w.shape[0])
+
+
+def pack_conv_weight_ex(w4d, ci_used, ci_out):
+    _chk(w4d, "pack_conv_weight_ex")
+    Co, Ci, KH, KW = w4d.shape
+    wp = torch.empty((Co, KH * KW * ci_out), device=w4d.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(w4d.device):
+        _lib.check(lib.m2h_pack_conv_weight_ex(_ptr(w4d), _ptr(wp), Co, Ci, KH, KW, ci_used, ci_out, _stream(w4d)), "m2h_pack_conv_weight_ex")
+    return wp
+
+
+def slice_concat_input(a, b=None, mul=None, bscale=None, op=0):
+    """AcousticMem / AudioCNN input glue (m2h_slice_concat_input).  a [B,F,T,Ca], b [B,F,T,Cb] -> NHWC [B,F/16,T,16*(Ca+Cb)]."""
+    for t in (a, b, mul, bscale):
+        _chk(t, "slice_concat_input")
+    B, F, T, Ca = a.shape
+    Cb = b.shape[3] if b is not None else 0
+    if b is not None and b.shape[:3] != a.shape[:3]:
+        raise RuntimeError("m2h.slice_concat_input: a %s vs b %s" % (tuple(a.shape), tuple(b.shape)))
+    if mul is not None and mul.shape != a.shape:
+        raise RuntimeError("m2h.slice_concat_input: mul shape")
+    if bscale is not None and bscale.numel() != B:
+        raise RuntimeError("m2h.slice_concat_input: bscale size")
+    out = torch.empty((B, F // 16, T, 16 * (Ca + Cb)), device=a.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(a.device):
+        _timed("slice_concat_input", {"bytes": 4.0 * (2 * out.numel())}, a.device,
+               lambda: _lib.check(lib.m2h_slice_concat_input(_ptr(a), Ca, _ptr(b), Cb, _ptr(mul), _ptr(bscale), op, _ptr(out), B, F, T,
+                                                             _stream(a)), "m2h_slice_concat_input"))
+    return out
+
+
+def visual_input(rgb, depth=None):
+    _chk(rgb, "visual_input(rgb)")
+    _chk(depth, "visual_input(depth)")
+    B, H, W, C = rgb.shape
+    if C != 3:
+        raise RuntimeError("m2h.visual_input: rgb must have 3 channels")
+    out = torch.empty((B, H, W, 4), device=rgb.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(rgb.device):
+        _lib.check(lib.m2h_visual_input(_ptr(rgb), _ptr(depth), _ptr(out), B, H, W, _stream(rgb)), "m2h_visual_input")
+    return out
+
+
+def gru_gates(gi, gh_raw, bhh, hprev, mask=None):
+    for t in (gi, gh_raw, bhh, hprev, mask):
+        _chk(t, "gru_gates")
+    M, H = hprev.shape
+    if gi.shape != (M, 3 * H) or gh_raw.shape != (M, 3 * H) or bhh.numel() != 3 * H or (mask is not None and mask.numel() != M):
+        raise RuntimeError("m2h.gru_gates: shape mismatch")
+    hout = torch.empty_like(hprev)
+    lib = _lib.load()
+    with torch.cuda.device(gi.device):
+        _lib.check(lib.m2h_gru_gates(_ptr(gi), _ptr(gh_raw), _ptr(bhh), _ptr(hprev), _ptr(mask), _ptr(hout), M, H, _stream(gi)), "m2h_gru_gates")
+    return hout
+
+
+def policy_heads(feats, Wa, ba, Wc, bc, actions=None):
+    """-> value [M,1], logp_all [M,A], probs [M,A], entropy [M], logp_act [M,1] or None."""
+    for t in (feats, Wa, ba, Wc, bc):
+        _chk(t, "policy_heads")
+    _chk(actions, "policy_heads(actions)", torch.int64)
+    M, H = feats.shape
+    A = Wa.shape[0]
+    dev = feats.device
+    value = torch.empty((M, 1), device=dev)
+    logp_all = torch.empty((M, A), device=dev)
+    probs = torch.empty((M, A), device=dev)
+    ent = torch.empty((M,), device=dev)
+    logp_act = torch.empty((M, 1), device=dev) if actions is not None else None
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.m2h_policy_heads(_ptr(feats), _ptr(Wa), _ptr(ba), _ptr(Wc), _ptr(bc), _ptr(actions), _ptr(value), _ptr(logp_all),
+                                        _ptr(probs), _ptr(ent), _ptr(logp_act), M, H, A, _stream(feats)), "m2h_policy_heads")
+    return value, logp_all, probs, ent, logp_act
+
+
+def gather_logp(logp_all, actions):
+    _chk(logp_all, "gather_logp")
+    _chk(actions, "gather_logp(actions)", torch.int64)
+    M, A = logp_all.shape
+    out = torch.empty((M, 1), device=logp_all.device)
+    lib = _lib.load()
+    with torch.cuda.device(logp_all.device):
+        _lib.check(lib.m2h_gather_logp(_ptr(logp_all), _ptr(actions), _ptr(out), M, A, _stream(logp_all)), "m2h_gather_logp")
+    return out
+
+
+def gae_returns(rewards, value_preds, masks, next_value, returns, use_gae, gamma, tau):
+    """In place on value_preds[-1] and returns (RolloutStoragePol.compute_returns).  Shapes [T,N,1]/[T+1,N,1]/[N,1]."""
+    for t in (rewards, value_preds, masks, next_value, returns):
+        _chk(t, "gae_returns")
+    T, N = rewards.shape[0], rewards.shape[1]
+    lib = _lib.load()
+    with torch.cuda.device(rewards.device):
+        _lib.check(lib.m2h_gae_returns(_ptr(rewards), _ptr(value_preds), _ptr(masks), _ptr(next_value), _ptr(returns), T, N,
+                                       1 if use_gae else 0, float(gamma), float(tau), _stream(rewards)), "m2h_gae_returns")
+
+
+def advantages(returns, value_preds, mode, eps=1e-5):
+    """returns/value_preds [T+1,N,1] -> (adv [T,N,1], stats [2]); mode 0 raw, 1 local-normalised, 2 raw + local mean."""
+    _chk(returns, "advantages")
+    _chk(value_preds, "advantages")
+    T = returns.shape[0] - 1
+    n = T * returns.shape[1]
+    adv = torch.empty((T,) + tuple(returns.shape[1:]), device=returns.device)
+    stats = torch.empty(2, device=returns.device)
+    lib = _lib.load()
+    with torch.cuda.device(returns.device):
+        _lib.check(lib.m2h_advantages(_ptr(returns), _ptr(value_preds), _ptr(adv), _ptr(stats), n, mode, float(eps), _stream(returns)),
+                   "m2h_advantages")
+    return adv, stats
+
+
+def adv_sqdiff(adv, gmean):
+    out = torch.empty(1, device=adv.device)
+    lib = _lib.load()
+    with torch.cuda.device(adv.device):
+        _lib.check(lib.m2h_adv_sqdiff(_ptr(adv), _ptr(gmean), _ptr(out), adv.numel(), _stream(adv)), "m2h_adv_sqdiff")
+    return out
+
+
+def adv_apply(adv, gmean, gvar, eps=1e-5):
+    lib = _lib.load()
+    with torch.cuda.device(adv.device):
+        _lib.check(lib.m2h_adv_apply(_ptr(adv), _ptr(gmean), _ptr(gvar), adv.numel(), float(eps), _stream(adv)), "m2h_adv_apply")
+    return adv
+
+
+def ppo_loss(values, logp, old_values, returns, adv, old_logp, clip, value_loss_coef=1.0, use_clipped_value_loss=True, want_grads=False):
+    """-> (out[2] = (value_loss, action_loss), g_values, g_logp)."""
+    for t in (values, logp, old_values, returns, adv, old_logp):
+        _chk(t, "ppo_loss")
+    n = values.numel()
+    out = torch.empty(2, device=values.device)
+    gv = torch.empty_like(values) if want_grads else None
+    gl = torch.empty_like(logp) if want_grads else None
+    lib = _lib.load()
+    with torch.cuda.device(values.device):
+        _lib.check(lib.m2h_ppo_loss(_ptr(values), _ptr(logp), _ptr(old_values), _ptr(returns), _ptr(adv), _ptr(old_logp), float(clip),
+                                    1 if use_clipped_value_loss else 0, float(value_loss_coef), _ptr(out), _ptr(gv), _ptr(gl), n,
+                                    _stream(values)), "m2h_ppo_loss")
+    return out, gv, gl
+
+
+def sq_stats(pred, gt_comps, gt_off=0):
+    """Per-env (sum (pred-gt)^2, sum gt^2); pred [N,F,T,1], gt_comps [N,F,T,Cg] read at channel gt_off."""
+    _chk(pred, "sq_stats")
+    _chk(gt_comps, "sq_stats")
+    N = pred.shape[0]
+    L = pred.numel() // N
+    stats = torch.empty((N, 2), device=pred.device)
+    lib = _lib.load()
+    with torch.cuda.device(pred.device):
+        _lib.check(lib.m2h_sq_stats(_ptr(pred), _ptr(gt_comps), gt_comps.shape[-1], gt_off, _ptr(stats), N, L, _stream(pred)), "m2h_sq_stats")
+    return stats
+
+
+def rewards_from_stats(next_stats, cur_stats, not_done, L, quality_improvement, mult=10.0):
+    N = next_stats.shape[0]
+    rewards = torch.empty((N, 1), device=next_stats.device)
+    lib = _lib.load()
+    with torch.cuda.device(next_stats.device):
+        _lib.check(lib.m2h_rewards_from_stats(_ptr(next_stats), _ptr(cur_stats), _ptr(not_done), _ptr(rewards), N, L,
+                                              1 if quality_improvement else 0, float(mult), _stream(next_stats)), "m2h_rewards_from_stats")
+    return rewards
+
+
+def stft_l2(pred, gt_comps, nch, mix=None):
+    """STFT-L2 per env -> [N,1].  pred [N,F,T,Cp], gt_comps [N,F,T,Cg]; mix given => pred is a mask on exp(mix)-1."""
+    _chk(pred, "stft_l2")
+    _chk(gt_comps, "stft_l2")
+    _chk(mix, "stft_l2")
+    N = pred.shape[0]
+    L = pred.shape[1] * pred.shape[2]
+    out = torch.empty((N, 1), device=pred.device)
+    lib = _lib.load()
+    with torch.cuda.device(pred.device):
+        _lib.check(lib.m2h_stft_l2(_ptr(mix), _ptr(pred), pred.shape[3], _ptr(gt_comps), gt_comps.shape[3], nch, 1 if mix is not None else 0,
+                                   _ptr(out), N, L, _stream(pred)), "m2h_stft_l2")
+    return out
+
+
+def gather_envs(src, perm):
+    """src [T,N,...] , perm [Nsel] int64 (device) -> [T*Nsel, ...]  (recurrent_generator stack + flatten)."""
+    if not src.is_cuda or not src.is_contiguous():
+        raise RuntimeError("m2h.gather_envs: src must be a contiguous GPU tensor")
+    _chk(perm, "gather_envs(perm)", torch.int64)
+    T, N = src.shape[0], src.shape[1]
+    nsel = perm.numel()
+    row = src[0, 0].numel() * src.element_size()
+    dst = torch.empty((T * nsel,) + tuple(src.shape[2:]), device=src.device, dtype=src.dtype)
+    lib = _lib.load()
+    with torch.cuda.device(src.device):
+        _timed("gather_envs", {"bytes": 2.0 * dst.numel() * dst.element_size()}, src.device,
+               lambda: _lib.check(lib.m2h_gather_envs(_ptr(src), _ptr(perm), _ptr(dst), T, N, nsel, row, _stream(src)), "m2h_gather_envs"))
+    return dst

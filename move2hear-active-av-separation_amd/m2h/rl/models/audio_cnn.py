@@ -1,0 +1,103 @@
+"""Audio encoder on MI355X: drop-in for audio_separation/rl/models/audio_cnn.py (AudioCNN, :8-140).
+
+Same constructor / forward signature / state_dict keys (``cnn.{0,2,4}.{weight,bias}``, ``cnn.7.{weight,bias}``).
+The pre-op (:121-127), BHWC->slice glue (:129-133) run as one HBM-bound kernel; conv8x8s4, conv4x4s2, conv2x2s1 (+bias+ReLU)
+and the Linear(+ReLU) run on the MFMA implicit-GEMM engine; the NCHW flatten order of :131-132 is absorbed in the packed
+Linear weight.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ._common import PackedCache, check_inference
+
+
+class Flatten(nn.Module):
+    """Placeholder keeping the reference's nn.Sequential indices (common/utils.py:11-13); never executed."""
+
+    def forward(self, x):
+        return x.reshape(x.size(0), -1)
+
+
+def conv_output_dim(dimension, padding, dilation, kernel_size, stride):
+    return tuple(int(np.floor(((dimension[i] + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) / stride[i]) + 1))
+                 for i in range(len(dimension)))
+
+
+class AudioCNN(nn.Module):
+    def __init__(self, observation_space, output_size, encode_monoNmonoFromMem=False):
+        super().__init__()
+        self.encode_monoNmonoFromMem = encode_monoNmonoFromMem
+        self._slice_factor = 16
+        self._n_input_audio = 2 * self._slice_factor
+        self._cnn_layers_kernel_size = [(8, 8), (4, 4), (2, 2)]
+        self._cnn_layers_stride = [(4, 4), (2, 2), (1, 1)]
+        shp = observation_space.spaces["mixed_bin_audio_mag"].shape
+        cnn_dims = (shp[0] // 16, shp[1])
+        for k, s in zip(self._cnn_layers_kernel_size, self._cnn_layers_stride):
+            cnn_dims = conv_output_dim(cnn_dims, (0, 0), (1, 1), k, s)
+        self._out_dims = cnn_dims
+        self.cnn = nn.Sequential(
+            nn.Conv2d(self._n_input_audio, 32, kernel_size=self._cnn_layers_kernel_size[0], stride=self._cnn_layers_stride[0]),
+            nn.ReLU(True),
+            nn.Conv2d(32, 64, kernel_size=self._cnn_layers_kernel_size[1], stride=self._cnn_layers_stride[1]),
+            nn.ReLU(True),
+            nn.Conv2d(64, 32, kernel_size=self._cnn_layers_kernel_size[2], stride=self._cnn_layers_stride[2]),
+            nn.ReLU(True),
+            Flatten(),
+            nn.Linear(32 * cnn_dims[0] * cnn_dims[1], output_size),
+            nn.ReLU(True),
+        )
+        self.layer_init()
+        self._cache = PackedCache()
+
+    def layer_init(self):
+        for layer in self.cnn:
+            if isinstance(layer, (nn.Conv2d, nn.Linear)):
+                nn.init.kaiming_normal_(layer.weight, nn.init.calculate_gain("relu"))
+                if layer.bias is not None:
+                    nn.init.constant_(layer.bias, val=0)
+
+    def _packed(self):
+        convs = [self.cnn[0], self.cnn[2], self.cnn[4]]
+        fc = self.cnn[7]
+        srcs = [t for c in convs for t in (c.weight, c.bias)] + [fc.weight, fc.bias]
+
+        def build():
+            out = [(ops.pack_conv_weight(c.weight.detach().contiguous()), c.bias.detach().contiguous()) for c in convs]
+            h, w = self._out_dims
+            fw = fc.weight.detach().reshape(fc.weight.shape[0], 32, h, w).contiguous()
+            out.append((ops.pack_conv_weight(fw), fc.bias.detach().contiguous()))
+            return out
+
+        return self._cache.get(srcs, build)
+
+    def encode(self, x_nhwc):
+        """conv stack + FC on an already sliced NHWC input [B,32,T,32]."""
+        (w0, b0), (w1, b1), (w2, b2), (wf, bf) = self._packed()
+        x = ops.conv2d_nhwc(x_nhwc, w0, 32, 8, 8, stride=4, bias=b0, slope=0.0, name="audio_cnn.conv0")
+        x = ops.conv2d_nhwc(x, w1, 64, 4, 4, stride=2, bias=b1, slope=0.0, name="audio_cnn.conv1")
+        x = ops.conv2d_nhwc(x, w2, 32, 2, 2, stride=1, bias=b2, slope=0.0, name="audio_cnn.conv2")
+        h, w = self._out_dims
+        if x.shape[1] != h or x.shape[2] != w:
+            raise RuntimeError("m2h AudioCNN: conv output %s does not match the Linear built for %s" % (tuple(x.shape[1:3]), (h, w)))
+        y = ops.conv2d_nhwc(x, wf, wf.shape[0], h, w, stride=1, bias=bf, slope=0.0, name="audio_cnn.fc")
+        return y.reshape(y.shape[0], -1)
+
+    def forward_pair(self, pred_mono, pred_monoFromMem):
+        """monoNmonoFromMem path without materialising torch.cat((mono, mem), dim=3) (rl/ppo/policy.py:103)."""
+        check_inference(self, pred_mono, pred_monoFromMem)
+        return self.encode(ops.slice_concat_input(pred_mono.contiguous(), pred_monoFromMem.contiguous(), op=2))
+
+    def forward(self, observations, pred_binSepMasks=None, pred_monoNmonoFromMem=None):
+        if self.encode_monoNmonoFromMem:
+            assert pred_monoNmonoFromMem is not None
+            check_inference(self, pred_monoNmonoFromMem)
+            x = ops.slice_concat_input(pred_monoNmonoFromMem.contiguous(), op=2)  # log1p(clamp0(x))  reference :121-122
+        else:
+            assert pred_binSepMasks is not None
+            mix = observations["mixed_bin_audio_mag"]
+            check_inference(self, mix, pred_binSepMasks)
+            x = ops.slice_concat_input(mix.contiguous(), mul=pred_binSepMasks.contiguous(), op=1)  # reference :125-128
+        return self.encode(x)

@@ -1,0 +1,64 @@
+"""Acoustic memory on MI355X: drop-in for audio_separation/rl/models/memory_nets.py (AcousticMem, :5-69).
+
+Same constructor, forward signature and state_dict keys (``cnn.0.weight``, ``cnn.2.weight`` for the DD-PPO variant).
+forward = slice both inputs 16-way + concat (one HBM-bound kernel, concat never materialised as NCHW) -> conv3x3+ReLU ->
+conv3x3 with the de-slice fused into its store; both convs run on the MFMA implicit-GEMM engine.
+``forward_masked`` additionally fuses the not-done masking of the previous memory (ppo_trainer.py:310-314, ppo.py:206-209).
+"""
+import torch.nn as nn
+
+from ... import ops
+from ._common import PackedCache, check_inference
+
+
+class AcousticMem(nn.Module):
+    def __init__(self, use_ddppo=False):
+        super().__init__()
+        self._slice_factor = 16
+        _n_out_audio = self._slice_factor
+        if use_ddppo:
+            self.cnn = nn.Sequential(
+                nn.Conv2d(_n_out_audio * 2, 32, kernel_size=3, padding=1, bias=False),
+                nn.ReLU(inplace=True),
+                nn.Conv2d(32, _n_out_audio, kernel_size=3, padding=1, bias=False),
+            )
+        else:
+            self.cnn = nn.Sequential(
+                nn.Conv2d(_n_out_audio * 2, 32, kernel_size=3, padding=1, bias=False),
+                nn.BatchNorm2d(32),
+                nn.ReLU(inplace=True),
+                nn.Conv2d(32, _n_out_audio, kernel_size=3, padding=1, bias=False),
+            )
+        self._use_ddppo = use_ddppo
+        self.layer_init()
+        self._cache = PackedCache()
+
+    def layer_init(self):
+        # reference :26-38
+        for layer in self.cnn:
+            if isinstance(layer, (nn.Conv2d, nn.ConvTranspose2d, nn.Linear)):
+                nn.init.kaiming_normal_(layer.weight, nn.init.calculate_gain("relu"))
+                if layer.bias is not None:
+                    nn.init.constant_(layer.bias, val=0)
+            elif isinstance(layer, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                if layer.affine:
+                    layer.weight.data.fill_(1)
+                    layer.bias.data.zero_()
+
+    def _packed(self):
+        convs = [m for m in self.cnn if isinstance(m, nn.Conv2d)]
+        return self._cache.get([c.weight for c in convs],
+                               lambda: [ops.pack_conv_weight(c.weight.detach().contiguous()) for c in convs])
+
+    def forward_masked(self, pred_mono, prev_pred_monoFromMem, masks=None):
+        if not self._use_ddppo:
+            raise NotImplementedError("m2h AcousticMem: only the DD-PPO variant (no BatchNorm, memory_nets.py:11-16) is built")
+        check_inference(self, pred_mono, prev_pred_monoFromMem)
+        bscale = masks.reshape(-1).contiguous() if masks is not None else None
+        x = ops.slice_concat_input(pred_mono.contiguous(), prev_pred_monoFromMem.contiguous(), bscale=bscale, op=0)
+        w0, w1 = self._packed()
+        x = ops.conv2d_nhwc(x, w0, 32, 3, 3, stride=1, pad=1, slope=0.0, name="acoustic_mem.conv0")
+        return ops.conv2d_nhwc(x, w1, self._slice_factor, 3, 3, stride=1, pad=1, slope=1.0, deslice=True, name="acoustic_mem.conv1")
+
+    def forward(self, pred_mono, prev_pred_monoFromMem_masked):
+        return self.forward_masked(pred_mono, prev_pred_monoFromMem_masked, None)

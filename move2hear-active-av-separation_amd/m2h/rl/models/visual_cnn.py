@@ -1,0 +1,93 @@
+"""Visual encoder on MI355X: drop-in for audio_separation/rl/models/visual_cnn.py (VisualCNN, :8-152).
+
+Same constructor / forward / state_dict keys (``cnn.{0,2,4}.{weight,bias}``, ``cnn.6.{weight,bias}``).  rgb/255 (+depth) is
+written once as a 4-channel NHWC tensor (the observation already is BHWC == NHWC); the 3- or 4-channel first conv is packed
+to 4 input channels; conv8x8s4+ReLU, conv4x4s2+ReLU, conv3x3s1 and the Linear+ReLU run on the MFMA implicit-GEMM engine.
+"""
+import torch.nn as nn
+
+from ... import ops
+from ._common import PackedCache, check_inference
+from .audio_cnn import Flatten, conv_output_dim
+
+
+class VisualCNN(nn.Module):
+    def __init__(self, observation_space, output_size, extra_rgb, extra_depth):
+        super().__init__()
+        if "rgb" in observation_space.spaces and (not extra_rgb):
+            self._n_input_rgb = observation_space.spaces["rgb"].shape[2]
+        else:
+            self._n_input_rgb = 0
+        if "depth" in observation_space.spaces and (not extra_depth):
+            self._n_input_depth = observation_space.spaces["depth"].shape[2]
+        else:
+            self._n_input_depth = 0
+        self._cnn_layers_kernel_size = [(8, 8), (4, 4), (3, 3)]
+        self._cnn_layers_stride = [(4, 4), (2, 2), (1, 1)]
+        if self._n_input_rgb > 0:
+            cnn_dims = (128, 128)  # hard-coded in the reference (:43-45)
+        elif self._n_input_depth > 0:
+            cnn_dims = tuple(observation_space.spaces["depth"].shape[:2])
+        if self.is_blind:
+            self.cnn = nn.Sequential()
+        else:
+            for k, s in zip(self._cnn_layers_kernel_size, self._cnn_layers_stride):
+                cnn_dims = conv_output_dim(cnn_dims, (0, 0), (1, 1), k, s)
+            self._out_dims = cnn_dims
+            self.cnn = nn.Sequential(
+                nn.Conv2d(self._n_input_rgb + self._n_input_depth, 32, kernel_size=self._cnn_layers_kernel_size[0],
+                          stride=self._cnn_layers_stride[0]),
+                nn.ReLU(True),
+                nn.Conv2d(32, 64, kernel_size=self._cnn_layers_kernel_size[1], stride=self._cnn_layers_stride[1]),
+                nn.ReLU(True),
+                nn.Conv2d(64, 32, kernel_size=self._cnn_layers_kernel_size[2], stride=self._cnn_layers_stride[2]),
+                Flatten(),
+                nn.Linear(32 * cnn_dims[0] * cnn_dims[1], output_size),
+                nn.ReLU(True),
+            )
+        self.layer_init()
+        self._cache = PackedCache()
+
+    def layer_init(self):
+        for layer in self.cnn:
+            if isinstance(layer, (nn.Conv2d, nn.Linear)):
+                nn.init.kaiming_normal_(layer.weight, nn.init.calculate_gain("relu"))
+                if layer.bias is not None:
+                    nn.init.constant_(layer.bias, val=0)
+
+    @property
+    def is_blind(self):
+        return self._n_input_rgb + self._n_input_depth == 0
+
+    def _packed(self):
+        convs = [self.cnn[0], self.cnn[2], self.cnn[4]]
+        fc = self.cnn[6]
+        srcs = [t for c in convs for t in (c.weight, c.bias)] + [fc.weight, fc.bias]
+
+        def build():
+            c0 = convs[0]
+            out = [(ops.pack_conv_weight_ex(c0.weight.detach().contiguous(), c0.weight.shape[1], 4), c0.bias.detach().contiguous())]
+            out += [(ops.pack_conv_weight(c.weight.detach().contiguous()), c.bias.detach().contiguous()) for c in convs[1:]]
+            h, w = self._out_dims
+            fw = fc.weight.detach().reshape(fc.weight.shape[0], 32, h, w).contiguous()
+            out.append((ops.pack_conv_weight(fw), fc.bias.detach().contiguous()))
+            return out
+
+        return self._cache.get(srcs, build)
+
+    def forward(self, observations):
+        if self.is_blind:
+            raise NotImplementedError("m2h VisualCNN: blind configuration has no encoder")
+        if self._n_input_rgb != 3 or self._n_input_depth not in (0, 1):
+            raise NotImplementedError("m2h VisualCNN: built for rgb (3 ch) with optional depth (1 ch)")
+        rgb = observations["rgb"]
+        depth = observations["depth"] if self._n_input_depth > 0 else None
+        check_inference(self, rgb)
+        x = ops.visual_input(rgb.contiguous(), depth.contiguous() if depth is not None else None)
+        (w0, b0), (w1, b1), (w2, b2), (wf, bf) = self._packed()
+        x = ops.conv2d_nhwc(x, w0, 32, 8, 8, stride=4, bias=b0, slope=0.0, name="visual_cnn.conv0")
+        x = ops.conv2d_nhwc(x, w1, 64, 4, 4, stride=2, bias=b1, slope=0.0, name="visual_cnn.conv1")
+        x = ops.conv2d_nhwc(x, w2, 32, 3, 3, stride=1, bias=b2, slope=1.0, name="visual_cnn.conv2")  # no ReLU (:81-88)
+        h, w = self._out_dims
+        y = ops.conv2d_nhwc(x, wf, wf.shape[0], h, w, stride=1, bias=bf, slope=0.0, name="visual_cnn.fc")
+        return y.reshape(y.shape[0], -1)

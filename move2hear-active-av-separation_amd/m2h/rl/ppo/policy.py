@@ -1,0 +1,171 @@
+"""Move2Hear RL policy on MI355X: drop-in for audio_separation/rl/ppo/policy.py.
+
+Same class names (CriticHead, PolicyNet, PassiveSepEnc/Dec, Policy, Move2HearPolicy), constructor arguments, method
+signatures/return conventions (:183-273) and state_dict keys (158 entries, checked against the reference).  Every
+arithmetic step runs in libm2h.so; only inference (rollout: act / get_value under torch.no_grad(), ppo_trainer.py:322-335,
+:500-507) is built so far -- evaluate_actions computes the forward values but refuses to run where autograd would be needed.
+"""
+import abc
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...common.utils import CategoricalNet, CustomFixedCategorical
+from ...pretrain.passive.policy import PassiveSepDec, PassiveSepEnc  # identical wrappers (reference :121-156)
+from ..models._common import check_inference
+from ..models.audio_cnn import AudioCNN
+from ..models.memory_nets import AcousticMem
+from ..models.rnn_state_encoder import RNNStateEncoder
+from ..models.visual_cnn import VisualCNN
+
+
+class CriticHead(nn.Module):
+    def __init__(self, input_size):
+        super().__init__()
+        self.fc = nn.Linear(input_size, 1)
+        nn.init.orthogonal_(self.fc.weight)
+        nn.init.constant_(self.fc.bias, 0)
+
+    def forward(self, x):
+        return ops.linear(x.contiguous(), self.fc.weight.detach(), self.fc.bias.detach(), name="critic")
+
+
+class Net(nn.Module, metaclass=abc.ABCMeta):
+    @abc.abstractmethod
+    def forward(self, observations, rnn_hidden_states, prev_actions, masks):
+        pass
+
+    @property
+    @abc.abstractmethod
+    def output_size(self):
+        pass
+
+    @property
+    @abc.abstractmethod
+    def num_recurrent_layers(self):
+        pass
+
+    @property
+    @abc.abstractmethod
+    def is_blind(self):
+        pass
+
+
+class PolicyNet(Net):
+    r"""Visual + two audio encoders -> concat -> GRU (reference :46-118)."""
+
+    def __init__(self, observation_space, hidden_size, goal_sensor_uuid, extra_rgb=False, extra_depth=False, world_rank=0):
+        super().__init__()
+        assert 'mixed_bin_audio_mag' in observation_space.spaces
+        self.goal_sensor_uuid = goal_sensor_uuid
+        self._hidden_size = hidden_size
+        self.visual_encoder = VisualCNN(observation_space, hidden_size, extra_rgb, extra_depth)
+        self.bin_encoder = AudioCNN(observation_space, hidden_size)
+        self.monoNmonoFromMem_encoder = AudioCNN(observation_space, hidden_size, encode_monoNmonoFromMem=True)
+        rnn_input_size = 3 * self._hidden_size
+        self.state_encoder = RNNStateEncoder(rnn_input_size, self._hidden_size)
+
+    @property
+    def is_blind(self):
+        return False
+
+    @property
+    def output_size(self):
+        return self._hidden_size
+
+    @property
+    def num_recurrent_layers(self):
+        return self.state_encoder.num_recurrent_layers
+
+    def forward(self, observations, rnn_hidden_states, masks, pred_binSepMasks=None, pred_mono=None, pred_monoFromMem=None):
+        check_inference(self, pred_binSepMasks, pred_mono, pred_monoFromMem, rnn_hidden_states)
+        x = [
+            self.visual_encoder(observations),
+            self.bin_encoder(observations, pred_binSepMasks=pred_binSepMasks),
+            self.monoNmonoFromMem_encoder.forward_pair(pred_mono, pred_monoFromMem),  # cat(dim=3) read in place
+        ]
+        x1 = torch.cat(x, dim=1)
+        x2, rnn_hidden_states_new = self.state_encoder(x1, rnn_hidden_states, masks)
+        # the reference asserts "not isnan(x2).any().item()" here (:116): a host sync per call; dropped.
+        return x2, rnn_hidden_states_new
+
+
+class Policy(nn.Module):
+    r"""Full Move2Hear policy: separation + action-making (reference :159-273)."""
+
+    def __init__(self, pol_net, dim_actions, binSep_enc, binSep_dec, bin2mono_enc, bin2mono_dec, acoustic_mem):
+        super().__init__()
+        self.dim_actions = dim_actions
+        self.pol_net = pol_net
+        self.action_dist = CategoricalNet(self.pol_net.output_size, self.dim_actions)
+        self.critic = CriticHead(self.pol_net.output_size)
+        self.binSep_enc = binSep_enc
+        self.binSep_dec = binSep_dec
+        self.bin2mono_enc = bin2mono_enc
+        self.bin2mono_dec = bin2mono_dec
+        self.acoustic_mem = acoustic_mem
+
+    def forward(self):
+        raise NotImplementedError
+
+    def get_binSepMasks(self, observations):
+        bottleneck_feats, lst_skip_feats = self.binSep_enc(observations)
+        return self.binSep_dec(bottleneck_feats, lst_skip_feats)
+
+    def convert_bin2mono(self, pred_binSepMasks, mixed_audio=None):
+        bottleneck_feats, lst_skip_feats = self.bin2mono_enc(pred_binSepMasks, mixed_audio=mixed_audio)
+        return self.bin2mono_dec(bottleneck_feats, lst_skip_feats)
+
+    def get_monoFromMem(self, pred_mono, prev_pred_monoFromMem_masked):
+        return self.acoustic_mem(pred_mono, prev_pred_monoFromMem_masked)
+
+    def get_monoFromMem_masked(self, pred_mono, prev_pred_monoFromMem, masks):
+        """get_monoFromMem with the not-done masking of the previous memory fused (ppo_trainer.py:310-319)."""
+        return self.acoustic_mem.forward_masked(pred_mono, prev_pred_monoFromMem, masks)
+
+    def _heads(self, feats, actions=None):
+        a, c = self.action_dist.linear, self.critic.fc
+        value, logp_all, probs, ent, logp_act = ops.policy_heads(
+            feats.contiguous(), a.weight.detach(), a.bias.detach(), c.weight.detach(), c.bias.detach(),
+            actions.reshape(-1).contiguous() if actions is not None else None)
+        return value, CustomFixedCategorical(logp_all, probs, ent), logp_act
+
+    def act(self, observations, rnn_hidden_states_pol, masks, deterministic=False, pred_binSepMasks=None, pred_mono=None,
+            pred_monoFromMem=None):
+        feats_pol, rnn_hidden_states_pol = self.pol_net(
+            observations, rnn_hidden_states_pol, masks, pred_binSepMasks=pred_binSepMasks.detach(),
+            pred_mono=pred_mono.detach(), pred_monoFromMem=pred_monoFromMem.detach())
+        value, dist, _ = self._heads(feats_pol)
+        action = dist.mode() if deterministic else dist.sample()
+        action_log_probs = dist.log_probs(action)
+        return value, action, action_log_probs, rnn_hidden_states_pol, dist.get_probs()
+
+    def get_value(self, observations, rnn_hidden_states_pol, masks, pred_binSepMasks=None, pred_mono=None, pred_monoFromMem=None):
+        feats_pol, _ = self.pol_net(
+            observations, rnn_hidden_states_pol, masks, pred_binSepMasks=pred_binSepMasks.detach(),
+            pred_mono=pred_mono.detach(), pred_monoFromMem=pred_monoFromMem.detach())
+        value, _, _ = self._heads(feats_pol)
+        return value
+
+    def evaluate_actions(self, observations, rnn_hidden_states_pol, masks, action, pred_binSepMasks=None, pred_mono=None,
+                         pred_monoFromMem=None):
+        feats_pol, rnn_hidden_states_pol = self.pol_net(
+            observations, rnn_hidden_states_pol, masks, pred_binSepMasks=pred_binSepMasks, pred_mono=pred_mono,
+            pred_monoFromMem=pred_monoFromMem)
+        value, dist, action_log_probs = self._heads(feats_pol, action)
+        dist_entropy = dist.entropy().mean()
+        return value, action_log_probs, dist_entropy, rnn_hidden_states_pol
+
+
+class Move2HearPolicy(Policy):
+    def __init__(self, observation_space, action_space, goal_sensor_uuid, hidden_size=512, extra_rgb=False, extra_depth=False,
+                 use_ddppo=False, world_rank=0, use_smartnav_for_eval_pol_mix=False):
+        pol_net = PolicyNet(observation_space=observation_space, hidden_size=hidden_size, goal_sensor_uuid=goal_sensor_uuid,
+                            extra_rgb=extra_rgb, extra_depth=extra_depth, world_rank=world_rank)
+        binSep_enc = PassiveSepEnc(observation_space=observation_space, world_rank=world_rank)
+        binSep_dec = PassiveSepDec()
+        bin2mono_enc = PassiveSepEnc(observation_space=observation_space, world_rank=world_rank, convert_bin2mono=True)
+        bin2mono_dec = PassiveSepDec(convert_bin2mono=True)
+        acoustic_mem = AcousticMem(use_ddppo=use_ddppo)
+        super().__init__(pol_net, action_space.n, binSep_enc, binSep_dec, bin2mono_enc, bin2mono_dec, acoustic_mem)

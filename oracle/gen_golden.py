@@ -136,6 +136,16 @@ def gen_init(ref):
     with open(os.path.join(GOLD, "passive_init_seed0.json"), "w") as f:
         json.dump({"meta": META, "params": rec}, f, indent=0)
     print("init: %d entries" % len(rec))
+    # full RL policy (ppo_trainer.py:168-177 arguments), SEED 0
+    torch.manual_seed(0)
+    pol = ref["rl_policy"].Move2HearPolicy(FakeObsSpace(32), FakeActionSpace(), "spectrogram", 512, False, True, use_ddppo=True)
+    rec = {}
+    for k, v in pol.state_dict().items():
+        a = v.detach().double().reshape(-1)
+        rec[k] = {"shape": list(v.shape), "sum": float(a.sum()), "abssum": float(a.abs().sum())}
+    with open(os.path.join(GOLD, "rl_init_seed0.json"), "w") as f:
+        json.dump({"meta": META, "params": rec}, f, indent=0)
+    print("rl init: %d entries" % len(rec))
 
 
 # ----------------------------------------------------------------------------------------------

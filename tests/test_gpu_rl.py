@@ -1,0 +1,196 @@
+"""GPU parity tests of the RL forward path (AcousticMem, encoders, GRU, heads/act, storage, GAE, advantages, PPO loss,
+rewards, STFT-L2) through the C-ABI, against the reference-generated fixtures and the CPU oracle.
+Tolerances: fp32 path, rel-L1 <= 2e-5 on feature tensors (contract 1e-3); index/permutation work bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import m2h_oracle as O
+from m2h import synthetic
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+def _policy(seed, dev):
+    from m2h.common.spaces import Discrete, move2hear_observation_space
+    from m2h.rl.ppo.policy import Move2HearPolicy
+    pol = Move2HearPolicy(move2hear_observation_space(), Discrete(3), "spectrogram", 512, False, True, use_ddppo=True)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), seed).items()}
+    pol.load_state_dict(sd, strict=True)
+    pol = pol.to(dev)
+    pol.train()
+    for m in (pol.binSep_enc, pol.binSep_dec, pol.bin2mono_enc, pol.bin2mono_dec):  # ppo_trainer.py:557-577
+        m.eval()
+        for p in m.parameters():
+            p.requires_grad_(False)
+    return pol, sd
+
+
+def _obs(n, seed, dev):
+    return {k: torch.from_numpy(v).float().to(dev) for k, v in synthetic.make_rl_observations(n, seed).items()}
+
+
+def _rel(a, b):
+    return O.rel_l1(torch.as_tensor(a).cpu(), torch.as_tensor(b))
+
+
+def test_rl_forward_matches_reference_fixture(golden_dir):
+    dev = _dev()
+    g = np.load(os.path.join(golden_dir, "rl_forward.npz"))
+    pol, sd = _policy(int(g["seed_w"]), dev)
+    N = int(g["N"])
+    obs = _obs(N, int(g["seed_x"]), dev)
+    masks, h0, prev = (torch.from_numpy(g[k]).to(dev) for k in ("masks", "h0", "prev_mem"))
+    with torch.no_grad():
+        pm = pol.get_binSepMasks(obs)
+        mono = pol.convert_bin2mono(pm, mixed_audio=obs["mixed_bin_audio_mag"])
+        assert _rel(pm, g["pred_binSepMasks"]) < TOL and _rel(mono, g["pred_mono"]) < TOL
+        # AcousticMem: reference-style (pre-masked input) and fused-mask entry points agree with the fixture
+        prev_masked = prev * masks.reshape(-1, 1, 1, 1)
+        mem = pol.get_monoFromMem(mono, prev_masked)
+        mem2 = pol.get_monoFromMem_masked(mono, prev, masks)
+        assert mem.shape == (N, 512, 32, 1)
+        assert _rel(mem, g["pred_monoFromMem"]) < TOL and torch.equal(mem, mem2)
+        assert _rel(pol.pol_net.visual_encoder(obs), g["visual_feats"]) < TOL
+        assert _rel(pol.pol_net.bin_encoder(obs, pred_binSepMasks=pm), g["bin_feats"]) < TOL
+        cat = torch.cat((mono, mem), dim=3)
+        assert _rel(pol.pol_net.monoNmonoFromMem_encoder(obs, pred_monoNmonoFromMem=cat), g["mnm_feats"]) < TOL
+        feats, h1 = pol.pol_net(obs, h0, masks, pred_binSepMasks=pm, pred_mono=mono, pred_monoFromMem=mem)
+        assert _rel(feats, g["gru_out"]) < TOL and _rel(h1, g["h1"]) < TOL
+        # act: values/probs match; deterministic action is bit-exact; sampled action is multinomial on the same probs
+        torch.manual_seed(5)
+        v, a, lp, hh, probs = pol.act(obs, h0, masks, deterministic=False, pred_binSepMasks=pm, pred_mono=mono, pred_monoFromMem=mem)
+        torch.manual_seed(5)
+        a_ref = torch.multinomial(probs, 1, True)
+        assert torch.equal(a, a_ref) and a.dtype == torch.int64 and a.shape == (N, 1)
+        assert _rel(v, g["act_value"]) < TOL and _rel(probs, g["act_probs"]) < TOL
+        assert torch.allclose(lp.cpu(), torch.log(probs.cpu()).gather(1, a.cpu()), atol=1e-6)
+        v2, a2, lp2, _, _ = pol.act(obs, h0, masks, deterministic=True, pred_binSepMasks=pm, pred_mono=mono, pred_monoFromMem=mem)
+        assert torch.equal(a2.cpu(), torch.from_numpy(g["det_action"])) and _rel(lp2, g["det_logp"]) < TOL
+        assert _rel(pol.get_value(obs, h0, masks, pred_binSepMasks=pm, pred_mono=mono, pred_monoFromMem=mem), g["get_value"]) < TOL
+        # evaluate_actions on a T=3 x N=2 flattened sequence with a mid-sequence reset
+        T, n = 3, 2
+        obs_seq = {k: v_[:T * n].contiguous() for k, v_ in obs.items()}
+        ev, elp, eent, eh = pol.evaluate_actions(obs_seq, h0[:, :n].contiguous(), torch.from_numpy(g["eval_masks"]).to(dev),
+                                                 torch.from_numpy(g["eval_actions"]).to(dev), pred_binSepMasks=pm[:T * n].contiguous(),
+                                                 pred_mono=mono[:T * n].contiguous(), pred_monoFromMem=mem[:T * n].contiguous())
+        assert _rel(ev, g["eval_value"]) < TOL and _rel(elp, g["eval_logp"]) < TOL and _rel(eh, g["eval_h"]) < TOL
+        assert abs(eent.item() - float(g["eval_entropy"])) < 1e-5
+
+
+def test_policy_refuses_autograd():
+    dev = _dev()
+    pol, _ = _policy(2, dev)
+    obs = _obs(2, 3, dev)
+    z = torch.zeros(2, 512, 32, 2, device=dev)
+    with pytest.raises(NotImplementedError):
+        pol.pol_net.bin_encoder(obs, pred_binSepMasks=z)  # grad enabled + trainable params -> loud failure, no silent graph-less result
+
+
+def test_returns_advantages_and_generators_match_fixture(golden_dir):
+    from m2h import ops
+    from m2h.common.rollout_storage import RolloutStoragePol, RolloutStorageSep
+    from m2h.common.spaces import Box, DictSpace
+    dev = _dev()
+    g = np.load(os.path.join(golden_dir, "rl_scalars.npz"))
+    T, N = int(g["T"]), int(g["N"])
+    space = DictSpace({"gt_mono_comps": Box((512, 32, 4)), "target_class": Box((1,))})
+    ro = RolloutStoragePol(T, N, space, 512)
+    ro.to(dev)
+    ro.rewards.copy_(torch.from_numpy(g["rewards"]))
+    ro.value_preds.copy_(torch.from_numpy(g["value_preds"]))
+    ro.masks.copy_(torch.from_numpy(g["masks"]))
+    nv = torch.from_numpy(g["next_value"]).to(dev)
+    ro.compute_returns(nv, True, 0.99, 0.95)
+    assert torch.allclose(ro.returns.cpu(), torch.from_numpy(g["returns_gae"]), atol=1e-6)  # <= 1e-6 abs
+    adv, _ = ops.advantages(ro.returns, ro.value_preds, 1)
+    assert torch.allclose(adv.cpu(), torch.from_numpy(g["advantages"]), atol=2e-6)
+    # distributed recipe with world = 1: biased variance around the global mean
+    raw, stats = ops.advantages(ro.returns, ro.value_preds, 2)
+    gmean = stats[0:1].clone()
+    gvar = ops.adv_sqdiff(raw, gmean)
+    d = ops.adv_apply(raw.clone(), gmean, gvar).cpu()
+    a = torch.from_numpy(g["returns_gae"])[:-1] - ro.value_preds.cpu()[:-1]
+    assert torch.allclose(d, (a - a.mean()) / (a.var(unbiased=False).sqrt() + 1e-5), atol=2e-6)
+    ro2 = RolloutStoragePol(T, N, space, 512)
+    ro2.to(dev)
+    ro2.rewards.copy_(ro.rewards)
+    ro2.masks.copy_(ro.masks)
+    ro2.compute_returns(nv, False, 0.99, 0.95)
+    assert torch.allclose(ro2.returns.cpu(), torch.from_numpy(g["returns_nogae"]), atol=1e-6)
+    # generator order: bit-exact with the reference for the same CPU seed
+    ro.actions.copy_(torch.arange(T * N).reshape(T, N, 1))
+    torch.manual_seed(int(g["gen_seed"]))
+    batch = next(iter(ro.recurrent_generator(adv, 1)))
+    assert torch.equal(batch[8].cpu(), torch.from_numpy(g["gen_actions_flat"]))
+    assert batch[0]["gt_mono_comps"].shape == (T * N, 512, 32, 4) and batch[1].shape == (1, N, 512)
+    rs = RolloutStorageSep(6, 5, space)
+    rs.to(dev)
+    rs.masks.copy_(torch.arange(7 * 5).reshape(7, 5, 1).float())
+    torch.manual_seed(int(g["gen_sep_seed"]))
+    sb = next(iter(rs.recurrent_generator(1)))
+    assert torch.equal(sb[3].cpu(), torch.from_numpy(g["gen_sep_masks_flat"]))
+
+
+def test_stft_l2_and_rewards_match_fixture(golden_dir):
+    from m2h import ops
+    dev = _dev()
+    g = np.load(os.path.join(golden_dir, "rl_scalars.npz"))
+    obs = _obs(5, int(g["l2_seed_x"]), dev)
+    pm, pmono = torch.from_numpy(g["l2_masks"]).to(dev), torch.from_numpy(g["l2_mono"]).to(dev)
+    d_bin = ops.stft_l2(pm, obs["gt_bin_comps"], 2, mix=obs["mixed_bin_audio_mag"])
+    d_mono = ops.stft_l2(pmono, obs["gt_mono_comps"], 1)
+    assert torch.allclose(d_bin.cpu(), torch.from_numpy(g["stft_l2_bin"]), rtol=2e-5)
+    assert torch.allclose(d_mono.cpu(), torch.from_numpy(g["stft_l2_mono"]), rtol=2e-5)
+    nxt, cur = torch.from_numpy(g["rew_mem_next"]).to(dev), torch.from_numpy(g["rew_mem_cur"]).to(dev)
+    not_done = torch.from_numpy(1.0 - g["rew_dones"].astype(np.float32)).to(dev)
+    L = 512 * 32
+    ns, cs = ops.sq_stats(nxt, obs["gt_mono_comps"], 0), ops.sq_stats(cur, obs["gt_mono_comps"], 0)
+    r1 = ops.rewards_from_stats(ns, cs, not_done, L, True).cpu().double().reshape(-1).numpy()
+    r2 = ops.rewards_from_stats(ns, None, not_done, L, False, 10.0).cpu().double().reshape(-1).numpy()
+    assert np.allclose(r1, g["rew_quality_improvement"], rtol=2e-5, atol=1e-7)
+    assert np.allclose(r2, g["rew_extra"], rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("clipped", [True, False])
+def test_ppo_loss_forward_and_gradients_match_autograd(clipped):
+    from m2h import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(3)
+    n = 280
+    values = torch.randn(n, 1, generator=gen, requires_grad=True)
+    logp = (torch.randn(n, 1, generator=gen) * 0.3 - 1.0).requires_grad_(True)
+    old_values, returns, adv = (torch.randn(n, 1, generator=gen) for _ in range(3))
+    old_logp = logp.detach() + torch.randn(n, 1, generator=gen) * 0.2
+    vl, al, total = O.ppo_losses(values, logp, torch.tensor(0.0), old_values, returns, adv, old_logp, 0.1, 0.5, 0.2, clipped)
+    total.backward()
+    out, gv, gl = ops.ppo_loss(values.detach().to(dev), logp.detach().to(dev), old_values.to(dev), returns.to(dev), adv.to(dev),
+                               old_logp.to(dev), 0.1, value_loss_coef=0.5, use_clipped_value_loss=clipped, want_grads=True)
+    assert abs(out[0].item() - vl.item()) < 1e-5 * max(1, abs(vl.item())) and abs(out[1].item() - al.item()) < 1e-5
+    assert torch.allclose(gv.cpu(), values.grad, atol=1e-7, rtol=1e-4)
+    assert torch.allclose(gl.cpu(), logp.grad, atol=1e-7, rtol=1e-4)
+
+
+def test_generic_conv_engine_matches_torch():
+    """The igemm engine on the policy-net shapes (8x8 s4, 4x4 s2, 3x3, 2x2, FC-as-conv), ragged M, odd spatial sizes."""
+    import torch.nn.functional as F
+    from m2h import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(11)
+    for (B, H, W, Ci, Co, k, s, p) in [(3, 128, 128, 4, 32, 8, 4, 0), (3, 31, 31, 32, 64, 4, 2, 0), (2, 14, 14, 64, 32, 3, 1, 0),
+                                       (5, 32, 32, 32, 32, 3, 1, 1), (7, 2, 2, 64, 32, 2, 1, 0), (9, 12, 12, 32, 512, 12, 1, 0)]:
+        x = torch.randn(B, Ci, H, W, generator=gen)
+        w = torch.randn(Co, Ci, k, k, generator=gen) * (2.0 / (Ci * k * k)) ** 0.5
+        b = torch.randn(Co, generator=gen) * 0.1
+        ref = F.relu(F.conv2d(x, w, b, stride=s, padding=p))
+        y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), ops.pack_conv_weight(w.to(dev)), Co, k, k, stride=s, pad=p,
+                            bias=b.to(dev), slope=0.0)
+        assert _rel(y.permute(0, 3, 1, 2), ref) < TOL, (B, H, W, Ci, Co, k, s, p)
