@@ -190,11 +190,13 @@ int m2h_advantages(const float* returns, const float* value_preds, float* adv, f
 int m2h_adv_sqdiff(const float* adv, const float* gmean, float* out, int n, m2h_stream stream);
 int m2h_adv_apply(float* adv, const float* gmean, const float* gvar, int n, float eps, m2h_stream stream);
 
-/* PPO losses (ppo.py:125-157) forward and analytic gradients: out[0] = value_loss, out[1] = action_loss;
- * g_values = d(value_loss_coef*value_loss)/dvalues, g_logp = d(action_loss)/d(action_log_probs) (either may be NULL). */
+/* PPO losses (ppo.py:125-157) forward and analytic gradients: out[4] = (value_loss, action_loss, mean entropy, total_loss =
+ * value_loss*value_loss_coef + action_loss - entropy*entropy_coef); entropy[n] per-row entropies or NULL;
+ * g_values = d(total)/dvalues, g_logp = d(total)/d(action_log_probs) (either may be NULL); d(total)/d(entropy_row) is the
+ * constant -entropy_coef/n. */
 int m2h_ppo_loss(const float* values, const float* logp, const float* old_values, const float* returns, const float* adv,
-                 const float* old_logp, float clip, int use_clipped_value_loss, float value_loss_coef, float* out, float* g_values,
-                 float* g_logp, int n, m2h_stream stream);
+                 const float* old_logp, const float* entropy, float clip, int use_clipped_value_loss, float value_loss_coef,
+                 float entropy_coef, float* out, float* g_values, float* g_logp, int n, m2h_stream stream);
 
 /* reward_util / override_rewards (common/env_utils.py:690-713).  m2h_sq_stats: per env e, stats[e] = (sum (pred-gt)^2,
  * sum gt^2) over L elements, gt read with stride/offset from an interleaved components tensor (gt_mono_comps[...,0]).
@@ -214,6 +216,63 @@ int m2h_gather_envs(const void* src, const long long* perm, void* dst, int T, in
  * pred/mix: [N][L][Cp]; gt_comps: [N][L][Cg] = per channel (mag, phase). */
 int m2h_stft_l2(const float* mix, const float* pred, int Cp, const float* gt_comps, int Cg, int nch, int use_mix, float* out, int N,
                 int L, m2h_stream stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Backward of the implicit-GEMM convolution (training rows: ppo.py:159-175 update_pol, :224-241 update_sep).
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* Weight gradient in the packed layout: dw[n][k] = sum_m dy[m][n] * A[m][k], with A gathered from args->src0/src1 exactly as
+ * the forward launch described by args does (same geometry fields; wp/scale/shift/dst are ignored; conv_transpose must be
+ * 0).  dy: [M][ldy] (the NHWC output gradient, activation already back-propagated with m2h_act_bwd).  args->workspace must
+ * hold m2h_conv_wgrad_workspace_bytes(args) bytes (pixel range is split over blocks, partial tiles are summed in a fixed
+ * order: bit-reproducible). */
+size_t m2h_conv_wgrad_workspace_bytes(const m2h_conv_args* args /* host */);
+int m2h_conv_wgrad_f32(const m2h_conv_args* args /* host */, const float* dy, int ldy, float* dw, m2h_stream stream);
+
+/* Input gradient = forward engine on re-laid-out weights: for a Conv2d(k, stride s, pad p) weight w [Co][Ci][KH][KW]
+ * (KH, KW multiples of s) writes s*s phase matrices wp[ph*s+pw][ci][th][tw][co] = w[co][ci][(ph+p)%s + s*th][(pw+p)%s + s*tw].
+ * Phase (ph,pw) of dx is then m2h_conv_igemm_f32 with src0 = dy (C0 = Co), N = Ci, taps (KH/s, KW/s), mulh = mulw = -1,
+ * offh = (ph + p - (ph+p)%s)/s (likewise offw), stride 1, os = s, output phase (ph,pw), Hq = ceil((H_in - ph)/s). */
+int m2h_pack_dgrad_weight(const float* w, float* wp, int Co, int Ci, int KH, int KW, int stride, int pad, m2h_stream stream);
+
+/* out = dy * (y > 0 ? 1 : slope): backward of the fused ReLU (slope 0) / LeakyReLU epilogue, y = the forward output. */
+int m2h_act_bwd(const float* dy, const float* y, float slope, float* out, size_t n, m2h_stream stream);
+
+/* db[n] = sum_m dy[m][n]  (Conv2d / Linear bias gradient), deterministic. */
+int m2h_bias_grad(const float* dy, float* db, int M, int N, m2h_stream stream);
+
+/* GRU backward, one time step (torch.nn.GRU semantics, rnn_state_encoder.py:86-137 under autograd): inputs of
+ * m2h_gru_gates plus dh = dL/dh_out; outputs dgi = dL/d(gi), dpre = dL/d(mask*gh_raw + b_hh) (so dL/dgh_raw = mask*dpre,
+ * db_hh = column sums of dpre), dhp = dh*z (direct path to the masked h_prev) and hpm = mask*h_prev.
+ * m2h_gru_bwd_combine: out = a + mask_row*(b + c)  (a may be NULL): total gradient reaching h_{t-1}. */
+int m2h_gru_gates_bwd(const float* gi, const float* gh_raw, const float* bhh, const float* hprev, const float* mask, const float* dh,
+                      float* dgi, float* dpre, float* dhp, float* hpm, int M, int H, m2h_stream stream);
+int m2h_gru_bwd_combine(const float* a, const float* b, const float* c, const float* mask, float* out, int M, int H, m2h_stream stream);
+
+/* Backward of m2h_policy_heads: g_value[M], g_logp[M], g_ent[M] = dL/d(value | logp_act | entropy row) (each may be NULL); dz [M][ZS] receives
+ * (dL/dlogits[0..A), dL/dvalue, 0...) with ZS = A+1 rounded up to a multiple of 4; dfeats [M][H]. */
+int m2h_policy_heads_bwd(const float* logp_all, const float* probs, const long long* actions, const float* g_value, const float* g_logp,
+                         const float* g_ent, const float* Wa, const float* Wc, float* dz, float* dfeats, int M, int H, int A, int ZS,
+                         m2h_stream stream);
+
+/* F.l1_loss(pred, gt) with gt read strided from an interleaved tensor (ppo.py:212-221; passive_trainer.py:271-275):
+ * loss[0] = mean |pred - gt|, grad[i] = sign(pred-gt)/n (NULL to skip).  scratch: >= 1024 floats. */
+int m2h_l1_loss(const float* pred, const float* gt, int gt_stride, int gt_off, float* loss, float* grad, float* scratch, size_t n,
+                m2h_stream stream);
+
+/* Binaural separation L1 (ppo.py:219-221; passive_trainer.py:270-272): loss[0] = mean |(exp(mix)-1)*masks - gt_bin_comps[..., {0,2}]|
+ * over [npix][2]; grad_masks (NULL to skip) = d loss / d masks.  mix, masks: [npix][2]; gt_bin_comps: [npix][Cg]. */
+int m2h_bin_l1_loss(const float* mix, const float* masks, const float* gt_bin_comps, int Cg, float* loss, float* grad_masks, float* scratch,
+                    size_t npix, m2h_stream stream);
+
+/* nn.utils.clip_grad_norm_ (ppo.py:254-268) over one flat gradient buffer: coef[0] = min(1, max_norm/(||g||_2 + 1e-6))
+ * (1 when max_norm <= 0), coef[1] = ||g||_2; stays on the device (no host sync).  scratch: >= 1024 floats. */
+int m2h_grad_clip_coef(const float* g, size_t n, float max_norm, float* coef, float* scratch, m2h_stream stream);
+
+/* torch.optim.Adam step (ppo.py:48-55: eps=1e-5, no weight decay, no amsgrad) over flat buffers; g is first scaled in place by
+ * coef[0]*gscale (clip coefficient from m2h_grad_clip_coef, gscale = 1/world_size after a sum all-reduce). step >= 1. */
+int m2h_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,
+                  const float* coef, float gscale, m2h_stream stream);
 
 #ifdef __cplusplus
 }

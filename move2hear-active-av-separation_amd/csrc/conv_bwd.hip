@@ -1,0 +1,324 @@
+// Backward pieces of the implicit-GEMM convolution (gfx950, fp32 MFMA).
+//
+//   wgrad   dW[n][k] = sum_m dY[m][n] * A[m][k]      (reduction over output pixels m; A gathered exactly as in the forward)
+//           = the weight gradient of Conv2d / Linear in the packed [N][K] layout, K = (tap, channel).
+//   dgrad   runs on the FORWARD engine (conv_igemm.hip): the input gradient of a stride-s conv is s*s sub-pixel phase
+//           convolutions of dY with the (ci <-> co)-transposed, tap-strided weights; m2h_pack_dgrad_weight lays those out.
+//   act_bwd dY * (y > 0 ? 1 : slope)  for the fused ReLU / LeakyReLU epilogues;  bias_grad = column sums of dY.
+//
+// wgrad tiling: block = BNG (n) x 128 (k) output tile, 4 waves, fp32 v_mfma_f32_32x32x2; the reduction runs over 32-pixel
+// chunks staged [m][n] / [m][k] in LDS (double buffered through registers); fragments are ds_read_b32 column reads
+// (consecutive lanes -> consecutive addresses, conflict free).  The pixel range is split over grid.z; partial tiles go to a
+// slab [split][N][Kpad] and an ordered reduce kernel sums them (deterministic, no atomics).
+#include "m2h_internal.h"
+
+namespace m2h {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WGradP {
+  const float* src0;
+  const float* src1;
+  int C0, C1, Ctot;
+  int B, Hi, Wi, Hq, Wq;
+  int stride, ntw, ntap, mulh, offh, mulw, offw;
+  const float* dy;  // [M][ldy]
+  int ldy;
+  int N, K, Kpad;   // Kpad = K rounded up to 128
+  int M;
+  int S;            // splits over m (grid z)
+  int chunks;       // ceil(M / 32)
+  float* ws;        // [S][N][Kpad]
+  float* dw;        // [N][K]
+};
+
+constexpr int WK = 128;  // k tile
+constexpr int WM = 32;   // pixels per reduction chunk
+
+template <int BNG>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
+  constexpr int WN_ = (BNG == 128) ? 2 : 1;       // waves along n
+  constexpr int WK_ = 4 / WN_;                    // waves along k
+  constexpr int TN = BNG / WN_, TK = WK / WK_;    // wave tile: 64x64 (BNG 128) or 32x32 (BNG 32)
+  constexpr int FN = TN / 32, FK = TK / 32;
+  constexpr int YSEG = BNG / 4;                   // 16-byte segments per dY row
+  constexpr int YR = (WM * YSEG + 255) / 256;     // dY segments per thread
+  __shared__ __attribute__((aligned(16))) float Ys[2][WM * BNG];
+  __shared__ __attribute__((aligned(16))) float As[2][WM * WK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave / WK_, wk = wave % WK_;
+  const int n0 = blockIdx.x * BNG;
+  const int k0 = blockIdx.y * WK;
+  const int split = blockIdx.z;
+  const int c0 = (int)(((long)p.chunks * split) / p.S), c1 = (int)(((long)p.chunks * (split + 1)) / p.S);
+
+  // this thread's fixed A column: decode (tap, channel) once
+  const int aseg = tid & 31;        // 32 segments of 4 floats = 128 k
+  const int arow = tid >> 5;        // 0..7, rows arow + 8*i
+  const int k = k0 + aseg * 4;
+  const bool kok = k < p.K;
+  int tap = 0, ci = k;
+  if (p.ntap > 1) {
+    tap = (unsigned)k / (unsigned)p.Ctot;
+    ci = k - tap * p.Ctot;
+  }
+  const int th = (unsigned)tap / (unsigned)p.ntw, tw = tap - th * p.ntw;
+  const int dh = th * p.mulh + p.offh, dw = tw * p.mulw + p.offw;
+  const float* src = p.src0;
+  int Cs = p.C0, cc = ci;
+  if (ci >= p.C0) {
+    src = p.src1;
+    Cs = p.C1;
+    cc = ci - p.C0;
+  }
+  const int yseg = tid % YSEG, yrow0 = tid / YSEG;  // dY: rows yrow0 + (256/YSEG)*i
+  constexpr int YSTEP = 256 / YSEG;
+
+  f32x16 acc[FN][FK];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FK; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  f32x4 ra[4], ry[YR];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  auto load_chunk = [&](int c) {
+    const int mbase = c * WM;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mbase + arow + 8 * i;
+      ra[i] = zero4;
+      if (kok && m < p.M) {
+        const int rr = m % p.Wq;
+        const int t = m / p.Wq;
+        const int q = t % p.Hq;
+        const int b = t / p.Hq;
+        const int ih = q * p.stride + dh, iw = rr * p.stride + dw;
+        if ((unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) {
+          const size_t off = ((size_t)(b * p.Hi * p.Wi + ih * p.Wi + iw)) * (size_t)Cs + (size_t)cc;
+          ra[i] = *reinterpret_cast<const f32x4*>(src + off);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < YR; ++i) {
+      const int row = yrow0 + YSTEP * i;
+      const int m = mbase + row;
+      const int n = n0 + yseg * 4;
+      ry[i] = zero4;
+      if (row < WM && m < p.M && n < p.N) {
+        const float* yp = p.dy + (size_t)m * p.ldy + n;
+        if (n + 3 < p.N && (p.ldy & 3) == 0) {
+          ry[i] = *reinterpret_cast<const f32x4*>(yp);
+        } else {
+          for (int j = 0; j < 4; ++j)
+            if (n + j < p.N) ry[i][j] = yp[j];
+        }
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&As[buf][(arow + 8 * i) * WK + aseg * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < YR; ++i) {
+      const int row = yrow0 + YSTEP * i;
+      if (row < WM) *reinterpret_cast<f32x4*>(&Ys[buf][row * BNG + yseg * 4]) = ry[i];
+    }
+  };
+  const int fi = lane & 31, fh = lane >> 5;
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < WM / 2; ++j) {
+      const int m = 2 * j + fh;
+      float a[FN], b[FK];
+#pragma unroll
+      for (int x = 0; x < FN; ++x) a[x] = Ys[buf][m * BNG + wn * TN + x * 32 + fi];
+#pragma unroll
+      for (int x = 0; x < FK; ++x) b[x] = As[buf][m * WK + wk * TK + x * 32 + fi];
+#pragma unroll
+      for (int x = 0; x < FN; ++x)
+#pragma unroll
+        for (int y = 0; y < FK; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+    }
+  };
+
+  if (c0 < c1) {
+    load_chunk(c0);
+    store_chunk(0);
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {
+      const int cur = (c - c0) & 1;
+      if (c + 1 < c1) load_chunk(c + 1);
+      compute(cur);
+      if (c + 1 < c1) store_chunk(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // partial tile -> slab[split][n][k]
+  float* slab = p.ws + (size_t)split * p.N * p.Kpad;
+  const int col = lane & 31, rhalf = (lane >> 5) * 4;
+#pragma unroll
+  for (int x = 0; x < FN; ++x)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = n0 + wn * TN + x * 32 + (e & 3) + 8 * (e >> 2) + rhalf;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int y = 0; y < FK; ++y) {
+        const int kk = k0 + wk * TK + y * 32 + col;
+        slab[(size_t)n * p.Kpad + kk] = acc[x][y][e];
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WGradP p) {
+  const size_t total = (size_t)p.N * p.K;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / p.K);
+    const int k = (int)(i - (size_t)n * p.K);
+    float s = 0.f;
+    for (int z = 0; z < p.S; ++z) s += p.ws[((size_t)z * p.N + n) * p.Kpad + k];
+    p.dw[i] = s;
+  }
+}
+
+static int wgrad_splits(long M, int N, int K) {
+  const int bng = N > 32 ? 128 : 32;
+  const long tiles = ((N + bng - 1) / bng) * (long)((K + WK - 1) / WK);
+  const long chunks = (M + WM - 1) / WM;
+  long S = (1024 + tiles - 1) / tiles;  // ~4 blocks per CU
+  if (S > chunks / 4) S = chunks / 4;   // at least 4 chunks per split
+  if (S > 1024) S = 1024;
+  if (S < 1) S = 1;
+  return (int)S;
+}
+
+size_t conv_wgrad_workspace_bytes(const m2h_conv_args& a) {
+  const long M = (long)a.B * a.Hq * a.Wq;
+  const int K = a.nth * a.ntw * (a.C0 + a.C1);
+  const int Kpad = (K + WK - 1) / WK * WK;
+  return (size_t)wgrad_splits(M, a.N, K) * a.N * Kpad * sizeof(float);
+}
+
+int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, hipStream_t st) {
+  M2H_REQUIRE(a.src0 != nullptr && dy != nullptr && dw != nullptr, "conv_wgrad: null pointer");
+  M2H_REQUIRE(a.conv_transpose == 0, "conv_wgrad: transposed conv not supported yet");
+  M2H_REQUIRE(a.C0 > 0 && a.C0 % 4 == 0 && a.C1 >= 0 && a.C1 % 4 == 0, "conv_wgrad: C0/C1 must be multiples of 4");
+  M2H_REQUIRE((a.C1 == 0) == (a.src1 == nullptr), "conv_wgrad: src1/C1 mismatch");
+  M2H_REQUIRE(a.B > 0 && a.Hi > 0 && a.Wi > 0 && a.Hq > 0 && a.Wq > 0 && a.N > 0 && a.nth > 0 && a.ntw > 0 && a.stride > 0, "conv_wgrad: bad sizes");
+  M2H_REQUIRE(ldy >= a.N, "conv_wgrad: ldy (%d) < N (%d)", ldy, a.N);
+  const long M = (long)a.B * a.Hq * a.Wq;
+  M2H_REQUIRE(M < (1L << 30) && (long)a.B * a.Hi * a.Wi < (1L << 30), "conv_wgrad: too many pixels");
+  WGradP p;
+  p.src0 = a.src0; p.src1 = a.src1; p.C0 = a.C0; p.C1 = a.C1; p.Ctot = a.C0 + a.C1;
+  p.B = a.B; p.Hi = a.Hi; p.Wi = a.Wi; p.Hq = a.Hq; p.Wq = a.Wq;
+  p.stride = a.stride; p.ntw = a.ntw; p.ntap = a.nth * a.ntw; p.mulh = a.mulh; p.offh = a.offh; p.mulw = a.mulw; p.offw = a.offw;
+  p.dy = dy; p.ldy = ldy; p.N = a.N; p.K = p.ntap * p.Ctot; p.Kpad = (p.K + WK - 1) / WK * WK;
+  p.M = (int)M; p.chunks = (int)((M + WM - 1) / WM);
+  p.S = wgrad_splits(M, a.N, p.K);
+  M2H_REQUIRE(a.workspace != nullptr && a.workspace_bytes >= (size_t)p.S * p.N * p.Kpad * sizeof(float), "conv_wgrad: workspace too small (need %zu bytes)",
+              (size_t)p.S * p.N * p.Kpad * sizeof(float));
+  p.ws = static_cast<float*>(a.workspace);
+  p.dw = dw;
+  const int ktiles = p.Kpad / WK;
+  if (a.N > 32) {
+    dim3 grid((a.N + 127) / 128, ktiles, p.S);
+    hipLaunchKernelGGL(wgrad_kernel<128>, grid, dim3(256), 0, st, p);
+  } else {
+    dim3 grid(1, ktiles, p.S);
+    hipLaunchKernelGGL(wgrad_kernel<32>, grid, dim3(256), 0, st, p);
+  }
+  int rc = launch_status("conv_wgrad");
+  if (rc) return rc;
+  const size_t total = (size_t)p.N * p.K;
+  size_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, p);
+  return launch_status("conv_wgrad reduce");
+}
+
+// w [Co][Ci][KH][KW] -> per phase (ph,pw) of the stride: wp[phase][ci][th][tw][co] = w[co][ci][kh0(ph)+s*th][kw0(pw)+s*tw],
+// kh0(ph) = (ph + pad) % s.  Requires KH % s == 0, KW % s == 0.  The matching launch: N = Ci, taps (KH/s, KW/s), mul = -1,
+// off = (ph + pad - kh0)/s, stride 1, output step s, phase (ph,pw).
+__global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int KH, int KW, int s, int pad) {
+  const int th_n = KH / s, tw_n = KW / s;
+  const size_t per_phase = (size_t)Ci * th_n * tw_n * Co;
+  const size_t total = per_phase * s * s;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Co);
+    size_t r = i / Co;
+    const int tw = (int)(r % tw_n);
+    r /= tw_n;
+    const int th = (int)(r % th_n);
+    r /= th_n;
+    const int ci = (int)(r % Ci);
+    const int phase = (int)(r / Ci);
+    const int ph = phase / s, pw = phase % s;
+    const int kh = (ph + pad) % s + s * th, kw = (pw + pad) % s + s * tw;
+    wp[i] = w[(((size_t)co * Ci + ci) * KH + kh) * KW + kw];
+  }
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float slope, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+
+// db[n] = sum_m dy[m][n]; one block per 64 columns, 4 waves stride the rows, ordered final sum (deterministic).
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int N) {
+  __shared__ float sh[4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  float s = 0.f;
+  if (n < N)
+    for (int m = w; m < M; m += 4) s += dy[(size_t)m * N + n];
+  sh[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && n < N) db[n] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+}  // namespace m2h
+
+using namespace m2h;
+
+extern "C" {
+
+size_t m2h_conv_wgrad_workspace_bytes(const m2h_conv_args* args) { return args ? conv_wgrad_workspace_bytes(*args) : 0; }
+
+int m2h_conv_wgrad_f32(const m2h_conv_args* args, const float* dy, int ldy, float* dw, m2h_stream stream) {
+  M2H_REQUIRE(args != nullptr, "conv_wgrad: null args");
+  return conv_wgrad_f32(*args, dy, ldy, dw, as_stream(stream));
+}
+
+int m2h_pack_dgrad_weight(const float* w, float* wp, int Co, int Ci, int KH, int KW, int stride, int pad, m2h_stream stream) {
+  M2H_REQUIRE(w && wp && Co > 0 && Ci > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "pack_dgrad_weight: bad arguments");
+  M2H_REQUIRE(KH % stride == 0 && KW % stride == 0, "pack_dgrad_weight: kernel size must be a multiple of the stride");
+  const size_t total = (size_t)Co * Ci * KH * KW;
+  size_t g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), w, wp, Co, Ci, KH, KW, stride, pad);
+  return launch_status("pack_dgrad_weight");
+}
+
+int m2h_act_bwd(const float* dy, const float* y, float slope, float* out, size_t n, m2h_stream stream) {
+  M2H_REQUIRE(dy && y && out && n > 0, "act_bwd: bad arguments");
+  size_t g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), dy, y, slope, out, n);
+  return launch_status("act_bwd");
+}
+
+int m2h_bias_grad(const float* dy, float* db, int M, int N, m2h_stream stream) {
+  M2H_REQUIRE(dy && db && M > 0 && N > 0, "bias_grad: bad arguments");
+  hipLaunchKernelGGL(bias_grad_kernel, dim3((N + 63) / 64), dim3(256), 0, as_stream(stream), dy, db, M, N);
+  return launch_status("bias_grad");
+}
+
+}  // extern "C"

@@ -232,10 +232,11 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__
                                                        const float* __restrict__ adv, const float* __restrict__ old_logp,
                                                        float clip, int use_clipped_value_loss, float* __restrict__ out,
                                                        float* __restrict__ g_values, float* __restrict__ g_logp,
-                                                       float value_loss_coef, int n) {
+                                                       float value_loss_coef, const float* __restrict__ entropy, float entropy_coef, int n) {
   __shared__ float sh[4];
-  float sv = 0.f, sa = 0.f;
+  float sv = 0.f, sa = 0.f, se = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) {
+    if (entropy != nullptr) se += entropy[i];
     const float ratio = expf(logp[i] - old_logp[i]);
     const float a = adv[i];
     const float s1 = ratio * a;
@@ -269,9 +270,12 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__
   }
   const float tv = block_sum(sv, sh);
   const float ta = block_sum(sa, sh);
+  const float te = block_sum(se, sh);
   if (threadIdx.x == 0) {
     out[0] = 0.5f * tv / (float)n;
     out[1] = -ta / (float)n;
+    out[2] = te / (float)n;                                                      // dist_entropy (mean over rows)
+    out[3] = out[0] * value_loss_coef + out[1] - out[2] * entropy_coef;          // total_loss (ppo.py:150-154)
   }
 }
 
@@ -338,6 +342,181 @@ __global__ __launch_bounds__(256) void stft_l2_kernel(const float* __restrict__ 
     tot += block_sum(s, sh) / (float)(2 * L);
   }
   if (threadIdx.x == 0) out[e] = tot;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// training-side kernels: GRU / heads backward, losses, grad-norm clipping, Adam
+// ---------------------------------------------------------------------------------------------------------------
+
+// Backward of gru_gates_kernel for one time step.  Inputs as the forward plus dh = dL/dh_out.  Outputs:
+//   dgi  [M,3H] = dL/d(x W_ih^T + b_ih)           dpre [M,3H] = dL/d(m * gh_raw + b_hh)  (so dL/dgh_raw = m * dpre)
+//   dhp  [M,H]  = dh * z  (direct path to the masked previous hidden state; caller applies the mask)
+//   hpm  [M,H]  = m * hprev  (masked previous hidden state, the A operand of the W_hh weight gradient)
+__global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh_raw,
+                                                            const float* __restrict__ bhh, const float* __restrict__ hprev,
+                                                            const float* __restrict__ mask, const float* __restrict__ dh,
+                                                            float* __restrict__ dgi, float* __restrict__ dpre, float* __restrict__ dhp,
+                                                            float* __restrict__ hpm, int M, int H) {
+  const int total = M * H;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int row = i / H, j = i - row * H;
+    const float m = mask != nullptr ? mask[row] : 1.f;
+    const size_t o = (size_t)row * 3 * H;
+    const float r = sigmoidf_(gi[o + j] + (m * gh_raw[o + j] + bhh[j]));
+    const float z = sigmoidf_(gi[o + H + j] + (m * gh_raw[o + H + j] + bhh[H + j]));
+    const float hn = m * gh_raw[o + 2 * H + j] + bhh[2 * H + j];
+    const float n = tanhf(gi[o + 2 * H + j] + r * hn);
+    const float hp = m * hprev[i];
+    const float g = dh[i];
+    const float dn = g * (1.f - z);
+    const float dz = g * (hp - n);
+    const float dan = dn * (1.f - n * n);
+    const float dr = dan * hn;
+    const float daz = dz * z * (1.f - z);
+    const float dar = dr * r * (1.f - r);
+    dgi[o + j] = dar;
+    dgi[o + H + j] = daz;
+    dgi[o + 2 * H + j] = dan;
+    dpre[o + j] = dar;
+    dpre[o + H + j] = daz;
+    dpre[o + 2 * H + j] = dan * r;
+    dhp[i] = g * z;
+    hpm[i] = hp;
+  }
+}
+
+// out = a + mask_row * (b + c): total gradient of h_{t-1} = output-path gradient + masked recurrent-path gradient
+__global__ void gru_bwd_combine_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                       const float* __restrict__ mask, float* __restrict__ out, int M, int H) {
+  const int total = M * H;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const float m = mask != nullptr ? mask[i / H] : 1.f;
+    out[i] = (a != nullptr ? a[i] : 0.f) + m * (b[i] + c[i]);
+  }
+}
+
+// Backward of policy_heads_kernel: one wave per row.  g_value, g_logp, g_ent_rows = dL/d(value | logp_act | entropy) per row.
+//   dz [M][ZS]: columns 0..A-1 = dL/dlogits, column A = dL/dvalue, rest 0   (ZS = A+1 rounded up to 4)
+//   dfeats [M][H] = sum_a dlogit_a * Wa[a] + dvalue * Wc
+__global__ __launch_bounds__(256) void policy_heads_bwd_kernel(const float* __restrict__ logp_all, const float* __restrict__ probs,
+                                                               const long long* __restrict__ actions, const float* __restrict__ g_value,
+                                                               const float* __restrict__ g_logp, const float* __restrict__ g_ent_rows, const float* __restrict__ Wa,
+                                                               const float* __restrict__ Wc, float* __restrict__ dz,
+                                                               float* __restrict__ dfeats, int M, int H, int A, int ZS) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float ent = 0.f;
+  for (int a = 0; a < A; ++a) ent -= probs[row * A + a] * logp_all[row * A + a];
+  const int act = actions != nullptr ? (int)actions[row] : -1;
+  const float gl = g_logp != nullptr ? g_logp[row] : 0.f;
+  const float gv = g_value != nullptr ? g_value[row] : 0.f;
+  const float g_ent = g_ent_rows != nullptr ? g_ent_rows[row] : 0.f;
+  float dl[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    dl[a] = 0.f;
+    if (a < A) {
+      const float p = probs[row * A + a], lp = logp_all[row * A + a];
+      dl[a] = gl * ((a == act ? 1.f : 0.f) - p) + g_ent * (-p * (lp + ent));
+    }
+  }
+  if (lane == 0) {
+    for (int a = 0; a < ZS; ++a) dz[row * ZS + a] = a < A ? dl[a] : (a == A ? gv : 0.f);
+  }
+  for (int k = lane; k < H; k += 64) {
+    float s = gv * Wc[k];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+      if (a < A) s += dl[a] * Wa[a * H + k];
+    dfeats[(size_t)row * H + k] = s;
+  }
+}
+
+// L1 loss against a strided ground truth (F.l1_loss(pred, gt_comps[..., off], reduction=mean); ppo.py:213,216,221):
+// partial sums per block into part[blockIdx], grad[i] = sign(p - g) / n  (sign(0) = 0 like torch).
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int gt_stride, int gt_off,
+                                                      float* __restrict__ part, float* __restrict__ grad, size_t n) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  const float inv = 1.f / (float)n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = pred[i] - gt[i * gt_stride + gt_off];
+    s += fabsf(d);
+    if (grad != nullptr) grad[i] = d > 0.f ? inv : (d < 0.f ? -inv : 0.f);
+  }
+  const float t = block_sum(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// bin loss for logging (ppo.py:219-221; passive_trainer.py:270-272): mean | (exp(mix)-1)*mask - gt_bin_comps[..., 2c] | over [.., c<2]
+__global__ __launch_bounds__(256) void bin_l1_kernel(const float* __restrict__ mix, const float* __restrict__ masks, const float* __restrict__ gt,
+                                                     int Cg, float* __restrict__ part, float* __restrict__ grad_masks, size_t npix) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  const float inv = 1.f / (float)(2 * npix);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * npix; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i >> 1;
+    const int c = (int)(i & 1);
+    const float e = expf(mix[i]) - 1.f;
+    const float d = e * masks[i] - gt[pix * Cg + 2 * c];
+    s += fabsf(d);
+    if (grad_masks != nullptr) grad_masks[i] = (d > 0.f ? inv : (d < 0.f ? -inv : 0.f)) * e;
+  }
+  const float t = block_sum(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// out[0] = scale * sum(part[0..n))   (ordered, single thread: n <= a few thousand)
+__global__ void sum_partials_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += part[i];
+    out[0] = s * scale;
+  }
+}
+
+// sum of squares partials (grad-norm): part[blockIdx] = sum x^2 over the block's grid-stride share
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ part) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += x[i] * x[i];
+  const float t = block_sum(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// clip_grad_norm_ coefficient (torch: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1): coef[0] = coefficient,
+// coef[1] = total_norm.  part holds nparts sums of squares.  max_norm <= 0 -> coef 1.
+__global__ void clip_coef_kernel(const float* __restrict__ part, int nparts, float max_norm, float* __restrict__ coef) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < nparts; ++i) s += part[i];
+    const float norm = sqrtf(s);
+    float c = 1.f;
+    if (max_norm > 0.f) c = fminf(max_norm / (norm + 1e-6f), 1.f);
+    coef[0] = c;
+    coef[1] = norm;
+  }
+}
+
+// torch.optim.Adam step (no amsgrad, no weight decay) over a flat buffer; the gradient is scaled by coef[0] (clip) * gscale
+// (1/world_size after a sum all-reduce) and written back scaled (as clip_grad_norm_ does in place).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   size_t n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                   const float* __restrict__ coef, float gscale) {
+  const float c = (coef != nullptr ? coef[0] : 1.f) * gscale;
+  const float step = lr / bc1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * c;
+    g[i] = gi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= step * (mi / denom);
+  }
 }
 
 // Minibatch gather of the recurrent generators (common/rollout_storage.py:182-298,392-457):
@@ -450,12 +629,73 @@ int m2h_adv_apply(float* adv, const float* gmean, const float* gvar, int n, floa
 }
 
 int m2h_ppo_loss(const float* values, const float* logp, const float* old_values, const float* returns, const float* adv,
-                 const float* old_logp, float clip, int use_clipped_value_loss, float value_loss_coef, float* out, float* g_values,
-                 float* g_logp, int n, m2h_stream stream) {
+                 const float* old_logp, const float* entropy, float clip, int use_clipped_value_loss, float value_loss_coef,
+                 float entropy_coef, float* out, float* g_values, float* g_logp, int n, m2h_stream stream) {
   M2H_REQUIRE(values && logp && old_values && returns && adv && old_logp && out && n > 0, "ppo_loss: bad arguments");
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), values, logp, old_values, returns, adv, old_logp, clip,
-                     use_clipped_value_loss, out, g_values, g_logp, value_loss_coef, n);
+                     use_clipped_value_loss, out, g_values, g_logp, value_loss_coef, entropy, entropy_coef, n);
   return launch_status("ppo_loss");
+}
+
+int m2h_gru_gates_bwd(const float* gi, const float* gh_raw, const float* bhh, const float* hprev, const float* mask, const float* dh,
+                      float* dgi, float* dpre, float* dhp, float* hpm, int M, int H, m2h_stream stream) {
+  M2H_REQUIRE(gi && gh_raw && bhh && hprev && dh && dgi && dpre && dhp && hpm && M > 0 && H > 0, "gru_gates_bwd: bad arguments");
+  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(grid_for((size_t)M * H)), dim3(256), 0, as_stream(stream), gi, gh_raw, bhh, hprev, mask, dh,
+                     dgi, dpre, dhp, hpm, M, H);
+  return launch_status("gru_gates_bwd");
+}
+
+int m2h_gru_bwd_combine(const float* a, const float* b, const float* c, const float* mask, float* out, int M, int H, m2h_stream stream) {
+  M2H_REQUIRE(b && c && out && M > 0 && H > 0, "gru_bwd_combine: bad arguments");
+  hipLaunchKernelGGL(gru_bwd_combine_kernel, dim3(grid_for((size_t)M * H)), dim3(256), 0, as_stream(stream), a, b, c, mask, out, M, H);
+  return launch_status("gru_bwd_combine");
+}
+
+int m2h_policy_heads_bwd(const float* logp_all, const float* probs, const long long* actions, const float* g_value, const float* g_logp,
+                         const float* g_ent, const float* Wa, const float* Wc, float* dz, float* dfeats, int M, int H, int A, int ZS,
+                         m2h_stream stream) {
+  M2H_REQUIRE(logp_all && probs && Wa && Wc && dz && dfeats && M > 0 && H > 0 && A > 0 && A <= 8 && ZS >= A + 1 && ZS % 4 == 0,
+              "policy_heads_bwd: bad arguments");
+  hipLaunchKernelGGL(policy_heads_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), logp_all, probs, actions, g_value, g_logp,
+                     g_ent, Wa, Wc, dz, dfeats, M, H, A, ZS);
+  return launch_status("policy_heads_bwd");
+}
+
+#define M2H_PARTS 1024
+int m2h_l1_loss(const float* pred, const float* gt, int gt_stride, int gt_off, float* loss, float* grad, float* scratch, size_t n,
+                m2h_stream stream) {
+  M2H_REQUIRE(pred && gt && loss && scratch && n > 0 && gt_stride > 0 && gt_off >= 0 && gt_off < gt_stride, "l1_loss: bad arguments");
+  const unsigned g = grid_for(n, M2H_PARTS);
+  hipLaunchKernelGGL(l1_loss_kernel, dim3(g), dim3(256), 0, as_stream(stream), pred, gt, gt_stride, gt_off, scratch, grad, n);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch, (int)g, 1.f / (float)n, loss);
+  return launch_status("l1_loss");
+}
+
+int m2h_bin_l1_loss(const float* mix, const float* masks, const float* gt_bin_comps, int Cg, float* loss, float* grad_masks, float* scratch,
+                    size_t npix, m2h_stream stream) {
+  M2H_REQUIRE(mix && masks && gt_bin_comps && loss && scratch && npix > 0 && Cg >= 3, "bin_l1_loss: bad arguments");
+  const unsigned g = grid_for(2 * npix, M2H_PARTS);
+  hipLaunchKernelGGL(bin_l1_kernel, dim3(g), dim3(256), 0, as_stream(stream), mix, masks, gt_bin_comps, Cg, scratch, grad_masks, npix);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch, (int)g, 1.f / (float)(2 * npix), loss);
+  return launch_status("bin_l1_loss");
+}
+
+int m2h_grad_clip_coef(const float* g, size_t n, float max_norm, float* coef, float* scratch, m2h_stream stream) {
+  M2H_REQUIRE(g && coef && scratch && n > 0, "grad_clip_coef: bad arguments");
+  const unsigned gr = grid_for(n, M2H_PARTS);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(gr), dim3(256), 0, as_stream(stream), g, n, scratch);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch, (int)gr, max_norm, coef);
+  return launch_status("grad_clip_coef");
+}
+
+int m2h_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,
+                  const float* coef, float gscale, m2h_stream stream) {
+  M2H_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps, bc1,
+                     sqrtf(bc2), coef, gscale);
+  return launch_status("adam_step");
 }
 
 int m2h_sq_stats(const float* pred, const float* gt_comps, int gt_stride, int gt_off, float* stats, int N, int L, m2h_stream stream) {

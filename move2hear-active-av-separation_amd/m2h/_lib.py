@@ -15,7 +15,7 @@ _REPO_ROOT = os.path.dirname(_PKG_ROOT)
 CSRC = os.path.join(_PKG_ROOT, "csrc")
 INCLUDE = os.path.join(_REPO_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libm2h.so")
-SOURCES = ["conv_igemm.hip", "layout.hip", "rl_ops.hip", "api.hip"]
+SOURCES = ["conv_igemm.hip", "conv_bwd.hip", "layout.hip", "rl_ops.hip", "api.hip"]
 
 _lock = threading.Lock()
 _lib = None
@@ -100,9 +100,21 @@ SIGNATURES = {
     "m2h_advantages": [_P, _P, _P, _P, _I, _I, _F, _P],
     "m2h_adv_sqdiff": [_P, _P, _P, _I, _P],
     "m2h_adv_apply": [_P, _P, _P, _I, _F, _P],
-    "m2h_ppo_loss": [_P, _P, _P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _I, _P],
+    "m2h_ppo_loss": [_P, _P, _P, _P, _P, _P, _P, _F, _I, _F, _F, _P, _P, _P, _I, _P],
+    "m2h_gru_gates_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "m2h_gru_bwd_combine": [_P, _P, _P, _P, _P, _I, _I, _P],
+    "m2h_policy_heads_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "m2h_l1_loss": [_P, _P, _I, _I, _P, _P, _P, _Z, _P],
+    "m2h_bin_l1_loss": [_P, _P, _P, _I, _P, _P, _P, _Z, _P],
+    "m2h_grad_clip_coef": [_P, _Z, _F, _P, _P, _P],
+    "m2h_adam_step": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _P, _F, _P],
     "m2h_sq_stats": [_P, _P, _I, _I, _P, _I, _I, _P],
     "m2h_rewards_from_stats": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "m2h_conv_wgrad_workspace_bytes": [ctypes.POINTER(ConvArgs)],
+    "m2h_conv_wgrad_f32": [ctypes.POINTER(ConvArgs), _P, _I, _P, _P],
+    "m2h_pack_dgrad_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "m2h_act_bwd": [_P, _P, _F, _P, _Z, _P],
+    "m2h_bias_grad": [_P, _P, _I, _I, _P],
     "m2h_gather_envs": [_P, _P, _P, _I, _I, _I, _Z, _P],
     "m2h_stft_l2": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
 }

@@ -110,14 +110,17 @@ class RolloutStorageSep:
         self.masks = torch.ones(num_steps + 1, num_envs, 1)
         self.num_steps = num_steps
         self.step = 0
+        self.generation = 0  # bumped whenever stored observations change (keys PPO's separator-output cache)
 
     def to(self, device):
         for sensor in self.observations:
             self.observations[sensor] = self.observations[sensor].to(device)
         self.prev_pred_monoFromMem = self.prev_pred_monoFromMem.to(device)
         self.masks = self.masks.to(device)
+        self.generation += 1
 
     def insert(self, observations, masks, pred_monoFromMem=None):
+        self.generation += 1
         for sensor in observations:
             self.observations[sensor][self.step + 1].copy_(observations[sensor])
         self.prev_pred_monoFromMem[self.step + 1].copy_(pred_monoFromMem)
@@ -125,12 +128,20 @@ class RolloutStorageSep:
         self.step = (self.step + 1) % self.num_steps
 
     def after_update(self):
+        # NB: copies obs[-1] -> obs[0]; when the buffer has just been refilled (step wrapped to 0) obs[0] already holds the
+        # same tensor the policy storage carried over, so re-running after_update between the 6 sub-updates of a cycle does
+        # not change what is stored: compare before bumping the generation would need a sync, so track it by step instead.
+        changed = self.step != getattr(self, "_last_after_update_step", None) or self.generation != getattr(self, "_last_after_update_gen", None)
         for sensor in self.observations:
             self.observations[sensor][0].copy_(self.observations[sensor][-1])
         self.prev_pred_monoFromMem[0].copy_(self.prev_pred_monoFromMem[-1])
         self.masks[0].copy_(self.masks[-1])
+        if changed:
+            self.generation += 1
+            self._last_after_update_gen = self.generation
+            self._last_after_update_step = self.step
 
-    def recurrent_generator(self, num_mini_batch):
+    def recurrent_generator(self, num_mini_batch, with_perm=False):
         num_processes = self.masks.size(1)
         assert num_processes >= num_mini_batch
         num_envs_per_batch = num_processes // num_mini_batch
@@ -139,9 +150,10 @@ class RolloutStorageSep:
         for start_ind in range(0, num_processes, num_envs_per_batch):
             idx = perm[start_ind:start_ind + num_envs_per_batch].to(dev)
             observations_batch = {s: ops.gather_envs(self.observations[s][:-1], idx) for s in self.observations}
-            yield (
+            out = (
                 observations_batch,
                 ops.gather_envs(self.prev_pred_monoFromMem[1:], idx),
                 ops.gather_envs(self.prev_pred_monoFromMem[:-1], idx),
                 ops.gather_envs(self.masks[:-1], idx),
             )
+            yield out + (idx,) if with_perm else out

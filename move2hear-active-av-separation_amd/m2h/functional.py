@@ -1,0 +1,349 @@
+"""Differentiable front ends: torch.autograd.Function wrappers whose forward AND backward arithmetic run in libm2h.so.
+
+PyTorch's autograd engine only orders the calls and accumulates ``.grad`` (plumbing); every gradient value is produced by
+a HIP kernel:
+  conv / linear   dgrad = forward igemm engine on m2h_pack_dgrad_weight phase matrices; wgrad = m2h_conv_wgrad_f32;
+                  bias = m2h_bias_grad; fused ReLU/LeakyReLU = m2h_act_bwd
+Replaces torch's Conv2d/Linear autograd in audio_separation/rl/ppo/ppo.py:159-161 (update_pol) and :228-230 (update_sep).
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+
+
+def _conv_args(x, x2, n_out, kh, kw, stride, pad, Ho, Wo):
+    B, H, W, C0 = x.shape
+    a = _lib.ConvArgs()
+    a.src0, a.src1, a.C0, a.C1 = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), C0, (x2.shape[3] if x2 is not None else 0)
+    a.B, a.Hi, a.Wi, a.Hq, a.Wq = B, H, W, Ho, Wo
+    a.stride, a.nth, a.ntw, a.mulh, a.offh, a.mulw, a.offw = stride, kh, kw, 1, -pad, 1, -pad
+    a.conv_transpose, a.N = 0, n_out
+    a.Ho, a.Wo, a.os, a.ph, a.pw, a.ldc, a.out_mode = Ho, Wo, 1, 0, 0, n_out, 0
+    return a
+
+
+def conv_wgrad(x, x2, dy, n_out, kh, kw, stride, pad):
+    """Packed weight gradient [n_out, kh*kw*(C0+C1)] of a conv whose NHWC inputs were x (+x2) and NHWC output grad is dy."""
+    B, Ho, Wo, N = dy.shape
+    a = _conv_args(x, x2, n_out, kh, kw, stride, pad, Ho, Wo)
+    lib = _lib.load()
+    K = kh * kw * (x.shape[3] + (x2.shape[3] if x2 is not None else 0))
+    dw = torch.empty((n_out, K), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        nbytes = lib.m2h_conv_wgrad_workspace_bytes(ctypes.byref(a))
+        ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+        M = B * Ho * Wo
+        meta = {"kernel": "wgrad_f32", "M": M, "N": n_out, "K": K, "flops": 2.0 * M * n_out * K, "bytes": 4.0 * (x.numel() + dy.numel() + dw.numel())}
+        ops._timed("conv_wgrad", meta, x.device,
+                   lambda: _lib.check(lib.m2h_conv_wgrad_f32(ctypes.byref(a), ops._ptr(dy), N, ops._ptr(dw), ops._stream(x)), "m2h_conv_wgrad_f32"))
+    return dw
+
+
+def pack_dgrad_weight(w4d, stride, pad):
+    Co, Ci, KH, KW = w4d.shape
+    wp = torch.empty((stride * stride, Ci, (KH // stride) * (KW // stride) * Co), device=w4d.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(w4d.device):
+        _lib.check(lib.m2h_pack_dgrad_weight(ops._ptr(w4d), ops._ptr(wp), Co, Ci, KH, KW, stride, pad, ops._stream(w4d)), "m2h_pack_dgrad_weight")
+    return wp
+
+
+def conv_dgrad(dy, w4d, in_hw, stride, pad, ci_out=None):
+    """Input gradient [B,H,W,Ci] of Conv2d(w4d [Co,Ci,KH,KW], stride, pad) given the NHWC output gradient dy [B,Ho,Wo,Co]."""
+    B, Ho, Wo, Co = dy.shape
+    _, Ci, KH, KW = w4d.shape
+    H, W = in_hw
+    s = stride
+    wp = pack_dgrad_weight(w4d, s, pad)
+    dx = torch.empty((B, H, W, Ci), device=dy.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(dy.device):
+        for ph in range(s):
+            for pw in range(s):
+                Hq, Wq = (H - ph + s - 1) // s, (W - pw + s - 1) // s
+                if Hq <= 0 or Wq <= 0:
+                    continue
+                a = _lib.ConvArgs()
+                a.src0, a.src1, a.C0, a.C1 = dy.data_ptr(), None, Co, 0
+                a.B, a.Hi, a.Wi, a.Hq, a.Wq = B, Ho, Wo, Hq, Wq
+                a.stride, a.nth, a.ntw = 1, KH // s, KW // s
+                a.mulh, a.offh = -1, (ph + pad - (ph + pad) % s) // s
+                a.mulw, a.offw = -1, (pw + pad - (pw + pad) % s) // s
+                a.conv_transpose, a.wp, a.N = 0, wp[ph * s + pw].data_ptr(), Ci
+                a.scale, a.shift, a.slope, a.cls_table, a.cls_val = None, None, 1.0, None, None
+                a.dst, a.Ho, a.Wo, a.os, a.ph, a.pw, a.ldc, a.out_mode = dx.data_ptr(), H, W, s, ph, pw, Ci, 0
+                nbytes = lib.m2h_conv_igemm_workspace_bytes(ctypes.byref(a))
+                ws = torch.empty((nbytes + 3) // 4, device=dy.device, dtype=torch.float32) if nbytes else None
+                a.workspace, a.workspace_bytes = (ws.data_ptr() if ws is not None else None), nbytes
+                M = B * Hq * Wq
+                K = (KH // s) * (KW // s) * Co
+                meta = {"kernel": ops.igemm_config(Ci), "M": M, "N": Ci, "K": K, "flops": 2.0 * M * Ci * K}
+                ops._timed("conv_dgrad", meta, dy.device,
+                           lambda: _lib.check(lib.m2h_conv_igemm_f32(ctypes.byref(a), ops._stream(dy)), "m2h_conv_igemm_f32(dgrad)"))
+    return dx
+
+
+def act_bwd(dy, y, slope):
+    out = torch.empty_like(dy)
+    lib = _lib.load()
+    with torch.cuda.device(dy.device):
+        _lib.check(lib.m2h_act_bwd(ops._ptr(dy), ops._ptr(y), float(slope), ops._ptr(out), dy.numel(), ops._stream(dy)), "m2h_act_bwd")
+    return out
+
+
+def bias_grad(dy2d):
+    M, N = dy2d.shape
+    db = torch.empty(N, device=dy2d.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(dy2d.device):
+        _lib.check(lib.m2h_bias_grad(ops._ptr(dy2d), ops._ptr(db), M, N, ops._stream(dy2d)), "m2h_bias_grad")
+    return db
+
+
+_param_epoch = 0
+
+
+def bump_param_epoch():
+    """Called by FlatAdam.step: its kernels update parameters through raw pointers, which torch's version counters do not
+    see, so packed-weight memos also key on this epoch."""
+    global _param_epoch
+    _param_epoch += 1
+
+
+class _PackMemo:
+    """Packed forward weights per (data_ptr, version, optimizer epoch): re-packed only when the weights may have changed."""
+
+    def __init__(self):
+        self.key, self.val = None, None
+
+    def get(self, w, ci_pad):
+        key = (w.data_ptr(), w._version, ci_pad, _param_epoch)
+        if key != self.key:
+            self.val = ops.pack_conv_weight_ex(w.detach().contiguous(), w.shape[1], ci_pad)
+            self.key = key
+        return self.val
+
+
+class Conv2dNHWC(torch.autograd.Function):
+    """y = act(conv2d(cat(x, x2), w) + b) over NHWC activations; w, b in torch layout ([Co,Ci,KH,KW], [Co]).
+    ``deslice``: the output is stored de-sliced in the reference's BHWC layout (memory_nets.py:62-67)."""
+
+    @staticmethod
+    def forward(ctx, x, x2, w, b, stride, pad, slope, deslice, memo, name):
+        Co, Ci, KH, KW = w.shape
+        c_in = x.shape[3] + (x2.shape[3] if x2 is not None else 0)
+        wp = memo.get(w, c_in) if memo is not None else ops.pack_conv_weight_ex(w.detach().contiguous(), Ci, c_in)
+        y = ops.conv2d_nhwc(x, wp, Co, KH, KW, stride=stride, pad=pad, bias=b.detach() if b is not None else None, slope=slope, x2=x2,
+                            deslice=deslice, name=name)
+        ctx.cfg = (stride, pad, slope, deslice, Ci, KH, KW, Co)
+        ctx.has_x2 = x2 is not None
+        ctx.save_for_backward(x, x2 if x2 is not None else x.new_empty(0), w, y if slope != 1.0 else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, pad, slope, deslice, Ci, KH, KW, Co = ctx.cfg
+        x, x2, w, y = ctx.saved_tensors
+        x2 = x2 if ctx.has_x2 else None
+        dy = dy.contiguous()
+        if deslice:
+            # BHWC [B,16*Ho,Wo,Co/16] gradient -> NHWC [B,Ho,Wo,Co]: the same 16-way slice map as the forward input glue
+            dy = ops.slice_concat_input(dy, op=0)
+            if slope != 1.0:
+                raise NotImplementedError("m2h Conv2dNHWC: activation + de-sliced output has no backward")
+        if slope != 1.0:
+            dy = act_bwd(dy, y, slope)
+        B, Ho, Wo, _ = dy.shape
+        gx = gx2 = gw = gb = None
+        if ctx.needs_input_grad[2]:
+            c_in = x.shape[3] + (x2.shape[3] if x2 is not None else 0)
+            dwp = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad)  # [Co, KH*KW*c_in]
+            gw = dwp.view(Co, KH, KW, c_in)[..., :Ci].permute(0, 3, 1, 2).contiguous()
+        if ctx.needs_input_grad[3]:
+            gb = bias_grad(dy.view(B * Ho * Wo, Co))
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
+            if x2 is not None:
+                raise NotImplementedError("m2h Conv2dNHWC: input gradient of a two-source conv is not built yet")
+            gx = conv_dgrad(dy, w.detach().contiguous(), (x.shape[1], x.shape[2]), stride, pad)
+            if gx.shape[3] != x.shape[3]:  # channel-padded input (VisualCNN 3 -> 4): padded channels carry no gradient
+                gx = torch.nn.functional.pad(gx, (0, x.shape[3] - gx.shape[3]))
+        return gx, gx2, gw, gb, None, None, None, None, None, None
+
+
+def conv2d(x, w, b=None, stride=1, pad=0, slope=1.0, x2=None, deslice=False, memo=None, name="conv2d"):
+    return Conv2dNHWC.apply(x, x2, w, b, stride, pad, slope, deslice, memo, name)
+
+
+def linear(x, w, b=None, slope=1.0, memo=None, name="linear"):
+    """y = act(x W^T + b) with autograd (x [M,K], w [N,K])."""
+    M, K = x.shape
+    y = conv2d(x.reshape(M, 1, 1, K), w.reshape(w.shape[0], K, 1, 1), b, 1, 0, slope, memo=memo, name=name)
+    return y.reshape(M, w.shape[0])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# GRU (sequence with per-step hidden resets), policy heads, losses
+# ----------------------------------------------------------------------------------------------------------------
+def _lin_nograd(x, w_nk, bias=None, name="linear"):
+    return ops.linear(x, w_nk, bias, name=name)
+
+
+class GRUSequence(torch.autograd.Function):
+    """h_t = GRUCell(x_t, h_{t-1} * mask_t) for t < T over N rows; x [T*N, I], h0 [N, H], masks [T*N] -> (out [T*N, H], hT).
+    Covers single_forward (T = 1) and seq_forward (rnn_state_encoder.py:74-137).  Backward = BPTT with HIP kernels:
+    per step one fused gate-gradient kernel + one recurrent GEMM; the four weight/bias gradients and dx are batched GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, h0, masks, w_ih, w_hh, b_ih, b_hh, T):
+        N, H = h0.shape
+        gi = _lin_nograd(x.contiguous(), w_ih.detach(), b_ih.detach(), "gru.ih")  # [T*N, 3H]
+        masks = masks.reshape(T * N).contiguous()
+        out = torch.empty((T * N, H), device=x.device, dtype=torch.float32)
+        gh = torch.empty((T * N, 3 * H), device=x.device, dtype=torch.float32)
+        h = h0.contiguous()
+        for t in range(T):
+            sl = slice(t * N, (t + 1) * N)
+            ght = _lin_nograd(h, w_hh.detach(), None, "gru.hh")
+            gh[sl].copy_(ght)
+            h = ops.gru_gates(gi[sl], ght, b_hh.detach(), h, masks[sl])
+            out[sl].copy_(h)
+        ctx.T = T
+        ctx.save_for_backward(x, h0, masks, w_ih, w_hh, b_hh, gi, gh, out)
+        return out, h
+
+    @staticmethod
+    def backward(ctx, g_out, g_hT):
+        x, h0, masks, w_ih, w_hh, b_hh, gi, gh, out = ctx.saved_tensors
+        T = ctx.T
+        N, H = h0.shape
+        dev = x.device
+        lib = _lib.load()
+        g_out = g_out.contiguous() if g_out is not None else torch.zeros_like(out)
+        dgi = torch.empty_like(gi)
+        dpre = torch.empty_like(gh)
+        hpm = torch.empty_like(out)
+        dhp = torch.empty((N, H), device=dev)
+        # W_hh^T as an [H][3H] "Linear" weight for the recurrent dgrad GEMM
+        whh_t = pack_dgrad_weight(w_hh.detach().reshape(3 * H, H, 1, 1).contiguous(), 1, 0).view(H, 3 * H)
+        dh = g_out[(T - 1) * N:T * N].clone()
+        if g_hT is not None:
+            dh = dh + g_hT  # tiny [N,H] add; hT is rarely used downstream
+        dh = dh.contiguous()
+        with torch.cuda.device(dev):
+            for t in range(T - 1, -1, -1):
+                sl = slice(t * N, (t + 1) * N)
+                hprev = out[(t - 1) * N:t * N] if t > 0 else h0
+                _lib.check(lib.m2h_gru_gates_bwd(ops._ptr(gi[sl]), ops._ptr(gh[sl]), ops._ptr(b_hh), ops._ptr(hprev.contiguous()),
+                                                 ops._ptr(masks[sl]), ops._ptr(dh), ops._ptr(dgi[sl]), ops._ptr(dpre[sl]), ops._ptr(dhp),
+                                                 ops._ptr(hpm[sl]), N, H, ops._stream(x)), "m2h_gru_gates_bwd")
+                rec = _lin_nograd(dpre[sl], whh_t, None, "gru.hh.dgrad")  # dpre @ W_hh  [N,H]
+                nxt = torch.empty((N, H), device=dev)
+                a = g_out[(t - 1) * N:t * N] if t > 0 else None
+                _lib.check(lib.m2h_gru_bwd_combine(ops._ptr(a), ops._ptr(rec), ops._ptr(dhp), ops._ptr(masks[sl]), ops._ptr(nxt), N, H,
+                                                   ops._stream(x)), "m2h_gru_bwd_combine")
+                dh = nxt
+        g_h0 = dh if ctx.needs_input_grad[1] else None
+        # batched parameter / input gradients
+        M = T * N
+        I = x.shape[1]
+        g_wih = conv_wgrad(x.reshape(M, 1, 1, I), None, dgi.view(M, 1, 1, 3 * H), 3 * H, 1, 1, 1, 0) if ctx.needs_input_grad[3] else None
+        g_whh = conv_wgrad(hpm.view(M, 1, 1, H), None, dpre.view(M, 1, 1, 3 * H), 3 * H, 1, 1, 1, 0) if ctx.needs_input_grad[4] else None
+        g_bih = bias_grad(dgi) if ctx.needs_input_grad[5] else None
+        g_bhh = bias_grad(dpre) if ctx.needs_input_grad[6] else None
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            wih_t = pack_dgrad_weight(w_ih.detach().reshape(3 * H, I, 1, 1).contiguous(), 1, 0).view(I, 3 * H)
+            g_x = _lin_nograd(dgi, wih_t, None, "gru.ih.dgrad")
+        return g_x, g_h0, None, g_wih, g_whh, g_bih, g_bhh, None
+
+
+class PolicyHeads(torch.autograd.Function):
+    """(value [M,1], logp_act [M,1], entropy [M], probs [M,A], logp_all [M,A]) from feats and the two Linear heads
+    (common/utils.py:42-50, rl/ppo/policy.py:15-23); backward for value / logp_act / entropy."""
+
+    @staticmethod
+    def forward(ctx, feats, wa, ba, wc, bc, actions):
+        value, logp_all, probs, ent, logp_act = ops.policy_heads(feats.contiguous(), wa.detach(), ba.detach(), wc.detach(), bc.detach(),
+                                                                 actions)
+        ctx.save_for_backward(feats, wa, wc, logp_all, probs, actions if actions is not None else feats.new_empty(0))
+        ctx.has_actions = actions is not None
+        ctx.mark_non_differentiable(probs, logp_all)
+        if logp_act is None:
+            logp_act = feats.new_zeros((feats.shape[0], 1))
+        return value, logp_act, ent, probs, logp_all
+
+    @staticmethod
+    def backward(ctx, g_value, g_logp, g_ent, _gp, _gl):
+        feats, wa, wc, logp_all, probs, actions = ctx.saved_tensors
+        M, H = feats.shape
+        A = wa.shape[0]
+        ZS = (A + 1 + 3) // 4 * 4
+        dev = feats.device
+        ge = g_ent.reshape(-1).contiguous() if g_ent is not None else None
+        dz = torch.empty((M, ZS), device=dev)
+        dfeats = torch.empty((M, H), device=dev)
+        gv = g_value.reshape(-1).contiguous() if g_value is not None else None
+        gl = g_logp.reshape(-1).contiguous() if (g_logp is not None and ctx.has_actions) else None
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            _lib.check(lib.m2h_policy_heads_bwd(ops._ptr(logp_all), ops._ptr(probs), ops._ptr(actions if ctx.has_actions else None),
+                                                ops._ptr(gv), ops._ptr(gl), ops._ptr(ge), ops._ptr(wa.detach()), ops._ptr(wc.detach()), ops._ptr(dz),
+                                                ops._ptr(dfeats), M, H, A, ZS, ops._stream(feats)), "m2h_policy_heads_bwd")
+        dw = conv_wgrad(feats.detach().reshape(M, 1, 1, H), None, dz.view(M, 1, 1, ZS), ZS, 1, 1, 1, 0)  # [ZS, H]
+        db = bias_grad(dz)
+        return dfeats, dw[:A].contiguous(), db[:A].contiguous(), dw[A:A + 1].contiguous(), db[A:A + 1].contiguous(), None
+
+
+class PPOLoss(torch.autograd.Function):
+    """total = value_loss*value_loss_coef + action_loss - entropy.mean()*entropy_coef (ppo.py:125-154), one kernel computing the
+    losses and their gradients; returns (total, stats[4] = (value_loss, action_loss, entropy, total))."""
+
+    @staticmethod
+    def forward(ctx, values, logp, entropy, old_values, returns, adv, old_logp, clip, value_loss_coef, entropy_coef, clipped):
+        out, gv, gl = ops.ppo_loss(values.contiguous(), logp.contiguous(), old_values.contiguous(), returns.contiguous(), adv.contiguous(),
+                                   old_logp.contiguous(), clip, value_loss_coef, clipped, True, entropy.contiguous(), entropy_coef)
+        ctx.save_for_backward(gv, gl)
+        ctx.ecoef = entropy_coef
+        ctx.n = values.numel()
+        ctx.mark_non_differentiable(out)
+        return out[3], out
+
+    @staticmethod
+    def backward(ctx, g_total, _g_stats):
+        gv, gl = ctx.saved_tensors
+        # g_total is 1 for total_loss.backward(); scaling by it is a scalar multiply on [n,1] tensors
+        ge = torch.full((ctx.n,), -ctx.ecoef / ctx.n, device=gv.device) * g_total
+        return gv * g_total, gl * g_total, ge, None, None, None, None, None, None, None, None
+
+
+class L1Loss(torch.autograd.Function):
+    """F.l1_loss(pred, gt_comps[..., off:off+1]) with the ground truth read strided in place (ppo.py:212-213)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt_comps, off):
+        pred = pred.contiguous()
+        n = pred.numel()
+        loss = torch.empty(1, device=pred.device)
+        grad = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+        scratch = torch.empty(1024, device=pred.device)
+        lib = _lib.load()
+        with torch.cuda.device(pred.device):
+            _lib.check(lib.m2h_l1_loss(ops._ptr(pred), ops._ptr(gt_comps), gt_comps.shape[-1], off, ops._ptr(loss), ops._ptr(grad),
+                                       ops._ptr(scratch), n, ops._stream(pred)), "m2h_l1_loss")
+        if grad is not None:
+            ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def l1_loss(pred, gt_comps, off=0):
+    if pred.numel() != gt_comps.numel() // gt_comps.shape[-1]:
+        raise RuntimeError("m2h.l1_loss: pred %s vs gt_comps %s" % (tuple(pred.shape), tuple(gt_comps.shape)))
+    return L1Loss.apply(pred, gt_comps.contiguous(), off)

@@ -407,19 +407,20 @@ def adv_apply(adv, gmean, gvar, eps=1e-5):
     return adv
 
 
-def ppo_loss(values, logp, old_values, returns, adv, old_logp, clip, value_loss_coef=1.0, use_clipped_value_loss=True, want_grads=False):
-    """-> (out[2] = (value_loss, action_loss), g_values, g_logp)."""
-    for t in (values, logp, old_values, returns, adv, old_logp):
+def ppo_loss(values, logp, old_values, returns, adv, old_logp, clip, value_loss_coef=1.0, use_clipped_value_loss=True, want_grads=False,
+             entropy=None, entropy_coef=0.0):
+    """-> (out[4] = (value_loss, action_loss, mean entropy, total_loss), g_values, g_logp)."""
+    for t in (values, logp, old_values, returns, adv, old_logp, entropy):
         _chk(t, "ppo_loss")
     n = values.numel()
-    out = torch.empty(2, device=values.device)
+    out = torch.empty(4, device=values.device)
     gv = torch.empty_like(values) if want_grads else None
     gl = torch.empty_like(logp) if want_grads else None
     lib = _lib.load()
     with torch.cuda.device(values.device):
-        _lib.check(lib.m2h_ppo_loss(_ptr(values), _ptr(logp), _ptr(old_values), _ptr(returns), _ptr(adv), _ptr(old_logp), float(clip),
-                                    1 if use_clipped_value_loss else 0, float(value_loss_coef), _ptr(out), _ptr(gv), _ptr(gl), n,
-                                    _stream(values)), "m2h_ppo_loss")
+        _lib.check(lib.m2h_ppo_loss(_ptr(values), _ptr(logp), _ptr(old_values), _ptr(returns), _ptr(adv), _ptr(old_logp), _ptr(entropy),
+                                    float(clip), 1 if use_clipped_value_loss else 0, float(value_loss_coef), float(entropy_coef), _ptr(out),
+                                    _ptr(gv), _ptr(gl), n, _stream(values)), "m2h_ppo_loss")
     return out, gv, gl
 
 
@@ -475,3 +476,17 @@ def gather_envs(src, perm):
         _timed("gather_envs", {"bytes": 2.0 * dst.numel() * dst.element_size()}, src.device,
                lambda: _lib.check(lib.m2h_gather_envs(_ptr(src), _ptr(perm), _ptr(dst), T, N, nsel, row, _stream(src)), "m2h_gather_envs"))
     return dst
+
+
+def bin_l1_loss(mix, masks, gt_bin_comps):
+    """mean |(exp(mix)-1)*masks - gt_bin_mag| (logging loss of update_sep, ppo.py:219-221) -> 0-dim device tensor."""
+    for t in (mix, masks, gt_bin_comps):
+        _chk(t, "bin_l1_loss")
+    npix = mix.numel() // 2
+    loss = torch.empty(1, device=mix.device)
+    scratch = torch.empty(1024, device=mix.device)
+    lib = _lib.load()
+    with torch.cuda.device(mix.device):
+        _lib.check(lib.m2h_bin_l1_loss(_ptr(mix), _ptr(masks), _ptr(gt_bin_comps), gt_bin_comps.shape[-1], _ptr(loss), None, _ptr(scratch), npix,
+                                       _stream(mix)), "m2h_bin_l1_loss")
+    return loss[0]

@@ -1,0 +1,88 @@
+"""Adam + gradient-norm clipping over flat buffers, arithmetic in libm2h.so (K19/K20 of SURVEY 2.2).
+
+``FlatAdam`` is a ``torch.optim.Optimizer`` (so ``LambdaLR`` of ppo_trainer.py:711-718 drives its lr) whose parameters and
+gradients are views into two flat fp32 buffers: one sum-of-squares reduction gives the clip coefficient (kept on the device,
+no host sync), one kernel applies clip + Adam to all parameters, and -- for DD-PPO -- the flat gradient buffer is the single
+RCCL all-reduce payload (23.3 MB for the policy).  Semantics are torch.optim.Adam's (betas 0.9/0.999, no weight
+decay, no amsgrad) with eps from the config (1e-5, ppo.py:48-55) and nn.utils.clip_grad_norm_'s coefficient.
+"""
+import torch
+
+from . import _lib, ops
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr, eps=1e-8, betas=(0.9, 0.999)):
+        params = [p for p in params]
+        super().__init__(params, dict(lr=lr, eps=eps, betas=betas))
+        self._built = False
+        self.t = 0
+
+    def _build(self):
+        """Flat buffers over the parameters that require grad NOW (the trainer may freeze modules after construction)."""
+        ps = [p for p in self.param_groups[0]["params"] if p.requires_grad]
+        if not ps:
+            raise ValueError("FlatAdam: no trainable parameters")
+        dev = ps[0].device
+        if not ps[0].is_cuda:
+            raise RuntimeError("FlatAdam: parameters must live on the GPU (no CPU path)")
+        n = sum(p.numel() for p in ps)
+        self._ps = ps
+        self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.coef = torch.ones(2, device=dev, dtype=torch.float32)
+        self._scratch = torch.empty(1024, device=dev, dtype=torch.float32)
+        off = 0
+        with torch.no_grad():
+            for p in ps:
+                k = p.numel()
+                self.flat_p[off:off + k].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[off:off + k].view_as(p)          # parameter storage now lives in the flat buffer
+                p.grad = self.flat_g[off:off + k].view_as(p)          # autograd accumulates in place into the flat buffer
+                off += k
+        self.n = n
+        self._built = True
+
+    def zero_grad(self, set_to_none=False):
+        if not self._built:
+            self._build()
+        self.flat_g.zero_()
+        for p in self._ps:  # re-attach views if something replaced them
+            if p.grad is None or p.grad.data_ptr() < self.flat_g.data_ptr() or p.grad.data_ptr() >= self.flat_g.data_ptr() + 4 * self.n:
+                raise RuntimeError("FlatAdam: a parameter's .grad no longer points into the flat buffer (was it set to None?)")
+
+    def grad_buffer(self):
+        """The flat gradient (all-reduce payload)."""
+        if not self._built:
+            self._build()
+        return self.flat_g
+
+    @torch.no_grad()
+    def step(self, max_grad_norm=None, grad_scale=1.0):
+        """clip_grad_norm_(params, max_grad_norm) followed by Adam.step(); grad_scale multiplies the gradient first
+        (1/world_size after a sum all-reduce; the clip norm is computed on the scaled gradient like DDP's averaged grads)."""
+        if not self._built:
+            raise RuntimeError("FlatAdam.step before zero_grad()/backward")
+        g = self.param_groups[0]
+        lr, eps, (b1, b2) = g["lr"], g["eps"], g["betas"]
+        self.t += 1
+        lib = _lib.load()
+        dev = self.flat_p.device
+        with torch.cuda.device(dev):
+            st = ops._stream(self.flat_p)
+            if grad_scale != 1.0:
+                self.flat_g.mul_(grad_scale)
+            mg = float(max_grad_norm) if max_grad_norm is not None else 0.0
+            _lib.check(lib.m2h_grad_clip_coef(ops._ptr(self.flat_g), self.n, mg, ops._ptr(self.coef), ops._ptr(self._scratch), st),
+                       "m2h_grad_clip_coef")
+            _lib.check(lib.m2h_adam_step(ops._ptr(self.flat_p), ops._ptr(self.flat_g), ops._ptr(self.exp_avg), ops._ptr(self.exp_avg_sq),
+                                         self.n, float(lr), float(b1), float(b2), float(eps), self.t, ops._ptr(self.coef), 1.0, st),
+                       "m2h_adam_step")
+        from . import functional
+        functional.bump_param_epoch()
+
+    def grad_norm(self):
+        """||g||_2 measured by the last step (device tensor)."""
+        return self.coef[1]

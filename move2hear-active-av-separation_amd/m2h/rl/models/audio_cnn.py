@@ -9,8 +9,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ... import functional as MF
 from ... import ops
-from ._common import PackedCache, check_inference
 
 
 class Flatten(nn.Module):
@@ -50,7 +50,7 @@ class AudioCNN(nn.Module):
             nn.ReLU(True),
         )
         self.layer_init()
-        self._cache = PackedCache()
+        self._memo = [MF._PackMemo() for _ in range(4)]
 
     def layer_init(self):
         for layer in self.cnn:
@@ -59,45 +59,29 @@ class AudioCNN(nn.Module):
                 if layer.bias is not None:
                     nn.init.constant_(layer.bias, val=0)
 
-    def _packed(self):
-        convs = [self.cnn[0], self.cnn[2], self.cnn[4]]
-        fc = self.cnn[7]
-        srcs = [t for c in convs for t in (c.weight, c.bias)] + [fc.weight, fc.bias]
-
-        def build():
-            out = [(ops.pack_conv_weight(c.weight.detach().contiguous()), c.bias.detach().contiguous()) for c in convs]
-            h, w = self._out_dims
-            fw = fc.weight.detach().reshape(fc.weight.shape[0], 32, h, w).contiguous()
-            out.append((ops.pack_conv_weight(fw), fc.bias.detach().contiguous()))
-            return out
-
-        return self._cache.get(srcs, build)
-
     def encode(self, x_nhwc):
-        """conv stack + FC on an already sliced NHWC input [B,32,T,32]."""
-        (w0, b0), (w1, b1), (w2, b2), (wf, bf) = self._packed()
-        x = ops.conv2d_nhwc(x_nhwc, w0, 32, 8, 8, stride=4, bias=b0, slope=0.0, name="audio_cnn.conv0")
-        x = ops.conv2d_nhwc(x, w1, 64, 4, 4, stride=2, bias=b1, slope=0.0, name="audio_cnn.conv1")
-        x = ops.conv2d_nhwc(x, w2, 32, 2, 2, stride=1, bias=b2, slope=0.0, name="audio_cnn.conv2")
+        """conv stack + FC on an already sliced NHWC input [B,32,T,32] (differentiable w.r.t. the parameters)."""
+        c0, c1, c2, fc = self.cnn[0], self.cnn[2], self.cnn[4], self.cnn[7]
+        x = MF.conv2d(x_nhwc, c0.weight, c0.bias, 4, 0, slope=0.0, memo=self._memo[0], name="audio_cnn.conv0")
+        x = MF.conv2d(x, c1.weight, c1.bias, 2, 0, slope=0.0, memo=self._memo[1], name="audio_cnn.conv1")
+        x = MF.conv2d(x, c2.weight, c2.bias, 1, 0, slope=0.0, memo=self._memo[2], name="audio_cnn.conv2")
         h, w = self._out_dims
         if x.shape[1] != h or x.shape[2] != w:
             raise RuntimeError("m2h AudioCNN: conv output %s does not match the Linear built for %s" % (tuple(x.shape[1:3]), (h, w)))
-        y = ops.conv2d_nhwc(x, wf, wf.shape[0], h, w, stride=1, bias=bf, slope=0.0, name="audio_cnn.fc")
+        # Linear over the NCHW-flattened map == conv with an (h x w) kernel over the NHWC map (weight viewed [N,32,h,w])
+        y = MF.conv2d(x, fc.weight.view(fc.weight.shape[0], 32, h, w), fc.bias, 1, 0, slope=0.0, memo=self._memo[3], name="audio_cnn.fc")
         return y.reshape(y.shape[0], -1)
 
     def forward_pair(self, pred_mono, pred_monoFromMem):
         """monoNmonoFromMem path without materialising torch.cat((mono, mem), dim=3) (rl/ppo/policy.py:103)."""
-        check_inference(self, pred_mono, pred_monoFromMem)
         return self.encode(ops.slice_concat_input(pred_mono.contiguous(), pred_monoFromMem.contiguous(), op=2))
 
     def forward(self, observations, pred_binSepMasks=None, pred_monoNmonoFromMem=None):
         if self.encode_monoNmonoFromMem:
             assert pred_monoNmonoFromMem is not None
-            check_inference(self, pred_monoNmonoFromMem)
             x = ops.slice_concat_input(pred_monoNmonoFromMem.contiguous(), op=2)  # log1p(clamp0(x))  reference :121-122
         else:
             assert pred_binSepMasks is not None
             mix = observations["mixed_bin_audio_mag"]
-            check_inference(self, mix, pred_binSepMasks)
             x = ops.slice_concat_input(mix.contiguous(), mul=pred_binSepMasks.contiguous(), op=1)  # reference :125-128
         return self.encode(x)

@@ -5,10 +5,11 @@ forward = slice both inputs 16-way + concat (one HBM-bound kernel, concat never 
 conv3x3 with the de-slice fused into its store; both convs run on the MFMA implicit-GEMM engine.
 ``forward_masked`` additionally fuses the not-done masking of the previous memory (ppo_trainer.py:310-314, ppo.py:206-209).
 """
+import torch
 import torch.nn as nn
 
+from ... import functional as MF
 from ... import ops
-from ._common import PackedCache, check_inference
 
 
 class AcousticMem(nn.Module):
@@ -31,7 +32,7 @@ class AcousticMem(nn.Module):
             )
         self._use_ddppo = use_ddppo
         self.layer_init()
-        self._cache = PackedCache()
+        self._memo = [MF._PackMemo(), MF._PackMemo()]
 
     def layer_init(self):
         # reference :26-38
@@ -45,20 +46,17 @@ class AcousticMem(nn.Module):
                     layer.weight.data.fill_(1)
                     layer.bias.data.zero_()
 
-    def _packed(self):
-        convs = [m for m in self.cnn if isinstance(m, nn.Conv2d)]
-        return self._cache.get([c.weight for c in convs],
-                               lambda: [ops.pack_conv_weight(c.weight.detach().contiguous()) for c in convs])
-
     def forward_masked(self, pred_mono, prev_pred_monoFromMem, masks=None):
         if not self._use_ddppo:
             raise NotImplementedError("m2h AcousticMem: only the DD-PPO variant (no BatchNorm, memory_nets.py:11-16) is built")
-        check_inference(self, pred_mono, prev_pred_monoFromMem)
+        if torch.is_grad_enabled() and (pred_mono.requires_grad or prev_pred_monoFromMem.requires_grad):
+            raise NotImplementedError("m2h AcousticMem: gradients w.r.t. the inputs are not built (the separators are frozen in RL, "
+                                      "ppo.py:184-195); detach the inputs")
         bscale = masks.reshape(-1).contiguous() if masks is not None else None
         x = ops.slice_concat_input(pred_mono.contiguous(), prev_pred_monoFromMem.contiguous(), bscale=bscale, op=0)
-        w0, w1 = self._packed()
-        x = ops.conv2d_nhwc(x, w0, 32, 3, 3, stride=1, pad=1, slope=0.0, name="acoustic_mem.conv0")
-        return ops.conv2d_nhwc(x, w1, self._slice_factor, 3, 3, stride=1, pad=1, slope=1.0, deslice=True, name="acoustic_mem.conv1")
+        c0, c1 = self.cnn[0], self.cnn[-1]
+        x = MF.conv2d(x, c0.weight, None, 1, 1, slope=0.0, memo=self._memo[0], name="acoustic_mem.conv0")
+        return MF.conv2d(x, c1.weight, None, 1, 1, slope=1.0, deslice=True, memo=self._memo[1], name="acoustic_mem.conv1")
 
     def forward(self, pred_mono, prev_pred_monoFromMem_masked):
         return self.forward_masked(pred_mono, prev_pred_monoFromMem_masked, None)

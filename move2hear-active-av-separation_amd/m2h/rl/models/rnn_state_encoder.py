@@ -6,11 +6,9 @@ the MFMA engine (torch's [3H][K] weight layout is already the packed [N][K] form
 stretch; masking h with masks[t] before every step is the same function, needs no device->host sync (the reference's
 ``.nonzero().cpu()`` at :105) and is what is done here; the input GEMM is batched over all T*N rows.
 """
-import torch
 import torch.nn as nn
 
-from ... import ops
-from ._common import check_inference
+from ... import functional as MF
 
 
 class RNNStateEncoder(nn.Module):
@@ -34,31 +32,9 @@ class RNNStateEncoder(nn.Module):
     def num_recurrent_layers(self):
         return self._num_recurrent_layers
 
-    def _step(self, gi, h, mask):
-        gh = ops.linear(h, self.rnn.weight_hh_l0.detach(), None, name="gru.hh")
-        return ops.gru_gates(gi, gh, self.rnn.bias_hh_l0.detach(), h, mask)
-
-    def single_forward(self, x, hidden_states, masks):
-        h = hidden_states[0].contiguous()
-        gi = ops.linear(x.contiguous(), self.rnn.weight_ih_l0.detach(), self.rnn.bias_ih_l0.detach(), name="gru.ih")
-        h = self._step(gi, h, masks.reshape(-1).contiguous())
-        return h, h.unsqueeze(0)
-
-    def seq_forward(self, x, hidden_states, masks):
-        n = hidden_states.size(1)
-        t = int(x.size(0) / n)
-        gi = ops.linear(x.contiguous(), self.rnn.weight_ih_l0.detach(), self.rnn.bias_ih_l0.detach(), name="gru.ih")
-        gi = gi.view(t, n, -1)
-        masks = masks.reshape(t, n).contiguous()
-        h = hidden_states[0].contiguous()
-        outs = torch.empty((t, n, h.shape[1]), device=x.device, dtype=torch.float32)
-        for i in range(t):
-            h = self._step(gi[i], h, masks[i])
-            outs[i].copy_(h)
-        return outs.view(t * n, -1), h.unsqueeze(0)
-
     def forward(self, x, hidden_states, masks):
-        check_inference(self, x, hidden_states)
-        if x.size(0) == hidden_states.size(1):
-            return self.single_forward(x, hidden_states, masks)
-        return self.seq_forward(x, hidden_states, masks)
+        n = hidden_states.size(1)
+        t = x.size(0) // n  # 1: single_forward (:74-84); > 1: seq_forward (:86-137)
+        r = self.rnn
+        out, h = MF.GRUSequence.apply(x, hidden_states[0], masks, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0, t)
+        return out, h.unsqueeze(0)

@@ -6,8 +6,8 @@ to 4 input channels; conv8x8s4+ReLU, conv4x4s2+ReLU, conv3x3s1 and the Linear+Re
 """
 import torch.nn as nn
 
+from ... import functional as MF
 from ... import ops
-from ._common import PackedCache, check_inference
 from .audio_cnn import Flatten, conv_output_dim
 
 
@@ -46,7 +46,7 @@ class VisualCNN(nn.Module):
                 nn.ReLU(True),
             )
         self.layer_init()
-        self._cache = PackedCache()
+        self._memo = [MF._PackMemo() for _ in range(4)]
 
     def layer_init(self):
         for layer in self.cnn:
@@ -59,22 +59,6 @@ class VisualCNN(nn.Module):
     def is_blind(self):
         return self._n_input_rgb + self._n_input_depth == 0
 
-    def _packed(self):
-        convs = [self.cnn[0], self.cnn[2], self.cnn[4]]
-        fc = self.cnn[6]
-        srcs = [t for c in convs for t in (c.weight, c.bias)] + [fc.weight, fc.bias]
-
-        def build():
-            c0 = convs[0]
-            out = [(ops.pack_conv_weight_ex(c0.weight.detach().contiguous(), c0.weight.shape[1], 4), c0.bias.detach().contiguous())]
-            out += [(ops.pack_conv_weight(c.weight.detach().contiguous()), c.bias.detach().contiguous()) for c in convs[1:]]
-            h, w = self._out_dims
-            fw = fc.weight.detach().reshape(fc.weight.shape[0], 32, h, w).contiguous()
-            out.append((ops.pack_conv_weight(fw), fc.bias.detach().contiguous()))
-            return out
-
-        return self._cache.get(srcs, build)
-
     def forward(self, observations):
         if self.is_blind:
             raise NotImplementedError("m2h VisualCNN: blind configuration has no encoder")
@@ -82,12 +66,11 @@ class VisualCNN(nn.Module):
             raise NotImplementedError("m2h VisualCNN: built for rgb (3 ch) with optional depth (1 ch)")
         rgb = observations["rgb"]
         depth = observations["depth"] if self._n_input_depth > 0 else None
-        check_inference(self, rgb)
         x = ops.visual_input(rgb.contiguous(), depth.contiguous() if depth is not None else None)
-        (w0, b0), (w1, b1), (w2, b2), (wf, bf) = self._packed()
-        x = ops.conv2d_nhwc(x, w0, 32, 8, 8, stride=4, bias=b0, slope=0.0, name="visual_cnn.conv0")
-        x = ops.conv2d_nhwc(x, w1, 64, 4, 4, stride=2, bias=b1, slope=0.0, name="visual_cnn.conv1")
-        x = ops.conv2d_nhwc(x, w2, 32, 3, 3, stride=1, bias=b2, slope=1.0, name="visual_cnn.conv2")  # no ReLU (:81-88)
+        c0, c1, c2, fc = self.cnn[0], self.cnn[2], self.cnn[4], self.cnn[6]
+        x = MF.conv2d(x, c0.weight, c0.bias, 4, 0, slope=0.0, memo=self._memo[0], name="visual_cnn.conv0")  # Ci 3 packed to 4
+        x = MF.conv2d(x, c1.weight, c1.bias, 2, 0, slope=0.0, memo=self._memo[1], name="visual_cnn.conv1")
+        x = MF.conv2d(x, c2.weight, c2.bias, 1, 0, slope=1.0, memo=self._memo[2], name="visual_cnn.conv2")  # no ReLU (:81-88)
         h, w = self._out_dims
-        y = ops.conv2d_nhwc(x, wf, wf.shape[0], h, w, stride=1, bias=bf, slope=0.0, name="visual_cnn.fc")
+        y = MF.conv2d(x, fc.weight.view(fc.weight.shape[0], 32, h, w), fc.bias, 1, 0, slope=0.0, memo=self._memo[3], name="visual_cnn.fc")
         return y.reshape(y.shape[0], -1)

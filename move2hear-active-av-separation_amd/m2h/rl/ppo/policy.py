@@ -2,18 +2,18 @@
 
 Same class names (CriticHead, PolicyNet, PassiveSepEnc/Dec, Policy, Move2HearPolicy), constructor arguments, method
 signatures/return conventions (:183-273) and state_dict keys (158 entries, checked against the reference).  Every
-arithmetic step runs in libm2h.so; only inference (rollout: act / get_value under torch.no_grad(), ppo_trainer.py:322-335,
-:500-507) is built so far -- evaluate_actions computes the forward values but refuses to run where autograd would be needed.
+arithmetic step -- forward and backward -- runs in libm2h.so (m2h.functional wraps the kernels as autograd Functions); the
+frozen separator U-Nets are inference-only, exactly how the RL trainer uses them (ppo_trainer.py:557-577).
 """
 import abc
 
 import torch
 import torch.nn as nn
 
+from ... import functional as MF
 from ... import ops
 from ...common.utils import CategoricalNet, CustomFixedCategorical
 from ...pretrain.passive.policy import PassiveSepDec, PassiveSepEnc  # identical wrappers (reference :121-156)
-from ..models._common import check_inference
 from ..models.audio_cnn import AudioCNN
 from ..models.memory_nets import AcousticMem
 from ..models.rnn_state_encoder import RNNStateEncoder
@@ -79,7 +79,6 @@ class PolicyNet(Net):
         return self.state_encoder.num_recurrent_layers
 
     def forward(self, observations, rnn_hidden_states, masks, pred_binSepMasks=None, pred_mono=None, pred_monoFromMem=None):
-        check_inference(self, pred_binSepMasks, pred_mono, pred_monoFromMem, rnn_hidden_states)
         x = [
             self.visual_encoder(observations),
             self.bin_encoder(observations, pred_binSepMasks=pred_binSepMasks),
@@ -126,10 +125,18 @@ class Policy(nn.Module):
 
     def _heads(self, feats, actions=None):
         a, c = self.action_dist.linear, self.critic.fc
-        value, logp_all, probs, ent, logp_act = ops.policy_heads(
-            feats.contiguous(), a.weight.detach(), a.bias.detach(), c.weight.detach(), c.bias.detach(),
-            actions.reshape(-1).contiguous() if actions is not None else None)
-        return value, CustomFixedCategorical(logp_all, probs, ent), logp_act
+        acts = actions.reshape(-1).contiguous() if actions is not None else None
+        value, logp_act, ent, probs, logp_all = MF.PolicyHeads.apply(feats, a.weight, a.bias, c.weight, c.bias, acts)
+        return value, CustomFixedCategorical(logp_all, probs, ent), (logp_act if actions is not None else None)
+
+    def evaluate_rows(self, observations, rnn_hidden_states_pol, masks, action, pred_binSepMasks=None, pred_mono=None,
+                      pred_monoFromMem=None):
+        """evaluate_actions with the per-row entropies (what the fused PPO-loss kernel consumes)."""
+        feats_pol, rnn_hidden_states_pol = self.pol_net(
+            observations, rnn_hidden_states_pol, masks, pred_binSepMasks=pred_binSepMasks, pred_mono=pred_mono,
+            pred_monoFromMem=pred_monoFromMem)
+        value, dist, action_log_probs = self._heads(feats_pol, action)
+        return value, action_log_probs, dist.entropy(), rnn_hidden_states_pol
 
     def act(self, observations, rnn_hidden_states_pol, masks, deterministic=False, pred_binSepMasks=None, pred_mono=None,
             pred_monoFromMem=None):

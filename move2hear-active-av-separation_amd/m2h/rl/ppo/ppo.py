@@ -1,0 +1,188 @@
+"""PPO / DD-PPO on MI355X: drop-in for audio_separation/rl/ppo/ppo.py (PPO :11-272, DecentralizedDistributedMixin :275-319).
+
+Same constructor arguments, attributes (optimizer_pol, optimizer_sep, clip_param ...) and methods (update_pol, update_sep,
+get_advantages, load_pretrained_passive_separators, init_distributed).  Mechanism:
+  * every forward/backward value is produced by HIP kernels (m2h.functional); torch.autograd only orders them;
+  * the clipped-surrogate / value / entropy losses and their gradients are ONE kernel (m2h_ppo_loss);
+  * the two optimizers are FlatAdam: grad-norm clip + Adam in two launches over a flat buffer, no host sync;
+  * DD-PPO: instead of DDP's bucketed reducer the flat gradient buffer is all-reduced (sum, RCCL) once per backward and
+    averaged inside the optimizer step (same update as ppo.py:313-319 + DDP: grads averaged before clip and step);
+    parameters are broadcast from rank 0 at init_distributed; the advantage normalisation uses the two scalar all-reduces
+    of ddppo_utils.py:168-190;
+  * update_sep (D13 of SURVEY): the frozen, eval-mode separators are deterministic per observation, so their outputs are
+    computed once per stored buffer generation and re-used by the 4 epochs x 6 sub-updates that the reference recomputes
+    (24x fewer U-Net passes, identical numbers); ``cache_separator_outputs=False`` restores the reference schedule.
+  * loss scalars are accumulated on the device and read back once per update instead of 3 ``.item()`` per minibatch.
+"""
+import torch
+import torch.nn as nn
+
+from ... import functional as MF
+from ... import ops
+from ...optim import FlatAdam
+
+EPS_PPO = 1e-5
+
+
+class PPO(nn.Module):
+    def __init__(self, actor_critic, clip_param, ppo_epoch, num_mini_batch, value_loss_coef, bin_separation_loss_coef,
+                 mono_conversion_loss_coef, entropy_coef, lr_pol=None, lr_sep=None, eps=None, max_grad_norm=None,
+                 freeze_passive_separators=False, use_clipped_value_loss=True, use_normalized_advantage=True,
+                 cache_separator_outputs=True):
+        super().__init__()
+        self.actor_critic = actor_critic
+        self.clip_param = clip_param
+        self.ppo_epoch = ppo_epoch
+        self.num_mini_batch = num_mini_batch
+        self.value_loss_coef = value_loss_coef
+        self.bin_separation_loss_coef = bin_separation_loss_coef
+        self.mono_conversion_loss_coef = mono_conversion_loss_coef
+        self.entropy_coef = entropy_coef
+        self.max_grad_norm = max_grad_norm
+        self.use_clipped_value_loss = use_clipped_value_loss
+        self.use_normalized_advantage = use_normalized_advantage
+        self.freeze_passive_separators = freeze_passive_separators
+        self.cache_separator_outputs = cache_separator_outputs
+        ac = actor_critic
+        pol_params = list(ac.pol_net.parameters()) + list(ac.action_dist.parameters()) + list(ac.critic.parameters())
+        sep_params = list(ac.binSep_enc.parameters()) + list(ac.binSep_dec.parameters()) + list(ac.bin2mono_enc.parameters()) + \
+            list(ac.bin2mono_dec.parameters()) + list(ac.acoustic_mem.parameters())
+        # flat buffers are built lazily at the first step, over the parameters that require grad THEN (the trainer freezes
+        # the separators after constructing the agent, ppo_trainer.py:637-641)
+        self.optimizer_pol = FlatAdam(pol_params, lr=lr_pol, eps=eps)
+        self.optimizer_sep = FlatAdam(sep_params, lr=lr_sep, eps=eps)
+        self.device = next(actor_critic.parameters()).device
+        self._world = 1
+        self._sep_cache = None
+
+    def load_pretrained_passive_separators(self, state_dict):
+        ac = self.actor_critic
+        for mod_name in ("binSep_enc", "binSep_dec", "bin2mono_enc", "bin2mono_dec"):
+            mod = getattr(ac, mod_name)
+            sd = mod.state_dict()
+            for name in sd:
+                sd[name].copy_(state_dict["actor_critic." + mod_name + "." + name])
+
+    def forward(self, *x):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ advantages
+    def get_advantages(self, rollouts_pol):
+        if not self.use_normalized_advantage:
+            return ops.advantages(rollouts_pol.returns, rollouts_pol.value_preds, 0)[0]
+        if self._world > 1:
+            return self._get_advantages_distributed(rollouts_pol)
+        return ops.advantages(rollouts_pol.returns, rollouts_pol.value_preds, 1, EPS_PPO)[0]
+
+    def _get_advantages_distributed(self, rollouts_pol):
+        import torch.distributed as dist
+        adv, stats = ops.advantages(rollouts_pol.returns, rollouts_pol.value_preds, 2)
+        mean = stats[0:1].clone()
+        dist.all_reduce(mean)
+        mean /= self._world
+        var = ops.adv_sqdiff(adv, mean)
+        dist.all_reduce(var)
+        var /= self._world
+        return ops.adv_apply(adv, mean, var, EPS_PPO)
+
+    # ------------------------------------------------------------------ distributed
+    def init_distributed(self, find_unused_params: bool = True) -> None:
+        """Broadcast rank 0's parameters/buffers and switch gradient reduction on (reference :286-311)."""
+        import torch.distributed as dist
+        self._world = dist.get_world_size()
+        self.find_unused_params = find_unused_params
+        with torch.no_grad():
+            for t in list(self.actor_critic.parameters()) + list(self.actor_critic.buffers()):
+                dist.broadcast(t.data, 0)
+
+    def _reduce_grads(self, opt):
+        if self._world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(opt.grad_buffer())  # one flat sum all-reduce (RCCL); averaged by grad_scale in the step
+            return 1.0 / self._world
+        return 1.0
+
+    # ------------------------------------------------------------------ policy update (reference :82-177)
+    def update_pol(self, rollouts_pol):
+        advantages = self.get_advantages(rollouts_pol)
+        acc = torch.zeros(4, device=self.device)
+        for _e in range(self.ppo_epoch):
+            for sample in rollouts_pol.recurrent_generator(advantages, self.num_mini_batch):
+                (obs_batch, h_batch, pm_batch, mono_batch, mem_batch, value_preds_batch, return_batch, adv_targ, actions_batch,
+                 old_logp_batch, masks_batch) = sample
+                values, logp, ent_rows, _ = self.actor_critic.evaluate_rows(
+                    obs_batch, h_batch, masks_batch, actions_batch, pred_binSepMasks=pm_batch, pred_mono=mono_batch,
+                    pred_monoFromMem=mem_batch)
+                self.optimizer_pol.zero_grad()
+                total_loss, stats = MF.PPOLoss.apply(values, logp, ent_rows, value_preds_batch, return_batch, adv_targ, old_logp_batch,
+                                                     float(self.clip_param), float(self.value_loss_coef), float(self.entropy_coef),
+                                                     bool(self.use_clipped_value_loss))
+                total_loss.backward()
+                gscale = self._reduce_grads(self.optimizer_pol)
+                self.optimizer_pol.step(max_grad_norm=self.max_grad_norm, grad_scale=gscale)  # before_step_pol + step
+                acc += stats
+        num_updates = self.ppo_epoch * self.num_mini_batch
+        v, a, h, _ = (acc / num_updates).tolist()  # the only host read of the update
+        return v, a, h
+
+    # ------------------------------------------------------------------ separator (acoustic memory) update (reference :179-246)
+    def _separator_outputs(self, rollouts_sep):
+        """pred_binSepMasks / pred_mono for every stored (t, env), storage order [T, N]."""
+        key = (id(rollouts_sep), getattr(rollouts_sep, "generation", None), rollouts_sep.observations["mixed_bin_audio_mag"].data_ptr())
+        if self.cache_separator_outputs and self._sep_cache is not None and self._sep_cache[0] == key and key[1] is not None:
+            return self._sep_cache[1]
+        mix = rollouts_sep.observations["mixed_bin_audio_mag"][:-1]
+        T, N = mix.shape[0], mix.shape[1]
+        obs = {"mixed_bin_audio_mag": mix.reshape(T * N, *mix.shape[2:]),
+               "target_class": rollouts_sep.observations["target_class"][:-1].reshape(T * N, -1)}
+        with torch.no_grad():
+            pm = self.actor_critic.get_binSepMasks(obs)
+            mono = self.actor_critic.convert_bin2mono(pm, mixed_audio=obs["mixed_bin_audio_mag"])
+        val = (pm.view(T, N, *pm.shape[1:]), mono.view(T, N, *mono.shape[1:]))
+        self._sep_cache = (key, val)
+        return val
+
+    def update_sep(self, rollouts_sep):
+        acc = torch.zeros(3, device=self.device)
+        sep_frozen = not any(p.requires_grad for m in (self.actor_critic.binSep_enc, self.actor_critic.binSep_dec,
+                                                        self.actor_critic.bin2mono_enc, self.actor_critic.bin2mono_dec)
+                             for p in m.parameters())
+        if not sep_frozen:
+            raise NotImplementedError("m2h PPO.update_sep: training the passive separators inside RL is not built "
+                                      "(shipped configs freeze them, ppo_trainer.py:557-577)")
+        cached = self._separator_outputs(rollouts_sep) if self.cache_separator_outputs else None
+        for _e in range(self.ppo_epoch):
+            gen = rollouts_sep.recurrent_generator(self.num_mini_batch, with_perm=True)
+            for sample in gen:
+                obs_batch, _mem_batch, prev_mem_batch, masks_batch, idx = sample
+                if cached is not None:
+                    pred_binSepMasks = ops.gather_envs(cached[0], idx)
+                    pred_mono = ops.gather_envs(cached[1], idx)
+                else:
+                    with torch.no_grad():  # reference :184-195
+                        pred_binSepMasks = self.actor_critic.get_binSepMasks(obs_batch)
+                        pred_mono = self.actor_critic.convert_bin2mono(pred_binSepMasks.detach(),
+                                                                       mixed_audio=obs_batch["mixed_bin_audio_mag"])
+                pred_monoFromMem = self.actor_critic.get_monoFromMem_masked(pred_mono, prev_mem_batch, masks_batch)
+                gt_mono = obs_batch["gt_mono_comps"]
+                monoFromMem_loss = MF.l1_loss(pred_monoFromMem, gt_mono, 0)          # gt_mono_comps[..., 0::2][..., :1]
+                with torch.no_grad():
+                    mono_loss = MF.l1_loss(pred_mono, gt_mono, 0)
+                    bin_loss = ops.bin_l1_loss(obs_batch["mixed_bin_audio_mag"], pred_binSepMasks, obs_batch["gt_bin_comps"])
+                self.optimizer_sep.zero_grad()
+                monoFromMem_loss.backward()                                          # total_loss = monoFromMem_loss (:226)
+                gscale = self._reduce_grads(self.optimizer_sep)
+                self.optimizer_sep.step(max_grad_norm=self.max_grad_norm, grad_scale=gscale)
+                acc += torch.stack((bin_loss, mono_loss, monoFromMem_loss.detach()))
+        num_updates = self.ppo_epoch * self.num_mini_batch
+        b, m, mm = (acc / num_updates).tolist()
+        return b, m, mm
+
+
+class DecentralizedDistributedMixin:
+    """Kept for API parity (reference :275-319): the distributed behaviour lives in PPO itself and is switched on by
+    init_distributed()."""
+
+
+class DDPPO(DecentralizedDistributedMixin, PPO):
+    pass

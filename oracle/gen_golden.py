@@ -284,8 +284,73 @@ def gen_rl_scalars(ref):
     print("rl_scalars: returns mean", float(out["returns_gae"].mean()), "rew", out["rew_quality_improvement"])
 
 
+def _fill_pol_storage(ro, obs_all, T, N, g):
+    """Deterministic contents for a RolloutStoragePol [T(+1), N]; obs_all: dict of [(T+1)*N, ...] tensors."""
+    for k in ro.observations:
+        ro.observations[k].copy_(obs_all[k].reshape(T + 1, N, *obs_all[k].shape[1:]))
+    ro.recurrent_hidden_states_pol.copy_(torch.randn(T + 1, 1, N, 512, generator=g) * 0.3)
+    ro.pred_binSepMasks.copy_(torch.randn(T, N, 512, 32, 2, generator=g))
+    ro.pred_mono.copy_(torch.rand(T, N, 512, 32, 1, generator=g))
+    ro.prev_pred_monoFromMem.copy_(torch.rand(T + 1, N, 512, 32, 1, generator=g))
+    ro.rewards.copy_(torch.randn(T, N, 1, generator=g) * 0.1)
+    ro.value_preds.copy_(torch.randn(T + 1, N, 1, generator=g) * 0.2)
+    ro.returns.copy_(torch.randn(T + 1, N, 1, generator=g) * 0.2)
+    ro.action_log_probs.copy_(-1.1 + 0.1 * torch.randn(T, N, 1, generator=g))
+    ro.actions.copy_(torch.randint(0, 3, (T, N, 1), generator=g))
+    m = (torch.rand(T + 1, N, 1, generator=g) > 0.2).float()
+    ro.masks.copy_(m)
+
+
+def gen_rl_updates(ref):
+    """G10 / G11: one PPO.update_pol (2 epochs) and one PPO.update_sep (2 epochs) of the reference on small seeded storages:
+    returned losses and post-update parameter checksums."""
+    seed_w = 3
+    pol, sd = build_ref_rl(ref, seed_w)
+    PPO = ref["ppo"].PPO
+    agent = PPO(actor_critic=pol, clip_param=0.1, ppo_epoch=2, num_mini_batch=1, value_loss_coef=0.5, bin_separation_loss_coef=1.0,
+                mono_conversion_loss_coef=1.0, entropy_coef=0.2, lr_pol=1e-4, lr_sep=5e-4, eps=1e-5, max_grad_norm=0.5,
+                freeze_passive_separators=True)
+    RS = ref["rollout_storage"]
+    g = torch.Generator().manual_seed(17)
+    T, N = 4, 3
+    obs_all = _obs_t(synthetic.make_rl_observations((T + 1) * N, 51))
+    ro = RS.RolloutStoragePol(T, N, FakeObsSpace(32), 512)
+    _fill_pol_storage(ro, obs_all, T, N, g)
+    torch.manual_seed(99)
+    v, a, h = agent.update_pol(ro)
+    out = {"seed_w": seed_w, "pol_T": T, "pol_N": N, "pol_obs_seed": 51, "pol_fill_seed": 17, "pol_perm_seed": 99,
+           "pol_losses": np.array([v, a, h])}
+    for k, t in pol.state_dict().items():
+        if k.startswith(("pol_net", "action_dist", "critic")):
+            if t.numel() <= 100000:
+                out["polpost." + k] = t.numpy().copy()  # full tensor: the update delta is checked element-wise
+            else:
+                out["polsum." + k] = np.array([t.double().sum().item(), t.double().abs().sum().item()])
+    # ---- update_sep on a fresh policy copy (same weights)
+    pol2, _ = build_ref_rl(ref, seed_w)
+    agent2 = PPO(actor_critic=pol2, clip_param=0.1, ppo_epoch=2, num_mini_batch=1, value_loss_coef=0.5, bin_separation_loss_coef=1.0,
+                 mono_conversion_loss_coef=1.0, entropy_coef=0.2, lr_pol=1e-4, lr_sep=5e-4, eps=1e-5, max_grad_norm=0.5,
+                 freeze_passive_separators=True)
+    Ts, Ns = 3, 2
+    obs_s = _obs_t(synthetic.make_rl_observations((Ts + 1) * Ns, 52))
+    rs = RS.RolloutStorageSep(Ts, Ns, FakeObsSpace(32))
+    g2 = torch.Generator().manual_seed(18)
+    for k in rs.observations:
+        rs.observations[k].copy_(obs_s[k].reshape(Ts + 1, Ns, *obs_s[k].shape[1:]))
+    rs.prev_pred_monoFromMem.copy_(torch.rand(Ts + 1, Ns, 512, 32, 1, generator=g2))
+    rs.masks.copy_((torch.rand(Ts + 1, Ns, 1, generator=g2) > 0.3).float())
+    torch.manual_seed(100)
+    b, m, mm = agent2.update_sep(rs)
+    out.update(sep_T=Ts, sep_N=Ns, sep_obs_seed=52, sep_fill_seed=18, sep_perm_seed=100, sep_losses=np.array([b, m, mm]))
+    for k in ("acoustic_mem.cnn.0.weight", "acoustic_mem.cnn.2.weight"):
+        t = pol2.state_dict()[k]
+        out["seppost." + k] = t.numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "rl_updates.npz"), meta=json.dumps(META), **out)
+    print("rl_updates: pol losses", v, a, h, "sep losses", b, m, mm)
+
+
 GENS = {"unet_tm32": gen_unet_tm32, "unet_tm256": gen_unet_tm256, "init": gen_init,
-        "rl_forward": gen_rl_forward, "rl_scalars": gen_rl_scalars}
+        "rl_forward": gen_rl_forward, "rl_scalars": gen_rl_scalars, "rl_updates": gen_rl_updates}
 
 
 def main():
