@@ -86,13 +86,18 @@ def test_rl_forward_matches_reference_fixture(golden_dir):
         assert abs(eent.item() - float(g["eval_entropy"])) < 1e-5
 
 
-def test_policy_refuses_autograd():
+def test_unbuilt_gradient_paths_fail_loudly():
+    """What is not built raises instead of silently returning graph-less tensors: gradients into the (frozen) separator
+    outputs through AcousticMem, and autograd through the U-Nets themselves."""
     dev = _dev()
     pol, _ = _policy(2, dev)
-    obs = _obs(2, 3, dev)
-    z = torch.zeros(2, 512, 32, 2, device=dev)
+    mono = torch.rand(2, 512, 32, 1, device=dev, requires_grad=True)
     with pytest.raises(NotImplementedError):
-        pol.pol_net.bin_encoder(obs, pred_binSepMasks=z)  # grad enabled + trainable params -> loud failure, no silent graph-less result
+        pol.get_monoFromMem(mono, torch.rand(2, 512, 32, 1, device=dev))
+    for p in pol.binSep_enc.parameters():
+        p.requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        pol.get_binSepMasks(_obs(2, 3, dev))
 
 
 def test_returns_advantages_and_generators_match_fixture(golden_dir):
