@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--ddppo-cycles", type=int, default=2, help="timed DD-PPO cycles (0 = skip); one untimed warm-up cycle precedes them")
     return ap.parse_args()
 
 
@@ -105,6 +106,45 @@ def cpu_baseline(sd, tm, seconds):
     return {"value": round(bs * n / el, 2), "unit": "spectrograms/s", "cores": best_n, "kind": "port",
             "sample": "%d batches of %d 512x%d spectrograms through oracle.passive_pair (PyTorch-CPU fp32, %d of %d host threads), %.1f s"
                       % (n, bs, tm, best_n, ncpu, el)}
+
+
+def run_ddppo(args, dev, rank, world, dist):
+    """Second figure of BASELINE.json's metric: DD-PPO env-steps/s on the reference schedule (nearTarget.yaml: 14 envs/rank,
+    T=20, 6 policy updates + 6 separator updates per cycle, 4 epochs, 1 minibatch) with the synthetic on-device env.
+    Whole-job rate = all ranks' env steps / max-over-ranks time; gradients are all-reduced over RCCL when world > 1."""
+    from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config
+    cfg = near_target_config()
+    tr = PPOTrainer(cfg, dev, world_rank=rank, world_size=world)
+    tr.setup()
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in __import__("m2h.synthetic", fromlist=["x"]).make_state_dict(
+        __import__("m2h.synthetic", fromlist=["x"]).policy_shapes(), 1).items()}
+    tr.actor_critic.load_state_dict(sd)
+    tr.train_cycle()  # warm-up (allocator, pack caches, lazy optimizer buffers)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    steps = 0
+    last = None
+    for _ in range(args.ddppo_cycles):
+        last = tr.train_cycle()
+        steps += last["env_steps"]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return {"metric": "ddppo_env_steps_per_sec", "value": round(world * steps / el, 1), "unit": "env-steps/s", "n_gpus": world,
+            "cycles": args.ddppo_cycles, "s_per_cycle": round(el / args.ddppo_cycles, 4), "envs_per_rank": cfg.NUM_PROCESSES,
+            "schedule": "nearTarget.yaml: T=20, 6x(rollout+update_pol) + 6x update_sep per cycle, ppo_epoch 4, 1 minibatch, hidden 512",
+            "env": "synthetic on-device env (cached 128x128 RGB-D frames + spectrogram pool), zero-cost dynamics",
+            "separator_output_reuse": "frozen eval-mode U-Net outputs computed once per stored observation and re-used by the 24 "
+                                      "update_sep passes and by the next rollout step (result-preserving; SURVEY D13)",
+            "last_pol_losses": [round(x, 5) for x in last["pol_losses"]], "last_sep_losses": [round(x, 5) for x in last["sep_losses"]],
+            "reference_cpu_env_steps_per_sec_survey_probe": 4.3}
 
 
 def main():
@@ -198,6 +238,8 @@ def main():
         layers = {k: {"us": round(1e3 * v["ms"] / v["n"], 1), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None}
                   for k, v in per_layer.items()}
 
+    ddppo = run_ddppo(args, dev, rank, world, dist) if args.ddppo_cycles > 0 else None
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -220,6 +262,7 @@ def main():
                    "batch_per_gpu": args.batch, "n_freq": 512, "time_frames": args.tm, "parallelism": "dp%d (batch-sharded, no collective)" % world,
                    "weights": "synthetic (m2h.synthetic seed 1), reference architecture 33.47 M params"},
         "roofline": roofline,
+        "ddppo": ddppo,
         "cpu_baseline": cpu,
         "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
         "layers": layers,

@@ -1,0 +1,88 @@
+"""Synthetic vector environment: the Habitat/SoundSpaces loop of the reference replaced by an on-device feeder.
+
+Stands in for ``VectorEnvCustom`` + ``HabitatSimAudioEnabledTrain`` (audio_separation/common/env_utils.py:71-528,
+habitat_audio/simulator_train.py:386-486), which need the simulator and Matterport data.  What is kept from them:
+  * observation dict with the reference's sensors and shapes (config/default.py:130-157);
+  * cached RGB-D frames indexed by (node, angle) like ``_frame_cache`` (simulator_train.py:216-227);
+  * action set MOVE_FORWARD / TURN_LEFT / TURN_RIGHT, fixed-length episodes with auto-reset (env_utils.py:186-187):
+    every env is done after ``episode_len`` steps (20 nearTarget / 80 farTarget);
+  * per-rank seeding ``SEED + rank * NUM_PROCESSES`` (ppo_trainer.py:609-611).
+Everything lives on the GPU: step() takes the device action tensor and returns device tensors, so the rollout loop has no
+host<->device synchronisation (the reference pays ``actions[i].item()`` + pipes + ``batch_obs`` H2D per step).
+The audio pool holds log1p-magnitude / phase tensors with the statistics of the feeder (dataset.py:190-228); generating
+them from RIR-convolved waveforms on the GPU is row N1 of SURVEY 8f.
+"""
+import torch
+
+from ..common.spaces import Discrete, move2hear_observation_space
+
+
+class SyntheticVecEnv:
+    def __init__(self, num_envs, device, seed=0, episode_len=20, tm=32, n_freq=512, audio_pool=64, n_nodes=64):
+        self.num_envs = num_envs
+        self.device = device
+        self.episode_len = episode_len
+        self.observation_spaces = [move2hear_observation_space(tm, n_freq)] * num_envs
+        self.action_spaces = [Discrete(3)] * num_envs
+        g = torch.Generator(device=device).manual_seed(int(seed))
+        P = audio_pool
+        gain = torch.exp(torch.rand(P, n_freq, 1, 1, device=device, generator=g) * 3.0 - 2.0)
+        re, im = (torch.randn(P, n_freq, tm, 2, device=device, generator=g) for _ in range(2))
+        self.pool_mixed = torch.log1p(torch.sqrt(re * re + im * im) * gain).contiguous()
+        gb = torch.empty(P, n_freq, tm, 8, device=device)
+        gm = torch.empty(P, n_freq, tm, 4, device=device)
+        for j in range(0, 8, 2):
+            gb[..., j] = torch.log1p(torch.randn(P, n_freq, tm, device=device, generator=g).abs())
+            gb[..., j + 1] = (torch.rand(P, n_freq, tm, device=device, generator=g) * 2 - 1) * 3.14159265
+        for j in range(0, 4, 2):
+            gm[..., j] = torch.log1p(torch.randn(P, n_freq, tm, device=device, generator=g).abs())
+            gm[..., j + 1] = (torch.rand(P, n_freq, tm, device=device, generator=g) * 2 - 1) * 3.14159265
+        self.pool_gt_bin, self.pool_gt_mono = gb, gm
+        self.pool_class = torch.randint(0, 11, (P, 1), device=device, generator=g).float()
+        self.n_nodes = n_nodes
+        self.frames_rgb = torch.randint(0, 256, (n_nodes * 4, 128, 128, 3), device=device, generator=g).float()
+        self.frames_depth = torch.rand(n_nodes * 4, 128, 128, 1, device=device, generator=g)
+        self._g = g
+        self.audio_idx = torch.randint(0, P, (num_envs,), device=device, generator=g)
+        self.node = torch.randint(0, n_nodes, (num_envs,), device=device, generator=g)
+        self.angle = torch.randint(0, 4, (num_envs,), device=device, generator=g)
+        self.t = 0  # all envs step in lockstep: host-side counter, no sync
+        self.pool = P
+
+    def _obs(self):
+        f = self.node * 4 + self.angle
+        a = self.audio_idx
+        return {
+            "rgb": self.frames_rgb.index_select(0, f),
+            "depth": self.frames_depth.index_select(0, f),
+            "mixed_bin_audio_mag": self.pool_mixed.index_select(0, a),
+            "gt_bin_comps": self.pool_gt_bin.index_select(0, a),
+            "gt_mono_comps": self.pool_gt_mono.index_select(0, a),
+            "target_class": self.pool_class.index_select(0, a),
+        }
+
+    def reset(self):
+        self.t = 0
+        return self._obs()
+
+    def step(self, actions):
+        """actions: [N,1] int64 on the device.  Returns (obs dict, rewards [N,1], not_done masks [N,1], infos dict)."""
+        a = actions.reshape(-1)
+        fwd = (a == 0).long()
+        self.node = (self.node + fwd) % self.n_nodes
+        self.angle = (self.angle + (a == 1).long() + 3 * (a == 2).long()) % 4
+        self.t += 1
+        done = self.t >= self.episode_len
+        if done:  # auto-reset: a new mixture and pose for every env
+            self.t = 0
+            self.audio_idx = torch.randint(0, self.pool, (self.num_envs,), device=self.device, generator=self._g)
+            self.node = torch.randint(0, self.n_nodes, (self.num_envs,), device=self.device, generator=self._g)
+            self.angle = torch.randint(0, 4, (self.num_envs,), device=self.device, generator=self._g)
+        masks = torch.full((self.num_envs, 1), 0.0 if done else 1.0, device=self.device)
+        rewards = torch.zeros(self.num_envs, 1, device=self.device)  # nav reward (weight 0 in nearTarget.yaml:48-49)
+        infos = {"normalized_geo_distance_to_target_audio_source": torch.zeros(self.num_envs, 1, device=self.device),
+                 "geo_distance_to_target_audio_source": torch.zeros(self.num_envs, 1, device=self.device)}
+        return self._obs(), rewards, masks, infos
+
+    def close(self):
+        pass

@@ -1,0 +1,231 @@
+"""DD-PPO trainer on MI355X: the training cycle of audio_separation/rl/ppo/ppo_trainer.py (PPOTrainer, :40-1013) restated
+around the m2h modules and the synthetic on-device environment.
+
+Kept: the schedule (num_updates_per_cycle x (num_steps rollout + update_pol), then num_updates_per_cycle x update_sep;
+:730-1011), _collect_rollout_step's data flow (:253-478), reward override incl. the extra reward at MAX_EPISODE_STEPS-2
+(:385-405), STFT-L2 bookkeeping (:407-420), linear LR / clip decay (:733-739, :711-718), per-rank seeding (:609-611), the
+stats all-reduces (:839-860).  Changed in mechanism only:
+  * no host sync inside the rollout step: the env consumes device actions, rewards/losses/statistics stay on the device
+    (the reference does ~50 ``.item()``/``.cpu()`` per step);
+  * the separator outputs for the *next* observation, which the reference computes for the reward (:358-373), are re-used as
+    the *current* outputs of the following step (same frozen networks, same observation): half the U-Net passes, identical
+    values; invalidated whenever acoustic_mem changes (after update_sep);
+  * checkpoints keep the reference format {"state_dict", "config"} (:223-238).
+Out of scope: Habitat env construction, TensorBoard, the eval loop (:1015-1551).
+"""
+import os
+import time
+import warnings
+from types import SimpleNamespace
+
+import torch
+from torch.optim.lr_scheduler import LambdaLR
+
+from ... import ops
+from ...common.rollout_storage import RolloutStoragePol, RolloutStorageSep
+from ...common.utils import linear_decay
+from ...envs.synthetic_env import SyntheticVecEnv
+from .policy import Move2HearPolicy
+from .ppo import DDPPO, PPO
+
+
+def near_target_config(**over):
+    """RL.PPO.* of config/train/nearTarget.yaml:17-56 (+ config/default.py:66-98 defaults) as a flat namespace."""
+    c = dict(NUM_PROCESSES=14, NUM_UPDATES=16786, CHECKPOINT_INTERVAL=89, LOG_INTERVAL=50, SEED=0, EXTRA_RGB=False, EXTRA_DEPTH=True,
+             MAX_EPISODE_STEPS=20, num_updates_per_cycle=6, hidden_size=512, value_loss_coef=0.5, bin_separation_loss_coef=1.0,
+             mono_conversion_loss_coef=1.0, entropy_coef=0.20, lr_pol=1.0e-4, lr_sep=5.0e-4, clip_param=0.1, ppo_epoch=4,
+             num_mini_batch=1, eps=1.0e-5, max_grad_norm=0.5, num_steps=20, use_gae=True, gamma=0.99, tau=0.95,
+             use_linear_clip_decay=True, use_linear_lr_decay=True, sep_reward_weight=1.0, nav_reward_weight=0.0,
+             extra_reward_multiplier=10.0, reward_window_size=50, use_ddppo=True, CHECKPOINT_FOLDER=None)
+    c.update(over)
+    return SimpleNamespace(**c)
+
+
+def far_target_config(**over):
+    """config/train/farTarget.yaml differs in reward weights and episode length only."""
+    return near_target_config(**dict(dict(MAX_EPISODE_STEPS=80, sep_reward_weight=0.0, nav_reward_weight=1.0), **over))
+
+
+class PPOTrainer:
+    def __init__(self, config=None, device=None, world_rank=0, world_size=1):
+        self.config = config if config is not None else near_target_config()
+        self.device = device if device is not None else torch.device("cuda", 0)
+        self.world_rank, self.world_size = world_rank, world_size
+        self.actor_critic = None
+        self.agent = None
+        self.envs = None
+        self._next_cache = None
+
+    # ------------------------------------------------------------------ setup (reference :101-222, :542-577, :588-661)
+    def setup(self, passive_state_dict=None):
+        cfg = self.config
+        seed = cfg.SEED + self.world_rank * cfg.NUM_PROCESSES
+        torch.manual_seed(seed)
+        self.envs = SyntheticVecEnv(cfg.NUM_PROCESSES, self.device, seed=seed, episode_len=cfg.MAX_EPISODE_STEPS)
+        self.actor_critic = Move2HearPolicy(
+            observation_space=self.envs.observation_spaces[0], action_space=self.envs.action_spaces[0], goal_sensor_uuid="spectrogram",
+            hidden_size=cfg.hidden_size, extra_rgb=cfg.EXTRA_RGB, extra_depth=cfg.EXTRA_DEPTH, use_ddppo=cfg.use_ddppo,
+            world_rank=self.world_rank)
+        self.actor_critic.to(self.device)
+        cls = DDPPO if cfg.use_ddppo else PPO
+        self.agent = cls(actor_critic=self.actor_critic, clip_param=cfg.clip_param, ppo_epoch=cfg.ppo_epoch,
+                         num_mini_batch=cfg.num_mini_batch, value_loss_coef=cfg.value_loss_coef,
+                         bin_separation_loss_coef=cfg.bin_separation_loss_coef, mono_conversion_loss_coef=cfg.mono_conversion_loss_coef,
+                         entropy_coef=cfg.entropy_coef, lr_pol=cfg.lr_pol, lr_sep=cfg.lr_sep, eps=cfg.eps,
+                         max_grad_norm=cfg.max_grad_norm, freeze_passive_separators=True)
+        self.actor_critic.train()
+        if passive_state_dict is not None:
+            self.agent.load_pretrained_passive_separators(passive_state_dict)
+        for name in ("binSep_enc", "binSep_dec", "bin2mono_enc", "bin2mono_dec"):  # :557-577
+            m = getattr(self.actor_critic, name)
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad_(False)
+        if cfg.use_ddppo and self.world_size > 1:
+            self.agent.init_distributed(find_unused_params=True)
+        N = self.envs.num_envs
+        space = self.envs.observation_spaces[0]
+        self.rollouts_pol = RolloutStoragePol(cfg.num_steps, N, space, cfg.hidden_size)
+        self.rollouts_sep = RolloutStorageSep(cfg.num_steps * cfg.num_updates_per_cycle, N, space)
+        self.rollouts_pol.to(self.device)
+        self.rollouts_sep.to(self.device)
+        batch = self.envs.reset()
+        for sensor in self.rollouts_pol.observations:
+            self.rollouts_pol.observations[sensor][0].copy_(batch[sensor])
+            self.rollouts_sep.observations[sensor][0].copy_(batch[sensor])
+        z = lambda *s: torch.zeros(*s, device=self.device)  # noqa: E731
+        self.stats = SimpleNamespace(
+            episode_rewards=z(N, 1), episode_counts=z(N, 1), episode_steps=z(N, 1), episode_dist_probs=z(N, 3),
+            episode_bin_losses_allSteps=z(N, 1), episode_mono_losses_lastStep=z(N, 1), episode_mono_losses_allSteps=z(N, 1),
+            episode_monoFromMem_losses_lastStep=z(N, 1), episode_monoFromMem_losses_allSteps=z(N, 1),
+            current_episode_reward=z(N, 1), current_episode_step=z(N, 1), current_episode_dist_probs=z(N, 3),
+            current_episode_bin_losses=z(N, 1), current_episode_mono_losses=z(N, 1), current_episode_monoFromMem_losses=z(N, 1))
+        self._episode_step_host = 0
+        # the reference steps the LR schedulers at the START of each sub-update (:733-735, :981-982); torch warns about that order
+        warnings.filterwarnings("ignore", message="Detected call of `lr_scheduler.step\\(\\)` before `optimizer.step\\(\\)`")
+        self.lr_scheduler_pol = LambdaLR(self.agent.optimizer_pol, lr_lambda=lambda x: linear_decay(x, cfg.NUM_UPDATES))
+        self.lr_scheduler_sep = LambdaLR(self.agent.optimizer_sep, lr_lambda=lambda x: linear_decay(x, cfg.NUM_UPDATES))
+        self.count_steps = 0
+        self.num_updates_done = 0
+
+    # ------------------------------------------------------------------ rollout step (reference :253-478)
+    def _separate(self, obs):
+        ac = self.actor_critic
+        pm = ac.get_binSepMasks(obs)
+        mono = ac.convert_bin2mono(pm, mixed_audio=obs["mixed_bin_audio_mag"])
+        return pm, mono
+
+    def _collect_rollout_step(self):
+        cfg, ac, ro, rs, st = self.config, self.actor_critic, self.rollouts_pol, self.rollouts_sep, self.stats
+        L = 512 * 32
+        with torch.no_grad():
+            step_observation = {k: v[ro.step] for k, v in ro.observations.items()}
+            if self._next_cache is not None:
+                pred_binSepMasks, pred_mono, pred_monoFromMem = self._next_cache  # computed for the reward of the previous step
+            else:
+                pred_binSepMasks, pred_mono = self._separate(step_observation)
+                pred_monoFromMem = ac.get_monoFromMem_masked(pred_mono, ro.prev_pred_monoFromMem[ro.step], ro.masks[ro.step])
+            values, actions, actions_log_probs, recurrent_hidden_states_pol, distribution_probs = ac.act(
+                step_observation, ro.recurrent_hidden_states_pol[ro.step], ro.masks[ro.step], pred_binSepMasks=pred_binSepMasks,
+                pred_mono=pred_mono, pred_monoFromMem=pred_monoFromMem)
+            batch, rewards, masks, infos = self.envs.step(actions)  # device in, device out
+            # next-step predictions, needed for the reward of the present step (:358-373)
+            next_pred_binSepMasks, next_pred_mono = self._separate(batch)
+            next_pred_monoFromMem = ac.get_monoFromMem_masked(next_pred_mono, pred_monoFromMem, masks)
+            self._next_cache = (next_pred_binSepMasks, next_pred_mono, next_pred_monoFromMem)
+            if cfg.sep_reward_weight == 1.0 and cfg.nav_reward_weight == 0.0:  # :385-405
+                nxt = ops.sq_stats(next_pred_monoFromMem, batch["gt_mono_comps"], 0)
+                cur = ops.sq_stats(pred_monoFromMem, step_observation["gt_mono_comps"], 0)
+                rewards = ops.rewards_from_stats(nxt, cur, masks, L, True)
+                if self._episode_step_host == cfg.MAX_EPISODE_STEPS - 2:
+                    rewards = rewards + ops.rewards_from_stats(nxt, None, masks, L, False, cfg.extra_reward_multiplier)
+            # STFT-L2 bookkeeping (:407-420)
+            bin_losses = ops.stft_l2(pred_binSepMasks, step_observation["gt_bin_comps"], 2, mix=step_observation["mixed_bin_audio_mag"])
+            mono_losses = ops.stft_l2(pred_mono, step_observation["gt_mono_comps"], 1)
+            monoFromMem_losses = ops.stft_l2(pred_monoFromMem, step_observation["gt_mono_comps"], 1)
+            st.current_episode_reward += rewards
+            st.current_episode_step += 1
+            st.current_episode_dist_probs += distribution_probs
+            st.current_episode_bin_losses += bin_losses
+            st.current_episode_mono_losses += mono_losses
+            st.current_episode_monoFromMem_losses += monoFromMem_losses
+            nd = 1 - masks
+            st.episode_rewards += nd * st.current_episode_reward
+            st.episode_steps += nd * st.current_episode_step
+            st.episode_counts += nd
+            st.episode_dist_probs += nd * (st.current_episode_dist_probs / st.current_episode_step)
+            st.episode_bin_losses_allSteps += nd * (st.current_episode_bin_losses / st.current_episode_step)
+            st.episode_mono_losses_lastStep += nd * mono_losses
+            st.episode_mono_losses_allSteps += nd * (st.current_episode_mono_losses / st.current_episode_step)
+            st.episode_monoFromMem_losses_lastStep += nd * monoFromMem_losses
+            st.episode_monoFromMem_losses_allSteps += nd * (st.current_episode_monoFromMem_losses / st.current_episode_step)
+            for name in ("current_episode_reward", "current_episode_step", "current_episode_bin_losses", "current_episode_mono_losses",
+                         "current_episode_monoFromMem_losses", "current_episode_dist_probs"):
+                getattr(st, name).mul_(masks)
+            self._episode_step_host = (self._episode_step_host + 1) % cfg.MAX_EPISODE_STEPS
+            ro.insert(batch, recurrent_hidden_states_pol, actions, actions_log_probs, values, rewards, masks,
+                      pred_binSepMasks=pred_binSepMasks, pred_mono=pred_mono, pred_monoFromMem=pred_monoFromMem)
+            rs.insert(batch, masks, pred_monoFromMem=pred_monoFromMem)
+        return self.envs.num_envs
+
+    # ------------------------------------------------------------------ updates (reference :480-541)
+    def _update_pol(self):
+        cfg, ro = self.config, self.rollouts_pol
+        with torch.no_grad():
+            last_observation = {k: v[-1] for k, v in ro.observations.items()}
+            next_value = self.actor_critic.get_value(
+                last_observation, ro.recurrent_hidden_states_pol[-1], ro.masks[-1], pred_binSepMasks=ro.pred_binSepMasks[-1],
+                pred_mono=ro.pred_mono[-1], pred_monoFromMem=ro.prev_pred_monoFromMem[-1]).detach()
+        ro.compute_returns(next_value, cfg.use_gae, cfg.gamma, cfg.tau)
+        out = self.agent.update_pol(ro)
+        ro.after_update()
+        return out
+
+    def _update_sep(self):
+        out = self.agent.update_sep(self.rollouts_sep)
+        self.rollouts_sep.after_update()
+        self._next_cache = None  # acoustic_mem changed: the cached next-step memory output is stale
+        return out
+
+    def train_cycle(self):
+        """One cycle of the reference schedule (:730-1011): returns a dict of timings and losses."""
+        cfg = self.config
+        t0 = time.perf_counter()
+        steps = 0
+        pol_losses, sep_losses = None, None
+        for _sub in range(cfg.num_updates_per_cycle):
+            if cfg.use_linear_lr_decay:
+                self.lr_scheduler_pol.step()
+            if cfg.use_linear_clip_decay:
+                self.agent.clip_param = cfg.clip_param * linear_decay(self.num_updates_done, cfg.NUM_UPDATES)
+            for _step in range(cfg.num_steps):
+                steps += self._collect_rollout_step()
+            pol_losses = self._update_pol()
+            self.num_updates_done += 1
+        for _sub in range(cfg.num_updates_per_cycle):
+            if cfg.use_linear_lr_decay:
+                self.lr_scheduler_sep.step()
+            sep_losses = self._update_sep()
+        self.count_steps += steps
+        return {"env_steps": steps, "seconds": time.perf_counter() - t0, "pol_losses": pol_losses, "sep_losses": sep_losses}
+
+    def all_reduce_stats(self):
+        """The per-update statistics all-reduces of :790-860, fused into one small collective."""
+        st = self.stats
+        t = torch.cat([st.episode_rewards, st.episode_counts, st.episode_steps, st.episode_bin_losses_allSteps,
+                       st.episode_mono_losses_lastStep, st.episode_monoFromMem_losses_lastStep], dim=1).sum(0)
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t)
+        return t
+
+    def save_checkpoint(self, file_name):
+        ckpt = {"state_dict": {"actor_critic." + k: v for k, v in self.actor_critic.state_dict().items()}, "config": vars(self.config)}
+        os.makedirs(self.config.CHECKPOINT_FOLDER, exist_ok=True)
+        torch.save(ckpt, os.path.join(self.config.CHECKPOINT_FOLDER, file_name))
+
+    def train(self, num_cycles):
+        out = []
+        for _ in range(num_cycles):
+            out.append(self.train_cycle())
+        return out
