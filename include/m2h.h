@@ -238,8 +238,10 @@ int m2h_pack_dgrad_weight(const float* w, float* wp, int Co, int Ci, int KH, int
 /* out = dy * (y > 0 ? 1 : slope): backward of the fused ReLU (slope 0) / LeakyReLU epilogue, y = the forward output. */
 int m2h_act_bwd(const float* dy, const float* y, float slope, float* out, size_t n, m2h_stream stream);
 
-/* db[n] = sum_m dy[m][n]  (Conv2d / Linear bias gradient), deterministic. */
-int m2h_bias_grad(const float* dy, float* db, int M, int N, m2h_stream stream);
+/* db[n] = sum_m dy[m][n]  (Conv2d / Linear bias gradient); two ordered reduction stages (deterministic).
+ * workspace: m2h_bias_grad_workspace_bytes(M, N) bytes of device scratch. */
+size_t m2h_bias_grad_workspace_bytes(int M, int N);
+int m2h_bias_grad(const float* dy, float* db, int M, int N, float* workspace, m2h_stream stream);
 
 /* GRU backward, one time step (torch.nn.GRU semantics, rnn_state_encoder.py:86-137 under autograd): inputs of
  * m2h_gru_gates plus dh = dL/dh_out; outputs dgi = dL/d(gi), dpre = dL/d(mask*gh_raw + b_hh) (so dL/dgh_raw = mask*dpre,

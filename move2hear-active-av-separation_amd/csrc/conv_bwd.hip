@@ -271,17 +271,36 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     out[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
 }
 
-// db[n] = sum_m dy[m][n]; one block per 64 columns, 4 waves stride the rows, ordered final sum (deterministic).
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int N) {
+// db[n] = sum_m dy[m][n].  Two ordered stages (deterministic): grid (column blocks of 64, row splits) -> part[split][n],
+// then one thread per column sums the splits.  Lanes walk columns (coalesced 256-byte rows), the 4 waves stride the rows.
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dy, float* __restrict__ part, int M, int N, int rows_per_split) {
   __shared__ float sh[4][64];
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   const int w = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * rows_per_split;
+  const int m1 = min(M, m0 + rows_per_split);
   float s = 0.f;
   if (n < N)
-    for (int m = w; m < M; m += 4) s += dy[(size_t)m * N + n];
+    for (int m = m0 + w; m < m1; m += 4) s += dy[(size_t)m * N + n];
   sh[w][threadIdx.x & 63] = s;
   __syncthreads();
-  if (w == 0 && n < N) db[n] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+  if (w == 0 && n < N) part[(size_t)blockIdx.y * N + n] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+__global__ void bias_grad_final_kernel(const float* __restrict__ part, float* __restrict__ db, int N, int splits) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += part[(size_t)z * N + n];
+  db[n] = s;
+}
+
+static int bias_grad_splits(int M, int N) {
+  const int colblocks = (N + 63) / 64;
+  int splits = (1024 + colblocks - 1) / colblocks;  // ~4 blocks per CU
+  if (splits > (M + 63) / 64) splits = (M + 63) / 64;  // at least 64 rows per split
+  if (splits < 1) splits = 1;
+  return splits;
 }
 
 }  // namespace m2h
@@ -315,9 +334,17 @@ int m2h_act_bwd(const float* dy, const float* y, float slope, float* out, size_t
   return launch_status("act_bwd");
 }
 
-int m2h_bias_grad(const float* dy, float* db, int M, int N, m2h_stream stream) {
-  M2H_REQUIRE(dy && db && M > 0 && N > 0, "bias_grad: bad arguments");
-  hipLaunchKernelGGL(bias_grad_kernel, dim3((N + 63) / 64), dim3(256), 0, as_stream(stream), dy, db, M, N);
+size_t m2h_bias_grad_workspace_bytes(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (size_t)bias_grad_splits(M, N) * N * sizeof(float);
+}
+
+int m2h_bias_grad(const float* dy, float* db, int M, int N, float* workspace, m2h_stream stream) {
+  M2H_REQUIRE(dy && db && workspace && M > 0 && N > 0, "bias_grad: bad arguments");
+  const int splits = bias_grad_splits(M, N);
+  const int rps = (M + splits - 1) / splits;
+  hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, as_stream(stream), dy, workspace, M, N, rps);
+  hipLaunchKernelGGL(bias_grad_final_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), workspace, db, N, splits);
   return launch_status("bias_grad");
 }
 

@@ -99,7 +99,8 @@ def bias_grad(dy2d):
     db = torch.empty(N, device=dy2d.device, dtype=torch.float32)
     lib = _lib.load()
     with torch.cuda.device(dy2d.device):
-        _lib.check(lib.m2h_bias_grad(ops._ptr(dy2d), ops._ptr(db), M, N, ops._stream(dy2d)), "m2h_bias_grad")
+        ws = torch.empty((lib.m2h_bias_grad_workspace_bytes(M, N) + 3) // 4, device=dy2d.device, dtype=torch.float32)
+        _lib.check(lib.m2h_bias_grad(ops._ptr(dy2d), ops._ptr(db), M, N, ops._ptr(ws), ops._stream(dy2d)), "m2h_bias_grad")
     return db
 
 
@@ -206,10 +207,8 @@ class GRUSequence(torch.autograd.Function):
         h = h0.contiguous()
         for t in range(T):
             sl = slice(t * N, (t + 1) * N)
-            ght = _lin_nograd(h, w_hh.detach(), None, "gru.hh")
-            gh[sl].copy_(ght)
-            h = ops.gru_gates(gi[sl], ght, b_hh.detach(), h, masks[sl])
-            out[sl].copy_(h)
+            ght = ops.linear(h, w_hh.detach(), None, name="gru.hh", out=gh[sl])      # written in place into the saved buffer
+            h = ops.gru_gates(gi[sl], ght, b_hh.detach(), h, masks[sl], out=out[sl])
         ctx.T = T
         ctx.save_for_backward(x, h0, masks, w_ih, w_hh, b_hh, gi, gh, out)
         return out, h

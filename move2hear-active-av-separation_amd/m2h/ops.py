@@ -231,7 +231,7 @@ def conv_igemm_f32(**kw):
 # ----------------------------------------------------------------------------------------------------------------
 # generic conv / linear on the igemm engine, and the RL-path ops
 # ----------------------------------------------------------------------------------------------------------------
-def conv2d_nhwc(x, wp, n_out, kh, kw, stride=1, pad=0, bias=None, scale=None, slope=1.0, x2=None, deslice=False, name="conv2d"):
+def conv2d_nhwc(x, wp, n_out, kh, kw, stride=1, pad=0, bias=None, scale=None, slope=1.0, x2=None, deslice=False, name="conv2d", out=None):
     """Conv2d over NHWC activations through m2h_conv_igemm_f32.  x [B,H,W,C0] (+ x2 [B,H,W,C1] concatenated on channels),
     wp packed [n_out, kh*kw*(C0+C1)], bias -> epilogue shift, slope: 1 none / 0 ReLU / 0.2 LeakyReLU.
     Returns NHWC [B,Ho,Wo,n_out], or the de-sliced BHWC [B,16*Ho,Wo,n_out/16] when deslice."""
@@ -245,7 +245,11 @@ def conv2d_nhwc(x, wp, n_out, kh, kw, stride=1, pad=0, bias=None, scale=None, sl
     Wo = (W + 2 * pad - kw) // stride + 1
     if wp.numel() != n_out * kh * kw * (C0 + C1):
         raise RuntimeError("m2h.%s: packed weight has %d elements, expected %d" % (name, wp.numel(), n_out * kh * kw * (C0 + C1)))
-    if deslice:
+    if out is not None:
+        _chk(out, name + "(out)")
+        if out.numel() != B * Ho * Wo * n_out:
+            raise RuntimeError("m2h.%s: out has %d elements, expected %d" % (name, out.numel(), B * Ho * Wo * n_out))
+    elif deslice:
         out = torch.empty((B, 16 * Ho, Wo, n_out // 16), device=x.device, dtype=torch.float32)
     else:
         out = torch.empty((B, Ho, Wo, n_out), device=x.device, dtype=torch.float32)
@@ -271,10 +275,10 @@ def conv2d_nhwc(x, wp, n_out, kh, kw, stride=1, pad=0, bias=None, scale=None, sl
     return out
 
 
-def linear(x, w, bias=None, slope=1.0, name="linear"):
-    """y = act(x W^T + b): x [M,K], w [N,K] (torch Linear layout == packed [N][K])."""
+def linear(x, w, bias=None, slope=1.0, name="linear", out=None):
+    """y = act(x W^T + b): x [M,K], w [N,K] (torch Linear layout == packed [N][K]); out: optional [M,N] destination."""
     M, K = x.shape
-    y = conv2d_nhwc(x.reshape(M, 1, 1, K), w, w.shape[0], 1, 1, bias=bias, slope=slope, name=name)
+    y = conv2d_nhwc(x.reshape(M, 1, 1, K), w, w.shape[0], 1, 1, bias=bias, slope=slope, name=name, out=out)
     return y.reshape(M, w.shape[0])
 
 
@@ -322,13 +326,13 @@ def visual_input(rgb, depth=None):
     return out
 
 
-def gru_gates(gi, gh_raw, bhh, hprev, mask=None):
-    for t in (gi, gh_raw, bhh, hprev, mask):
+def gru_gates(gi, gh_raw, bhh, hprev, mask=None, out=None):
+    for t in (gi, gh_raw, bhh, hprev, mask, out):
         _chk(t, "gru_gates")
     M, H = hprev.shape
     if gi.shape != (M, 3 * H) or gh_raw.shape != (M, 3 * H) or bhh.numel() != 3 * H or (mask is not None and mask.numel() != M):
         raise RuntimeError("m2h.gru_gates: shape mismatch")
-    hout = torch.empty_like(hprev)
+    hout = out if out is not None else torch.empty_like(hprev)
     lib = _lib.load()
     with torch.cuda.device(gi.device):
         _lib.check(lib.m2h_gru_gates(_ptr(gi), _ptr(gh_raw), _ptr(bhh), _ptr(hprev), _ptr(mask), _ptr(hout), M, H, _stream(gi)), "m2h_gru_gates")
