@@ -1,0 +1,76 @@
+"""DD-PPO collectives: drop-in for the distributed part of audio_separation/rl/ppo/ddppo_utils.py (:117-190) and of
+DecentralizedDistributedMixin (ppo.py:275-319).  One process per GPU, torch.distributed over RCCL ("nccl" on ROCm); the
+same code runs over gloo on CPU for the world_size-2 tests.  The data path of the hot loop has exactly three collectives:
+
+  broadcast_parameters   once, rank 0 -> all  (DDP construction, ppo.py:298-307)
+  reduce_gradients       one flat sum all-reduce per backward (23.3 MB for the policy; replaces DDP's bucketed reducer,
+                         ppo.py:313-319); the division by world size happens inside the optimizer step
+  advantage statistics   two scalar all-reduces per update_pol (ddppo_utils.py:168-190)
+
+The local arithmetic (means, squared differences, normalisation) is injected as callables: HIP kernels in the product
+(m2h.ops.advantages / adv_sqdiff / adv_apply), the CPU oracle in the gloo tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distrib(backend="nccl", device=None):
+    """Env-var rendezvous of torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), the same
+    variables init_distrib_slurm reads (ddppo_utils.py:131-147).  Returns (local_rank, world_rank, world_size)."""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_rank = int(os.environ.get("RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "8738")  # config/default.py:97
+    if world_size > 1 and not dist.is_initialized():
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, rank=world_rank, world_size=world_size, **kw)
+    return local_rank, world_rank, world_size
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def broadcast_parameters(tensors, src=0):
+    if world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in tensors:
+            dist.broadcast(t.data, src)
+
+
+def reduce_gradients(flat_grad):
+    """Sum all-reduce of the flat gradient buffer; returns the scale (1/world) the optimizer applies before clipping."""
+    w = world_size()
+    if w == 1:
+        return 1.0
+    dist.all_reduce(flat_grad)
+    return 1.0 / w
+
+
+def normalize_advantages_distributed(raw_adv, local_mean, sqdiff_fn, apply_fn, eps=1e-5):
+    """_get_advantages_distributed (ppo.py:275-284): global mean = mean of per-rank means, global var = mean over ranks of the
+    per-rank mean((A - mean)^2) (biased), A <- (A - mean) / (sqrt(var) + eps).
+    local_mean: 1-element tensor; sqdiff_fn(adv, mean) -> 1-element tensor mean((adv-mean)^2); apply_fn(adv, mean, var, eps)."""
+    w = world_size()
+    mean = local_mean.clone()
+    if w > 1:
+        dist.all_reduce(mean)
+        mean /= w
+    var = sqdiff_fn(raw_adv, mean)
+    if w > 1:
+        dist.all_reduce(var)
+        var /= w
+    return apply_fn(raw_adv, mean, var, eps)
+
+
+def all_reduce_stats(t):
+    """The logging all-reduces of ppo_trainer.py:839-860 fused into one call."""
+    if world_size() > 1:
+        dist.all_reduce(t)
+    return t

@@ -20,6 +20,7 @@ import torch.nn as nn
 from ... import functional as MF
 from ... import ops
 from ...optim import FlatAdam
+from . import ddppo_utils
 
 EPS_PPO = 1e-5
 
@@ -75,31 +76,19 @@ class PPO(nn.Module):
         return ops.advantages(rollouts_pol.returns, rollouts_pol.value_preds, 1, EPS_PPO)[0]
 
     def _get_advantages_distributed(self, rollouts_pol):
-        import torch.distributed as dist
         adv, stats = ops.advantages(rollouts_pol.returns, rollouts_pol.value_preds, 2)
-        mean = stats[0:1].clone()
-        dist.all_reduce(mean)
-        mean /= self._world
-        var = ops.adv_sqdiff(adv, mean)
-        dist.all_reduce(var)
-        var /= self._world
-        return ops.adv_apply(adv, mean, var, EPS_PPO)
+        return ddppo_utils.normalize_advantages_distributed(adv, stats[0:1], ops.adv_sqdiff, ops.adv_apply, EPS_PPO)
 
     # ------------------------------------------------------------------ distributed
     def init_distributed(self, find_unused_params: bool = True) -> None:
         """Broadcast rank 0's parameters/buffers and switch gradient reduction on (reference :286-311)."""
-        import torch.distributed as dist
-        self._world = dist.get_world_size()
+        self._world = ddppo_utils.world_size()
         self.find_unused_params = find_unused_params
-        with torch.no_grad():
-            for t in list(self.actor_critic.parameters()) + list(self.actor_critic.buffers()):
-                dist.broadcast(t.data, 0)
+        ddppo_utils.broadcast_parameters(list(self.actor_critic.parameters()) + list(self.actor_critic.buffers()))
 
     def _reduce_grads(self, opt):
         if self._world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(opt.grad_buffer())  # one flat sum all-reduce (RCCL); averaged by grad_scale in the step
-            return 1.0 / self._world
+            return ddppo_utils.reduce_gradients(opt.grad_buffer())  # one flat sum all-reduce (RCCL)
         return 1.0
 
     # ------------------------------------------------------------------ policy update (reference :82-177)

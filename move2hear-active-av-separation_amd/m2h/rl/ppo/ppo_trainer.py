@@ -214,10 +214,8 @@ class PPOTrainer:
         st = self.stats
         t = torch.cat([st.episode_rewards, st.episode_counts, st.episode_steps, st.episode_bin_losses_allSteps,
                        st.episode_mono_losses_lastStep, st.episode_monoFromMem_losses_lastStep], dim=1).sum(0)
-        if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(t)
-        return t
+        from . import ddppo_utils
+        return ddppo_utils.all_reduce_stats(t)
 
     def save_checkpoint(self, file_name):
         ckpt = {"state_dict": {"actor_critic." + k: v for k, v in self.actor_critic.state_dict().items()}, "config": vars(self.config)}

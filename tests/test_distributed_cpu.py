@@ -1,0 +1,69 @@
+"""CPU, 2 processes over gloo: the collective protocol of the DD-PPO path (m2h/rl/ppo/ddppo_utils.py) -- parameter
+broadcast, flat gradient all-reduce + averaging, distributed advantage normalisation -- with the local arithmetic supplied
+by the CPU oracle (the HIP kernels that supply it in the product are covered by the -m gpu tests)."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    for p in (os.path.join(ROOT, "move2hear-active-av-separation_amd"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import m2h_oracle as O
+    from m2h.rl.ppo import ddppo_utils as D
+    lr, wr, ws = D.init_distrib("gloo")
+    assert (lr, wr, ws) == (rank, rank, world) and D.world_size() == world
+    # 1. broadcast: every rank ends with rank 0's parameters
+    g = torch.Generator().manual_seed(100 + rank)
+    params = [torch.randn(7, 5, generator=g), torch.randn(11, generator=g)]
+    D.broadcast_parameters(params)
+    ref = [torch.randn(7, 5, generator=torch.Generator().manual_seed(100)), None]
+    ok_b = torch.equal(params[0], ref[0])
+    # 2. flat gradient all-reduce + 1/world scaling == mean of the per-rank gradients
+    grads = [torch.full((1000,), float(r + 1)) + torch.arange(1000.0) * (r + 1) for r in range(world)]
+    flat = grads[rank].clone()
+    scale = D.reduce_gradients(flat)
+    ok_g = torch.allclose(flat * scale, sum(grads) / world)
+    # 3. distributed advantage normalisation == the reference formula evaluated on all ranks' data
+    advs = [torch.randn(20, 14, 1, generator=torch.Generator().manual_seed(7 + r)) * (1 + r) + r for r in range(world)]
+    mine = advs[rank].clone()
+    out = D.normalize_advantages_distributed(
+        mine, mine.mean().reshape(1), lambda a, m: (a - m).pow(2).mean().reshape(1), lambda a, m, v, e: (a - m) / (v.sqrt() + e), 1e-5)
+    expect = O.get_advantages_distributed(advs)[rank]
+    ok_a = torch.allclose(out, expect, atol=1e-6)
+    # 4. fused stats all-reduce
+    t = D.all_reduce_stats(torch.tensor([1.0 + rank, 2.0]))
+    ok_s = torch.allclose(t, torch.tensor([sum(1.0 + r for r in range(world)), 2.0 * world]))
+    q.put((rank, ok_b, ok_g, ok_a, ok_s))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_protocol():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    for r in res:
+        assert all(r[1:]), r
