@@ -223,7 +223,8 @@ int m2h_stft_l2(const float* mix, const float* pred, int Cp, const float* gt_com
 
 /* Weight gradient in the packed layout: dw[n][k] = sum_m dy[m][n] * A[m][k], with A gathered from args->src0/src1 exactly as
  * the forward launch described by args does (same geometry fields; wp/scale/shift/dst are ignored; conv_transpose must be
- * 0).  dy: [M][ldy] (the NHWC output gradient, activation already back-propagated with m2h_act_bwd).  args->workspace must
+ * 0).  dy: NHWC output gradient [B][Ho][Wo][ldy] (activation already back-propagated); row m is read at output pixel
+ * (q*os+ph, r*os+pw), i.e. at row m itself for an ordinary conv.  args->workspace must
  * hold m2h_conv_wgrad_workspace_bytes(args) bytes (pixel range is split over blocks, partial tiles are summed in a fixed
  * order: bit-reproducible). */
 size_t m2h_conv_wgrad_workspace_bytes(const m2h_conv_args* args /* host */);
@@ -262,10 +263,11 @@ int m2h_policy_heads_bwd(const float* logp_all, const float* probs, const long l
 int m2h_l1_loss(const float* pred, const float* gt, int gt_stride, int gt_off, float* loss, float* grad, float* scratch, size_t n,
                 m2h_stream stream);
 
-/* Binaural separation L1 (ppo.py:219-221; passive_trainer.py:270-272): loss[0] = mean |(exp(mix)-1)*masks - gt_bin_comps[..., {0,2}]|
- * over [npix][2]; grad_masks (NULL to skip) = d loss / d masks.  mix, masks: [npix][2]; gt_bin_comps: [npix][Cg]. */
-int m2h_bin_l1_loss(const float* mix, const float* masks, const float* gt_bin_comps, int Cg, float* loss, float* grad_masks, float* scratch,
-                    size_t npix, m2h_stream stream);
+/* Binaural separation L1 (ppo.py:219-221; passive_trainer.py:270-272): loss[0] = mean |(exp(mix)-1)*masks - gt[..., cstep*c]|, c < 2,
+ * over [npix][2]; gt: [npix][Cg] (cstep 2 reads the magnitudes of interleaved (mag, phase) components, cstep 1 a plain
+ * 2-channel tensor); grad_masks (NULL to skip) = d loss / d masks.  mix, masks: [npix][2]. */
+int m2h_bin_l1_loss(const float* mix, const float* masks, const float* gt_bin_comps, int Cg, int cstep, float* loss, float* grad_masks,
+                    float* scratch, size_t npix, m2h_stream stream);
 
 /* nn.utils.clip_grad_norm_ (ppo.py:254-268) over one flat gradient buffer: coef[0] = min(1, max_norm/(||g||_2 + 1e-6))
  * (1 when max_norm <= 0), coef[1] = ||g||_2; stays on the device (no host sync).  scratch: >= 1024 floats. */
@@ -275,6 +277,29 @@ int m2h_grad_clip_coef(const float* g, size_t n, float max_norm, float* coef, fl
  * coef[0]*gscale (clip coefficient from m2h_grad_clip_coef, gscale = 1/world_size after a sum all-reduce). step >= 1. */
 int m2h_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,
                   const float* coef, float gscale, m2h_stream stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Passive pre-training (pretrain/passive/passive_trainer.py:218-286): train-mode BatchNorm and transposed-conv gradients.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* binSep stage-0 input for training: the 16-way slice of mix plus the (target_class+1) plane as a real channel
+ * (separator_cnn.py:85-99): out [B][F/16][T][ldo], channels [0,16C) = slice, 16C = cls_val[b], rest 0; ldo % 4 == 0. */
+int m2h_sep_slice_input_plane(const float* mix, const float* cls_val, float* out, int B, int F, int T, int C, int ldo, m2h_stream stream);
+
+/* nn.BatchNorm2d in train mode + LeakyReLU/ReLU (separator_cnn.py:9-12,21-24) on z [M][C] (NHWC conv output), C % 4 == 0:
+ * batch mean / biased variance (Welford-combined, ordered), y = act((z-mean)*invstd*gamma+beta), running statistics updated
+ * in place with `momentum` and the unbiased variance (NULL to skip).  mean/invstd [C] are saved for the backward.
+ * Backward: given dy (w.r.t. y), returns dgamma, dbeta and dz.  workspace: m2h_bn_workspace_bytes(M, C). */
+size_t m2h_bn_workspace_bytes(int M, int C);
+int m2h_bn_train_fwd(const float* z, const float* gamma, const float* beta, float eps, float momentum, float slope, float* running_mean,
+                     float* running_var, float* mean, float* invstd, float* y, int M, int C, float* workspace, m2h_stream stream);
+int m2h_bn_train_bwd(const float* dy, const float* y, const float* z, const float* mean, const float* invstd, const float* gamma, float slope,
+                     float* dgamma, float* dbeta, float* dz, int M, int C, float* workspace, m2h_stream stream);
+
+/* Weight gradient of ConvTranspose2d(4,2,1): run m2h_conv_wgrad_f32 once per sub-pixel phase (args: taps 2x2, mul = 2*ph-1,
+ * off 0, stride 1, os 2, phase (ph,pw), Ho = 2*Hi: the dy rows are then read at output pixel (2q+ph, 2r+pw)) into
+ * dwp[phase][Co][4*Ci], then scatter to the torch layout dw [Ci][Co][4][4] with this call. */
+int m2h_unpack_convT_wgrad(const float* dwp, float* dw, int Ci, int Co, m2h_stream stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,212 @@
+// Train-mode BatchNorm2d over NHWC activations (gfx950, fp32), forward and backward, fused with the U-Net activations.
+// Replaces nn.BatchNorm2d(train) + LeakyReLU/ReLU of audio_separation/rl/models/separator_cnn.py:5-24 during passive
+// pre-training (pretrain/passive/passive_trainer.py:211-249, BN in train mode) and their autograd.
+//
+// Layout: z [M][C] = the conv output viewed as rows of C channels (C contiguous).  All reductions are two ordered stages
+// (row splits -> per-channel combine), so results are bit-reproducible; batch statistics use Welford/Chan combination
+// (no E[x^2]-E[x]^2 cancellation).  HBM-bound: forward reads z twice and writes y once; backward reads dy, y, z twice and
+// writes dz once.
+#include "m2h_internal.h"
+
+namespace m2h {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Wf {
+  float n, mean, m2;
+};
+
+__device__ __forceinline__ Wf wf_combine(Wf a, Wf b) {
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  Wf r;
+  r.n = a.n + b.n;
+  const float d = b.mean - a.mean;
+  r.mean = a.mean + d * (b.n / r.n);
+  r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / r.n);
+  return r;
+}
+
+// stage 1: part[split][c] = (n, mean, M2) over the split's rows
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ z, float* __restrict__ part, int M, int C, int rows_per_split) {
+  __shared__ Wf sh[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
+  Wf a = {0.f, 0.f, 0.f};
+  if (c < C)
+    for (int m = m0 + w; m < m1; m += 4) {
+      const float x = z[(size_t)m * C + c];
+      a.n += 1.f;
+      const float d = x - a.mean;
+      a.mean += d / a.n;
+      a.m2 += d * (x - a.mean);
+    }
+  sh[w][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    Wf r = wf_combine(wf_combine(sh[0][threadIdx.x], sh[1][threadIdx.x]), wf_combine(sh[2][threadIdx.x], sh[3][threadIdx.x]));
+    float* p = part + ((size_t)blockIdx.y * C + c) * 3;
+    p[0] = r.n;
+    p[1] = r.mean;
+    p[2] = r.m2;
+  }
+}
+
+// stage 2: mean, invstd = 1/sqrt(var_biased + eps); running stats update (momentum, unbiased variance) as torch does
+__global__ void bn_stats_final_kernel(const float* __restrict__ part, int splits, int C, float eps, float momentum, float* __restrict__ mean,
+                                      float* __restrict__ invstd, float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  Wf r = {0.f, 0.f, 0.f};
+  for (int s = 0; s < splits; ++s) {
+    const float* p = part + ((size_t)s * C + c) * 3;
+    Wf b = {p[0], p[1], p[2]};
+    r = wf_combine(r, b);
+  }
+  const float var_b = r.m2 / r.n;
+  mean[c] = r.mean;
+  invstd[c] = 1.f / sqrtf(var_b + eps);
+  if (running_mean != nullptr) {
+    const float var_u = r.n > 1.f ? r.m2 / (r.n - 1.f) : var_b;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * r.mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * var_u;
+  }
+}
+
+// y = act((z - mean) * invstd * gamma + beta),  act(v) = v > 0 ? v : v*slope.  C % 4 == 0.
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                       float* __restrict__ y, size_t n4, int C4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(z + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = (x[j] - mean[c + j]) * invstd[c + j] * gamma[c + j] + beta[c + j];
+      o[j] = v > 0.f ? v : v * slope;
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+  }
+}
+
+// backward stage 1: with g = dy * act'(y) and xh = (z - mean) * invstd:  part[split][0][c] = sum g, part[split][1][c] = sum g*xh
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ z,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd, float slope,
+                                                             float* __restrict__ part, int M, int C, int rows_per_split) {
+  __shared__ float sh[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    const float mu = mean[c], is = invstd[c];
+    for (int m = m0 + w; m < m1; m += 4) {
+      const size_t i = (size_t)m * C + c;
+      const float g = y[i] > 0.f ? dy[i] : dy[i] * slope;
+      s0 += g;
+      s1 += g * ((z[i] - mu) * is);
+    }
+  }
+  sh[0][w][threadIdx.x & 63] = s0;
+  sh[1][w][threadIdx.x & 63] = s1;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    const int t = threadIdx.x;
+    part[((size_t)blockIdx.y * 2 + 0) * C + c] = sh[0][0][t] + sh[0][1][t] + sh[0][2][t] + sh[0][3][t];
+    part[((size_t)blockIdx.y * 2 + 1) * C + c] = sh[1][0][t] + sh[1][1][t] + sh[1][2][t] + sh[1][3][t];
+  }
+}
+
+__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int splits, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    s0 += part[((size_t)s * 2 + 0) * C + c];
+    s1 += part[((size_t)s * 2 + 1) * C + c];
+  }
+  dbeta[c] = s0;
+  dgamma[c] = s1;
+}
+
+// dz = gamma * invstd * (g - dbeta/M - xh * dgamma/M)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ z,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, float slope, float invM, float* __restrict__ dz,
+                                                           size_t n4, int C4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const f32x4 gy = *reinterpret_cast<const f32x4*>(dy + i * 4);
+    const f32x4 yy = *reinterpret_cast<const f32x4*>(y + i * 4);
+    const f32x4 zz = *reinterpret_cast<const f32x4*>(z + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = yy[j] > 0.f ? gy[j] : gy[j] * slope;
+      const float xh = (zz[j] - mean[c + j]) * invstd[c + j];
+      o[j] = gamma[c + j] * invstd[c + j] * (g - dbeta[c + j] * invM - xh * dgamma[c + j] * invM);
+    }
+    *reinterpret_cast<f32x4*>(dz + i * 4) = o;
+  }
+}
+
+static int bn_splits(int M, int C) {
+  const int colblocks = (C + 63) / 64;
+  int splits = (1024 + colblocks - 1) / colblocks;
+  if (splits > (M + 31) / 32) splits = (M + 31) / 32;
+  if (splits < 1) splits = 1;
+  return splits;
+}
+
+static unsigned ew_grid(size_t n) {
+  size_t g = (n + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace m2h
+
+using namespace m2h;
+
+extern "C" {
+
+size_t m2h_bn_workspace_bytes(int M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  return (size_t)bn_splits(M, C) * C * 3 * sizeof(float);
+}
+
+int m2h_bn_train_fwd(const float* z, const float* gamma, const float* beta, float eps, float momentum, float slope, float* running_mean,
+                     float* running_var, float* mean, float* invstd, float* y, int M, int C, float* workspace, m2h_stream stream) {
+  M2H_REQUIRE(z && gamma && beta && mean && invstd && y && workspace && M > 1 && C > 0 && C % 4 == 0, "bn_train_fwd: bad arguments (C %% 4, M > 1)");
+  M2H_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_fwd: running stats mismatch");
+  const int splits = bn_splits(M, C);
+  const int rps = (M + splits - 1) / splits;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, z, workspace, M, C, rps);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, splits, C, eps, momentum, mean, invstd,
+                     running_mean, running_var);
+  const size_t n4 = (size_t)M * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, z, mean, invstd, gamma, beta, slope, y, n4, C / 4);
+  return launch_status("bn_train_fwd");
+}
+
+int m2h_bn_train_bwd(const float* dy, const float* y, const float* z, const float* mean, const float* invstd, const float* gamma, float slope,
+                     float* dgamma, float* dbeta, float* dz, int M, int C, float* workspace, m2h_stream stream) {
+  M2H_REQUIRE(dy && y && z && mean && invstd && gamma && dgamma && dbeta && dz && workspace && M > 1 && C > 0 && C % 4 == 0,
+              "bn_train_bwd: bad arguments");
+  const int splits = bn_splits(M, C);
+  const int rps = (M + splits - 1) / splits;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, y, z, mean, invstd, slope, workspace, M, C, rps);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, splits, C, dgamma, dbeta);
+  const size_t n4 = (size_t)M * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, dgamma, dbeta, slope,
+                     1.f / (float)M, dz, n4, C / 4);
+  return launch_status("bn_train_bwd");
+}
+
+}  // extern "C"

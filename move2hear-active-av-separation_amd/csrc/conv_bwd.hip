@@ -23,8 +23,10 @@ struct WGradP {
   int C0, C1, Ctot;
   int B, Hi, Wi, Hq, Wq;
   int stride, ntw, ntap, mulh, offh, mulw, offw;
-  const float* dy;  // [M][ldy]
+  const float* dy;  // row m -> output pixel (b, q*os+ph, r*os+pw) of an NHWC [B][Ho][Wo][ldy] tensor
   int ldy;
+  int Ho, Wo, os, ph, pw;
+  int direct;       // 1: pixel index == m (os 1, Ho x Wo == Hq x Wq)
   int N, K, Kpad;   // Kpad = K rounded up to 128
   int M;
   int S;            // splits over m (grid z)
@@ -112,7 +114,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
       const int n = n0 + yseg * 4;
       ry[i] = zero4;
       if (row < WM && m < p.M && n < p.N) {
-        const float* yp = p.dy + (size_t)m * p.ldy + n;
+        size_t pix = (size_t)m;
+        if (!p.direct) {
+          const int rr = m % p.Wq;
+          const int t = m / p.Wq;
+          const int q = t % p.Hq;
+          const int b = t / p.Hq;
+          pix = ((size_t)b * p.Ho + (size_t)(q * p.os + p.ph)) * p.Wo + (size_t)(rr * p.os + p.pw);
+        }
+        const float* yp = p.dy + pix * p.ldy + n;
         if (n + 3 < p.N && (p.ldy & 3) == 0) {
           ry[i] = *reinterpret_cast<const f32x4*>(yp);
         } else {
@@ -220,6 +230,9 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   p.src0 = a.src0; p.src1 = a.src1; p.C0 = a.C0; p.C1 = a.C1; p.Ctot = a.C0 + a.C1;
   p.B = a.B; p.Hi = a.Hi; p.Wi = a.Wi; p.Hq = a.Hq; p.Wq = a.Wq;
   p.stride = a.stride; p.ntw = a.ntw; p.ntap = a.nth * a.ntw; p.mulh = a.mulh; p.offh = a.offh; p.mulw = a.mulw; p.offw = a.offw;
+  p.Ho = a.Ho; p.Wo = a.Wo; p.os = a.os; p.ph = a.ph; p.pw = a.pw;
+  p.direct = (a.os == 1 && a.ph == 0 && a.pw == 0 && a.Ho == a.Hq && a.Wo == a.Wq) ? 1 : 0;
+  M2H_REQUIRE(a.os >= 1 && (a.Hq - 1) * a.os + a.ph < a.Ho && (a.Wq - 1) * a.os + a.pw < a.Wo, "conv_wgrad: output pixel grid exceeds Ho x Wo");
   p.dy = dy; p.ldy = ldy; p.N = a.N; p.K = p.ntap * p.Ctot; p.Kpad = (p.K + WK - 1) / WK * WK;
   p.M = (int)M; p.chunks = (int)((M + WM - 1) / WM);
   p.S = wgrad_splits(M, a.N, p.K);
@@ -263,6 +276,24 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __r
     const int ph = phase / s, pw = phase % s;
     const int kh = (ph + pad) % s + s * th, kw = (pw + pad) % s + s * tw;
     wp[i] = w[(((size_t)co * Ci + ci) * KH + kh) * KW + kw];
+  }
+}
+
+// inverse of pack_convT_weight for gradients: dw[ci][co][kh][kw] = dwp[phase][co][th][tw][ci], kh = (ph ? 2 : 1) + th*(ph ? -2 : 2)
+__global__ void unpack_convT_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Ci, int Co) {
+  const size_t total = (size_t)16 * Co * Ci;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Ci);
+    size_t r = i / Ci;
+    const int tw = (int)(r & 1);
+    const int th = (int)((r >> 1) & 1);
+    r >>= 2;
+    const int co = (int)(r % Co);
+    const int phase = (int)(r / Co);
+    const int ph = phase >> 1, pw = phase & 1;
+    const int kh = (ph ? 2 : 1) + th * (ph ? -2 : 2);
+    const int kw = (pw ? 2 : 1) + tw * (pw ? -2 : 2);
+    dw[(((size_t)ci * Co + co) * 4 + kh) * 4 + kw] = dwp[i];
   }
 }
 
@@ -324,6 +355,14 @@ int m2h_pack_dgrad_weight(const float* w, float* wp, int Co, int Ci, int KH, int
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), w, wp, Co, Ci, KH, KW, stride, pad);
   return launch_status("pack_dgrad_weight");
+}
+
+int m2h_unpack_convT_wgrad(const float* dwp, float* dw, int Ci, int Co, m2h_stream stream) {
+  M2H_REQUIRE(dwp && dw && Ci > 0 && Co > 0, "unpack_convT_wgrad: bad arguments");
+  size_t g = ((size_t)16 * Co * Ci + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(unpack_convT_wgrad_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), dwp, dw, Ci, Co);
+  return launch_status("unpack_convT_wgrad");
 }
 
 int m2h_act_bwd(const float* dy, const float* y, float slope, float* out, size_t n, m2h_stream stream) {

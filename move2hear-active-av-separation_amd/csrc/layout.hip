@@ -41,6 +41,38 @@ __global__ __launch_bounds__(256) void sep_slice_input_kernel(const float* __res
   }
 }
 
+// Training-time variant: same slice, but each pixel row has ldo >= 16*C+1 channels: channel 16*C holds the (target_class+1)
+// plane (separator_cnn.py:93-99 materialised so that its weight gradient falls out of the ordinary wgrad), the rest 0.
+__global__ __launch_bounds__(256) void sep_slice_input_plane_kernel(const float* __restrict__ mix, const float* __restrict__ cls_val,
+                                                                    float* __restrict__ out, int B, int F, int T, int C, int ldo) {
+  const int Hs = F >> 4;
+  const int CG = ldo >> 2;
+  const int nc = 16 * C;
+  const size_t total = (size_t)B * Hs * T * CG;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % CG);
+    size_t r = i / CG;
+    const int t = (int)(r % T);
+    r /= T;
+    const int h = (int)(r % Hs);
+    const int b = (int)(r / Hs);
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = cg * 4 + j;
+      float x = 0.f;
+      if (n < nc) {
+        const int c = n >> 4, s = n & 15;
+        x = mix[(((size_t)b * F + (size_t)s * Hs + h) * T + t) * C + c];
+      } else if (n == nc) {
+        x = cls_val[b];
+      }
+      v[j] = x;
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+  }
+}
+
 // [Co][Ci][KH][KW] -> [Co][KH][KW][cout]; channels >= cu are zero
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int KH, int KW, int cu, int cout) {
   const size_t total = (size_t)Co * KH * KW * cout;
@@ -119,6 +151,14 @@ int m2h_sep_slice_input(const float* mix, const float* masks, float* out, int B,
   const size_t total = (size_t)B * (F / 16) * T * (16 * C / 4);
   hipLaunchKernelGGL(sep_slice_input_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, as_stream(stream), mix, masks, out, B, F, T, C);
   return launch_status("sep_slice_input");
+}
+
+int m2h_sep_slice_input_plane(const float* mix, const float* cls_val, float* out, int B, int F, int T, int C, int ldo, m2h_stream stream) {
+  M2H_REQUIRE(mix && cls_val && out && B > 0 && F > 0 && T > 0 && C > 0 && F % 16 == 0, "sep_slice_input_plane: bad arguments");
+  M2H_REQUIRE(ldo >= 16 * C + 1 && ldo % 4 == 0, "sep_slice_input_plane: ldo must be a multiple of 4 and > 16*C");
+  const size_t total = (size_t)B * (F / 16) * T * (ldo / 4);
+  hipLaunchKernelGGL(sep_slice_input_plane_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, as_stream(stream), mix, cls_val, out, B, F, T, C, ldo);
+  return launch_status("sep_slice_input_plane");
 }
 
 int m2h_pack_conv_weight_ex(const float* w, float* wp, int Co, int Ci, int KH, int KW, int ci_used, int ci_out, m2h_stream stream) {

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ 
 
 // bin loss for logging (ppo.py:219-221; passive_trainer.py:270-272): mean | (exp(mix)-1)*mask - gt_bin_comps[..., 2c] | over [.., c<2]
 __global__ __launch_bounds__(256) void bin_l1_kernel(const float* __restrict__ mix, const float* __restrict__ masks, const float* __restrict__ gt,
-                                                     int Cg, float* __restrict__ part, float* __restrict__ grad_masks, size_t npix) {
+                                                     int Cg, int cstep, float* __restrict__ part, float* __restrict__ grad_masks, size_t npix) {
   __shared__ float sh[4];
   float s = 0.f;
   const float inv = 1.f / (float)(2 * npix);
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void bin_l1_kernel(const float* __restrict__ m
     const size_t pix = i >> 1;
     const int c = (int)(i & 1);
     const float e = expf(mix[i]) - 1.f;
-    const float d = e * masks[i] - gt[pix * Cg + 2 * c];
+    const float d = e * masks[i] - gt[pix * Cg + cstep * c];
     s += fabsf(d);
     if (grad_masks != nullptr) grad_masks[i] = (d > 0.f ? inv : (d < 0.f ? -inv : 0.f)) * e;
   }
@@ -671,11 +671,11 @@ int m2h_l1_loss(const float* pred, const float* gt, int gt_stride, int gt_off, f
   return launch_status("l1_loss");
 }
 
-int m2h_bin_l1_loss(const float* mix, const float* masks, const float* gt_bin_comps, int Cg, float* loss, float* grad_masks, float* scratch,
-                    size_t npix, m2h_stream stream) {
-  M2H_REQUIRE(mix && masks && gt_bin_comps && loss && scratch && npix > 0 && Cg >= 3, "bin_l1_loss: bad arguments");
+int m2h_bin_l1_loss(const float* mix, const float* masks, const float* gt_bin_comps, int Cg, int cstep, float* loss, float* grad_masks,
+                    float* scratch, size_t npix, m2h_stream stream) {
+  M2H_REQUIRE(mix && masks && gt_bin_comps && loss && scratch && npix > 0 && cstep >= 1 && Cg >= cstep + 1, "bin_l1_loss: bad arguments");
   const unsigned g = grid_for(2 * npix, M2H_PARTS);
-  hipLaunchKernelGGL(bin_l1_kernel, dim3(g), dim3(256), 0, as_stream(stream), mix, masks, gt_bin_comps, Cg, scratch, grad_masks, npix);
+  hipLaunchKernelGGL(bin_l1_kernel, dim3(g), dim3(256), 0, as_stream(stream), mix, masks, gt_bin_comps, Cg, cstep, scratch, grad_masks, npix);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch, (int)g, 1.f / (float)(2 * npix), loss);
   return launch_status("bin_l1_loss");
 }

@@ -15,7 +15,7 @@ _REPO_ROOT = os.path.dirname(_PKG_ROOT)
 CSRC = os.path.join(_PKG_ROOT, "csrc")
 INCLUDE = os.path.join(_REPO_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libm2h.so")
-SOURCES = ["conv_igemm.hip", "conv_bwd.hip", "layout.hip", "rl_ops.hip", "api.hip"]
+SOURCES = ["conv_igemm.hip", "conv_bwd.hip", "bn.hip", "layout.hip", "rl_ops.hip", "api.hip"]
 
 _lock = threading.Lock()
 _lib = None
@@ -105,7 +105,7 @@ SIGNATURES = {
     "m2h_gru_bwd_combine": [_P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_policy_heads_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "m2h_l1_loss": [_P, _P, _I, _I, _P, _P, _P, _Z, _P],
-    "m2h_bin_l1_loss": [_P, _P, _P, _I, _P, _P, _P, _Z, _P],
+    "m2h_bin_l1_loss": [_P, _P, _P, _I, _I, _P, _P, _P, _Z, _P],
     "m2h_grad_clip_coef": [_P, _Z, _F, _P, _P, _P],
     "m2h_adam_step": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _P, _F, _P],
     "m2h_sq_stats": [_P, _P, _I, _I, _P, _I, _I, _P],
@@ -116,6 +116,11 @@ SIGNATURES = {
     "m2h_act_bwd": [_P, _P, _F, _P, _Z, _P],
     "m2h_bias_grad_workspace_bytes": [_I, _I],
     "m2h_bias_grad": [_P, _P, _I, _I, _P, _P],
+    "m2h_sep_slice_input_plane": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "m2h_bn_workspace_bytes": [_I, _I],
+    "m2h_bn_train_fwd": [_P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _I, _I, _P, _P],
+    "m2h_bn_train_bwd": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P],
+    "m2h_unpack_convT_wgrad": [_P, _P, _I, _I, _P],
     "m2h_gather_envs": [_P, _P, _P, _I, _I, _I, _Z, _P],
     "m2h_stft_l2": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
 }

@@ -346,3 +346,147 @@ def l1_loss(pred, gt_comps, off=0):
     if pred.numel() != gt_comps.numel() // gt_comps.shape[-1]:
         raise RuntimeError("m2h.l1_loss: pred %s vs gt_comps %s" % (tuple(pred.shape), tuple(gt_comps.shape)))
     return L1Loss.apply(pred, gt_comps.contiguous(), off)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# passive pre-training pieces: train-mode BN + activation, transposed conv with gradients, binaural L1
+# ----------------------------------------------------------------------------------------------------------------
+class BNAct(torch.autograd.Function):
+    """y = act(BatchNorm2d_train(z)) on NHWC z; running statistics updated in place (momentum 0.1, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, eps, momentum, slope):
+        z = z.contiguous()
+        C = z.shape[-1]
+        M = z.numel() // C
+        dev = z.device
+        y = torch.empty_like(z)
+        mean = torch.empty(C, device=dev)
+        invstd = torch.empty(C, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            ws = torch.empty((lib.m2h_bn_workspace_bytes(M, C) + 3) // 4, device=dev)
+            _lib.check(lib.m2h_bn_train_fwd(ops._ptr(z), ops._ptr(gamma.detach()), ops._ptr(beta.detach()), float(eps), float(momentum), float(slope),
+                                            ops._ptr(running_mean), ops._ptr(running_var), ops._ptr(mean), ops._ptr(invstd), ops._ptr(y), M, C,
+                                            ops._ptr(ws), ops._stream(z)), "m2h_bn_train_fwd")
+        ctx.slope = slope
+        ctx.save_for_backward(z, y, mean, invstd, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, y, mean, invstd, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = z.shape[-1]
+        M = z.numel() // C
+        dev = z.device
+        dz = torch.empty_like(z)
+        dgamma = torch.empty(C, device=dev)
+        dbeta = torch.empty(C, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            ws = torch.empty((lib.m2h_bn_workspace_bytes(M, C) + 3) // 4, device=dev)
+            _lib.check(lib.m2h_bn_train_bwd(ops._ptr(dy), ops._ptr(y), ops._ptr(z), ops._ptr(mean), ops._ptr(invstd), ops._ptr(gamma.detach()),
+                                            float(ctx.slope), ops._ptr(dgamma), ops._ptr(dbeta), ops._ptr(dz), M, C, ops._ptr(ws),
+                                            ops._stream(z)), "m2h_bn_train_bwd")
+        return dz, dgamma, dbeta, None, None, None, None, None
+
+
+def bn_act_train(z, bn, slope):
+    """Train-mode nn.BatchNorm2d `bn` (parameter container) + activation on NHWC z."""
+    y = BNAct.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum if bn.momentum is not None else 0.1, slope)
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+    return y
+
+
+def _convT_phase_args(x, x2, Co, ph, pw):
+    B, H, W, C0 = x.shape
+    a = _lib.ConvArgs()
+    a.src0, a.src1, a.C0, a.C1 = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), C0, (x2.shape[3] if x2 is not None else 0)
+    a.B, a.Hi, a.Wi, a.Hq, a.Wq = B, H, W, H, W
+    a.stride, a.nth, a.ntw = 1, 2, 2
+    a.mulh, a.offh, a.mulw, a.offw = 2 * ph - 1, 0, 2 * pw - 1, 0
+    a.conv_transpose, a.N = 0, Co
+    a.Ho, a.Wo, a.os, a.ph, a.pw, a.ldc, a.out_mode = 2 * H, 2 * W, 2, ph, pw, Co, 0
+    return a
+
+
+class ConvTranspose2dNHWC(torch.autograd.Function):
+    """z = conv_transpose2d(cat(x, x2), w, stride 2, pad 1, 4x4) on NHWC (no bias / activation): forward = 4 sub-pixel phase
+    GEMMs in one launch; backward: dgrad = an ordinary 4x4/s2/p1 conv of dz with w read as a conv weight (one launch per
+    source), wgrad = the wgrad kernel per phase + scatter to torch layout."""
+
+    @staticmethod
+    def forward(ctx, x, x2, w, memo):
+        Cin, Co = w.shape[0], w.shape[1]
+        key_ok = memo is not None
+        if key_ok:
+            k = (w.data_ptr(), w._version, _param_epoch)
+            if memo.key != k:
+                memo.val = ops.pack_convT_weight(w.detach().contiguous())
+                memo.key = k
+            wp = memo.val
+        else:
+            wp = ops.pack_convT_weight(w.detach().contiguous())
+        z = ops.unet_up_fwd_raw(x, x2, wp, Co)
+        ctx.has_x2 = x2 is not None
+        ctx.save_for_backward(x, x2 if x2 is not None else x.new_empty(0), w)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, x2, w = ctx.saved_tensors
+        x2 = x2 if ctx.has_x2 else None
+        dz = dz.contiguous()
+        Cin, Co = w.shape[0], w.shape[1]
+        C0 = x.shape[3]
+        B, H, W, _ = x.shape
+        gx = gx2 = gw = None
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
+            wconv = ops.pack_conv_weight(w.detach().contiguous())  # [Cin][4][4][Co]: w read as a Conv2d weight [out=Cin][in=Co]
+            if ctx.needs_input_grad[0]:
+                gx = ops.conv2d_nhwc(dz, wconv[:C0].contiguous(), C0, 4, 4, stride=2, pad=1, slope=1.0, name="convT.dgrad")
+            if x2 is not None and ctx.needs_input_grad[1]:
+                gx2 = ops.conv2d_nhwc(dz, wconv[C0:].contiguous(), Cin - C0, 4, 4, stride=2, pad=1, slope=1.0, name="convT.dgrad")
+        if ctx.needs_input_grad[2]:
+            lib = _lib.load()
+            dwp = torch.empty((4, Co, 4 * Cin), device=x.device)
+            with torch.cuda.device(x.device):
+                for ph in range(2):
+                    for pw in range(2):
+                        a = _convT_phase_args(x, x2, Co, ph, pw)
+                        nbytes = lib.m2h_conv_wgrad_workspace_bytes(ctypes.byref(a))
+                        ws = torch.empty((nbytes + 3) // 4, device=x.device)
+                        a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+                        M = B * H * W
+                        meta = {"kernel": "wgrad_f32", "M": M, "N": Co, "K": 4 * Cin, "flops": 2.0 * M * Co * 4 * Cin}
+                        ops._timed("convT_wgrad", meta, x.device,
+                                   lambda: _lib.check(lib.m2h_conv_wgrad_f32(ctypes.byref(a), ops._ptr(dz), Co, ops._ptr(dwp[ph * 2 + pw]),
+                                                                             ops._stream(x)), "m2h_conv_wgrad_f32(convT)"))
+                gw = torch.empty_like(w)
+                _lib.check(lib.m2h_unpack_convT_wgrad(ops._ptr(dwp), ops._ptr(gw), Cin, Co, ops._stream(x)), "m2h_unpack_convT_wgrad")
+        return gx, gx2, gw, None
+
+
+def conv_transpose2d(x, w, x2=None, memo=None):
+    return ConvTranspose2dNHWC.apply(x, x2, w, memo)
+
+
+class BinL1Loss(torch.autograd.Function):
+    """F.l1_loss(masks * (exp(mix) - 1), gt_bin_mag) with gradient w.r.t. masks (passive_trainer.py:270-272)."""
+
+    @staticmethod
+    def forward(ctx, masks, mix, gt, cstep):
+        loss, grad = ops.bin_l1_loss(mix.contiguous(), masks.contiguous(), gt.contiguous(), cstep, want_grad=True)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
+def bin_l1_loss(masks, mix, gt, cstep=1):
+    return BinL1Loss.apply(masks, mix, gt, cstep)

@@ -482,15 +482,56 @@ def gather_envs(src, perm):
     return dst
 
 
-def bin_l1_loss(mix, masks, gt_bin_comps):
-    """mean |(exp(mix)-1)*masks - gt_bin_mag| (logging loss of update_sep, ppo.py:219-221) -> 0-dim device tensor."""
-    for t in (mix, masks, gt_bin_comps):
+def bin_l1_loss(mix, masks, gt, cstep=2, want_grad=False):
+    """mean |(exp(mix)-1)*masks - gt[..., cstep*c]| (ppo.py:219-221 with cstep 2 on gt_bin_comps; passive_trainer.py:270-272 with
+    cstep 1 on gt_bin_mag) -> 0-dim device tensor (and d loss / d masks when want_grad)."""
+    for t in (mix, masks, gt):
         _chk(t, "bin_l1_loss")
     npix = mix.numel() // 2
     loss = torch.empty(1, device=mix.device)
+    grad = torch.empty_like(masks) if want_grad else None
     scratch = torch.empty(1024, device=mix.device)
     lib = _lib.load()
     with torch.cuda.device(mix.device):
-        _lib.check(lib.m2h_bin_l1_loss(_ptr(mix), _ptr(masks), _ptr(gt_bin_comps), gt_bin_comps.shape[-1], _ptr(loss), None, _ptr(scratch), npix,
+        _lib.check(lib.m2h_bin_l1_loss(_ptr(mix), _ptr(masks), _ptr(gt), gt.shape[-1], cstep, _ptr(loss), _ptr(grad), _ptr(scratch), npix,
                                        _stream(mix)), "m2h_bin_l1_loss")
-    return loss[0]
+    return (loss[0], grad) if want_grad else loss[0]
+
+
+def sep_slice_input_plane(mix, cls_val, ldo=36):
+    """binSep stage-0 training input: slice + (target_class+1) plane as channel 32, zero padded to ldo channels."""
+    _chk(mix, "sep_slice_input_plane")
+    _chk(cls_val, "sep_slice_input_plane")
+    B, F, T, C = mix.shape
+    out = torch.empty((B, F // 16, T, ldo), device=mix.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(mix.device):
+        _lib.check(lib.m2h_sep_slice_input_plane(_ptr(mix), _ptr(cls_val), _ptr(out), B, F, T, C, ldo, _stream(mix)), "m2h_sep_slice_input_plane")
+    return out
+
+
+def unet_up_fwd_raw(x, skip, wp, Co):
+    """Transposed conv 4x4/s2/p1 of cat(x, skip) WITHOUT BatchNorm/activation (training path: batch statistics come next)."""
+    _chk(x, "unet_up_fwd_raw(x)")
+    _chk(skip, "unet_up_fwd_raw(skip)")
+    _chk(wp, "unet_up_fwd_raw(wp)")
+    B, H, W, C0 = x.shape
+    C1 = skip.shape[3] if skip is not None else 0
+    if wp.numel() != 16 * Co * (C0 + C1):
+        raise RuntimeError("m2h.unet_up_fwd_raw: packed weight size")
+    y = torch.empty((B, 2 * H, 2 * W, Co), device=x.device, dtype=torch.float32)
+    a = _lib.ConvArgs()
+    a.src0, a.src1, a.C0, a.C1 = x.data_ptr(), (skip.data_ptr() if skip is not None else None), C0, C1
+    a.B, a.Hi, a.Wi, a.Hq, a.Wq = B, H, W, H, W
+    a.stride, a.nth, a.ntw, a.mulh, a.offh, a.mulw, a.offw = 1, 2, 2, 0, 0, 0, 0
+    a.conv_transpose, a.wp, a.N = 1, wp.data_ptr(), Co
+    a.scale, a.shift, a.slope, a.cls_table, a.cls_val = None, None, 1.0, None, None
+    a.dst, a.Ho, a.Wo, a.os, a.ph, a.pw, a.ldc, a.out_mode = y.data_ptr(), 2 * H, 2 * W, 2, 0, 0, Co, OUT_NHWC
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        ws, wsb = _workspace(lib.m2h_conv_igemm_workspace_bytes(ctypes.byref(a)), x.device)
+        a.workspace, a.workspace_bytes = (ws.data_ptr() if ws is not None else None), wsb
+        M = B * H * W
+        meta = {"kernel": igemm_config(Co), "M": 4 * M, "N": Co, "K": 4 * (C0 + C1), "flops": 2.0 * 4 * M * Co * 4 * (C0 + C1)}
+        _timed("unet_up_fwd_raw", meta, x.device, lambda: _lib.check(lib.m2h_conv_igemm_f32(ctypes.byref(a), _stream(x)), "m2h_conv_igemm_f32"))
+    return y

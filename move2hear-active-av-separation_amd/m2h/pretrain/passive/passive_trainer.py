@@ -1,0 +1,126 @@
+"""Passive pre-training on MI355X: the training loop of audio_separation/pretrain/passive/passive_trainer.py
+(PassiveTrainer, :50-286) around the m2h modules and a synthetic on-device data feeder.
+
+Kept: model construction (:57-82), Adam(lr 5e-4, eps 1e-5) over the trainable parameters (:194-195), the per-batch flow
+get_binSepMasks -> convert_bin2mono(masks.detach()) -> optimize_supervised_loss (:218-249, 269-286) including the fact that
+``clip_grad_norm_`` runs BEFORE ``backward`` and therefore clips nothing, train-mode BatchNorm for the train
+split and eval mode for validation (:211-214), best-validation checkpointing in the reference format (:84-99, 259-266).
+Replaced: PassiveDataset/DataLoader (RIR convolution + librosa STFT on 60 CPU workers) by a seeded on-device batch feeder
+(the GPU STFT feeder is row N1 of SURVEY 8f); TensorBoard logging dropped.
+Losses stay on the device; one host read per epoch instead of two ``.item()`` per batch (:248-249).
+"""
+import os
+from types import SimpleNamespace
+
+import torch
+
+from ... import functional as MF
+from ...common.spaces import move2hear_observation_space
+from ...optim import FlatAdam
+from .passive import Passive
+from .policy import Move2HearPassiveWoMemoryPolicy
+
+
+def passive_config(**over):
+    """Pretrain.Passive.* of config/default.py:106-111 + config/pretrain_passive.yaml (BATCH_SIZE 64)."""
+    c = dict(SEED=0, lr=5.0e-4, eps=1.0e-5, max_grad_norm=0.8, NUM_EPOCHS=1000, BATCH_SIZE=64, BATCHES_PER_EPOCH=8, VAL_BATCHES=2,
+             CHECKPOINT_FOLDER=None, TM=32)
+    c.update(over)
+    return SimpleNamespace(**c)
+
+
+class SyntheticPassiveFeeder:
+    """Seeded batches with the tensors the reference DataLoader yields (:219-222): mixed_audio [B,512,Tm,2], gt_bin_mag
+    [B,512,Tm,2], gt_mono_mag [B,512,Tm,1], target_class [B,1]; log1p-magnitude statistics of dataset.py:190-228."""
+
+    def __init__(self, device, batch_size, tm, seed):
+        self.device, self.bs, self.tm = device, batch_size, tm
+        self.g = torch.Generator(device=device).manual_seed(int(seed))
+
+    def batch(self):
+        d, g, B, T = self.device, self.g, self.bs, self.tm
+        gain = torch.exp(torch.rand(B, 512, 1, 1, device=d, generator=g) * 3.0 - 2.0)
+        src = [torch.sqrt(torch.randn(B, 512, T, 2, device=d, generator=g) ** 2 + torch.randn(B, 512, T, 2, device=d, generator=g) ** 2) * gain
+               for _ in range(2)]
+        mixed = torch.log1p(0.5 * (src[0] + src[1])).contiguous()
+        gt_bin = (0.5 * src[0]).contiguous()                       # magnitude of the target source, binaural
+        gt_mono = (0.5 * src[0].mean(dim=3, keepdim=True)).contiguous()
+        tc = torch.randint(0, 11, (B, 1), device=d, generator=g)
+        return mixed, gt_bin, gt_mono, tc
+
+
+class PassiveTrainer:
+    def __init__(self, config=None, device=None):
+        self.config = config if config is not None else passive_config()
+        self.device = device if device is not None else torch.device("cuda", 0)
+        self.actor_critic = None
+        self.agent = None
+        self.optimizer = None
+
+    def _setup_passive_agent(self):
+        self.actor_critic = Move2HearPassiveWoMemoryPolicy(observation_space=move2hear_observation_space(self.config.TM))
+        self.agent = Passive(actor_critic=self.actor_critic)
+        self.actor_critic.to(self.device)
+        self.actor_critic.train()
+
+    def optimize_supervised_loss(self, mixed_audio, pred_binSepMasks, gt_bin_mag, pred_mono, gt_mono_mag, split="train"):
+        """:269-286.  bin_loss = L1(mask*(exp(mix)-1), gt_bin); mono_loss = L1(mono, gt_mono); train: zero_grad, (no-op clip),
+        backward, Adam step.  Returns device scalars."""
+        if split == "train":
+            bin_loss = MF.bin_l1_loss(pred_binSepMasks, mixed_audio, gt_bin_mag, cstep=1)
+            mono_loss = MF.l1_loss(pred_mono, gt_mono_mag, 0)
+            self.optimizer.zero_grad()
+            loss = bin_loss + mono_loss
+            # nn.utils.clip_grad_norm_ is called here in the reference, on freshly zeroed gradients: no effect (D11)
+            loss.backward()
+            self.optimizer.step(max_grad_norm=None)
+        else:
+            from ... import ops
+            bin_loss = ops.bin_l1_loss(mixed_audio, pred_binSepMasks, gt_bin_mag, cstep=1)
+            mono_loss = MF.l1_loss(pred_mono, gt_mono_mag, 0)
+        return bin_loss.detach(), mono_loss.detach()
+
+    def train_batch(self, mixed_audio, gt_bin_mag, gt_mono_mag, target_class, split="train"):
+        obs_batch = {"mixed_bin_audio_mag": mixed_audio, "target_class": target_class}
+        if split == "train":
+            pred_binSepMasks = self.actor_critic.get_binSepMasks(obs_batch)
+            pred_mono = self.actor_critic.convert_bin2mono(pred_binSepMasks.detach(), mixed_audio=mixed_audio)
+        else:
+            with torch.no_grad():
+                pred_binSepMasks = self.actor_critic.get_binSepMasks(obs_batch)
+                pred_mono = self.actor_critic.convert_bin2mono(pred_binSepMasks.detach(), mixed_audio=mixed_audio)
+        return self.optimize_supervised_loss(mixed_audio, pred_binSepMasks, gt_bin_mag, pred_mono, gt_mono_mag, split)
+
+    def setup(self):
+        cfg = self.config
+        torch.manual_seed(cfg.SEED)
+        self._setup_passive_agent()
+        self.optimizer = FlatAdam([p for p in self.actor_critic.parameters() if p.requires_grad], lr=cfg.lr, eps=cfg.eps)
+        self.feeders = {"train": SyntheticPassiveFeeder(self.device, cfg.BATCH_SIZE, cfg.TM, cfg.SEED + 1),
+                        "val": SyntheticPassiveFeeder(self.device, cfg.BATCH_SIZE, cfg.TM, cfg.SEED + 2)}
+
+    def save_checkpoint(self, file_name):
+        ckpt = {"state_dict": self.agent.state_dict(), "config": vars(self.config)}
+        os.makedirs(self.config.CHECKPOINT_FOLDER, exist_ok=True)
+        torch.save(ckpt, os.path.join(self.config.CHECKPOINT_FOLDER, file_name))
+
+    def train(self, num_epochs=None):
+        cfg = self.config
+        if self.actor_critic is None:
+            self.setup()
+        best = float("inf")
+        log = []
+        for epoch in range(num_epochs if num_epochs is not None else cfg.NUM_EPOCHS):
+            rec = {}
+            for split, nb in (("train", cfg.BATCHES_PER_EPOCH), ("val", cfg.VAL_BATCHES)):
+                self.actor_critic.train() if split == "train" else self.actor_critic.eval()
+                acc = torch.zeros(2, device=self.device)
+                for _ in range(nb):
+                    b, m = self.train_batch(*self.feeders[split].batch(), split=split)
+                    acc += torch.stack((b, m))
+                rec[split] = (acc / nb).tolist()
+            if rec["val"][1] < best and cfg.CHECKPOINT_FOLDER:
+                best = rec["val"][1]
+                self.save_checkpoint("best_ckpt_val.pth")
+            log.append(rec)
+        return log

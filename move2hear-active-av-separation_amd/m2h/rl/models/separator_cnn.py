@@ -18,13 +18,18 @@ works (the reference's ``view(B,-1,1,1)`` at :154 pins Tm = 32).
 Feature maps cross the module boundary as NCHW-shaped tensors in channels-last memory (zero-copy views of
 the NHWC buffers the kernels use).
 
-Only inference is built so far (eval-mode BatchNorm, no autograd): this is the mode every RL call site
-uses (ppo_trainer.py:557-577, ppo.py:184-195).  Calling forward in training mode, or with gradients
-required, raises NotImplementedError rather than silently computing something else.
+Two execution modes, chosen like torch does by ``module.training``:
+  eval   (every RL call site: ppo_trainer.py:557-577, ppo.py:184-195)  the fused inference kernels above, BN folded;
+         no autograd (raises NotImplementedError if gradients are required rather than silently dropping the graph).
+  train  (passive pre-training, passive_trainer.py:211-249)  per stage: raw conv / transposed conv (same MFMA engine) ->
+         train-mode BatchNorm + activation kernel (batch statistics, running stats updated) with full autograd through
+         m2h.functional (wgrad/dgrad/BN-backward kernels).  The (target_class+1) plane is a real channel in this mode so
+         that its weight gradient falls out of the ordinary wgrad.
 """
 import torch
 import torch.nn as nn
 
+from ... import functional as MF
 from ... import ops
 
 
@@ -70,15 +75,11 @@ class _PackedCache:
 
 
 def _check_inference(module, *tensors):
-    if module.training:
-        raise NotImplementedError(
-            "m2h %s: train-mode BatchNorm / backward is not built yet (inference only); call .eval()"
-            % type(module).__name__)
     if torch.is_grad_enabled() and (any(p.requires_grad for p in module.parameters())
                                     or any(t is not None and t.requires_grad for t in tensors)):
         raise NotImplementedError(
-            "m2h %s: no autograd through the HIP path yet; wrap the call in torch.no_grad() or freeze the "
-            "separator (requires_grad_(False)) as ppo_trainer.py:557-577 does" % type(module).__name__)
+            "m2h %s: eval-mode (folded BatchNorm) forward has no autograd; call .train() for the differentiable path, or wrap "
+            "the call in torch.no_grad() / freeze the separator as ppo_trainer.py:557-577 does" % type(module).__name__)
 
 
 def _as_nhwc(t):
@@ -126,7 +127,30 @@ class PassiveSepEncCNN(nn.Module):
 
         return self._cache.get(srcs, build)
 
+    def _forward_train(self, observations, mixed_audio):
+        if self._convert_bin2mono:
+            if observations.requires_grad:
+                raise NotImplementedError("m2h PassiveSepEncCNN(train): gradients into pred_binSepMasks are not built (the passive "
+                                          "trainer detaches them, passive_trainer.py:229-230)")
+            out = ops.sep_slice_input(mixed_audio.contiguous(), observations.detach().contiguous())
+        else:
+            cls_val = (observations["target_class"].reshape(-1).to(torch.float32) + 1.0).contiguous()
+            out = ops.sep_slice_input_plane(observations["mixed_bin_audio_mag"].contiguous(), cls_val, 36)
+        if not hasattr(self, "_memo_t"):
+            self._memo_t = [MF._PackMemo() for _ in range(5)]
+        feats = []
+        for i, m in enumerate(self.cnn):
+            z = MF.conv2d(out, m[0].weight, None, 2, 1, slope=1.0, memo=self._memo_t[i], name="unet_down.train")
+            out = MF.bn_act_train(z, m[1], 0.2)
+            feats.append(out.permute(0, 3, 1, 2))
+        bottleneck = feats[-1]
+        return bottleneck.reshape(bottleneck.size(0), -1), feats[:-1][::-1]
+
     def forward(self, observations, mixed_audio=None):
+        if self.training:
+            if self._convert_bin2mono:
+                assert mixed_audio is not None
+            return self._forward_train(observations, mixed_audio)
         if self._convert_bin2mono:
             assert mixed_audio is not None
             _check_inference(self, observations, mixed_audio)
@@ -186,7 +210,23 @@ class PassiveSepDecCNN(nn.Module):
 
         return self._cache.get(srcs, build)
 
+    def _forward_train(self, bottleneck_feats, lst_skip_feats):
+        B = bottleneck_feats.size(0)
+        wb = lst_skip_feats[0].size(3) // 2
+        out = _as_nhwc(bottleneck_feats.reshape(B, -1, 1, wb))
+        if not hasattr(self, "_memo_t"):
+            self._memo_t = [MF._PackMemo() for _ in range(6)]
+        for idx in range(5):
+            m = self.cnn[idx]
+            skip = None if idx == 0 else _as_nhwc(lst_skip_feats[idx - 1])
+            z = MF.conv_transpose2d(out, m[0].weight, skip, memo=self._memo_t[idx])
+            out = MF.bn_act_train(z, m[1], 0.0)
+        head = self.cnn[5][0]
+        return MF.conv2d(out, head.weight, head.bias, 1, 0, slope=1.0, deslice=True, memo=self._memo_t[5], name="unet_head.train")
+
     def forward(self, bottleneck_feats, lst_skip_feats):
+        if self.training:
+            return self._forward_train(bottleneck_feats, lst_skip_feats)
         _check_inference(self, bottleneck_feats, *lst_skip_feats)
         B = bottleneck_feats.size(0)
         # reference :154 is view(B,-1,1,1) (Tm = 32); in general the bottleneck is [B,512,1,Tm/32]

@@ -349,8 +349,51 @@ def gen_rl_updates(ref):
     print("rl_updates: pol losses", v, a, h, "sep losses", b, m, mm)
 
 
+def gen_passive_train(ref):
+    """G12: one passive training step of the reference (train-mode BN, losses, Adam, D11 no-op clipping), B=4, 512x32."""
+    seed_w, seed_x, B = 6, 61, 4
+    pol = ref["passive_policy"].Move2HearPassiveWoMemoryPolicy(FakeObsSpace(32))
+    sd = synthetic.make_state_dict(synthetic.passive_shapes(), seed_w)
+    pol.load_state_dict(_t(sd), strict=True)
+    pol.train()
+    mixed, tc = synthetic.make_passive_inputs(B, 32, seed_x)
+    g = torch.Generator().manual_seed(62)
+    gt_bin = torch.rand(B, 512, 32, 2, generator=g) * 2
+    gt_mono = torch.rand(B, 512, 32, 1, generator=g) * 2
+    mix = torch.from_numpy(mixed)
+    obs = {"mixed_bin_audio_mag": mix, "target_class": torch.from_numpy(tc)}
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, pol.parameters()), lr=5.0e-4, eps=1.0e-5)
+    out = {"seed_w": seed_w, "seed_x": seed_x, "B": B, "gt_seed": 62}
+    losses = []
+    for step in range(2):
+        masks = pol.get_binSepMasks(obs)
+        mono = pol.convert_bin2mono(masks.detach(), mixed_audio=mix)
+        # passive_trainer.py:269-286 (optimize_supervised_loss), restated with the reference modules
+        pred_bin = masks * (torch.exp(mix) - 1)
+        bin_loss = torch.nn.functional.l1_loss(pred_bin, gt_bin)
+        mono_loss = torch.nn.functional.l1_loss(mono, gt_mono)
+        opt.zero_grad()
+        loss = bin_loss + mono_loss
+        torch.nn.utils.clip_grad_norm_(pol.parameters(), 0.8)  # before backward: clips nothing (SURVEY D11)
+        loss.backward()
+        opt.step()
+        losses.append([bin_loss.item(), mono_loss.item()])
+        if step == 0:
+            out["masks_step0"] = masks.detach().contiguous().numpy()
+            out["mono_step0"] = mono.detach().contiguous().numpy()
+    out["losses"] = np.array(losses)
+    post = pol.state_dict()
+    for k, t in post.items():
+        if t.numel() <= 70000 and t.dtype.is_floating_point:
+            out["post." + k] = t.numpy().copy()
+        elif t.dtype.is_floating_point:
+            out["postsum." + k] = np.array([t.double().sum().item(), t.double().abs().sum().item()])
+    np.savez_compressed(os.path.join(GOLD, "passive_train.npz"), meta=json.dumps(META), **out)
+    print("passive_train: losses", losses)
+
+
 GENS = {"unet_tm32": gen_unet_tm32, "unet_tm256": gen_unet_tm256, "init": gen_init,
-        "rl_forward": gen_rl_forward, "rl_scalars": gen_rl_scalars, "rl_updates": gen_rl_updates}
+        "rl_forward": gen_rl_forward, "rl_scalars": gen_rl_scalars, "rl_updates": gen_rl_updates, "passive_train": gen_passive_train}
 
 
 def main():

@@ -380,3 +380,35 @@ def gt_mags(obs):
     gt_mono_mag = obs["gt_mono_comps"][..., 0::2][..., :1]
     gt_bin_mag = obs["gt_bin_comps"][..., 0::2][..., :2]
     return gt_bin_mag, gt_mono_mag
+
+
+# ==============================================================================================
+# A4: passive pre-training step (pretrain/passive/passive_trainer.py:218-249, 269-286)
+# ==============================================================================================
+def passive_losses(sd, mixed_bin_audio_mag, target_class, gt_bin_mag, gt_mono_mag, train_bn=True, stats_out=None):
+    """Forward of one passive batch: masks from binSep, mono from bin2mono on the DETACHED masks (:228-230), the two L1 losses
+    (:270-275).  With train_bn the BatchNorms use batch statistics (the trainer calls actor_critic.train(), :211-212)."""
+    masks = get_binSepMasks(sd, mixed_bin_audio_mag, target_class, train_bn, stats_out)
+    mono = convert_bin2mono(sd, masks.detach(), mixed_bin_audio_mag, train_bn, stats_out)
+    bin_loss = F.l1_loss(masks * (torch.exp(mixed_bin_audio_mag) - 1), gt_bin_mag)
+    mono_loss = F.l1_loss(mono, gt_mono_mag)
+    return bin_loss, mono_loss, masks, mono
+
+
+def passive_train_step(params, buffers, batch, lr=5e-4, eps=1e-5, opt_state=None):
+    """optimize_supervised_loss (:269-286): loss = bin + mono, zero_grad, clip_grad_norm_ BEFORE backward (clips nothing, SURVEY
+    D11), backward, Adam(lr, eps).  params: dict name -> leaf tensor requiring grad; buffers: BN running stats (updated in
+    place with momentum 0.1).  Returns (bin_loss, mono_loss, optimizer)."""
+    sd = dict(params)
+    sd.update(buffers)
+    stats = {}
+    bin_loss, mono_loss, _, _ = passive_losses(sd, batch["mixed_bin_audio_mag"], batch["target_class"], batch["gt_bin_mag"],
+                                               batch["gt_mono_mag"], True, stats)
+    opt = opt_state if opt_state is not None else torch.optim.Adam(list(params.values()), lr=lr, eps=eps)
+    opt.zero_grad()
+    (bin_loss + mono_loss).backward()
+    opt.step()
+    with torch.no_grad():
+        for k, v in stats.items():
+            buffers[k].copy_(v)
+    return bin_loss.detach(), mono_loss.detach(), opt

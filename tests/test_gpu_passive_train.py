@@ -1,0 +1,129 @@
+"""GPU: passive pre-training path (train-mode BN, transposed-conv / conv / BN backward, Adam) against two training steps
+of the reference (tests/golden/passive_train.npz) and against torch autograd for the new kernels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import m2h_oracle as O
+from m2h import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _rel(a, b):
+    return O.rel_l1(torch.as_tensor(a).detach().cpu(), torch.as_tensor(b).detach())
+
+
+@pytest.mark.parametrize("slope", [0.2, 0.0])
+def test_bn_act_train_forward_backward_match_torch(slope):
+    from m2h import functional as MF
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(6, 64, 8, 16, generator=g) * 1.7 + 0.4).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(64)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(64, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(64, generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(64, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(64, generator=g) + 0.5)
+    bn2 = torch.nn.BatchNorm2d(64)
+    bn2.load_state_dict(bn.state_dict())
+    bn2 = bn2.to(dev)
+    bn.train()
+    y = F.leaky_relu(bn(x), slope) if slope else F.relu(bn(x))
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    yd = MF.bn_act_train(xd, bn2, slope)
+    assert _rel(yd.permute(0, 3, 1, 2), y) < 2e-5
+    yd.backward(gy.permute(0, 2, 3, 1).contiguous().to(dev))
+    assert _rel(xd.grad.permute(0, 3, 1, 2), x.grad) < 1e-4
+    assert _rel(bn2.weight.grad, bn.weight.grad) < 1e-4 and _rel(bn2.bias.grad, bn.bias.grad) < 1e-4
+    assert torch.allclose(bn2.running_mean.cpu(), bn.running_mean, atol=1e-6) and torch.allclose(bn2.running_var.cpu(), bn.running_var, rtol=1e-5)
+    assert int(bn2.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("B,H,W,C0,C1,Co", [(3, 1, 1, 512, 0, 512), (2, 2, 2, 512, 512, 256), (2, 8, 8, 128, 128, 64), (2, 16, 16, 64, 64, 16)])
+def test_conv_transpose_backward_matches_torch(B, H, W, C0, C1, Co):
+    from m2h import functional as MF
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + H + Co)
+    x = torch.randn(B, C0, H, W, generator=g, requires_grad=True)
+    s = torch.randn(B, C1, H, W, generator=g, requires_grad=True) if C1 else None
+    w = (torch.randn(C0 + C1, Co, 4, 4, generator=g) * (0.5 / (C0 + C1)) ** 0.5).requires_grad_(True)
+    xin = x if s is None else torch.cat((x, s), 1)
+    z = F.conv_transpose2d(xin, w, None, 2, 1)
+    gz = torch.randn(z.shape, generator=g)
+    z.backward(gz)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    sd_ = s.detach().permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True) if s is not None else None
+    wd = w.detach().to(dev).requires_grad_(True)
+    zd = MF.conv_transpose2d(xd, wd, sd_)
+    assert _rel(zd.permute(0, 3, 1, 2), z) < 2e-5
+    zd.backward(gz.permute(0, 2, 3, 1).contiguous().to(dev))
+    assert _rel(wd.grad, w.grad) < 1e-4
+    assert _rel(xd.grad.permute(0, 3, 1, 2), x.grad) < 1e-4
+    if s is not None:
+        assert _rel(sd_.grad.permute(0, 3, 1, 2), s.grad) < 1e-4
+
+
+def test_passive_training_steps_match_reference_fixture(golden_dir):
+    from m2h.pretrain.passive.passive_trainer import PassiveTrainer, passive_config
+    dev = _dev()
+    g = np.load(os.path.join(golden_dir, "passive_train.npz"))
+    tr = PassiveTrainer(passive_config(), dev)
+    tr.setup()
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.passive_shapes(), int(g["seed_w"])).items()}
+    tr.actor_critic.load_state_dict(sd)
+    tr.actor_critic.train()
+    B = int(g["B"])
+    mixed, tc = synthetic.make_passive_inputs(B, 32, int(g["seed_x"]))
+    gen = torch.Generator().manual_seed(int(g["gt_seed"]))
+    gt_bin = (torch.rand(B, 512, 32, 2, generator=gen) * 2).to(dev)
+    gt_mono = (torch.rand(B, 512, 32, 1, generator=gen) * 2).to(dev)
+    mix, tct = torch.from_numpy(mixed).to(dev), torch.from_numpy(tc).to(dev)
+    # step 0 forward (train-mode BN) matches the reference's outputs
+    obs = {"mixed_bin_audio_mag": mix, "target_class": tct}
+    for step in range(2):
+        if step == 0:
+            masks = tr.actor_critic.get_binSepMasks(obs)
+            mono = tr.actor_critic.convert_bin2mono(masks.detach(), mixed_audio=mix)
+            assert _rel(masks, g["masks_step0"]) < 5e-5 and _rel(mono, g["mono_step0"]) < 5e-5
+            b, m = tr.optimize_supervised_loss(mix, masks, gt_bin, mono, gt_mono, "train")
+        else:
+            b, m = tr.train_batch(mix, gt_bin, gt_mono, tct, "train")
+        assert abs(b.item() - g["losses"][step][0]) < 1e-4 and abs(m.item() - g["losses"][step][1]) < 1e-4, (step, b.item(), m.item())
+    post = tr.actor_critic.state_dict()
+    n = 0
+    for key in g.files:
+        if not key.startswith("post."):
+            continue
+        k = key[5:]
+        ref = torch.from_numpy(g[key])
+        mine = post[k].cpu()
+        if "running_" in k:
+            assert torch.allclose(mine, ref, rtol=2e-4, atol=2e-6), k
+        else:
+            bad = ((mine - sd[k]) - (ref - sd[k])).abs().gt(2e-4).float().mean().item()  # two Adam steps of lr 5e-4
+            assert bad < 0.02, (k, bad)
+        n += 1
+    assert n > 40
+    # eval after training still runs the fused inference path
+    tr.actor_critic.eval()
+    with torch.no_grad():
+        assert tr.actor_critic.get_binSepMasks(obs).shape == (B, 512, 32, 2)
+
+
+def test_passive_trainer_epoch_runs():
+    from m2h.pretrain.passive.passive_trainer import PassiveTrainer, passive_config
+    tr = PassiveTrainer(passive_config(BATCH_SIZE=8, BATCHES_PER_EPOCH=3, VAL_BATCHES=1), _dev())
+    log = tr.train(num_epochs=2)
+    assert len(log) == 2 and all(np.isfinite(v) for r in log for v in r["train"] + r["val"])
+    assert log[1]["train"][0] < log[0]["train"][0] * 1.5  # sanity: not diverging
