@@ -301,6 +301,27 @@ int m2h_bn_train_bwd(const float* dy, const float* y, const float* z, const floa
  * dwp[phase][Co][4*Ci], then scatter to the torch layout dw [Ci][Co][4][4] with this call. */
 int m2h_unpack_convT_wgrad(const float* dwp, float* dw, int Ci, int Co, m2h_stream stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Feeder STFT (A20 / N1) and eval iSTFT (A21 / N2).  librosa 0.8.0 semantics (third-party dependency of the reference:
+ * dataset.py:190-228, simulator_train.py:425-486, eval_metrics.py:232-251).  The DFT itself is a [frames x 1024] x
+ * [1024 x 1024] fp32 GEMM through m2h_conv_igemm_f32 (cos/-sin matrix built on the host); these are the glue kernels.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* frames[s][t][n] = window[n] * y_reflect[s][t*hop + n - n_fft/2] for n < n_fft, 0 for n_fft <= n < ldf.
+ * y: [S][L] waveforms; np.pad(mode="reflect") indexing; T = 1 + (L + 2*(n_fft/2) - n_fft)/hop frames. */
+int m2h_stft_frames(const float* y, const float* window, float* frames, int S, int L, int T, int n_fft, int hop, int ldf, m2h_stream stream);
+
+/* spec [S = B*C][T][lds] holds Re in [0,nb) and Im in [nb,2nb) (GEMM output).  Writes BHWC [B][nb][T][C]:
+ * mag_out = |X| (mode 0), log1p|X| (mode 1, dataset.py:228) or log1p(fp16(|X|)) (mode 2, simulator_train.py:437-441,483-486);
+ * phase_out = atan2(Im, Re) (np.angle).  Either output may be NULL. */
+int m2h_stft_post(const float* spec, float* mag_out, float* phase_out, int B, int C, int T, int nb, int lds, int mode, m2h_stream stream);
+
+/* iSTFT: rows[b][t][k] = mag*cos(phase), rows[b][t][nb+k] = mag*sin(phase) for channel c of BHWC mag/phase [B][nb][T][C]
+ * (eval_metrics.py:243,248: mag * exp(1j*phase)); the inverse real DFT is again a GEMM; then windowed overlap-add with
+ * window-sum-of-squares normalisation, centre trim n_fft/2 and fixed output length: y [S][length]. */
+int m2h_istft_pre(const float* mag, const float* phase, float* rows, int B, int C, int c, int T, int nb, int ldr, m2h_stream stream);
+int m2h_istft_ola(const float* frames, const float* window, float* y, int S, int T, int n_fft, int hop, int ldf, int length, m2h_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

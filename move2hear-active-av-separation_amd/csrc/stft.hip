@@ -1,0 +1,144 @@
+// Feeder STFT and eval iSTFT on the GPU (gfx950, fp32) -- rows N1 / N2 of SURVEY 8f (A20, A21).
+//
+// Reference semantics (third-party, not under the reference tree): librosa==0.8.0 `stft(y, n_fft=1023, hop_length=512)`
+// as called at audio_separation/pretrain/datasets/dataset.py:190-226 and habitat_audio/simulator_train.py:425-481
+// (win_length = n_fft, periodic Hann, center=True with reflect padding n_fft//2, 1 + len//hop frames, 512 bins), followed by
+// np.abs / np.angle and log1p (dataset.py:228; the simulator rounds the magnitude to fp16 first, simulator_train.py:437-441);
+// and `istft(mag*exp(j*phase), hop_length=512, length=16000)` at common/eval_metrics.py:232-251 (n_fft inferred 2*(512-1) =
+// 1022, periodic Hann(1022), overlap-add, division by the window sum-of-squares where > tiny, trim n_fft//2, fix length).
+//
+// Structure: 1023 (and 1022) are not powers of two and the transforms are tiny, so the DFT is a dense [frames x 1024] x
+// [1024 x 1024] fp32 GEMM on the MFMA engine (m2h_conv_igemm_f32 as a Linear; the cos/-sin matrix is built once on the host
+// in float64).  The kernels here are the HBM-bound glue: framing with reflect padding + window, magnitude/phase/log1p with
+// the BHWC store, and the iSTFT pre/post (complex assembly, windowed overlap-add as a gather -- no atomics).
+#include "m2h_internal.h"
+
+namespace m2h {
+
+// frames[s][t][n] = n < n_fft ? window[n] * y_reflect[s][t*hop + n - n_fft/2] : 0     (row length ldf >= n_fft, zero padded)
+__global__ __launch_bounds__(256) void stft_frames_kernel(const float* __restrict__ y, const float* __restrict__ window, float* __restrict__ frames,
+                                                          int S, int L, int T, int n_fft, int hop, int ldf) {
+  const size_t total = (size_t)S * T * ldf;
+  const int pad = n_fft / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % ldf);
+    const size_t r = i / ldf;
+    const int t = (int)(r % T);
+    const int s = (int)(r / T);
+    float v = 0.f;
+    if (n < n_fft) {
+      int idx = t * hop + n - pad;
+      if (idx < 0) idx = -idx;                       // np.pad(mode="reflect"): edge sample not repeated
+      if (idx >= L) idx = 2 * (L - 1) - idx;
+      v = window[n] * y[(size_t)s * L + idx];
+    }
+    frames[i] = v;
+  }
+}
+
+// spec[s][t][0..nb) = Re, [nb..2nb) = Im  ->  mag_out[b][k][t][c] = f(|X|), phase_out likewise (signal s = b*C + c)
+// f: mode 0 |X|; 1 log1p(|X|); 2 log1p(fp16(|X|)) (simulator path).  Outputs are BHWC [B][nb][T][C]; either may be NULL.
+__global__ __launch_bounds__(256) void stft_post_kernel(const float* __restrict__ spec, float* __restrict__ mag_out, float* __restrict__ phase_out,
+                                                        int B, int C, int T, int nb, int lds, int mode) {
+  const size_t total = (size_t)B * nb * T * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int t = (int)(r % T);
+    r /= T;
+    const int k = (int)(r % nb);
+    const int b = (int)(r / nb);
+    const float* row = spec + ((size_t)(b * C + c) * T + t) * lds;
+    const float re = row[k], im = row[nb + k];
+    if (mag_out != nullptr) {
+      float m = sqrtf(re * re + im * im);
+      if (mode == 2) m = (float)(_Float16)m;
+      if (mode >= 1) m = log1pf(m);
+      mag_out[i] = m;
+    }
+    if (phase_out != nullptr) phase_out[i] = atan2f(im, re);
+  }
+}
+
+// iSTFT pre: rows[s][t][k] = mag*cos(phase), rows[s][t][nb+k] = mag*sin(phase) from BHWC mag/phase (channel c of C; s = b)
+__global__ __launch_bounds__(256) void istft_pre_kernel(const float* __restrict__ mag, const float* __restrict__ phase, float* __restrict__ rows,
+                                                        int B, int C, int c, int T, int nb, int ldr) {
+  const size_t total = (size_t)B * T * nb;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % nb);
+    const size_t r = i / nb;
+    const int t = (int)(r % T);
+    const int b = (int)(r / T);
+    const size_t src = (((size_t)b * nb + k) * T + t) * C + c;
+    const float m = mag[src], p = phase[src];
+    float* row = rows + ((size_t)b * T + t) * ldr;
+    row[k] = m * cosf(p);
+    row[nb + k] = m * sinf(p);
+  }
+}
+
+// overlap-add as a gather: y[s][j] = (sum_t frames[s][t][jj - t*hop] * window[jj - t*hop]) / wss(jj),  jj = j + n_fft/2,
+// wss(jj) = sum_t window^2[jj - t*hop] (divide only where > tiny, librosa.util.tiny(float32) = 1.1754944e-38)
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ window, float* __restrict__ y,
+                                                        int S, int T, int n_fft, int hop, int ldf, int length) {
+  const size_t total = (size_t)S * length;
+  const int full = n_fft + hop * (T - 1);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % length);
+    const int s = (int)(i / length);
+    const int jj = j + n_fft / 2;
+    float acc = 0.f, wss = 0.f;
+    if (jj < full) {
+      int t1 = jj / hop;
+      if (t1 > T - 1) t1 = T - 1;
+      for (int t = t1; t >= 0; --t) {
+        const int n = jj - t * hop;
+        if (n >= n_fft) break;
+        const float w = window[n];
+        acc += frames[((size_t)s * T + t) * ldf + n] * w;
+        wss += w * w;
+      }
+    }
+    y[i] = wss > 1.1754944e-38f ? acc / wss : acc;
+  }
+}
+
+static inline unsigned sgrid(size_t total) {
+  size_t g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace m2h
+
+using namespace m2h;
+
+extern "C" {
+
+int m2h_stft_frames(const float* y, const float* window, float* frames, int S, int L, int T, int n_fft, int hop, int ldf, m2h_stream stream) {
+  M2H_REQUIRE(y && window && frames && S > 0 && L > n_fft / 2 && T > 0 && n_fft > 1 && hop > 0 && ldf >= n_fft, "stft_frames: bad arguments");
+  M2H_REQUIRE((T - 1) * hop + n_fft - n_fft / 2 <= L + n_fft / 2, "stft_frames: frames exceed the padded signal");
+  hipLaunchKernelGGL(stft_frames_kernel, dim3(sgrid((size_t)S * T * ldf)), dim3(256), 0, as_stream(stream), y, window, frames, S, L, T, n_fft, hop, ldf);
+  return launch_status("stft_frames");
+}
+
+int m2h_stft_post(const float* spec, float* mag_out, float* phase_out, int B, int C, int T, int nb, int lds, int mode, m2h_stream stream) {
+  M2H_REQUIRE(spec && (mag_out || phase_out) && B > 0 && C > 0 && T > 0 && nb > 0 && lds >= 2 * nb && mode >= 0 && mode <= 2, "stft_post: bad arguments");
+  hipLaunchKernelGGL(stft_post_kernel, dim3(sgrid((size_t)B * nb * T * C)), dim3(256), 0, as_stream(stream), spec, mag_out, phase_out, B, C, T, nb, lds, mode);
+  return launch_status("stft_post");
+}
+
+int m2h_istft_pre(const float* mag, const float* phase, float* rows, int B, int C, int c, int T, int nb, int ldr, m2h_stream stream) {
+  M2H_REQUIRE(mag && phase && rows && B > 0 && C > 0 && c >= 0 && c < C && T > 0 && nb > 0 && ldr >= 2 * nb, "istft_pre: bad arguments");
+  hipLaunchKernelGGL(istft_pre_kernel, dim3(sgrid((size_t)B * T * nb)), dim3(256), 0, as_stream(stream), mag, phase, rows, B, C, c, T, nb, ldr);
+  return launch_status("istft_pre");
+}
+
+int m2h_istft_ola(const float* frames, const float* window, float* y, int S, int T, int n_fft, int hop, int ldf, int length, m2h_stream stream) {
+  M2H_REQUIRE(frames && window && y && S > 0 && T > 0 && n_fft > 1 && hop > 0 && ldf >= n_fft && length > 0, "istft_ola: bad arguments");
+  hipLaunchKernelGGL(istft_ola_kernel, dim3(sgrid((size_t)S * length)), dim3(256), 0, as_stream(stream), frames, window, y, S, T, n_fft, hop, ldf, length);
+  return launch_status("istft_ola");
+}
+
+}  // extern "C"

@@ -15,7 +15,7 @@ _REPO_ROOT = os.path.dirname(_PKG_ROOT)
 CSRC = os.path.join(_PKG_ROOT, "csrc")
 INCLUDE = os.path.join(_REPO_ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libm2h.so")
-SOURCES = ["conv_igemm.hip", "conv_bwd.hip", "bn.hip", "layout.hip", "rl_ops.hip", "api.hip"]
+SOURCES = ["conv_igemm.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "api.hip"]
 
 _lock = threading.Lock()
 _lib = None
@@ -121,6 +121,10 @@ SIGNATURES = {
     "m2h_bn_train_fwd": [_P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "m2h_bn_train_bwd": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P],
     "m2h_unpack_convT_wgrad": [_P, _P, _I, _I, _P],
+    "m2h_stft_frames": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "m2h_stft_post": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "m2h_istft_pre": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "m2h_istft_ola": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "m2h_gather_envs": [_P, _P, _P, _I, _I, _I, _Z, _P],
     "m2h_stft_l2": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
 }

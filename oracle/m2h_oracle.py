@@ -412,3 +412,66 @@ def passive_train_step(params, buffers, batch, lr=5e-4, eps=1e-5, opt_state=None
         for k, v in stats.items():
             buffers[k].copy_(v)
     return bin_loss.detach(), mono_loss.detach(), opt
+
+
+# ==============================================================================================
+# A20 / A21: feeder STFT and eval iSTFT -- librosa 0.8.0 semantics restated in numpy.
+# librosa is a third-party dependency of the reference (requirements.txt:85) that is NOT installed here: parity for these two
+# functions is pinned against torch.stft / torch.istft (an independent implementation) in tests/test_oracle_stft.py, not
+# against the reference itself ("parity unpinned" by the reference).
+# ==============================================================================================
+def np_hann_periodic(n):
+    import numpy as np
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)
+
+
+def np_stft(y, n_fft=1023, hop=512):
+    """librosa.stft(y, n_fft, hop_length=hop): win_length = n_fft, periodic Hann, center=True, pad_mode='reflect';
+    returns complex64 [1 + n_fft//2, 1 + (len(y_padded) - n_fft)//hop]  (dataset.py:190-226; simulator_train.py:425-481)."""
+    import numpy as np
+    w = np_hann_periodic(n_fft).astype(np.float32)
+    yp = np.pad(y.astype(np.float32), n_fft // 2, mode="reflect")
+    T = 1 + (len(yp) - n_fft) // hop
+    frames = np.stack([yp[t * hop:t * hop + n_fft] * w for t in range(T)], axis=1)
+    return np.fft.rfft(frames, axis=0).astype(np.complex64)
+
+
+def np_istft(stft_matrix, hop=512, length=16000):
+    """librosa.istft(stft_matrix, hop_length=hop, length=length): n_fft = 2*(bins-1), periodic Hann, overlap-add, division by
+    the window sum-of-squares where > tiny, trim n_fft//2, fix length  (eval_metrics.py:232-251)."""
+    import numpy as np
+    nb, T = stft_matrix.shape
+    n_fft = 2 * (nb - 1)
+    w = np_hann_periodic(n_fft).astype(np.float32)
+    full = n_fft + hop * (T - 1)
+    y = np.zeros(full, np.float32)
+    wss = np.zeros(full, np.float32)
+    frames = np.fft.irfft(stft_matrix, n=n_fft, axis=0).astype(np.float32)
+    for t in range(T):
+        y[t * hop:t * hop + n_fft] += frames[:, t] * w
+        wss[t * hop:t * hop + n_fft] += w * w
+    nz = wss > np.finfo(np.float32).tiny
+    y[nz] /= wss[nz]
+    y = y[n_fft // 2:]
+    if len(y) >= length:
+        return y[:length]
+    return np.pad(y, (0, length - len(y)))
+
+
+def np_stft_features(wave_bcl, fp16_round=False):
+    """[B,C,L] -> (log1p|STFT| BHWC [B,512,T,C], phase BHWC): dataset.py:228 / simulator_train.py:437-441,483-486."""
+    import numpy as np
+    B, C, L = wave_bcl.shape
+    mags, phs = [], []
+    for b in range(B):
+        mc, pc = [], []
+        for c in range(C):
+            X = np_stft(wave_bcl[b, c])
+            m = np.abs(X)
+            if fp16_round:
+                m = m.astype(np.float16).astype(np.float32)
+            mc.append(np.log1p(m))
+            pc.append(np.angle(X))
+        mags.append(np.stack(mc, -1))
+        phs.append(np.stack(pc, -1))
+    return np.stack(mags).astype(np.float32), np.stack(phs).astype(np.float32)
