@@ -151,69 +151,124 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
   f32x4 ra[AR], rb[BR];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  auto load_tile = [&](int kt) {
-    const int k = kt * BK + seg * 4;
-    const bool kok = k < p.K;
-    int tap = 0, ci = k;
+  // ---- per-thread k decode state for the tile being loaded: k = kt*BK + seg*4 -> (th, tw, ci); advanced incrementally ----
+  int ld_k, ld_th, ld_tw, ld_ci;
+  auto seek_tile = [&](int kt) {
+    ld_k = kt * BK + seg * 4;
+    int tap = 0;
+    ld_ci = ld_k;
     if (p.ntap > 1) {
-      tap = (unsigned)k / (unsigned)p.Ctot;
-      ci = k - tap * p.Ctot;
+      tap = (unsigned)ld_k / (unsigned)p.Ctot;
+      ld_ci = ld_k - tap * p.Ctot;
     }
-    const int th = (unsigned)tap / (unsigned)p.ntw;
-    const int tw = tap - th * p.ntw;
-    const int dh = th * mulh, dw = tw * mulw;
-    const float* src = p.src0;
-    int Cs = p.C0, c = ci;
-    if (ci >= p.C0) {
-      src = p.src1;
-      Cs = p.C1;
-      c = ci - p.C0;
-    }
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      const int ih = a_qh[i] + dh, iw = a_rw[i] + dw;
-      const bool ok = kok && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-      ra[i] = zero4;
-      if (ok) {
-        const size_t off = ((size_t)(a_bpix[i] + ih * p.Wi + iw)) * (size_t)Cs + (size_t)c;
-        ra[i] = *reinterpret_cast<const f32x4*>(src + off);
+    ld_th = (unsigned)tap / (unsigned)p.ntw;
+    ld_tw = tap - ld_th * p.ntw;
+  };
+  auto next_tile = [&]() {
+    if (p.Ctot >= BK) {  // at most one wrap per 32-deep step (wave-uniform branch)
+      ld_k += BK;
+      ld_ci += BK;
+      if (ld_ci >= p.Ctot) {
+        ld_ci -= p.Ctot;
+        if (++ld_tw == p.ntw) {
+          ld_tw = 0;
+          ++ld_th;
+        }
       }
+    } else {
+      seek_tile(ld_k / BK + 1);
     }
-#pragma unroll
-    for (int j = 0; j < BR; ++j) {
-      const int n = n0 + srow + 32 * j;
-      rb[j] = zero4;
-      if (kok && n < p.N) rb[j] = *reinterpret_cast<const f32x4*>(wbase + (size_t)n * p.K + k);
+  };
+  // per-tile values shared by the row loads
+  bool t_kok;
+  int t_dh, t_dw, t_Cs, t_c;
+  const float* t_src;
+  auto tile_setup = [&]() {
+    t_kok = ld_k < p.K;
+    t_dh = ld_th * mulh;
+    t_dw = ld_tw * mulw;
+    t_src = p.src0;
+    t_Cs = p.C0;
+    t_c = ld_ci;
+    if (ld_ci >= p.C0 && p.src1 != nullptr) {  // second source; beyond-K padding tiles of a single-source conv keep src0
+      t_src = p.src1;
+      t_Cs = p.C1;
+      t_c = ld_ci - p.C0;
     }
+  };
+  // Loads are unconditional (clamped to element 0 of the source when masked) and zeroed by a select afterwards: no
+  // divergent branches in the k-loop, so the loads can be scheduled into the MFMA shadows.
+  // The loaded value is NOT touched until store_tile (a select right after the load would force a vmcnt(0) wait there);
+  // the validity bits travel in a mask.
+  unsigned okmask = 0;
+  auto load_a = [&](int i) {
+    const int ih = a_qh[i] + t_dh, iw = a_rw[i] + t_dw;
+    const bool ok = t_kok && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+    const unsigned off = ok ? (unsigned)(a_bpix[i] + ih * p.Wi + iw) * (unsigned)t_Cs + (unsigned)t_c : 0u;
+    ra[i] = *reinterpret_cast<const f32x4*>(t_src + off);
+    okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
+  };
+  auto load_b = [&](int j) {
+    const int n = n0 + srow + 32 * j;
+    const bool ok = t_kok && n < p.N;
+    const unsigned off = ok ? (unsigned)n * (unsigned)p.K + (unsigned)ld_k : 0u;
+    rb[j] = *reinterpret_cast<const f32x4*>(wbase + off);
+    okmask = ok ? (okmask | (1u << (8 + j))) : (okmask & ~(1u << (8 + j)));
   };
 
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(&As[buf][(srow + 32 * i) * LDK + seg * 4]) = ra[i];
+    for (int i = 0; i < AR; ++i)
+      *reinterpret_cast<f32x4*>(&As[buf][(srow + 32 * i) * LDK + seg * 4]) = (okmask & (1u << i)) ? ra[i] : zero4;
 #pragma unroll
-    for (int j = 0; j < BR; ++j) *reinterpret_cast<f32x4*>(&Bs[buf][(srow + 32 * j) * LDK + seg * 4]) = rb[j];
+    for (int j = 0; j < BR; ++j)
+      *reinterpret_cast<f32x4*>(&Bs[buf][(srow + 32 * j) * LDK + seg * 4]) = (okmask & (1u << (8 + j))) ? rb[j] : zero4;
   };
 
   const int frow = lane & 31;        // fragment row (A: pixel, B: channel)
   const int fk = (lane >> 5) * 4;    // k offset of this lane half inside an 8-deep group
 
-  auto compute = [&](int buf) {
+  f32x4 fa[2][FM], fb[2][FN];  // fragment double buffer: group g+1 is read from LDS while group g's MFMAs run
+  auto read_frags = [&](int buf, int g, int slot) {
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      f32x4 a[FM], b[FN];
+    for (int mi = 0; mi < FM; ++mi)
+      fa[slot][mi] = *reinterpret_cast<const f32x4*>(&As[buf][(wm * TM + mi * 32 + frow) * LDK + g * 8 + fk]);
+#pragma unroll
+    for (int ni = 0; ni < FN; ++ni)
+      fb[slot][ni] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wn * TN + ni * 32 + frow) * LDK + g * 8 + fk]);
+  };
+  auto mfma_group = [&](int slot) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int mi = 0; mi < FM; ++mi)
-        a[mi] = *reinterpret_cast<const f32x4*>(&As[buf][(wm * TM + mi * 32 + frow) * LDK + g * 8 + fk]);
 #pragma unroll
-      for (int ni = 0; ni < FN; ++ni)
-        b[ni] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wn * TN + ni * 32 + frow) * LDK + g * 8 + fk]);
+        for (int ni = 0; ni < FN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][mi][j], fb[slot][ni][j], acc[mi][ni], 0, 0, 0);
+  };
+
+  // one k-tile with prefetch: the next tile's global loads are spread over the four 8-deep MFMA groups of the current tile.
+  // Straight-line (no conditionals): the last tile of the range is peeled off below.
+  auto tile_body_prefetch = [&](int buf) {
+    next_tile();
+    tile_setup();
+    read_frags(buf, 0, 0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+    for (int g = 0; g < BK / 8; ++g) {
+      if (g + 1 < BK / 8) read_frags(buf, g + 1, (g + 1) & 1);
 #pragma unroll
-        for (int mi = 0; mi < FM; ++mi)
+      for (int i = g; i < AR; i += BK / 8) load_a(i);
 #pragma unroll
-          for (int ni = 0; ni < FN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+      for (int j = g; j < BR; j += BK / 8) load_b(j);
+      mfma_group(g & 1);
+    }
+  };
+  auto tile_body_last = [&](int buf) {
+    read_frags(buf, 0, 0);
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      if (g + 1 < BK / 8) read_frags(buf, g + 1, (g + 1) & 1);
+      mfma_group(g & 1);
     }
   };
 
@@ -221,28 +276,32 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
   const int split = blockIdx.y;
   const int kt0 = (int)(((long)nk_all * split) / p.S);
   const int kt1 = (int)(((long)nk_all * (split + 1)) / p.S);
-  load_tile(kt0);
+  seek_tile(kt0);
+  tile_setup();
+#pragma unroll
+  for (int i = 0; i < AR; ++i) load_a(i);
+#pragma unroll
+  for (int j = 0; j < BR; ++j) load_b(j);
   store_tile(0);
   __syncthreads();
   if constexpr (NSTAGE == 2) {
-    for (int kt = kt0; kt < kt1; ++kt) {
-      const int cur = (kt - kt0) & 1;
-      if (kt + 1 < kt1) load_tile(kt + 1);  // global loads fly under the MFMAs of this tile
-      compute(cur);
-      if (kt + 1 < kt1) store_tile(cur ^ 1);
+    int cur = 0;
+    for (int kt = kt0; kt + 1 < kt1; ++kt) {
+      tile_body_prefetch(cur);  // global loads fly under the MFMAs of this tile
+      store_tile(cur ^ 1);
       __syncthreads();
+      cur ^= 1;
     }
+    tile_body_last(cur);
   } else {
     // single LDS stage: half the LDS, twice the resident blocks; other blocks' MFMAs cover the two barriers
-    for (int kt = kt0; kt < kt1; ++kt) {
-      if (kt + 1 < kt1) load_tile(kt + 1);
-      compute(0);
-      if (kt + 1 < kt1) {
-        __syncthreads();
-        store_tile(0);
-        __syncthreads();
-      }
+    for (int kt = kt0; kt + 1 < kt1; ++kt) {
+      tile_body_prefetch(0);
+      __syncthreads();
+      store_tile(0);
+      __syncthreads();
     }
+    tile_body_last(0);
   }
 
   if (p.S > 1) {
@@ -355,6 +414,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IGemmP p) {
 // Debug/tuning knobs (m2h_debug_set): 0 = automatic.
 int g_force_splitk = 0;   // >0: force this split-K factor (when workspace allows), -1: never split
 int g_force_stages = 0;   // 1 | 2: force the LDS stage count of the narrow-N configs
+int g_wide_stages = 0;    // 1 | 2: LDS stage count of the 128x128 config (0 = 2)
 
 static int choose_splitk(const IGemmP& p, int BM, int BN, size_t ws_bytes) {
   if (p.ws == nullptr || g_force_splitk < 0 || (p.N & 3) != 0) return 1;
@@ -430,6 +490,8 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   M2H_REQUIRE(M < (1L << 30), "conv_igemm: M too large");
   M2H_REQUIRE((long)a.B * a.Hi * a.Wi < (1L << 30), "conv_igemm: input pixel count too large");
   M2H_REQUIRE((long)a.B * 16 * a.Ho * a.Wo < (1L << 31), "conv_igemm: output pixel count too large");
+  M2H_REQUIRE((long)a.B * a.Hi * a.Wi * (a.C0 > a.C1 ? a.C0 : a.C1) < (1L << 32), "conv_igemm: source tensor exceeds 32-bit element offsets");
+  M2H_REQUIRE((long)a.N * a.nth * a.ntw * (a.C0 + a.C1) < (1L << 32), "conv_igemm: weight matrix exceeds 32-bit element offsets");
   if (a.out_mode == M2H_OUT_DESLICE) {
     M2H_REQUIRE(a.N % 16 == 0, "conv_igemm: de-slice needs N %% 16 == 0");
   } else {
@@ -450,7 +512,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
 
   p.ws = static_cast<float*>(a.workspace);
   const size_t wsb = a.workspace != nullptr ? a.workspace_bytes : 0;
-  if (p.N > 64) return launch_cfg<128, 128, 2, 2, 2>(p, wsb, st);
+  if (p.N > 64) return g_wide_stages == 1 ? launch_cfg<128, 128, 2, 2, 1>(p, wsb, st) : launch_cfg<128, 128, 2, 2, 2>(p, wsb, st);
   // narrow-N tiles: one LDS stage doubles the resident blocks; measured better for the transposed-conv phases and the
   // 32-wide tiles, worse for the short-K stride-2 conv (layer_bench.py, round 1)
   if (p.N > 32) {

@@ -191,6 +191,8 @@ def test_error_behaviour():
     with pytest.raises(RuntimeError):
         ops.sep_slice_input(torch.zeros(1, 500, 32, 2, device=dev))  # F % 16 != 0 -> C-ABI argument error
     pol, _ = _policy(2, dev)
+    with pytest.raises(NotImplementedError):  # eval-mode (folded BN) path has no autograd: refuses instead of dropping the graph
+        pol.get_binSepMasks({"mixed_bin_audio_mag": torch.zeros(1, 512, 32, 2, device=dev), "target_class": torch.zeros(1, 1, device=dev)})
     pol.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):  # train-mode BN needs more than one value per channel (torch raises here too)
         pol.get_binSepMasks({"mixed_bin_audio_mag": torch.zeros(1, 512, 32, 2, device=dev), "target_class": torch.zeros(1, 1, device=dev)})
