@@ -322,6 +322,32 @@ int m2h_stft_post(const float* spec, float* mag_out, float* phase_out, int B, in
 int m2h_istft_pre(const float* mag, const float* phase, float* rows, int B, int C, int c, int T, int nb, int ldr, m2h_stream stream);
 int m2h_istft_ola(const float* frames, const float* window, float* y, int S, int T, int n_fft, int hop, int ldf, int length, m2h_stream stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Whole-network runner: one C call enqueues every kernel of one separator U-Net forward (K1/K2 slice, 5 down stages, 5 up
+ * stages, head) = PassiveSepEncCNN.forward + PassiveSepDecCNN.forward (separator_cnn.py:70-108,153-170) in eval mode.  Same
+ * kernels and results as the per-op entry points; exists because at rollout batch sizes (14 envs) the per-launch host cost
+ * of a Python-driven chain exceeds the GPU time.  All pointers are device pointers to buffers produced by the m2h_pack_* /
+ * m2h_fold_bn calls; intermediates live in the caller-owned workspace.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct m2h_unet_weights {
+  const float* down_w[5];     /* packed conv weights [Co][16*Ci] (stage 0: Ci = 32, class plane dropped) */
+  const float* down_scale[5]; /* folded BN */
+  const float* down_shift[5];
+  const float* cls_table;     /* [9][64] for binSep stage 0, NULL for bin2mono */
+  const float* up_w[5];       /* packed transposed-conv weights [4][Co][4*Cin] */
+  const float* up_scale[5];
+  const float* up_shift[5];
+  const float* head_w;        /* [n_out][n_out] */
+  const float* head_b;        /* [n_out] */
+  int n_out;                  /* 32 (binSep) or 16 (bin2mono) */
+} m2h_unet_weights;
+
+size_t m2h_unet_fwd_workspace_bytes(int B, int F, int T);
+/* mix [B][F][T][2]; masks [B][F][T][2] or NULL (binSep); cls_val [B] = target_class + 1 (binSep) or NULL; out BHWC
+ * [B][F][T][n_out/16].  F = 512 (16 slices of 32 rows), T % 32 == 0. */
+int m2h_unet_fwd(const m2h_unet_weights* w /* host */, const float* mix, const float* masks, const float* cls_val, float* out,
+                 int B, int F, int T, void* workspace, size_t workspace_bytes, m2h_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

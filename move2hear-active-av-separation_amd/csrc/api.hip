@@ -97,4 +97,93 @@ int m2h_unet_head_fwd(const float* x, const float* wp, const float* bias, float*
   return conv_igemm_f32(a, as_stream(stream));
 }
 
+// ---- whole-network runner -----------------------------------------------------------------------------------------
+static const int kEnc[6] = {32, 64, 128, 256, 512, 512};
+
+static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+struct UnetLayout {
+  size_t x0, e[5], d[5], splitk, total;
+};
+
+static UnetLayout unet_layout(int B, int F, int T, int n_out) {
+  UnetLayout L;
+  const int H = F / 16;
+  size_t off = 0;
+  L.x0 = off; off += align256((size_t)B * H * T * 32 * 4);
+  int h = H, w = T;
+  for (int i = 0; i < 5; ++i) {
+    h /= 2; w /= 2;
+    L.e[i] = off; off += align256((size_t)B * h * w * kEnc[i + 1] * 4);
+  }
+  const int dco[5] = {512, 256, 128, 64, n_out};
+  for (int i = 0; i < 5; ++i) {
+    h *= 2; w *= 2;
+    L.d[i] = off; off += align256((size_t)B * h * w * dco[i] * 4);
+  }
+  // split-K scratch: the largest request of any stage
+  size_t sk = 0;
+  h = H; w = T;
+  for (int i = 0; i < 5; ++i) {
+    size_t b = m2h_unet_down_workspace_bytes(B, h, w, kEnc[i], kEnc[i + 1]);
+    if (b > sk) sk = b;
+    h /= 2; w /= 2;
+  }
+  const int c0[5] = {512, 512, 256, 128, 64}, c1[5] = {0, 512, 256, 128, 64};
+  for (int i = 0; i < 5; ++i) {
+    size_t b = m2h_unet_up_workspace_bytes(B, h, w, c0[i], c1[i], dco[i]);
+    if (b > sk) sk = b;
+    h *= 2; w *= 2;
+  }
+  L.splitk = off; off += align256(sk);
+  L.total = off;
+  return L;
+}
+
+size_t m2h_unet_fwd_workspace_bytes(int B, int F, int T) {
+  if (B <= 0 || F <= 0 || T <= 0) return 0;
+  return unet_layout(B, F, T, 32).total;
+}
+
+int m2h_unet_fwd(const m2h_unet_weights* wts, const float* mix, const float* masks, const float* cls_val, float* out, int B, int F,
+                 int T, void* workspace, size_t workspace_bytes, m2h_stream stream) {
+  M2H_REQUIRE(wts && mix && out && workspace, "unet_fwd: null pointer");
+  M2H_REQUIRE(B > 0 && F == 512 && T > 0 && T % 32 == 0, "unet_fwd: F must be 512 and T a multiple of 32 (got %d x %d)", F, T);
+  M2H_REQUIRE(wts->n_out == 32 || wts->n_out == 16, "unet_fwd: n_out must be 32 or 16");
+  M2H_REQUIRE((wts->cls_table == nullptr) == (cls_val == nullptr), "unet_fwd: class table / value mismatch");
+  const UnetLayout L = unet_layout(B, F, T, wts->n_out);
+  M2H_REQUIRE(workspace_bytes >= L.total, "unet_fwd: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+  char* ws = static_cast<char*>(workspace);
+  float* x0 = reinterpret_cast<float*>(ws + L.x0);
+  float* e[5];
+  float* d[5];
+  for (int i = 0; i < 5; ++i) {
+    e[i] = reinterpret_cast<float*>(ws + L.e[i]);
+    d[i] = reinterpret_cast<float*>(ws + L.d[i]);
+  }
+  void* sk = ws + L.splitk;
+  const size_t skb = L.total - L.splitk;
+  int rc = m2h_sep_slice_input(mix, masks, x0, B, F, T, 2, stream);
+  if (rc) return rc;
+  int h = F / 16, w = T;
+  const float* cur = x0;
+  for (int i = 0; i < 5; ++i) {
+    rc = m2h_unet_down_fwd(cur, wts->down_w[i], wts->down_scale[i], wts->down_shift[i], i == 0 ? wts->cls_table : nullptr,
+                           i == 0 ? cls_val : nullptr, e[i], B, h, w, kEnc[i], kEnc[i + 1], sk, skb, stream);
+    if (rc) return rc;
+    cur = e[i];
+    h /= 2; w /= 2;
+  }
+  const int c0[5] = {512, 512, 256, 128, 64}, c1[5] = {0, 512, 256, 128, 64};
+  const int dco[5] = {512, 256, 128, 64, wts->n_out};
+  for (int i = 0; i < 5; ++i) {
+    const float* skip = i == 0 ? nullptr : e[4 - i];
+    rc = m2h_unet_up_fwd(cur, skip, wts->up_w[i], wts->up_scale[i], wts->up_shift[i], d[i], B, h, w, c0[i], c1[i], dco[i], sk, skb, stream);
+    if (rc) return rc;
+    cur = d[i];
+    h *= 2; w *= 2;
+  }
+  return m2h_unet_head_fwd(cur, wts->head_w, wts->head_b, out, B, h, w, wts->n_out, wts->n_out, stream);
+}
+
 }  // extern "C"

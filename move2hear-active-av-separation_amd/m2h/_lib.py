@@ -69,6 +69,17 @@ class ConvArgs(ctypes.Structure):
     ]
 
 
+class UnetWeights(ctypes.Structure):
+    """Mirror of ``struct m2h_unet_weights`` (include/m2h.h)."""
+    _fields_ = [
+        ("down_w", ctypes.c_void_p * 5), ("down_scale", ctypes.c_void_p * 5), ("down_shift", ctypes.c_void_p * 5),
+        ("cls_table", ctypes.c_void_p),
+        ("up_w", ctypes.c_void_p * 5), ("up_scale", ctypes.c_void_p * 5), ("up_shift", ctypes.c_void_p * 5),
+        ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p),
+        ("n_out", ctypes.c_int),
+    ]
+
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
@@ -125,6 +136,8 @@ SIGNATURES = {
     "m2h_stft_post": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "m2h_istft_pre": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "m2h_istft_ola": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "m2h_unet_fwd_workspace_bytes": [_I, _I, _I],
+    "m2h_unet_fwd": [ctypes.POINTER(UnetWeights), _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P],
     "m2h_gather_envs": [_P, _P, _P, _I, _I, _I, _Z, _P],
     "m2h_stft_l2": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
 }

@@ -21,6 +21,11 @@ def set_timing(sink):
     _timing = sink
 
 
+def timing_enabled():
+    """True while bench.py brackets every launch with HIP events (the per-op path is then used so that each kernel is timed)."""
+    return _timing is not None
+
+
 def igemm_config(N):
     """Name of the igemm_f32_kernel instantiation conv_igemm.hip picks for N output channels."""
     return "igemm_f32<128,128>" if N > 64 else ("igemm_f32<128,64>" if N > 32 else "igemm_f32<128,32>")

@@ -237,3 +237,41 @@ class PassiveSepDecCNN(nn.Module):
             skip = None if idx == 0 else _as_nhwc(lst_skip_feats[idx - 1])
             out = ops.unet_up_fwd(out, skip, wp, scale, shift, co)
         return ops.unet_head_fwd(out, hw, hb, hco)  # BHWC, contiguous
+
+
+def unet_forward(enc, dec, mix, masks=None, target_class=None):
+    """Eval-mode forward of one encoder/decoder pair through the whole-network C runner (m2h_unet_fwd): same kernels and
+    values as ``dec(*enc(...))``, one host call instead of ~13.  enc: PassiveSepEncCNN, dec: PassiveSepDecCNN."""
+    import ctypes
+
+    from ... import _lib
+    _check_inference(enc, mix, masks)
+    _check_inference(dec)
+    downs = enc._packed()
+    ups, (hw, hb, hco) = dec._packed()
+    mix = mix.contiguous()
+    B, F, T, C = mix.shape
+    if C != 2 or F != 512 or T % 32 != 0:
+        raise RuntimeError("m2h.unet_forward: expected mix [B,512,T,2] with T %% 32 == 0, got %s" % (tuple(mix.shape),))
+    w = _lib.UnetWeights()
+    keep = [mix]
+    for i, (wp, scale, shift, table, _co) in enumerate(downs):
+        w.down_w[i], w.down_scale[i], w.down_shift[i] = wp.data_ptr(), scale.data_ptr(), shift.data_ptr()
+    table = downs[0][3]
+    w.cls_table = table.data_ptr() if table is not None else None
+    for i, (wp, scale, shift, _co) in enumerate(ups):
+        w.up_w[i], w.up_scale[i], w.up_shift[i] = wp.data_ptr(), scale.data_ptr(), shift.data_ptr()
+    w.head_w, w.head_b, w.n_out = hw.data_ptr(), hb.data_ptr(), hco
+    cls_val = None
+    if table is not None:
+        cls_val = (target_class.reshape(-1).to(torch.float32) + 1.0).contiguous()
+    if masks is not None:
+        masks = masks.contiguous()
+    lib = _lib.load()
+    out = torch.empty((B, F, T, hco // 16), device=mix.device, dtype=torch.float32)
+    with torch.cuda.device(mix.device):
+        nbytes = lib.m2h_unet_fwd_workspace_bytes(B, F, T)
+        ws = torch.empty(nbytes // 4, device=mix.device, dtype=torch.float32)
+        _lib.check(lib.m2h_unet_fwd(ctypes.byref(w), ops._ptr(mix), ops._ptr(masks), ops._ptr(cls_val), ops._ptr(out), B, F, T, ops._ptr(ws),
+                                    nbytes, ops._stream(mix)), "m2h_unet_fwd")
+    return out

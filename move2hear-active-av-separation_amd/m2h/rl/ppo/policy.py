@@ -15,6 +15,7 @@ from ... import ops
 from ...common.utils import CategoricalNet, CustomFixedCategorical
 from ...pretrain.passive.policy import PassiveSepDec, PassiveSepEnc  # identical wrappers (reference :121-156)
 from ..models.audio_cnn import AudioCNN
+from ..models.separator_cnn import unet_forward
 from ..models.memory_nets import AcousticMem
 from ..models.rnn_state_encoder import RNNStateEncoder
 from ..models.visual_cnn import VisualCNN
@@ -109,10 +110,17 @@ class Policy(nn.Module):
         raise NotImplementedError
 
     def get_binSepMasks(self, observations):
+        enc, dec = self.binSep_enc.passive_sep_encoder, self.binSep_dec.passive_sep_decoder
+        if not enc.training and not dec.training and not ops.timing_enabled() and observations["mixed_bin_audio_mag"].shape[1] == 512:
+            # eval mode (every RL call site): the whole U-Net is enqueued by one C call (m2h_unet_fwd)
+            return unet_forward(enc, dec, observations["mixed_bin_audio_mag"], None, observations["target_class"])
         bottleneck_feats, lst_skip_feats = self.binSep_enc(observations)
         return self.binSep_dec(bottleneck_feats, lst_skip_feats)
 
     def convert_bin2mono(self, pred_binSepMasks, mixed_audio=None):
+        enc, dec = self.bin2mono_enc.passive_sep_encoder, self.bin2mono_dec.passive_sep_decoder
+        if not enc.training and not dec.training and not ops.timing_enabled() and mixed_audio.shape[1] == 512:
+            return unet_forward(enc, dec, mixed_audio, pred_binSepMasks)
         bottleneck_feats, lst_skip_feats = self.bin2mono_enc(pred_binSepMasks, mixed_audio=mixed_audio)
         return self.bin2mono_dec(bottleneck_feats, lst_skip_feats)
 

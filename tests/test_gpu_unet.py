@@ -196,3 +196,18 @@ def test_error_behaviour():
     pol.train()
     with pytest.raises(RuntimeError):  # train-mode BN needs more than one value per channel (torch raises here too)
         pol.get_binSepMasks({"mixed_bin_audio_mag": torch.zeros(1, 512, 32, 2, device=dev), "target_class": torch.zeros(1, 1, device=dev)})
+
+
+def test_whole_network_runner_is_bitwise_the_module_chain():
+    """m2h_unet_fwd (one C call per U-Net) enqueues the same kernels as the encoder/decoder module chain."""
+    dev = _dev()
+    pol, _ = _policy(2, dev)
+    for B, tm in ((3, 32), (2, 64)):
+        mixed, tc = synthetic.make_passive_inputs(B, tm, 40 + B)
+        obs = {"mixed_bin_audio_mag": torch.from_numpy(mixed).to(dev), "target_class": torch.from_numpy(tc).to(dev)}
+        with torch.no_grad():
+            fast_m = pol.get_binSepMasks(obs)
+            fast_mono = pol.convert_bin2mono(fast_m, mixed_audio=obs["mixed_bin_audio_mag"])
+            chain_m = pol.binSep_dec(*pol.binSep_enc(obs))
+            chain_mono = pol.bin2mono_dec(*pol.bin2mono_enc(chain_m, mixed_audio=obs["mixed_bin_audio_mag"]))
+        assert torch.equal(fast_m, chain_m) and torch.equal(fast_mono, chain_mono)
