@@ -6,7 +6,7 @@ namespace m2h {
 thread_local char g_err[512] = {0};
 int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st);
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a);
-extern int g_force_splitk, g_force_stages, g_wide_stages;
+extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny;
 }  // namespace m2h
 
 using namespace m2h;
@@ -30,6 +30,7 @@ int m2h_debug_set(int knob, int value) {
   if (knob == 0) g_force_splitk = value;
   else if (knob == 1) g_force_stages = value;
   else if (knob == 2) g_wide_stages = value;
+  else if (knob == 3) g_skinny = value;
   else return fail(-1, "debug_set: unknown knob %d", knob);
   return 0;
 }

@@ -318,12 +318,15 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __r
   if (w == 0 && n < N) part[(size_t)blockIdx.y * N + n] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
-__global__ void bias_grad_final_kernel(const float* __restrict__ part, float* __restrict__ db, int N, int splits) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per column: lanes sum the splits strided by 64, then a fixed butterfly (deterministic)
+__global__ __launch_bounds__(256) void bias_grad_final_kernel(const float* __restrict__ part, float* __restrict__ db, int N, int splits) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += part[(size_t)z * N + n];
-  db[n] = s;
+  for (int z = threadIdx.x & 63; z < splits; z += 64) s += part[(size_t)z * N + n];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) db[n] = s;
 }
 
 static int bias_grad_splits(int M, int N) {
@@ -383,7 +386,7 @@ int m2h_bias_grad(const float* dy, float* db, int M, int N, float* workspace, m2
   const int splits = bias_grad_splits(M, N);
   const int rps = (M + splits - 1) / splits;
   hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, as_stream(stream), dy, workspace, M, N, rps);
-  hipLaunchKernelGGL(bias_grad_final_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), workspace, db, N, splits);
+  hipLaunchKernelGGL(bias_grad_final_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), workspace, db, N, splits);
   return launch_status("bias_grad");
 }
 

@@ -415,21 +415,43 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IGemmP p) {
 int g_force_splitk = 0;   // >0: force this split-K factor (when workspace allows), -1: never split
 int g_force_stages = 0;   // 1 | 2: force the LDS stage count of the narrow-N configs
 int g_wide_stages = 0;    // 1 | 2: LDS stage count of the 128x128 config (0 = 2)
+int g_skinny = 0;         // -1: never use the 32/64-row tiles
+
+// Tile choice: N picks the width; skinny M (rollout batches, GRU steps: weight-streaming bound, nothing to re-use along M)
+// gets 32- or 64-row tiles so that four times as many blocks stream the weights.
+static void pick_tile(long M, int N, int& BM, int& BN) {
+  BN = N > 64 ? 128 : (N > 32 ? 64 : 32);
+  BM = 128;
+  if (BN == 128 && g_skinny >= 0) {
+    if (M <= 32) BM = 32;
+    else if (M <= 64) BM = 64;
+  }
+}
+
+static int splitk_for(long M, int N, int K, int phases, int BM, int BN) {
+  if ((N & 3) != 0) return 1;
+  const int nk = (K + BK - 1) / BK;
+  const long mt = (M + BM - 1) / BM, ntl = (N + BN - 1) / BN;
+  const long blocks = mt * ntl * phases;  // working blocks (padding blocks of the XCD map exit at once)
+  long S = 1;
+  if (blocks < 512) {
+    S = (512 + blocks - 1) / blocks;  // aim at two resident blocks per CU
+    const long cap = BM < 128 ? 64 : 32;
+    if (S > cap) S = cap;
+  }
+  if (S > nk / 2) S = nk / 2;  // at least two k-tiles per split
+  return S < 1 ? 1 : (int)S;
+}
 
 static int choose_splitk(const IGemmP& p, int BM, int BN, size_t ws_bytes) {
   if (p.ws == nullptr || g_force_splitk < 0 || (p.N & 3) != 0) return 1;
   const int phases = p.convT ? 4 : 1;
-  const int nk = (p.K + BK - 1) / BK;
-  const long mt = (p.M + BM - 1) / BM, ntl = (p.N + BN - 1) / BN;
-  const long blocks = mt * ntl * phases;  // working blocks (padding blocks of the XCD map exit at once)
-  int S = 1;
+  int S = splitk_for(p.M, p.N, p.K, phases, BM, BN);
   if (g_force_splitk > 0) {
     S = g_force_splitk;
-  } else if (blocks < 512) {
-    S = (int)((512 + blocks - 1) / blocks);  // aim at two resident blocks per CU
-    if (S > 32) S = 32;
+    const int nk = (p.K + BK - 1) / BK;
+    if (S > nk / 2) S = nk / 2;
   }
-  if (S > nk / 2) S = nk / 2;  // at least two k-tiles per split
   while (S > 1 && (size_t)phases * S * p.M * p.N * sizeof(float) > ws_bytes) --S;
   return S < 1 ? 1 : S;
 }
@@ -455,20 +477,13 @@ static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
 }
 
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a) {
-  // enough for the automatic split-K choice on any tile config: phases * S * M * N floats, S <= 32 and only when the
-  // grid is small (blocks < 512  =>  M*N*phases < 512 * 128 * 128), so cap at 32 * 512 * 128 * 128 * 4 B = 1 GiB worst case;
-  // the exact figure for these arguments:
+  // the exact split-K scratch of the automatic choice for these arguments: phases * S * M * N floats
   const long M = (long)a.B * a.Hq * a.Wq;
   const int phases = a.conv_transpose ? 4 : 1;
   const int K = a.nth * a.ntw * (a.C0 + a.C1);
-  const int BN = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
-  const long mt = (M + 127) / 128, ntl = (a.N + BN - 1) / BN;
-  const long blocks = mt * ntl * phases;
-  if (blocks >= 512 || (a.N & 3) != 0) return 0;
-  long S = (512 + blocks - 1) / blocks;
-  if (S > 32) S = 32;
-  const long nk = (K + BK - 1) / BK;
-  if (S > nk / 2) S = nk / 2;
+  int BM, BN;
+  pick_tile(M, a.N, BM, BN);
+  const int S = splitk_for(M, a.N, K, phases, BM, BN);
   if (S <= 1) return 0;
   return (size_t)phases * S * M * a.N * sizeof(float);
 }
@@ -512,6 +527,10 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
 
   p.ws = static_cast<float*>(a.workspace);
   const size_t wsb = a.workspace != nullptr ? a.workspace_bytes : 0;
+  int BM, BN;
+  pick_tile(M, p.N, BM, BN);
+  if (BM == 32) return launch_cfg<32, 128, 1, 4, 2>(p, wsb, st);
+  if (BM == 64) return launch_cfg<64, 128, 2, 2, 2>(p, wsb, st);
   if (p.N > 64) return g_wide_stages == 1 ? launch_cfg<128, 128, 2, 2, 1>(p, wsb, st) : launch_cfg<128, 128, 2, 2, 2>(p, wsb, st);
   // narrow-N tiles: one LDS stage doubles the resident blocks; measured better for the transposed-conv phases and the
   // 32-wide tiles, worse for the short-K stride-2 conv (layer_bench.py, round 1)

@@ -468,13 +468,12 @@ __global__ __launch_bounds__(256) void bin_l1_kernel(const float* __restrict__ m
   if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
-// out[0] = scale * sum(part[0..n))   (ordered, single thread: n <= a few thousand)
+// out[0] = scale * sum(part[0..n))   (one wave, fixed lane-strided order + butterfly: deterministic)
 __global__ void sum_partials_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ out) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < n; ++i) s += part[i];
-    out[0] = s * scale;
-  }
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[0] = s * scale;
 }
 
 // sum of squares partials (grad-norm): part[blockIdx] = sum x^2 over the block's grid-stride share
@@ -489,9 +488,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 // clip_grad_norm_ coefficient (torch: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1): coef[0] = coefficient,
 // coef[1] = total_norm.  part holds nparts sums of squares.  max_norm <= 0 -> coef 1.
 __global__ void clip_coef_kernel(const float* __restrict__ part, int nparts, float max_norm, float* __restrict__ coef) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < nparts; ++i) s += part[i];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 64) s += part[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) {
     const float norm = sqrtf(s);
     float c = 1.f;
     if (max_norm > 0.f) c = fminf(max_norm / (norm + 1e-6f), 1.f);

@@ -168,7 +168,15 @@ class Conv2dNHWC(torch.autograd.Function):
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             if x2 is not None:
                 raise NotImplementedError("m2h Conv2dNHWC: input gradient of a two-source conv is not built yet")
-            gx = conv_dgrad(dy, w.detach().contiguous(), (x.shape[1], x.shape[2]), stride, pad)
+            if KH == x.shape[1] and KW == x.shape[2] and pad == 0 and Ho == 1 and Wo == 1:
+                # full-spatial conv (a Linear over the NCHW-flattened map, visual_cnn.py:140-141): dX = dY @ Wp as ONE GEMM.
+                # The generic phase formulation would walk KH*KW taps per input pixel with a single valid one (144x the work).
+                c_in = x.shape[3]
+                wp = ops.pack_conv_weight_ex(w.detach().contiguous(), Ci, c_in)          # [Co][(h,w,c)]
+                wt = pack_dgrad_weight(wp.view(Co, KH * KW * c_in, 1, 1), 1, 0).view(KH * KW * c_in, Co)
+                gx = ops.linear(dy.view(B, Co), wt, None, name="fc.dgrad").view(B, KH, KW, c_in)
+            else:
+                gx = conv_dgrad(dy, w.detach().contiguous(), (x.shape[1], x.shape[2]), stride, pad)
             if gx.shape[3] != x.shape[3]:  # channel-padded input (VisualCNN 3 -> 4): padded channels carry no gradient
                 gx = torch.nn.functional.pad(gx, (0, x.shape[3] - gx.shape[3]))
         return gx, gx2, gw, gb, None, None, None, None, None, None

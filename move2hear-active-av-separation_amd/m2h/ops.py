@@ -27,7 +27,7 @@ def timing_enabled():
 
 
 def igemm_config(N):
-    """Name of the igemm_f32_kernel instantiation conv_igemm.hip picks for N output channels."""
+    """Name of the igemm_f32_kernel width conv_igemm.hip picks for N output channels (skinny-M launches use 32/64-row tiles)."""
     return "igemm_f32<128,128>" if N > 64 else ("igemm_f32<128,64>" if N > 32 else "igemm_f32<128,32>")
 
 
