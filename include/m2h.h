@@ -104,6 +104,8 @@ typedef struct m2h_conv_args {
   int out_mode;
   void* workspace;        /* optional split-K scratch (device); NULL = never split */
   size_t workspace_bytes; /* size of workspace; m2h_conv_igemm_workspace_bytes() says how much the launch can use */
+  const float* head_w;    /* optional fused 1x1 head (N in {16,32}, M2H_OUT_DESLICE, workspace NULL): [N][N], applied after the */
+  const float* head_b;    /*   activation; out = head_w . act(...) + head_b, stored de-sliced.  NULL = no head.                */
 } m2h_conv_args;
 
 int m2h_conv_igemm_f32(const m2h_conv_args* args /* host */, m2h_stream stream);
@@ -136,6 +138,11 @@ int m2h_unet_down_fwd(const float* x, const float* wp, const float* scale, const
 int m2h_unet_up_fwd(const float* x, const float* skip, const float* wp, const float* scale, const float* shift,
                     float* y, int B, int H, int W, int C0, int C1, int Co, void* workspace, size_t workspace_bytes,
                     m2h_stream stream);
+/* K4+K5 fused: the last decoder stage (Co in {16,32}) followed by the 1x1 head, de-sliced straight into BHWC
+ * out [B][16*2H][2W][Co/16]: the stage's activation never leaves the chip (separator_cnn.py:133-134,163-168). */
+int m2h_unet_up_head_fwd(const float* x, const float* skip, const float* wp, const float* scale, const float* shift,
+                         const float* head_w, const float* head_b, float* out, int B, int H, int W, int C0, int C1, int Co,
+                         m2h_stream stream);
 /* split-K scratch the two ops above can use for these shapes (0 = none needed) */
 size_t m2h_unet_down_workspace_bytes(int B, int H, int W, int Ci, int Co);
 size_t m2h_unet_up_workspace_bytes(int B, int H, int W, int C0, int C1, int Co);

@@ -6,7 +6,7 @@ namespace m2h {
 thread_local char g_err[512] = {0};
 int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st);
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a);
-extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny;
+extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny, g_narrow16;
 }  // namespace m2h
 
 using namespace m2h;
@@ -31,6 +31,7 @@ int m2h_debug_set(int knob, int value) {
   else if (knob == 1) g_force_stages = value;
   else if (knob == 2) g_wide_stages = value;
   else if (knob == 3) g_skinny = value;
+  else if (knob == 4) g_narrow16 = value;
   else return fail(-1, "debug_set: unknown knob %d", knob);
   return 0;
 }
@@ -78,6 +79,16 @@ int m2h_unet_up_fwd(const float* x, const float* skip, const float* wp, const fl
                     int B, int H, int W, int C0, int C1, int Co, void* workspace, size_t workspace_bytes, m2h_stream stream) {
   m2h_conv_args a = up_args(x, skip, wp, scale, shift, y, B, H, W, C0, C1, Co);
   a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+  return conv_igemm_f32(a, as_stream(stream));
+}
+
+int m2h_unet_up_head_fwd(const float* x, const float* skip, const float* wp, const float* scale, const float* shift, const float* head_w,
+                         const float* head_b, float* out, int B, int H, int W, int C0, int C1, int Co, m2h_stream stream) {
+  M2H_REQUIRE(head_w != nullptr && head_b != nullptr, "unet_up_head: null head");
+  m2h_conv_args a = up_args(x, skip, wp, scale, shift, out, B, H, W, C0, C1, Co);
+  a.out_mode = M2H_OUT_DESLICE;
+  a.head_w = head_w;
+  a.head_b = head_b;
   return conv_igemm_f32(a, as_stream(stream));
 }
 
@@ -177,14 +188,16 @@ int m2h_unet_fwd(const m2h_unet_weights* wts, const float* mix, const float* mas
   }
   const int c0[5] = {512, 512, 256, 128, 64}, c1[5] = {0, 512, 256, 128, 64};
   const int dco[5] = {512, 256, 128, 64, wts->n_out};
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const float* skip = i == 0 ? nullptr : e[4 - i];
     rc = m2h_unet_up_fwd(cur, skip, wts->up_w[i], wts->up_scale[i], wts->up_shift[i], d[i], B, h, w, c0[i], c1[i], dco[i], sk, skb, stream);
     if (rc) return rc;
     cur = d[i];
     h *= 2; w *= 2;
   }
-  return m2h_unet_head_fwd(cur, wts->head_w, wts->head_b, out, B, h, w, wts->n_out, wts->n_out, stream);
+  // last stage + 1x1 head + de-slice in one kernel
+  return m2h_unet_up_head_fwd(cur, e[0], wts->up_w[4], wts->up_scale[4], wts->up_shift[4], wts->head_w, wts->head_b, out, B, h, w, c0[4],
+                              c1[4], dco[4], stream);
 }
 
 }  // extern "C"

@@ -21,6 +21,8 @@
 //
 // Block -> tile map: n-tiles of one m-tile are consecutive on one XCD (blocks b and b+8 share an XCD's
 // L2), so the gathered A panel is fetched from HBM once and re-read from L2 by its sibling n-tiles.
+#include <type_traits>
+
 #include "m2h_internal.h"
 
 namespace m2h {
@@ -48,6 +50,8 @@ struct IGemmP {
   float* dst;
   int Ho, Wo, os, ph, pw, ldc, out_mode;
   int M, MT, NT;
+  const float* head_w;  // fused 1x1 head (N <= 32, one n-tile): [N][N] weights applied to the activated tile, + head_b, de-sliced store
+  const float* head_b;
   int S;       // split-K factor (grid y); S > 1: raw partial sums go to `ws`, the epilogue runs in splitk_epilogue_kernel
   float* ws;   // [phase][S][M][N] fp32 partial slabs (caller-owned workspace)
 };
@@ -71,16 +75,23 @@ __device__ __forceinline__ void decode_row(const IGemmP& p, int m, int ph, int p
   bc = b * 16 + ch * 3 + cw;
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+// FR = MFMA fragment edge: 32 (v_mfma_f32_32x32x2_f32, 8 k per 16-byte LDS read) or 16 (v_mfma_f32_16x16x4_f32, 16 k per read;
+// used for N <= 16 so that a 16-channel layer does not pay for a half-empty 32-wide tile).  Same FLOP rate per cycle.
+template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32>
 __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
-  constexpr int FM = TM / 32, FN = TN / 32;  // 32x32 MFMA fragments per wave
-  constexpr int AR = BM / 32, BR = BN / 32;  // staged rows per thread (256 threads = 32 rows x 8 segments)
-  static_assert(FM >= 1 && FN >= 1, "wave tile must hold at least one 32x32 fragment");
+  constexpr int FM = TM / FR, FN = TN / FR;  // MFMA fragments per wave
+  constexpr int BNS = BN < 32 ? 32 : BN;     // staged weight rows (256 threads = 32 rows x 8 segments)
+  constexpr int AR = BM / 32, BR = BNS / 32; // staged rows per thread
+  constexpr int GK = FR == 32 ? 8 : 16;      // k covered by one fragment group (one 16-byte read per lane)
+  constexpr int NG = BK / GK;                // fragment groups per k-tile
+  constexpr int NE = FR == 32 ? 16 : 4;      // accumulator elements per lane
+  using AccT = typename std::conditional<FR == 32, f32x16, f32x4>::type;
+  static_assert(FM >= 1 && FN >= 1, "wave tile must hold at least one fragment");
 
   __shared__ __attribute__((aligned(16))) float As[NSTAGE][BM * LDK];
-  __shared__ __attribute__((aligned(16))) float Bs[NSTAGE][BN * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[NSTAGE][BNS * LDK];
   __shared__ int ri_qh[BM], ri_rw[BM], ri_bpix[BM], ri_out[BM], ri_bc[BM];
 
   const int tid = threadIdx.x;
@@ -140,13 +151,15 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
     a_bpix[i] = ri_bpix[srow + 32 * i];
   }
 
-  f32x16 acc[FM][FN];
+  AccT acc[FM][FN];
 #pragma unroll
   for (int mi = 0; mi < FM; ++mi)
 #pragma unroll
     for (int ni = 0; ni < FN; ++ni)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+      for (int e = 0; e < NE; ++e) acc[mi][ni][e] = 0.f;
+  // accumulator element e of this lane -> fragment row (C/D layout of the two MFMA shapes); column = lane & (FR-1)
+  auto row_of = [&](int e) { return FR == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : (lane >> 4) * 4 + e; };
 
   f32x4 ra[AR], rb[BR];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -225,17 +238,17 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
       *reinterpret_cast<f32x4*>(&Bs[buf][(srow + 32 * j) * LDK + seg * 4]) = (okmask & (1u << (8 + j))) ? rb[j] : zero4;
   };
 
-  const int frow = lane & 31;        // fragment row (A: pixel, B: channel)
-  const int fk = (lane >> 5) * 4;    // k offset of this lane half inside an 8-deep group
+  const int frow = lane & (FR - 1);  // fragment row (A: pixel, B: channel)
+  const int fk = (lane / FR) * 4;    // k offset of this lane group inside a GK-deep fragment group
 
   f32x4 fa[2][FM], fb[2][FN];  // fragment double buffer: group g+1 is read from LDS while group g's MFMAs run
   auto read_frags = [&](int buf, int g, int slot) {
 #pragma unroll
     for (int mi = 0; mi < FM; ++mi)
-      fa[slot][mi] = *reinterpret_cast<const f32x4*>(&As[buf][(wm * TM + mi * 32 + frow) * LDK + g * 8 + fk]);
+      fa[slot][mi] = *reinterpret_cast<const f32x4*>(&As[buf][(wm * TM + mi * FR + frow) * LDK + g * GK + fk]);
 #pragma unroll
     for (int ni = 0; ni < FN; ++ni)
-      fb[slot][ni] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wn * TN + ni * 32 + frow) * LDK + g * 8 + fk]);
+      fb[slot][ni] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wn * TN + ni * FR + frow) * LDK + g * GK + fk]);
   };
   auto mfma_group = [&](int slot) {
 #pragma unroll
@@ -244,7 +257,10 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
       for (int mi = 0; mi < FM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < FN; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][mi][j], fb[slot][ni][j], acc[mi][ni], 0, 0, 0);
+          if constexpr (FR == 32)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][mi][j], fb[slot][ni][j], acc[mi][ni], 0, 0, 0);
+          else
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[slot][mi][j], fb[slot][ni][j], acc[mi][ni], 0, 0, 0);
   };
 
   // one k-tile with prefetch: the next tile's global loads are spread over the four 8-deep MFMA groups of the current tile.
@@ -254,20 +270,20 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
     tile_setup();
     read_frags(buf, 0, 0);
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      if (g + 1 < BK / 8) read_frags(buf, g + 1, (g + 1) & 1);
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) read_frags(buf, g + 1, (g + 1) & 1);
 #pragma unroll
-      for (int i = g; i < AR; i += BK / 8) load_a(i);
+      for (int i = g; i < AR; i += NG) load_a(i);
 #pragma unroll
-      for (int j = g; j < BR; j += BK / 8) load_b(j);
+      for (int j = g; j < BR; j += NG) load_b(j);
       mfma_group(g & 1);
     }
   };
   auto tile_body_last = [&](int buf) {
     read_frags(buf, 0, 0);
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      if (g + 1 < BK / 8) read_frags(buf, g + 1, (g + 1) & 1);
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) read_frags(buf, g + 1, (g + 1) & 1);
       mfma_group(g & 1);
     }
   };
@@ -307,17 +323,16 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
   if (p.S > 1) {
     // split-K: raw partial sums to the slab [phase][split][M][N]; BN/activation/store happen in the reduce kernel
     float* slab = p.ws + ((size_t)(phase * p.S + split) * p.M) * p.N;
-    const int col = lane & 31;
-    const int rhalf = (lane >> 5) * 4;
+    const int col = lane & (FR - 1);
 #pragma unroll
     for (int mi = 0; mi < FM; ++mi)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * TM + mi * 32 + (e & 3) + 8 * (e >> 2) + rhalf;
+      for (int e = 0; e < NE; ++e) {
+        const int m = m0 + wm * TM + mi * FR + row_of(e);
         if (m >= p.M) continue;
 #pragma unroll
         for (int ni = 0; ni < FN; ++ni) {
-          const int n = n0 + wn * TN + ni * 32 + col;
+          const int n = n0 + wn * TN + ni * FR + col;
           if (n < p.N) slab[(size_t)m * p.N + n] = acc[mi][ni][e];
         }
       }
@@ -325,13 +340,93 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
   }
 
   // ---- fused epilogue ----
-  const int col = lane & 31;
-  const int rhalf = (lane >> 5) * 4;
+  const int col = lane & (FR - 1);
+  if constexpr (BN <= 32 && WM == 4) {
+    if (p.head_w != nullptr) {
+      // Last decoder stage + head in one kernel (separator_cnn.py:133-134,163-168): y = ReLU(BN(convT)) stays on chip, a second
+      // small MFMA pass applies the 1x1 conv, the result is transposed through LDS and stored de-sliced with one contiguous
+      // (s, pixel-run) segment per wave instruction instead of 4-byte scatters.
+      constexpr int LDT = 129;       // [n'][m] staging stride: conflict-free column writes
+      constexpr int NGH = FR / GK;   // fragment groups of the FR-deep head contraction
+      float* Y = &As[0][0];
+      float* Wh = &Bs[0][0];
+      __syncthreads();  // every wave is done with the main loop's LDS tiles
+      {
+        const int n = col;
+        const float scn = (p.scale != nullptr && n < p.N) ? p.scale[n] : 1.f;
+        const float shn = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const int lrow = wm * TM + mi * FR + row_of(e);
+            float v = 0.f;
+            if (n < p.N) {
+              v = acc[mi][0][e] * scn + shn;
+              v = v > 0.f ? v : v * p.slope;
+            }
+            Y[lrow * LDK + n] = v;
+          }
+        for (int idx = tid; idx < FR * FR; idx += 256) {  // FR x FR head matrix, zero padded
+          const int n2 = idx / FR, k = idx % FR;
+          Wh[n2 * LDK + k] = (n2 < p.N && k < p.N) ? p.head_w[n2 * p.N + k] : 0.f;
+        }
+      }
+      __syncthreads();
+      AccT acc2[FM];
+#pragma unroll
+      for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) acc2[mi][e] = 0.f;
+#pragma unroll
+      for (int g = 0; g < NGH; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&Wh[frow * LDK + g * GK + fk]);
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(&Y[(wm * TM + mi * FR + frow) * LDK + g * GK + fk]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if constexpr (FR == 32)
+              acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc2[mi], 0, 0, 0);
+            else
+              acc2[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc2[mi], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();  // Y fully consumed before it is overwritten by the transposed staging
+      float* Tt = Y;
+      const float hb = col < p.N ? p.head_b[col] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) Tt[col * LDT + wm * TM + mi * FR + row_of(e)] = acc2[mi][e] + hb;
+      __syncthreads();
+      const size_t plane2 = (size_t)p.Ho * p.Wo;
+      const int Cc2 = p.N >> 4;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int i = tid + 256 * it;
+        const int s = i >> 7, m = i & 127;
+        const int out = ri_out[m];
+        if (out < 0) continue;
+        float* dptr = p.dst + ((size_t)out + (size_t)s * plane2) * Cc2;
+        if (Cc2 == 2) {
+          float2 v2;
+          v2.x = Tt[s * LDT + m];
+          v2.y = Tt[(16 + s) * LDT + m];
+          *reinterpret_cast<float2*>(dptr) = v2;
+        } else {
+          dptr[0] = Tt[s * LDT + m];
+        }
+      }
+      return;
+    }
+  }
   float sc[FN], sh[FN];
   int nn[FN];
 #pragma unroll
   for (int ni = 0; ni < FN; ++ni) {
-    const int n = n0 + wn * TN + ni * 32 + col;
+    const int n = n0 + wn * TN + ni * FR + col;
     nn[ni] = n;
     sc[ni] = (p.scale != nullptr && n < p.N) ? p.scale[n] : 1.f;
     sh[ni] = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
@@ -341,8 +436,8 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
 #pragma unroll
   for (int mi = 0; mi < FM; ++mi) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int lrow = wm * TM + mi * 32 + (e & 3) + 8 * (e >> 2) + rhalf;
+    for (int e = 0; e < NE; ++e) {
+      const int lrow = wm * TM + mi * FR + row_of(e);
       const int out = ri_out[lrow];
       if (out < 0) continue;
       const int bc = ri_bc[lrow];
@@ -416,11 +511,12 @@ int g_force_splitk = 0;   // >0: force this split-K factor (when workspace allow
 int g_force_stages = 0;   // 1 | 2: force the LDS stage count of the narrow-N configs
 int g_wide_stages = 0;    // 1 | 2: LDS stage count of the 128x128 config (0 = 2)
 int g_skinny = 0;         // -1: never use the 32/64-row tiles
+int g_narrow16 = 0;       // -1: never use the 16-wide (v_mfma_f32_16x16x4_f32) tile for N <= 16
 
 // Tile choice: N picks the width; skinny M (rollout batches, GRU steps: weight-streaming bound, nothing to re-use along M)
 // gets 32- or 64-row tiles so that four times as many blocks stream the weights.
 static void pick_tile(long M, int N, int& BM, int& BN) {
-  BN = N > 64 ? 128 : (N > 32 ? 64 : 32);
+  BN = N > 64 ? 128 : (N > 32 ? 64 : (N > 16 ? 32 : 16));
   BM = 128;
   if (BN == 128 && g_skinny >= 0) {
     if (M <= 32) BM = 32;
@@ -456,7 +552,7 @@ static int choose_splitk(const IGemmP& p, int BM, int BN, size_t ws_bytes) {
   return S < 1 ? 1 : S;
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32>
 static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   p.MT = (p.M + BM - 1) / BM;
   p.NT = (p.N + BN - 1) / BN;
@@ -466,7 +562,7 @@ static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   if (nblk > 0x7fffffffL) return fail(-1, "conv_igemm: grid too large (%ld blocks)", nblk);
   const int phases = p.convT ? 4 : 1;
   dim3 grid((unsigned)nblk, (unsigned)p.S, phases);
-  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE>), grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR>), grid, dim3(256), 0, st, p);
   int rc = launch_status("conv_igemm_f32");
   if (rc != 0 || p.S == 1) return rc;
   const long total = (long)p.M * (p.N >> 2);
@@ -521,6 +617,11 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   p.mulh = a.mulh; p.offh = a.offh; p.mulw = a.mulw; p.offw = a.offw; p.convT = a.conv_transpose ? 1 : 0;
   p.w = a.wp; p.N = a.N; p.K = p.ntap * p.Ctot;
   p.scale = a.scale; p.shift = a.shift; p.slope = a.slope; p.cls_table = a.cls_table; p.cls_val = a.cls_val;
+  p.head_w = a.head_w; p.head_b = a.head_b;
+  if (a.head_w != nullptr) {
+    M2H_REQUIRE(a.head_b != nullptr && (a.N == 32 || a.N == 16) && a.out_mode == M2H_OUT_DESLICE && a.workspace == nullptr && a.cls_table == nullptr,
+                "conv_igemm: fused head needs N in {16,32}, de-sliced output, no split-K workspace, no class plane");
+  }
   p.dst = a.dst; p.Ho = a.Ho; p.Wo = a.Wo; p.os = a.os; p.ph = a.ph; p.pw = a.pw; p.ldc = a.ldc; p.out_mode = a.out_mode;
   p.M = (int)M;
   M2H_REQUIRE(p.K % 4 == 0, "conv_igemm: K must be a multiple of 4");
@@ -539,6 +640,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
     return one_stage ? launch_cfg<128, 64, 2, 2, 1>(p, wsb, st) : launch_cfg<128, 64, 2, 2, 2>(p, wsb, st);
   }
   const bool one_stage = g_force_stages != 2;
+  if (p.N <= 16 && g_narrow16 >= 0) return launch_cfg<128, 16, 4, 1, 1, 16>(p, wsb, st);  // 16-wide MFMA: no half-empty tile
   return one_stage ? launch_cfg<128, 32, 4, 1, 1>(p, wsb, st) : launch_cfg<128, 32, 4, 1, 2>(p, wsb, st);
 }
 

@@ -66,6 +66,7 @@ class ConvArgs(ctypes.Structure):
         ("os", ctypes.c_int), ("ph", ctypes.c_int), ("pw", ctypes.c_int),
         ("ldc", ctypes.c_int), ("out_mode", ctypes.c_int),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+        ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p),
     ]
 
 
@@ -100,6 +101,7 @@ SIGNATURES = {
     "m2h_unet_up_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P],
     "m2h_unet_down_workspace_bytes": [_I, _I, _I, _I, _I],
     "m2h_unet_up_workspace_bytes": [_I, _I, _I, _I, _I, _I],
+    "m2h_unet_up_head_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "m2h_unet_head_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "m2h_pack_conv_weight_ex": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "m2h_slice_concat_input": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P],

@@ -28,7 +28,7 @@ def timing_enabled():
 
 def igemm_config(N):
     """Name of the igemm_f32_kernel width conv_igemm.hip picks for N output channels (skinny-M launches use 32/64-row tiles)."""
-    return "igemm_f32<128,128>" if N > 64 else ("igemm_f32<128,64>" if N > 32 else "igemm_f32<128,32>")
+    return "igemm_f32<128,128>" if N > 64 else ("igemm_f32<128,64>" if N > 32 else ("igemm_f32<128,32>" if N > 16 else "igemm_f32<128,16>"))
 
 
 def _timed(name, meta, dev, fn):
@@ -540,3 +540,23 @@ def unet_up_fwd_raw(x, skip, wp, Co):
         meta = {"kernel": igemm_config(Co), "M": 4 * M, "N": Co, "K": 4 * (C0 + C1), "flops": 2.0 * 4 * M * Co * 4 * (C0 + C1)}
         _timed("unet_up_fwd_raw", meta, x.device, lambda: _lib.check(lib.m2h_conv_igemm_f32(ctypes.byref(a), _stream(x)), "m2h_conv_igemm_f32"))
     return y
+
+
+def unet_up_head_fwd(x, skip, wp, scale, shift, head_w, head_b, Co):
+    """K4+K5 fused: last decoder stage + 1x1 head + de-slice -> BHWC [B, 16*2H, 2W, Co/16]."""
+    for t in (x, skip, wp, scale, shift, head_w, head_b):
+        _chk(t, "unet_up_head_fwd")
+    B, H, W, C0 = x.shape
+    C1 = skip.shape[3] if skip is not None else 0
+    if wp.numel() != 16 * Co * (C0 + C1) or head_w.numel() != Co * Co or head_b.numel() != Co or Co not in (16, 32):
+        raise RuntimeError("m2h.unet_up_head_fwd: bad weight sizes")
+    out = torch.empty((B, 32 * H, 2 * W, Co // 16), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        M = B * H * W
+        meta = {"kernel": igemm_config(Co), "M": 4 * M, "N": Co, "K": 4 * (C0 + C1), "flops": 2.0 * 4 * M * Co * (4 * (C0 + C1) + Co),
+                "bytes": 4.0 * (x.numel() + (skip.numel() if skip is not None else 0) + out.numel() + wp.numel())}
+        _timed("unet_up_head_fwd", meta, x.device,
+               lambda: _lib.check(lib.m2h_unet_up_head_fwd(_ptr(x), _ptr(skip), _ptr(wp), _ptr(scale), _ptr(shift), _ptr(head_w), _ptr(head_b),
+                                                           _ptr(out), B, H, W, C0, C1, Co, _stream(x)), "m2h_unet_up_head_fwd"))
+    return out

@@ -233,10 +233,12 @@ class PassiveSepDecCNN(nn.Module):
         wb = lst_skip_feats[0].size(3) // 2
         out = _as_nhwc(bottleneck_feats.reshape(B, -1, 1, wb))
         ups, (hw, hb, hco) = self._packed()
-        for idx, (wp, scale, shift, co) in enumerate(ups):
+        for idx, (wp, scale, shift, co) in enumerate(ups[:4]):
             skip = None if idx == 0 else _as_nhwc(lst_skip_feats[idx - 1])
             out = ops.unet_up_fwd(out, skip, wp, scale, shift, co)
-        return ops.unet_head_fwd(out, hw, hb, hco)  # BHWC, contiguous
+        wp, scale, shift, co = ups[4]
+        # last stage + biased 1x1 conv + de-slice fused in one kernel -> BHWC, contiguous
+        return ops.unet_up_head_fwd(out, _as_nhwc(lst_skip_feats[3]), wp, scale, shift, hw, hb, hco)
 
 
 def unet_forward(enc, dec, mix, masks=None, target_class=None):
