@@ -52,9 +52,17 @@ struct IGemmP {
   int M, MT, NT;
   const float* head_w;  // fused 1x1 head (N <= 32, one n-tile): [N][N] weights applied to the activated tile, + head_b, de-sliced store
   const float* head_b;
+  int stagger;  // tuning: blocks of odd 256-block generations sleep this many x64 cycles before the k-loop
+  int pmaj;    // transposed conv: phase is folded into grid x (fastest) instead of grid z
   int S;       // split-K factor (grid y); S > 1: raw partial sums go to `ws`, the epilogue runs in splitk_epilogue_kernel
   float* ws;   // [phase][S][M][N] fp32 partial slabs (caller-owned workspace)
 };
+
+#ifdef M2H_CLOCK_DIAG
+// Diagnostic build only (tools/clock_diag.py): shader-clock vs 100 MHz real-time stamps around the k-loop of each block, to read
+// the clock the chip holds under this kernel (MI355X_MICROARCH.md, DVFS give-back item 6).  Never compiled into libm2h.so.
+__device__ unsigned long long g_clock_dbg[8192][6];
+#endif
 
 constexpr int BK = 32;   // k-tile depth (floats)
 constexpr int LDK = 36;  // padded LDS row (floats): 144 B, keeps 16-B alignment, conflict-free b128 reads
@@ -77,9 +85,17 @@ __device__ __forceinline__ void decode_row(const IGemmP& p, int m, int ph, int p
 
 // FR = MFMA fragment edge: 32 (v_mfma_f32_32x32x2_f32, 8 k per 16-byte LDS read) or 16 (v_mfma_f32_16x16x4_f32, 16 k per read;
 // used for N <= 16 so that a 16-channel layer does not pay for a half-empty 32-wide tile).  Same FLOP rate per cycle.
-template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32>
-__global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
-  static_assert(WM * WN == 4, "4 waves per block");
+//
+// PP = 1 ("ping-pong", 512 threads): two 4-wave groups share the block's output tile and split its k-tiles (even / odd).  Each
+// SIMD then hosts one wave of each group and the block's barriers keep the groups in ANTI-PHASE: while group 0 runs the 64
+// MFMAs of its tile (and issues the global loads of its next one), group 1 writes its next tile to its own LDS buffer, and vice
+// versa -- the matrix pipe always has exactly one wave feeding it.  (Two independent co-resident blocks leave it ~25 % idle:
+// the older wave wins every arbitration and the younger one starves; measured with in-kernel stamps, tools/clock_diag.py.)
+// The two partial accumulators are summed through LDS once, after the k-loop.
+template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32, int PP = 0>
+__global__ __launch_bounds__(PP ? 512 : 256) void igemm_f32_kernel(const IGemmP p) {
+  static_assert(WM * WN == 4, "4 waves per block (per group)");
+  static_assert(!PP || (NSTAGE == 2 && FR == 32), "ping-pong uses the two LDS stages as the two groups' buffers");
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
   constexpr int FM = TM / FR, FN = TN / FR;  // MFMA fragments per wave
   constexpr int BNS = BN < 32 ? 32 : BN;     // staged weight rows (256 threads = 32 rows x 8 segments)
@@ -87,6 +103,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
   constexpr int GK = FR == 32 ? 8 : 16;      // k covered by one fragment group (one 16-byte read per lane)
   constexpr int NG = BK / GK;                // fragment groups per k-tile
   constexpr int NE = FR == 32 ? 16 : 4;      // accumulator elements per lane
+  constexpr int LOADG = 1;                   // fragment groups over which the next tile's global loads are issued
   using AccT = typename std::conditional<FR == 32, f32x16, f32x4>::type;
   static_assert(FM >= 1 && FN >= 1, "wave tile must hold at least one fragment");
 
@@ -94,7 +111,8 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
   __shared__ __attribute__((aligned(16))) float Bs[NSTAGE][BNS * LDK];
   __shared__ int ri_qh[BM], ri_rw[BM], ri_bpix[BM], ri_out[BM], ri_bc[BM];
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 255;  // thread index inside its 4-wave group
+  const int grp = threadIdx.x >> 8;   // 0 (always) or 1 (second ping-pong group)
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -104,7 +122,18 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
   // ---- block -> (m-tile, n-tile): siblings (same m-tile) run back to back on one XCD ----
   const int L = blockIdx.x;
   const int xcd = L & 7;
-  const int idx = L >> 3;
+  int idx = L >> 3;
+  // transposed conv: the four sub-pixel phases of one m-tile read the same 3x3 input neighbourhood; with pmaj they are
+  // consecutive blocks of one XCD (input tile served by that XCD's L2) instead of four passes over the whole input
+  int phase = 0;
+  if (p.convT) {
+    if (p.pmaj) {
+      phase = idx & 3;
+      idx >>= 2;
+    } else {
+      phase = blockIdx.z;
+    }
+  }
   const int mt = (idx / p.NT) * 8 + xcd;
   const int nt = idx - (idx / p.NT) * p.NT;
   if (mt >= p.MT) return;  // whole block leaves before any barrier
@@ -113,7 +142,6 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
 
   int mulh = p.mulh, offh = p.offh, mulw = p.mulw, offw = p.offw, ph = p.ph, pw = p.pw;
   const float* wbase = p.w;
-  const int phase = p.convT ? blockIdx.z : 0;
   if (p.convT) {
     ph = phase >> 1;
     pw = phase & 1;
@@ -125,7 +153,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
   }
 
   // ---- per-row (output pixel) bookkeeping, once per block ----
-  for (int r = tid; r < BM; r += 256) {
+  for (int r = threadIdx.x; r < BM; r += (PP ? 512 : 256)) {
     const int m = m0 + r;
     int qh = -(1 << 24), rw = -(1 << 24), bpix = 0, out = -1, bc = 0;
     if (m < p.M) {
@@ -272,10 +300,12 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (g + 1 < NG) read_frags(buf, g + 1, (g + 1) & 1);
+      // all of the next tile's loads go out in the first half of the MFMA phase: an HBM/L2 round trip (1-2 us) then hides under
+      // the remaining MFMAs instead of being waited for at the LDS-write step
 #pragma unroll
-      for (int i = g; i < AR; i += NG) load_a(i);
+      for (int i = g; i < AR; i += LOADG) if (g < LOADG) load_a(i);
 #pragma unroll
-      for (int j = g; j < BR; j += NG) load_b(j);
+      for (int j = g; j < BR; j += LOADG) if (g < LOADG) load_b(j);
       mfma_group(g & 1);
     }
   };
@@ -292,32 +322,147 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
   const int split = blockIdx.y;
   const int kt0 = (int)(((long)nk_all * split) / p.S);
   const int kt1 = (int)(((long)nk_all * (split + 1)) / p.S);
-  seek_tile(kt0);
-  tile_setup();
+  if (p.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+    // de-phase the two co-resident blocks of a CU (they otherwise hit their barriers together)
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  }
+  if constexpr (PP) {
+    // ---------------- ping-pong schedule ----------------
+    const int ntl = kt1 - kt0;
+    const int my_n = (ntl + 1 - grp) / 2;  // this group's tiles: kt0 + grp, kt0 + grp + 2, ...
+    const int iters = (ntl + 1) / 2;
+    auto body_prefetch2 = [&](int buf) {   // as tile_body_prefetch, but the group's next tile is two k-tiles ahead
+      next_tile();
+      next_tile();
+      tile_setup();
+      read_frags(buf, 0, 0);
 #pragma unroll
-  for (int i = 0; i < AR; ++i) load_a(i);
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) read_frags(buf, g + 1, (g + 1) & 1);
 #pragma unroll
-  for (int j = 0; j < BR; ++j) load_b(j);
-  store_tile(0);
-  __syncthreads();
-  if constexpr (NSTAGE == 2) {
-    int cur = 0;
-    for (int kt = kt0; kt + 1 < kt1; ++kt) {
-      tile_body_prefetch(cur);  // global loads fly under the MFMAs of this tile
-      store_tile(cur ^ 1);
-      __syncthreads();
-      cur ^= 1;
+        for (int i = g; i < AR; i += NG) load_a(i);
+#pragma unroll
+        for (int j = g; j < BR; j += NG) load_b(j);
+        mfma_group(g & 1);
+      }
+    };
+    seek_tile(kt0 + grp);
+    tile_setup();
+    if (my_n > 0) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) load_a(i);
+#pragma unroll
+      for (int j = 0; j < BR; ++j) load_b(j);
+      store_tile(grp);
     }
-    tile_body_last(cur);
+    __syncthreads();
+#ifdef M2H_CLOCK_DIAG
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int i = 0; i < iters; ++i) {
+      // phase A: group 0 computes its tile i; group 1 writes the tile it fetched during the previous phase B
+      if (grp == 0) {
+        if (i + 1 < my_n) body_prefetch2(0); else tile_body_last(0);
+      } else if (i > 0 && i < my_n) {
+        store_tile(1);
+      }
+      __syncthreads();
+      // phase B: roles swapped
+      if (grp == 1) {
+        if (i < my_n) {
+          if (i + 1 < my_n) body_prefetch2(1); else tile_body_last(1);
+        }
+      } else if (i + 1 < my_n) {
+        store_tile(0);
+      }
+      __syncthreads();
+    }
+#ifdef M2H_CLOCK_DIAG
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
+      const unsigned bi = blockIdx.x + gridDim.x * blockIdx.z;
+      if (bi < 8192) {
+        g_clock_dbg[bi][0] = __builtin_amdgcn_s_memtime() - dbg_t0;
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        g_clock_dbg[bi][1] = r1 - dbg_r0;
+        g_clock_dbg[bi][2] = dbg_r0;
+        g_clock_dbg[bi][3] = r1;
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_clock_dbg[bi][4] = hwid;
+        g_clock_dbg[bi][5] = xcc;
+      }
+    }
+#endif
+    // ---------------- sum the two groups' accumulators through LDS (all tiles are consumed: buffers are free) ----------------
+    {
+      float* R0 = &As[0][0];  // fragments (0,0),(0,1): 4 waves x 2 x 16 x 64 floats = 32 KiB  (As holds 36 KiB)
+      float* R1 = &Bs[0][0];  // fragments (1,0),(1,1)
+      if (grp == 1) {
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < FN; ++ni)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) (mi == 0 ? R0 : R1)[((wave * FN + ni) * NE + e) * 64 + lane] = acc[mi][ni][e];
+      }
+      __syncthreads();
+      if (grp == 1) return;
+#pragma unroll
+      for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < FN; ++ni)
+#pragma unroll
+          for (int e = 0; e < NE; ++e) acc[mi][ni][e] += (mi == 0 ? R0 : R1)[((wave * FN + ni) * NE + e) * 64 + lane];
+    }
   } else {
-    // single LDS stage: half the LDS, twice the resident blocks; other blocks' MFMAs cover the two barriers
-    for (int kt = kt0; kt + 1 < kt1; ++kt) {
-      tile_body_prefetch(0);
-      __syncthreads();
-      store_tile(0);
-      __syncthreads();
+    seek_tile(kt0);
+    tile_setup();
+#pragma unroll
+    for (int i = 0; i < AR; ++i) load_a(i);
+#pragma unroll
+    for (int j = 0; j < BR; ++j) load_b(j);
+    store_tile(0);
+    __syncthreads();
+#ifdef M2H_CLOCK_DIAG
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if constexpr (NSTAGE == 2) {
+      int cur = 0;
+      for (int kt = kt0; kt + 1 < kt1; ++kt) {
+        tile_body_prefetch(cur);  // global loads fly under the MFMAs of this tile
+        store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+      }
+      tile_body_last(cur);
+    } else {
+      // single LDS stage: half the LDS, twice the resident blocks; other blocks' MFMAs cover the two barriers
+      for (int kt = kt0; kt + 1 < kt1; ++kt) {
+        tile_body_prefetch(0);
+        __syncthreads();
+        store_tile(0);
+        __syncthreads();
+      }
+      tile_body_last(0);
     }
-    tile_body_last(0);
+#ifdef M2H_CLOCK_DIAG
+    if (tid == 0 && blockIdx.y == 0) {
+      const unsigned bi = blockIdx.x + gridDim.x * blockIdx.z;
+      if (bi < 8192) {
+        g_clock_dbg[bi][0] = __builtin_amdgcn_s_memtime() - dbg_t0;
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        g_clock_dbg[bi][1] = r1 - dbg_r0;
+        g_clock_dbg[bi][2] = dbg_r0;
+        g_clock_dbg[bi][3] = r1;
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_clock_dbg[bi][4] = hwid;
+        g_clock_dbg[bi][5] = xcc;
+      }
+    }
+#endif
   }
 
   if (p.S > 1) {
@@ -511,6 +656,10 @@ int g_force_splitk = 0;   // >0: force this split-K factor (when workspace allow
 int g_force_stages = 0;   // 1 | 2: force the LDS stage count of the narrow-N configs
 int g_wide_stages = 0;    // 1 | 2: LDS stage count of the 128x128 config (0 = 2)
 int g_skinny = 0;         // -1: never use the 32/64-row tiles
+int g_stagger = 0;        // tuning experiment: see IGemmP::stagger
+int g_extra_lds = 0;      // tuning experiment: dynamic LDS bytes added to every launch (lowers blocks/CU)
+int g_pingpong = 0;       // 1: 512-thread ping-pong schedule for the 128x128 tile (measured slower than two independent blocks)
+int g_phase_major = 0;    // -1: transposed-conv phases as grid z (four passes over the input) instead of interleaved
 int g_narrow16 = 0;       // -1: never use the 16-wide (v_mfma_f32_16x16x4_f32) tile for N <= 16
 
 // Tile choice: N picks the width; skinny M (rollout batches, GRU steps: weight-streaming bound, nothing to re-use along M)
@@ -552,7 +701,7 @@ static int choose_splitk(const IGemmP& p, int BM, int BN, size_t ws_bytes) {
   return S < 1 ? 1 : S;
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32, int PP = 0>
 static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   p.MT = (p.M + BM - 1) / BM;
   p.NT = (p.N + BN - 1) / BN;
@@ -561,8 +710,9 @@ static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   const long nblk = mtpad * p.NT;
   if (nblk > 0x7fffffffL) return fail(-1, "conv_igemm: grid too large (%ld blocks)", nblk);
   const int phases = p.convT ? 4 : 1;
-  dim3 grid((unsigned)nblk, (unsigned)p.S, phases);
-  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR>), grid, dim3(256), 0, st, p);
+  p.pmaj = (p.convT && g_phase_major >= 0 && nblk * 4 <= 0x7fffffffL) ? 1 : 0;
+  dim3 grid((unsigned)(p.pmaj ? nblk * 4 : nblk), (unsigned)p.S, p.pmaj ? 1 : phases);
+  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, PP>), grid, dim3(PP ? 512 : 256), (size_t)g_extra_lds, st, p);
   int rc = launch_status("conv_igemm_f32");
   if (rc != 0 || p.S == 1) return rc;
   const long total = (long)p.M * (p.N >> 2);
@@ -571,6 +721,12 @@ static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g, phases), dim3(256), 0, st, p);
   return launch_status("conv_igemm_f32 split-K epilogue");
 }
+
+#ifdef M2H_CLOCK_DIAG
+extern "C" int m2h_diag_read_clocks(unsigned long long* host_out, int nblocks) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock_dbg), (size_t)nblocks * 6 * sizeof(unsigned long long));
+}
+#endif
 
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a) {
   // the exact split-K scratch of the automatic choice for these arguments: phases * S * M * N floats
@@ -618,6 +774,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   p.w = a.wp; p.N = a.N; p.K = p.ntap * p.Ctot;
   p.scale = a.scale; p.shift = a.shift; p.slope = a.slope; p.cls_table = a.cls_table; p.cls_val = a.cls_val;
   p.head_w = a.head_w; p.head_b = a.head_b;
+  p.stagger = g_stagger;
   if (a.head_w != nullptr) {
     M2H_REQUIRE(a.head_b != nullptr && (a.N == 32 || a.N == 16) && a.out_mode == M2H_OUT_DESLICE && a.workspace == nullptr && a.cls_table == nullptr,
                 "conv_igemm: fused head needs N in {16,32}, de-sliced output, no split-K workspace, no class plane");
@@ -632,7 +789,10 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   pick_tile(M, p.N, BM, BN);
   if (BM == 32) return launch_cfg<32, 128, 1, 4, 2>(p, wsb, st);
   if (BM == 64) return launch_cfg<64, 128, 2, 2, 2>(p, wsb, st);
-  if (p.N > 64) return g_wide_stages == 1 ? launch_cfg<128, 128, 2, 2, 1>(p, wsb, st) : launch_cfg<128, 128, 2, 2, 2>(p, wsb, st);
+  if (p.N > 64) {
+    if (g_pingpong > 0 && g_wide_stages == 0) return launch_cfg<128, 128, 2, 2, 2, 32, 1>(p, wsb, st);  // ping-pong groups (slower: kept as an experiment)
+    return g_wide_stages == 1 ? launch_cfg<128, 128, 2, 2, 1>(p, wsb, st) : launch_cfg<128, 128, 2, 2, 2>(p, wsb, st);
+  }
   // narrow-N tiles: one LDS stage doubles the resident blocks; measured better for the transposed-conv phases and the
   // 32-wide tiles, worse for the short-K stride-2 conv (layer_bench.py, round 1)
   if (p.N > 32) {
