@@ -25,6 +25,10 @@
 
 #include "m2h_internal.h"
 
+#ifndef M2H_SCHED
+#define M2H_SCHED 0  // instruction-interleave experiment selector for the k-loop (0 = compiler default)
+#endif
+
 namespace m2h {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -52,7 +56,7 @@ struct IGemmP {
   int M, MT, NT;
   const float* head_w;  // fused 1x1 head (N <= 32, one n-tile): [N][N] weights applied to the activated tile, + head_b, de-sliced store
   const float* head_b;
-  int stagger;  // tuning: blocks of odd 256-block generations sleep this many x64 cycles before the k-loop
+  int fast_ok; // scalar-decode loader applicable (host check)
   int pmaj;    // transposed conv: phase is folded into grid x (fastest) instead of grid z
   int S;       // split-K factor (grid y); S > 1: raw partial sums go to `ws`, the epilogue runs in splitk_epilogue_kernel
   float* ws;   // [phase][S][M][N] fp32 partial slabs (caller-owned workspace)
@@ -86,16 +90,13 @@ __device__ __forceinline__ void decode_row(const IGemmP& p, int m, int ph, int p
 // FR = MFMA fragment edge: 32 (v_mfma_f32_32x32x2_f32, 8 k per 16-byte LDS read) or 16 (v_mfma_f32_16x16x4_f32, 16 k per read;
 // used for N <= 16 so that a 16-channel layer does not pay for a half-empty 32-wide tile).  Same FLOP rate per cycle.
 //
-// PP = 1 ("ping-pong", 512 threads): two 4-wave groups share the block's output tile and split its k-tiles (even / odd).  Each
-// SIMD then hosts one wave of each group and the block's barriers keep the groups in ANTI-PHASE: while group 0 runs the 64
-// MFMAs of its tile (and issues the global loads of its next one), group 1 writes its next tile to its own LDS buffer, and vice
-// versa -- the matrix pipe always has exactly one wave feeding it.  (Two independent co-resident blocks leave it ~25 % idle:
-// the older wave wins every arbitration and the younger one starves; measured with in-kernel stamps, tools/clock_diag.py.)
-// The two partial accumulators are summed through LDS once, after the k-loop.
-template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32, int PP = 0>
-__global__ __launch_bounds__(PP ? 512 : 256) void igemm_f32_kernel(const IGemmP p) {
-  static_assert(WM * WN == 4, "4 waves per block (per group)");
-  static_assert(!PP || (NSTAGE == 2 && FR == 32), "ping-pong uses the two LDS stages as the two groups' buffers");
+// FAST = 1 (both sources' channel counts multiples of the 32-deep k-tile, operands < 4 GiB): every k-tile lies inside one
+// (tap, source) segment, so the whole k decode is SCALAR (SGPR) work and a load's address is `uniform base + per-lane 32-bit
+// offset` with the per-lane part recomputed only when the segment changes (every C/32 tiles).  The generic path decodes k per
+// lane (any C % 4 == 0) and costs ~250 vector instructions per k-tile, which made the k-loop issue-bound beside 64 MFMAs.
+template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32, int FAST = 0>
+__global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
+  static_assert(WM * WN == 4, "4 waves per block");
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
   constexpr int FM = TM / FR, FN = TN / FR;  // MFMA fragments per wave
   constexpr int BNS = BN < 32 ? 32 : BN;     // staged weight rows (256 threads = 32 rows x 8 segments)
@@ -103,7 +104,6 @@ __global__ __launch_bounds__(PP ? 512 : 256) void igemm_f32_kernel(const IGemmP 
   constexpr int GK = FR == 32 ? 8 : 16;      // k covered by one fragment group (one 16-byte read per lane)
   constexpr int NG = BK / GK;                // fragment groups per k-tile
   constexpr int NE = FR == 32 ? 16 : 4;      // accumulator elements per lane
-  constexpr int LOADG = 1;                   // fragment groups over which the next tile's global loads are issued
   using AccT = typename std::conditional<FR == 32, f32x16, f32x4>::type;
   static_assert(FM >= 1 && FN >= 1, "wave tile must hold at least one fragment");
 
@@ -111,8 +111,7 @@ __global__ __launch_bounds__(PP ? 512 : 256) void igemm_f32_kernel(const IGemmP 
   __shared__ __attribute__((aligned(16))) float Bs[NSTAGE][BNS * LDK];
   __shared__ int ri_qh[BM], ri_rw[BM], ri_bpix[BM], ri_out[BM], ri_bc[BM];
 
-  const int tid = threadIdx.x & 255;  // thread index inside its 4-wave group
-  const int grp = threadIdx.x >> 8;   // 0 (always) or 1 (second ping-pong group)
+  const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(PP ? 512 : 256) void igemm_f32_kernel(const IGemmP 
   }
 
   // ---- per-row (output pixel) bookkeeping, once per block ----
-  for (int r = threadIdx.x; r < BM; r += (PP ? 512 : 256)) {
+  for (int r = threadIdx.x; r < BM; r += 256) {
     const int m = m0 + r;
     int qh = -(1 << 24), rw = -(1 << 24), bpix = 0, out = -1, bc = 0;
     if (m < p.M) {
@@ -189,12 +188,30 @@ __global__ __launch_bounds__(PP ? 512 : 256) void igemm_f32_kernel(const IGemmP 
   // accumulator element e of this lane -> fragment row (C/D layout of the two MFMA shapes); column = lane & (FR-1)
   auto row_of = [&](int e) { return FR == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : (lane >> 4) * 4 + e; };
 
-  f32x4 ra[AR], rb[BR];
+  // Two register sets for the staged tile: the loads of k-tile t+2 are issued at the top of tile t's MFMA phase and are not
+  // consumed (LDS write) until the end of tile t+1, so a loaded-chip HBM/L2 round trip (several microseconds) has a whole
+  // tile of MFMAs (>= 4096 cycles on the 128x128 tile) to land instead of the tail of the current one.
+  f32x4 ra[2][AR], rb[2][BR];
+  unsigned okmask[2] = {0u, 0u};
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  // ---- per-thread k decode state for the tile being loaded: k = kt*BK + seg*4 -> (th, tw, ci); advanced incrementally ----
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int split = blockIdx.y;
+  const int kt0 = (int)(((long)nk_all * split) / p.S);
+  const int kt1 = (int)(((long)nk_all * (split + 1)) / p.S);
+  const int k_end = min(p.K, kt1 * BK);  // loads past this block's k-range are masked (they re-read element 0: a cache hit)
+
+  // ---- loader state for the tile being loaded (advanced incrementally, one k-tile at a time) ----
+  // generic: per-lane k = kt*BK + seg*4 -> (th, tw, ci)
   int ld_k, ld_th, ld_tw, ld_ci;
-  auto seek_tile = [&](int kt) {
+  bool t_kok;
+  int t_dh, t_dw, t_Cs, t_c;
+  const float* t_src;
+  // FAST: uniform tile index / tap / channel offset; per-lane byte offsets of the staged rows inside the current segment
+  int u_kt, u_th, u_tw, u_ci;
+  unsigned voffA[AR], voffB[BR], okA = 0;
+
+  auto seek_generic = [&](int kt) {
     ld_k = kt * BK + seg * 4;
     int tap = 0;
     ld_ci = ld_k;
@@ -205,65 +222,120 @@ __global__ __launch_bounds__(PP ? 512 : 256) void igemm_f32_kernel(const IGemmP 
     ld_th = (unsigned)tap / (unsigned)p.ntw;
     ld_tw = tap - ld_th * p.ntw;
   };
-  auto next_tile = [&]() {
-    if (p.Ctot >= BK) {  // at most one wrap per 32-deep step (wave-uniform branch)
-      ld_k += BK;
-      ld_ci += BK;
-      if (ld_ci >= p.Ctot) {
-        ld_ci -= p.Ctot;
-        if (++ld_tw == p.ntw) {
-          ld_tw = 0;
-          ++ld_th;
+  // FAST: per-lane row offsets for the current (tap, source) segment
+  auto segment_rows = [&]() {
+    const int dh = u_th * mulh, dw = u_tw * mulw;
+    const int Cs = (u_ci >= p.C0 && p.src1 != nullptr) ? p.C1 : p.C0;
+    okA = 0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int ih = a_qh[i] + dh, iw = a_rw[i] + dw;
+      const bool ok = (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+      voffA[i] = ok ? ((unsigned)(a_bpix[i] + ih * p.Wi + iw) * (unsigned)Cs + (unsigned)(seg * 4)) * 4u : 0u;
+      okA |= ok ? (1u << i) : 0u;
+    }
+  };
+  auto loader_seek = [&](int kt) {
+    if constexpr (FAST) {
+      u_kt = kt;
+      const int k0 = kt * BK;
+      const int tap = p.ntap > 1 ? k0 / p.Ctot : 0;
+      u_ci = k0 - tap * p.Ctot;
+      u_th = tap / p.ntw;
+      u_tw = tap - u_th * p.ntw;
+      segment_rows();
+#pragma unroll
+      for (int j = 0; j < BR; ++j)  // rows past N re-read row N-1 (their products are never stored): no mask on the weight side
+        voffB[j] = ((unsigned)min(n0 + srow + 32 * j, p.N - 1) * (unsigned)p.K + (unsigned)(seg * 4)) * 4u;
+    } else {
+      seek_generic(kt);
+    }
+  };
+  auto loader_next = [&]() {
+    if constexpr (FAST) {
+      if (u_kt + 1 < kt1) {  // past this block's k-range the loader stays on the last tile (a harmless cached re-read)
+        ++u_kt;
+        u_ci += BK;
+        bool reseg = u_ci == p.C0 && p.src1 != nullptr;
+        if (u_ci == p.Ctot) {
+          u_ci = 0;
+          reseg = true;
+          if (++u_tw == p.ntw) {
+            u_tw = 0;
+            ++u_th;
+          }
         }
+        if (reseg) segment_rows();  // wave-uniform branch
       }
     } else {
-      seek_tile(ld_k / BK + 1);
+      if (p.Ctot >= BK) {  // at most one wrap per 32-deep step; selects, not branches (the wrap differs per lane)
+        ld_k += BK;
+        ld_ci += BK;
+        const bool wrap = ld_ci >= p.Ctot;
+        ld_ci -= wrap ? p.Ctot : 0;
+        ld_tw += wrap ? 1 : 0;
+        const bool wrap2 = ld_tw == p.ntw;
+        ld_tw = wrap2 ? 0 : ld_tw;
+        ld_th += wrap2 ? 1 : 0;
+      } else {
+        seek_generic(ld_k / BK + 1);
+      }
     }
   };
-  // per-tile values shared by the row loads
-  bool t_kok;
-  int t_dh, t_dw, t_Cs, t_c;
-  const float* t_src;
-  auto tile_setup = [&]() {
-    t_kok = ld_k < p.K;
-    t_dh = ld_th * mulh;
-    t_dw = ld_tw * mulw;
-    t_src = p.src0;
-    t_Cs = p.C0;
-    t_c = ld_ci;
-    if (ld_ci >= p.C0 && p.src1 != nullptr) {  // second source; beyond-K padding tiles of a single-source conv keep src0
-      t_src = p.src1;
-      t_Cs = p.C1;
-      t_c = ld_ci - p.C0;
-    }
-  };
-  // Loads are unconditional (clamped to element 0 of the source when masked) and zeroed by a select afterwards: no
+  // Generic loads are unconditional (clamped to element 0 of the source when masked) and zeroed by a select afterwards: no
   // divergent branches in the k-loop, so the loads can be scheduled into the MFMA shadows.
   // The loaded value is NOT touched until store_tile (a select right after the load would force a vmcnt(0) wait there);
   // the validity bits travel in a mask.
-  unsigned okmask = 0;
-  auto load_a = [&](int i) {
+  auto load_a = [&](int set, int i) {
     const int ih = a_qh[i] + t_dh, iw = a_rw[i] + t_dw;
     const bool ok = t_kok && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
     const unsigned off = ok ? (unsigned)(a_bpix[i] + ih * p.Wi + iw) * (unsigned)t_Cs + (unsigned)t_c : 0u;
-    ra[i] = *reinterpret_cast<const f32x4*>(t_src + off);
-    okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
+    ra[set][i] = *reinterpret_cast<const f32x4*>(t_src + off);
+    okmask[set] = ok ? (okmask[set] | (1u << i)) : (okmask[set] & ~(1u << i));
   };
-  auto load_b = [&](int j) {
+  auto load_b = [&](int set, int j) {
     const int n = n0 + srow + 32 * j;
     const bool ok = t_kok && n < p.N;
     const unsigned off = ok ? (unsigned)n * (unsigned)p.K + (unsigned)ld_k : 0u;
-    rb[j] = *reinterpret_cast<const f32x4*>(wbase + off);
-    okmask = ok ? (okmask | (1u << (8 + j))) : (okmask & ~(1u << (8 + j)));
+    rb[set][j] = *reinterpret_cast<const f32x4*>(wbase + off);
+    okmask[set] = ok ? (okmask[set] | (1u << (8 + j))) : (okmask[set] & ~(1u << (8 + j)));
   };
-
-  auto store_tile = [&](int buf) {
+  auto load_tile = [&](int set) {
+    if constexpr (FAST) {
+      const bool second = u_ci >= p.C0 && p.src1 != nullptr;
+      const char* baseA = reinterpret_cast<const char*>(second ? p.src1 + (u_ci - p.C0) : p.src0 + u_ci);  // uniform
+      const char* baseB = reinterpret_cast<const char*>(wbase + (size_t)u_kt * BK);                          // uniform
+#pragma unroll
+      for (int i = 0; i < AR; ++i) ra[set][i] = *reinterpret_cast<const f32x4*>(baseA + voffA[i]);
+#pragma unroll
+      for (int j = 0; j < BR; ++j) rb[set][j] = *reinterpret_cast<const f32x4*>(baseB + voffB[j]);
+      okmask[set] = okA;
+    } else {
+      t_kok = ld_k < k_end;
+      t_dh = ld_th * mulh;
+      t_dw = ld_tw * mulw;
+      t_src = p.src0;
+      t_Cs = p.C0;
+      t_c = ld_ci;
+      if (ld_ci >= p.C0 && p.src1 != nullptr) {  // second source; beyond-K padding tiles of a single-source conv keep src0
+        t_src = p.src1;
+        t_Cs = p.C1;
+        t_c = ld_ci - p.C0;
+      }
+#pragma unroll
+      for (int i = 0; i < AR; ++i) load_a(set, i);
+#pragma unroll
+      for (int j = 0; j < BR; ++j) load_b(set, j);
+    }
+  };
+  auto store_tile = [&](int set, int buf) {
 #pragma unroll
     for (int i = 0; i < AR; ++i)
-      *reinterpret_cast<f32x4*>(&As[buf][(srow + 32 * i) * LDK + seg * 4]) = (okmask & (1u << i)) ? ra[i] : zero4;
+      *reinterpret_cast<f32x4*>(&As[buf][(srow + 32 * i) * LDK + seg * 4]) = (okmask[set] & (1u << i)) ? ra[set][i] : zero4;
 #pragma unroll
     for (int j = 0; j < BR; ++j)
-      *reinterpret_cast<f32x4*>(&Bs[buf][(srow + 32 * j) * LDK + seg * 4]) = (okmask & (1u << (8 + j))) ? rb[j] : zero4;
+      *reinterpret_cast<f32x4*>(&Bs[buf][(srow + 32 * j) * LDK + seg * 4]) =
+          (FAST || (okmask[set] & (1u << (8 + j)))) ? rb[set][j] : zero4;
   };
 
   const int frow = lane & (FR - 1);  // fragment row (A: pixel, B: channel)
@@ -290,26 +362,7 @@ __global__ __launch_bounds__(PP ? 512 : 256) void igemm_f32_kernel(const IGemmP 
           else
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[slot][mi][j], fb[slot][ni][j], acc[mi][ni], 0, 0, 0);
   };
-
-  // one k-tile with prefetch: the next tile's global loads are spread over the four 8-deep MFMA groups of the current tile.
-  // Straight-line (no conditionals): the last tile of the range is peeled off below.
-  auto tile_body_prefetch = [&](int buf) {
-    next_tile();
-    tile_setup();
-    read_frags(buf, 0, 0);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      if (g + 1 < NG) read_frags(buf, g + 1, (g + 1) & 1);
-      // all of the next tile's loads go out in the first half of the MFMA phase: an HBM/L2 round trip (1-2 us) then hides under
-      // the remaining MFMAs instead of being waited for at the LDS-write step
-#pragma unroll
-      for (int i = g; i < AR; i += LOADG) if (g < LOADG) load_a(i);
-#pragma unroll
-      for (int j = g; j < BR; j += LOADG) if (g < LOADG) load_b(j);
-      mfma_group(g & 1);
-    }
-  };
-  auto tile_body_last = [&](int buf) {
+  auto mfma_tile = [&](int buf) {
     read_frags(buf, 0, 0);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -317,153 +370,61 @@ __global__ __launch_bounds__(PP ? 512 : 256) void igemm_f32_kernel(const IGemmP 
       mfma_group(g & 1);
     }
   };
+  // One k-tile t (straight-line, no conditionals): issue the loads of tile t+2 into register set `par`, run tile t's MFMAs
+  // from LDS stage `rd`, then write tile t+1 (register set par^1, loaded during tile t-1) to stage `wr`.
+  auto tile_step = [&](int par, int rd, int wr) {
+    loader_next();
+    load_tile(par);
+    mfma_tile(rd);
+    if constexpr (NSTAGE == 1) __syncthreads();  // single stage: everyone is done reading before it is overwritten
+    store_tile(par ^ 1, wr);
+    __syncthreads();
+  };
 
-  const int nk_all = (p.K + BK - 1) / BK;
-  const int split = blockIdx.y;
-  const int kt0 = (int)(((long)nk_all * split) / p.S);
-  const int kt1 = (int)(((long)nk_all * (split + 1)) / p.S);
-  if (p.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
-    // de-phase the two co-resident blocks of a CU (they otherwise hit their barriers together)
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  // prologue: tile 0 -> LDS stage 0; tile 1 in flight in register set 1
+  loader_seek(kt0);
+  load_tile(0);
+  store_tile(0, 0);
+  if (kt1 - kt0 > 1) {
+    loader_next();
+    load_tile(1);
   }
-  if constexpr (PP) {
-    // ---------------- ping-pong schedule ----------------
-    const int ntl = kt1 - kt0;
-    const int my_n = (ntl + 1 - grp) / 2;  // this group's tiles: kt0 + grp, kt0 + grp + 2, ...
-    const int iters = (ntl + 1) / 2;
-    auto body_prefetch2 = [&](int buf) {   // as tile_body_prefetch, but the group's next tile is two k-tiles ahead
-      next_tile();
-      next_tile();
-      tile_setup();
-      read_frags(buf, 0, 0);
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) read_frags(buf, g + 1, (g + 1) & 1);
-#pragma unroll
-        for (int i = g; i < AR; i += NG) load_a(i);
-#pragma unroll
-        for (int j = g; j < BR; j += NG) load_b(j);
-        mfma_group(g & 1);
-      }
-    };
-    seek_tile(kt0 + grp);
-    tile_setup();
-    if (my_n > 0) {
-#pragma unroll
-      for (int i = 0; i < AR; ++i) load_a(i);
-#pragma unroll
-      for (int j = 0; j < BR; ++j) load_b(j);
-      store_tile(grp);
-    }
-    __syncthreads();
+  __syncthreads();
 #ifdef M2H_CLOCK_DIAG
-    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (int i = 0; i < iters; ++i) {
-      // phase A: group 0 computes its tile i; group 1 writes the tile it fetched during the previous phase B
-      if (grp == 0) {
-        if (i + 1 < my_n) body_prefetch2(0); else tile_body_last(0);
-      } else if (i > 0 && i < my_n) {
-        store_tile(1);
-      }
-      __syncthreads();
-      // phase B: roles swapped
-      if (grp == 1) {
-        if (i < my_n) {
-          if (i + 1 < my_n) body_prefetch2(1); else tile_body_last(1);
-        }
-      } else if (i + 1 < my_n) {
-        store_tile(0);
-      }
-      __syncthreads();
+  {
+    // all but the last tile; unrolled by two so that register sets and LDS stages are compile-time
+    const int nfull = kt1 - kt0 - 1;
+    int t = 0;
+    for (; t + 1 < nfull; t += 2) {
+      tile_step(0, 0, NSTAGE == 2 ? 1 : 0);
+      tile_step(1, NSTAGE == 2 ? 1 : 0, 0);
     }
-#ifdef M2H_CLOCK_DIAG
-    if (threadIdx.x == 0 && blockIdx.y == 0) {
-      const unsigned bi = blockIdx.x + gridDim.x * blockIdx.z;
-      if (bi < 8192) {
-        g_clock_dbg[bi][0] = __builtin_amdgcn_s_memtime() - dbg_t0;
-        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-        g_clock_dbg[bi][1] = r1 - dbg_r0;
-        g_clock_dbg[bi][2] = dbg_r0;
-        g_clock_dbg[bi][3] = r1;
-        unsigned hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_clock_dbg[bi][4] = hwid;
-        g_clock_dbg[bi][5] = xcc;
-      }
-    }
-#endif
-    // ---------------- sum the two groups' accumulators through LDS (all tiles are consumed: buffers are free) ----------------
-    {
-      float* R0 = &As[0][0];  // fragments (0,0),(0,1): 4 waves x 2 x 16 x 64 floats = 32 KiB  (As holds 36 KiB)
-      float* R1 = &Bs[0][0];  // fragments (1,0),(1,1)
-      if (grp == 1) {
-#pragma unroll
-        for (int mi = 0; mi < FM; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < FN; ++ni)
-#pragma unroll
-            for (int e = 0; e < NE; ++e) (mi == 0 ? R0 : R1)[((wave * FN + ni) * NE + e) * 64 + lane] = acc[mi][ni][e];
-      }
-      __syncthreads();
-      if (grp == 1) return;
-#pragma unroll
-      for (int mi = 0; mi < FM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < FN; ++ni)
-#pragma unroll
-          for (int e = 0; e < NE; ++e) acc[mi][ni][e] += (mi == 0 ? R0 : R1)[((wave * FN + ni) * NE + e) * 64 + lane];
-    }
-  } else {
-    seek_tile(kt0);
-    tile_setup();
-#pragma unroll
-    for (int i = 0; i < AR; ++i) load_a(i);
-#pragma unroll
-    for (int j = 0; j < BR; ++j) load_b(j);
-    store_tile(0);
-    __syncthreads();
-#ifdef M2H_CLOCK_DIAG
-    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    if constexpr (NSTAGE == 2) {
-      int cur = 0;
-      for (int kt = kt0; kt + 1 < kt1; ++kt) {
-        tile_body_prefetch(cur);  // global loads fly under the MFMAs of this tile
-        store_tile(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-      }
-      tile_body_last(cur);
+    if (t < nfull) {
+      tile_step(0, 0, NSTAGE == 2 ? 1 : 0);
+      mfma_tile(NSTAGE == 2 ? 1 : 0);
     } else {
-      // single LDS stage: half the LDS, twice the resident blocks; other blocks' MFMAs cover the two barriers
-      for (int kt = kt0; kt + 1 < kt1; ++kt) {
-        tile_body_prefetch(0);
-        __syncthreads();
-        store_tile(0);
-        __syncthreads();
-      }
-      tile_body_last(0);
+      mfma_tile(0);
     }
-#ifdef M2H_CLOCK_DIAG
-    if (tid == 0 && blockIdx.y == 0) {
-      const unsigned bi = blockIdx.x + gridDim.x * blockIdx.z;
-      if (bi < 8192) {
-        g_clock_dbg[bi][0] = __builtin_amdgcn_s_memtime() - dbg_t0;
-        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-        g_clock_dbg[bi][1] = r1 - dbg_r0;
-        g_clock_dbg[bi][2] = dbg_r0;
-        g_clock_dbg[bi][3] = r1;
-        unsigned hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_clock_dbg[bi][4] = hwid;
-        g_clock_dbg[bi][5] = xcc;
-      }
-    }
-#endif
   }
+#ifdef M2H_CLOCK_DIAG
+  if (tid == 0 && blockIdx.y == 0) {
+    const unsigned bi = blockIdx.x + gridDim.x * blockIdx.z;
+    if (bi < 8192) {
+      g_clock_dbg[bi][0] = __builtin_amdgcn_s_memtime() - dbg_t0;
+      const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+      g_clock_dbg[bi][1] = r1 - dbg_r0;
+      g_clock_dbg[bi][2] = dbg_r0;
+      g_clock_dbg[bi][3] = r1;
+      unsigned hwid, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_clock_dbg[bi][4] = hwid;
+      g_clock_dbg[bi][5] = xcc;
+    }
+  }
+#endif
 
   if (p.S > 1) {
     // split-K: raw partial sums to the slab [phase][split][M][N]; BN/activation/store happen in the reduce kernel
@@ -656,10 +617,9 @@ int g_force_splitk = 0;   // >0: force this split-K factor (when workspace allow
 int g_force_stages = 0;   // 1 | 2: force the LDS stage count of the narrow-N configs
 int g_wide_stages = 0;    // 1 | 2: LDS stage count of the 128x128 config (0 = 2)
 int g_skinny = 0;         // -1: never use the 32/64-row tiles
-int g_stagger = 0;        // tuning experiment: see IGemmP::stagger
 int g_extra_lds = 0;      // tuning experiment: dynamic LDS bytes added to every launch (lowers blocks/CU)
-int g_pingpong = 0;       // 1: 512-thread ping-pong schedule for the 128x128 tile (measured slower than two independent blocks)
 int g_phase_major = 0;    // -1: transposed-conv phases as grid z (four passes over the input) instead of interleaved
+int g_fast_loader = 0;    // -1: always use the generic (per-lane k decode) loader
 int g_narrow16 = 0;       // -1: never use the 16-wide (v_mfma_f32_16x16x4_f32) tile for N <= 16
 
 // Tile choice: N picks the width; skinny M (rollout batches, GRU steps: weight-streaming bound, nothing to re-use along M)
@@ -701,8 +661,9 @@ static int choose_splitk(const IGemmP& p, int BM, int BN, size_t ws_bytes) {
   return S < 1 ? 1 : S;
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32, int PP = 0>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32>
 static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
+  const bool fast = g_fast_loader >= 0 && p.fast_ok;
   p.MT = (p.M + BM - 1) / BM;
   p.NT = (p.N + BN - 1) / BN;
   p.S = choose_splitk(p, BM, BN, ws_bytes);
@@ -712,7 +673,10 @@ static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   const int phases = p.convT ? 4 : 1;
   p.pmaj = (p.convT && g_phase_major >= 0 && nblk * 4 <= 0x7fffffffL) ? 1 : 0;
   dim3 grid((unsigned)(p.pmaj ? nblk * 4 : nblk), (unsigned)p.S, p.pmaj ? 1 : phases);
-  hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, PP>), grid, dim3(PP ? 512 : 256), (size_t)g_extra_lds, st, p);
+  if (fast)
+    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1>), grid, dim3(256), (size_t)g_extra_lds, st, p);
+  else
+    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 0>), grid, dim3(256), (size_t)g_extra_lds, st, p);
   int rc = launch_status("conv_igemm_f32");
   if (rc != 0 || p.S == 1) return rc;
   const long total = (long)p.M * (p.N >> 2);
@@ -774,13 +738,18 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   p.w = a.wp; p.N = a.N; p.K = p.ntap * p.Ctot;
   p.scale = a.scale; p.shift = a.shift; p.slope = a.slope; p.cls_table = a.cls_table; p.cls_val = a.cls_val;
   p.head_w = a.head_w; p.head_b = a.head_b;
-  p.stagger = g_stagger;
   if (a.head_w != nullptr) {
     M2H_REQUIRE(a.head_b != nullptr && (a.N == 32 || a.N == 16) && a.out_mode == M2H_OUT_DESLICE && a.workspace == nullptr && a.cls_table == nullptr,
                 "conv_igemm: fused head needs N in {16,32}, de-sliced output, no split-K workspace, no class plane");
   }
   p.dst = a.dst; p.Ho = a.Ho; p.Wo = a.Wo; p.os = a.os; p.ph = a.ph; p.pw = a.pw; p.ldc = a.ldc; p.out_mode = a.out_mode;
   p.M = (int)M;
+  {
+    const size_t pix = (size_t)a.B * a.Hi * a.Wi;
+    const size_t lim = (size_t)1 << 32;
+    p.fast_ok = (a.C0 % BK == 0 && a.C1 % BK == 0 && a.C0 > 0 && pix * a.C0 * 4 < lim && pix * (size_t)a.C1 * 4 < lim &&
+                 (size_t)a.N * p.K * 4 < lim) ? 1 : 0;
+  }
   M2H_REQUIRE(p.K % 4 == 0, "conv_igemm: K must be a multiple of 4");
 
   p.ws = static_cast<float*>(a.workspace);
@@ -790,13 +759,12 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   if (BM == 32) return launch_cfg<32, 128, 1, 4, 2>(p, wsb, st);
   if (BM == 64) return launch_cfg<64, 128, 2, 2, 2>(p, wsb, st);
   if (p.N > 64) {
-    if (g_pingpong > 0 && g_wide_stages == 0) return launch_cfg<128, 128, 2, 2, 2, 32, 1>(p, wsb, st);  // ping-pong groups (slower: kept as an experiment)
     return g_wide_stages == 1 ? launch_cfg<128, 128, 2, 2, 1>(p, wsb, st) : launch_cfg<128, 128, 2, 2, 2>(p, wsb, st);
   }
-  // narrow-N tiles: one LDS stage doubles the resident blocks; measured better for the transposed-conv phases and the
-  // 32-wide tiles, worse for the short-K stride-2 conv (layer_bench.py, round 1)
+  // narrow-N tiles: one LDS stage doubles the resident blocks; measured better on every 64- and 32-wide layer once the loader
+  // became scalar (layer_bench.py: down0 345 vs 382 us, up3 588 vs 618 us)
   if (p.N > 32) {
-    const bool one_stage = g_force_stages ? (g_force_stages == 1) : (p.convT != 0);
+    const bool one_stage = g_force_stages != 2;
     return one_stage ? launch_cfg<128, 64, 2, 2, 1>(p, wsb, st) : launch_cfg<128, 64, 2, 2, 2>(p, wsb, st);
   }
   const bool one_stage = g_force_stages != 2;

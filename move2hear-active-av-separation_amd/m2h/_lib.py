@@ -14,7 +14,8 @@ _PKG_ROOT = os.path.dirname(_HERE)
 _REPO_ROOT = os.path.dirname(_PKG_ROOT)
 CSRC = os.path.join(_PKG_ROOT, "csrc")
 INCLUDE = os.path.join(_REPO_ROOT, "include")
-LIB_PATH = os.path.join(_HERE, "libm2h.so")
+# M2H_LIB: kernel-tuning override -- load an experimental build of the same C-ABI (tools/build_variant.sh) instead of the in-tree one
+LIB_PATH = os.environ.get("M2H_LIB") or os.path.join(_HERE, "libm2h.so")
 SOURCES = ["conv_igemm.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "api.hip"]
 
 _lock = threading.Lock()
