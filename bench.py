@@ -219,9 +219,18 @@ def main():
         tot_fl = sum(v["flops"] for v in igemm.values())
         dom = max(igemm.items(), key=lambda kv: kv[1]["ms"])
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        # HBM traffic of the dominant instantiation: PMC counters cannot be read from inside this process, so the per-launch
+        # figure of the committed rocprofv3 --pmc passes over this same command is reported (null when the file is absent)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic, traffic_src = tj.get("traffic_bytes_per_launch"), tj.get("source")
         roofline = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch of the dominant instantiation (2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
             "kernel": "m2h::igemm_f32_kernel (all instantiations; MFMA f32 32x32x2 implicit-GEMM conv)",
             "launches_per_step": sum(v["launches"] for v in igemm.values()) // args.steps,
             "kernel_ms_per_step": round(tot_ms / args.steps, 4),
