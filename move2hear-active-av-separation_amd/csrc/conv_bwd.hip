@@ -6,8 +6,8 @@
 //           convolutions of dY with the (ci <-> co)-transposed, tap-strided weights; m2h_pack_dgrad_weight lays those out.
 //   act_bwd dY * (y > 0 ? 1 : slope)  for the fused ReLU / LeakyReLU epilogues;  bias_grad = column sums of dY.
 //
-// wgrad tiling: block = BNG (n) x 128 (k) output tile, 4 waves, fp32 v_mfma_f32_32x32x2; the reduction runs over 32-pixel
-// chunks staged [m][n] / [m][k] in LDS (double buffered through registers); fragments are ds_read_b32 column reads
+// wgrad tiling: block = BNG (n) x 128*KT (k) output tile, 4 waves, fp32 v_mfma_f32_32x32x2; the reduction runs over 32-pixel
+// chunks staged [m][n] / [m][k] in LDS (prefetched through registers); fragments are ds_read_b32 column reads
 // (consecutive lanes -> consecutive addresses, conflict free).  The pixel range is split over grid.z; partial tiles go to a
 // slab [split][N][Kpad] and an ordered reduce kernel sums them (deterministic, no atomics).
 #include "m2h_internal.h"
@@ -31,52 +31,81 @@ struct WGradP {
   int M;
   int S;            // splits over m (grid z)
   int chunks;       // ceil(M / 32)
+  int ntiles, ktiles;  // output tiles along n and k
   float* ws;        // [S][N][Kpad]
   float* dw;        // [N][K]
 };
 
-constexpr int WK = 128;  // k tile
+constexpr int WK = 128;  // k sub-tile (one 16-byte segment per thread of a 32-thread row group)
 constexpr int WM = 32;   // pixels per reduction chunk
 
-template <int BNG>
+// BNG = n extent of the block (32 | 128); KT = number of 128-wide k sub-tiles of the block (k extent 128*KT).
+// Narrow layers (N <= 32) would give a wave ONE 32x32 fragment per chunk (16 MFMAs beside ~300 other instructions: the first
+// version ran issue-bound at 30 % matrix-pipe utilisation); with KT = 2 or 3 a wave owns KT fragments that share one dY
+// operand, the input rows are fetched once per chunk instead of once per k-tile, and the row bookkeeping is amortised.
+// NST = LDS stages (2: one barrier per chunk; 1: two barriers, for the wide-k blocks whose tile would not fit twice).
+template <int BNG, int KT, int NST>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
+  constexpr int WKB = WK * KT;                    // k extent of the block
   constexpr int WN_ = (BNG == 128) ? 2 : 1;       // waves along n
   constexpr int WK_ = 4 / WN_;                    // waves along k
-  constexpr int TN = BNG / WN_, TK = WK / WK_;    // wave tile: 64x64 (BNG 128) or 32x32 (BNG 32)
+  constexpr int TN = BNG / WN_, TK = WKB / WK_;   // wave tile
   constexpr int FN = TN / 32, FK = TK / 32;
   constexpr int YSEG = BNG / 4;                   // 16-byte segments per dY row
   constexpr int YR = (WM * YSEG + 255) / 256;     // dY segments per thread
-  __shared__ __attribute__((aligned(16))) float Ys[2][WM * BNG];
-  __shared__ __attribute__((aligned(16))) float As[2][WM * WK];
+  constexpr int YSTEP = 256 / YSEG;
+  static_assert(TK % 32 == 0 && FK >= 1, "wave k extent must be whole fragments");
+  __shared__ __attribute__((aligned(16))) float Ys[NST][WM * BNG];
+  __shared__ __attribute__((aligned(16))) float As[NST][WM * WKB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WK_, wk = wave % WK_;
-  const int n0 = blockIdx.x * BNG;
-  const int k0 = blockIdx.y * WK;
-  const int split = blockIdx.z;
+  // 1-D grid, XCD-aware: the (n-tile, k-tile) blocks of one pixel split are consecutive blocks of ONE XCD (L % 8), so the
+  // split's input rows and dY rows meet in that XCD's L2
+  const int L = blockIdx.x;
+  const int tiles = p.ntiles * p.ktiles;
+  int tile, split;
+  if (p.S >= 8) {
+    const int idx = L >> 3;
+    tile = idx % tiles;
+    split = (idx / tiles) * 8 + (L & 7);
+    if (split >= p.S) return;  // padding blocks of the XCD map (whole block, before any barrier)
+  } else {  // few splits (short M): plain order, tiles spread over all XCDs
+    tile = L % tiles;
+    split = L / tiles;
+  }
+  const int n0 = (tile / p.ktiles) * BNG;
+  const int k0 = (tile % p.ktiles) * WKB;
   const int c0 = (int)(((long)p.chunks * split) / p.S), c1 = (int)(((long)p.chunks * (split + 1)) / p.S);
 
-  // this thread's fixed A column: decode (tap, channel) once
-  const int aseg = tid & 31;        // 32 segments of 4 floats = 128 k
-  const int arow = tid >> 5;        // 0..7, rows arow + 8*i
-  const int k = k0 + aseg * 4;
-  const bool kok = k < p.K;
-  int tap = 0, ci = k;
-  if (p.ntap > 1) {
-    tap = (unsigned)k / (unsigned)p.Ctot;
-    ci = k - tap * p.Ctot;
+  // this thread's fixed A columns (one per k sub-tile): decode (tap, channel) once
+  const int aseg = tid & 31;  // 32 segments of 4 floats = 128 k
+  const int arow = tid >> 5;  // 0..7, rows arow + 8*i
+  bool kok[KT];
+  int dh[KT], dw[KT], Cs[KT], cc[KT];
+  const float* src[KT];
+#pragma unroll
+  for (int c = 0; c < KT; ++c) {
+    const int k = k0 + c * WK + aseg * 4;
+    kok[c] = k < p.K;
+    int tap = 0, ci = k;
+    if (p.ntap > 1) {
+      tap = (unsigned)k / (unsigned)p.Ctot;
+      ci = k - tap * p.Ctot;
+    }
+    const int th = (unsigned)tap / (unsigned)p.ntw, tw = tap - th * p.ntw;
+    dh[c] = th * p.mulh + p.offh;
+    dw[c] = tw * p.mulw + p.offw;
+    src[c] = p.src0;
+    Cs[c] = p.C0;
+    cc[c] = ci;
+    if (ci >= p.C0 && p.src1 != nullptr) {  // (padding columns k >= K of a single-source conv keep src0: their loads are masked, not skipped)
+      src[c] = p.src1;
+      Cs[c] = p.C1;
+      cc[c] = ci - p.C0;
+    }
   }
-  const int th = (unsigned)tap / (unsigned)p.ntw, tw = tap - th * p.ntw;
-  const int dh = th * p.mulh + p.offh, dw = tw * p.mulw + p.offw;
-  const float* src = p.src0;
-  int Cs = p.C0, cc = ci;
-  if (ci >= p.C0) {
-    src = p.src1;
-    Cs = p.C1;
-    cc = ci - p.C0;
-  }
-  const int yseg = tid % YSEG, yrow0 = tid / YSEG;  // dY: rows yrow0 + (256/YSEG)*i
-  constexpr int YSTEP = 256 / YSEG;
+  const int yseg = tid % YSEG, yrow0 = tid / YSEG;  // dY: rows yrow0 + YSTEP*i
 
   f32x16 acc[FN][FK];
 #pragma unroll
@@ -86,88 +115,138 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  f32x4 ra[4], ry[YR];
+  f32x4 ra[4][KT], ry[YR];
+  unsigned okm = 0;  // validity bits of the staged registers (A: bit i*KT+c, dY: bit 16+i); selects happen at the LDS write
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  auto load_chunk = [&](int c) {
-    const int mbase = c * WM;
+  // Row state (b, q, r) of the rows this thread stages, advanced by 32 pixels per chunk WITHOUT divisions.
+  // 32 = d_b * Hq*Wq + d_q * Wq + d_r  (uniform), so one conditional carry per digit suffices.
+  const int d_r = WM % p.Wq, d_q = (WM / p.Wq) % p.Hq, d_b = WM / (p.Wq * p.Hq);
+  struct Row { int m, b, q, r; };
+  auto row_init = [&](int m) {
+    Row w;
+    w.m = m;
+    w.r = m % p.Wq;
+    const int t = m / p.Wq;
+    w.q = t % p.Hq;
+    w.b = t / p.Hq;
+    return w;
+  };
+  auto row_next = [&](Row& w) {
+    w.m += WM;
+    w.r += d_r;
+    const int c1_ = w.r >= p.Wq ? 1 : 0;
+    w.r -= c1_ ? p.Wq : 0;
+    w.q += d_q + c1_;
+    const int c2_ = w.q >= p.Hq ? 1 : 0;
+    w.q -= c2_ ? p.Hq : 0;
+    w.b += d_b + c2_;
+  };
+  Row rowA[4], rowY[YR];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rowA[i] = row_init(c0 * WM + arow + 8 * i);
+#pragma unroll
+  for (int i = 0; i < YR; ++i) rowY[i] = row_init(c0 * WM + yrow0 + YSTEP * i);
+  const int ny = n0 + yseg * 4;
+  const bool yvec = ny + 3 < p.N && (p.ldy & 3) == 0;
+
+  // loads the chunk the row state points at (unconditional loads from a clamped offset; no divergent branches), then advances
+  auto load_chunk = [&]() {
+    okm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = mbase + arow + 8 * i;
-      ra[i] = zero4;
-      if (kok && m < p.M) {
-        const int rr = m % p.Wq;
-        const int t = m / p.Wq;
-        const int q = t % p.Hq;
-        const int b = t / p.Hq;
-        const int ih = q * p.stride + dh, iw = rr * p.stride + dw;
-        if ((unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) {
-          const size_t off = ((size_t)(b * p.Hi * p.Wi + ih * p.Wi + iw)) * (size_t)Cs + (size_t)cc;
-          ra[i] = *reinterpret_cast<const f32x4*>(src + off);
-        }
+      const Row& w = rowA[i];
+      const int bpix = w.b * p.Hi * p.Wi, qs = w.q * p.stride, rs = w.r * p.stride;
+      const bool rok = w.m < p.M;
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        const int ih = qs + dh[c], iw = rs + dw[c];
+        const bool ok = kok[c] && rok && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+        const size_t off = ok ? ((size_t)(bpix + ih * p.Wi + iw)) * (size_t)Cs[c] + (size_t)cc[c] : (size_t)0;
+        ra[i][c] = *reinterpret_cast<const f32x4*>(src[c] + off);
+        okm |= ok ? (1u << (i * KT + c)) : 0u;
       }
+      row_next(rowA[i]);
     }
 #pragma unroll
     for (int i = 0; i < YR; ++i) {
+      const Row& w = rowY[i];
       const int row = yrow0 + YSTEP * i;
-      const int m = mbase + row;
-      const int n = n0 + yseg * 4;
-      ry[i] = zero4;
-      if (row < WM && m < p.M && n < p.N) {
-        size_t pix = (size_t)m;
-        if (!p.direct) {
-          const int rr = m % p.Wq;
-          const int t = m / p.Wq;
-          const int q = t % p.Hq;
-          const int b = t / p.Hq;
-          pix = ((size_t)b * p.Ho + (size_t)(q * p.os + p.ph)) * p.Wo + (size_t)(rr * p.os + p.pw);
-        }
-        const float* yp = p.dy + pix * p.ldy + n;
-        if (n + 3 < p.N && (p.ldy & 3) == 0) {
-          ry[i] = *reinterpret_cast<const f32x4*>(yp);
-        } else {
+      const bool ok = row < WM && w.m < p.M && ny < p.N;
+      size_t pix = (size_t)w.m;
+      if (!p.direct) pix = ((size_t)w.b * p.Ho + (size_t)(w.q * p.os + p.ph)) * p.Wo + (size_t)(w.r * p.os + p.pw);
+      const float* yp = p.dy + (ok ? pix * p.ldy + ny : (size_t)0);
+      if (yvec) {
+        ry[i] = *reinterpret_cast<const f32x4*>(yp);
+      } else {  // ragged N or unaligned rows (heads): scalar tail, block-uniform branch
+        ry[i] = zero4;
+        if (ok)
           for (int j = 0; j < 4; ++j)
-            if (n + j < p.N) ry[i][j] = yp[j];
-        }
+            if (ny + j < p.N) ry[i][j] = yp[j];
       }
+      okm |= ok ? (1u << (16 + i)) : 0u;
+      row_next(rowY[i]);
     }
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&As[buf][(arow + 8 * i) * WK + aseg * 4]) = ra[i];
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+        *reinterpret_cast<f32x4*>(&As[buf][(arow + 8 * i) * WKB + c * WK + aseg * 4]) = (okm & (1u << (i * KT + c))) ? ra[i][c] : zero4;
 #pragma unroll
     for (int i = 0; i < YR; ++i) {
       const int row = yrow0 + YSTEP * i;
-      if (row < WM) *reinterpret_cast<f32x4*>(&Ys[buf][row * BNG + yseg * 4]) = ry[i];
+      if (row < WM) *reinterpret_cast<f32x4*>(&Ys[buf][row * BNG + yseg * 4]) = (okm & (1u << (16 + i))) ? ry[i] : zero4;
     }
   };
   const int fi = lane & 31, fh = lane >> 5;
+  // The fragment reads of half a chunk are issued together and the MFMAs follow (the first version's read -> wait -> MFMA
+  // chain exposed the LDS latency 16 times per chunk).
   auto compute = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < WM / 2; ++j) {
-      const int m = 2 * j + fh;
-      float a[FN], b[FK];
+    for (int half = 0; half < 2; ++half) {
+      float av[WM / 4][FN], bv[WM / 4][FK];
 #pragma unroll
-      for (int x = 0; x < FN; ++x) a[x] = Ys[buf][m * BNG + wn * TN + x * 32 + fi];
+      for (int j = 0; j < WM / 4; ++j) {
+        const int m = 2 * (half * (WM / 4) + j) + fh;
 #pragma unroll
-      for (int x = 0; x < FK; ++x) b[x] = As[buf][m * WK + wk * TK + x * 32 + fi];
+        for (int x = 0; x < FN; ++x) av[j][x] = Ys[buf][m * BNG + wn * TN + x * 32 + fi];
 #pragma unroll
-      for (int x = 0; x < FN; ++x)
+        for (int x = 0; x < FK; ++x) bv[j][x] = As[buf][m * WKB + wk * TK + x * 32 + fi];
+      }
 #pragma unroll
-        for (int y = 0; y < FK; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+      for (int j = 0; j < WM / 4; ++j)
+#pragma unroll
+        for (int x = 0; x < FN; ++x)
+#pragma unroll
+          for (int y = 0; y < FK; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][x], bv[j][y], acc[x][y], 0, 0, 0);
     }
   };
 
   if (c0 < c1) {
-    load_chunk(c0);
+    load_chunk();
     store_chunk(0);
     __syncthreads();
-    for (int c = c0; c < c1; ++c) {
-      const int cur = (c - c0) & 1;
-      if (c + 1 < c1) load_chunk(c + 1);
+    if constexpr (NST == 2) {
+      int cur = 0;
+      for (int c = c0; c + 1 < c1; ++c) {  // straight-line body; the last chunk is peeled
+        load_chunk();
+        compute(cur);
+        store_chunk(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+      }
       compute(cur);
-      if (c + 1 < c1) store_chunk(cur ^ 1);
-      __syncthreads();
+    } else {
+      for (int c = c0; c + 1 < c1; ++c) {
+        load_chunk();
+        compute(0);
+        __syncthreads();  // everyone is done reading the stage
+        store_chunk(0);
+        __syncthreads();
+      }
+      compute(0);
     }
   }
 
@@ -183,7 +262,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
 #pragma unroll
       for (int y = 0; y < FK; ++y) {
         const int kk = k0 + wk * TK + y * 32 + col;
-        slab[(size_t)n * p.Kpad + kk] = acc[x][y][e];
+        if (kk < p.Kpad) slab[(size_t)n * p.Kpad + kk] = acc[x][y][e];
       }
     }
 }
@@ -199,11 +278,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WGradP p) {
   }
 }
 
+int g_wgrad_blocks = 0;  // tuning knob (m2h_debug_set 11): target block count of a weight-gradient launch
+
+// block shape for (N, K): n extent, k sub-tiles per block, blocks along k
+static void wgrad_cfg(int N, int K, int& bng, int& kt, int& ktiles) {
+  const int kt128 = (K + WK - 1) / WK;
+  bng = N > 32 ? 128 : 32;
+  kt = bng == 32 ? (kt128 >= 3 ? 3 : kt128) : 1;  // narrow layers: up to three k sub-tiles per block share the dY operand
+  ktiles = (kt128 + kt - 1) / kt;
+}
+
 static int wgrad_splits(long M, int N, int K) {
-  const int bng = N > 32 ? 128 : 32;
-  const long tiles = ((N + bng - 1) / bng) * (long)((K + WK - 1) / WK);
+  int bng, kt, ktiles;
+  wgrad_cfg(N, K, bng, kt, ktiles);
+  const long tiles = ((N + bng - 1) / bng) * (long)ktiles;
   const long chunks = (M + WM - 1) / WM;
-  long S = (1024 + tiles - 1) / tiles;  // ~4 blocks per CU
+  // one wave front, no tail round: 3 resident blocks per CU for the one-sub-tile kernels (40 / 64 KB LDS, <= 176 VGPRs), 2 for
+  // the wide-k ones (196-240 VGPRs)
+  const long target = g_wgrad_blocks > 0 ? g_wgrad_blocks : (kt >= 2 ? 512 : 768);
+  long S = (target + tiles - 1) / tiles;
   if (S > chunks / 4) S = chunks / 4;   // at least 4 chunks per split
   if (S > 1024) S = 1024;
   if (S < 1) S = 1;
@@ -240,14 +333,16 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
               (size_t)p.S * p.N * p.Kpad * sizeof(float));
   p.ws = static_cast<float*>(a.workspace);
   p.dw = dw;
-  const int ktiles = p.Kpad / WK;
-  if (a.N > 32) {
-    dim3 grid((a.N + 127) / 128, ktiles, p.S);
-    hipLaunchKernelGGL(wgrad_kernel<128>, grid, dim3(256), 0, st, p);
-  } else {
-    dim3 grid(1, ktiles, p.S);
-    hipLaunchKernelGGL(wgrad_kernel<32>, grid, dim3(256), 0, st, p);
-  }
+  int bng, kt;
+  wgrad_cfg(a.N, p.K, bng, kt, p.ktiles);
+  p.ntiles = (a.N + bng - 1) / bng;
+  const long nblk = (long)(p.S >= 8 ? (p.S + 7) / 8 * 8 : p.S) * p.ntiles * p.ktiles;
+  M2H_REQUIRE(nblk < 0x7fffffffL, "conv_wgrad: grid too large");
+  const dim3 grid((unsigned)nblk), blk(256);
+  if (bng == 128) hipLaunchKernelGGL((wgrad_kernel<128, 1, 2>), grid, blk, 0, st, p);
+  else if (kt == 1) hipLaunchKernelGGL((wgrad_kernel<32, 1, 2>), grid, blk, 0, st, p);
+  else if (kt == 2) hipLaunchKernelGGL((wgrad_kernel<32, 2, 1>), grid, blk, 0, st, p);
+  else hipLaunchKernelGGL((wgrad_kernel<32, 3, 1>), grid, blk, 0, st, p);
   int rc = launch_status("conv_wgrad");
   if (rc) return rc;
   const size_t total = (size_t)p.N * p.K;

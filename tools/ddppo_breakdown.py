@@ -41,13 +41,23 @@ def main():
             torch.cuda.synchronize(); ph["update_sep"] += time.perf_counter() - t; marks["update_sep"] = marks.get("update_sep", 0) + len(sink) - n0
         ops.set_timing(None)
         gpu_ms = {}
+        shapes = {}
         for name, meta, e0, e1 in sink:
-            gpu_ms[name] = gpu_ms.get(name, 0.0) + e0.elapsed_time(e1)
+            ms = e0.elapsed_time(e1)
+            gpu_ms[name] = gpu_ms.get(name, 0.0) + ms
+            key = (name, meta.get("M"), meta.get("N"), meta.get("K"))
+            c = shapes.setdefault(key, [0, 0.0])
+            c[0] += 1
+            c[1] += ms
         tot = sum(ph.values())
         print("cycle %d: %.3f s  -> %.0f env-steps/s" % (rep, tot, 1680 / tot))
         for k, v in ph.items():
             print("  %-11s %.3f s   timed-op launches %d" % (k, v, marks[k]))
         print("  GPU time of timed ops (ms):", {k: round(v, 1) for k, v in sorted(gpu_ms.items(), key=lambda kv: -kv[1])[:14]})
+        if rep == 1:
+            print("  per-shape (event time includes the split-K reduce):")
+            for (name, M, N, K), (n, ms) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:40]:
+                print("    %-22s M=%-8s N=%-6s K=%-6s calls=%5d total=%7.2f ms avg=%7.1f us" % (name, M, N, K, n, ms, 1e3 * ms / n))
 
 
 if __name__ == "__main__":
