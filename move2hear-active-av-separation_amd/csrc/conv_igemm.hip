@@ -639,12 +639,12 @@ static int splitk_for(long M, int N, int K, int phases, int BM, int BN) {
   const long mt = (M + BM - 1) / BM, ntl = (N + BN - 1) / BN;
   const long blocks = mt * ntl * phases;  // working blocks (padding blocks of the XCD map exit at once)
   long S = 1;
-  if (blocks < 512) {
-    S = (512 + blocks - 1) / blocks;  // aim at two resident blocks per CU
-    const long cap = BM < 128 ? 64 : 32;
-    if (S > cap) S = cap;
-  }
-  if (S > nk / 2) S = nk / 2;  // at least two k-tiles per split
+  if (blocks < 512) S = (512 + blocks - 1) / blocks;  // aim at two resident blocks per CU
+  // ... but keep enough k-tiles per split to amortise a block's fixed cost (row decode, cold first loads, slab write): measured
+  // optimum at the rollout shapes (layer_bench --batch 14 --tm 32) is ~4 tiles for the MFMA-paced 128-row tile and ~16 for the
+  // weight-streaming 32/64-row tiles (deeper splits made the 14-env U-Net pass 25 % slower)
+  const long tmin = BM < 128 ? 16 : 4;
+  if (S > nk / tmin) S = nk / tmin;
   return S < 1 ? 1 : (int)S;
 }
 
