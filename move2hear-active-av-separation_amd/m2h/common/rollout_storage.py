@@ -76,26 +76,31 @@ class RolloutStoragePol:
         num_envs_per_batch = num_processes // num_mini_batch
         perm = torch.randperm(num_processes)  # CPU generator, as the reference
         dev = self.rewards.device
+        # One mini-batch = every environment, merely re-ordered: the update is a mean over the batch and the GRU sequences are
+        # per environment, so the order only changes fp summation order.  With full_batch_views the physical gather (hundreds
+        # of MB per epoch) is skipped and the batch is a view of the storage; the permutation is still drawn (RNG state).
+        ident = bool(getattr(self, "full_batch_views", False)) and num_mini_batch == 1
         for start_ind in range(0, num_processes, num_envs_per_batch):
-            idx = perm[start_ind:start_ind + num_envs_per_batch].to(dev)
+            idx = None if ident else perm[start_ind:start_ind + num_envs_per_batch].to(dev)
+            take = lambda t: ops.take_envs(t, idx, ident)  # noqa: E731
             observations_batch = defaultdict(list)
             for sensor in self.observations:
-                observations_batch[sensor] = ops.gather_envs(self.observations[sensor][:-1], idx)
+                observations_batch[sensor] = take(self.observations[sensor][:-1])
             # hidden state: [layers, N_sel, H] from step 0
             hs = self.recurrent_hidden_states_pol[0]  # [layers, N, H] at step 0
-            recurrent_hidden_states_pol_batch = ops.gather_envs(hs, idx).view(hs.size(0), idx.numel(), hs.size(2))
+            recurrent_hidden_states_pol_batch = hs if ident else ops.gather_envs(hs, idx).view(hs.size(0), idx.numel(), hs.size(2))
             yield (
                 observations_batch,
                 recurrent_hidden_states_pol_batch,
-                ops.gather_envs(self.pred_binSepMasks, idx),
-                ops.gather_envs(self.pred_mono, idx),
-                ops.gather_envs(self.prev_pred_monoFromMem[1:], idx),
-                ops.gather_envs(self.value_preds[:-1], idx),
-                ops.gather_envs(self.returns[:-1], idx),
-                ops.gather_envs(advantages.contiguous(), idx),
-                ops.gather_envs(self.actions, idx),
-                ops.gather_envs(self.action_log_probs, idx),
-                ops.gather_envs(self.masks[:-1], idx),
+                take(self.pred_binSepMasks),
+                take(self.pred_mono),
+                take(self.prev_pred_monoFromMem[1:]),
+                take(self.value_preds[:-1]),
+                take(self.returns[:-1]),
+                take(advantages.contiguous()),
+                take(self.actions),
+                take(self.action_log_probs),
+                take(self.masks[:-1]),
             )
 
 
@@ -141,19 +146,23 @@ class RolloutStorageSep:
             self._last_after_update_gen = self.generation
             self._last_after_update_step = self.step
 
-    def recurrent_generator(self, num_mini_batch, with_perm=False):
+    def recurrent_generator(self, num_mini_batch, with_perm=False, sensors=None):
+        """sensors: optional subset of observation names to materialise (the separator update needs three of them)."""
         num_processes = self.masks.size(1)
         assert num_processes >= num_mini_batch
         num_envs_per_batch = num_processes // num_mini_batch
         perm = torch.randperm(num_processes)
         dev = self.masks.device
+        ident = bool(getattr(self, "full_batch_views", False)) and num_mini_batch == 1  # see RolloutStoragePol.recurrent_generator
         for start_ind in range(0, num_processes, num_envs_per_batch):
-            idx = perm[start_ind:start_ind + num_envs_per_batch].to(dev)
-            observations_batch = {s: ops.gather_envs(self.observations[s][:-1], idx) for s in self.observations}
+            idx = None if ident else perm[start_ind:start_ind + num_envs_per_batch].to(dev)
+            take = lambda t: ops.take_envs(t, idx, ident)  # noqa: E731
+            names = self.observations if sensors is None else [s for s in self.observations if s in sensors]
+            observations_batch = {s: take(self.observations[s][:-1]) for s in names}
             out = (
                 observations_batch,
-                ops.gather_envs(self.prev_pred_monoFromMem[1:], idx),
-                ops.gather_envs(self.prev_pred_monoFromMem[:-1], idx),
-                ops.gather_envs(self.masks[:-1], idx),
+                take(self.prev_pred_monoFromMem[1:]),
+                take(self.prev_pred_monoFromMem[:-1]),
+                take(self.masks[:-1]),
             )
             yield out + (idx,) if with_perm else out

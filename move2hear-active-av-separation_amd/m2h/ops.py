@@ -487,6 +487,14 @@ def gather_envs(src, perm):
     return dst
 
 
+def take_envs(src, perm, identity=False):
+    """gather_envs, or -- when the caller knows the selection is ALL environments in storage order -- the same rows as a
+    zero-copy view [T*N, ...] of the storage."""
+    if identity:
+        return src.reshape((src.shape[0] * src.shape[1],) + tuple(src.shape[2:]))
+    return gather_envs(src, perm)
+
+
 def bin_l1_loss(mix, masks, gt, cstep=2, want_grad=False):
     """mean |(exp(mix)-1)*masks - gt[..., cstep*c]| (ppo.py:219-221 with cstep 2 on gt_bin_comps; passive_trainer.py:270-272 with
     cstep 1 on gt_bin_mag) -> 0-dim device tensor (and d loss / d masks when want_grad)."""

@@ -141,12 +141,13 @@ class PPO(nn.Module):
                                       "(shipped configs freeze them, ppo_trainer.py:557-577)")
         cached = self._separator_outputs(rollouts_sep) if self.cache_separator_outputs else None
         for _e in range(self.ppo_epoch):
-            gen = rollouts_sep.recurrent_generator(self.num_mini_batch, with_perm=True)
+            needed = ("mixed_bin_audio_mag", "gt_mono_comps", "gt_bin_comps", "target_class")  # what this update reads
+            gen = rollouts_sep.recurrent_generator(self.num_mini_batch, with_perm=True, sensors=needed)
             for sample in gen:
                 obs_batch, _mem_batch, prev_mem_batch, masks_batch, idx = sample
                 if cached is not None:
-                    pred_binSepMasks = ops.gather_envs(cached[0], idx)
-                    pred_mono = ops.gather_envs(cached[1], idx)
+                    pred_binSepMasks = ops.take_envs(cached[0], idx, idx is None)
+                    pred_mono = ops.take_envs(cached[1], idx, idx is None)
                 else:
                     with torch.no_grad():  # reference :184-195
                         pred_binSepMasks = self.actor_critic.get_binSepMasks(obs_batch)

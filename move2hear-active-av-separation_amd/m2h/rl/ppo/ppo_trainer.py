@@ -87,6 +87,9 @@ class PPOTrainer:
         space = self.envs.observation_spaces[0]
         self.rollouts_pol = RolloutStoragePol(cfg.num_steps, N, space, cfg.hidden_size)
         self.rollouts_sep = RolloutStorageSep(cfg.num_steps * cfg.num_updates_per_cycle, N, space)
+        # nearTarget/farTarget use one mini-batch: the update batch is the whole storage, read in place (rollout_storage.py)
+        self.rollouts_pol.full_batch_views = True
+        self.rollouts_sep.full_batch_views = True
         self.rollouts_pol.to(self.device)
         self.rollouts_sep.to(self.device)
         batch = self.envs.reset()

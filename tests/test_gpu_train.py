@@ -206,7 +206,10 @@ def _agent(seed, dev, cache=True):
     return agent, pol, sd
 
 
-def test_update_pol_matches_reference_fixture(golden_dir):
+@pytest.mark.parametrize("views", [False, True])
+def test_update_pol_matches_reference_fixture(golden_dir, views):
+    """views=True: the one-mini-batch update reads the storage in place instead of gathering a permuted copy (the trainer's
+    setting); both must reproduce the reference's losses and post-step weights."""
     from m2h.common.rollout_storage import RolloutStoragePol
     from m2h.common.spaces import move2hear_observation_space
     dev = _dev()
@@ -217,6 +220,7 @@ def test_update_pol_matches_reference_fixture(golden_dir):
     ro = RolloutStoragePol(T, N, move2hear_observation_space(), 512)
     _fill_pol_storage(ro, obs_all, T, N, torch.Generator().manual_seed(int(gold["pol_fill_seed"])))
     ro.to(dev)
+    ro.full_batch_views = views
     torch.manual_seed(int(gold["pol_perm_seed"]))
     v, a, h = agent.update_pol(ro)
     ref = gold["pol_losses"]
@@ -239,8 +243,8 @@ def test_update_pol_matches_reference_fixture(golden_dir):
     assert checked >= 15
 
 
-@pytest.mark.parametrize("cache", [True, False])
-def test_update_sep_matches_reference_fixture(golden_dir, cache):
+@pytest.mark.parametrize("cache,views", [(True, False), (False, False), (True, True), (False, True)])
+def test_update_sep_matches_reference_fixture(golden_dir, cache, views):
     from m2h.common.rollout_storage import RolloutStorageSep
     from m2h.common.spaces import move2hear_observation_space
     dev = _dev()
@@ -255,6 +259,7 @@ def test_update_sep_matches_reference_fixture(golden_dir, cache):
     rs.prev_pred_monoFromMem.copy_(torch.rand(T + 1, N, 512, 32, 1, generator=g2))
     rs.masks.copy_((torch.rand(T + 1, N, 1, generator=g2) > 0.3).float())
     rs.to(dev)
+    rs.full_batch_views = views
     torch.manual_seed(int(gold["sep_perm_seed"]))
     b, m, mm = agent.update_sep(rs)
     ref = gold["sep_losses"]
