@@ -267,7 +267,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
     }
 }
 
+// dw[n][k] = sum over splits, fixed order.  A block owns 64 consecutive k of one row n; its four waves each sum a quarter of
+// the splits (four loads in flight per lane), then the quarters are combined in wave order.  (One thread per element walking
+// all splits serially took 39 us for a 32 x 384 gradient with 512 splits: 36 blocks, one dependent load at a time.)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WGradP p) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int kb = (p.K + 63) / 64;
+  const int n = blockIdx.x / kb;
+  const int k = (blockIdx.x - n * kb) * 64 + lane;
+  const int z0 = (int)(((long)p.S * w) / 4), z1 = (int)(((long)p.S * (w + 1)) / 4);
+  const size_t zs = (size_t)p.N * p.Kpad;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (k < p.K) {
+    const float* src = p.ws + (size_t)n * p.Kpad + k;
+    int z = z0;
+    for (; z + 3 < z1; z += 4) {
+      const float v0 = src[(size_t)z * zs], v1 = src[(size_t)(z + 1) * zs], v2 = src[(size_t)(z + 2) * zs], v3 = src[(size_t)(z + 3) * zs];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; z < z1; ++z) a0 += src[(size_t)z * zs];
+  }
+  sh[w][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (w == 0 && k < p.K) p.dw[(size_t)n * p.K + k] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+
+// few splits: one thread per element (the block-per-64-k form above would be tens of thousands of near-empty blocks)
+__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const WGradP p) {
   const size_t total = (size_t)p.N * p.K;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int n = (int)(i / p.K);
@@ -345,10 +372,15 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   else hipLaunchKernelGGL((wgrad_kernel<32, 3, 1>), grid, blk, 0, st, p);
   int rc = launch_status("conv_wgrad");
   if (rc) return rc;
-  const size_t total = (size_t)p.N * p.K;
-  size_t g = (total + 255) / 256;
-  if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, p);
+  if (p.S >= 16) {
+    const long g = (long)p.N * ((p.K + 63) / 64);
+    M2H_REQUIRE(g < 0x7fffffffL, "conv_wgrad: reduce grid too large");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, p);
+  } else {
+    size_t g = ((size_t)p.N * p.K + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)g), dim3(256), 0, st, p);
+  }
   return launch_status("conv_wgrad reduce");
 }
 
