@@ -51,16 +51,18 @@ def main():
         if i < 4:
             H *= 2
             W *= 2
+    layers.append(("up4+head(32)", "uphead", B, 16, T // 2, 64, 64, 32))
+    layers.append(("up4+head(16)", "uphead", B, 16, T // 2, 64, 64, 16))
     layers.append(("head32", "head", B, 32, T, 32, 0, 32))
     layers.append(("head16", "head", B, 32, T, 16, 0, 16))
 
     variants = []
     for v in a.variants.split(";"):
-        kn = {i: 0 for i in range(10)}
+        kn = {i: 0 for i in range(13)}
         if v != "auto":
             for kv in v.split(","):
                 k, val = kv.split("=")
-                kn[{"splitk": 0, "stages": 1, "wide": 2, "skinny": 3, "n16": 4, "stagger": 5, "pp": 6, "lds": 7, "pmaj": 8, "fast": 9}[k]] = int(val)
+                kn[{"splitk": 0, "stages": 1, "wide": 2, "skinny": 3, "n16": 4, "stagger": 5, "pp": 6, "lds": 7, "pmaj": 8, "fast": 9, "direct": 12}[k]] = int(val)
         variants.append((v, kn))
 
     print("%-12s %10s %8s %6s | " % ("layer", "M", "K", "N") + " | ".join("%22s" % v for v, _ in variants))
@@ -79,6 +81,12 @@ def main():
             wp = torch.randn(4, co, 4 * (c0 + c1), device=dev, generator=g) * 0.05
             fn = lambda: ops.unet_up_fwd(x, skip, wp, sc, sh, co)
             M, K = 4 * B_ * H * W, 4 * (c0 + c1)
+        elif kind == "uphead":
+            skip = torch.randn(B_, H, W, c1, device=dev, generator=g)
+            wp = torch.randn(4, co, 4 * (c0 + c1), device=dev, generator=g) * 0.05
+            hw, hb = torch.randn(co, co, device=dev, generator=g) * 0.2, torch.randn(co, device=dev, generator=g) * 0.1
+            fn = lambda: ops.unet_up_head_fwd(x, skip, wp, sc, sh, hw, hb, co)
+            M, K = 4 * B_ * H * W, 4 * (c0 + c1)
         else:
             wp = torch.randn(co, c0, device=dev, generator=g) * 0.2
             fn = lambda: ops.unet_head_fwd(x, wp, sh, co)
@@ -92,7 +100,7 @@ def main():
             tot[vi] += us
             cells.append("%9.1f us %6.1f TF/s" % (us, flops / us / 1e6))
         print("%-12s %10d %8d %6d | " % (name, M, K, co) + " | ".join(cells))
-    for k in range(10):
+    for k in range(13):
         ops.debug_set(k, 0)
     print("%-12s %26s | " % ("total(us)", "") + " | ".join("%22.1f" % t for t in tot))
 
