@@ -329,6 +329,13 @@ int m2h_stft_post(const float* spec, float* mag_out, float* phase_out, int B, in
 int m2h_istft_pre(const float* mag, const float* phase, float* rows, int B, int C, int c, int T, int nb, int ldr, m2h_stream stream);
 int m2h_istft_ola(const float* frames, const float* window, float* y, int S, int T, int n_fft, int hop, int ldf, int length, m2h_stream stream);
 
+/* Waveform quality metrics (common/eval_metrics.py:12-166, scale_bss_eval / evaluate_helper for the single reference source
+ * the evaluation uses; preprocess :170-196 removes every signal's mean and averages the mixture's channels).
+ * ref, est, mix_l, mix_r: [S][L] waveforms (mix_r may be NULL for a mono mixture).
+ * out [S][11] = si_sdr, si_sir, si_sar, sd_sdr, snr, srr, si_sdri, sd_sdri, snri, si_siri, si_sari (dB; the "i" metrics are the
+ * improvement over using the mixture as the estimate). */
+int m2h_bss_metrics(const float* ref, const float* est, const float* mix_l, const float* mix_r, float* out, int S, int L, m2h_stream stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Whole-network runner: one C call enqueues every kernel of one separator U-Net forward (K1/K2 slice, 5 down stages, 5 up
  * stages, head) = PassiveSepEncCNN.forward + PassiveSepDecCNN.forward (separator_cnn.py:70-108,153-170) in eval mode.  Same

@@ -103,6 +103,109 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
   }
 }
 
+
+// Waveform quality metrics of common/eval_metrics.py:12-166 (scale_bss_eval for ONE reference source, the only case the
+// reference evaluates: evaluate_helper passes references[..., 0, :] with a single source): one 1024-thread block per clip.
+//   preprocess (:170-196): every signal has its mean removed; the mixture is the mean of its two mean-removed channels.
+//   helper(s, x) (:12-58): alpha = <s,x>/<s,s>;  snr = 10log10(<s,s>/|x-s|^2);  si_sdr = 10log10(|alpha s|^2/|x-alpha s|^2);
+//   srr = -10log10((1-1/alpha)^2);  sd_sdr = snr + 10log10(alpha^2);  b = <s, x-alpha s>/<s,s> + EPS;
+//   si_sir = 10log10(|alpha s|^2/|s b|^2);  si_sar = 10log10(|alpha s|^2/|x - alpha s - s b + EPS|^2).
+// out[clip][11] = si_sdr, si_sir, si_sar, sd_sdr, snr, srr of the estimate, then si_sdri, sd_sdri, snri, si_siri, si_sari
+// (estimate minus the same metric of the mixture, :112-122).  Sums are fp32 per thread and double across the block.
+// (si_sir / si_sar of a single source divide by rounding noise -- <s, x - alpha s> is zero in exact arithmetic -- in the
+// reference as here; only their order of magnitude is meaningful.)
+__device__ __forceinline__ double block_sum_d(double v, double* sh /* 16 */) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t += sh[i];
+  return t;
+}
+
+__global__ __launch_bounds__(1024) void bss_metrics_kernel(const float* __restrict__ ref, const float* __restrict__ est,
+                                                           const float* __restrict__ mixl, const float* __restrict__ mixr,
+                                                           float* __restrict__ out, int L) {
+  __shared__ double sh[16];
+  const int c = blockIdx.x;
+  const float* s = ref + (size_t)c * L;
+  const float* e = est + (size_t)c * L;
+  const float* ml = mixl + (size_t)c * L;
+  const float* mr = mixr != nullptr ? mixr + (size_t)c * L : nullptr;
+  const double EPS = 1e-13;
+  // pass 1: means
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int i = threadIdx.x; i < L; i += 1024) {
+    a0 += s[i];
+    a1 += e[i];
+    a2 += ml[i];
+    if (mr != nullptr) a3 += mr[i];
+  }
+  const float ms = (float)(block_sum_d(a0, sh) / L), me = (float)(block_sum_d(a1, sh) / L);
+  const float mml = (float)(block_sum_d(a2, sh) / L), mmr = (float)(block_sum_d(a3, sh) / L);
+  auto S = [&](int i) { return s[i] - ms; };
+  auto X = [&](int i, int which) {
+    if (which == 0) return e[i] - me;
+    const float l = ml[i] - mml;
+    return mr != nullptr ? 0.5f * (l + (mr[i] - mmr)) : l;
+  };
+  // pass 2: <s,s>, <s,x>
+  float ss_ = 0.f, sx0 = 0.f, sx1 = 0.f;
+  for (int i = threadIdx.x; i < L; i += 1024) {
+    const float sv = S(i);
+    ss_ += sv * sv;
+    sx0 += sv * X(i, 0);
+    sx1 += sv * X(i, 1);
+  }
+  const double ss = block_sum_d(ss_, sh);
+  const double sx[2] = {block_sum_d(sx0, sh), block_sum_d(sx1, sh)};
+  double m[2][6];
+  for (int w = 0; w < 2; ++w) {
+    const double alpha = sx[w] / ss;
+    const float af = (float)alpha;
+    // pass 3: |x - s|^2, |x - alpha s|^2, <s, x - alpha s>
+    float n1 = 0.f, n2 = 0.f, sr = 0.f;
+    for (int i = threadIdx.x; i < L; i += 1024) {
+      const float sv = S(i), xv = X(i, w);
+      const float d1 = xv - sv, d2 = xv - sv * af;
+      n1 += d1 * d1;
+      n2 += d2 * d2;
+      sr += sv * d2;
+    }
+    const double noise1 = block_sum_d(n1, sh), noise2 = block_sum_d(n2, sh);
+    const double b = block_sum_d(sr, sh) / ss + EPS;
+    const float bf = (float)b;
+    // pass 4: |x - alpha s - s b + EPS|^2
+    float ar = 0.f;
+    for (int i = threadIdx.x; i < L; i += 1024) {
+      const float sv = S(i);
+      const float d = (X(i, w) - sv * af) - sv * bf + (float)EPS;
+      ar += d * d;
+    }
+    const double artif = block_sum_d(ar, sh);
+    const double signal2 = alpha * alpha * ss;
+    const double snr = 10.0 * log10(ss / noise1);
+    m[w][0] = 10.0 * log10(signal2 / noise2);                     // si_sdr
+    m[w][1] = 10.0 * log10(signal2 / (b * b * ss));               // si_sir
+    m[w][2] = 10.0 * log10(signal2 / artif);                      // si_sar
+    m[w][3] = snr + 10.0 * log10(alpha * alpha);                  // sd_sdr
+    m[w][4] = snr;                                                // snr
+    m[w][5] = -10.0 * log10((1.0 - 1.0 / alpha) * (1.0 - 1.0 / alpha));  // srr
+  }
+  if (threadIdx.x == 0) {
+    float* o = out + (size_t)c * 11;
+    for (int j = 0; j < 6; ++j) o[j] = (float)m[0][j];
+    o[6] = (float)(m[0][0] - m[1][0]);   // si_sdri
+    o[7] = (float)(m[0][3] - m[1][3]);   // sd_sdri
+    o[8] = (float)(m[0][4] - m[1][4]);   // snri
+    o[9] = (float)(m[0][1] - m[1][1]);   // si_siri
+    o[10] = (float)(m[0][2] - m[1][2]);  // si_sari
+  }
+}
+
 static inline unsigned sgrid(size_t total) {
   size_t g = (total + 255) / 256;
   if (g > 8192) g = 8192;
@@ -139,6 +242,12 @@ int m2h_istft_ola(const float* frames, const float* window, float* y, int S, int
   M2H_REQUIRE(frames && window && y && S > 0 && T > 0 && n_fft > 1 && hop > 0 && ldf >= n_fft && length > 0, "istft_ola: bad arguments");
   hipLaunchKernelGGL(istft_ola_kernel, dim3(sgrid((size_t)S * length)), dim3(256), 0, as_stream(stream), frames, window, y, S, T, n_fft, hop, ldf, length);
   return launch_status("istft_ola");
+}
+
+int m2h_bss_metrics(const float* ref, const float* est, const float* mix_l, const float* mix_r, float* out, int S, int L, m2h_stream stream) {
+  M2H_REQUIRE(ref && est && mix_l && out && S > 0 && L > 1, "bss_metrics: bad arguments");
+  hipLaunchKernelGGL(bss_metrics_kernel, dim3(S), dim3(1024), 0, as_stream(stream), ref, est, mix_l, mix_r, out, L);
+  return launch_status("bss_metrics");
 }
 
 }  // extern "C"

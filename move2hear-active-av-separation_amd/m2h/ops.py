@@ -471,6 +471,20 @@ def stft_l2(pred, gt_comps, nch, mix=None):
     return out
 
 
+def bss_metrics(ref, est, mix_l, mix_r=None):
+    """Waveform metrics of eval_metrics.scale_bss_eval per clip: ref/est/mix [S, L] -> [S, 11] (order: eval_metrics.METRIC_ORDER)."""
+    for t in (ref, est, mix_l, mix_r):
+        _chk(t, "bss_metrics")
+    S, L = ref.shape
+    if est.shape != ref.shape or mix_l.shape != ref.shape or (mix_r is not None and mix_r.shape != ref.shape):
+        raise RuntimeError("m2h.bss_metrics: all waveforms must be [S, L]")
+    out = torch.empty((S, 11), device=ref.device)
+    lib = _lib.load()
+    with torch.cuda.device(ref.device):
+        _lib.check(lib.m2h_bss_metrics(_ptr(ref), _ptr(est), _ptr(mix_l), _ptr(mix_r), _ptr(out), S, L, _stream(ref)), "m2h_bss_metrics")
+    return out
+
+
 def gather_envs(src, perm):
     """src [T,N,...] , perm [Nsel] int64 (device) -> [T*Nsel, ...]  (recurrent_generator stack + flatten)."""
     if not src.is_cuda or not src.is_contiguous():

@@ -475,3 +475,60 @@ def np_stft_features(wave_bcl, fp16_round=False):
         mags.append(np.stack(mc, -1))
         phs.append(np.stack(pc, -1))
     return np.stack(mags).astype(np.float32), np.stack(phs).astype(np.float32)
+
+
+# ==============================================================================================
+# N2: waveform quality metrics (common/eval_metrics.py:12-196), restated in numpy following the reference line by line
+# ==============================================================================================
+BSS_EPS = 1e-13
+BSS_METRIC_ORDER = ("si_sdr", "si_sir", "si_sar", "sd_sdr", "snr", "srr", "si_sdri", "sd_sdri", "snri", "si_siri", "si_sari")
+
+
+def np_scale_bss_eval_helper(references, estimate, idx, compute_sir_sar=True):
+    """eval_metrics.py:12-58.  references [n_samples, n_sources], estimate [n_samples]."""
+    import numpy as np
+    source = references[..., idx]
+    source_energy = (source ** 2).sum()
+    alpha = source @ estimate / source_energy
+    e_true = source
+    e_res = estimate - e_true
+    signal = (e_true ** 2).sum()
+    noise = (e_res ** 2).sum()
+    snr = 10 * np.log10(signal / noise)
+    e_true = source * alpha
+    e_res = estimate - e_true
+    signal = (e_true ** 2).sum()
+    noise = (e_res ** 2).sum()
+    si_sdr = 10 * np.log10(signal / noise)
+    srr = -10 * np.log10((1 - (1 / alpha)) ** 2)
+    sd_sdr = snr + 10 * np.log10(alpha ** 2)
+    si_sir = si_sar = np.nan
+    if compute_sir_sar:
+        references_projection = references.T @ references
+        references_onto_residual = np.dot(references.transpose(), e_res)
+        b = np.linalg.solve(references_projection, references_onto_residual) + BSS_EPS
+        e_interf = np.dot(references, b)
+        e_artif = e_res - e_interf + BSS_EPS
+        si_sir = 10 * np.log10(signal / (e_interf ** 2).sum())
+        si_sar = 10 * np.log10(signal / (e_artif ** 2).sum())
+    return si_sdr, si_sir, si_sar, sd_sdr, snr, srr
+
+
+def np_waveform_metrics(gt_wave, est_wave, mix_lr, dtype=None):
+    """evaluate (:199-229) = preprocess (:170-196) + evaluate_helper (:124-167) + scale_bss_eval (:61-122) for one clip.
+    gt_wave, est_wave [L]; mix_lr [2, L].  Returns the 11 metrics in BSS_METRIC_ORDER.  dtype: compute dtype (the reference
+    works in the float32 librosa returns; float64 gives the well-conditioned reference values for tolerance checks)."""
+    import numpy as np
+    dt = dtype or np.float32
+    true_signal, estimated_signal, mixed_signal = [np.asarray(gt_wave, dt)[None]], [np.asarray(est_wave, dt)[None]], [np.asarray(mix_lr, dt)]
+    references = np.stack([x for x in true_signal], axis=-1).transpose(1, 0, 2)   # time x channels x sources
+    references = references - references.mean(axis=0)
+    estimates = np.stack([x for x in estimated_signal], axis=-1).transpose(1, 0, 2)
+    estimates = estimates - estimates.mean(axis=0)
+    mixture = mixed_signal[0].transpose(1, 0) - mixed_signal[0].transpose(1, 0).mean(axis=0)
+    mixture = np.mean(mixture, axis=1, keepdims=True)
+    est = np_scale_bss_eval_helper(references[..., 0, :], estimates[..., 0, 0], 0)
+    mix = np_scale_bss_eval_helper(references[..., 0, :], mixture[..., 0], 0)
+    si_sdr, si_sir, si_sar, sd_sdr, snr, srr = est
+    return np.array([si_sdr, si_sir, si_sar, sd_sdr, snr, srr, si_sdr - mix[0], sd_sdr - mix[3], snr - mix[4],
+                     si_sir - mix[1], si_sar - mix[2]], np.float64)
