@@ -3,9 +3,14 @@
 
     python main.py --exp-config <yaml> --run-type train --model-dir <dir> [KEY VALUE ...]
 
+    python main.py --exp-config <yaml> --run-type eval  --model-dir <dir> [--eval-ckpt <file>] [--eval-episodes N]
+
 Accepts the reference's experiment YAMLs (config/pretrain_passive.yaml, config/train/nearTarget.yaml, farTarget.yaml).  The
-environment is the synthetic on-device feeder; ``--run-type eval`` (the Habitat episodic eval loop) is out of scope.
+environment is the synthetic on-device feeder; ``--run-type eval`` runs the evaluation loop of ``_eval_checkpoint``
+(ppo_trainer.py:1015-1551: eval-mode policy, per-step STFT-L2, waveform SI-SDR of the last step, mean/std aggregation) on
+that feeder -- the Habitat episode datasets and simulator it iterates in the reference are out of scope.
 """
+import json
 import argparse
 import os
 import sys
@@ -19,10 +24,10 @@ def main():
     parser.add_argument("--exp-config", type=str, default=None, help="path to the experiment YAML")
     parser.add_argument("--model-dir", default=None)
     parser.add_argument("--cycles", type=int, default=1, help="ppo: training cycles to run; passive: epochs")
+    parser.add_argument("--eval-ckpt", default=None, help="eval: checkpoint file (default: <model-dir>/data/ckpt.0.pth if present)")
+    parser.add_argument("--eval-episodes", type=int, default=None, help="eval: episodes to aggregate (default: NUM_PROCESSES)")
     parser.add_argument("opts", default=None, nargs=argparse.REMAINDER, help="KEY VALUE overrides")
     args = parser.parse_args()
-    if args.run_type == "eval":
-        raise SystemExit("eval needs the Habitat simulator (out of scope); see DESIGN.md section 7")
     import torch
     from m2h.config.default import get_config, get_trainer
     config = get_config(args.exp_config, args.opts, args.model_dir, args.run_type, search_dirs=(".", os.path.dirname(args.exp_config or ".")))
@@ -30,6 +35,15 @@ def main():
     assert trainer_init is not None, f"{config.TRAINER_NAME} is not supported"
     trainer = trainer_init(config, torch.device("cuda", 0))
     trainer.setup()
+    if args.run_type == "eval":
+        if config.TRAINER_NAME != "ppo":
+            raise SystemExit("--run-type eval is the RL evaluation loop (TRAINER_NAME ppo)")
+        ckpt = args.eval_ckpt
+        if ckpt is None and config.CHECKPOINT_FOLDER and os.path.exists(os.path.join(config.CHECKPOINT_FOLDER, "ckpt.0.pth")):
+            ckpt = os.path.join(config.CHECKPOINT_FOLDER, "ckpt.0.pth")
+        stats = trainer.eval(num_episodes=args.eval_episodes, checkpoint_path=ckpt)
+        print(json.dumps(stats, indent=1))
+        return
     if config.TRAINER_NAME == "passive":
         for i, rec in enumerate(trainer.train(num_epochs=args.cycles)):
             print("epoch %d  train bin/mono %.4f %.4f   val %.4f %.4f" % (i, *rec["train"], *rec["val"]))

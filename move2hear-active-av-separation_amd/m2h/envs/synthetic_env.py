@@ -48,11 +48,17 @@ class SyntheticVecEnv:
         self.angle = torch.randint(0, 4, (num_envs,), device=device, generator=g)
         self.t = 0  # all envs step in lockstep: host-side counter, no sync
         self.pool = P
+        # eval-only sensor (config/default.py: MIXED_BIN_AUDIO_PHASE_SENSOR is added by the eval configs): phases of the mixture
+        self.include_phase = False
+        self.pool_mixed_phase = ((torch.rand(P, n_freq, tm, 2, device=device, generator=torch.Generator(device=device).manual_seed(int(seed) + 7)) * 2 - 1)
+                                 * 3.14159265).contiguous()
 
     def _obs(self):
         f = self.node * 4 + self.angle
         a = self.audio_idx
+        extra = {"mixed_bin_audio_phase": self.pool_mixed_phase.index_select(0, a)} if self.include_phase else {}
         return {
+            **extra,
             "rgb": self.frames_rgb.index_select(0, f),
             "depth": self.frames_depth.index_select(0, f),
             "mixed_bin_audio_mag": self.pool_mixed.index_select(0, a),

@@ -104,6 +104,18 @@ class PassiveTrainer:
         os.makedirs(self.config.CHECKPOINT_FOLDER, exist_ok=True)
         torch.save(ckpt, os.path.join(self.config.CHECKPOINT_FOLDER, file_name))
 
+    def load_checkpoint(self, checkpoint_path, *args, **kwargs):
+        """torch.load of a {"state_dict", "config"} checkpoint (reference passive_trainer.py save/load pair); returns the dict."""
+        kwargs.setdefault("map_location", "cpu")
+        kwargs.setdefault("weights_only", False)
+        return torch.load(checkpoint_path, *args, **kwargs)
+
+    def load_state_dict(self, state_dict, strict=True):
+        out = self.agent.load_state_dict(state_dict, strict=strict)
+        from ... import functional as MF
+        MF.bump_param_epoch()
+        return out
+
     def train(self, num_epochs=None):
         cfg = self.config
         if self.actor_critic is None:

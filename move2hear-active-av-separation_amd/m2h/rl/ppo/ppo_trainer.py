@@ -225,6 +225,101 @@ class PPOTrainer:
         os.makedirs(self.config.CHECKPOINT_FOLDER, exist_ok=True)
         torch.save(ckpt, os.path.join(self.config.CHECKPOINT_FOLDER, file_name))
 
+    def load_checkpoint(self, checkpoint_path, *args, **kwargs):
+        """torch.load of a {"state_dict", "config"} checkpoint (reference :240-251); returns the dict."""
+        kwargs.setdefault("map_location", "cpu")
+        kwargs.setdefault("weights_only", False)
+        return torch.load(checkpoint_path, *args, **kwargs)
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Loads agent weights saved by this trainer or by the reference (keys rooted at "actor_critic.")."""
+        sd = {k[len("actor_critic."):]: v for k, v in state_dict.items() if k.startswith("actor_critic.")}
+        if not sd:
+            raise RuntimeError("checkpoint state_dict has no 'actor_critic.*' keys")
+        out = self.actor_critic.load_state_dict(sd, strict=strict)
+        from ... import functional as MF
+        MF.bump_param_epoch()  # packed-weight memos key on the optimizer epoch
+        self._next_cache = None
+        return out
+
+    def eval(self, num_episodes=None, checkpoint_path=None, waveform_metrics=("si_sdr",), deterministic=None):
+        """Evaluation loop of `_eval_checkpoint` (reference :1015-1551) on this trainer's vectorised env: eval-mode policy,
+        deterministic or sampled actions (ppo_cfg.deterministic_eval), per-step STFT-L2 of the separated mono (:1369-1385),
+        waveform metrics of the LAST step of each episode (:1400-1415) when the env provides `mixed_bin_audio_phase`, and the
+        reference's aggregation (mean / std over episodes, :1484-1504).  Returns the aggregated-stats dict."""
+        import numpy as np
+        from ...common import eval_metrics as EM
+        cfg, ac = self.config, self.actor_critic
+        if checkpoint_path is not None:
+            self.load_state_dict(self.load_checkpoint(checkpoint_path)["state_dict"])
+        was_training = ac.training
+        ac.eval()
+        N = self.envs.num_envs
+        num_episodes = num_episodes or N
+        deterministic = getattr(cfg, "deterministic_eval", False) if deterministic is None else deterministic
+        had_phase = getattr(self.envs, "include_phase", None)
+        if had_phase is not None:
+            self.envs.include_phase = bool(waveform_metrics)
+        obs = self.envs.reset()
+        h = torch.zeros(ac.pol_net.num_recurrent_layers, N, cfg.hidden_size, device=self.device)
+        not_done = torch.ones(N, 1, device=self.device)
+        prev_mem = torch.zeros(N, 512, 32, 1, device=self.device)
+        per_ep = {k: [] for k in ("mono_loss_last_step", "mono_loss_all_steps", "monoFromMem_loss_last_step",
+                                  "monoFromMem_loss_all_steps", "reward")}
+        wave = {"mono": {m: [] for m in waveform_metrics}, "monoFromMem": {m: [] for m in waveform_metrics}}
+        cur_mono, cur_mem, cur_rew, cur_steps = (torch.zeros(N, 1, device=self.device) for _ in range(4))
+        done_eps = 0
+        with torch.no_grad():
+            while done_eps < num_episodes:
+                pm, mono = self._separate(obs)
+                mem = ac.get_monoFromMem_masked(mono, prev_mem, not_done)
+                _v, actions, _lp, h, _probs = ac.act(obs, h, not_done, deterministic=deterministic, pred_binSepMasks=pm, pred_mono=mono,
+                                                     pred_monoFromMem=mem)
+                _db, d_mono = EM.STFT_L2_distance(obs["mixed_bin_audio_mag"], pm, obs["gt_bin_comps"], mono, obs["gt_mono_comps"])
+                d_mem = ops.stft_l2(mem, obs["gt_mono_comps"], 1)
+                last_obs, last_mono, last_mem = obs, mono, mem
+                obs, rewards, not_done, _infos = self.envs.step(actions)
+                cur_mono += d_mono
+                cur_mem += d_mem
+                cur_rew += rewards
+                cur_steps += 1
+                prev_mem = mem
+                finished = (not_done.view(-1) == 0).nonzero().view(-1).tolist()  # host sync once per step, as the reference's loop
+                if finished:
+                    wm = None
+                    if waveform_metrics and "mixed_bin_audio_phase" in last_obs:
+                        gm, gp = last_obs["gt_mono_comps"][..., 0:1], last_obs["gt_mono_comps"][..., 1:2]
+                        wm = {k: EM.waveform_metrics(gm, gp, v, last_obs["mixed_bin_audio_mag"], last_obs["mixed_bin_audio_phase"]).cpu()
+                              for k, v in (("mono", last_mono), ("monoFromMem", last_mem))}
+                    for e in finished:
+                        if done_eps >= num_episodes:
+                            break
+                        n = float(cur_steps[e])
+                        per_ep["mono_loss_last_step"].append(float(d_mono[e]))
+                        per_ep["mono_loss_all_steps"].append(float(cur_mono[e]) / n)
+                        per_ep["monoFromMem_loss_last_step"].append(float(d_mem[e]))
+                        per_ep["monoFromMem_loss_all_steps"].append(float(cur_mem[e]) / n)
+                        per_ep["reward"].append(float(cur_rew[e]))
+                        if wm is not None:
+                            for k in wave:
+                                for m in waveform_metrics:
+                                    wave[k][m].append(float(wm[k][e, EM.METRIC_ORDER.index(m)]))
+                        done_eps += 1
+                    for t in (cur_mono, cur_mem, cur_rew, cur_steps):
+                        t.mul_(not_done)
+        if was_training:
+            ac.train()
+        if had_phase is not None:
+            self.envs.include_phase = had_phase
+        self._next_cache = None
+        agg = {k: {"mean": float(np.mean(v)), "std": float(np.std(v))} for k, v in per_ep.items()}
+        for k in wave:
+            for m, v in wave[k].items():
+                if v:
+                    agg["%s_%s" % (k, m)] = {"mean": float(np.mean(v)), "std": float(np.std(v))}
+        agg["num_episodes"] = done_eps
+        return agg
+
     def train(self, num_cycles):
         out = []
         for _ in range(num_cycles):
