@@ -329,6 +329,15 @@ int m2h_stft_post(const float* spec, float* mag_out, float* phase_out, int B, in
 int m2h_istft_pre(const float* mag, const float* phase, float* rows, int B, int C, int c, int T, int nb, int ldr, m2h_stream stream);
 int m2h_istft_ola(const float* frames, const float* window, float* y, int S, int T, int n_fft, int hop, int ldf, int length, m2h_stream stream);
 
+/* RIR-convolution feeder glue (pretrain/datasets/dataset.py:178-186,214-216; habitat_audio/simulator_train.py:416-424).
+ * m2h_feeder_round_mix: takes the "same"-mode window [start, start+L) of S full linear convolutions (rows of ldfull floats),
+ * applies np.round -> int16 -> float32 / 32768, optionally stores it (conv_out [S][L], NULL to skip) and accumulates it into
+ * mix [S][L] (first != 0: overwrite), scaling the accumulated mixture by mix_scale (1 / num_sources on the last source).
+ * m2h_rms_normalize: mag[s] *= norm / sqrt(mean(mag[s]^2)) unless that RMS is 0 (GT_MONO_MAG_NORM, dataset.py:205-206). */
+int m2h_feeder_round_mix(const float* full, int ldfull, int start, float* conv_out, float* mix, int S, int L, int first, float mix_scale,
+                         m2h_stream stream);
+int m2h_rms_normalize(float* mag, int S, int n, float norm, m2h_stream stream);
+
 /* Waveform quality metrics (common/eval_metrics.py:12-166, scale_bss_eval / evaluate_helper for the single reference source
  * the evaluation uses; preprocess :170-196 removes every signal's mean and averages the mixture's channels).
  * ref, est, mix_l, mix_r: [S][L] waveforms (mix_r may be NULL for a mono mixture).

@@ -206,6 +206,41 @@ __global__ __launch_bounds__(1024) void bss_metrics_kernel(const float* __restri
   }
 }
 
+// RIR-convolution feeder glue (dataset.py:178-186,214-216; simulator_train.py:416-424): the "same"-mode slice of the full
+// convolution, np.round (half to even) -> int16 (wrapping, as numpy's astype) -> float32 * (1/32768); the per-source result
+// is written (GT binaural waveform of source 0 feeds the GT spectrogram) and accumulated into the mixture, which the caller
+// divides by the number of sources through `mix_scale` on the last source.
+//   full [S][ldfull] = full linear convolution (S = clips * 2 channels), conv_out [S][L] (may be NULL), mix [S][L]
+__global__ __launch_bounds__(256) void feeder_round_mix_kernel(const float* __restrict__ full, int ldfull, int start, float* __restrict__ conv_out,
+                                                               float* __restrict__ mix, int S, int L, int first, float mix_scale) {
+  const size_t total = (size_t)S * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % L);
+    const size_t s = i / L;
+    const float v = full[s * ldfull + start + n];
+    const int r = (int)rintf(v);                 // np.round: half to even
+    const float q = (float)(short)r * (1.f / 32768.f);
+    if (conv_out != nullptr) conv_out[i] = q;
+    const float acc = first ? q : mix[i] + q;
+    mix[i] = acc * mix_scale;
+  }
+}
+
+// gt mono magnitude normalisation (dataset.py:205-206): mag *= norm / sqrt(mean(mag^2)) when that RMS is non-zero.
+// One 1024-thread block per clip over n = F*T elements.
+__global__ __launch_bounds__(1024) void rms_normalize_kernel(float* __restrict__ mag, int n, float norm) {
+  __shared__ double sh[16];
+  float* p = mag + (size_t)blockIdx.x * n;
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) a += p[i] * p[i];
+  const double ms = block_sum_d(a, sh) / n;
+  const float rms = sqrtf((float)ms);
+  if (rms != 0.f) {
+    const float k = norm / rms;
+    for (int i = threadIdx.x; i < n; i += 1024) p[i] *= k;
+  }
+}
+
 static inline unsigned sgrid(size_t total) {
   size_t g = (total + 255) / 256;
   if (g > 8192) g = 8192;
@@ -242,6 +277,20 @@ int m2h_istft_ola(const float* frames, const float* window, float* y, int S, int
   M2H_REQUIRE(frames && window && y && S > 0 && T > 0 && n_fft > 1 && hop > 0 && ldf >= n_fft && length > 0, "istft_ola: bad arguments");
   hipLaunchKernelGGL(istft_ola_kernel, dim3(sgrid((size_t)S * length)), dim3(256), 0, as_stream(stream), frames, window, y, S, T, n_fft, hop, ldf, length);
   return launch_status("istft_ola");
+}
+
+int m2h_feeder_round_mix(const float* full, int ldfull, int start, float* conv_out, float* mix, int S, int L, int first, float mix_scale,
+                          m2h_stream stream) {
+  M2H_REQUIRE(full && mix && S > 0 && L > 0 && start >= 0 && start + L <= ldfull, "feeder_round_mix: bad arguments");
+  hipLaunchKernelGGL(feeder_round_mix_kernel, dim3(sgrid((size_t)S * L)), dim3(256), 0, as_stream(stream), full, ldfull, start, conv_out, mix, S, L,
+                     first, mix_scale);
+  return launch_status("feeder_round_mix");
+}
+
+int m2h_rms_normalize(float* mag, int S, int n, float norm, m2h_stream stream) {
+  M2H_REQUIRE(mag && S > 0 && n > 0, "rms_normalize: bad arguments");
+  hipLaunchKernelGGL(rms_normalize_kernel, dim3(S), dim3(1024), 0, as_stream(stream), mag, n, norm);
+  return launch_status("rms_normalize");
 }
 
 int m2h_bss_metrics(const float* ref, const float* est, const float* mix_l, const float* mix_r, float* out, int S, int L, m2h_stream stream) {

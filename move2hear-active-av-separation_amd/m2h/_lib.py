@@ -140,6 +140,8 @@ SIGNATURES = {
     "m2h_istft_pre": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "m2h_istft_ola": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "m2h_bss_metrics": [_P, _P, _P, _P, _P, _I, _I, _P],
+    "m2h_feeder_round_mix": [_P, _I, _I, _P, _P, _I, _I, _I, _F, _P],
+    "m2h_rms_normalize": [_P, _I, _I, _F, _P],
     "m2h_unet_fwd_workspace_bytes": [_I, _I, _I],
     "m2h_unet_fwd": [ctypes.POINTER(UnetWeights), _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P],
     "m2h_gather_envs": [_P, _P, _P, _I, _I, _I, _Z, _P],

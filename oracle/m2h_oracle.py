@@ -532,3 +532,35 @@ def np_waveform_metrics(gt_wave, est_wave, mix_lr, dtype=None):
     si_sdr, si_sir, si_sar, sd_sdr, snr, srr = est
     return np.array([si_sdr, si_sir, si_sar, sd_sdr, snr, srr, si_sdr - mix[0], sd_sdr - mix[3], snr - mix[4],
                      si_sir - mix[1], si_sar - mix[2]], np.float64)
+
+
+# ==============================================================================================
+# N1: RIR-convolution feeder (pretrain/datasets/dataset.py:162-228), numpy/scipy restatement
+# ==============================================================================================
+def np_compute_audiospects(mono_sources, rirs, gt_mono_mag_norm=0.0):
+    """mono_sources [S][L] int16-valued, rirs [S][Lr][2] float32 -> (log1p mixed mag [512,T,2], gt_bin_mag [512,T,2],
+    gt_mono_mag [512,T,1], mixed waveform [2,L], per-source int16 waveforms) following compute_audiospects line by line
+    (scipy.signal.fftconvolve mode "same"; np.round -> int16 -> float32 / 32768; librosa.stft restated by np_stft)."""
+    import numpy as np
+    from scipy.signal import fftconvolve
+    gt_mono_mag, gt_bin_mag = None, None
+    mixed = 0
+    per_source = []
+    for idx in range(len(mono_sources)):
+        mono_audio = np.asarray(mono_sources[idx])
+        binaural_rir = np.asarray(rirs[idx])
+        conv = np.array([fftconvolve(mono_audio, binaural_rir[:, ch], mode="same") for ch in range(2)])
+        conv = np.round(conv).astype("int16").astype("float32")
+        conv *= (1 / 32768)
+        per_source.append(conv)
+        if idx == 0:
+            gt_bin_mag = np.stack([np.abs(np_stft(conv[0])), np.abs(np_stft(conv[1]))], axis=-1).astype("float32")
+            m = np.abs(np_stft(mono_audio.astype("float32") / 32768))
+            rms = np.power(np.mean(np.power(m, 2)), 0.5)
+            if gt_mono_mag_norm != 0.0 and rms != 0.:
+                m = m * gt_mono_mag_norm / rms
+            gt_mono_mag = m[..., None].astype("float32")
+        mixed = mixed + conv
+    mixed = mixed / len(mono_sources)
+    mixed_mag = np.stack([np.abs(np_stft(mixed[0])), np.abs(np_stft(mixed[1]))], axis=-1).astype("float32")
+    return np.log1p(mixed_mag), gt_bin_mag, gt_mono_mag, mixed, per_source
