@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--ddppo-cycles", type=int, default=2, help="timed DD-PPO cycles (0 = skip); one untimed warm-up cycle precedes them")
+    ap.add_argument("--train-steps", type=int, default=10, help="timed passive pre-training steps (0 = skip)")
+    ap.add_argument("--train-batch", type=int, default=64, help="pretrain_passive.yaml BATCH_SIZE")
+    ap.add_argument("--train-tm", type=int, default=32, help="time frames of the training clips (32 = 1 s, the reference's)")
     return ap.parse_args()
 
 
@@ -147,6 +150,32 @@ def run_ddppo(args, dev, rank, world, dist):
             "reference_cpu_env_steps_per_sec_survey_probe": 4.3}
 
 
+def run_passive_train(args, dev, rank):
+    """Secondary figure of SURVEY 8d config 2: the passive pre-training step (train-mode BN forward, U-Net backward, Adam) on
+    the reference's batch (pretrain_passive.yaml: 64 clips of 512x32) with the synthetic feeder; replicas only across GPUs
+    (train-mode BN), so every rank runs the same-size job and the rate is per replica."""
+    from m2h.pretrain.passive.passive_trainer import PassiveTrainer, passive_config
+    cfg = passive_config(BATCH_SIZE=args.train_batch, TM=args.train_tm, SEED=3 + rank)
+    tr = PassiveTrainer(cfg, dev)
+    tr.setup()
+    batch = tr.feeders["train"].batch()
+    for _ in range(2):
+        tr.train_batch(*batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        losses = tr.train_batch(*batch)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    gf = (0.4226 if args.train_tm == 32 else 0.4226 * args.train_tm / 32) * 3.0   # SURVEY 8d: training step ~ 3x the forward
+    return {"metric": "passive_train_spectrograms_per_sec", "value": round(args.train_batch * args.train_steps / el, 1),
+            "unit": "spectrograms/s", "ms_per_step": round(1e3 * el / args.train_steps, 3), "batch": args.train_batch,
+            "time_frames": args.train_tm, "steps": args.train_steps,
+            "algorithmic_tflops": round(gf * args.train_batch * args.train_steps / el / 1e3, 2),
+            "last_losses": [round(float(x), 5) for x in losses],
+            "what": "PassiveTrainer.train_batch: both U-Nets forward in train-mode BN, L1 losses, full backward, FlatAdam step"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -248,6 +277,7 @@ def main():
                   for k, v in per_layer.items()}
 
     ddppo = run_ddppo(args, dev, rank, world, dist) if args.ddppo_cycles > 0 else None
+    ptrain = run_passive_train(args, dev, rank) if args.train_steps > 0 else None
 
     if rank != 0:
         if dist is not None:
@@ -272,6 +302,7 @@ def main():
                    "weights": "synthetic (m2h.synthetic seed 1), reference architecture 33.47 M params"},
         "roofline": roofline,
         "ddppo": ddppo,
+        "passive_train": ptrain,
         "cpu_baseline": cpu,
         "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
         "layers": layers,
