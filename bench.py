@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--ddppo-cycles", type=int, default=2, help="timed DD-PPO cycles (0 = skip); one untimed warm-up cycle precedes them")
+    ap.add_argument("--math", choices=["fp32", "bf16x3"], default="bf16x3",
+                    help="arithmetic of the conv engine in the timed U-Net pair: fp32 MFMA (exact products) or bf16x3 split products")
     ap.add_argument("--train-steps", type=int, default=10, help="timed passive pre-training steps (0 = skip)")
     ap.add_argument("--train-batch", type=int, default=64, help="pretrain_passive.yaml BATCH_SIZE")
     ap.add_argument("--train-tm", type=int, default=32, help="time frames of the training clips (32 = 1 s, the reference's)")
@@ -202,34 +204,36 @@ def main():
             mono = pol.convert_bin2mono(masks, mixed_audio=mix)
         return masks, mono
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    PEAK_BF16 = 2500.0   # dense bf16 MFMA peak, TFLOP/s (MI355X_MICROARCH.md)
 
-    sink = None if args.no_kernel_timing else []
-    ops.set_timing(sink)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    ops.set_timing(None)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_run(mode, steps, warmup, with_events):
+        """W untimed + K timed steps of the pair in the given math mode -> (elapsed s, HIP-event sink or None)."""
+        ops.set_math_mode(ops.MATH_BF16X3 if mode == "bf16x3" else ops.MATH_FP32)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        sink = [] if with_events else None
+        ops.set_timing(sink)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        ops.set_timing(None)
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, sink
 
-    # per-kernel accounting from the HIP events of the timed region
-    roofline = None
-    layers = None
-    if sink:
-        fam = {}
-        per_layer = {}
+    def account(sink, steps, mode):
+        """per-kernel accounting from the HIP events of a timed region -> (roofline dict, per-layer dict)"""
+        fam, per_layer = {}, {}
         for name, meta, e0, e1 in sink:
             ms = e0.elapsed_time(e1)
             k = meta.get("kernel", name)
@@ -254,27 +258,63 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                tj = json.load(f)
+                tj = json.load(f).get(mode, {})
             traffic, traffic_src = tj.get("traffic_bytes_per_launch"), tj.get("source")
+        if mode == "bf16x3":
+            # every algorithmic product is three bf16 MFMA products: the ceiling of this formulation is a third of the bf16 peak
+            peak = PEAK_BF16 / 3.0
+            kern = ("m2h::igemm_f32_kernel<..., SPLIT=1> (all instantiations): fp32 operands split to bf16 hi+lo on the way into LDS, "
+                    "hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16, fp32 accumulate")
+        else:
+            peak = PEAK_F32_MFMA_TFLOPS
+            kern = "m2h::igemm_f32_kernel (all instantiations; MFMA f32 32x32x2 / 16x16x4 implicit-GEMM conv)"
         roofline = {
-            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": traffic,
             "traffic_unit": "HBM bytes per launch of the dominant instantiation (2*FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
-            "kernel": "m2h::igemm_f32_kernel (all instantiations; MFMA f32 32x32x2 implicit-GEMM conv)",
-            "launches_per_step": sum(v["launches"] for v in igemm.values()) // args.steps,
-            "kernel_ms_per_step": round(tot_ms / args.steps, 4),
-            "algorithmic_gflop_per_step": round(tot_fl / args.steps / 1e9, 3),
+            "kernel": kern,
+            "launches_per_step": sum(v["launches"] for v in igemm.values()) // steps,
+            "kernel_ms_per_step": round(tot_ms / steps, 4),
+            "algorithmic_gflop_per_step": round(tot_fl / steps / 1e9, 3),
             "dominant_instantiation": {
                 "name": dom[0], "avg_launch_us": round(1e3 * dom[1]["ms"] / dom[1]["launches"], 2),
-                "launches_per_step": dom[1]["launches"] // args.steps,
+                "launches_per_step": dom[1]["launches"] // steps,
                 "achieved_tflops": round(dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12, 2)},
-            "by_instantiation": {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // args.steps,
+            "by_instantiation": {k: {"ms_per_step": round(v["ms"] / steps, 4), "launches_per_step": v["launches"] // steps,
                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
                                      "algorithmic_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
                                  for k, v in fam.items()},
         }
+        if mode == "bf16x3":
+            roofline["peak_note"] = "bf16 dense MFMA peak 2500 TFLOP/s / 3 MFMA products per algorithmic product"
+            roofline["executed_bf16_mfma_tflops"] = round(3.0 * ach, 1)
+            roofline["frac_of_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 3)
         layers = {k: {"us": round(1e3 * v["ms"] / v["n"], 1), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None}
                   for k, v in per_layer.items()}
+        return roofline, layers
+
+    # the headline run, then the other arithmetic beside it (fewer steps), then the distance between the two results
+    other = "fp32" if args.math == "bf16x3" else "bf16x3"
+    elapsed, sink = timed_run(args.math, args.steps, args.warmup, not args.no_kernel_timing)
+    roofline, layers = account(sink, args.steps, args.math) if sink else (None, None)
+    o_steps = max(2, args.steps // 3)
+    o_elapsed, o_sink = timed_run(other, o_steps, 1, not args.no_kernel_timing)
+    o_roof, _ = account(o_sink, o_steps, other) if o_sink else (None, None)
+    ops.set_math_mode(ops.MATH_FP32)
+    m_a, mono_a = step()
+    ops.set_math_mode(ops.MATH_BF16X3)
+    m_b, mono_b = step()
+    ops.set_math_mode(ops.MATH_FP32)
+    em = torch.expm1(mix)
+    rel = lambda x, y: float(((x - y).abs().sum() / y.abs().sum()).item())  # noqa: E731
+    other_mode = {
+        "math": other, "value": round(world * args.batch * o_steps / o_elapsed, 1), "unit": "spectrograms/s", "steps": o_steps,
+        "ms_per_step": round(1e3 * o_elapsed / o_steps, 3),
+        "roofline": {k: o_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms_per_step", "dominant_instantiation")} if o_roof else None,
+    }
+    parity = {"what": "rel-L1 of the bf16x3 result against the fp32-MFMA result on the benchmark batch (contract: 1e-3 vs the reference)",
+              "pred_bin": rel(m_b * em, m_a * em), "pred_mono": rel(mono_b, mono_a)}
+    del m_a, m_b, mono_a, mono_b, em
 
     ddppo = run_ddppo(args, dev, rank, world, dist) if args.ddppo_cycles > 0 else None
     ptrain = run_passive_train(args, dev, rank) if args.train_steps > 0 else None
@@ -295,12 +335,16 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": ("bf16x3 (fp32 tensors; each product = hi*hi + hi*lo + lo*hi of bf16 halves on the bf16 MFMA pipe, fp32 accumulate)"
+                  if args.math == "bf16x3" else "f32"),
+        "data": "synthetic",
         "config": {"workload": "passive U-Net separator pair forward (get_binSepMasks + convert_bin2mono, eval-BN), "
                                "batch %d/GPU of 512x%d binaural log-magnitude spectrograms, inputs resident in HBM" % (args.batch, args.tm),
                    "batch_per_gpu": args.batch, "n_freq": 512, "time_frames": args.tm, "parallelism": "dp%d (batch-sharded, no collective)" % world,
                    "weights": "synthetic (m2h.synthetic seed 1), reference architecture 33.47 M params"},
         "roofline": roofline,
+        "other_math_mode": other_mode,
+        "math_mode_parity": parity,
         "ddppo": ddppo,
         "passive_train": ptrain,
         "cpu_baseline": cpu,

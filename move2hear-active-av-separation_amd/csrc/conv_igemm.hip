@@ -68,6 +68,9 @@ struct IGemmP {
 __device__ unsigned long long g_clock_dbg[8192][6];
 #endif
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 constexpr int BK = 32;   // k-tile depth (floats)
 constexpr int LDK = 36;  // padded LDS row (floats): 144 B, keeps 16-B alignment, conflict-free b128 reads
 
@@ -94,8 +97,16 @@ __device__ __forceinline__ void decode_row(const IGemmP& p, int m, int ph, int p
 // (tap, source) segment, so the whole k decode is SCALAR (SGPR) work and a load's address is `uniform base + per-lane 32-bit
 // offset` with the per-lane part recomputed only when the segment changes (every C/32 tiles).  The generic path decodes k per
 // lane (any C % 4 == 0) and costs ~250 vector instructions per k-tile, which made the k-loop issue-bound beside 64 MFMAs.
-template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32, int FAST = 0>
-__global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
+//
+// SPLIT = 1 ("bf16x3" math): fp32 operands are split on their way into LDS into bf16 high and low parts (x = hi + lo to 2^-17
+// relative) and each product a*b is formed as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix pipe with fp32 accumulation
+// (the dropped a_lo*b_lo term is 2^-16 of the dropped precision again): three bf16 MFMAs replace sixteen (32x32) or eight
+// (16x16) fp32 MFMAs per fragment and 32-deep k-tile -- the bf16 pipe is 16x the fp32 one -- at ~16 mantissa bits per product
+// instead of 24.  Tensors in HBM stay fp32; the LDS row keeps its 144-byte stride ([hi 64 B | lo 64 B | pad]) and the fragment
+// reads are byte-for-byte those of the fp32 path.  Measured end to end on the U-Net pair: rel-L1 1e-5 vs the fp32 reference
+// (plain bf16 operands: 4e-3..6e-3, outside the 1e-3 contract).
+template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32, int FAST = 0, int SPLIT = 0>
+__global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGemmP p) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
   constexpr int FM = TM / FR, FN = TN / FR;  // MFMA fragments per wave
@@ -328,14 +339,32 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
       for (int j = 0; j < BR; ++j) load_b(set, j);
     }
   };
+  // SPLIT: [hi bf16 x 32 | lo bf16 x 32] per row; this thread's four k-values land at byte seg*8 of each half
+  auto store_split = [&](float* rowp, f32x4 v) {
+    const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+    const f32x4 hf = __builtin_convertvector(hi, f32x4);
+    const bf16x4 lo = __builtin_convertvector(v - hf, bf16x4);
+    char* base = reinterpret_cast<char*>(rowp) + seg * 8;
+    *reinterpret_cast<bf16x4*>(base) = hi;
+    *reinterpret_cast<bf16x4*>(base + 64) = lo;
+  };
   auto store_tile = [&](int set, int buf) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i)
-      *reinterpret_cast<f32x4*>(&As[buf][(srow + 32 * i) * LDK + seg * 4]) = (okmask[set] & (1u << i)) ? ra[set][i] : zero4;
+    for (int i = 0; i < AR; ++i) {
+      const f32x4 v = (okmask[set] & (1u << i)) ? ra[set][i] : zero4;
+      if constexpr (SPLIT)
+        store_split(&As[buf][(srow + 32 * i) * LDK], v);
+      else
+        *reinterpret_cast<f32x4*>(&As[buf][(srow + 32 * i) * LDK + seg * 4]) = v;
+    }
 #pragma unroll
-    for (int j = 0; j < BR; ++j)
-      *reinterpret_cast<f32x4*>(&Bs[buf][(srow + 32 * j) * LDK + seg * 4]) =
-          (FAST || (okmask[set] & (1u << (8 + j)))) ? rb[set][j] : zero4;
+    for (int j = 0; j < BR; ++j) {
+      const f32x4 v = (FAST || (okmask[set] & (1u << (8 + j)))) ? rb[set][j] : zero4;
+      if constexpr (SPLIT)
+        store_split(&Bs[buf][(srow + 32 * j) * LDK], v);
+      else
+        *reinterpret_cast<f32x4*>(&Bs[buf][(srow + 32 * j) * LDK + seg * 4]) = v;
+    }
   };
 
   const int frow = lane & (FR - 1);  // fragment row (A: pixel, B: channel)
@@ -362,12 +391,37 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
           else
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[slot][mi][j], fb[slot][ni][j], acc[mi][ni], 0, 0, 0);
   };
+  // SPLIT: the 16-byte fragment reads are the same four (FR 32) / two (FR 16) groups; group g < NG/2 holds the hi parts of
+  // k-step g, group g + NG/2 the lo parts.  Per step: hi*hi + hi*lo + lo*hi (small terms first).
+  auto mfma_bf16 = [&](const f32x4& a, const f32x4& b, AccT& c) {
+    if constexpr (FR == 32)
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  };
   auto mfma_tile = [&](int buf) {
-    read_frags(buf, 0, 0);
+    if constexpr (SPLIT) {
+      constexpr int NSTEP = NG / 2;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      if (g + 1 < NG) read_frags(buf, g + 1, (g + 1) & 1);
-      mfma_group(g & 1);
+      for (int st = 0; st < NSTEP; ++st) {
+        read_frags(buf, st, 0);            // hi
+        read_frags(buf, st + NSTEP, 1);    // lo
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < FN; ++ni) {
+            mfma_bf16(fa[1][mi], fb[0][ni], acc[mi][ni]);
+            mfma_bf16(fa[0][mi], fb[1][ni], acc[mi][ni]);
+            mfma_bf16(fa[0][mi], fb[0][ni], acc[mi][ni]);
+          }
+      }
+    } else {
+      read_frags(buf, 0, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) read_frags(buf, g + 1, (g + 1) & 1);
+        mfma_group(g & 1);
+      }
     }
   };
   // One k-tile t (straight-line, no conditionals): issue the loads of tile t+2 into register set `par`, run tile t's MFMAs
@@ -619,6 +673,7 @@ int g_wide_stages = 0;    // 1 | 2: LDS stage count of the 128x128 config (0 = 2
 int g_skinny = 0;         // -1: never use the 32/64-row tiles
 int g_extra_lds = 0;      // tuning experiment: dynamic LDS bytes added to every launch (lowers blocks/CU)
 int g_phase_major = 0;    // -1: transposed-conv phases as grid z (four passes over the input) instead of interleaved
+int g_math_mode = 0;      // 0: fp32 MFMA (exact fp32 products); 1: bf16x3 split products (scalar-loader shapes only)
 int g_fast_loader = 0;    // -1: always use the generic (per-lane k decode) loader
 int g_narrow16 = 0;       // -1: never use the 16-wide (v_mfma_f32_16x16x4_f32) tile for N <= 16
 
@@ -673,7 +728,9 @@ static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   const int phases = p.convT ? 4 : 1;
   p.pmaj = (p.convT && g_phase_major >= 0 && nblk * 4 <= 0x7fffffffL) ? 1 : 0;
   dim3 grid((unsigned)(p.pmaj ? nblk * 4 : nblk), (unsigned)p.S, p.pmaj ? 1 : phases);
-  if (fast)
+  if (fast && g_math_mode == 1)
+    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1, 1>), grid, dim3(256), (size_t)g_extra_lds, st, p);
+  else if (fast)
     hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1>), grid, dim3(256), (size_t)g_extra_lds, st, p);
   else
     hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 0>), grid, dim3(256), (size_t)g_extra_lds, st, p);

@@ -56,6 +56,19 @@ def debug_set(knob, value):
     _lib.check(_lib.load().m2h_debug_set(int(knob), int(value)), "m2h_debug_set")
 
 
+MATH_FP32, MATH_BF16X3 = 0, 1
+
+
+def set_math_mode(mode):
+    """Process-wide arithmetic of the igemm forward engine (m2h_debug_set knob 14).
+    MATH_FP32 (default): fp32 matrix instructions, exact fp32 products.  MATH_BF16X3: fp32 operands split into bf16 hi + lo
+    inside the kernel, products hi*hi + hi*lo + lo*hi on the bf16 matrix pipe with fp32 accumulation (~16 mantissa bits per
+    product; tensors in HBM stay fp32).  Applies to shapes the scalar loader takes (channel counts multiples of 32)."""
+    if mode not in (MATH_FP32, MATH_BF16X3):
+        raise ValueError("math mode must be ops.MATH_FP32 or ops.MATH_BF16X3")
+    debug_set(14, mode)
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
