@@ -90,6 +90,147 @@ __device__ __forceinline__ void decode_row(const IGemmP& p, int m, int ph, int p
   bc = b * 16 + ch * 3 + cw;
 }
 
+// Fused epilogue shared by the LDS-staged kernel and the tap-sharing transposed-conv kernel: class-plane bias, BN scale/shift
+// or bias, LeakyReLU/ReLU and the NHWC / de-sliced store; with head_w, the last decoder stage's 1x1 head on the on-chip tile.
+// As0 / Bs0: LDS scratch of at least BM*LDK and max(BN,32)*LDK floats (the main loop's tiles, free by now).
+template <int BM, int BN, int WM, int WN, int FR, typename AccT>
+__device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM / WM / FR][BN / WN / FR], float* As0, float* Bs0,
+                                               const int* ri_out, const int* ri_bc, int n0, int tid) {
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int FM = TM / FR, FN = TN / FR;
+  constexpr int GK = FR == 32 ? 8 : 16;
+  constexpr int NE = FR == 32 ? 16 : 4;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int frow = lane & (FR - 1);
+  const int fk = (lane / FR) * 4;
+  auto row_of = [&](int e) { return FR == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : (lane >> 4) * 4 + e; };
+  const int col = lane & (FR - 1);
+  if constexpr (BN <= 32 && WM == 4) {
+    if (p.head_w != nullptr) {
+      // Last decoder stage + head in one kernel (separator_cnn.py:133-134,163-168): y = ReLU(BN(convT)) stays on chip, a second
+      // small MFMA pass applies the 1x1 conv, the result is transposed through LDS and stored de-sliced with one contiguous
+      // (s, pixel-run) segment per wave instruction instead of 4-byte scatters.
+      constexpr int LDT = 129;       // [n'][m] staging stride: conflict-free column writes
+      constexpr int NGH = FR / GK;   // fragment groups of the FR-deep head contraction
+      float* Y = As0;
+      float* Wh = Bs0;
+      __syncthreads();  // every wave is done with the main loop's LDS tiles
+      {
+        const int n = col;
+        const float scn = (p.scale != nullptr && n < p.N) ? p.scale[n] : 1.f;
+        const float shn = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const int lrow = wm * TM + mi * FR + row_of(e);
+            float v = 0.f;
+            if (n < p.N) {
+              v = acc[mi][0][e] * scn + shn;
+              v = v > 0.f ? v : v * p.slope;
+            }
+            Y[lrow * LDK + n] = v;
+          }
+        for (int idx = tid; idx < FR * FR; idx += 256) {  // FR x FR head matrix, zero padded
+          const int n2 = idx / FR, k = idx % FR;
+          Wh[n2 * LDK + k] = (n2 < p.N && k < p.N) ? p.head_w[n2 * p.N + k] : 0.f;
+        }
+      }
+      __syncthreads();
+      AccT acc2[FM];
+#pragma unroll
+      for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) acc2[mi][e] = 0.f;
+#pragma unroll
+      for (int g = 0; g < NGH; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&Wh[frow * LDK + g * GK + fk]);
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(&Y[(wm * TM + mi * FR + frow) * LDK + g * GK + fk]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if constexpr (FR == 32)
+              acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc2[mi], 0, 0, 0);
+            else
+              acc2[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc2[mi], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();  // Y fully consumed before it is overwritten by the transposed staging
+      float* Tt = Y;
+      const float hb = col < p.N ? p.head_b[col] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) Tt[col * LDT + wm * TM + mi * FR + row_of(e)] = acc2[mi][e] + hb;
+      __syncthreads();
+      const size_t plane2 = (size_t)p.Ho * p.Wo;
+      const int Cc2 = p.N >> 4;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int i = tid + 256 * it;
+        const int s = i >> 7, m = i & 127;
+        const int out = ri_out[m];
+        if (out < 0) continue;
+        float* dptr = p.dst + ((size_t)out + (size_t)s * plane2) * Cc2;
+        if (Cc2 == 2) {
+          float2 v2;
+          v2.x = Tt[s * LDT + m];
+          v2.y = Tt[(16 + s) * LDT + m];
+          *reinterpret_cast<float2*>(dptr) = v2;
+        } else {
+          dptr[0] = Tt[s * LDT + m];
+        }
+      }
+      return;
+    }
+  }
+  float sc[FN], sh[FN];
+  int nn[FN];
+#pragma unroll
+  for (int ni = 0; ni < FN; ++ni) {
+    const int n = n0 + wn * TN + ni * FR + col;
+    nn[ni] = n;
+    sc[ni] = (p.scale != nullptr && n < p.N) ? p.scale[n] : 1.f;
+    sh[ni] = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
+  }
+  const size_t plane = (size_t)p.Ho * p.Wo;
+  const int Cc = p.N >> 4;
+#pragma unroll
+  for (int mi = 0; mi < FM; ++mi) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int lrow = wm * TM + mi * FR + row_of(e);
+      const int out = ri_out[lrow];
+      if (out < 0) continue;
+      const int bc = ri_bc[lrow];
+      float cv = 0.f;
+      const float* ctab = nullptr;
+      if (p.cls_table != nullptr) {
+        cv = p.cls_val[bc >> 4];
+        ctab = p.cls_table + (size_t)(bc & 15) * p.N;
+      }
+#pragma unroll
+      for (int ni = 0; ni < FN; ++ni) {
+        const int n = nn[ni];
+        if (n >= p.N) continue;
+        float v = acc[mi][ni][e];
+        if (ctab != nullptr) v += cv * ctab[n];
+        v = v * sc[ni] + sh[ni];
+        v = v > 0.f ? v : v * p.slope;
+        if (p.out_mode == M2H_OUT_NHWC) {
+          p.dst[(size_t)out * p.ldc + n] = v;
+        } else {
+          const int c = n >> 4, s = n & 15;
+          p.dst[((size_t)out + (size_t)s * plane) * Cc + c] = v;
+        }
+      }
+    }
+  }
+}
+
 // FR = MFMA fragment edge: 32 (v_mfma_f32_32x32x2_f32, 8 k per 16-byte LDS read) or 16 (v_mfma_f32_16x16x4_f32, 16 k per read;
 // used for N <= 16 so that a 16-channel layer does not pay for a half-empty 32-wide tile).  Same FLOP rate per cycle.
 //
@@ -500,130 +641,204 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
   }
 
   // ---- fused epilogue ----
-  const int col = lane & (FR - 1);
-  if constexpr (BN <= 32 && WM == 4) {
-    if (p.head_w != nullptr) {
-      // Last decoder stage + head in one kernel (separator_cnn.py:133-134,163-168): y = ReLU(BN(convT)) stays on chip, a second
-      // small MFMA pass applies the 1x1 conv, the result is transposed through LDS and stored de-sliced with one contiguous
-      // (s, pixel-run) segment per wave instruction instead of 4-byte scatters.
-      constexpr int LDT = 129;       // [n'][m] staging stride: conflict-free column writes
-      constexpr int NGH = FR / GK;   // fragment groups of the FR-deep head contraction
-      float* Y = &As[0][0];
-      float* Wh = &Bs[0][0];
-      __syncthreads();  // every wave is done with the main loop's LDS tiles
-      {
-        const int n = col;
-        const float scn = (p.scale != nullptr && n < p.N) ? p.scale[n] : 1.f;
-        const float shn = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
+  fused_epilogue<BM, BN, WM, WN, FR, AccT>(p, acc, &As[0][0], &Bs[0][0], ri_out, ri_bc, n0, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Tap-sharing transposed-conv kernel (bf16x3 math, N <= 64): one sub-pixel phase of ConvTranspose2d(4, 2, 1) is a 2x2-tap
+// stride-1 conv, and its four taps read the SAME input pixels shifted by one row / one column.  The LDS-staged engine above
+// treats each tap as its own k-tile and fetches the 128-pixel operand tile four times; with the cheap bf16 products that
+// re-fetch (L1/TA traffic, splits, LDS writes, barriers) is what the narrow late decoder stages spend their time on.  Here a
+// k-step is a 32-CHANNEL chunk: the block stages the (R+1) x (Wq+1) input pixels its 128 output pixels touch ONCE per chunk
+// (R = 128 / Wq image rows), plus the four taps' weight rows, and runs the four taps' MFMAs from row-shifted windows of that
+// one LDS image.  Per thread the global offsets are fixed for the whole kernel (only a uniform channel base advances).
+// Requires: conv_transpose, FAST channels, 128 % Wq == 0, Wq >= 32, Hq % (128 / Wq) == 0.  Tile, accumulators and epilogue
+// (incl. the fused head) are those of igemm_f32_kernel<128, BN, 4, 1, *, FR, 1, 1>.
+template <int BN, int FR>
+__global__ __launch_bounds__(256, 2) void convT_tap_kernel(const IGemmP p) {
+  constexpr int BM = 128, WM = 4, WN = 1;
+  constexpr int TM = BM / WM;                    // 32 rows per wave
+  constexpr int FM = TM / FR, FN = BN / FR;
+  constexpr int GK = FR == 32 ? 8 : 16;
+  constexpr int NG = BK / GK, NSTEP = NG / 2;
+  constexpr int NE = FR == 32 ? 16 : 4;
+  using AccT = typename std::conditional<FR == 32, f32x16, f32x4>::type;
+  constexpr int PMAX = 2 * 129;                  // staged input pixels: (R+1)*(Wq+1) <= 258 for Wq in {32, 64, 128}
+  constexpr int AR = (PMAX * 8 + 255) / 256;     // 16-byte loads per thread for the input image
+  constexpr int BROWS = 4 * BN;                  // weight rows per chunk (4 taps x BN channels)
+  constexpr int BRL = BROWS * 8 / 256;           // loads per thread for them
+  static_assert(BROWS * 8 % 256 == 0 && FM >= 1 && FN >= 1, "tile shape");
+  __shared__ __attribute__((aligned(16))) float As[PMAX * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[BROWS * LDK];
+  __shared__ int ri_out[BM], ri_bc[BM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & (FR - 1);
+  const int fk = (lane / FR) * 4;
+  const int seg = tid & 7, srow = tid >> 3;
+
+  // ---- block -> (m-tile, phase): phase fastest, m-tiles round-robin over the XCDs ----
+  const int L = blockIdx.x;
+  const int xcd = L & 7;
+  int idx = L >> 3;
+  const int phase = idx & 3;
+  idx >>= 2;
+  const int mt = idx * 8 + xcd;
+  if (mt >= p.MT) return;
+  const int m0 = mt * BM;
+  const int ph = phase >> 1, pw = phase & 1;
+  const int dh = 2 * ph - 1, dw = 2 * pw - 1;
+  const int hoff = dh < 0 ? dh : 0, woff = dw < 0 ? dw : 0;
+  const float* wbase = p.w + (size_t)phase * p.N * p.K;
+  const int Wq = p.Wq, W1 = Wq + 1;
+  const int R = BM / Wq;
+  const int P = (R + 1) * W1;
+  const int b0 = m0 / (p.Hq * Wq);
+  const int q0 = (m0 / Wq) % p.Hq;
+
+  for (int r = tid; r < BM; r += 256) {
+    const int m = m0 + r;
+    int out = -1, bc = 0;
+    if (m < p.M) {
+      int q, rr, b;
+      decode_row(p, m, ph, pw, q, rr, b, out, bc);
+    }
+    ri_out[r] = out;
+    ri_bc[r] = bc;
+  }
+
+  // ---- fixed per-thread geometry of the staged input image and weight rows ----
+  int pixA[AR];        // input pixel index (b, ih, iw) of staged row l = srow + 32 i, or -1
+  unsigned voffA[AR], voffB[BRL];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int l = srow + 32 * i;
+    const int qi = l / W1, rr = l - qi * W1;
+    const int ih = q0 + qi + hoff, iw = rr + woff;
+    const bool ok = l < P && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi && b0 < p.B;
+    pixA[i] = ok ? (b0 * p.Hi + ih) * p.Wi + iw : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < BRL; ++j) {
+    const int row = srow + 32 * j;               // tap * BN + n
+    const int tap = row / BN, n = min(row - tap * BN, p.N - 1);   // rows past N re-read row N-1 (never stored)
+    voffB[j] = ((unsigned)n * (unsigned)p.K + (unsigned)(tap * p.Ctot + seg * 4)) * 4u;
+  }
+  auto set_source = [&](int second) {
+    const int Cs = second ? p.C1 : p.C0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) voffA[i] = pixA[i] >= 0 ? ((unsigned)pixA[i] * (unsigned)Cs + (unsigned)(seg * 4)) * 4u : 0u;
+  };
+
+  AccT acc[FM][FN];
+#pragma unroll
+  for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < FN; ++ni)
+#pragma unroll
+      for (int e = 0; e < NE; ++e) acc[mi][ni][e] = 0.f;
+
+  // LDS rows of this lane's fragments for tap (0,0)-relative addressing: row(qi, r) = qi*W1 + r, tap adds (a*W1 + b)
+  int fragrow[FM];
+#pragma unroll
+  for (int mi = 0; mi < FM; ++mi) {
+    const int ml = wave * TM + mi * FR;          // first tile row of the fragment; FR <= Wq keeps it inside one image row
+    fragrow[mi] = (ml / Wq) * W1 + (ml % Wq) + frow;
+  }
+  int tapoff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) tapoff[t] = ((t >> 1) * dh - hoff) * W1 + ((t & 1) * dw - woff);
+
+  f32x4 ra[AR], rb[BRL];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  int c_ci = 0, c_second = 0, c_k = 0;           // channel offset inside the source, source, chunk index (uniform)
+  auto load_chunk = [&]() {
+    const char* baseA = reinterpret_cast<const char*>((c_second ? p.src1 : p.src0) + c_ci);
+    const char* baseB = reinterpret_cast<const char*>(wbase + (c_second ? p.C0 : 0) + c_ci);
+#pragma unroll
+    for (int i = 0; i < AR; ++i) ra[i] = *reinterpret_cast<const f32x4*>(baseA + voffA[i]);
+#pragma unroll
+    for (int j = 0; j < BRL; ++j) rb[j] = *reinterpret_cast<const f32x4*>(baseB + voffB[j]);
+  };
+  auto next_chunk = [&]() {
+    ++c_k;
+    c_ci += BK;
+    if (c_ci == (c_second ? p.C1 : p.C0) && !c_second && p.src1 != nullptr) {
+      c_second = 1;
+      c_ci = 0;
+      set_source(1);
+    }
+  };
+  auto store_split = [&](float* rowp, f32x4 v) {
+    const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+    const f32x4 hf = __builtin_convertvector(hi, f32x4);
+    const bf16x4 lo = __builtin_convertvector(v - hf, bf16x4);
+    char* base = reinterpret_cast<char*>(rowp) + seg * 8;
+    *reinterpret_cast<bf16x4*>(base) = hi;
+    *reinterpret_cast<bf16x4*>(base + 64) = lo;
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int l = srow + 32 * i;
+      if (l < PMAX) store_split(&As[l * LDK], pixA[i] >= 0 ? ra[i] : zero4);
+    }
+#pragma unroll
+    for (int j = 0; j < BRL; ++j) store_split(&Bs[(srow + 32 * j) * LDK], rb[j]);
+  };
+  auto mfma_bf16 = [&](const f32x4& a, const f32x4& b, AccT& c) {
+    if constexpr (FR == 32)
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  };
+  auto compute_chunk = [&]() {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        f32x4 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) {
+          const float* rp = &As[(fragrow[mi] + tapoff[t]) * LDK + fk];
+          ah[mi] = *reinterpret_cast<const f32x4*>(rp + st * GK);
+          al[mi] = *reinterpret_cast<const f32x4*>(rp + (st + NSTEP) * GK);
+        }
+#pragma unroll
+        for (int ni = 0; ni < FN; ++ni) {
+          const float* rp = &Bs[(t * BN + ni * FR + frow) * LDK + fk];
+          bh[ni] = *reinterpret_cast<const f32x4*>(rp + st * GK);
+          bl[ni] = *reinterpret_cast<const f32x4*>(rp + (st + NSTEP) * GK);
+        }
 #pragma unroll
         for (int mi = 0; mi < FM; ++mi)
 #pragma unroll
-          for (int e = 0; e < NE; ++e) {
-            const int lrow = wm * TM + mi * FR + row_of(e);
-            float v = 0.f;
-            if (n < p.N) {
-              v = acc[mi][0][e] * scn + shn;
-              v = v > 0.f ? v : v * p.slope;
-            }
-            Y[lrow * LDK + n] = v;
+          for (int ni = 0; ni < FN; ++ni) {
+            mfma_bf16(al[mi], bh[ni], acc[mi][ni]);
+            mfma_bf16(ah[mi], bl[ni], acc[mi][ni]);
+            mfma_bf16(ah[mi], bh[ni], acc[mi][ni]);
           }
-        for (int idx = tid; idx < FR * FR; idx += 256) {  // FR x FR head matrix, zero padded
-          const int n2 = idx / FR, k = idx % FR;
-          Wh[n2 * LDK + k] = (n2 < p.N && k < p.N) ? p.head_w[n2 * p.N + k] : 0.f;
-        }
-      }
-      __syncthreads();
-      AccT acc2[FM];
-#pragma unroll
-      for (int mi = 0; mi < FM; ++mi)
-#pragma unroll
-        for (int e = 0; e < NE; ++e) acc2[mi][e] = 0.f;
-#pragma unroll
-      for (int g = 0; g < NGH; ++g) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(&Wh[frow * LDK + g * GK + fk]);
-#pragma unroll
-        for (int mi = 0; mi < FM; ++mi) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(&Y[(wm * TM + mi * FR + frow) * LDK + g * GK + fk]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if constexpr (FR == 32)
-              acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc2[mi], 0, 0, 0);
-            else
-              acc2[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc2[mi], 0, 0, 0);
-          }
-        }
-      }
-      __syncthreads();  // Y fully consumed before it is overwritten by the transposed staging
-      float* Tt = Y;
-      const float hb = col < p.N ? p.head_b[col] : 0.f;
-#pragma unroll
-      for (int mi = 0; mi < FM; ++mi)
-#pragma unroll
-        for (int e = 0; e < NE; ++e) Tt[col * LDT + wm * TM + mi * FR + row_of(e)] = acc2[mi][e] + hb;
-      __syncthreads();
-      const size_t plane2 = (size_t)p.Ho * p.Wo;
-      const int Cc2 = p.N >> 4;
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int i = tid + 256 * it;
-        const int s = i >> 7, m = i & 127;
-        const int out = ri_out[m];
-        if (out < 0) continue;
-        float* dptr = p.dst + ((size_t)out + (size_t)s * plane2) * Cc2;
-        if (Cc2 == 2) {
-          float2 v2;
-          v2.x = Tt[s * LDT + m];
-          v2.y = Tt[(16 + s) * LDT + m];
-          *reinterpret_cast<float2*>(dptr) = v2;
-        } else {
-          dptr[0] = Tt[s * LDT + m];
-        }
-      }
-      return;
-    }
-  }
-  float sc[FN], sh[FN];
-  int nn[FN];
-#pragma unroll
-  for (int ni = 0; ni < FN; ++ni) {
-    const int n = n0 + wn * TN + ni * FR + col;
-    nn[ni] = n;
-    sc[ni] = (p.scale != nullptr && n < p.N) ? p.scale[n] : 1.f;
-    sh[ni] = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
-  }
-  const size_t plane = (size_t)p.Ho * p.Wo;
-  const int Cc = p.N >> 4;
-#pragma unroll
-  for (int mi = 0; mi < FM; ++mi) {
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int lrow = wm * TM + mi * FR + row_of(e);
-      const int out = ri_out[lrow];
-      if (out < 0) continue;
-      const int bc = ri_bc[lrow];
-      float cv = 0.f;
-      const float* ctab = nullptr;
-      if (p.cls_table != nullptr) {
-        cv = p.cls_val[bc >> 4];
-        ctab = p.cls_table + (size_t)(bc & 15) * p.N;
-      }
-#pragma unroll
-      for (int ni = 0; ni < FN; ++ni) {
-        const int n = nn[ni];
-        if (n >= p.N) continue;
-        float v = acc[mi][ni][e];
-        if (ctab != nullptr) v += cv * ctab[n];
-        v = v * sc[ni] + sh[ni];
-        v = v > 0.f ? v : v * p.slope;
-        if (p.out_mode == M2H_OUT_NHWC) {
-          p.dst[(size_t)out * p.ldc + n] = v;
-        } else {
-          const int c = n >> 4, s = n & 15;
-          p.dst[((size_t)out + (size_t)s * plane) * Cc + c] = v;
-        }
       }
     }
+  };
+
+  const int nch = p.Ctot / BK;
+  set_source(0);
+  load_chunk();
+  store_chunk();
+  __syncthreads();
+  for (int c = 0; c + 1 < nch; ++c) {
+    next_chunk();
+    load_chunk();
+    compute_chunk();
+    __syncthreads();   // everyone is done reading the stage
+    store_chunk();
+    __syncthreads();
   }
+  compute_chunk();
+  __syncthreads();     // the staged image becomes the epilogue's scratch
+
+  fused_epilogue<BM, BN, WM, WN, FR, AccT>(p, acc, As, Bs, ri_out, ri_bc, 0, tid);
 }
 
 // Split-K epilogue: sums the S partial slabs of one output element in a fixed order (deterministic) and applies the
@@ -674,6 +889,7 @@ int g_skinny = 0;         // -1: never use the 32/64-row tiles
 int g_extra_lds = 0;      // tuning experiment: dynamic LDS bytes added to every launch (lowers blocks/CU)
 int g_phase_major = 0;    // -1: transposed-conv phases as grid z (four passes over the input) instead of interleaved
 int g_math_mode = 0;      // 0: fp32 MFMA (exact fp32 products); 1: bf16x3 split products (scalar-loader shapes only)
+int g_tapshare = 0;       // -1: never use the tap-sharing transposed-conv kernel
 int g_fast_loader = 0;    // -1: always use the generic (per-lane k decode) loader
 int g_narrow16 = 0;       // -1: never use the 16-wide (v_mfma_f32_16x16x4_f32) tile for N <= 16
 
@@ -811,6 +1027,32 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
 
   p.ws = static_cast<float*>(a.workspace);
   const size_t wsb = a.workspace != nullptr ? a.workspace_bytes : 0;
+  // narrow transposed convs in bf16x3 math: the four taps of a phase share one staged input image (convT_tap_kernel)
+  if (p.convT && g_math_mode == 1 && g_tapshare >= 0 && p.fast_ok && p.N <= 64 && a.Wq >= 32 && 128 % a.Wq == 0 &&
+      a.Hq % (128 / a.Wq) == 0 && g_force_splitk <= 0 && g_phase_major >= 0 && M >= 128L * 256) {
+    p.MT = (int)((M + 127) / 128);
+    p.NT = 1;
+    p.S = 1;
+    const long nblk = ((long)p.MT + 7) / 8 * 8 * 4;
+    if (nblk <= 0x7fffffffL) {
+      const dim3 grid((unsigned)nblk), blk(256);
+      // measured (layer_bench, B=256, 512x256): N=16 368 -> 308 us, N=64 277 -> 249 us; N=32 no change (450 us: its block is
+      // dominated by the fixed costs around a 4-chunk loop), so the 32-wide stage stays on the staged engine unless forced
+      const bool use32 = g_tapshare > 0;
+      if (p.N <= 16 && g_narrow16 >= 0) {
+        hipLaunchKernelGGL((convT_tap_kernel<16, 16>), grid, blk, 0, st, p);
+        return launch_status("conv_igemm_f32 (tap-sharing convT)");
+      }
+      if (p.N > 32) {
+        hipLaunchKernelGGL((convT_tap_kernel<64, 32>), grid, blk, 0, st, p);
+        return launch_status("conv_igemm_f32 (tap-sharing convT)");
+      }
+      if (use32) {
+        hipLaunchKernelGGL((convT_tap_kernel<32, 32>), grid, blk, 0, st, p);
+        return launch_status("conv_igemm_f32 (tap-sharing convT)");
+      }
+    }
+  }
   int BM, BN;
   pick_tile(M, p.N, BM, BN);
   if (BM == 32) return launch_cfg<32, 128, 1, 4, 2>(p, wsb, st);
