@@ -106,7 +106,19 @@ typedef struct m2h_conv_args {
   size_t workspace_bytes; /* size of workspace; m2h_conv_igemm_workspace_bytes() says how much the launch can use */
   const float* head_w;    /* optional fused 1x1 head (N in {16,32}, M2H_OUT_DESLICE, workspace NULL): [N][N], applied after the */
   const float* head_b;    /*   activation; out = head_w . act(...) + head_b, stored de-sliced.  NULL = no head.                */
+  int operand_format;     /* bf16x3 math only, bit set of M2H_FMT_*: operands that already are in the split32 layout (below),  */
+                          /*   and whether dst is to be written in it.  0 = plain fp32 everywhere.                              */
 } m2h_conv_args;
+
+/* split32 layout (internal operand format of the bf16x3 math mode): every aligned group of 32 consecutive fp32 values of the
+ * innermost (channel / k) dimension is replaced, in place of its 128 bytes, by 32 bf16 high parts followed by 32 bf16 low
+ * parts (x = hi + lo, hi = bf16(x), lo = bf16(x - hi), round to nearest even).  Same footprint, strides and alignment as the
+ * fp32 tensor; the channel count must be a multiple of 32.  m2h_split32 converts; the conv engine reads it with
+ * M2H_FMT_SRC_SPLIT / M2H_FMT_W_SPLIT and writes it with M2H_FMT_DST_SPLIT (NHWC output, N % 32 == 0). */
+#define M2H_FMT_SRC_SPLIT 1
+#define M2H_FMT_W_SPLIT 2
+#define M2H_FMT_DST_SPLIT 4
+int m2h_split32(const float* src, float* dst, size_t count /* floats, multiple of 32 */, m2h_stream stream);
 
 int m2h_conv_igemm_f32(const m2h_conv_args* args /* host */, m2h_stream stream);
 

@@ -57,6 +57,8 @@ struct IGemmP {
   const float* head_w;  // fused 1x1 head (N <= 32, one n-tile): [N][N] weights applied to the activated tile, + head_b, de-sliced store
   const float* head_b;
   int fast_ok; // scalar-decode loader applicable (host check)
+  int presplit;  // both operands arrive in the split32 layout
+  int dst_split; // epilogue writes dst in the split32 layout (bf16x3 math, NHWC, N % 32 == 0)
   int pmaj;    // transposed conv: phase is folded into grid x (fastest) instead of grid z
   int S;       // split-K factor (grid y); S > 1: raw partial sums go to `ws`, the epilogue runs in splitk_epilogue_kernel
   float* ws;   // [phase][S][M][N] fp32 partial slabs (caller-owned workspace)
@@ -221,7 +223,18 @@ __device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM /
         v = v * sc[ni] + sh[ni];
         v = v > 0.f ? v : v * p.slope;
         if (p.out_mode == M2H_OUT_NHWC) {
-          p.dst[(size_t)out * p.ldc + n] = v;
+          if (p.dst_split) {
+            // split32 store: lanes (n even, n odd) pair up; the even lane writes both hi halves, the odd lane both lo halves
+            const __bf16 hb = (__bf16)v;
+            const __bf16 lb = (__bf16)(v - (float)hb);
+            const unsigned h16 = __builtin_bit_cast(unsigned short, hb), l16 = __builtin_bit_cast(unsigned short, lb);
+            const unsigned ph_ = __shfl_xor(h16, 1, 64), pl_ = __shfl_xor(l16, 1, 64);
+            const unsigned word = (n & 1) ? (pl_ | (l16 << 16)) : (h16 | (ph_ << 16));
+            unsigned* drow = reinterpret_cast<unsigned*>(p.dst + (size_t)out * p.ldc + (n & ~31));
+            drow[((n & 1) ? 16 : 0) + ((n & 31) >> 1)] = word;
+          } else {
+            p.dst[(size_t)out * p.ldc + n] = v;
+          }
         } else {
           const int c = n >> 4, s = n & 15;
           p.dst[((size_t)out + (size_t)s * plane) * Cc + c] = v;
@@ -239,7 +252,7 @@ __device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM /
 // offset` with the per-lane part recomputed only when the segment changes (every C/32 tiles).  The generic path decodes k per
 // lane (any C % 4 == 0) and costs ~250 vector instructions per k-tile, which made the k-loop issue-bound beside 64 MFMAs.
 //
-// SPLIT = 1 ("bf16x3" math): fp32 operands are split on their way into LDS into bf16 high and low parts (x = hi + lo to 2^-17
+// SPLIT = 1 | 2 ("bf16x3" math; 2 = both operands already arrive in the split32 layout, no conversion in the loop): fp32 operands are split on their way into LDS into bf16 high and low parts (x = hi + lo to 2^-17
 // relative) and each product a*b is formed as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix pipe with fp32 accumulation
 // (the dropped a_lo*b_lo term is 2^-16 of the dropped precision again): three bf16 MFMAs replace sixteen (32x32) or eight
 // (16x16) fp32 MFMAs per fragment and 32-deep k-tile -- the bf16 pipe is 16x the fp32 one -- at ~16 mantissa bits per product
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const f32x4 v = (okmask[set] & (1u << i)) ? ra[set][i] : zero4;
-      if constexpr (SPLIT)
+      if constexpr (SPLIT == 1)
         store_split(&As[buf][(srow + 32 * i) * LDK], v);
       else
         *reinterpret_cast<f32x4*>(&As[buf][(srow + 32 * i) * LDK + seg * 4]) = v;
@@ -501,7 +514,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
       const f32x4 v = (FAST || (okmask[set] & (1u << (8 + j)))) ? rb[set][j] : zero4;
-      if constexpr (SPLIT)
+      if constexpr (SPLIT == 1)
         store_split(&Bs[buf][(srow + 32 * j) * LDK], v);
       else
         *reinterpret_cast<f32x4*>(&Bs[buf][(srow + 32 * j) * LDK + seg * 4]) = v;
@@ -654,7 +667,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
 // one LDS image.  Per thread the global offsets are fixed for the whole kernel (only a uniform channel base advances).
 // Requires: conv_transpose, FAST channels, 128 % Wq == 0, Wq >= 32, Hq % (128 / Wq) == 0.  Tile, accumulators and epilogue
 // (incl. the fused head) are those of igemm_f32_kernel<128, BN, 4, 1, *, FR, 1, 1>.
-template <int BN, int FR>
+template <int BN, int FR, int PRE = 0>   // PRE: operands already in the split32 layout (plain copies into LDS)
 __global__ __launch_bounds__(256, 2) void convT_tap_kernel(const IGemmP p) {
   constexpr int BM = 128, WM = 4, WN = 1;
   constexpr int TM = BM / WM;                    // 32 rows per wave
@@ -781,10 +794,21 @@ __global__ __launch_bounds__(256, 2) void convT_tap_kernel(const IGemmP p) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int l = srow + 32 * i;
-      if (l < PMAX) store_split(&As[l * LDK], pixA[i] >= 0 ? ra[i] : zero4);
+      if (l < PMAX) {
+        const f32x4 v = pixA[i] >= 0 ? ra[i] : zero4;
+        if constexpr (PRE)
+          *reinterpret_cast<f32x4*>(&As[l * LDK + seg * 4]) = v;
+        else
+          store_split(&As[l * LDK], v);
+      }
     }
 #pragma unroll
-    for (int j = 0; j < BRL; ++j) store_split(&Bs[(srow + 32 * j) * LDK], rb[j]);
+    for (int j = 0; j < BRL; ++j) {
+      if constexpr (PRE)
+        *reinterpret_cast<f32x4*>(&Bs[(srow + 32 * j) * LDK + seg * 4]) = rb[j];
+      else
+        store_split(&Bs[(srow + 32 * j) * LDK], rb[j]);
+    }
   };
   auto mfma_bf16 = [&](const f32x4& a, const f32x4& b, AccT& c) {
     if constexpr (FR == 32)
@@ -870,7 +894,16 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IGemmP p) {
       v[j] = x > 0.f ? x : x * p.slope;
     }
     if (p.out_mode == M2H_OUT_NHWC) {
-      *reinterpret_cast<f32x4*>(p.dst + (size_t)out * p.ldc + n) = v;
+      if (p.dst_split) {
+        const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+        const f32x4 hf = __builtin_convertvector(hi, f32x4);
+        const bf16x4 lo = __builtin_convertvector(v - hf, bf16x4);
+        char* base = reinterpret_cast<char*>(p.dst + (size_t)out * p.ldc + (n & ~31)) + ((n & 31) >> 2) * 8;
+        *reinterpret_cast<bf16x4*>(base) = hi;
+        *reinterpret_cast<bf16x4*>(base + 64) = lo;
+      } else {
+        *reinterpret_cast<f32x4*>(p.dst + (size_t)out * p.ldc + n) = v;
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -944,7 +977,9 @@ static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   const int phases = p.convT ? 4 : 1;
   p.pmaj = (p.convT && g_phase_major >= 0 && nblk * 4 <= 0x7fffffffL) ? 1 : 0;
   dim3 grid((unsigned)(p.pmaj ? nblk * 4 : nblk), (unsigned)p.S, p.pmaj ? 1 : phases);
-  if (fast && g_math_mode == 1)
+  if (fast && g_math_mode == 1 && p.presplit)
+    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1, 2>), grid, dim3(256), (size_t)g_extra_lds, st, p);
+  else if (fast && g_math_mode == 1)
     hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1, 1>), grid, dim3(256), (size_t)g_extra_lds, st, p);
   else if (fast)
     hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1>), grid, dim3(256), (size_t)g_extra_lds, st, p);
@@ -1011,6 +1046,16 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   p.w = a.wp; p.N = a.N; p.K = p.ntap * p.Ctot;
   p.scale = a.scale; p.shift = a.shift; p.slope = a.slope; p.cls_table = a.cls_table; p.cls_val = a.cls_val;
   p.head_w = a.head_w; p.head_b = a.head_b;
+  {
+    const int fmt = a.operand_format;
+    M2H_REQUIRE(fmt == 0 || g_math_mode == 1, "conv_igemm: operand_format needs the bf16x3 math mode");
+    const int both = M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT;
+    M2H_REQUIRE((fmt & both) == 0 || (fmt & both) == both, "conv_igemm: sources and weights must be split32 together");
+    p.presplit = (fmt & both) == both ? 1 : 0;
+    p.dst_split = (fmt & M2H_FMT_DST_SPLIT) ? 1 : 0;
+    M2H_REQUIRE(!p.dst_split || (a.out_mode == M2H_OUT_NHWC && a.N % 32 == 0 && a.ldc % 32 == 0 && a.head_w == nullptr),
+                "conv_igemm: split32 output needs NHWC, N %% 32 == 0, ldc %% 32 == 0, no fused head");
+  }
   if (a.head_w != nullptr) {
     M2H_REQUIRE(a.head_b != nullptr && (a.N == 32 || a.N == 16) && a.out_mode == M2H_OUT_DESLICE && a.workspace == nullptr && a.cls_table == nullptr,
                 "conv_igemm: fused head needs N in {16,32}, de-sliced output, no split-K workspace, no class plane");
@@ -1024,6 +1069,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
                  (size_t)a.N * p.K * 4 < lim) ? 1 : 0;
   }
   M2H_REQUIRE(p.K % 4 == 0, "conv_igemm: K must be a multiple of 4");
+  M2H_REQUIRE(!p.presplit || p.fast_ok, "conv_igemm: split32 operands need channel counts that are multiples of 32");
 
   p.ws = static_cast<float*>(a.workspace);
   const size_t wsb = a.workspace != nullptr ? a.workspace_bytes : 0;
@@ -1040,15 +1086,18 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
       // dominated by the fixed costs around a 4-chunk loop), so the 32-wide stage stays on the staged engine unless forced
       const bool use32 = g_tapshare > 0;
       if (p.N <= 16 && g_narrow16 >= 0) {
-        hipLaunchKernelGGL((convT_tap_kernel<16, 16>), grid, blk, 0, st, p);
+        if (p.presplit) hipLaunchKernelGGL((convT_tap_kernel<16, 16, 1>), grid, blk, 0, st, p);
+        else hipLaunchKernelGGL((convT_tap_kernel<16, 16, 0>), grid, blk, 0, st, p);
         return launch_status("conv_igemm_f32 (tap-sharing convT)");
       }
       if (p.N > 32) {
-        hipLaunchKernelGGL((convT_tap_kernel<64, 32>), grid, blk, 0, st, p);
+        if (p.presplit) hipLaunchKernelGGL((convT_tap_kernel<64, 32, 1>), grid, blk, 0, st, p);
+        else hipLaunchKernelGGL((convT_tap_kernel<64, 32, 0>), grid, blk, 0, st, p);
         return launch_status("conv_igemm_f32 (tap-sharing convT)");
       }
-      if (use32) {
-        hipLaunchKernelGGL((convT_tap_kernel<32, 32>), grid, blk, 0, st, p);
+      if (use32 || p.presplit) {
+        if (p.presplit) hipLaunchKernelGGL((convT_tap_kernel<32, 32, 1>), grid, blk, 0, st, p);
+        else hipLaunchKernelGGL((convT_tap_kernel<32, 32, 0>), grid, blk, 0, st, p);
         return launch_status("conv_igemm_f32 (tap-sharing convT)");
       }
     }

@@ -41,6 +41,56 @@ __global__ __launch_bounds__(256) void sep_slice_input_kernel(const float* __res
   }
 }
 
+// Tiled version for C == 2 (binaural spectrograms): a block takes one (b, h) and 64 time frames.  The 16 frequency rows it
+// needs (s*Hs + h) are each one contiguous 512-byte run -> coalesced 16-byte loads into an LDS tile [16][132]; the output is
+// then gathered from LDS and written as whole 128-byte pixel rows (8 KB contiguous per block).  The direct version above
+// reads with 4-byte gathers (64-byte pieces per wave instruction) and ran at 3.5 TB/s of the ~5.5 TB/s a copy reaches.
+__global__ __launch_bounds__(256) void sep_slice_input_c2_kernel(const float* __restrict__ mix, const float* __restrict__ masks,
+                                                                 float* __restrict__ out, int B, int F, int T) {
+  constexpr int TT = 64, LD = 132;
+  __shared__ __attribute__((aligned(16))) float tile[16 * LD];
+  const int Hs = F >> 4;
+  const int tiles_t = (T + TT - 1) / TT;
+  int blk = blockIdx.x;
+  const int tt = blk % tiles_t;
+  blk /= tiles_t;
+  const int h = blk % Hs;
+  const int b = blk / Hs;
+  const int t0 = tt * TT;
+  const int tid = threadIdx.x;
+  {
+    const int s = tid >> 4, q = tid & 15;
+    const size_t rowbase = (((size_t)b * F + (size_t)s * Hs + h) * T + t0) * 2;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int f4 = q + 16 * u;              // 16-byte segment inside the 64-frame run: frames 2*f4, 2*f4+1
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (t0 + 2 * f4 + 1 < T) {              // T is even: a segment is entirely inside or outside
+        v = *reinterpret_cast<const f32x4*>(mix + rowbase + f4 * 4);
+        if (masks != nullptr) {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(masks + rowbase + f4 * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = log1pf(fmaxf(m[j] * (expf(v[j]) - 1.f), 0.f));   // separator_cnn.py:77-79
+        }
+      }
+      *reinterpret_cast<f32x4*>(&tile[s * LD + f4 * 4]) = v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = tid + 256 * u;
+    const int cg = idx & 7, t = idx >> 3;     // 8 channel groups of 4 per pixel, 64 pixels
+    if (t0 + t >= T) continue;
+    const int n0 = cg * 4;
+    const int c = n0 >> 4, s0 = n0 & 15;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = tile[(s0 + j) * LD + 2 * t + c];
+    *reinterpret_cast<f32x4*>(out + (((size_t)b * Hs + h) * T + t0 + t) * 32 + n0) = v;
+  }
+}
+
 // Training-time variant: same slice, but each pixel row has ldo >= 16*C+1 channels: channel 16*C holds the (target_class+1)
 // plane (separator_cnn.py:93-99 materialised so that its weight gradient falls out of the ordinary wgrad), the rest 0.
 __global__ __launch_bounds__(256) void sep_slice_input_plane_kernel(const float* __restrict__ mix, const float* __restrict__ cls_val,
@@ -137,17 +187,43 @@ static inline unsigned grid_for(size_t total, int block = 256, unsigned cap = 25
   return (unsigned)g;
 }
 
+// fp32 -> split32 (include/m2h.h): thread = one 16-byte segment (4 values) of a 32-value group
+typedef __bf16 bf16x4_l __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void split32_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t nseg) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nseg; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + i * 4);
+    const bf16x4_l hi = __builtin_convertvector(v, bf16x4_l);
+    const f32x4 hf = __builtin_convertvector(hi, f32x4);
+    const bf16x4_l lo = __builtin_convertvector(v - hf, bf16x4_l);
+    const size_t g = i >> 3, sg = i & 7;
+    char* base = reinterpret_cast<char*>(dst + g * 32) + sg * 8;
+    *reinterpret_cast<bf16x4_l*>(base) = hi;
+    *reinterpret_cast<bf16x4_l*>(base + 64) = lo;
+  }
+}
+
 }  // namespace m2h
 
 using namespace m2h;
 
 extern "C" {
 
+int m2h_split32(const float* src, float* dst, size_t count, m2h_stream stream) {
+  M2H_REQUIRE(src != nullptr && dst != nullptr && src != dst && count > 0 && count % 32 == 0, "split32: bad arguments (count %% 32, out of place)");
+  hipLaunchKernelGGL(split32_kernel, dim3(grid_for(count / 4, 256, 256 * 16)), dim3(256), 0, as_stream(stream), src, dst, count / 4);
+  return launch_status("split32");
+}
+
 int m2h_sep_slice_input(const float* mix, const float* masks, float* out, int B, int F, int T, int C, m2h_stream stream) {
   M2H_REQUIRE(mix != nullptr && out != nullptr, "sep_slice_input: null pointer");
   M2H_REQUIRE(B > 0 && F > 0 && T > 0 && C > 0, "sep_slice_input: non-positive size");
   M2H_REQUIRE(F % 16 == 0, "sep_slice_input: F (%d) must be a multiple of 16", F);
   M2H_REQUIRE((16 * C) % 4 == 0, "sep_slice_input: 16*C must be a multiple of 4");
+  const long nblk = (long)B * (F / 16) * ((T + 63) / 64);
+  if (C == 2 && T % 2 == 0 && nblk <= 0x7fffffffL) {
+    hipLaunchKernelGGL(sep_slice_input_c2_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), mix, masks, out, B, F, T);
+    return launch_status("sep_slice_input");
+  }
   const size_t total = (size_t)B * (F / 16) * T * (16 * C / 4);
   hipLaunchKernelGGL(sep_slice_input_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, as_stream(stream), mix, masks, out, B, F, T, C);
   return launch_status("sep_slice_input");

@@ -68,6 +68,7 @@ class ConvArgs(ctypes.Structure):
         ("ldc", ctypes.c_int), ("out_mode", ctypes.c_int),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
         ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p),
+        ("operand_format", ctypes.c_int),
     ]
 
 
@@ -140,6 +141,7 @@ SIGNATURES = {
     "m2h_istft_pre": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "m2h_istft_ola": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "m2h_bss_metrics": [_P, _P, _P, _P, _P, _I, _I, _P],
+    "m2h_split32": [_P, _P, ctypes.c_size_t, _P],
     "m2h_feeder_round_mix": [_P, _I, _I, _P, _P, _I, _I, _I, _F, _P],
     "m2h_rms_normalize": [_P, _I, _I, _F, _P],
     "m2h_unet_fwd_workspace_bytes": [_I, _I, _I],

@@ -57,6 +57,18 @@ def debug_set(knob, value):
 
 
 MATH_FP32, MATH_BF16X3 = 0, 1
+FMT_SRC_SPLIT, FMT_W_SPLIT, FMT_DST_SPLIT = 1, 2, 4   # include/m2h.h M2H_FMT_*
+
+
+def split32(t):
+    """fp32 tensor (innermost dimension a multiple of 32) -> same-shape tensor in the split32 layout of include/m2h.h."""
+    _chk(t, "split32")
+    if t.shape[-1] % 32 != 0:
+        raise RuntimeError("m2h.split32: innermost dimension must be a multiple of 32")
+    out = torch.empty_like(t)
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.load().m2h_split32(_ptr(t), _ptr(out), t.numel(), _stream(t)), "m2h_split32")
+    return out
 
 
 def set_math_mode(mode):
@@ -249,7 +261,8 @@ def conv_igemm_f32(**kw):
 # ----------------------------------------------------------------------------------------------------------------
 # generic conv / linear on the igemm engine, and the RL-path ops
 # ----------------------------------------------------------------------------------------------------------------
-def conv2d_nhwc(x, wp, n_out, kh, kw, stride=1, pad=0, bias=None, scale=None, slope=1.0, x2=None, deslice=False, name="conv2d", out=None):
+def conv2d_nhwc(x, wp, n_out, kh, kw, stride=1, pad=0, bias=None, scale=None, slope=1.0, x2=None, deslice=False, name="conv2d", out=None,
+                operand_format=0):
     """Conv2d over NHWC activations through m2h_conv_igemm_f32.  x [B,H,W,C0] (+ x2 [B,H,W,C1] concatenated on channels),
     wp packed [n_out, kh*kw*(C0+C1)], bias -> epilogue shift, slope: 1 none / 0 ReLU / 0.2 LeakyReLU.
     Returns NHWC [B,Ho,Wo,n_out], or the de-sliced BHWC [B,16*Ho,Wo,n_out/16] when deslice."""
@@ -282,6 +295,7 @@ def conv2d_nhwc(x, wp, n_out, kh, kw, stride=1, pad=0, bias=None, scale=None, sl
     a.cls_table, a.cls_val = None, None
     a.dst, a.Ho, a.Wo, a.os, a.ph, a.pw, a.ldc = out.data_ptr(), Ho, Wo, 1, 0, 0, n_out
     a.out_mode = OUT_DESLICE if deslice else OUT_NHWC
+    a.operand_format = int(operand_format)   # FMT_* bits: split32 operands / output (bf16x3 math only)
     lib = _lib.load()
     with torch.cuda.device(x.device):
         ws, wsb = _workspace(lib.m2h_conv_igemm_workspace_bytes(ctypes.byref(a)), x.device)

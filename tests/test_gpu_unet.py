@@ -242,3 +242,37 @@ def test_pair_bf16x3_math_mode_within_contract(golden_dir, tm, B):
     assert O.rel_l1(O.pred_bin(masks.cpu(), mix), O.pred_bin(gm, mix)) < 1e-4
     assert torch.equal(masks, masks2) and torch.equal(mono, mono2)
     assert not torch.equal(masks, exact[0])
+
+
+@pytest.mark.parametrize("Ci,Co,H,W", [(64, 128, 16, 32), (512, 512, 4, 8), (32, 64, 8, 256)])
+def test_split32_operands_are_bitwise_the_on_the_fly_split(Ci, Co, H, W):
+    """bf16x3 math with operands converted to the split32 layout beforehand (and the output written in it) must equal the
+    in-kernel split bit for bit: hi = bf16(x), lo = bf16(x - hi) are the same values wherever they are computed."""
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(7)
+    B = 3
+    x = torch.randn(B, H, W, Ci, device=dev, generator=g)
+    wp = torch.randn(Co, 16 * Ci, device=dev, generator=g) * 0.05
+    sc = torch.rand(Co, device=dev, generator=g) + 0.5
+    sh = torch.randn(Co, device=dev, generator=g) * 0.1
+    ops.set_math_mode(ops.MATH_BF16X3)
+    try:
+        ref = ops.conv2d_nhwc(x, wp, Co, 4, 4, stride=2, pad=1, bias=sh, scale=sc, slope=0.2)
+        xs, ws = ops.split32(x), ops.split32(wp)
+        got = ops.conv2d_nhwc(xs, ws, Co, 4, 4, stride=2, pad=1, bias=sh, scale=sc, slope=0.2,
+                              operand_format=ops.FMT_SRC_SPLIT | ops.FMT_W_SPLIT)
+        got_split = ops.conv2d_nhwc(xs, ws, Co, 4, 4, stride=2, pad=1, bias=sh, scale=sc, slope=0.2,
+                                    operand_format=ops.FMT_SRC_SPLIT | ops.FMT_W_SPLIT | ops.FMT_DST_SPLIT)
+        with pytest.raises(RuntimeError):   # sources and weights must be converted together
+            ops.conv2d_nhwc(xs, wp, Co, 4, 4, stride=2, pad=1, operand_format=ops.FMT_SRC_SPLIT)
+    finally:
+        ops.set_math_mode(ops.MATH_FP32)
+    assert torch.equal(got, ref)
+    assert torch.equal(got_split, ops.split32(ref))
+    # the layout itself: hi + lo reconstructs x to 2^-16 relative
+    raw = xs.view(torch.int16).view(B, H, W, Ci // 32, 2, 32)
+    hi = (raw[..., 0, :].to(torch.int32) << 16).view(torch.float32)
+    lo = (raw[..., 1, :].to(torch.int32) << 16).view(torch.float32)
+    rec = (hi + lo).reshape(B, H, W, Ci)
+    assert ((rec - x).abs() <= x.abs() * 2.0 ** -16 + 1e-30).all()
