@@ -204,6 +204,52 @@ def main():
             mono = pol.convert_bin2mono(masks, mixed_audio=mix)
         return masks, mono
 
+    from m2h.rl.models.separator_cnn import unet_forward, UNET_KERNEL_NAMES
+
+    def unet_kernel_meta(n_out, with_masks, with_class):
+        """(name, instantiation, M, N, K, algorithmic flops, algorithmic bytes) of the 11 kernels of one U-Net at this batch."""
+        B, T = args.batch, args.tm
+        metas = [("sep_slice_input", "sep_slice_input", None, None, None, 0.0, (3 if with_masks else 2) * B * 512 * T * 2 * 4.0)]
+        enc = [32, 64, 128, 256, 512, 512]
+        H, W = 32, T
+        for i in range(5):
+            M, N, K = B * (H // 2) * (W // 2), enc[i + 1], 16 * enc[i]
+            fl = 2.0 * M * N * 16 * (enc[i] + (1 if (i == 0 and with_class) else 0))
+            by = 4.0 * (B * H * W * enc[i] + M * N + N * K)
+            metas.append(("unet_down_fwd", ops.igemm_config(N), M, N, K, fl, by))
+            H //= 2
+            W //= 2
+        c0, c1, co = [512, 512, 256, 128, 64], [0, 512, 256, 128, 64], [512, 256, 128, 64, n_out]
+        for i in range(5):
+            M, N, K = 4 * B * H * W, co[i], 4 * (c0[i] + c1[i])
+            fl = 2.0 * M * N * (K + (N if i == 4 else 0))                    # last stage carries the 1x1 head
+            outel = M * N if i < 4 else B * 512 * T * (n_out // 16)
+            by = 4.0 * (B * H * W * (c0[i] + c1[i]) + outel + 4 * N * K)
+            metas.append(("unet_up_fwd" if i < 4 else "unet_up_head_fwd", ops.igemm_config(N), M, N, K, fl, by))
+            H *= 2
+            W *= 2
+        return metas
+
+    META = {"binSep": unet_kernel_meta(32, False, True), "bin2mono": unet_kernel_meta(16, True, False)}
+
+    def step_events(sink):
+        """the same pair through the same one-call runner, which records an event around each of its 11 kernels"""
+        evs = []
+        with torch.no_grad():
+            for which in ("binSep", "bin2mono"):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
+                for e in ev:
+                    e.record()
+                evs.append(ev)
+            enc, dec = pol.binSep_enc.passive_sep_encoder, pol.binSep_dec.passive_sep_decoder
+            masks = unet_forward(enc, dec, mix, None, tc, events=evs[0])
+            enc, dec = pol.bin2mono_enc.passive_sep_encoder, pol.bin2mono_dec.passive_sep_decoder
+            mono = unet_forward(enc, dec, mix, masks, events=evs[1])
+        for which, ev in zip(("binSep", "bin2mono"), evs):
+            for i, (name, inst, M, N, K, fl, by) in enumerate(META[which]):
+                sink.append((name, {"kernel": inst, "M": M, "N": N, "K": K, "flops": fl, "bytes": by}, ev[i], ev[i + 1]))
+        return masks, mono
+
     PEAK_BF16 = 2500.0   # dense bf16 MFMA peak, TFLOP/s (MI355X_MICROARCH.md)
 
     def timed_run(mode, steps, warmup, with_events):
@@ -213,18 +259,19 @@ def main():
             step()
         torch.cuda.synchronize()
         sink = [] if with_events else None
-        ops.set_timing(sink)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step()
+            if with_events:
+                step_events(sink)
+            else:
+                step()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         el = time.perf_counter() - t0
-        ops.set_timing(None)
         if dist is not None:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -295,9 +342,8 @@ def main():
 
     # the headline run, then the other arithmetic beside it (fewer steps), then the distance between the two results
     # Headline pass: W warm-up + K timed steps with each U-Net enqueued by ONE C call (m2h_unet_fwd: what every RL call site
-    # runs).  Kernel durations for the roofline come from a second pass of the same K steps with a HIP-event pair around
-    # every kernel (the per-layer Python path launches the identical kernels; the events and per-layer host work cost ~10 %
-    # of wall time, which is why they are kept out of the headline pass).
+    # runs).  Kernel durations for the roofline come from a second pass of the same K steps through the same runner with an
+    # event recorded around each of its kernels (m2h_unet_fwd_events): identical kernels, ~24 extra event records per step.
     other = "fp32" if args.math == "bf16x3" else "bf16x3"
     elapsed, _ = timed_run(args.math, args.steps, args.warmup, False)
     roofline, layers, evented_ms = None, None, None

@@ -375,6 +375,8 @@ typedef struct m2h_unet_weights {
   const float* head_w;        /* [n_out][n_out] */
   const float* head_b;        /* [n_out] */
   int n_out;                  /* 32 (binSep) or 16 (bin2mono) */
+  int weights_split32;        /* bf16x3 math only: down_w / up_w are in the split32 layout (m2h_split32 of the packed weights); the runner
+                                 then keeps every intermediate activation in split32 too, so no kernel converts operands in its k-loop */
 } m2h_unet_weights;
 
 size_t m2h_unet_fwd_workspace_bytes(int B, int F, int T);
@@ -382,6 +384,15 @@ size_t m2h_unet_fwd_workspace_bytes(int B, int F, int T);
  * [B][F][T][n_out/16].  F = 512 (16 slices of 32 rows), T % 32 == 0. */
 int m2h_unet_fwd(const m2h_unet_weights* w /* host */, const float* mix, const float* masks, const float* cls_val, float* out,
                  int B, int F, int T, void* workspace, size_t workspace_bytes, m2h_stream stream);
+/* Same, recording caller-created events (hipEvent_t handles, e.g. torch.cuda.Event.cuda_event) on `stream` before the first
+ * kernel and after each of the 11 kernels: events[0..11] (n_events must be 12).  Kernel i ran between events[i] and
+ * events[i+1]: 0 slice, 1-5 encoder stages, 6-9 decoder stages, 10 last stage + head. */
+#define M2H_UNET_FWD_EVENTS 12
+int m2h_unet_fwd_events(const m2h_unet_weights* w /* host */, const float* mix, const float* masks, const float* cls_val, float* out,
+                        int B, int F, int T, void* workspace, size_t workspace_bytes, void* const* events, int n_events,
+                        m2h_stream stream);
+/* m2h_sep_slice_input with the output written in the split32 layout when split_out != 0 (C == 2 only). */
+int m2h_sep_slice_input_fmt(const float* mix, const float* masks, float* out, int B, int F, int T, int C, int split_out, m2h_stream stream);
 
 #ifdef __cplusplus
 }

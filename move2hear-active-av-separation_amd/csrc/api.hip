@@ -164,12 +164,13 @@ size_t m2h_unet_fwd_workspace_bytes(int B, int F, int T) {
   return unet_layout(B, F, T, 32).total;
 }
 
-int m2h_unet_fwd(const m2h_unet_weights* wts, const float* mix, const float* masks, const float* cls_val, float* out, int B, int F,
-                 int T, void* workspace, size_t workspace_bytes, m2h_stream stream) {
+static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const float* masks, const float* cls_val, float* out, int B, int F,
+                         int T, void* workspace, size_t workspace_bytes, void* const* events, m2h_stream stream) {
   M2H_REQUIRE(wts && mix && out && workspace, "unet_fwd: null pointer");
   M2H_REQUIRE(B > 0 && F == 512 && T > 0 && T % 32 == 0, "unet_fwd: F must be 512 and T a multiple of 32 (got %d x %d)", F, T);
   M2H_REQUIRE(wts->n_out == 32 || wts->n_out == 16, "unet_fwd: n_out must be 32 or 16");
   M2H_REQUIRE((wts->cls_table == nullptr) == (cls_val == nullptr), "unet_fwd: class table / value mismatch");
+  M2H_REQUIRE(!wts->weights_split32 || g_math_mode == 1, "unet_fwd: split32 weights need the bf16x3 math mode");
   const UnetLayout L = unet_layout(B, F, T, wts->n_out);
   M2H_REQUIRE(workspace_bytes >= L.total, "unet_fwd: workspace too small (%zu < %zu)", workspace_bytes, L.total);
   char* ws = static_cast<char*>(workspace);
@@ -182,14 +183,31 @@ int m2h_unet_fwd(const m2h_unet_weights* wts, const float* mix, const float* mas
   }
   void* sk = ws + L.splitk;
   const size_t skb = L.total - L.splitk;
-  int rc = m2h_sep_slice_input(mix, masks, x0, B, F, T, 2, stream);
+  hipStream_t st = as_stream(stream);
+  int ev = 0;
+  auto mark = [&]() -> int {
+    if (events == nullptr) return 0;
+    const hipError_t err = hipEventRecord(static_cast<hipEvent_t>(events[ev++]), st);
+    return err == hipSuccess ? 0 : fail((int)err, "unet_fwd: hipEventRecord failed: %s", hipGetErrorString(err));
+  };
+  // with split32 weights every intermediate tensor lives in the split32 layout: producers write it, consumers copy it to LDS
+  const int sp = wts->weights_split32 ? 1 : 0;
+  const int fmt_mid = sp ? (M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT | M2H_FMT_DST_SPLIT) : 0;
+  const int fmt_last = sp ? (M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT) : 0;
+  int rc = mark();
   if (rc) return rc;
+  rc = m2h_sep_slice_input_fmt(mix, masks, x0, B, F, T, 2, sp, stream);
+  if (rc) return rc;
+  if ((rc = mark())) return rc;
   int h = F / 16, w = T;
   const float* cur = x0;
   for (int i = 0; i < 5; ++i) {
-    rc = m2h_unet_down_fwd(cur, wts->down_w[i], wts->down_scale[i], wts->down_shift[i], i == 0 ? wts->cls_table : nullptr,
-                           i == 0 ? cls_val : nullptr, e[i], B, h, w, kEnc[i], kEnc[i + 1], sk, skb, stream);
-    if (rc) return rc;
+    M2H_REQUIRE(h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "unet_fwd: stage %d input %d x %d", i, h, w);
+    m2h_conv_args a = down_args(cur, wts->down_w[i], wts->down_scale[i], wts->down_shift[i], i == 0 ? wts->cls_table : nullptr,
+                                i == 0 ? cls_val : nullptr, e[i], B, h, w, kEnc[i], kEnc[i + 1]);
+    a.workspace = sk; a.workspace_bytes = skb; a.operand_format = fmt_mid;
+    if ((rc = conv_igemm_f32(a, st))) return rc;
+    if ((rc = mark())) return rc;
     cur = e[i];
     h /= 2; w /= 2;
   }
@@ -197,14 +215,34 @@ int m2h_unet_fwd(const m2h_unet_weights* wts, const float* mix, const float* mas
   const int dco[5] = {512, 256, 128, 64, wts->n_out};
   for (int i = 0; i < 4; ++i) {
     const float* skip = i == 0 ? nullptr : e[4 - i];
-    rc = m2h_unet_up_fwd(cur, skip, wts->up_w[i], wts->up_scale[i], wts->up_shift[i], d[i], B, h, w, c0[i], c1[i], dco[i], sk, skb, stream);
-    if (rc) return rc;
+    m2h_conv_args a = up_args(cur, skip, wts->up_w[i], wts->up_scale[i], wts->up_shift[i], d[i], B, h, w, c0[i], c1[i], dco[i]);
+    a.workspace = sk; a.workspace_bytes = skb; a.operand_format = fmt_mid;
+    if ((rc = conv_igemm_f32(a, st))) return rc;
+    if ((rc = mark())) return rc;
     cur = d[i];
     h *= 2; w *= 2;
   }
   // last stage + 1x1 head + de-slice in one kernel
-  return m2h_unet_up_head_fwd(cur, e[0], wts->up_w[4], wts->up_scale[4], wts->up_shift[4], wts->head_w, wts->head_b, out, B, h, w, c0[4],
-                              c1[4], dco[4], stream);
+  m2h_conv_args a = up_args(cur, e[0], wts->up_w[4], wts->up_scale[4], wts->up_shift[4], out, B, h, w, c0[4], c1[4], dco[4]);
+  a.out_mode = M2H_OUT_DESLICE;
+  a.head_w = wts->head_w;
+  a.head_b = wts->head_b;
+  a.operand_format = fmt_last;
+  M2H_REQUIRE(a.head_w != nullptr && a.head_b != nullptr, "unet_fwd: null head");
+  if ((rc = conv_igemm_f32(a, st))) return rc;
+  return mark();
+}
+
+int m2h_unet_fwd(const m2h_unet_weights* wts, const float* mix, const float* masks, const float* cls_val, float* out, int B, int F,
+                 int T, void* workspace, size_t workspace_bytes, m2h_stream stream) {
+  return unet_fwd_impl(wts, mix, masks, cls_val, out, B, F, T, workspace, workspace_bytes, nullptr, stream);
+}
+
+int m2h_unet_fwd_events(const m2h_unet_weights* wts, const float* mix, const float* masks, const float* cls_val, float* out, int B, int F,
+                        int T, void* workspace, size_t workspace_bytes, void* const* events, int n_events, m2h_stream stream) {
+  M2H_REQUIRE(events != nullptr && n_events == M2H_UNET_FWD_EVENTS, "unet_fwd_events: need %d events", M2H_UNET_FWD_EVENTS);
+  for (int i = 0; i < n_events; ++i) M2H_REQUIRE(events[i] != nullptr, "unet_fwd_events: null event %d", i);
+  return unet_fwd_impl(wts, mix, masks, cls_val, out, B, F, T, workspace, workspace_bytes, events, stream);
 }
 
 }  // extern "C"

@@ -45,8 +45,9 @@ __global__ __launch_bounds__(256) void sep_slice_input_kernel(const float* __res
 // needs (s*Hs + h) are each one contiguous 512-byte run -> coalesced 16-byte loads into an LDS tile [16][132]; the output is
 // then gathered from LDS and written as whole 128-byte pixel rows (8 KB contiguous per block).  The direct version above
 // reads with 4-byte gathers (64-byte pieces per wave instruction) and ran at 3.5 TB/s of the ~5.5 TB/s a copy reaches.
+typedef __bf16 bf16x4_s __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void sep_slice_input_c2_kernel(const float* __restrict__ mix, const float* __restrict__ masks,
-                                                                 float* __restrict__ out, int B, int F, int T) {
+                                                                 float* __restrict__ out, int B, int F, int T, int split_out) {
   constexpr int TT = 64, LD = 132;
   __shared__ __attribute__((aligned(16))) float tile[16 * LD];
   const int Hs = F >> 4;
@@ -87,7 +88,17 @@ __global__ __launch_bounds__(256) void sep_slice_input_c2_kernel(const float* __
     f32x4 v;
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = tile[(s0 + j) * LD + 2 * t + c];
-    *reinterpret_cast<f32x4*>(out + (((size_t)b * Hs + h) * T + t0 + t) * 32 + n0) = v;
+    float* prow = out + (((size_t)b * Hs + h) * T + t0 + t) * 32;
+    if (split_out) {   // split32 layout: the pixel's 32 channels are one group; this thread owns values n0 .. n0+3
+      const bf16x4_s hi = __builtin_convertvector(v, bf16x4_s);
+      const f32x4 hf = __builtin_convertvector(hi, f32x4);
+      const bf16x4_s lo = __builtin_convertvector(v - hf, bf16x4_s);
+      char* base = reinterpret_cast<char*>(prow) + cg * 8;
+      *reinterpret_cast<bf16x4_s*>(base) = hi;
+      *reinterpret_cast<bf16x4_s*>(base + 64) = lo;
+    } else {
+      *reinterpret_cast<f32x4*>(prow + n0) = v;
+    }
   }
 }
 
@@ -214,19 +225,24 @@ int m2h_split32(const float* src, float* dst, size_t count, m2h_stream stream) {
   return launch_status("split32");
 }
 
-int m2h_sep_slice_input(const float* mix, const float* masks, float* out, int B, int F, int T, int C, m2h_stream stream) {
+int m2h_sep_slice_input_fmt(const float* mix, const float* masks, float* out, int B, int F, int T, int C, int split_out, m2h_stream stream) {
   M2H_REQUIRE(mix != nullptr && out != nullptr, "sep_slice_input: null pointer");
   M2H_REQUIRE(B > 0 && F > 0 && T > 0 && C > 0, "sep_slice_input: non-positive size");
   M2H_REQUIRE(F % 16 == 0, "sep_slice_input: F (%d) must be a multiple of 16", F);
   M2H_REQUIRE((16 * C) % 4 == 0, "sep_slice_input: 16*C must be a multiple of 4");
   const long nblk = (long)B * (F / 16) * ((T + 63) / 64);
   if (C == 2 && T % 2 == 0 && nblk <= 0x7fffffffL) {
-    hipLaunchKernelGGL(sep_slice_input_c2_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), mix, masks, out, B, F, T);
+    hipLaunchKernelGGL(sep_slice_input_c2_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), mix, masks, out, B, F, T, split_out);
     return launch_status("sep_slice_input");
   }
+  M2H_REQUIRE(!split_out, "sep_slice_input: split32 output needs C == 2 and an even T");
   const size_t total = (size_t)B * (F / 16) * T * (16 * C / 4);
   hipLaunchKernelGGL(sep_slice_input_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, as_stream(stream), mix, masks, out, B, F, T, C);
   return launch_status("sep_slice_input");
+}
+
+int m2h_sep_slice_input(const float* mix, const float* masks, float* out, int B, int F, int T, int C, m2h_stream stream) {
+  return m2h_sep_slice_input_fmt(mix, masks, out, B, F, T, C, 0, stream);
 }
 
 int m2h_sep_slice_input_plane(const float* mix, const float* cls_val, float* out, int B, int F, int T, int C, int ldo, m2h_stream stream) {

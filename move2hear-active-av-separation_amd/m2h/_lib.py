@@ -80,6 +80,7 @@ class UnetWeights(ctypes.Structure):
         ("up_w", ctypes.c_void_p * 5), ("up_scale", ctypes.c_void_p * 5), ("up_shift", ctypes.c_void_p * 5),
         ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p),
         ("n_out", ctypes.c_int),
+        ("weights_split32", ctypes.c_int),
     ]
 
 
@@ -146,6 +147,8 @@ SIGNATURES = {
     "m2h_rms_normalize": [_P, _I, _I, _F, _P],
     "m2h_unet_fwd_workspace_bytes": [_I, _I, _I],
     "m2h_unet_fwd": [ctypes.POINTER(UnetWeights), _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P],
+    "m2h_unet_fwd_events": [ctypes.POINTER(UnetWeights), _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P, _I, _P],
+    "m2h_sep_slice_input_fmt": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "m2h_gather_envs": [_P, _P, _P, _I, _I, _I, _Z, _P],
     "m2h_stft_l2": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
 }

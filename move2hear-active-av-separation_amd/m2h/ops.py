@@ -57,6 +57,7 @@ def debug_set(knob, value):
 
 
 MATH_FP32, MATH_BF16X3 = 0, 1
+_math_mode = 0
 FMT_SRC_SPLIT, FMT_W_SPLIT, FMT_DST_SPLIT = 1, 2, 4   # include/m2h.h M2H_FMT_*
 
 
@@ -76,9 +77,15 @@ def set_math_mode(mode):
     MATH_FP32 (default): fp32 matrix instructions, exact fp32 products.  MATH_BF16X3: fp32 operands split into bf16 hi + lo
     inside the kernel, products hi*hi + hi*lo + lo*hi on the bf16 matrix pipe with fp32 accumulation (~16 mantissa bits per
     product; tensors in HBM stay fp32).  Applies to shapes the scalar loader takes (channel counts multiples of 32)."""
+    global _math_mode
     if mode not in (MATH_FP32, MATH_BF16X3):
         raise ValueError("math mode must be ops.MATH_FP32 or ops.MATH_BF16X3")
     debug_set(14, mode)
+    _math_mode = mode
+
+
+def math_mode():
+    return _math_mode
 
 
 def _ptr(t):

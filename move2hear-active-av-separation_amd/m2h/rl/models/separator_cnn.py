@@ -241,9 +241,25 @@ class PassiveSepDecCNN(nn.Module):
         return ops.unet_up_head_fwd(out, _as_nhwc(lst_skip_feats[3]), wp, scale, shift, hw, hb, hco)
 
 
-def unet_forward(enc, dec, mix, masks=None, target_class=None):
+UNET_KERNEL_NAMES = ("sep_slice_input", "down0", "down1", "down2", "down3", "down4", "up0", "up1", "up2", "up3", "up4+head")
+
+
+def _split32_of(wp):
+    """split32 copy of a packed weight, cached on the tensor object (a re-pack after a weight update makes new tensors)."""
+    sp = getattr(wp, "_m2h_split32", None)
+    if sp is None:
+        sp = ops.split32(wp)
+        wp._m2h_split32 = sp
+    return sp
+
+
+def unet_forward(enc, dec, mix, masks=None, target_class=None, events=None):
     """Eval-mode forward of one encoder/decoder pair through the whole-network C runner (m2h_unet_fwd): same kernels and
-    values as ``dec(*enc(...))``, one host call instead of ~13.  enc: PassiveSepEncCNN, dec: PassiveSepDecCNN."""
+    values as ``dec(*enc(...))``, one host call instead of ~13.  enc: PassiveSepEncCNN, dec: PassiveSepDecCNN.
+    In the bf16x3 math mode the runner gets split32 copies of the packed weights and keeps its intermediates in split32
+    (bit-identical results, no operand conversion inside the k-loops).
+    events: optional list of 12 recorded-once torch.cuda.Event(enable_timing=True): the runner records them around its 11
+    kernels (UNET_KERNEL_NAMES), for per-kernel timing without leaving the one-call path."""
     import ctypes
 
     from ... import _lib
@@ -255,15 +271,17 @@ def unet_forward(enc, dec, mix, masks=None, target_class=None):
     B, F, T, C = mix.shape
     if C != 2 or F != 512 or T % 32 != 0:
         raise RuntimeError("m2h.unet_forward: expected mix [B,512,T,2] with T %% 32 == 0, got %s" % (tuple(mix.shape),))
+    split = ops.math_mode() == ops.MATH_BF16X3
+    wsel = _split32_of if split else (lambda t: t)
     w = _lib.UnetWeights()
-    keep = [mix]
     for i, (wp, scale, shift, table, _co) in enumerate(downs):
-        w.down_w[i], w.down_scale[i], w.down_shift[i] = wp.data_ptr(), scale.data_ptr(), shift.data_ptr()
+        w.down_w[i], w.down_scale[i], w.down_shift[i] = wsel(wp).data_ptr(), scale.data_ptr(), shift.data_ptr()
     table = downs[0][3]
     w.cls_table = table.data_ptr() if table is not None else None
     for i, (wp, scale, shift, _co) in enumerate(ups):
-        w.up_w[i], w.up_scale[i], w.up_shift[i] = wp.data_ptr(), scale.data_ptr(), shift.data_ptr()
+        w.up_w[i], w.up_scale[i], w.up_shift[i] = wsel(wp).data_ptr(), scale.data_ptr(), shift.data_ptr()
     w.head_w, w.head_b, w.n_out = hw.data_ptr(), hb.data_ptr(), hco
+    w.weights_split32 = 1 if split else 0
     cls_val = None
     if table is not None:
         cls_val = (target_class.reshape(-1).to(torch.float32) + 1.0).contiguous()
@@ -274,6 +292,13 @@ def unet_forward(enc, dec, mix, masks=None, target_class=None):
     with torch.cuda.device(mix.device):
         nbytes = lib.m2h_unet_fwd_workspace_bytes(B, F, T)
         ws = torch.empty(nbytes // 4, device=mix.device, dtype=torch.float32)
-        _lib.check(lib.m2h_unet_fwd(ctypes.byref(w), ops._ptr(mix), ops._ptr(masks), ops._ptr(cls_val), ops._ptr(out), B, F, T, ops._ptr(ws),
-                                    nbytes, ops._stream(mix)), "m2h_unet_fwd")
+        if events is None:
+            _lib.check(lib.m2h_unet_fwd(ctypes.byref(w), ops._ptr(mix), ops._ptr(masks), ops._ptr(cls_val), ops._ptr(out), B, F, T,
+                                        ops._ptr(ws), nbytes, ops._stream(mix)), "m2h_unet_fwd")
+        else:
+            if len(events) != 12:
+                raise RuntimeError("m2h.unet_forward: events must be 12 torch.cuda.Event objects")
+            arr = (ctypes.c_void_p * 12)(*[ctypes.c_void_p(e.cuda_event) for e in events])
+            _lib.check(lib.m2h_unet_fwd_events(ctypes.byref(w), ops._ptr(mix), ops._ptr(masks), ops._ptr(cls_val), ops._ptr(out), B, F, T,
+                                               ops._ptr(ws), nbytes, arr, 12, ops._stream(mix)), "m2h_unet_fwd_events")
     return out

@@ -198,19 +198,39 @@ def test_error_behaviour():
         pol.get_binSepMasks({"mixed_bin_audio_mag": torch.zeros(1, 512, 32, 2, device=dev), "target_class": torch.zeros(1, 1, device=dev)})
 
 
-def test_whole_network_runner_is_bitwise_the_module_chain():
-    """m2h_unet_fwd (one C call per U-Net) enqueues the same kernels as the encoder/decoder module chain."""
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_whole_network_runner_is_bitwise_the_module_chain(mode):
+    """m2h_unet_fwd (one C call per U-Net) gives bit-identical results to the encoder/decoder module chain in both arithmetic
+    modes.  In bf16x3 the runner works on split32 weights and keeps its intermediates in split32 (no operand conversion in any
+    k-loop) while the module chain converts inside the kernels: hi/lo are the same values either way.  tm 256 reaches the
+    tap-sharing kernel and the long-M tiles."""
+    from m2h import ops
+    from m2h.rl.models.separator_cnn import unet_forward
     dev = _dev()
     pol, _ = _policy(2, dev)
-    for B, tm in ((3, 32), (2, 64)):
-        mixed, tc = synthetic.make_passive_inputs(B, tm, 40 + B)
-        obs = {"mixed_bin_audio_mag": torch.from_numpy(mixed).to(dev), "target_class": torch.from_numpy(tc).to(dev)}
+    ops.set_math_mode(ops.MATH_BF16X3 if mode == "bf16x3" else ops.MATH_FP32)
+    try:
+        for B, tm in ((3, 32), (2, 64), (1, 256)):
+            mixed, tc = synthetic.make_passive_inputs(B, tm, 40 + B)
+            obs = {"mixed_bin_audio_mag": torch.from_numpy(mixed).to(dev), "target_class": torch.from_numpy(tc).to(dev)}
+            with torch.no_grad():
+                fast_m = pol.get_binSepMasks(obs)
+                fast_mono = pol.convert_bin2mono(fast_m, mixed_audio=obs["mixed_bin_audio_mag"])
+                chain_m = pol.binSep_dec(*pol.binSep_enc(obs))
+                chain_mono = pol.bin2mono_dec(*pol.bin2mono_enc(chain_m, mixed_audio=obs["mixed_bin_audio_mag"]))
+            assert torch.equal(fast_m, chain_m) and torch.equal(fast_mono, chain_mono)
+        # the event-recording entry point: same result, 11 positive kernel durations
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
+        for e in evs:
+            e.record()
         with torch.no_grad():
-            fast_m = pol.get_binSepMasks(obs)
-            fast_mono = pol.convert_bin2mono(fast_m, mixed_audio=obs["mixed_bin_audio_mag"])
-            chain_m = pol.binSep_dec(*pol.binSep_enc(obs))
-            chain_mono = pol.bin2mono_dec(*pol.bin2mono_enc(chain_m, mixed_audio=obs["mixed_bin_audio_mag"]))
-        assert torch.equal(fast_m, chain_m) and torch.equal(fast_mono, chain_mono)
+            m_ev = unet_forward(pol.binSep_enc.passive_sep_encoder, pol.binSep_dec.passive_sep_decoder, obs["mixed_bin_audio_mag"], None,
+                                obs["target_class"], events=evs)
+        torch.cuda.synchronize()
+        assert torch.equal(m_ev, fast_m)
+        assert all(evs[i].elapsed_time(evs[i + 1]) > 0 for i in range(11))
+    finally:
+        ops.set_math_mode(ops.MATH_FP32)
 
 
 @pytest.mark.parametrize("tm,B", [(32, 2), (256, 1)])
