@@ -113,7 +113,7 @@ __device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM /
       // Last decoder stage + head in one kernel (separator_cnn.py:133-134,163-168): y = ReLU(BN(convT)) stays on chip, a second
       // small MFMA pass applies the 1x1 conv, the result is transposed through LDS and stored de-sliced with one contiguous
       // (s, pixel-run) segment per wave instruction instead of 4-byte scatters.
-      constexpr int LDT = 129;       // [n'][m] staging stride: conflict-free column writes
+      constexpr int LDT = BM + 1;    // [n'][m] staging stride: conflict-free column writes
       constexpr int NGH = FR / GK;   // fragment groups of the FR-deep head contraction
       float* Y = As0;
       float* Wh = Bs0;
@@ -171,9 +171,9 @@ __device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM /
       const size_t plane2 = (size_t)p.Ho * p.Wo;
       const int Cc2 = p.N >> 4;
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < 16 * BM / 256; ++it) {
         const int i = tid + 256 * it;
-        const int s = i >> 7, m = i & 127;
+        const int s = i / BM, m = i % BM;
         const int out = ri_out[m];
         if (out < 0) continue;
         float* dptr = p.dst + ((size_t)out + (size_t)s * plane2) * Cc2;
@@ -667,16 +667,19 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
 // one LDS image.  Per thread the global offsets are fixed for the whole kernel (only a uniform channel base advances).
 // Requires: conv_transpose, FAST channels, 128 % Wq == 0, Wq >= 32, Hq % (128 / Wq) == 0.  Tile, accumulators and epilogue
 // (incl. the fused head) are those of igemm_f32_kernel<128, BN, 4, 1, *, FR, 1, 1>.
-template <int BN, int FR, int PRE = 0>   // PRE: operands already in the split32 layout (plain copies into LDS)
+template <int BN, int FR, int PRE = 0, int BM = 128>   // PRE: operands already in the split32 layout (plain copies into LDS)
 __global__ __launch_bounds__(256, 2) void convT_tap_kernel(const IGemmP p) {
-  constexpr int BM = 128, WM = 4, WN = 1;
-  constexpr int TM = BM / WM;                    // 32 rows per wave
+  // BM = 256 (two image rows of 128, ...): the staged image grows by one row instead of doubling and the weight rows are
+  // shared by twice the outputs -- the kernel is bound by L2 -> LDS traffic (PMC: 49 % of wave cycles parked on waits,
+  // matrix pipe 24 % busy), so bytes per output are what counts.
+  constexpr int WM = 4, WN = 1;
+  constexpr int TM = BM / WM;                    // rows per wave
   constexpr int FM = TM / FR, FN = BN / FR;
   constexpr int GK = FR == 32 ? 8 : 16;
   constexpr int NG = BK / GK, NSTEP = NG / 2;
   constexpr int NE = FR == 32 ? 16 : 4;
   using AccT = typename std::conditional<FR == 32, f32x16, f32x4>::type;
-  constexpr int PMAX = 2 * 129;                  // staged input pixels: (R+1)*(Wq+1) <= 258 for Wq in {32, 64, 128}
+  constexpr int PMAX = (BM / 128 + 1) * 129;     // staged input pixels: (R+1)*(Wq+1) <= this for Wq in {32, 64, 128}
   constexpr int AR = (PMAX * 8 + 255) / 256;     // 16-byte loads per thread for the input image
   constexpr int BROWS = 4 * BN;                  // weight rows per chunk (4 taps x BN channels)
   constexpr int BRL = BROWS * 8 / 256;           // loads per thread for them
@@ -923,6 +926,7 @@ int g_extra_lds = 0;      // tuning experiment: dynamic LDS bytes added to every
 int g_phase_major = 0;    // -1: transposed-conv phases as grid z (four passes over the input) instead of interleaved
 int g_math_mode = 0;      // 0: fp32 MFMA (exact fp32 products); 1: bf16x3 split products (scalar-loader shapes only)
 int g_tapshare = 0;       // -1: never use the tap-sharing transposed-conv kernel
+int g_tap_bm = 0;         // 128: 128-output tiles only in the tap-sharing kernel
 int g_fast_loader = 0;    // -1: always use the generic (per-lane k decode) loader
 int g_narrow16 = 0;       // -1: never use the 16-wide (v_mfma_f32_16x16x4_f32) tile for N <= 16
 
@@ -1076,30 +1080,30 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   // narrow transposed convs in bf16x3 math: the four taps of a phase share one staged input image (convT_tap_kernel)
   if (p.convT && g_math_mode == 1 && g_tapshare >= 0 && p.fast_ok && p.N <= 64 && a.Wq >= 32 && 128 % a.Wq == 0 &&
       a.Hq % (128 / a.Wq) == 0 && g_force_splitk <= 0 && g_phase_major >= 0 && M >= 128L * 256) {
-    p.MT = (int)((M + 127) / 128);
+    // 256-output tiles when the image geometry and the block count allow (bytes per output: see the kernel)
+    const bool big = g_tap_bm != 128 && p.N <= 32 && a.Hq % (256 / a.Wq) == 0 && M >= 256L * 512;   // N = 64: 93 KB LDS, one block per CU
+    const int bm = big ? 256 : 128;
+    p.MT = (int)((M + bm - 1) / bm);
     p.NT = 1;
     p.S = 1;
     const long nblk = ((long)p.MT + 7) / 8 * 8 * 4;
-    if (nblk <= 0x7fffffffL) {
+    // measured (layer_bench, B=256, 512x256, 128-output tiles): N=16 368 -> 308 us, N=64 277 -> 249 us; N=32 no change, so the
+    // 32-wide stage uses this kernel only with split32 operands (runner) or when forced
+    const int w = (p.N <= 16 && g_narrow16 >= 0) ? 16 : (p.N <= 32 ? 32 : 64);
+    if (nblk <= 0x7fffffffL && (w != 32 || g_tapshare > 0 || p.presplit)) {
       const dim3 grid((unsigned)nblk), blk(256);
-      // measured (layer_bench, B=256, 512x256): N=16 368 -> 308 us, N=64 277 -> 249 us; N=32 no change (450 us: its block is
-      // dominated by the fixed costs around a 4-chunk loop), so the 32-wide stage stays on the staged engine unless forced
-      const bool use32 = g_tapshare > 0;
-      if (p.N <= 16 && g_narrow16 >= 0) {
-        if (p.presplit) hipLaunchKernelGGL((convT_tap_kernel<16, 16, 1>), grid, blk, 0, st, p);
-        else hipLaunchKernelGGL((convT_tap_kernel<16, 16, 0>), grid, blk, 0, st, p);
-        return launch_status("conv_igemm_f32 (tap-sharing convT)");
-      }
-      if (p.N > 32) {
-        if (p.presplit) hipLaunchKernelGGL((convT_tap_kernel<64, 32, 1>), grid, blk, 0, st, p);
-        else hipLaunchKernelGGL((convT_tap_kernel<64, 32, 0>), grid, blk, 0, st, p);
-        return launch_status("conv_igemm_f32 (tap-sharing convT)");
-      }
-      if (use32 || p.presplit) {
-        if (p.presplit) hipLaunchKernelGGL((convT_tap_kernel<32, 32, 1>), grid, blk, 0, st, p);
-        else hipLaunchKernelGGL((convT_tap_kernel<32, 32, 0>), grid, blk, 0, st, p);
-        return launch_status("conv_igemm_f32 (tap-sharing convT)");
-      }
+#define M2H_TAP(BN_, FR_)                                                                                   \
+  do {                                                                                                      \
+    if (p.presplit && big) hipLaunchKernelGGL((convT_tap_kernel<BN_, FR_, 1, 256>), grid, blk, 0, st, p);    \
+    else if (p.presplit) hipLaunchKernelGGL((convT_tap_kernel<BN_, FR_, 1, 128>), grid, blk, 0, st, p);      \
+    else if (big) hipLaunchKernelGGL((convT_tap_kernel<BN_, FR_, 0, 256>), grid, blk, 0, st, p);             \
+    else hipLaunchKernelGGL((convT_tap_kernel<BN_, FR_, 0, 128>), grid, blk, 0, st, p);                      \
+  } while (0)
+      if (w == 16) M2H_TAP(16, 16);
+      else if (w == 32) M2H_TAP(32, 32);
+      else M2H_TAP(64, 32);
+#undef M2H_TAP
+      return launch_status("conv_igemm_f32 (tap-sharing convT)");
     }
   }
   int BM, BN;
