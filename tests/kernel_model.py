@@ -139,3 +139,69 @@ def unet_forward(sd, enc_pre, dec_pre, mix, target_class=None, masks=None, eps=1
     B, H, W, _ = out.shape
     return conv_igemm(out, None, pack_conv_weight(hw), hw.shape[0], H, W, 1, 1, 1, 0, 0, 0, 0, False, None,
                       sd[dec_pre + "5.0.bias"], 1.0, None, None, H, W, 1, 0, 0, 1), feats
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16x3 math and the split32 layout (csrc/conv_igemm.hip SPLIT modes, include/m2h.h)
+# ---------------------------------------------------------------------------------------------------------------------
+def bf16_rne(x):
+    """fp32 -> bf16 (round to nearest even) -> fp32, as v_cvt_pk_bf16_f32 / a (__bf16) cast."""
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def split_hi_lo(x):
+    hi = bf16_rne(x)
+    lo = bf16_rne(np.asarray(x, np.float32) - hi)
+    return hi, lo
+
+
+def split32(x):
+    """fp32 array (last dim % 32 == 0) -> uint16 array [..., groups, 2, 32]: per 32-value group, 32 hi halves then 32 lo halves
+    (the byte image m2h_split32 writes in place of the group's 128 bytes)."""
+    x = np.asarray(x, np.float32)
+    g = x.reshape(x.shape[:-1] + (x.shape[-1] // 32, 32))
+    hi, lo = split_hi_lo(g)
+    return np.stack([(hi.view(np.uint32) >> 16).astype(np.uint16), (lo.view(np.uint32) >> 16).astype(np.uint16)], axis=-2)
+
+
+def bf16x3_matmul(a, w):
+    """A [M,K] x W[N,K]^T with the kernel's product formation: a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, fp32 accumulation
+    (numpy accumulates in float64 here: the model bounds the PRODUCT error, not the summation order)."""
+    ah, al = split_hi_lo(a)
+    wh, wl = split_hi_lo(w)
+    f = np.float64
+    return ah.astype(f) @ wh.astype(f).T + ah.astype(f) @ wl.astype(f).T + al.astype(f) @ wh.astype(f).T
+
+
+def convT_tap_phase(x, wp_phase, ph, pw, bm=128):
+    """Model of convT_tap_kernel for ONE sub-pixel phase: x NHWC [B,H,W,C] (one source), wp_phase [N][4*C] packed as
+    pack_convT_weight()[phase].  Follows the kernel's data flow: per tile of `bm` output pixels the (R+1) x (W+1) input
+    pixels are staged once (rows q0+hoff .., cols woff ..), and tap (th,tw) reads the window shifted by
+    tapoff = (th*dh - hoff)*W1 + (tw*dw - woff).  Returns the phase's outputs [B,H,W,N] (pixel (q,r) -> output (2q+ph, 2r+pw))."""
+    B, H, W, C = x.shape
+    N = wp_phase.shape[0]
+    assert bm % W == 0 and H % (bm // W) == 0
+    R, W1 = bm // W, W + 1
+    dh, dw = 2 * ph - 1, 2 * pw - 1
+    hoff, woff = min(dh, 0), min(dw, 0)
+    out = np.zeros((B, H, W, N), np.float64)
+    wt = wp_phase.reshape(N, 2, 2, C).astype(np.float64)
+    for b in range(B):
+        for q0 in range(0, H, R):
+            img = np.zeros(((R + 1) * W1, C), np.float64)          # the staged LDS image
+            for l in range((R + 1) * W1):
+                qi, rr = divmod(l, W1)
+                ih, iw = q0 + qi + hoff, rr + woff
+                if 0 <= ih < H and 0 <= iw < W:
+                    img[l] = x[b, ih, iw]
+            for ml in range(bm):                                    # tile row -> (qi, r); LDS row = qi*W1 + r + tapoff
+                qi, r = divmod(ml, W)
+                acc = np.zeros(N)
+                for th in range(2):
+                    for tw in range(2):
+                        tapoff = (th * dh - hoff) * W1 + (tw * dw - woff)
+                        acc += wt[:, th, tw, :] @ img[qi * W1 + r + tapoff]
+                out[b, q0 + qi, r] = acc
+    return out

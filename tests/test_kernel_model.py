@@ -33,3 +33,42 @@ def test_kernel_model_fully_convolutional_tm64():
         masks_o = O.get_binSepMasks(sd, torch.from_numpy(mixed), torch.from_numpy(tc))
     masks_k, _ = KM.unet_forward(sd_np, O.ENC_B, O.DEC_B, mixed, target_class=tc)
     assert O.rel_l1(torch.from_numpy(masks_k), masks_o) < 1e-5
+
+
+def test_split32_layout_and_bf16x3_product_error():
+    """x = hi + lo to 2^-16 relative; the three-product formation is within 2^-15 relative of the exact fp32 product sum
+    (the dropped lo*lo term and the two roundings), three orders of magnitude inside the 1e-3 contract."""
+    import kernel_model as KM
+    r = np.random.default_rng(0)
+    x = (r.standard_normal((5, 64)) * np.exp(r.uniform(-6, 6, (5, 64)))).astype(np.float32)
+    hi, lo = KM.split_hi_lo(x)
+    assert np.all(np.abs((hi.astype(np.float64) + lo) - x) <= np.abs(x) * 2.0 ** -16)
+    img = KM.split32(x)
+    assert img.shape == (5, 2, 2, 32) and img.dtype == np.uint16
+    back = (img[:, :, 0, :].astype(np.uint32) << 16).view(np.float32) + (img[:, :, 1, :].astype(np.uint32) << 16).view(np.float32)
+    assert np.array_equal(back.reshape(5, 64), (hi + lo).astype(np.float32))
+    a = r.standard_normal((33, 256)).astype(np.float32)
+    w = (r.standard_normal((17, 256)) * 0.1).astype(np.float32)
+    exact = a.astype(np.float64) @ w.astype(np.float64).T
+    got = KM.bf16x3_matmul(a, w)
+    scale = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T      # sum of |products|
+    assert np.all(np.abs(got - exact) <= scale * 2.0 ** -15)
+    plain = KM.bf16_rne(a).astype(np.float64) @ KM.bf16_rne(w).astype(np.float64).T
+    assert np.abs(plain - exact).max() > 30 * np.abs(got - exact).max()          # what the split buys over plain bf16 operands
+
+
+def test_tap_sharing_kernel_indexing_matches_conv_transpose():
+    """The staged-image / shifted-window indexing of convT_tap_kernel (128- and 256-output tiles, 1/2/4 image rows per tile)
+    reproduces torch's ConvTranspose2d(4, 2, 1) phase by phase."""
+    import kernel_model as KM
+    torch.manual_seed(0)
+    for (B, H, W, C, N, bm) in ((2, 4, 32, 8, 5, 128), (1, 2, 64, 4, 3, 128), (1, 2, 128, 4, 3, 256), (1, 8, 32, 4, 2, 256)):
+        x = torch.randn(B, C, H, W)
+        w = torch.randn(C, N, 4, 4) * 0.3
+        ref = torch.nn.functional.conv_transpose2d(x, w, stride=2, padding=1).permute(0, 2, 3, 1).double().numpy()
+        wp = KM.pack_convT_weight(w.numpy())
+        xn = x.permute(0, 2, 3, 1).contiguous().numpy()
+        for phase in range(4):
+            ph, pw = phase >> 1, phase & 1
+            got = KM.convT_tap_phase(xn, wp[phase], ph, pw, bm)
+            assert np.allclose(got, ref[:, ph::2, pw::2, :], atol=1e-5), (B, H, W, bm, phase)
