@@ -76,3 +76,21 @@ def test_checkpoint_round_trip_and_eval(tmp_path):
     stats3 = tr3.eval(num_episodes=3, checkpoint_path=str(tmp_path / "ckpt.0.pth"), waveform_metrics=("si_sdr", "si_sdri"), deterministic=True)
     assert abs(stats3["mono_loss_all_steps"]["mean"] - stats["mono_loss_all_steps"]["mean"]) < 1e-6
     assert abs(stats3["mono_si_sdr"]["mean"] - stats["mono_si_sdr"]["mean"]) < 1e-3
+
+
+def test_far_target_schedule_runs_with_env_rewards():
+    """farTarget.yaml (BASELINE config 5): nav_reward_weight 1 / sep_reward_weight 0 keeps the environment's
+    rewards (no quality-improvement override) and episodes are longer than the rollout; the cycle must run and update."""
+    from m2h.rl.ppo.ppo_trainer import PPOTrainer, far_target_config
+    cfg = far_target_config(NUM_PROCESSES=2, num_steps=4, num_updates_per_cycle=2, ppo_epoch=2, MAX_EPISODE_STEPS=6, use_ddppo=True)
+    assert cfg.nav_reward_weight == 1.0 and cfg.sep_reward_weight == 0.0
+    tr = PPOTrainer(cfg, torch.device("cuda", 0))
+    tr.setup()
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), 6).items()}
+    tr.actor_critic.load_state_dict(sd)
+    res = tr.train_cycle()
+    assert res["env_steps"] == 2 * 4 * 2
+    assert all(np.isfinite(res["pol_losses"])) and all(np.isfinite(res["sep_losses"]))
+    assert float(tr.rollouts_pol.rewards.abs().sum()) == 0.0           # the synthetic env's nav reward is zero and is NOT overridden
+    assert float(tr.stats.episode_counts.sum()) == 2                    # 8 steps per env, episodes of 6 -> one finished episode each
+    assert not torch.equal(tr.actor_critic.state_dict()["critic.fc.weight"].cpu(), sd["critic.fc.weight"])
