@@ -166,6 +166,9 @@ def load():
             raise RuntimeError(
                 "libm2h.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "-- the m2h ops have no CPU/PyTorch fallback." % LIB_PATH)
+        # torch first: libm2h.so's libamdhip64 dependency must bind to the HIP runtime torch has loaded (one runtime per
+        # process); loaded the other way round the two copies disagree about the device ("no ROCm-capable device").
+        import torch  # noqa: F401
         try:
             lib = ctypes.CDLL(LIB_PATH)
         except OSError as e:

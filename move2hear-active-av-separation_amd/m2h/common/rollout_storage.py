@@ -44,18 +44,29 @@ class RolloutStoragePol:
             setattr(self, name, getattr(self, name).to(device))
 
     def insert(self, observations, recurrent_hidden_states_pol, actions, action_log_probs, values, rewards, masks,
-               pred_binSepMasks=None, pred_mono=None, pred_monoFromMem=None):
+               pred_binSepMasks=None, pred_mono=None, pred_monoFromMem=None, at=None):
+        """at: None = the host step counter addresses the rows (reference behaviour, :68-96).  HIP-graph capture passes
+        ``(i, i1)`` = 1-element int64 device tensors holding step and step + 1: the rows are then addressed on the device
+        (index_copy_) and the host counter is left to the caller (``advance``), because a captured step is replayed."""
+        if at is None:
+            put = lambda t, off, v: t[self.step + off].copy_(v)  # noqa: E731
+        else:
+            put = lambda t, off, v: t.index_copy_(0, at[off], v.unsqueeze(0))  # noqa: E731
         for sensor in observations:
-            self.observations[sensor][self.step + 1].copy_(observations[sensor])
-        self.recurrent_hidden_states_pol[self.step + 1].copy_(recurrent_hidden_states_pol)
-        self.pred_binSepMasks[self.step].copy_(pred_binSepMasks)
-        self.pred_mono[self.step].copy_(pred_mono)
-        self.prev_pred_monoFromMem[self.step + 1].copy_(pred_monoFromMem)
-        self.rewards[self.step].copy_(rewards)
-        self.value_preds[self.step].copy_(values)
-        self.actions[self.step].copy_(actions)
-        self.action_log_probs[self.step].copy_(action_log_probs)
-        self.masks[self.step + 1].copy_(masks)
+            put(self.observations[sensor], 1, observations[sensor])
+        put(self.recurrent_hidden_states_pol, 1, recurrent_hidden_states_pol)
+        put(self.pred_binSepMasks, 0, pred_binSepMasks)
+        put(self.pred_mono, 0, pred_mono)
+        put(self.prev_pred_monoFromMem, 1, pred_monoFromMem)
+        put(self.rewards, 0, rewards)
+        put(self.value_preds, 0, values)
+        put(self.actions, 0, actions)
+        put(self.action_log_probs, 0, action_log_probs)
+        put(self.masks, 1, masks)
+        if at is None:
+            self.advance()
+
+    def advance(self):
         self.step = (self.step + 1) % self.num_steps
 
     def after_update(self):
@@ -124,12 +135,21 @@ class RolloutStorageSep:
         self.masks = self.masks.to(device)
         self.generation += 1
 
-    def insert(self, observations, masks, pred_monoFromMem=None):
-        self.generation += 1
+    def insert(self, observations, masks, pred_monoFromMem=None, at=None):
+        """at: see RolloutStoragePol.insert (here a 1-element device tensor holding step + 1)."""
+        if at is None:
+            put = lambda t, v: t[self.step + 1].copy_(v)  # noqa: E731
+        else:
+            put = lambda t, v: t.index_copy_(0, at, v.unsqueeze(0))  # noqa: E731
         for sensor in observations:
-            self.observations[sensor][self.step + 1].copy_(observations[sensor])
-        self.prev_pred_monoFromMem[self.step + 1].copy_(pred_monoFromMem)
-        self.masks[self.step + 1].copy_(masks)
+            put(self.observations[sensor], observations[sensor])
+        put(self.prev_pred_monoFromMem, pred_monoFromMem)
+        put(self.masks, masks)
+        if at is None:
+            self.advance()
+
+    def advance(self):
+        self.generation += 1
         self.step = (self.step + 1) % self.num_steps
 
     def after_update(self):

@@ -73,22 +73,34 @@ class SyntheticVecEnv:
 
     def step(self, actions):
         """actions: [N,1] int64 on the device.  Returns (obs dict, rewards [N,1], not_done masks [N,1], infos dict)."""
+        done = self.t + 1 >= self.episode_len
+        out = self.step_device(actions, done)
+        self.t = 0 if done else self.t + 1
+        return out
+
+    def step_device(self, actions, done):
+        """The device work of one step for a host-known ``done`` (all envs run fixed-length episodes in lockstep).  State
+        tensors are updated in place and nothing host-side changes, so the trainer can capture this in a HIP graph
+        (ppo_trainer.py); ``step`` = step_device + the host-side episode counter."""
         a = actions.reshape(-1)
         fwd = (a == 0).long()
-        self.node = (self.node + fwd) % self.n_nodes
-        self.angle = (self.angle + (a == 1).long() + 3 * (a == 2).long()) % 4
-        self.t += 1
-        done = self.t >= self.episode_len
         if done:  # auto-reset: a new mixture and pose for every env
-            self.t = 0
-            self.audio_idx = torch.randint(0, self.pool, (self.num_envs,), device=self.device, generator=self._g)
-            self.node = torch.randint(0, self.n_nodes, (self.num_envs,), device=self.device, generator=self._g)
-            self.angle = torch.randint(0, 4, (self.num_envs,), device=self.device, generator=self._g)
+            self.audio_idx.copy_(torch.randint(0, self.pool, (self.num_envs,), device=self.device, generator=self._g))
+            self.node.copy_(torch.randint(0, self.n_nodes, (self.num_envs,), device=self.device, generator=self._g))
+            self.angle.copy_(torch.randint(0, 4, (self.num_envs,), device=self.device, generator=self._g))
+        else:
+            self.node.copy_((self.node + fwd) % self.n_nodes)
+            self.angle.copy_((self.angle + (a == 1).long() + 3 * (a == 2).long()) % 4)
         masks = torch.full((self.num_envs, 1), 0.0 if done else 1.0, device=self.device)
         rewards = torch.zeros(self.num_envs, 1, device=self.device)  # nav reward (weight 0 in nearTarget.yaml:48-49)
         infos = {"normalized_geo_distance_to_target_audio_source": torch.zeros(self.num_envs, 1, device=self.device),
                  "geo_distance_to_target_audio_source": torch.zeros(self.num_envs, 1, device=self.device)}
         return self._obs(), rewards, masks, infos
+
+    @property
+    def generator(self):
+        """The env's device generator (a HIP graph that contains a reset must register it)."""
+        return self._g
 
     def close(self):
         pass

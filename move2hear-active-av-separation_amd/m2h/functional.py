@@ -8,6 +8,8 @@ Replaces torch's Conv2d/Linear autograd in audio_separation/rl/ppo/ppo.py:159-16
 """
 import ctypes
 
+import weakref
+
 import torch
 
 from . import _lib, ops
@@ -114,18 +116,42 @@ def bump_param_epoch():
     _param_epoch += 1
 
 
+def param_epoch():
+    return _param_epoch
+
+
+_pack_memos = weakref.WeakSet()
+
+
 class _PackMemo:
-    """Packed forward weights per (data_ptr, version, optimizer epoch): re-packed only when the weights may have changed."""
+    """Packed forward weights per (data_ptr, version, optimizer epoch): re-packed only when the weights may have changed, and
+    then IN PLACE, so the packed buffer keeps its address for as long as the weight keeps its shape (a captured HIP graph
+    holds that address; refresh_pack_memos() brings every memo up to date before a replay)."""
 
     def __init__(self):
-        self.key, self.val = None, None
+        self.key, self.val, self.src = None, None, None
+        _pack_memos.add(self)
 
     def get(self, w, ci_pad):
         key = (w.data_ptr(), w._version, ci_pad, _param_epoch)
         if key != self.key:
-            self.val = ops.pack_conv_weight_ex(w.detach().contiguous(), w.shape[1], ci_pad)
+            wd = w.detach().contiguous()
+            reuse = self.val is not None and self.key is not None and self.key[2] == ci_pad and self.val.device == wd.device \
+                and self.val.shape[0] == wd.shape[0] and self.val.shape[1] == wd.shape[2] * wd.shape[3] * ci_pad
+            self.val = ops.pack_conv_weight_ex(wd, w.shape[1], ci_pad, out=self.val if reuse else None)
             self.key = key
+            # the Parameter (whose storage FlatAdam may move into its flat buffer) rather than a view of its old storage
+            self.src = (w._base, tuple(w.shape), ci_pad) if w._base is not None else (w, None, ci_pad)
         return self.val
+
+
+def refresh_pack_memos():
+    """Re-packs (in place) every memo whose source weights changed since it was packed.  Called before a HIP-graph replay:
+    the graph reads the packed buffers by address and contains no pack kernels."""
+    for m in list(_pack_memos):
+        if m.src is not None:
+            base, shape, ci_pad = m.src
+            m.get(base if shape is None else base.view(shape), ci_pad)
 
 
 class Conv2dNHWC(torch.autograd.Function):

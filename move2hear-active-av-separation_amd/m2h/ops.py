@@ -321,10 +321,13 @@ def linear(x, w, bias=None, slope=1.0, name="linear", out=None):
     return y.reshape(M, w.shape[0])
 
 
-def pack_conv_weight_ex(w4d, ci_used, ci_out):
+def pack_conv_weight_ex(w4d, ci_used, ci_out, out=None):
+    """out: optional previously packed buffer of the same shape to refresh in place (its address stays valid for HIP graphs)."""
     _chk(w4d, "pack_conv_weight_ex")
     Co, Ci, KH, KW = w4d.shape
-    wp = torch.empty((Co, KH * KW * ci_out), device=w4d.device, dtype=torch.float32)
+    if out is not None and (tuple(out.shape) != (Co, KH * KW * ci_out) or out.device != w4d.device):
+        raise RuntimeError("pack_conv_weight_ex: out buffer does not match the packed shape")
+    wp = out if out is not None else torch.empty((Co, KH * KW * ci_out), device=w4d.device, dtype=torch.float32)
     lib = _lib.load()
     with torch.cuda.device(w4d.device):
         _lib.check(lib.m2h_pack_conv_weight_ex(_ptr(w4d), _ptr(wp), Co, Ci, KH, KW, ci_used, ci_out, _stream(w4d)), "m2h_pack_conv_weight_ex")

@@ -45,6 +45,12 @@ class FlatAdam(torch.optim.Optimizer):
         self.n = n
         self._built = True
 
+    def build(self):
+        """Moves the trainable parameters into the flat buffer now (otherwise done by the first zero_grad).  Anything that
+        holds parameter addresses across steps -- the trainer's HIP graphs -- calls this first."""
+        if not self._built:
+            self._build()
+
     def zero_grad(self, set_to_none=False):
         if not self._built:
             self._build()

@@ -7,6 +7,14 @@ same code runs over gloo on CPU for the world_size-2 tests.  The data path of th
                          ppo.py:313-319); the division by world size happens inside the optimizer step
   advantage statistics   two scalar all-reduces per update_pol (ddppo_utils.py:168-190)
 
+Overlap: ``GradReduceStep`` runs the all-reduce + clip + Adam of the LAST mini-batch of an update on a side HIP
+stream and hands back a fence; whoever next reads those parameters (Policy.act / get_value / evaluate_* for the policy,
+Policy.get_monoFromMem* for the acoustic memory) makes its stream wait on the fence first.  The collective and the optimizer
+step of update_pol's last epoch therefore run under the following update_sep passes / the bookkeeping of the next rollout,
+and those of update_sep's last epoch under the separator passes that open the next rollout -- the update itself is unchanged
+(gradients averaged before clip and step, every reader ordered after the step), which tests/test_distributed_cpu.py and
+tests/test_gpu_trainer.py check by comparing weights with the synchronous schedule.
+
 The local arithmetic (means, squared differences, normalisation) is injected as callables: HIP kernels in the product
 (m2h.ops.advantages / adv_sqdiff / adv_apply), the CPU oracle in the gloo tests.
 """
@@ -51,6 +59,56 @@ def reduce_gradients(flat_grad):
         return 1.0
     dist.all_reduce(flat_grad)
     return 1.0 / w
+
+
+class GradReduceStep:
+    """Gradient all-reduce + optimizer step of one backward, synchronous or deferred behind a fence.
+
+    submit(flat_grad, step_fn, defer): ``step_fn(grad_scale)`` launches clip + Adam on the *current* stream.
+      defer=False: all-reduce and step are enqueued on the caller's stream (the reference's order, ppo.py:313-319).
+      defer=True : GPU tensors -- both are enqueued on a side stream that first waits for the caller's stream (the backward);
+                   the caller's stream does not wait.  CPU tensors (gloo tests) -- the work is kept as a closure and executed
+                   by fence(), i.e. as late as the schedule allows, so a reader that forgets its fence shows up as a mismatch.
+    fence(): orders the current stream after the pending step (stream wait, no host sync); no-op when nothing is pending.
+    """
+
+    def __init__(self):
+        self._side = None
+        self._dev = None
+        self._event = None
+        self._lazy = None
+        self.deferred_steps = 0
+
+    def pending(self):
+        return self._event is not None or self._lazy is not None
+
+    def submit(self, flat_grad, step_fn, defer=False):
+        self.fence()  # at most one step in flight per parameter group; its buffers are about to be reused
+        if not defer:
+            step_fn(reduce_gradients(flat_grad))
+            return
+        self.deferred_steps += 1
+        if not flat_grad.is_cuda:
+            self._lazy = lambda: step_fn(reduce_gradients(flat_grad))
+            return
+        dev = self._dev = flat_grad.device
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        backward_done = torch.cuda.Event()
+        backward_done.record(torch.cuda.current_stream(dev))
+        self._side.wait_event(backward_done)
+        with torch.cuda.stream(self._side):
+            step_fn(reduce_gradients(flat_grad))
+            self._event = torch.cuda.Event()
+            self._event.record(self._side)
+
+    def fence(self):
+        if self._lazy is not None:
+            fn, self._lazy = self._lazy, None
+            fn()
+        if self._event is not None:
+            ev, self._event = self._event, None
+            torch.cuda.current_stream(self._dev).wait_event(ev)
 
 
 def normalize_advantages_distributed(raw_adv, local_mean, sqdiff_fn, apply_fn, eps=1e-5):

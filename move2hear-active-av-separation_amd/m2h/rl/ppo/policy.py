@@ -109,6 +109,19 @@ class Policy(nn.Module):
     def forward(self):
         raise NotImplementedError
 
+    # DD-PPO overlap (ppo.py, ddppo_utils.GradReduceStep): the optimizer step of a parameter group ("pol": pol_net + heads,
+    # "mem": acoustic_mem) may still be running on the side stream; every method that reads the group waits on its fence.
+    _param_fences = None
+
+    def _fence(self, group):
+        if self._param_fences is not None:
+            self._param_fences[group].fence()
+
+    def state_dict(self, *args, **kwargs):
+        self._fence("pol")
+        self._fence("mem")
+        return super().state_dict(*args, **kwargs)
+
     def get_binSepMasks(self, observations):
         enc, dec = self.binSep_enc.passive_sep_encoder, self.binSep_dec.passive_sep_decoder
         if not enc.training and not dec.training and not ops.timing_enabled() and observations["mixed_bin_audio_mag"].shape[1] == 512:
@@ -125,10 +138,12 @@ class Policy(nn.Module):
         return self.bin2mono_dec(bottleneck_feats, lst_skip_feats)
 
     def get_monoFromMem(self, pred_mono, prev_pred_monoFromMem_masked):
+        self._fence("mem")
         return self.acoustic_mem(pred_mono, prev_pred_monoFromMem_masked)
 
     def get_monoFromMem_masked(self, pred_mono, prev_pred_monoFromMem, masks):
         """get_monoFromMem with the not-done masking of the previous memory fused (ppo_trainer.py:310-319)."""
+        self._fence("mem")
         return self.acoustic_mem.forward_masked(pred_mono, prev_pred_monoFromMem, masks)
 
     def _heads(self, feats, actions=None):
@@ -140,6 +155,7 @@ class Policy(nn.Module):
     def evaluate_rows(self, observations, rnn_hidden_states_pol, masks, action, pred_binSepMasks=None, pred_mono=None,
                       pred_monoFromMem=None):
         """evaluate_actions with the per-row entropies (what the fused PPO-loss kernel consumes)."""
+        self._fence("pol")
         feats_pol, rnn_hidden_states_pol = self.pol_net(
             observations, rnn_hidden_states_pol, masks, pred_binSepMasks=pred_binSepMasks, pred_mono=pred_mono,
             pred_monoFromMem=pred_monoFromMem)
@@ -148,6 +164,7 @@ class Policy(nn.Module):
 
     def act(self, observations, rnn_hidden_states_pol, masks, deterministic=False, pred_binSepMasks=None, pred_mono=None,
             pred_monoFromMem=None):
+        self._fence("pol")
         feats_pol, rnn_hidden_states_pol = self.pol_net(
             observations, rnn_hidden_states_pol, masks, pred_binSepMasks=pred_binSepMasks.detach(),
             pred_mono=pred_mono.detach(), pred_monoFromMem=pred_monoFromMem.detach())
@@ -157,6 +174,7 @@ class Policy(nn.Module):
         return value, action, action_log_probs, rnn_hidden_states_pol, dist.get_probs()
 
     def get_value(self, observations, rnn_hidden_states_pol, masks, pred_binSepMasks=None, pred_mono=None, pred_monoFromMem=None):
+        self._fence("pol")
         feats_pol, _ = self.pol_net(
             observations, rnn_hidden_states_pol, masks, pred_binSepMasks=pred_binSepMasks.detach(),
             pred_mono=pred_mono.detach(), pred_monoFromMem=pred_monoFromMem.detach())
@@ -165,6 +183,7 @@ class Policy(nn.Module):
 
     def evaluate_actions(self, observations, rnn_hidden_states_pol, masks, action, pred_binSepMasks=None, pred_mono=None,
                          pred_monoFromMem=None):
+        self._fence("pol")
         feats_pol, rnn_hidden_states_pol = self.pol_net(
             observations, rnn_hidden_states_pol, masks, pred_binSepMasks=pred_binSepMasks, pred_mono=pred_mono,
             pred_monoFromMem=pred_monoFromMem)

@@ -29,7 +29,7 @@ class PPO(nn.Module):
     def __init__(self, actor_critic, clip_param, ppo_epoch, num_mini_batch, value_loss_coef, bin_separation_loss_coef,
                  mono_conversion_loss_coef, entropy_coef, lr_pol=None, lr_sep=None, eps=None, max_grad_norm=None,
                  freeze_passive_separators=False, use_clipped_value_loss=True, use_normalized_advantage=True,
-                 cache_separator_outputs=True):
+                 cache_separator_outputs=True, overlap_grad_reduce=None):
         super().__init__()
         self.actor_critic = actor_critic
         self.clip_param = clip_param
@@ -55,6 +55,11 @@ class PPO(nn.Module):
         self.device = next(actor_critic.parameters()).device
         self._world = 1
         self._sep_cache = None
+        # overlap_grad_reduce: None = on when distributed (init_distributed), True = also at world size 1 (the side-stream
+        # schedule without the collective; tests), False = the synchronous order of the reference
+        self.overlap_grad_reduce = overlap_grad_reduce
+        self._reducers = {"pol": ddppo_utils.GradReduceStep(), "mem": ddppo_utils.GradReduceStep()}
+        actor_critic._param_fences = self._reducers  # readers of the parameters fence on these (policy.py)
 
     def load_pretrained_passive_separators(self, state_dict):
         ac = self.actor_critic
@@ -86,17 +91,28 @@ class PPO(nn.Module):
         self.find_unused_params = find_unused_params
         ddppo_utils.broadcast_parameters(list(self.actor_critic.parameters()) + list(self.actor_critic.buffers()))
 
-    def _reduce_grads(self, opt):
-        if self._world > 1:
-            return ddppo_utils.reduce_gradients(opt.grad_buffer())  # one flat sum all-reduce (RCCL)
-        return 1.0
+    def _overlap(self):
+        return self._world > 1 if self.overlap_grad_reduce is None else bool(self.overlap_grad_reduce)
+
+    def _reduce_and_step(self, group, opt, last):
+        """One flat sum all-reduce (RCCL) + clip + Adam.  The last mini-batch of an update is deferred onto the side stream
+        when overlap is on: nothing in the rest of the update reads these parameters (ddppo_utils.GradReduceStep)."""
+        self._reducers[group].submit(
+            opt.grad_buffer(), lambda gscale: opt.step(max_grad_norm=self.max_grad_norm, grad_scale=gscale),
+            defer=last and self._overlap())
+
+    def synchronize_updates(self):
+        """Orders the current stream after every pending optimizer step (before reading parameters outside the policy's
+        own methods: checkpoints, tests)."""
+        for r in self._reducers.values():
+            r.fence()
 
     # ------------------------------------------------------------------ policy update (reference :82-177)
     def update_pol(self, rollouts_pol):
         advantages = self.get_advantages(rollouts_pol)
         acc = torch.zeros(4, device=self.device)
         for _e in range(self.ppo_epoch):
-            for sample in rollouts_pol.recurrent_generator(advantages, self.num_mini_batch):
+            for _mb, sample in enumerate(rollouts_pol.recurrent_generator(advantages, self.num_mini_batch)):
                 (obs_batch, h_batch, pm_batch, mono_batch, mem_batch, value_preds_batch, return_batch, adv_targ, actions_batch,
                  old_logp_batch, masks_batch) = sample
                 values, logp, ent_rows, _ = self.actor_critic.evaluate_rows(
@@ -107,8 +123,8 @@ class PPO(nn.Module):
                                                      float(self.clip_param), float(self.value_loss_coef), float(self.entropy_coef),
                                                      bool(self.use_clipped_value_loss))
                 total_loss.backward()
-                gscale = self._reduce_grads(self.optimizer_pol)
-                self.optimizer_pol.step(max_grad_norm=self.max_grad_norm, grad_scale=gscale)  # before_step_pol + step
+                self._reduce_and_step("pol", self.optimizer_pol,  # before_step_pol + step
+                                      last=_e == self.ppo_epoch - 1 and _mb == self.num_mini_batch - 1)
                 acc += stats
         num_updates = self.ppo_epoch * self.num_mini_batch
         v, a, h, _ = (acc / num_updates).tolist()  # the only host read of the update
@@ -143,7 +159,7 @@ class PPO(nn.Module):
         for _e in range(self.ppo_epoch):
             needed = ("mixed_bin_audio_mag", "gt_mono_comps", "gt_bin_comps", "target_class")  # what this update reads
             gen = rollouts_sep.recurrent_generator(self.num_mini_batch, with_perm=True, sensors=needed)
-            for sample in gen:
+            for _mb, sample in enumerate(gen):
                 obs_batch, _mem_batch, prev_mem_batch, masks_batch, idx = sample
                 if cached is not None:
                     pred_binSepMasks = ops.take_envs(cached[0], idx, idx is None)
@@ -161,8 +177,7 @@ class PPO(nn.Module):
                     bin_loss = ops.bin_l1_loss(obs_batch["mixed_bin_audio_mag"], pred_binSepMasks, obs_batch["gt_bin_comps"])
                 self.optimizer_sep.zero_grad()
                 monoFromMem_loss.backward()                                          # total_loss = monoFromMem_loss (:226)
-                gscale = self._reduce_grads(self.optimizer_sep)
-                self.optimizer_sep.step(max_grad_norm=self.max_grad_norm, grad_scale=gscale)
+                self._reduce_and_step("mem", self.optimizer_sep, last=_e == self.ppo_epoch - 1 and _mb == self.num_mini_batch - 1)
                 acc += torch.stack((bin_loss, mono_loss, monoFromMem_loss.detach()))
         num_updates = self.ppo_epoch * self.num_mini_batch
         b, m, mm = (acc / num_updates).tolist()

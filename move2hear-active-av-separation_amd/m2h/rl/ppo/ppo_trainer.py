@@ -36,7 +36,9 @@ def near_target_config(**over):
              mono_conversion_loss_coef=1.0, entropy_coef=0.20, lr_pol=1.0e-4, lr_sep=5.0e-4, clip_param=0.1, ppo_epoch=4,
              num_mini_batch=1, eps=1.0e-5, max_grad_norm=0.5, num_steps=20, use_gae=True, gamma=0.99, tau=0.95,
              use_linear_clip_decay=True, use_linear_lr_decay=True, sep_reward_weight=1.0, nav_reward_weight=0.0,
-             extra_reward_multiplier=10.0, reward_window_size=50, use_ddppo=True, CHECKPOINT_FOLDER=None)
+             extra_reward_multiplier=10.0, reward_window_size=50, use_ddppo=True, CHECKPOINT_FOLDER=None,
+             use_hip_graphs=True,       # build-side key: replay the rollout step from a HIP graph (same kernels, same results)
+             overlap_grad_reduce=None)  # build-side key: None = overlap the last all-reduce + step of an update when distributed
     c.update(over)
     return SimpleNamespace(**c)
 
@@ -55,6 +57,7 @@ class PPOTrainer:
         self.agent = None
         self.envs = None
         self._next_cache = None
+        self._graph_state = None
 
     # ------------------------------------------------------------------ setup (reference :101-222, :542-577, :588-661)
     def setup(self, passive_state_dict=None):
@@ -72,7 +75,8 @@ class PPOTrainer:
                          num_mini_batch=cfg.num_mini_batch, value_loss_coef=cfg.value_loss_coef,
                          bin_separation_loss_coef=cfg.bin_separation_loss_coef, mono_conversion_loss_coef=cfg.mono_conversion_loss_coef,
                          entropy_coef=cfg.entropy_coef, lr_pol=cfg.lr_pol, lr_sep=cfg.lr_sep, eps=cfg.eps,
-                         max_grad_norm=cfg.max_grad_norm, freeze_passive_separators=True)
+                         max_grad_norm=cfg.max_grad_norm, freeze_passive_separators=True,
+                         overlap_grad_reduce=getattr(cfg, "overlap_grad_reduce", None))
         self.actor_critic.train()
         if passive_state_dict is not None:
             self.agent.load_pretrained_passive_separators(passive_state_dict)
@@ -119,57 +123,141 @@ class PPOTrainer:
         return pm, mono
 
     def _collect_rollout_step(self):
+        """One environment step for all envs (reference :253-478).  With ``use_hip_graphs`` the step is replayed from a HIP
+        graph whenever the previous step left its next-observation separator outputs behind (every step but the first after
+        update_sep); otherwise it is enqueued kernel by kernel."""
+        cfg = self.config
+        override = cfg.sep_reward_weight == 1.0 and cfg.nav_reward_weight == 0.0
+        extra = override and self._episode_step_host == cfg.MAX_EPISODE_STEPS - 2
+        done = self.envs.t + 1 >= self.envs.episode_len
+        if self._graphs_enabled() and self._next_cache is not None:
+            self._graph_step(extra, done)
+            self.rollouts_pol.advance()  # the replayed inserts address their rows on the device
+            self.rollouts_sep.advance()
+        else:
+            with torch.no_grad():
+                self._next_cache = self._rollout_step_device(self._next_cache, None, extra, done)
+        # host-side counters
+        self.envs.t = 0 if done else self.envs.t + 1
+        self._episode_step_host = (self._episode_step_host + 1) % cfg.MAX_EPISODE_STEPS
+        return self.envs.num_envs
+
+    def _rollout_step_device(self, cache, at, extra, done):
+        """The device work of one rollout step.  With ``at`` it changes no host-side state, so it can be captured once and
+        replayed (without ``at`` the storages' inserts advance their host step counters, as in the reference).
+        cache: (pred_binSepMasks, pred_mono, pred_monoFromMem) of the current observation left by the previous step, or None.
+        at: None = rows of the storages addressed by their host step counters (views); HIP-graph capture passes the device
+        index tensors (ro_step, ro_step + 1, rs_step + 1).  extra / done: the two host-known schedule flags (extra reward at
+        MAX_EPISODE_STEPS - 2, :395-405; lockstep episode end).  Returns the next step's cache."""
         cfg, ac, ro, rs, st = self.config, self.actor_critic, self.rollouts_pol, self.rollouts_sep, self.stats
         L = 512 * 32
-        with torch.no_grad():
-            step_observation = {k: v[ro.step] for k, v in ro.observations.items()}
-            if self._next_cache is not None:
-                pred_binSepMasks, pred_mono, pred_monoFromMem = self._next_cache  # computed for the reward of the previous step
-            else:
-                pred_binSepMasks, pred_mono = self._separate(step_observation)
-                pred_monoFromMem = ac.get_monoFromMem_masked(pred_mono, ro.prev_pred_monoFromMem[ro.step], ro.masks[ro.step])
-            values, actions, actions_log_probs, recurrent_hidden_states_pol, distribution_probs = ac.act(
-                step_observation, ro.recurrent_hidden_states_pol[ro.step], ro.masks[ro.step], pred_binSepMasks=pred_binSepMasks,
-                pred_mono=pred_mono, pred_monoFromMem=pred_monoFromMem)
-            batch, rewards, masks, infos = self.envs.step(actions)  # device in, device out
-            # next-step predictions, needed for the reward of the present step (:358-373)
-            next_pred_binSepMasks, next_pred_mono = self._separate(batch)
-            next_pred_monoFromMem = ac.get_monoFromMem_masked(next_pred_mono, pred_monoFromMem, masks)
-            self._next_cache = (next_pred_binSepMasks, next_pred_mono, next_pred_monoFromMem)
-            if cfg.sep_reward_weight == 1.0 and cfg.nav_reward_weight == 0.0:  # :385-405
-                nxt = ops.sq_stats(next_pred_monoFromMem, batch["gt_mono_comps"], 0)
-                cur = ops.sq_stats(pred_monoFromMem, step_observation["gt_mono_comps"], 0)
-                rewards = ops.rewards_from_stats(nxt, cur, masks, L, True)
-                if self._episode_step_host == cfg.MAX_EPISODE_STEPS - 2:
-                    rewards = rewards + ops.rewards_from_stats(nxt, None, masks, L, False, cfg.extra_reward_multiplier)
-            # STFT-L2 bookkeeping (:407-420)
-            bin_losses = ops.stft_l2(pred_binSepMasks, step_observation["gt_bin_comps"], 2, mix=step_observation["mixed_bin_audio_mag"])
-            mono_losses = ops.stft_l2(pred_mono, step_observation["gt_mono_comps"], 1)
-            monoFromMem_losses = ops.stft_l2(pred_monoFromMem, step_observation["gt_mono_comps"], 1)
-            st.current_episode_reward += rewards
-            st.current_episode_step += 1
-            st.current_episode_dist_probs += distribution_probs
-            st.current_episode_bin_losses += bin_losses
-            st.current_episode_mono_losses += mono_losses
-            st.current_episode_monoFromMem_losses += monoFromMem_losses
-            nd = 1 - masks
-            st.episode_rewards += nd * st.current_episode_reward
-            st.episode_steps += nd * st.current_episode_step
-            st.episode_counts += nd
-            st.episode_dist_probs += nd * (st.current_episode_dist_probs / st.current_episode_step)
-            st.episode_bin_losses_allSteps += nd * (st.current_episode_bin_losses / st.current_episode_step)
-            st.episode_mono_losses_lastStep += nd * mono_losses
-            st.episode_mono_losses_allSteps += nd * (st.current_episode_mono_losses / st.current_episode_step)
-            st.episode_monoFromMem_losses_lastStep += nd * monoFromMem_losses
-            st.episode_monoFromMem_losses_allSteps += nd * (st.current_episode_monoFromMem_losses / st.current_episode_step)
-            for name in ("current_episode_reward", "current_episode_step", "current_episode_bin_losses", "current_episode_mono_losses",
-                         "current_episode_monoFromMem_losses", "current_episode_dist_probs"):
-                getattr(st, name).mul_(masks)
-            self._episode_step_host = (self._episode_step_host + 1) % cfg.MAX_EPISODE_STEPS
-            ro.insert(batch, recurrent_hidden_states_pol, actions, actions_log_probs, values, rewards, masks,
-                      pred_binSepMasks=pred_binSepMasks, pred_mono=pred_mono, pred_monoFromMem=pred_monoFromMem)
-            rs.insert(batch, masks, pred_monoFromMem=pred_monoFromMem)
-        return self.envs.num_envs
+        row = (lambda t: t[ro.step]) if at is None else (lambda t: t.index_select(0, at[0]).squeeze(0))
+        step_observation = {k: row(v) for k, v in ro.observations.items()}
+        step_masks, step_h = row(ro.masks), row(ro.recurrent_hidden_states_pol)
+        if cache is not None:
+            pred_binSepMasks, pred_mono, pred_monoFromMem = cache  # computed for the reward of the previous step
+        else:
+            pred_binSepMasks, pred_mono = self._separate(step_observation)
+            pred_monoFromMem = ac.get_monoFromMem_masked(pred_mono, row(ro.prev_pred_monoFromMem), step_masks)
+        values, actions, actions_log_probs, recurrent_hidden_states_pol, distribution_probs = ac.act(
+            step_observation, step_h, step_masks, pred_binSepMasks=pred_binSepMasks,
+            pred_mono=pred_mono, pred_monoFromMem=pred_monoFromMem)
+        batch, rewards, masks, infos = self.envs.step_device(actions, done)  # device in, device out
+        # next-step predictions, needed for the reward of the present step (:358-373)
+        next_pred_binSepMasks, next_pred_mono = self._separate(batch)
+        next_pred_monoFromMem = ac.get_monoFromMem_masked(next_pred_mono, pred_monoFromMem, masks)
+        if cfg.sep_reward_weight == 1.0 and cfg.nav_reward_weight == 0.0:  # :385-405
+            nxt = ops.sq_stats(next_pred_monoFromMem, batch["gt_mono_comps"], 0)
+            cur = ops.sq_stats(pred_monoFromMem, step_observation["gt_mono_comps"], 0)
+            rewards = ops.rewards_from_stats(nxt, cur, masks, L, True)
+            if extra:
+                rewards = rewards + ops.rewards_from_stats(nxt, None, masks, L, False, cfg.extra_reward_multiplier)
+        # STFT-L2 bookkeeping (:407-420)
+        bin_losses = ops.stft_l2(pred_binSepMasks, step_observation["gt_bin_comps"], 2, mix=step_observation["mixed_bin_audio_mag"])
+        mono_losses = ops.stft_l2(pred_mono, step_observation["gt_mono_comps"], 1)
+        monoFromMem_losses = ops.stft_l2(pred_monoFromMem, step_observation["gt_mono_comps"], 1)
+        st.current_episode_reward += rewards
+        st.current_episode_step += 1
+        st.current_episode_dist_probs += distribution_probs
+        st.current_episode_bin_losses += bin_losses
+        st.current_episode_mono_losses += mono_losses
+        st.current_episode_monoFromMem_losses += monoFromMem_losses
+        nd = 1 - masks
+        st.episode_rewards += nd * st.current_episode_reward
+        st.episode_steps += nd * st.current_episode_step
+        st.episode_counts += nd
+        st.episode_dist_probs += nd * (st.current_episode_dist_probs / st.current_episode_step)
+        st.episode_bin_losses_allSteps += nd * (st.current_episode_bin_losses / st.current_episode_step)
+        st.episode_mono_losses_lastStep += nd * mono_losses
+        st.episode_mono_losses_allSteps += nd * (st.current_episode_mono_losses / st.current_episode_step)
+        st.episode_monoFromMem_losses_lastStep += nd * monoFromMem_losses
+        st.episode_monoFromMem_losses_allSteps += nd * (st.current_episode_monoFromMem_losses / st.current_episode_step)
+        for name in ("current_episode_reward", "current_episode_step", "current_episode_bin_losses", "current_episode_mono_losses",
+                     "current_episode_monoFromMem_losses", "current_episode_dist_probs"):
+            getattr(st, name).mul_(masks)
+        ro.insert(batch, recurrent_hidden_states_pol, actions, actions_log_probs, values, rewards, masks,
+                  pred_binSepMasks=pred_binSepMasks, pred_mono=pred_mono, pred_monoFromMem=pred_monoFromMem,
+                  at=None if at is None else (at[0], at[1]))
+        rs.insert(batch, masks, pred_monoFromMem=pred_monoFromMem, at=None if at is None else at[2])
+        return next_pred_binSepMasks, next_pred_mono, next_pred_monoFromMem
+
+    # ------------------------------------------------------------------ HIP-graph replay of the rollout step
+    def _graphs_enabled(self):
+        return bool(getattr(self.config, "use_hip_graphs", False)) and not ops.timing_enabled()
+
+    def _graph_step(self, extra, done):
+        """The rollout step is ~150 small launches behind ~2 ms of Python; its device work depends on the host only through
+        (extra, done), so one HIP graph per flag pair is captured on first use and replayed afterwards.  The graph reads the
+        step's rows of the storages through device-resident indices (advanced inside the graph), the previous step's
+        separator outputs from three static buffers, and the policy / acoustic-memory weights by address: parameters live in
+        FlatAdam's flat buffers and packed copies are refreshed in place (functional.refresh_pack_memos) before a replay."""
+        from ... import functional as MF
+        ro, rs = self.rollouts_pol, self.rollouts_sep
+        gs = self._graph_state
+        if gs is None:
+            dev = self.device
+            gs = self._graph_state = SimpleNamespace(
+                graphs={}, pool=None, where=None, idx=torch.zeros(3, dtype=torch.int64, device=dev), expect=None, epoch=None,
+                cache=tuple(torch.empty_like(t) for t in self._next_cache))
+        if self._next_cache[0] is not gs.cache[0]:  # the previous step ran outside the graphs: hand its outputs over
+            for dst, src in zip(gs.cache, self._next_cache):
+                dst.copy_(src)
+            self._next_cache = gs.cache
+        if gs.expect != (ro.step, rs.step):  # device indices out of step with the host counters (eager steps in between)
+            for j, v in enumerate((ro.step, ro.step + 1, rs.step + 1)):
+                gs.idx[j:j + 1].fill_(v)
+        if gs.epoch != MF.param_epoch():
+            self.agent.optimizer_pol.build()  # parameters move into the flat buffers once; the graphs hold their addresses
+            self.agent.optimizer_sep.build()
+            self.actor_critic._fence("pol")
+            self.actor_critic._fence("mem")
+            MF.refresh_pack_memos()
+            gs.epoch = MF.param_epoch()
+            where = tuple(p.data_ptr() for p in self.actor_critic.parameters())
+            if where != gs.where:  # a parameter was re-allocated (first build, .to(), ...): captured addresses are stale
+                gs.graphs.clear()
+                gs.where = where
+        key = (bool(extra), bool(done))
+        g = gs.graphs.get(key)
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            g.register_generator_state(self.envs.generator)
+            with torch.no_grad(), torch.cuda.graph(g, pool=gs.pool):
+                at = (gs.idx[0:1], gs.idx[1:2], gs.idx[2:3])
+                nxt = self._rollout_step_device(gs.cache, at, extra, done)
+                for dst, src in zip(gs.cache, nxt):
+                    dst.copy_(src)
+                # advance the device-side step indices: ro_step <- (ro_step + 1) % T, rs_step likewise
+                nro = (gs.idx[0:1] + 1) % ro.num_steps
+                nrs = gs.idx[2:3] % rs.num_steps  # idx[2] holds rs_step + 1
+                gs.idx[0:1].copy_(nro)
+                gs.idx[1:2].copy_(nro + 1)
+                gs.idx[2:3].copy_(nrs + 1)
+            if gs.pool is None:
+                gs.pool = g.pool()
+            gs.graphs[key] = g
+        g.replay()
+        gs.expect = ((ro.step + 1) % ro.num_steps, (rs.step + 1) % rs.num_steps)
 
     # ------------------------------------------------------------------ updates (reference :480-541)
     def _update_pol(self):
@@ -236,6 +324,7 @@ class PPOTrainer:
         sd = {k[len("actor_critic."):]: v for k, v in state_dict.items() if k.startswith("actor_critic.")}
         if not sd:
             raise RuntimeError("checkpoint state_dict has no 'actor_critic.*' keys")
+        self.agent.synchronize_updates()  # a deferred optimizer step may still be writing the parameters
         out = self.actor_critic.load_state_dict(sd, strict=strict)
         from ... import functional as MF
         MF.bump_param_epoch()  # packed-weight memos key on the optimizer epoch

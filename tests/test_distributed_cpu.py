@@ -48,7 +48,32 @@ def _worker(rank, world, port, q):
     # 4. fused stats all-reduce
     t = D.all_reduce_stats(torch.tensor([1.0 + rank, 2.0]))
     ok_s = torch.allclose(t, torch.tensor([sum(1.0 + r for r in range(world)), 2.0 * world]))
-    q.put((rank, ok_b, ok_g, ok_a, ok_s))
+    # 5. deferred all-reduce + step (GradReduceStep): a toy DD-PPO schedule -- "rollouts" read the parameters through the fence,
+    #    each update = 2 epochs whose last step is deferred -- ends with the weights of the synchronous schedule, and the
+    #    deferral is real (before the fence the parameters are still the old ones)
+    def run(defer_last):
+        p = torch.linspace(-1, 1, 64).clone()
+        red = D.GradReduceStep()
+        seen, late = [], True
+        for upd in range(3):
+            red.fence()                                   # reader: the rollout
+            seen.append(p.clone())
+            for ep in range(2):
+                red.fence()                               # reader: evaluate_actions
+                grad = torch.sin(p * (upd + 1)) * (rank + 1) + ep
+
+                def step(scale, grad=grad):
+                    p.sub_(0.1 * grad * scale)
+                before = p.clone()
+                red.submit(grad, step, defer=defer_last and ep == 1)
+                if defer_last and ep == 1:
+                    late = late and torch.equal(p, before) and red.pending()
+        red.fence()
+        return p, seen, late, red.deferred_steps
+    p_sync, seen_sync, _, n_sync = run(False)
+    p_def, seen_def, late, n_def = run(True)
+    ok_d = torch.equal(p_sync, p_def) and all(torch.equal(a, b) for a, b in zip(seen_sync, seen_def)) and late and (n_sync, n_def) == (0, 3)
+    q.put((rank, ok_b, ok_g, ok_a, ok_s, ok_d))
     torch.distributed.destroy_process_group()
 
 

@@ -37,6 +37,55 @@ def test_training_cycle_runs_and_updates_only_trainable_parts():
     assert all(np.isfinite(res2["pol_losses"]))
 
 
+def test_overlapped_grad_reduce_schedule_gives_the_synchronous_weights():
+    """running the last all-reduce + clip + Adam of every update on the side stream, fenced at the next reader of
+    those parameters, must give bit-identical weights, losses and rollout contents to the synchronous order."""
+    runs = []
+    for overlap in (False, True):
+        tr, _ = _trainer(overlap_grad_reduce=overlap)
+        losses = []
+        for c in range(2):
+            torch.manual_seed(500 + c)  # action sampling draws from the global device generator
+            res = tr.train_cycle()
+            losses.append((res["pol_losses"], res["sep_losses"]))
+        red = tr.agent._reducers
+        assert (red["pol"].deferred_steps, red["mem"].deferred_steps) == ((4, 4) if overlap else (0, 0))
+        assert red["pol"].pending() == overlap  # the last policy step is still fenced until someone reads the policy
+        sd = {k: v.detach().cpu().clone() for k, v in tr.actor_critic.state_dict().items()}  # state_dict() fences
+        assert not red["pol"].pending() and not red["mem"].pending()
+        runs.append((losses, sd, tr.rollouts_pol.value_preds.cpu().clone(), tr.rollouts_sep.prev_pred_monoFromMem.cpu().clone()))
+    (la, sa, va, ma), (lb, sb, vb, mb) = runs
+    assert la == lb
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert torch.equal(va, vb) and torch.equal(ma, mb)
+
+
+def test_hip_graph_rollout_equals_the_kernel_by_kernel_rollout():
+    """The rollout step replayed from a HIP graph (device-indexed storage rows, static separator-output buffers, in-place
+    packed weights) must leave bit-identical storages, statistics, sampled actions and -- after the updates -- weights."""
+    runs = []
+    for graphs in (False, True):
+        tr, _ = _trainer(use_hip_graphs=graphs, MAX_EPISODE_STEPS=3)  # episodes of 3 against rollouts of 4: every (extra, done) variant
+        snaps = []
+        for c in range(2):
+            torch.manual_seed(900 + c)
+            tr.train_cycle()
+            snaps.append((tr.rollouts_pol.actions.cpu().clone(), tr.rollouts_pol.rewards.cpu().clone(),
+                          tr.rollouts_pol.observations["rgb"].cpu().clone(), tr.rollouts_sep.prev_pred_monoFromMem.cpu().clone(),
+                          tr.rollouts_sep.observations["mixed_bin_audio_mag"].cpu().clone(), tr.stats.episode_rewards.cpu().clone(),
+                          tr.stats.episode_counts.cpu().clone(), tr.rollouts_pol.recurrent_hidden_states_pol.cpu().clone()))
+        gs = tr._graph_state
+        assert (gs is not None and len(gs.graphs) == 3) if graphs else gs is None  # (extra, done) in {(0,0), (1,0), (0,1)}
+        runs.append((snaps, {k: v.detach().cpu().clone() for k, v in tr.actor_critic.state_dict().items()}))
+    (sa, wa), (sb, wb) = runs
+    for ca, cb in zip(sa, sb):
+        for ta, tb in zip(ca, cb):
+            assert torch.equal(ta, tb)
+    for k in wa:
+        assert torch.equal(wa[k], wb[k]), k
+
+
 def test_next_step_cache_preserves_rollout_contents():
     """Re-using the next-observation separator outputs as the following step's current outputs stores exactly what a
     from-scratch recomputation stores (frozen eval-mode networks are deterministic per observation)."""
