@@ -212,10 +212,11 @@ int m2h_adv_apply(float* adv, const float* gmean, const float* gvar, int n, floa
 /* PPO losses (ppo.py:125-157) forward and analytic gradients: out[4] = (value_loss, action_loss, mean entropy, total_loss =
  * value_loss*value_loss_coef + action_loss - entropy*entropy_coef); entropy[n] per-row entropies or NULL;
  * g_values = d(total)/dvalues, g_logp = d(total)/d(action_log_probs) (either may be NULL); d(total)/d(entropy_row) is the
- * constant -entropy_coef/n. */
+ * constant -entropy_coef/n.  clip_dev: NULL, or a device scalar that replaces `clip` and is read when the kernel runs (a
+ * captured HIP graph of the update then follows the linear clip decay of ppo_trainer.py:736-739). */
 int m2h_ppo_loss(const float* values, const float* logp, const float* old_values, const float* returns, const float* adv,
-                 const float* old_logp, const float* entropy, float clip, int use_clipped_value_loss, float value_loss_coef,
-                 float entropy_coef, float* out, float* g_values, float* g_logp, int n, m2h_stream stream);
+                 const float* old_logp, const float* entropy, float clip, const float* clip_dev, int use_clipped_value_loss,
+                 float value_loss_coef, float entropy_coef, float* out, float* g_values, float* g_logp, int n, m2h_stream stream);
 
 /* reward_util / override_rewards (common/env_utils.py:690-713).  m2h_sq_stats: per env e, stats[e] = (sum (pred-gt)^2,
  * sum gt^2) over L elements, gt read with stride/offset from an interleaved components tensor (gt_mono_comps[...,0]).

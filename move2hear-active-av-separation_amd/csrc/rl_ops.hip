@@ -243,10 +243,11 @@ __global__ void adv_apply_kernel(float* __restrict__ adv, const float* __restric
 __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__ values, const float* __restrict__ logp,
                                                        const float* __restrict__ old_values, const float* __restrict__ returns,
                                                        const float* __restrict__ adv, const float* __restrict__ old_logp,
-                                                       float clip, int use_clipped_value_loss, float* __restrict__ out,
-                                                       float* __restrict__ g_values, float* __restrict__ g_logp,
+                                                       float clip_host, const float* __restrict__ clip_dev, int use_clipped_value_loss,
+                                                       float* __restrict__ out, float* __restrict__ g_values, float* __restrict__ g_logp,
                                                        float value_loss_coef, const float* __restrict__ entropy, float entropy_coef, int n) {
   __shared__ float sh[4];
+  const float clip = clip_dev != nullptr ? clip_dev[0] : clip_host;  // device scalar: a replayed HIP graph follows the clip decay
   float sv = 0.f, sa = 0.f, se = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) {
     if (entropy != nullptr) se += entropy[i];
@@ -663,11 +664,11 @@ int m2h_adv_apply(float* adv, const float* gmean, const float* gvar, int n, floa
 }
 
 int m2h_ppo_loss(const float* values, const float* logp, const float* old_values, const float* returns, const float* adv,
-                 const float* old_logp, const float* entropy, float clip, int use_clipped_value_loss, float value_loss_coef,
-                 float entropy_coef, float* out, float* g_values, float* g_logp, int n, m2h_stream stream) {
+                 const float* old_logp, const float* entropy, float clip, const float* clip_dev, int use_clipped_value_loss,
+                 float value_loss_coef, float entropy_coef, float* out, float* g_values, float* g_logp, int n, m2h_stream stream) {
   M2H_REQUIRE(values && logp && old_values && returns && adv && old_logp && out && n > 0, "ppo_loss: bad arguments");
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), values, logp, old_values, returns, adv, old_logp, clip,
-                     use_clipped_value_loss, out, g_values, g_logp, value_loss_coef, entropy, entropy_coef, n);
+                     clip_dev, use_clipped_value_loss, out, g_values, g_logp, value_loss_coef, entropy, entropy_coef, n);
   return launch_status("ppo_loss");
 }
 

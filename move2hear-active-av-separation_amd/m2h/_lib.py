@@ -116,7 +116,7 @@ SIGNATURES = {
     "m2h_advantages": [_P, _P, _P, _P, _I, _I, _F, _P],
     "m2h_adv_sqdiff": [_P, _P, _P, _I, _P],
     "m2h_adv_apply": [_P, _P, _P, _I, _F, _P],
-    "m2h_ppo_loss": [_P, _P, _P, _P, _P, _P, _P, _F, _I, _F, _F, _P, _P, _P, _I, _P],
+    "m2h_ppo_loss": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _F, _F, _P, _P, _P, _I, _P],
     "m2h_gru_gates_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_gru_bwd_combine": [_P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_policy_heads_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -455,8 +455,10 @@ def adv_apply(adv, gmean, gvar, eps=1e-5):
 
 def ppo_loss(values, logp, old_values, returns, adv, old_logp, clip, value_loss_coef=1.0, use_clipped_value_loss=True, want_grads=False,
              entropy=None, entropy_coef=0.0):
-    """-> (out[4] = (value_loss, action_loss, mean entropy, total_loss), g_values, g_logp)."""
-    for t in (values, logp, old_values, returns, adv, old_logp, entropy):
+    """-> (out[4] = (value_loss, action_loss, mean entropy, total_loss), g_values, g_logp).
+    clip: python float, or a 1-element device tensor read when the kernel runs (HIP-graph replay of the update)."""
+    clip_dev = clip if torch.is_tensor(clip) else None
+    for t in (values, logp, old_values, returns, adv, old_logp, entropy, clip_dev):
         _chk(t, "ppo_loss")
     n = values.numel()
     out = torch.empty(4, device=values.device)
@@ -465,7 +467,7 @@ def ppo_loss(values, logp, old_values, returns, adv, old_logp, clip, value_loss_
     lib = _lib.load()
     with torch.cuda.device(values.device):
         _lib.check(lib.m2h_ppo_loss(_ptr(values), _ptr(logp), _ptr(old_values), _ptr(returns), _ptr(adv), _ptr(old_logp), _ptr(entropy),
-                                    float(clip), 1 if use_clipped_value_loss else 0, float(value_loss_coef), float(entropy_coef), _ptr(out),
+                                    0.0 if clip_dev is not None else float(clip), _ptr(clip_dev), 1 if use_clipped_value_loss else 0, float(value_loss_coef), float(entropy_coef), _ptr(out),
                                     _ptr(gv), _ptr(gl), n, _stream(values)), "m2h_ppo_loss")
     return out, gv, gl
 

@@ -29,7 +29,7 @@ class PPO(nn.Module):
     def __init__(self, actor_critic, clip_param, ppo_epoch, num_mini_batch, value_loss_coef, bin_separation_loss_coef,
                  mono_conversion_loss_coef, entropy_coef, lr_pol=None, lr_sep=None, eps=None, max_grad_norm=None,
                  freeze_passive_separators=False, use_clipped_value_loss=True, use_normalized_advantage=True,
-                 cache_separator_outputs=True, overlap_grad_reduce=None):
+                 cache_separator_outputs=True, overlap_grad_reduce=None, use_hip_graphs=False):
         super().__init__()
         self.actor_critic = actor_critic
         self.clip_param = clip_param
@@ -58,6 +58,11 @@ class PPO(nn.Module):
         # overlap_grad_reduce: None = on when distributed (init_distributed), True = also at world size 1 (the side-stream
         # schedule without the collective; tests), False = the synchronous order of the reference
         self.overlap_grad_reduce = overlap_grad_reduce
+        # use_hip_graphs: replay one epoch of update_pol (forward, losses, backward) from a HIP graph (same kernels and values;
+        # the epoch is ~400 small launches behind ~5 ms of Python and autograd dispatch)
+        self.use_hip_graphs = use_hip_graphs
+        self._pol_graph = None
+        self._pol_updates = 0
         self._reducers = {"pol": ddppo_utils.GradReduceStep(), "mem": ddppo_utils.GradReduceStep()}
         actor_critic._param_fences = self._reducers  # readers of the parameters fence on these (policy.py)
 
@@ -108,26 +113,70 @@ class PPO(nn.Module):
             r.fence()
 
     # ------------------------------------------------------------------ policy update (reference :82-177)
+    def _pol_epoch(self, sample, clip, acc):
+        """Forward, losses and backward of one mini-batch (reference :94-163); the optimizer step follows in the caller."""
+        (obs_batch, h_batch, pm_batch, mono_batch, mem_batch, value_preds_batch, return_batch, adv_targ, actions_batch,
+         old_logp_batch, masks_batch) = sample
+        values, logp, ent_rows, _ = self.actor_critic.evaluate_rows(
+            obs_batch, h_batch, masks_batch, actions_batch, pred_binSepMasks=pm_batch, pred_mono=mono_batch,
+            pred_monoFromMem=mem_batch)
+        self.optimizer_pol.zero_grad()
+        total_loss, stats = MF.PPOLoss.apply(values, logp, ent_rows, value_preds_batch, return_batch, adv_targ, old_logp_batch,
+                                             clip, float(self.value_loss_coef), float(self.entropy_coef),
+                                             bool(self.use_clipped_value_loss))
+        total_loss.backward()
+        acc += stats
+
     def update_pol(self, rollouts_pol):
         advantages = self.get_advantages(rollouts_pol)
+        self._pol_updates += 1
+        if (self.use_hip_graphs and self._pol_updates > 1 and self.num_mini_batch == 1 and not ops.timing_enabled()
+                and getattr(rollouts_pol, "full_batch_views", False)):
+            return self._update_pol_graph(rollouts_pol, advantages)  # (the first update runs kernel by kernel: warm-up)
         acc = torch.zeros(4, device=self.device)
         for _e in range(self.ppo_epoch):
             for _mb, sample in enumerate(rollouts_pol.recurrent_generator(advantages, self.num_mini_batch)):
-                (obs_batch, h_batch, pm_batch, mono_batch, mem_batch, value_preds_batch, return_batch, adv_targ, actions_batch,
-                 old_logp_batch, masks_batch) = sample
-                values, logp, ent_rows, _ = self.actor_critic.evaluate_rows(
-                    obs_batch, h_batch, masks_batch, actions_batch, pred_binSepMasks=pm_batch, pred_mono=mono_batch,
-                    pred_monoFromMem=mem_batch)
-                self.optimizer_pol.zero_grad()
-                total_loss, stats = MF.PPOLoss.apply(values, logp, ent_rows, value_preds_batch, return_batch, adv_targ, old_logp_batch,
-                                                     float(self.clip_param), float(self.value_loss_coef), float(self.entropy_coef),
-                                                     bool(self.use_clipped_value_loss))
-                total_loss.backward()
+                self._pol_epoch(sample, float(self.clip_param), acc)
                 self._reduce_and_step("pol", self.optimizer_pol,  # before_step_pol + step
                                       last=_e == self.ppo_epoch - 1 and _mb == self.num_mini_batch - 1)
-                acc += stats
         num_updates = self.ppo_epoch * self.num_mini_batch
         v, a, h, _ = (acc / num_updates).tolist()  # the only host read of the update
+        return v, a, h
+
+    def _update_pol_graph(self, rollouts_pol, advantages):
+        """update_pol with each epoch's forward + losses + backward replayed from one HIP graph.  With one mini-batch the batch
+        is the whole storage read in place (rollout_storage.py), so every address the epoch touches is fixed: storages, flat
+        parameter / gradient buffers, and three static inputs -- the advantages, the clip range (device scalar, it decays per
+        update) and the loss accumulator.  Outside the graph stay: the advantage statistics (collectives), the CPU randperm
+        (drawn as in the kernel-by-kernel path, so the generator streams stay aligned), the in-place re-pack of the conv
+        weights after each optimizer step, the gradient all-reduce and the optimizer step."""
+        gs = self._pol_graph
+        self.optimizer_pol.build()
+        sig = (id(rollouts_pol), rollouts_pol.rewards.data_ptr(), tuple(advantages.shape), float(self.value_loss_coef),
+               float(self.entropy_coef), bool(self.use_clipped_value_loss),
+               tuple(p.data_ptr() for p in self.optimizer_pol.param_groups[0]["params"]))
+        if gs is None or gs.sig != sig:
+            from types import SimpleNamespace
+            gs = self._pol_graph = SimpleNamespace(sig=sig, graph=None, adv=torch.empty_like(advantages),
+                                                   clip=torch.zeros(1, device=self.device), acc=torch.zeros(4, device=self.device))
+        gs.adv.copy_(advantages)
+        gs.clip.fill_(float(self.clip_param))
+        gs.acc.zero_()
+        num_envs = rollouts_pol.rewards.size(1)
+        for _e in range(self.ppo_epoch):
+            self._reducers["pol"].fence()   # the graph holds no fence: order it after a pending optimizer step here
+            MF.refresh_pack_memos()         # conv weights re-packed in place after the previous step
+            if gs.graph is None:
+                cpu_rng = torch.get_rng_state()  # capture executes the python once without running kernels: no RNG side effect
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._pol_epoch(next(iter(rollouts_pol.recurrent_generator(gs.adv, 1))), gs.clip, gs.acc)
+                torch.set_rng_state(cpu_rng)
+                gs.graph = g
+            torch.randperm(num_envs)        # recurrent_generator's draw (:197); the batch itself is the storage in place
+            gs.graph.replay()
+            self._reduce_and_step("pol", self.optimizer_pol, last=_e == self.ppo_epoch - 1)
+        v, a, h, _ = (gs.acc / self.ppo_epoch).tolist()
         return v, a, h
 
     # ------------------------------------------------------------------ separator (acoustic memory) update (reference :179-246)

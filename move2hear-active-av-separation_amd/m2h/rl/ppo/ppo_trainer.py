@@ -37,7 +37,7 @@ def near_target_config(**over):
              num_mini_batch=1, eps=1.0e-5, max_grad_norm=0.5, num_steps=20, use_gae=True, gamma=0.99, tau=0.95,
              use_linear_clip_decay=True, use_linear_lr_decay=True, sep_reward_weight=1.0, nav_reward_weight=0.0,
              extra_reward_multiplier=10.0, reward_window_size=50, use_ddppo=True, CHECKPOINT_FOLDER=None,
-             use_hip_graphs=True,       # build-side key: replay the rollout step from a HIP graph (same kernels, same results)
+             use_hip_graphs=True,       # build-side key: replay the rollout step and the update_pol epoch from HIP graphs (same kernels, same results)
              overlap_grad_reduce=None)  # build-side key: None = overlap the last all-reduce + step of an update when distributed
     c.update(over)
     return SimpleNamespace(**c)
@@ -76,7 +76,8 @@ class PPOTrainer:
                          bin_separation_loss_coef=cfg.bin_separation_loss_coef, mono_conversion_loss_coef=cfg.mono_conversion_loss_coef,
                          entropy_coef=cfg.entropy_coef, lr_pol=cfg.lr_pol, lr_sep=cfg.lr_sep, eps=cfg.eps,
                          max_grad_norm=cfg.max_grad_norm, freeze_passive_separators=True,
-                         overlap_grad_reduce=getattr(cfg, "overlap_grad_reduce", None))
+                         overlap_grad_reduce=getattr(cfg, "overlap_grad_reduce", None),
+                         use_hip_graphs=bool(getattr(cfg, "use_hip_graphs", False)))
         self.actor_critic.train()
         if passive_state_dict is not None:
             self.agent.load_pretrained_passive_separators(passive_state_dict)

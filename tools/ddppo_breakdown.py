@@ -22,10 +22,12 @@ def main():
     tr.actor_critic.load_state_dict(sd)
     tr.train_cycle()
     cfg = tr.config
+    phases_only = "--phases" in sys.argv  # wall time per phase only: the op timing hook switches the HIP-graph rollout off
     for rep in range(2):
         ph = {"rollout": 0.0, "update_pol": 0.0, "update_sep": 0.0}
         sink = []
-        ops.set_timing(sink)
+        if not phases_only:
+            ops.set_timing(sink)
         marks = {}
         for _sub in range(cfg.num_updates_per_cycle):
             torch.cuda.synchronize(); t = time.perf_counter(); n0 = len(sink)
