@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue the pair kernel by kernel instead of replaying a HIP graph")
     ap.add_argument("--ddppo-cycles", type=int, default=2, help="timed DD-PPO cycles (0 = skip); one untimed warm-up cycle precedes them")
     ap.add_argument("--math", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the conv engine in the timed U-Net pair: fp32 MFMA (exact products) or bf16x3 split products")
@@ -198,7 +199,14 @@ def main():
     mix, tc = make_inputs(dev, args.batch, args.tm, 1000 + rank)
     obs = {"mixed_bin_audio_mag": mix, "target_class": tc}
 
+    from m2h.graphs import GraphedSeparatorPair
+    graphed = None if args.no_graph else GraphedSeparatorPair(pol, obs)
+
     def step():
+        """one pass of the pair over the resident batch; by default replayed from a HIP graph (the same 22 kernels, captured
+        once per arithmetic mode) -- --no-graph enqueues them through the two m2h_unet_fwd calls instead"""
+        if graphed is not None:
+            return graphed()
         with torch.no_grad():
             masks = pol.get_binSepMasks(obs)
             mono = pol.convert_bin2mono(masks, mixed_audio=mix)
@@ -359,9 +367,9 @@ def main():
         _e, o_sink = timed_run(other, o_steps, 1, True)
         o_roof, _ = account(o_sink, o_steps, other)
     ops.set_math_mode(ops.MATH_FP32)
-    m_a, mono_a = step()
+    m_a, mono_a = (t.clone() for t in step())  # (graph replays return their static output buffers)
     ops.set_math_mode(ops.MATH_BF16X3)
-    m_b, mono_b = step()
+    m_b, mono_b = (t.clone() for t in step())
     ops.set_math_mode(ops.MATH_FP32)
     em = torch.expm1(mix)
     rel = lambda x, y: float(((x - y).abs().sum() / y.abs().sum()).item())  # noqa: E731
@@ -399,7 +407,9 @@ def main():
         "config": {"workload": "passive U-Net separator pair forward (get_binSepMasks + convert_bin2mono, eval-BN), "
                                "batch %d/GPU of 512x%d binaural log-magnitude spectrograms, inputs resident in HBM" % (args.batch, args.tm),
                    "batch_per_gpu": args.batch, "n_freq": 512, "time_frames": args.tm, "parallelism": "dp%d (batch-sharded, no collective)" % world,
-                   "weights": "synthetic (m2h.synthetic seed 1), reference architecture 33.47 M params"},
+                   "weights": "synthetic (m2h.synthetic seed 1), reference architecture 33.47 M params",
+                   "launch": ("two m2h_unet_fwd calls per step (22 kernels enqueued one by one)" if args.no_graph else
+                              "HIP graph: the step's 22 kernels captured once per arithmetic mode, replayed every step (m2h.graphs)")},
         "roofline": roofline,
         "other_math_mode": other_mode,
         "math_mode_parity": parity,

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from ... import functional as MF
+from ... import graphs
 from ... import ops
 from ...optim import FlatAdam
 from . import ddppo_utils
@@ -169,7 +170,7 @@ class PPO(nn.Module):
             if gs.graph is None:
                 cpu_rng = torch.get_rng_state()  # capture executes the python once without running kernels: no RNG side effect
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with graphs.capture(g):
                     self._pol_epoch(next(iter(rollouts_pol.recurrent_generator(gs.adv, 1))), gs.clip, gs.acc)
                 torch.set_rng_state(cpu_rng)
                 gs.graph = g

@@ -21,7 +21,7 @@ from types import SimpleNamespace
 import torch
 from torch.optim.lr_scheduler import LambdaLR
 
-from ... import ops
+from ... import graphs, ops
 from ...common.rollout_storage import RolloutStoragePol, RolloutStorageSep
 from ...common.utils import linear_decay
 from ...envs.synthetic_env import SyntheticVecEnv
@@ -243,7 +243,7 @@ class PPOTrainer:
         if g is None:
             g = torch.cuda.CUDAGraph()
             g.register_generator_state(self.envs.generator)
-            with torch.no_grad(), torch.cuda.graph(g, pool=gs.pool):
+            with torch.no_grad(), graphs.capture(g, pool=gs.pool):
                 at = (gs.idx[0:1], gs.idx[1:2], gs.idx[2:3])
                 nxt = self._rollout_step_device(gs.cache, at, extra, done)
                 for dst, src in zip(gs.cache, nxt):
