@@ -231,6 +231,45 @@ int m2h_rewards_from_stats(const float* next_stats, const float* cur_stats, cons
  * The result viewed as [T*Nsel][row] is the reference's stacked + flattened minibatch. */
 int m2h_gather_envs(const void* src, const long long* perm, void* dst, int T, int N, int Nsel, size_t row_bytes, m2h_stream stream);
 
+/* Per-episode statistics kept by the rollout step (ppo_trainer.py:407-478): after every env step, for each of N envs the
+ * running sums of the current episode take the step's reward / action probabilities / STFT-L2 losses, finished episodes
+ * (not_done == 0) are folded into the totals (rewards, steps, counts, per-step means, last-step values) and their running
+ * sums reset.  All tensors are [N] floats (dist_probs: [N][A]) owned by the caller. */
+typedef struct m2h_episode_stats {
+  float* episode_rewards;
+  float* episode_counts;
+  float* episode_steps;
+  float* episode_dist_probs;
+  float* episode_bin_losses_allSteps;
+  float* episode_mono_losses_lastStep;
+  float* episode_mono_losses_allSteps;
+  float* episode_monoFromMem_losses_lastStep;
+  float* episode_monoFromMem_losses_allSteps;
+  float* current_episode_reward;
+  float* current_episode_step;
+  float* current_episode_dist_probs;
+  float* current_episode_bin_losses;
+  float* current_episode_mono_losses;
+  float* current_episode_monoFromMem_losses;
+} m2h_episode_stats;
+int m2h_episode_stats_update(const m2h_episode_stats* st, const float* rewards, const float* dist_probs, const float* bin_losses,
+                             const float* mono_losses, const float* monoFromMem_losses, const float* not_done, int N, int A,
+                             m2h_stream stream);
+
+/* Batched row copies with DEVICE-resident row indices: RolloutStoragePol.insert / RolloutStorageSep.insert and the rollout
+ * step's reads of row `step` (common/rollout_storage.py:68-96, 372-390; ppo_trainer.py:262-300) when the step is replayed from
+ * a HIP graph and the host step counter cannot be baked into addresses.  Item i copies `bytes` bytes (multiple of 4) from
+ * src + idx[src_slot]*bytes to dst + idx[dst_slot]*bytes; a negative slot means no offset.  idx: int64 device array. */
+#define M2H_ROWS_COPY_MAX 32
+typedef struct m2h_row_copy {
+  const void* src;
+  void* dst;
+  size_t bytes;
+  int src_slot;
+  int dst_slot;
+} m2h_row_copy;
+int m2h_rows_copy(const m2h_row_copy* items, int n_items, const long long* idx, m2h_stream stream);
+
 /* STFT_L2_distance (common/eval_metrics.py:306-366) for nch channels: out[e] = sum_ch mean_{re/im,F,T} of the squared
  * distance between (gt_mag, pred_mag) x (cos, sin)(gt_phase); pred_mag = pred (use_mix 0) or (exp(mix)-1)*pred (use_mix 1).
  * pred/mix: [N][L][Cp]; gt_comps: [N][L][Cg] = per channel (mag, phase). */

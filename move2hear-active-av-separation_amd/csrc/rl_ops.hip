@@ -380,6 +380,66 @@ __global__ __launch_bounds__(1024) void stft_l2_kernel(const float* __restrict__
 }
 
 
+
+// Per-episode statistics of the rollout step (ppo_trainer.py:407-478: the reference keeps them as python floats / numpy and
+// pays a host sync per value): one thread per env does what the reference does after every env step -- accumulate the
+// running sums of the current episode, fold them into the finished-episode totals where the env is done (nd = 1 - not_done),
+// reset the running sums there.  Arithmetic order and rounding are those of the elementwise formulation
+// (cur += x; total += nd * (cur / steps); cur *= not_done), without fused multiply-adds.
+__global__ void episode_stats_kernel(m2h_episode_stats st, const float* __restrict__ rewards, const float* __restrict__ dist_probs,
+                                     const float* __restrict__ bin_losses, const float* __restrict__ mono_losses,
+                                     const float* __restrict__ mem_losses, const float* __restrict__ not_done, int N, int A) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const float m = not_done[e];
+  const float nd = 1.f - m;
+  const float cr = __fadd_rn(st.current_episode_reward[e], rewards[e]);
+  const float cs = __fadd_rn(st.current_episode_step[e], 1.f);
+  const float cb = __fadd_rn(st.current_episode_bin_losses[e], bin_losses[e]);
+  const float cm = __fadd_rn(st.current_episode_mono_losses[e], mono_losses[e]);
+  const float cf = __fadd_rn(st.current_episode_monoFromMem_losses[e], mem_losses[e]);
+  st.episode_rewards[e] = __fadd_rn(st.episode_rewards[e], __fmul_rn(nd, cr));
+  st.episode_steps[e] = __fadd_rn(st.episode_steps[e], __fmul_rn(nd, cs));
+  st.episode_counts[e] = __fadd_rn(st.episode_counts[e], nd);
+  for (int a = 0; a < A; ++a) {
+    const float cp = __fadd_rn(st.current_episode_dist_probs[e * A + a], dist_probs[e * A + a]);
+    st.episode_dist_probs[e * A + a] = __fadd_rn(st.episode_dist_probs[e * A + a], __fmul_rn(nd, __fdiv_rn(cp, cs)));
+    st.current_episode_dist_probs[e * A + a] = __fmul_rn(cp, m);
+  }
+  st.episode_bin_losses_allSteps[e] = __fadd_rn(st.episode_bin_losses_allSteps[e], __fmul_rn(nd, __fdiv_rn(cb, cs)));
+  st.episode_mono_losses_lastStep[e] = __fadd_rn(st.episode_mono_losses_lastStep[e], __fmul_rn(nd, mono_losses[e]));
+  st.episode_mono_losses_allSteps[e] = __fadd_rn(st.episode_mono_losses_allSteps[e], __fmul_rn(nd, __fdiv_rn(cm, cs)));
+  st.episode_monoFromMem_losses_lastStep[e] = __fadd_rn(st.episode_monoFromMem_losses_lastStep[e], __fmul_rn(nd, mem_losses[e]));
+  st.episode_monoFromMem_losses_allSteps[e] = __fadd_rn(st.episode_monoFromMem_losses_allSteps[e], __fmul_rn(nd, __fdiv_rn(cf, cs)));
+  st.current_episode_reward[e] = __fmul_rn(cr, m);
+  st.current_episode_step[e] = __fmul_rn(cs, m);
+  st.current_episode_bin_losses[e] = __fmul_rn(cb, m);
+  st.current_episode_mono_losses[e] = __fmul_rn(cm, m);
+  st.current_episode_monoFromMem_losses[e] = __fmul_rn(cf, m);
+}
+
+// Batched row copies with device-resident row indices (RolloutStoragePol/Sep.insert and the per-step row reads of the rollout,
+// common/rollout_storage.py:68-96, 372-390, when the step is replayed from a HIP graph): item i copies `bytes` bytes from
+// src + idx[src_slot] * bytes to dst + idx[dst_slot] * bytes (slot < 0: no offset).  grid.y = item, grid.x strides over it.
+struct RowsCopyArgs {
+  m2h_row_copy item[M2H_ROWS_COPY_MAX];
+};
+__global__ __launch_bounds__(256) void rows_copy_kernel(RowsCopyArgs a, const long long* __restrict__ idx) {
+  const m2h_row_copy it = a.item[blockIdx.y];
+  const char* src = static_cast<const char*>(it.src) + (it.src_slot >= 0 ? (size_t)idx[it.src_slot] * it.bytes : 0);
+  char* dst = static_cast<char*>(it.dst) + (it.dst_slot >= 0 ? (size_t)idx[it.dst_slot] * it.bytes : 0);
+  const size_t start = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  if (((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst) | it.bytes) & 15) == 0) {  // block-uniform
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (size_t i = start; i < it.bytes / 16; i += stride) d4[i] = s4[i];
+  } else {
+    const uint32_t* s1 = reinterpret_cast<const uint32_t*>(src);
+    uint32_t* d1 = reinterpret_cast<uint32_t*>(dst);
+    for (size_t i = start; i < it.bytes / 4; i += stride) d1[i] = s1[i];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // training-side kernels: GRU / heads backward, losses, grad-norm clipping, Adam
 // ---------------------------------------------------------------------------------------------------------------
@@ -760,6 +820,34 @@ int m2h_stft_l2(const float* mix, const float* pred, int Cp, const float* gt_com
   M2H_REQUIRE(pred && gt_comps && out && N > 0 && L > 0 && nch > 0 && Cp >= nch && Cg >= 2 * nch && (!use_mix || mix), "stft_l2: bad arguments");
   hipLaunchKernelGGL(stft_l2_kernel, dim3(N), dim3(1024), 0, as_stream(stream), mix, pred, Cp, gt_comps, Cg, nch, use_mix, out, L);
   return launch_status("stft_l2");
+}
+
+int m2h_episode_stats_update(const m2h_episode_stats* st, const float* rewards, const float* dist_probs, const float* bin_losses,
+                             const float* mono_losses, const float* monoFromMem_losses, const float* not_done, int N, int A,
+                             m2h_stream stream) {
+  M2H_REQUIRE(st && rewards && dist_probs && bin_losses && mono_losses && monoFromMem_losses && not_done && N > 0 && A > 0,
+              "episode_stats_update: bad arguments");
+  const float* const* fields = reinterpret_cast<const float* const*>(st);
+  for (size_t i = 0; i < sizeof(m2h_episode_stats) / sizeof(float*); ++i) M2H_REQUIRE(fields[i], "episode_stats_update: null statistics tensor");
+  hipLaunchKernelGGL(episode_stats_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), *st, rewards, dist_probs, bin_losses,
+                     mono_losses, monoFromMem_losses, not_done, N, A);
+  return launch_status("episode_stats_update");
+}
+
+int m2h_rows_copy(const m2h_row_copy* items, int n_items, const long long* idx, m2h_stream stream) {
+  M2H_REQUIRE(items && n_items > 0 && n_items <= M2H_ROWS_COPY_MAX, "rows_copy: 1..%d items", M2H_ROWS_COPY_MAX);
+  RowsCopyArgs a;
+  size_t big = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const m2h_row_copy& it = items[i];
+    M2H_REQUIRE(it.src && it.dst && it.bytes > 0 && it.bytes % 4 == 0, "rows_copy: item %d: null pointer or size not a multiple of 4", i);
+    M2H_REQUIRE((it.src_slot < 0 && it.dst_slot < 0) || idx, "rows_copy: item %d uses a row index but idx is NULL", i);
+    a.item[i] = it;
+    big = it.bytes > big ? it.bytes : big;
+  }
+  const int gx = (int)((big / 16 + 255) / 256 > 256 ? 256 : ((big / 16 + 255) / 256 < 1 ? 1 : (big / 16 + 255) / 256));
+  hipLaunchKernelGGL(rows_copy_kernel, dim3(gx, n_items), dim3(256), 0, as_stream(stream), a, idx);
+  return launch_status("rows_copy");
 }
 
 }  // extern "C"

@@ -84,6 +84,27 @@ class UnetWeights(ctypes.Structure):
     ]
 
 
+EPISODE_STATS_FIELDS = (
+    "episode_rewards", "episode_counts", "episode_steps", "episode_dist_probs", "episode_bin_losses_allSteps",
+    "episode_mono_losses_lastStep", "episode_mono_losses_allSteps", "episode_monoFromMem_losses_lastStep",
+    "episode_monoFromMem_losses_allSteps", "current_episode_reward", "current_episode_step", "current_episode_dist_probs",
+    "current_episode_bin_losses", "current_episode_mono_losses", "current_episode_monoFromMem_losses")
+
+
+class EpisodeStats(ctypes.Structure):
+    """Mirror of ``struct m2h_episode_stats`` (include/m2h.h)."""
+    _fields_ = [(name, ctypes.c_void_p) for name in EPISODE_STATS_FIELDS]
+
+
+ROWS_COPY_MAX = 32
+
+
+class RowCopy(ctypes.Structure):
+    """Mirror of ``struct m2h_row_copy`` (include/m2h.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_size_t), ("src_slot", ctypes.c_int),
+                ("dst_slot", ctypes.c_int)]
+
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
@@ -150,6 +171,8 @@ SIGNATURES = {
     "m2h_unet_fwd_events": [ctypes.POINTER(UnetWeights), _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P, _I, _P],
     "m2h_sep_slice_input_fmt": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "m2h_gather_envs": [_P, _P, _P, _I, _I, _I, _Z, _P],
+    "m2h_episode_stats_update": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "m2h_rows_copy": [_P, _I, _P, _P],
     "m2h_stft_l2": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
 }
 

@@ -43,28 +43,26 @@ class RolloutStoragePol:
         for name in self._TENSORS:
             setattr(self, name, getattr(self, name).to(device))
 
-    def insert(self, observations, recurrent_hidden_states_pol, actions, action_log_probs, values, rewards, masks,
-               pred_binSepMasks=None, pred_mono=None, pred_monoFromMem=None, at=None):
-        """at: None = the host step counter addresses the rows (reference behaviour, :68-96).  HIP-graph capture passes
-        ``(i, i1)`` = 1-element int64 device tensors holding step and step + 1: the rows are then addressed on the device
-        (index_copy_) and the host counter is left to the caller (``advance``), because a captured step is replayed."""
-        if at is None:
-            put = lambda t, off, v: t[self.step + off].copy_(v)  # noqa: E731
-        else:
-            put = lambda t, off, v: t.index_copy_(0, at[off], v.unsqueeze(0))  # noqa: E731
-        for sensor in observations:
-            put(self.observations[sensor], 1, observations[sensor])
-        put(self.recurrent_hidden_states_pol, 1, recurrent_hidden_states_pol)
-        put(self.pred_binSepMasks, 0, pred_binSepMasks)
-        put(self.pred_mono, 0, pred_mono)
-        put(self.prev_pred_monoFromMem, 1, pred_monoFromMem)
-        put(self.rewards, 0, rewards)
-        put(self.value_preds, 0, values)
-        put(self.actions, 0, actions)
-        put(self.action_log_probs, 0, action_log_probs)
-        put(self.masks, 1, masks)
-        if at is None:
-            self.advance()
+    def _rows(self, observations, recurrent_hidden_states_pol, actions, action_log_probs, values, rewards, masks,
+              pred_binSepMasks=None, pred_mono=None, pred_monoFromMem=None):
+        """(storage tensor, row offset relative to step, value) of one insert (reference :68-96)."""
+        rows = [(self.observations[sensor], 1, observations[sensor]) for sensor in observations]
+        rows += [(self.recurrent_hidden_states_pol, 1, recurrent_hidden_states_pol), (self.pred_binSepMasks, 0, pred_binSepMasks),
+                 (self.pred_mono, 0, pred_mono), (self.prev_pred_monoFromMem, 1, pred_monoFromMem), (self.rewards, 0, rewards),
+                 (self.value_preds, 0, values), (self.actions, 0, actions), (self.action_log_probs, 0, action_log_probs),
+                 (self.masks, 1, masks)]
+        return rows
+
+    def insert(self, *args, **kwargs):
+        for dst, off, v in self._rows(*args, **kwargs):
+            dst[self.step + off].copy_(v)
+        self.advance()
+
+    def insert_items(self, slots, *args, **kwargs):
+        """The same insert as a list of m2h.ops.rows_copy items addressing the rows through device-resident indices
+        (slots = positions of `step` and `step + 1` in the index tensor): for the rollout step replayed from a HIP graph,
+        where the host counter cannot be baked into addresses.  The host counter is left to the caller (``advance``)."""
+        return [(v.contiguous().view(dst.shape[1:]), dst, -1, slots[off]) for dst, off, v in self._rows(*args, **kwargs)]
 
     def advance(self):
         self.step = (self.step + 1) % self.num_steps
@@ -135,18 +133,18 @@ class RolloutStorageSep:
         self.masks = self.masks.to(device)
         self.generation += 1
 
-    def insert(self, observations, masks, pred_monoFromMem=None, at=None):
-        """at: see RolloutStoragePol.insert (here a 1-element device tensor holding step + 1)."""
-        if at is None:
-            put = lambda t, v: t[self.step + 1].copy_(v)  # noqa: E731
-        else:
-            put = lambda t, v: t.index_copy_(0, at, v.unsqueeze(0))  # noqa: E731
-        for sensor in observations:
-            put(self.observations[sensor], observations[sensor])
-        put(self.prev_pred_monoFromMem, pred_monoFromMem)
-        put(self.masks, masks)
-        if at is None:
-            self.advance()
+    def _rows(self, observations, masks, pred_monoFromMem=None):
+        return [(self.observations[sensor], observations[sensor]) for sensor in observations] + \
+            [(self.prev_pred_monoFromMem, pred_monoFromMem), (self.masks, masks)]
+
+    def insert(self, observations, masks, pred_monoFromMem=None):
+        for dst, v in self._rows(observations, masks, pred_monoFromMem):
+            dst[self.step + 1].copy_(v)
+        self.advance()
+
+    def insert_items(self, slot, observations, masks, pred_monoFromMem=None):
+        """See RolloutStoragePol.insert_items; slot = position of `step + 1` in the index tensor."""
+        return [(v.contiguous().view(dst.shape[1:]), dst, -1, slot) for dst, v in self._rows(observations, masks, pred_monoFromMem)]
 
     def advance(self):
         self.generation += 1

@@ -540,6 +540,52 @@ def gather_envs(src, perm):
     return dst
 
 
+def episode_stats_update(stats, rewards, dist_probs, bin_losses, mono_losses, monoFromMem_losses, not_done):
+    """The per-episode bookkeeping of one rollout step (ppo_trainer.py:407-478) in one launch.  stats: object with the fifteen
+    [N,1] / [N,A] float tensors named in _lib.EPISODE_STATS_FIELDS, updated in place."""
+    st = _lib.EpisodeStats()
+    for name in _lib.EPISODE_STATS_FIELDS:
+        t = getattr(stats, name)
+        _chk(t, "episode_stats_update")
+        setattr(st, name, t.data_ptr())
+    ins = [t.contiguous() for t in (rewards, dist_probs, bin_losses, mono_losses, monoFromMem_losses, not_done)]
+    for t in ins:
+        _chk(t, "episode_stats_update")
+    N, A = ins[1].shape
+    if any(t.numel() != N for t in ins[:1] + ins[2:]) or stats.episode_dist_probs.numel() != N * A or stats.episode_rewards.numel() != N:
+        raise RuntimeError("m2h.episode_stats_update: per-env tensors must hold one value per env (dist_probs: [N, A])")
+    with torch.cuda.device(ins[0].device):
+        _lib.check(_lib.load().m2h_episode_stats_update(ctypes.byref(st), *[_ptr(t) for t in ins], N, A, _stream(ins[0])),
+                   "m2h_episode_stats_update")
+
+
+def rows_copy(items, idx):
+    """Batched row copies with device-resident row indices (m2h_rows_copy).  items: (src, dst, src_slot, dst_slot) with
+    tensors; a slot >= 0 selects row idx[slot] along dim 0 of that tensor (the other side is then one whole row), a negative
+    slot means the tensor itself is the row.  idx: int64 device tensor."""
+    lib = _lib.load()
+    if idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous():
+        raise RuntimeError("m2h.rows_copy: idx must be a contiguous int64 device tensor")
+    arr = []
+    for src, dst, ss, ds in items:
+        for t in (src, dst):
+            if not t.is_cuda or not t.is_contiguous():
+                raise RuntimeError("m2h.rows_copy: tensors must be contiguous device tensors")
+        if src.dtype != dst.dtype:
+            raise RuntimeError("m2h.rows_copy: dtype mismatch %s -> %s" % (src.dtype, dst.dtype))
+        srow = src[0] if ss >= 0 else src
+        drow = dst[0] if ds >= 0 else dst
+        if srow.numel() != drow.numel():
+            raise RuntimeError("m2h.rows_copy: row sizes differ (%s vs %s)" % (tuple(srow.shape), tuple(drow.shape)))
+        if max(ss, ds) >= idx.numel():
+            raise RuntimeError("m2h.rows_copy: slot out of range")
+        arr.append(_lib.RowCopy(src.data_ptr(), dst.data_ptr(), srow.numel() * srow.element_size(), ss, ds))
+    with torch.cuda.device(idx.device):
+        for i in range(0, len(arr), _lib.ROWS_COPY_MAX):
+            chunk = arr[i:i + _lib.ROWS_COPY_MAX]
+            _lib.check(lib.m2h_rows_copy((_lib.RowCopy * len(chunk))(*chunk), len(chunk), _ptr(idx), _stream(idx)), "m2h_rows_copy")
+
+
 def take_envs(src, perm, identity=False):
     """gather_envs, or -- when the caller knows the selection is ALL environments in storage order -- the same rows as a
     zero-copy view [T*N, ...] of the storage."""

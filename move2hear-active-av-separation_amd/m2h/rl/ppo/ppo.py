@@ -197,6 +197,12 @@ class PPO(nn.Module):
         self._sep_cache = (key, val)
         return val
 
+    def _sep_cache_add_losses(self, bin_loss, mono_loss):
+        key, val = self._sep_cache
+        val = (val[0], val[1], (bin_loss.detach(), mono_loss.detach()))
+        self._sep_cache = (key, val)
+        return val
+
     def update_sep(self, rollouts_sep):
         acc = torch.zeros(3, device=self.device)
         sep_frozen = not any(p.requires_grad for m in (self.actor_critic.binSep_enc, self.actor_critic.binSep_dec,
@@ -222,9 +228,16 @@ class PPO(nn.Module):
                 pred_monoFromMem = self.actor_critic.get_monoFromMem_masked(pred_mono, prev_mem_batch, masks_batch)
                 gt_mono = obs_batch["gt_mono_comps"]
                 monoFromMem_loss = MF.l1_loss(pred_monoFromMem, gt_mono, 0)          # gt_mono_comps[..., 0::2][..., :1]
-                with torch.no_grad():
-                    mono_loss = MF.l1_loss(pred_mono, gt_mono, 0)
-                    bin_loss = ops.bin_l1_loss(obs_batch["mixed_bin_audio_mag"], pred_binSepMasks, obs_batch["gt_bin_comps"])
+                if cached is not None and idx is None and len(cached) > 2:
+                    bin_loss, mono_loss = cached[2]  # logging losses of the frozen separators: same buffer, same numbers
+                else:
+                    with torch.no_grad():
+                        mono_loss = MF.l1_loss(pred_mono, gt_mono, 0)
+                        bin_loss = ops.bin_l1_loss(obs_batch["mixed_bin_audio_mag"], pred_binSepMasks, obs_batch["gt_bin_comps"])
+                    if cached is not None and idx is None:
+                        # the two losses that are only logged (:219-224) are functions of the stored observations and the cached
+                        # separator outputs alone: computed once per buffer generation like those outputs
+                        cached = self._sep_cache_add_losses(bin_loss, mono_loss)
                 self.optimizer_sep.zero_grad()
                 monoFromMem_loss.backward()                                          # total_loss = monoFromMem_loss (:226)
                 self._reduce_and_step("mem", self.optimizer_sep, last=_e == self.ppo_epoch - 1 and _mb == self.num_mini_batch - 1)

@@ -148,13 +148,21 @@ class PPOTrainer:
         replayed (without ``at`` the storages' inserts advance their host step counters, as in the reference).
         cache: (pred_binSepMasks, pred_mono, pred_monoFromMem) of the current observation left by the previous step, or None.
         at: None = rows of the storages addressed by their host step counters (views); HIP-graph capture passes the device
-        index tensors (ro_step, ro_step + 1, rs_step + 1).  extra / done: the two host-known schedule flags (extra reward at
+        index tensor [ro_step, ro_step + 1, rs_step + 1] (rows then move through m2h_rows_copy).  extra / done: the two host-known schedule flags (extra reward at
         MAX_EPISODE_STEPS - 2, :395-405; lockstep episode end).  Returns the next step's cache."""
         cfg, ac, ro, rs, st = self.config, self.actor_critic, self.rollouts_pol, self.rollouts_sep, self.stats
         L = 512 * 32
-        row = (lambda t: t[ro.step]) if at is None else (lambda t: t.index_select(0, at[0]).squeeze(0))
-        step_observation = {k: row(v) for k, v in ro.observations.items()}
-        step_masks, step_h = row(ro.masks), row(ro.recurrent_hidden_states_pol)
+        if at is None:
+            row = lambda t: t[ro.step]  # noqa: E731
+            step_observation = {k: row(v) for k, v in ro.observations.items()}
+            step_masks, step_h = row(ro.masks), row(ro.recurrent_hidden_states_pol)
+        else:  # rows addressed by the device-resident step index: one batched copy into this graph's own buffers
+            src = dict(ro.observations, _masks=ro.masks, _h=ro.recurrent_hidden_states_pol)
+            got = {k: torch.empty_like(v[0]) for k, v in src.items()}
+            ops.rows_copy([(src[k], got[k], 0, -1) for k in src], at)
+            step_masks, step_h = got.pop("_masks"), got.pop("_h")
+            step_observation = got
+            row = None  # (the previous memory is read only without a cache, which a captured step always has)
         if cache is not None:
             pred_binSepMasks, pred_mono, pred_monoFromMem = cache  # computed for the reward of the previous step
         else:
@@ -177,29 +185,14 @@ class PPOTrainer:
         bin_losses = ops.stft_l2(pred_binSepMasks, step_observation["gt_bin_comps"], 2, mix=step_observation["mixed_bin_audio_mag"])
         mono_losses = ops.stft_l2(pred_mono, step_observation["gt_mono_comps"], 1)
         monoFromMem_losses = ops.stft_l2(pred_monoFromMem, step_observation["gt_mono_comps"], 1)
-        st.current_episode_reward += rewards
-        st.current_episode_step += 1
-        st.current_episode_dist_probs += distribution_probs
-        st.current_episode_bin_losses += bin_losses
-        st.current_episode_mono_losses += mono_losses
-        st.current_episode_monoFromMem_losses += monoFromMem_losses
-        nd = 1 - masks
-        st.episode_rewards += nd * st.current_episode_reward
-        st.episode_steps += nd * st.current_episode_step
-        st.episode_counts += nd
-        st.episode_dist_probs += nd * (st.current_episode_dist_probs / st.current_episode_step)
-        st.episode_bin_losses_allSteps += nd * (st.current_episode_bin_losses / st.current_episode_step)
-        st.episode_mono_losses_lastStep += nd * mono_losses
-        st.episode_mono_losses_allSteps += nd * (st.current_episode_mono_losses / st.current_episode_step)
-        st.episode_monoFromMem_losses_lastStep += nd * monoFromMem_losses
-        st.episode_monoFromMem_losses_allSteps += nd * (st.current_episode_monoFromMem_losses / st.current_episode_step)
-        for name in ("current_episode_reward", "current_episode_step", "current_episode_bin_losses", "current_episode_mono_losses",
-                     "current_episode_monoFromMem_losses", "current_episode_dist_probs"):
-            getattr(st, name).mul_(masks)
-        ro.insert(batch, recurrent_hidden_states_pol, actions, actions_log_probs, values, rewards, masks,
-                  pred_binSepMasks=pred_binSepMasks, pred_mono=pred_mono, pred_monoFromMem=pred_monoFromMem,
-                  at=None if at is None else (at[0], at[1]))
-        rs.insert(batch, masks, pred_monoFromMem=pred_monoFromMem, at=None if at is None else at[2])
+        ops.episode_stats_update(st, rewards, distribution_probs, bin_losses, mono_losses, monoFromMem_losses, masks)  # :421-478
+        pol_args = (batch, recurrent_hidden_states_pol, actions, actions_log_probs, values, rewards, masks)
+        pol_kw = dict(pred_binSepMasks=pred_binSepMasks, pred_mono=pred_mono, pred_monoFromMem=pred_monoFromMem)
+        if at is None:
+            ro.insert(*pol_args, **pol_kw)
+            rs.insert(batch, masks, pred_monoFromMem=pred_monoFromMem)
+        else:
+            ops.rows_copy(ro.insert_items((0, 1), *pol_args, **pol_kw) + rs.insert_items(2, batch, masks, pred_monoFromMem=pred_monoFromMem), at)
         return next_pred_binSepMasks, next_pred_mono, next_pred_monoFromMem
 
     # ------------------------------------------------------------------ HIP-graph replay of the rollout step
@@ -244,8 +237,7 @@ class PPOTrainer:
             g = torch.cuda.CUDAGraph()
             g.register_generator_state(self.envs.generator)
             with torch.no_grad(), graphs.capture(g, pool=gs.pool):
-                at = (gs.idx[0:1], gs.idx[1:2], gs.idx[2:3])
-                nxt = self._rollout_step_device(gs.cache, at, extra, done)
+                nxt = self._rollout_step_device(gs.cache, gs.idx, extra, done)
                 for dst, src in zip(gs.cache, nxt):
                     dst.copy_(src)
                 # advance the device-side step indices: ro_step <- (ro_step + 1) % T, rs_step likewise

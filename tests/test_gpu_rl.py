@@ -199,3 +199,72 @@ def test_generic_conv_engine_matches_torch():
         y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), ops.pack_conv_weight(w.to(dev)), Co, k, k, stride=s, pad=p,
                             bias=b.to(dev), slope=0.0)
         assert _rel(y.permute(0, 3, 1, 2), ref) < TOL, (B, H, W, Ci, Co, k, s, p)
+
+
+def test_episode_stats_update_matches_the_elementwise_bookkeeping():
+    """m2h_episode_stats_update == the reference's per-step bookkeeping (ppo_trainer.py:421-478) written as elementwise torch
+    ops, over several steps with episode ends on some envs, bit for bit."""
+    from types import SimpleNamespace
+    from m2h import _lib, ops
+    dev = _dev()
+    N, A = 14, 3
+    g = torch.Generator().manual_seed(3)
+    mk = lambda: SimpleNamespace(**{n: torch.zeros(N, A if "dist_probs" in n else 1) for n in _lib.EPISODE_STATS_FIELDS})  # noqa: E731
+    ref, st = mk(), mk()
+    for n in _lib.EPISODE_STATS_FIELDS:
+        setattr(st, n, getattr(st, n).to(dev))
+    for step in range(7):
+        rewards, bl, ml, fl = (torch.randn(N, 1, generator=g) for _ in range(4))
+        probs = torch.softmax(torch.randn(N, A, generator=g), dim=1)
+        masks = (torch.rand(N, 1, generator=g) > (0.4 if step in (2, 5) else 2.0)).float()
+        if step == 6:
+            masks.zero_()
+        r = ref
+        r.current_episode_reward += rewards
+        r.current_episode_step += 1
+        r.current_episode_dist_probs += probs
+        r.current_episode_bin_losses += bl
+        r.current_episode_mono_losses += ml
+        r.current_episode_monoFromMem_losses += fl
+        nd = 1 - masks
+        r.episode_rewards += nd * r.current_episode_reward
+        r.episode_steps += nd * r.current_episode_step
+        r.episode_counts += nd
+        r.episode_dist_probs += nd * (r.current_episode_dist_probs / r.current_episode_step)
+        r.episode_bin_losses_allSteps += nd * (r.current_episode_bin_losses / r.current_episode_step)
+        r.episode_mono_losses_lastStep += nd * ml
+        r.episode_mono_losses_allSteps += nd * (r.current_episode_mono_losses / r.current_episode_step)
+        r.episode_monoFromMem_losses_lastStep += nd * fl
+        r.episode_monoFromMem_losses_allSteps += nd * (r.current_episode_monoFromMem_losses / r.current_episode_step)
+        for name in ("current_episode_reward", "current_episode_step", "current_episode_bin_losses", "current_episode_mono_losses",
+                     "current_episode_monoFromMem_losses", "current_episode_dist_probs"):
+            getattr(r, name).mul_(masks)
+        ops.episode_stats_update(st, rewards.to(dev), probs.to(dev), bl.to(dev), ml.to(dev), fl.to(dev), masks.to(dev))
+    for n in _lib.EPISODE_STATS_FIELDS:
+        assert torch.equal(getattr(st, n).cpu(), getattr(ref, n)), n
+
+
+def test_rows_copy_moves_rows_by_device_indices():
+    """m2h_rows_copy: batched gathers / scatters of storage rows addressed by a device-resident index tensor, all dtypes and
+    row sizes the rollout storages hold (16-byte and 4-byte paths)."""
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    idx = torch.tensor([3, 4, 0], dtype=torch.int64, device=dev)
+    big = torch.randn(6, 14, 64, 8, generator=g).to(dev)          # 16-byte path
+    small = torch.randn(6, 14, 1, generator=g).to(dev)            # 56-byte rows: 4-byte path
+    acts = torch.randint(0, 3, (6, 14, 1), generator=g).to(dev)   # int64
+    v_big, v_small, v_acts = torch.randn(14, 64, 8, generator=g).to(dev), torch.randn(14, 1, generator=g).to(dev), torch.randint(0, 3, (14, 1), generator=g).to(dev)
+    exp_big, exp_small, exp_acts = big.clone(), small.clone(), acts.clone()
+    exp_big[4], exp_small[3], exp_acts[0] = v_big, v_small, v_acts
+    got_row = torch.empty_like(big[0])
+    want_row = big[3].clone()
+    ops.rows_copy([(big, got_row, 0, -1)], idx)
+    ops.rows_copy([(v_big, big, -1, 1), (v_small, small, -1, 0), (v_acts, acts, -1, 2)], idx)
+    assert torch.equal(got_row, want_row)
+    assert torch.equal(big, exp_big) and torch.equal(small, exp_small) and torch.equal(acts, exp_acts)
+    many = [(v_small, small, -1, 0)] * 40                            # more than one launch's worth of items
+    ops.rows_copy(many, idx)
+    assert torch.equal(small, exp_small)
+    with pytest.raises(RuntimeError):
+        ops.rows_copy([(v_small, big, -1, 0)], idx)
