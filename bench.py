@@ -147,6 +147,11 @@ def run_ddppo(args, dev, rank, world, dist):
             "cycles": args.ddppo_cycles, "s_per_cycle": round(el / args.ddppo_cycles, 4), "envs_per_rank": cfg.NUM_PROCESSES,
             "schedule": "nearTarget.yaml: T=20, 6x(rollout+update_pol) + 6x update_sep per cycle, ppo_epoch 4, 1 minibatch, hidden 512",
             "env": "synthetic on-device env (cached 128x128 RGB-D frames + spectrogram pool), zero-cost dynamics",
+            "launch": ("HIP graphs: the rollout step (one graph per (extra-reward, episode-end) flag pair) and the update_pol epoch "
+                       "(forward + losses + backward) are captured once and replayed; optimizer steps, collectives and update_sep "
+                       "are enqueued kernel by kernel" if cfg.use_hip_graphs else "kernel by kernel"),
+            "grad_reduce": ("flat-buffer sum all-reduce per backward (RCCL); the last all-reduce + clip + Adam of every update runs on a "
+                            "side stream, fenced at the next reader of those parameters" if world > 1 else "single rank: no collective"),
             "separator_output_reuse": "frozen eval-mode U-Net outputs computed once per stored observation and re-used by the 24 "
                                       "update_sep passes and by the next rollout step (result-preserving; SURVEY D13)",
             "last_pol_losses": [round(x, 5) for x in last["pol_losses"]], "last_sep_losses": [round(x, 5) for x in last["sep_losses"]],
