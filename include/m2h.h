@@ -188,6 +188,12 @@ int m2h_visual_input(const float* rgb, const float* depth, float* out, int B, in
 int m2h_gru_gates(const float* gi, const float* gh_raw, const float* bhh, const float* hprev, const float* mask, float* hout,
                   int M, int H, m2h_stream stream);
 
+/* One whole GRU time step for M <= 16 rows (rnn_state_encoder.py:74-84 single_forward, and each step of seq_forward :86-137 at
+ * the rollout width): gh_raw = hprev W_hh^T ([M][3H], written because the backward pass reads it) and the gate math of
+ * m2h_gru_gates in one launch.  whh: [3H][H] (torch weight_hh_l0).  H % 4 == 0, H <= 512. */
+int m2h_gru_step(const float* gi, const float* whh, const float* bhh, const float* hprev, const float* mask, float* gh_raw, float* hout,
+                 int M, int H, m2h_stream stream);
+
 /* CategoricalNet + CriticHead (common/utils.py:16-50, rl/ppo/policy.py:15-23): logits = feats Wa^T + ba (A <= 8),
  * value = feats Wc^T + bc, logp_all = log_softmax, probs = softmax, entropy = -sum p*logp per row; when actions != NULL
  * also logp_act[row] = logp_all[row][actions[row]] (CustomFixedCategorical.log_probs).  actions: int64. */

@@ -114,6 +114,95 @@ __global__ __launch_bounds__(256) void gru_gates_kernel(const float* __restrict_
   }
 }
 
+// One GRU time step for a handful of rows (M <= 16: the rollout's 14 envs, one step of the update's sequence pass) in ONE
+// launch: recurrent product gh_raw = h W_hh^T and the gate math of gru_gates_kernel.  At this size the product is a weight
+// stream (3H x H floats, 3 MB at H = 512) against 14 rows: a tiled-GEMM launch + its split-K reduce + the gate kernel spend
+// ~29 us on it, almost all launch and pipeline latency.  Here a block owns GRU_U hidden units = 3*GRU_U weight rows (r, z, n),
+// stages them and the hidden state in LDS (padded rows: conflict-free 16-byte reads) and thread (row, env) runs the H-long
+// dot product; the three gates of a unit meet through LDS.  gh_raw is written too (the backward pass reads it).
+constexpr int GRU_U = 4;     // hidden units per block
+constexpr int GRU_E = 16;    // env slots per block (M <= 16)
+__global__ __launch_bounds__(3 * GRU_U * GRU_E) void gru_step_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
+                                                                   const float* __restrict__ bhh, const float* __restrict__ hprev,
+                                                                   const float* __restrict__ mask, float* __restrict__ gh_raw,
+                                                                   float* __restrict__ hout, int M, int H) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LD = H + 4;                       // padded row (floats): consecutive rows start 4 banks apart
+  float* Ws = smem;                           // [3*GRU_U][LD]
+  float* Hs = smem + 3 * GRU_U * LD;          // [GRU_E][LD]
+  float* G = Hs + GRU_E * LD;                 // [3*GRU_U][GRU_E] raw gate products
+  const int tid = threadIdx.x;
+  const int j0 = blockIdx.x * GRU_U;
+  const int H4 = H >> 2;
+  // all global loads of the block are issued before the first LDS store (a load-store loop would wait out one memory round
+  // trip per iteration): H <= 512 bounds the per-thread counts
+  constexpr int NT = 3 * GRU_U * GRU_E;                              // threads
+  constexpr int NW = (3 * GRU_U * 128 + NT - 1) / NT;                // 16-byte weight loads per thread at H = 512
+  constexpr int NH = (GRU_E * 128 + NT - 1) / NT;                    // 16-byte hidden-state loads per thread
+  float4 wreg[NW], hreg[NH];
+  // gate inputs of this thread's (unit, env) pair, fetched up front as well
+  const int gu = tid / GRU_E, ge = min(tid - gu * GRU_E, M - 1), gj = min(j0 + (gu % GRU_U), H - 1);
+  const float gmask = mask != nullptr ? mask[ge] : 1.f;
+  const float gi_r = gi[(size_t)ge * 3 * H + gj], gi_z = gi[(size_t)ge * 3 * H + H + gj], gi_n = gi[(size_t)ge * 3 * H + 2 * H + gj];
+  const float b_r = bhh[gj], b_z = bhh[H + gj], b_n = bhh[2 * H + gj];
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    const int i = min(tid + k * NT, 3 * GRU_U * H4 - 1);
+    const int r = i / H4, c = i - r * H4;
+    const int g = r / GRU_U, u = r - g * GRU_U;
+    wreg[k] = *reinterpret_cast<const float4*>(&whh[((size_t)g * H + (j0 + u)) * H + 4 * c]);
+  }
+#pragma unroll
+  for (int k = 0; k < NH; ++k) {
+    const int i = min(tid + k * NT, GRU_E * H4 - 1);
+    const int e = min(i / H4, M - 1), c = i % H4;
+    hreg[k] = *reinterpret_cast<const float4*>(&hprev[(size_t)e * H + 4 * c]);
+  }
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    const int i = tid + k * NT;
+    if (i < 3 * GRU_U * H4) *reinterpret_cast<float4*>(&Ws[(i / H4) * LD + 4 * (i % H4)]) = wreg[k];
+  }
+#pragma unroll
+  for (int k = 0; k < NH; ++k) {
+    const int i = tid + k * NT;
+    if (i < GRU_E * H4) *reinterpret_cast<float4*>(&Hs[(i / H4) * LD + 4 * (i % H4)]) = hreg[k];  // rows >= M: a copy of row M-1, never used
+  }
+  __syncthreads();
+  const int r = tid / GRU_E, e = tid - r * GRU_E;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const float* wr = Ws + r * LD;
+  const float* hr = Hs + e * LD;
+#pragma unroll 4
+  for (int c = 0; c < H4; ++c) {
+    const float4 w = *reinterpret_cast<const float4*>(wr + 4 * c);
+    const float4 h = *reinterpret_cast<const float4*>(hr + 4 * c);
+    a0 = fmaf(w.x, h.x, a0);
+    a1 = fmaf(w.y, h.y, a1);
+    a2 = fmaf(w.z, h.z, a2);
+    a3 = fmaf(w.w, h.w, a3);
+  }
+  const float acc = (a0 + a1) + (a2 + a3);
+  G[r * GRU_E + e] = acc;
+  {
+    const int g = r / GRU_U, u = r - g * GRU_U;
+    if (e < M && j0 + u < H) gh_raw[(size_t)e * 3 * H + (size_t)g * H + j0 + u] = acc;
+  }
+  __syncthreads();
+  if (tid < GRU_U * GRU_E) {
+    const int u = tid / GRU_E, e2 = tid - u * GRU_E, j = j0 + u;
+    if (e2 < M && j < H) {
+      const float m = gmask;  // (tid < GRU_U * GRU_E: gu == u, ge == e2, gj == j)
+      const float gr = G[(0 * GRU_U + u) * GRU_E + e2], gz = G[(1 * GRU_U + u) * GRU_E + e2], gn = G[(2 * GRU_U + u) * GRU_E + e2];
+      const float rg = sigmoidf_(gi_r + (m * gr + b_r));
+      const float z = sigmoidf_(gi_z + (m * gz + b_z));
+      const float n = tanhf(gi_n + rg * (m * gn + b_n));
+      const float hp = m * Hs[e2 * LD + j];
+      hout[(size_t)e2 * H + j] = (1.f - z) * n + z * hp;
+    }
+  }
+}
+
 // One wave per row: logits = feats Wa^T + ba (A <= 8 actions), value = feats Wc^T + bc; log-softmax, softmax, entropy,
 // optional log-prob of a given action.  H multiple of 64.
 __global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restrict__ feats, const float* __restrict__ Wa,
@@ -678,6 +767,17 @@ int m2h_gru_gates(const float* gi, const float* gh_raw, const float* bhh, const 
   M2H_REQUIRE(gi && gh_raw && bhh && hprev && hout && M > 0 && H > 0, "gru_gates: bad arguments");
   hipLaunchKernelGGL(gru_gates_kernel, dim3(grid_for((size_t)M * H)), dim3(256), 0, as_stream(stream), gi, gh_raw, bhh, hprev, mask, hout, M, H);
   return launch_status("gru_gates");
+}
+
+int m2h_gru_step(const float* gi, const float* whh, const float* bhh, const float* hprev, const float* mask, float* gh_raw, float* hout,
+                 int M, int H, m2h_stream stream) {
+  M2H_REQUIRE(gi && whh && bhh && hprev && gh_raw && hout, "gru_step: null pointer");
+  M2H_REQUIRE(M > 0 && M <= GRU_E && H > 0 && H % 4 == 0 && H <= 512, "gru_step: needs 1 <= M <= %d rows and H %% 4 == 0, H <= 512 (got M=%d, H=%d)",
+              GRU_E, M, H);
+  const size_t lds = ((size_t)(3 * GRU_U + GRU_E) * (H + 4) + 3 * GRU_U * GRU_E) * sizeof(float);  // 58.6 KB at H = 512
+  hipLaunchKernelGGL(gru_step_kernel, dim3((H + GRU_U - 1) / GRU_U), dim3(3 * GRU_U * GRU_E), lds, as_stream(stream), gi, whh, bhh, hprev, mask,
+                     gh_raw, hout, M, H);
+  return launch_status("gru_step");
 }
 
 int m2h_policy_heads(const float* feats, const float* Wa, const float* ba, const float* Wc, const float* bc,

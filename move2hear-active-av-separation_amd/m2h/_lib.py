@@ -171,6 +171,7 @@ SIGNATURES = {
     "m2h_unet_fwd_events": [ctypes.POINTER(UnetWeights), _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P, _I, _P],
     "m2h_sep_slice_input_fmt": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "m2h_gather_envs": [_P, _P, _P, _I, _I, _I, _Z, _P],
+    "m2h_gru_step": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_episode_stats_update": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_rows_copy": [_P, _I, _P, _P],
     "m2h_stft_l2": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],

@@ -239,10 +239,15 @@ class GRUSequence(torch.autograd.Function):
         out = torch.empty((T * N, H), device=x.device, dtype=torch.float32)
         gh = torch.empty((T * N, 3 * H), device=x.device, dtype=torch.float32)
         h = h0.contiguous()
+        fused = N <= ops.GRU_STEP_MAX_ROWS and H % 4 == 0 and H <= 512  # rollout width: the whole step is one launch
+        whh, bhh = w_hh.detach().contiguous(), b_hh.detach()
         for t in range(T):
             sl = slice(t * N, (t + 1) * N)
-            ght = ops.linear(h, w_hh.detach(), None, name="gru.hh", out=gh[sl])      # written in place into the saved buffer
-            h = ops.gru_gates(gi[sl], ght, b_hh.detach(), h, masks[sl], out=out[sl])
+            if fused:
+                h, _ = ops.gru_step(gi[sl], whh, bhh, h, masks[sl], gh_out=gh[sl], out=out[sl])
+                continue
+            ght = ops.linear(h, whh, None, name="gru.hh", out=gh[sl])      # written in place into the saved buffer
+            h = ops.gru_gates(gi[sl], ght, bhh, h, masks[sl], out=out[sl])
         ctx.T = T
         ctx.save_for_backward(x, h0, masks, w_ih, w_hh, b_hh, gi, gh, out)
         return out, h

@@ -381,6 +381,27 @@ def gru_gates(gi, gh_raw, bhh, hprev, mask=None, out=None):
     return hout
 
 
+GRU_STEP_MAX_ROWS = 16
+
+
+def gru_step(gi, whh, bhh, hprev, mask=None, gh_out=None, out=None):
+    """One GRU time step for M <= 16 rows in one launch (m2h_gru_step): recurrent product + gates.  -> (hout, gh_raw)."""
+    for t in (gi, whh, bhh, hprev, mask, gh_out, out):
+        _chk(t, "gru_step")
+    M, H = hprev.shape
+    if gi.shape != (M, 3 * H) or whh.shape != (3 * H, H) or bhh.numel() != 3 * H or (mask is not None and mask.numel() != M):
+        raise RuntimeError("m2h.gru_step: shape mismatch")
+    hout = out if out is not None else torch.empty_like(hprev)
+    gh = gh_out if gh_out is not None else torch.empty_like(gi)
+    if hout.shape != (M, H) or gh.shape != (M, 3 * H):
+        raise RuntimeError("m2h.gru_step: output shape mismatch")
+    with torch.cuda.device(gi.device):
+        _timed("gru.step", {"M": M, "N": 3 * H, "K": H}, gi.device,
+               lambda: _lib.check(_lib.load().m2h_gru_step(_ptr(gi), _ptr(whh), _ptr(bhh), _ptr(hprev), _ptr(mask), _ptr(gh), _ptr(hout), M, H,
+                                                           _stream(gi)), "m2h_gru_step"))
+    return hout, gh
+
+
 def policy_heads(feats, Wa, ba, Wc, bc, actions=None):
     """-> value [M,1], logp_all [M,A], probs [M,A], entropy [M], logp_act [M,1] or None."""
     for t in (feats, Wa, ba, Wc, bc):

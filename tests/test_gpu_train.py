@@ -83,11 +83,12 @@ def test_visual_conv0_padded_channels_and_deslice_backward():
     assert _rel(w2d.grad, w2.grad) < TOL
 
 
-def test_gru_sequence_backward_matches_torch():
+@pytest.mark.parametrize("N", [4, 16, 20])  # <= 16 rows: one fused launch per step (m2h_gru_step); above: GEMM + gate kernel
+def test_gru_sequence_backward_matches_torch(N):
     from m2h import functional as MF
     dev = _dev()
     g = torch.Generator().manual_seed(8)
-    T, N, I, H = 5, 4, 1536, 512
+    T, I, H = 5, 1536, 512
     sd = {O.GRU + "weight_ih_l0": (torch.randn(3 * H, I, generator=g) * I ** -0.5).requires_grad_(True),
           O.GRU + "weight_hh_l0": (torch.randn(3 * H, H, generator=g) * H ** -0.5).requires_grad_(True),
           O.GRU + "bias_ih_l0": (torch.randn(3 * H, generator=g) * 0.05).requires_grad_(True),
