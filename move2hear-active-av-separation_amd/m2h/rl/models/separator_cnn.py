@@ -67,7 +67,11 @@ class _PackedCache:
         self.val = None
 
     def get(self, tensors, build):
-        key = tuple((t.data_ptr(), t._version, t.device) for t in tensors)
+        # trainable sources: FlatAdam and the train-mode BN kernels write through raw pointers, which torch's version counters
+        # do not see, so the key carries the optimizer epoch too (frozen separators -- every RL call site -- keep one key for
+        # good: their packed buffers are never rebuilt and HIP graphs may hold their addresses)
+        epoch = MF.param_epoch() if any(t.requires_grad for t in tensors) else -1
+        key = tuple((t.data_ptr(), t._version, t.device) for t in tensors) + (epoch,)
         if key != self.key:
             self.val = build()
             self.key = key

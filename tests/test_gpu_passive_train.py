@@ -121,6 +121,46 @@ def test_passive_training_steps_match_reference_fixture(golden_dir):
         assert tr.actor_critic.get_binSepMasks(obs).shape == (B, 512, 32, 2)
 
 
+def test_graphed_training_batches_equal_the_kernel_by_kernel_batches_and_eval_sees_the_new_weights():
+    """A training batch replayed from a HIP graph (forward with train-mode BN, losses, backward; Adam outside) leaves the same
+    weights, BN statistics and losses as the kernel-by-kernel batch; and an eval-mode forward between training batches is
+    computed from the CURRENT weights (the fused inference path re-packs after optimizer steps of trainable separators)."""
+    from m2h.common.spaces import move2hear_observation_space
+    from m2h.pretrain.passive.passive_trainer import PassiveTrainer, passive_config
+    from m2h.pretrain.passive.policy import Move2HearPassiveWoMemoryPolicy
+    dev = _dev()
+    outs = []
+    for graphs in (False, True):
+        tr = PassiveTrainer(passive_config(BATCH_SIZE=4, use_hip_graphs=graphs), dev)
+        tr.setup()
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.passive_shapes(), 4).items()}
+        tr.actor_critic.load_state_dict(sd)
+        losses, evals = [], []
+        for i in range(4):
+            tr.actor_critic.train()
+            b, m = tr.train_batch(*tr.feeders["train"].batch())
+            losses.append((b.item(), m.item()))
+            tr.actor_critic.eval()
+            mix, _gb, _gm, tc = tr.feeders["val"].batch()
+            with torch.no_grad():
+                evals.append(tr.actor_critic.get_binSepMasks({"mixed_bin_audio_mag": mix, "target_class": tc}).cpu())
+        assert (tr._train_graph is not None) == graphs
+        outs.append((losses, evals, {k: v.detach().cpu().clone() for k, v in tr.actor_critic.state_dict().items()}, mix, tc))
+    (la, ea, wa, _, _), (lb, eb, wb, mix, tc) = outs
+    assert la == lb
+    for x, y in zip(ea, eb):
+        assert torch.equal(x, y)
+    for k in wa:
+        assert torch.equal(wa[k], wb[k]), k
+    assert not torch.equal(ea[0], ea[1])  # the weights moved between the two eval passes and the eval path noticed
+    fresh = Move2HearPassiveWoMemoryPolicy(move2hear_observation_space(32))
+    fresh.load_state_dict(wb)
+    fresh = fresh.to(dev).eval()
+    with torch.no_grad():
+        ref = fresh.get_binSepMasks({"mixed_bin_audio_mag": mix, "target_class": tc}).cpu()
+    assert torch.equal(ref, eb[-1])
+
+
 def test_passive_trainer_epoch_runs():
     from m2h.pretrain.passive.passive_trainer import PassiveTrainer, passive_config
     tr = PassiveTrainer(passive_config(BATCH_SIZE=8, BATCHES_PER_EPOCH=3, VAL_BATCHES=1), _dev())
