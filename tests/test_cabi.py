@@ -48,3 +48,32 @@ def test_conv_args_struct_matches_header_field_order():
         names.append(first[0].replace("*", " ").split()[-1])
         names += [x.strip().replace("*", "") for x in first[1:]]
     assert names == [f for f, _ in _lib.ConvArgs._fields_], names
+
+
+def _struct_fields(name):
+    txt = open(os.path.join(ROOT, "include", "m2h.h")).read()
+    body = txt[txt.index("typedef struct %s {" % name):txt.index("} %s;" % name)]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S).replace("typedef struct %s {" % name, "")
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            first = decl.split(",")
+            names.append(first[0].replace("*", " ").split()[-1])
+            names += [x.strip().replace("*", "") for x in first[1:]]
+    return names
+
+
+def test_rollout_structs_match_header_field_order():
+    """m2h_episode_stats / m2h_row_copy mirrors (ctypes) follow the header field for field; argument errors of the two entry
+    points are reported without a launch (negative return, message), so this runs without a GPU."""
+    assert _struct_fields("m2h_episode_stats") == [f for f, _ in _lib.EpisodeStats._fields_] == list(_lib.EPISODE_STATS_FIELDS)
+    assert _struct_fields("m2h_row_copy") == [f for f, _ in _lib.RowCopy._fields_]
+    assert ctypes.sizeof(_lib.RowCopy) == 32 and ctypes.sizeof(_lib.EpisodeStats) == 15 * ctypes.sizeof(ctypes.c_void_p)
+    lib = _lib.load()
+    assert lib.m2h_rows_copy(None, 0, None, None) < 0 and b"rows_copy" in lib.m2h_last_error()
+    items = (_lib.RowCopy * 1)(_lib.RowCopy(8, 16, 6, -1, -1))   # size not a multiple of 4
+    assert lib.m2h_rows_copy(items, 1, None, None) < 0 and b"multiple of 4" in lib.m2h_last_error()
+    st = _lib.EpisodeStats()                                      # null statistics tensors
+    assert lib.m2h_episode_stats_update(ctypes.byref(st), 8, 8, 8, 8, 8, 8, 14, 3, None) < 0
+    assert lib.m2h_gru_step(8, 8, 8, 8, None, 8, 8, 17, 512, None) < 0 and b"gru_step" in lib.m2h_last_error()
