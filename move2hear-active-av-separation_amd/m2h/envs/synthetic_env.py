@@ -104,3 +104,33 @@ class SyntheticVecEnv:
 
     def close(self):
         pass
+
+
+class SyntheticHostVecEnv:
+    """The same synthetic world behind the reference's HOST-side vector-env protocol (common/env_utils.py:71-528): ``reset()``
+    returns a list of per-env numpy observation dicts, ``step(list of int actions)`` a list of ``(observation, reward, done,
+    info)`` tuples.  Stands where ``VectorEnvCustom`` stands, so the real-env adapter (vector_env_adapter.py) and the
+    trainer's host-env path can be exercised without Habitat."""
+
+    def __init__(self, num_envs, device, **kw):
+        self._env = SyntheticVecEnv(num_envs, device, **kw)
+        self.num_envs = num_envs
+        self.observation_spaces = self._env.observation_spaces
+        self.action_spaces = self._env.action_spaces
+
+    def _split(self, batch):
+        host = {k: v.cpu().numpy() for k, v in batch.items()}
+        return [{k: host[k][i] for k in host} for i in range(self.num_envs)]
+
+    def reset(self):
+        return self._split(self._env.reset())
+
+    def step(self, actions):
+        dev = self._env.device
+        batch, rewards, masks, infos = self._env.step(torch.tensor(actions, dtype=torch.int64, device=dev).reshape(-1, 1))
+        obs, r, m = self._split(batch), rewards.reshape(-1).tolist(), masks.reshape(-1).tolist()
+        inf = {k: v.reshape(-1).tolist() for k, v in infos.items()}
+        return [(obs[i], r[i], m[i] == 0.0, {k: inf[k][i] for k in inf}) for i in range(self.num_envs)]
+
+    def close(self):
+        self._env.close()

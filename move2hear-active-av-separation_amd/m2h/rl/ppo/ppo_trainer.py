@@ -49,13 +49,16 @@ def far_target_config(**over):
 
 
 class PPOTrainer:
-    def __init__(self, config=None, device=None, world_rank=0, world_size=1):
+    def __init__(self, config=None, device=None, world_rank=0, world_size=1, envs=None):
+        """envs: optional environment object.  None = the synthetic on-device env; anything with ``reset() / step(actions)``
+        returning device tensors as ``SyntheticVecEnv`` does -- e.g. ``HostVectorEnvAdapter`` around the reference's
+        ``VectorEnvCustom`` (row N4) -- replaces it; without ``step_device`` the rollout step is enqueued kernel by kernel."""
         self.config = config if config is not None else near_target_config()
         self.device = device if device is not None else torch.device("cuda", 0)
         self.world_rank, self.world_size = world_rank, world_size
         self.actor_critic = None
         self.agent = None
-        self.envs = None
+        self.envs = envs
         self._next_cache = None
         self._graph_state = None
 
@@ -64,7 +67,8 @@ class PPOTrainer:
         cfg = self.config
         seed = cfg.SEED + self.world_rank * cfg.NUM_PROCESSES
         torch.manual_seed(seed)
-        self.envs = SyntheticVecEnv(cfg.NUM_PROCESSES, self.device, seed=seed, episode_len=cfg.MAX_EPISODE_STEPS)
+        if self.envs is None:
+            self.envs = SyntheticVecEnv(cfg.NUM_PROCESSES, self.device, seed=seed, episode_len=cfg.MAX_EPISODE_STEPS)
         self.actor_critic = Move2HearPolicy(
             observation_space=self.envs.observation_spaces[0], action_space=self.envs.action_spaces[0], goal_sensor_uuid="spectrogram",
             hidden_size=cfg.hidden_size, extra_rgb=cfg.EXTRA_RGB, extra_depth=cfg.EXTRA_DEPTH, use_ddppo=cfg.use_ddppo,
@@ -130,8 +134,9 @@ class PPOTrainer:
         cfg = self.config
         override = cfg.sep_reward_weight == 1.0 and cfg.nav_reward_weight == 0.0
         extra = override and self._episode_step_host == cfg.MAX_EPISODE_STEPS - 2
-        done = self.envs.t + 1 >= self.envs.episode_len
-        if self._graphs_enabled() and self._next_cache is not None:
+        on_device = hasattr(self.envs, "step_device")  # host-side envs (the real simulator) report `done` themselves
+        done = self.envs.t + 1 >= self.envs.episode_len if on_device else None
+        if on_device and self._graphs_enabled() and self._next_cache is not None:
             self._graph_step(extra, done)
             self.rollouts_pol.advance()  # the replayed inserts address their rows on the device
             self.rollouts_sep.advance()
@@ -139,7 +144,8 @@ class PPOTrainer:
             with torch.no_grad():
                 self._next_cache = self._rollout_step_device(self._next_cache, None, extra, done)
         # host-side counters
-        self.envs.t = 0 if done else self.envs.t + 1
+        if on_device:
+            self.envs.t = 0 if done else self.envs.t + 1
         self._episode_step_host = (self._episode_step_host + 1) % cfg.MAX_EPISODE_STEPS
         return self.envs.num_envs
 
@@ -171,7 +177,8 @@ class PPOTrainer:
         values, actions, actions_log_probs, recurrent_hidden_states_pol, distribution_probs = ac.act(
             step_observation, step_h, step_masks, pred_binSepMasks=pred_binSepMasks,
             pred_mono=pred_mono, pred_monoFromMem=pred_monoFromMem)
-        batch, rewards, masks, infos = self.envs.step_device(actions, done)  # device in, device out
+        # device in, device out; a host-side env (done is None) pays its device<->host round trip inside step()
+        batch, rewards, masks, infos = self.envs.step_device(actions, done) if done is not None else self.envs.step(actions)
         # next-step predictions, needed for the reward of the present step (:358-373)
         next_pred_binSepMasks, next_pred_mono = self._separate(batch)
         next_pred_monoFromMem = ac.get_monoFromMem_masked(next_pred_mono, pred_monoFromMem, masks)

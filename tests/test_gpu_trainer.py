@@ -86,6 +86,38 @@ def test_hip_graph_rollout_equals_the_kernel_by_kernel_rollout():
         assert torch.equal(wa[k], wb[k]), k
 
 
+def test_host_vector_env_adapter_reproduces_the_on_device_env_run():
+    """Row N4: the reference's host-side vector-env protocol (lists of per-env numpy observation dicts, python actions, done
+    flags) through HostVectorEnvAdapter drives the same training run as the on-device env, bit for bit."""
+    from m2h.envs.synthetic_env import SyntheticHostVecEnv
+    from m2h.envs.vector_env_adapter import HostVectorEnvAdapter
+    from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config
+    dev = torch.device("cuda", 0)
+    over = dict(NUM_PROCESSES=3, num_steps=4, num_updates_per_cycle=2, ppo_epoch=2, MAX_EPISODE_STEPS=3, use_ddppo=True, use_hip_graphs=False)
+    runs = []
+    for host in (False, True):
+        cfg = near_target_config(**over)
+        envs = HostVectorEnvAdapter(SyntheticHostVecEnv(cfg.NUM_PROCESSES, dev, seed=cfg.SEED, episode_len=cfg.MAX_EPISODE_STEPS), dev) if host else None
+        tr = PPOTrainer(cfg, dev, envs=envs)
+        tr.setup()
+        tr.actor_critic.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), 5).items()})
+        for c in range(2):
+            torch.manual_seed(700 + c)
+            res = tr.train_cycle()
+        runs.append((res, tr.rollouts_pol.actions.cpu().clone(), tr.rollouts_pol.rewards.cpu().clone(), tr.rollouts_pol.masks.cpu().clone(),
+                     tr.rollouts_sep.observations["gt_bin_comps"].cpu().clone(), tr.stats.episode_counts.cpu().clone(),
+                     {k: v.detach().cpu().clone() for k, v in tr.actor_critic.state_dict().items()}))
+        if host:
+            tr.envs.close()
+    a, b = runs
+    assert a[0]["pol_losses"] == b[0]["pol_losses"] and a[0]["sep_losses"] == b[0]["sep_losses"]
+    for x, y in zip(a[1:6], b[1:6]):
+        assert torch.equal(x, y)
+    assert float(a[5].sum()) > 0  # episodes did finish (done flags travelled through the host protocol)
+    for k in a[6]:
+        assert torch.equal(a[6][k], b[6][k]), k
+
+
 def test_next_step_cache_preserves_rollout_contents():
     """Re-using the next-observation separator outputs as the following step's current outputs stores exactly what a
     from-scratch recomputation stores (frozen eval-mode networks are deterministic per observation)."""
