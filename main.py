@@ -41,7 +41,10 @@ def main():
         ckpt = args.eval_ckpt
         if ckpt is None and config.CHECKPOINT_FOLDER and os.path.exists(os.path.join(config.CHECKPOINT_FOLDER, "ckpt.0.pth")):
             ckpt = os.path.join(config.CHECKPOINT_FOLDER, "ckpt.0.pth")
-        stats = trainer.eval(num_episodes=args.eval_episodes, checkpoint_path=ckpt)
+        if getattr(config, "switch_policy", False):  # config/test/farTarget.yaml: two-policy checkpoint (state_dict_nav / state_dict_qualImprov)
+            stats = trainer.eval(num_episodes=args.eval_episodes, switch_checkpoint_path=ckpt)
+        else:
+            stats = trainer.eval(num_episodes=args.eval_episodes, checkpoint_path=ckpt)
         print(json.dumps(stats, indent=1))
         return
     if config.TRAINER_NAME == "passive":

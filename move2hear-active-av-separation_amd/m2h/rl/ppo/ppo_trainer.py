@@ -37,6 +37,7 @@ def near_target_config(**over):
              num_mini_batch=1, eps=1.0e-5, max_grad_norm=0.5, num_steps=20, use_gae=True, gamma=0.99, tau=0.95,
              use_linear_clip_decay=True, use_linear_lr_decay=True, sep_reward_weight=1.0, nav_reward_weight=0.0,
              extra_reward_multiplier=10.0, reward_window_size=50, use_ddppo=True, CHECKPOINT_FOLDER=None,
+             switch_policy=False, time_thres_for_pol_switch=80, deterministic_eval=False,   # config/default.py:99-101
              use_hip_graphs=True,       # build-side key: replay the rollout step and the update_pol epoch from HIP graphs (same kernels, same results)
              overlap_grad_reduce=None)  # build-side key: None = overlap the last all-reduce + step of an update when distributed
     c.update(over)
@@ -331,16 +332,51 @@ class PPOTrainer:
         self._next_cache = None
         return out
 
-    def eval(self, num_episodes=None, checkpoint_path=None, waveform_metrics=("si_sdr",), deterministic=None):
+    @staticmethod
+    def save_switch_checkpoint(path, nav_checkpoint, qual_improv_checkpoint):
+        """The far-target evaluation's two-policy checkpoint (scripts/farTarget_eval/copy_individualCkptsNCfgs_switchPolicyEval.ipynb):
+        ``state_dict_nav`` / ``config_nav`` from the far-target (navigation) run, ``state_dict_qualImprov`` /
+        ``config_qualImprov`` from the near-target (quality-improvement) run.  Arguments: checkpoint dicts or paths."""
+        load = lambda c: c if isinstance(c, dict) else torch.load(c, map_location="cpu", weights_only=False)  # noqa: E731
+        nav, qual = load(nav_checkpoint), load(qual_improv_checkpoint)
+        torch.save({"state_dict_nav": nav["state_dict"], "config_nav": nav["config"],
+                    "state_dict_qualImprov": qual["state_dict"], "config_qualImprov": qual["config"]}, path)
+
+    def _policy_from_state_dict(self, state_dict):
+        """A second eval-mode Move2HearPolicy (same construction as setup()) carrying a checkpoint's ``actor_critic.*`` weights."""
+        cfg = self.config
+        ac = Move2HearPolicy(observation_space=self.envs.observation_spaces[0], action_space=self.envs.action_spaces[0],
+                             goal_sensor_uuid="spectrogram", hidden_size=cfg.hidden_size, extra_rgb=cfg.EXTRA_RGB, extra_depth=cfg.EXTRA_DEPTH,
+                             use_ddppo=cfg.use_ddppo, world_rank=self.world_rank)
+        sd = {k[len("actor_critic."):]: v for k, v in state_dict.items() if k.startswith("actor_critic.")}
+        if not sd:
+            raise RuntimeError("checkpoint state_dict has no 'actor_critic.*' keys")
+        ac.load_state_dict(sd, strict=True)
+        return ac.to(self.device).eval()
+
+    def eval(self, num_episodes=None, checkpoint_path=None, waveform_metrics=("si_sdr",), deterministic=None,
+             switch_checkpoint_path=None, time_thres_for_pol_switch=None):
         """Evaluation loop of `_eval_checkpoint` (reference :1015-1551) on this trainer's vectorised env: eval-mode policy,
         deterministic or sampled actions (ppo_cfg.deterministic_eval), per-step STFT-L2 of the separated mono (:1369-1385),
         waveform metrics of the LAST step of each episode (:1400-1415) when the env provides `mixed_bin_audio_phase`, and the
-        reference's aggregation (mean / std over episodes, :1484-1504).  Returns the aggregated-stats dict."""
+        reference's aggregation (mean / std over episodes, :1484-1504).  Returns the aggregated-stats dict.
+        switch_checkpoint_path: the far-target evaluation with TWO policies (RL.PPO.switch_policy, :1093-1130, :1231-1312): a file
+        holding ``state_dict_nav`` and ``state_dict_qualImprov``; the navigation policy (with its own separators, memory and
+        hidden state) acts for the first ``time_thres_for_pol_switch`` steps of an episode (config/default.py:101: 80), the
+        quality-improvement policy afterwards; the memory is masked by the navigation policy's not-done flags throughout and the
+        quality-improvement policy's flags start tracking the env only once it acts (:1348-1360)."""
         import numpy as np
         from ...common import eval_metrics as EM
         cfg, ac = self.config, self.actor_critic
         if checkpoint_path is not None:
             self.load_state_dict(self.load_checkpoint(checkpoint_path)["state_dict"])
+        acs = None
+        if switch_checkpoint_path is not None:
+            ck = self.load_checkpoint(switch_checkpoint_path)
+            if "state_dict_nav" not in ck or "state_dict_qualImprov" not in ck:
+                raise RuntimeError("switch-policy checkpoint needs 'state_dict_nav' and 'state_dict_qualImprov' (save_switch_checkpoint)")
+            acs = (self._policy_from_state_dict(ck["state_dict_nav"]), self._policy_from_state_dict(ck["state_dict_qualImprov"]))
+            thres = int(time_thres_for_pol_switch if time_thres_for_pol_switch is not None else getattr(cfg, "time_thres_for_pol_switch", 80))
         was_training = ac.training
         ac.eval()
         N = self.envs.num_envs
@@ -352,6 +388,7 @@ class PPOTrainer:
         obs = self.envs.reset()
         h = torch.zeros(ac.pol_net.num_recurrent_layers, N, cfg.hidden_size, device=self.device)
         not_done = torch.ones(N, 1, device=self.device)
+        h_q, not_done_q, step_in_episode = torch.zeros_like(h), torch.ones(N, 1, device=self.device), 0  # switch-policy state
         prev_mem = torch.zeros(N, 512, 32, 1, device=self.device)
         per_ep = {k: [] for k in ("mono_loss_last_step", "mono_loss_all_steps", "monoFromMem_loss_last_step",
                                   "monoFromMem_loss_all_steps", "reward")}
@@ -360,20 +397,30 @@ class PPOTrainer:
         done_eps = 0
         with torch.no_grad():
             while done_eps < num_episodes:
-                pm, mono = self._separate(obs)
-                mem = ac.get_monoFromMem_masked(mono, prev_mem, not_done)
-                _v, actions, _lp, h, _probs = ac.act(obs, h, not_done, deterministic=deterministic, pred_binSepMasks=pm, pred_mono=mono,
-                                                     pred_monoFromMem=mem)
+                qual = acs is not None and step_in_episode >= thres            # :1231-1240 (step count of env 0: lockstep episodes)
+                pol = ac if acs is None else acs[1 if qual else 0]
+                pm = pol.get_binSepMasks(obs)
+                mono = pol.convert_bin2mono(pm, mixed_audio=obs["mixed_bin_audio_mag"])
+                mem = pol.get_monoFromMem_masked(mono, prev_mem, not_done)      # the nav flags mask the memory in both phases (:1276-1281)
+                if qual:
+                    _v, actions, _lp, h_q, _probs = pol.act(obs, h_q, not_done_q, deterministic=deterministic, pred_binSepMasks=pm,
+                                                            pred_mono=mono, pred_monoFromMem=mem)
+                else:
+                    _v, actions, _lp, h, _probs = pol.act(obs, h, not_done, deterministic=deterministic, pred_binSepMasks=pm, pred_mono=mono,
+                                                          pred_monoFromMem=mem)
                 _db, d_mono = EM.STFT_L2_distance(obs["mixed_bin_audio_mag"], pm, obs["gt_bin_comps"], mono, obs["gt_mono_comps"])
                 d_mem = ops.stft_l2(mem, obs["gt_mono_comps"], 1)
                 last_obs, last_mono, last_mem = obs, mono, mem
                 obs, rewards, not_done, _infos = self.envs.step(actions)
+                if qual:
+                    not_done_q = not_done                                        # :1354-1359
                 cur_mono += d_mono
                 cur_mem += d_mem
                 cur_rew += rewards
                 cur_steps += 1
                 prev_mem = mem
                 finished = (not_done.view(-1) == 0).nonzero().view(-1).tolist()  # host sync once per step, as the reference's loop
+                step_in_episode = 0 if 0 in finished else step_in_episode + 1    # :1216 (env 0's step count)
                 if finished:
                     wm = None
                     if waveform_metrics and "mixed_bin_audio_phase" in last_obs:

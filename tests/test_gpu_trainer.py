@@ -159,6 +159,35 @@ def test_checkpoint_round_trip_and_eval(tmp_path):
     assert abs(stats3["mono_si_sdr"]["mean"] - stats["mono_si_sdr"]["mean"]) < 1e-3
 
 
+def test_switch_policy_evaluation_with_a_two_policy_checkpoint(tmp_path):
+    """Far-target evaluation (RL.PPO.switch_policy, ppo_trainer.py:1093-1130, 1231-1312): the navigation policy acts for the first
+    `time_thres_for_pol_switch` steps of an episode, the quality-improvement policy afterwards.  With the threshold beyond the
+    episode length the run is the plain evaluation of the navigation checkpoint, with threshold 0 that of the other one."""
+    from m2h.rl.ppo.ppo_trainer import PPOTrainer
+    paths = {}
+    for name, seed in (("nav", 11), ("qual", 12)):
+        tr, _ = _trainer(CHECKPOINT_FOLDER=str(tmp_path / name))
+        tr.actor_critic.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), seed).items()})
+        tr.save_checkpoint("ckpt.0.pth")
+        paths[name] = str(tmp_path / name / "ckpt.0.pth")
+    sw = str(tmp_path / "ckpt_polSwitch.pth")
+    PPOTrainer.save_switch_checkpoint(sw, paths["nav"], paths["qual"])
+    ck = torch.load(sw, map_location="cpu", weights_only=False)
+    assert set(ck) == {"state_dict_nav", "config_nav", "state_dict_qualImprov", "config_qualImprov"}
+
+    def run(**kw):
+        tr, _ = _trainer()  # episodes of 4 steps; a fresh trainer = the same env seed every time
+        return tr.eval(num_episodes=6, waveform_metrics=(), deterministic=True, **kw)
+    plain_nav, plain_qual = run(checkpoint_path=paths["nav"]), run(checkpoint_path=paths["qual"])
+    late, never_nav, mixed = (run(switch_checkpoint_path=sw, time_thres_for_pol_switch=t) for t in (99, 0, 2))
+    key = "monoFromMem_loss_all_steps"
+    assert late == plain_nav and never_nav == plain_qual
+    assert plain_nav[key]["mean"] != plain_qual[key]["mean"]
+    assert mixed["num_episodes"] == 6 and np.isfinite(mixed[key]["mean"]) and mixed != plain_nav and mixed != plain_qual
+    with pytest.raises(RuntimeError):
+        run(switch_checkpoint_path=paths["nav"])  # not a two-policy file
+
+
 def test_far_target_schedule_runs_with_env_rewards():
     """farTarget.yaml (BASELINE config 5): nav_reward_weight 1 / sep_reward_weight 0 keeps the environment's
     rewards (no quality-improvement override) and episodes are longer than the rollout; the cycle must run and update."""
