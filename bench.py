@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-far-target", action="store_true", help="skip the far-target / mixed-precision DD-PPO leg")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the pair kernel by kernel instead of replaying a HIP graph")
     ap.add_argument("--ddppo-cycles", type=int, default=2, help="timed DD-PPO cycles (0 = skip); one untimed warm-up cycle precedes them")
     ap.add_argument("--math", choices=["fp32", "bf16x3"], default="bf16x3",
@@ -114,48 +115,77 @@ def cpu_baseline(sd, tm, seconds):
                       % (n, bs, tm, best_n, ncpu, el)}
 
 
-def run_ddppo(args, dev, rank, world, dist):
+def run_ddppo(args, dev, rank, world, dist, far_target=False):
     """Second figure of BASELINE.json's metric: DD-PPO env-steps/s on the reference schedule (nearTarget.yaml: 14 envs/rank,
     T=20, 6 policy updates + 6 separator updates per cycle, 4 epochs, 1 minibatch) with the synthetic on-device env.
-    Whole-job rate = all ranks' env steps / max-over-ranks time; gradients are all-reduced over RCCL when world > 1."""
-    from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config
-    cfg = near_target_config()
-    tr = PPOTrainer(cfg, dev, world_rank=rank, world_size=world)
-    tr.setup()
-    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in __import__("m2h.synthetic", fromlist=["x"]).make_state_dict(
-        __import__("m2h.synthetic", fromlist=["x"]).policy_shapes(), 1).items()}
-    tr.actor_critic.load_state_dict(sd)
-    tr.train_cycle()  # warm-up (allocator, pack caches, lazy optimizer buffers)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    steps = 0
-    last = None
-    for _ in range(args.ddppo_cycles):
-        last = tr.train_cycle()
-        steps += last["env_steps"]
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    return {"metric": "ddppo_env_steps_per_sec", "value": round(world * steps / el, 1), "unit": "env-steps/s", "n_gpus": world,
-            "cycles": args.ddppo_cycles, "s_per_cycle": round(el / args.ddppo_cycles, 4), "envs_per_rank": cfg.NUM_PROCESSES,
-            "schedule": "nearTarget.yaml: T=20, 6x(rollout+update_pol) + 6x update_sep per cycle, ppo_epoch 4, 1 minibatch, hidden 512",
-            "env": "synthetic on-device env (cached 128x128 RGB-D frames + spectrogram pool), zero-cost dynamics",
-            "launch": ("HIP graphs: the rollout step (one graph per (extra-reward, episode-end) flag pair) and the update_pol epoch "
-                       "(forward + losses + backward) are captured once and replayed; optimizer steps, collectives and update_sep "
-                       "are enqueued kernel by kernel" if cfg.use_hip_graphs else "kernel by kernel"),
-            "grad_reduce": ("flat-buffer sum all-reduce per backward (RCCL); the last all-reduce + clip + Adam of every update runs on a "
-                            "side stream, fenced at the next reader of those parameters" if world > 1 else "single rank: no collective"),
-            "separator_output_reuse": "frozen eval-mode U-Net outputs computed once per stored observation and re-used by the 24 "
-                                      "update_sep passes and by the next rollout step (result-preserving; SURVEY D13)",
-            "last_pol_losses": [round(x, 5) for x in last["pol_losses"]], "last_sep_losses": [round(x, 5) for x in last["sep_losses"]],
-            "reference_cpu_env_steps_per_sec_survey_probe": 4.3}
+    Whole-job rate = all ranks' env steps / max-over-ranks time; gradients are all-reduced over RCCL when world > 1.
+    far_target: BASELINE config 5 -- farTarget.yaml (episodes of 80 steps, the environment's navigation reward, no reward
+    override) with the forward / input-gradient GEMMs in bf16x3 math (the build-side mixed-precision mode); the
+    distance of that arithmetic from the fp32 one is measured on one evaluate_actions batch and reported beside the rate."""
+    from m2h import ops
+    from m2h.rl.ppo.ppo_trainer import PPOTrainer, far_target_config, near_target_config
+    syn = __import__("m2h.synthetic", fromlist=["x"])
+    cfg = far_target_config() if far_target else near_target_config()
+    ops.set_math_mode(ops.MATH_BF16X3 if far_target else ops.MATH_FP32)
+    try:
+        tr = PPOTrainer(cfg, dev, world_rank=rank, world_size=world)
+        tr.setup()
+        tr.actor_critic.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_state_dict(syn.policy_shapes(), 1).items()})
+        tr.train_cycle()  # warm-up (allocator, pack caches, lazy optimizer buffers, graph capture)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        steps = 0
+        last = None
+        for _ in range(args.ddppo_cycles):
+            last = tr.train_cycle()
+            steps += last["env_steps"]
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        mixed = None
+        if far_target:
+            # the same evaluate_actions batch (the policy storage as it stands) in both arithmetic modes
+            ro, ac = tr.rollouts_pol, tr.actor_critic
+            flat = lambda x: x.reshape((x.shape[0] * x.shape[1],) + tuple(x.shape[2:]))  # noqa: E731
+            obs = {k: flat(v[:-1]) for k, v in ro.observations.items()}
+            outs = []
+            for mode in (ops.MATH_FP32, ops.MATH_BF16X3):
+                ops.set_math_mode(mode)
+                with torch.no_grad():
+                    v, lp, _ent, _h = ac.evaluate_actions(obs, ro.recurrent_hidden_states_pol[0], flat(ro.masks[:-1]), flat(ro.actions),
+                                                          pred_binSepMasks=flat(ro.pred_binSepMasks), pred_mono=flat(ro.pred_mono),
+                                                          pred_monoFromMem=flat(ro.prev_pred_monoFromMem[1:]))
+                outs.append((v.clone(), lp.clone()))
+            rel = lambda a, b: float(((a - b).abs().sum() / b.abs().sum()).item())  # noqa: E731
+            mixed = {"what": "rel-L1 of evaluate_actions (280 stored samples) in bf16x3 math against fp32 math, same weights and inputs",
+                     "value": rel(outs[1][0], outs[0][0]), "action_log_probs": rel(outs[1][1], outs[0][1])}
+    finally:
+        ops.set_math_mode(ops.MATH_FP32)
+    out = {"metric": "ddppo_env_steps_per_sec", "value": round(world * steps / el, 1), "unit": "env-steps/s", "n_gpus": world,
+           "cycles": args.ddppo_cycles, "s_per_cycle": round(el / args.ddppo_cycles, 4), "envs_per_rank": cfg.NUM_PROCESSES,
+           "schedule": ("farTarget.yaml: episodes of 80 steps, navigation reward (no override), " if far_target else "nearTarget.yaml: ") +
+                       "T=20, 6x(rollout+update_pol) + 6x update_sep per cycle, ppo_epoch 4, 1 minibatch, hidden 512",
+           "env": "synthetic on-device env (cached 128x128 RGB-D frames + spectrogram pool), zero-cost dynamics",
+           "launch": ("HIP graphs: the rollout step (one graph per (extra-reward, episode-end) flag pair) and the update_pol epoch "
+                      "(forward + losses + backward) are captured once and replayed; optimizer steps, collectives and update_sep "
+                      "are enqueued kernel by kernel" if cfg.use_hip_graphs else "kernel by kernel"),
+           "grad_reduce": ("flat-buffer sum all-reduce per backward (RCCL); the last all-reduce + clip + Adam of every update runs on a "
+                           "side stream, fenced at the next reader of those parameters" if world > 1 else "single rank: no collective"),
+           "separator_output_reuse": "frozen eval-mode U-Net outputs computed once per stored observation and re-used by the 24 "
+                                     "update_sep passes and by the next rollout step (result-preserving; SURVEY D13)",
+           "last_pol_losses": [round(x, 5) for x in last["pol_losses"]], "last_sep_losses": [round(x, 5) for x in last["sep_losses"]],
+           "reference_cpu_env_steps_per_sec_survey_probe": 4.3}
+    if far_target:
+        out["math"] = "bf16x3 products (fp32 tensors and accumulation) in every forward / input-gradient GEMM; weight gradients, reductions, Adam in fp32"
+        out["mixed_precision_parity"] = mixed
+    return out
 
 
 def run_passive_train(args, dev, rank):
@@ -388,6 +418,7 @@ def main():
     del m_a, m_b, mono_a, mono_b, em
 
     ddppo = run_ddppo(args, dev, rank, world, dist) if args.ddppo_cycles > 0 else None
+    ddppo_far = run_ddppo(args, dev, rank, world, dist, far_target=True) if (args.ddppo_cycles > 0 and not args.no_far_target) else None
     ptrain = run_passive_train(args, dev, rank) if args.train_steps > 0 else None
 
     if rank != 0:
@@ -419,6 +450,7 @@ def main():
         "other_math_mode": other_mode,
         "math_mode_parity": parity,
         "ddppo": ddppo,
+        "ddppo_far_target": ddppo_far,
         "passive_train": ptrain,
         "cpu_baseline": cpu,
         "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
