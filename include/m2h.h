@@ -316,6 +316,11 @@ int m2h_bias_grad(const float* dy, float* db, int M, int N, float* workspace, m2
 int m2h_gru_gates_bwd(const float* gi, const float* gh_raw, const float* bhh, const float* hprev, const float* mask, const float* dh,
                       float* dgi, float* dpre, float* dhp, float* hpm, int M, int H, m2h_stream stream);
 int m2h_gru_bwd_combine(const float* a, const float* b, const float* c, const float* mask, float* out, int M, int H, m2h_stream stream);
+/* The recurrent half of one GRU backward step for M <= 16 rows in one launch: out = a + mask_row*(dpre W_hh + dhp), i.e. the
+ * [M,3H]x[3H,H] product and m2h_gru_bwd_combine (torch autograd of rnn_state_encoder.py:86-137 at the rollout width).
+ * whh_t: W_hh^T as [H][3H] (m2h_pack_dgrad_weight of weight_hh_l0); a may be NULL.  H % 16 == 0, H <= 512. */
+int m2h_gru_bwd_rec(const float* dpre, const float* whh_t, const float* a, const float* dhp, const float* mask, float* out, int M, int H,
+                    m2h_stream stream);
 
 /* Backward of m2h_policy_heads: g_value[M], g_logp[M], g_ent[M] = dL/d(value | logp_act | entropy row) (each may be NULL); dz [M][ZS] receives
  * (dL/dlogits[0..A), dL/dvalue, 0...) with ZS = A+1 rounded up to a multiple of 4; dfeats [M][H]. */

@@ -580,6 +580,80 @@ __global__ void gru_bwd_combine_kernel(const float* __restrict__ a, const float*
   }
 }
 
+// Recurrent part of one GRU backward step for M <= 16 rows in one launch: out = a + mask * (dpre W_hh + dhp), i.e. the
+// [M,3H] x [3H,H] product (a 3 MB weight stream against 14 rows), and m2h_gru_bwd_combine.  Structure of gru_step_kernel: a
+// block owns 4 hidden units = 4 rows of W_hh^T; the 3H-long reduction is walked in three H-long parts (one per gate block),
+// each staged in LDS with the matching slice of dpre (41 KB in all); all global loads are issued before the first LDS store.
+// Thread (k-quarter, unit, env) sums a quarter of every part; the four quarters meet through LDS in a fixed order.
+constexpr int GB_U = 4, GB_E = 16, GB_KQ = 4, GB_NT = GB_U * GB_E * GB_KQ;
+__global__ __launch_bounds__(GB_NT) void gru_bwd_rec_kernel(const float* __restrict__ dpre, const float* __restrict__ whh_t,
+                                                           const float* __restrict__ a, const float* __restrict__ dhp,
+                                                           const float* __restrict__ mask, float* __restrict__ out, int M, int H) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LD = H + 4;
+  float* Ws = smem;                  // [GB_U][LD]
+  float* Ds = Ws + GB_U * LD;        // [GB_E][LD]
+  float* P = Ds + GB_E * LD;         // [GB_KQ][GB_U][GB_E]
+  const int tid = threadIdx.x;
+  const int j0 = blockIdx.x * GB_U;
+  const int H4 = H >> 2, K = 3 * H;
+  constexpr int NWL = (GB_U * 128 + GB_NT - 1) / GB_NT;   // 16-byte loads per thread and part at H = 512
+  constexpr int NDL = (GB_E * 128 + GB_NT - 1) / GB_NT;
+  float4 wreg[3][NWL], dreg[3][NDL];
+#pragma unroll
+  for (int part = 0; part < 3; ++part) {
+#pragma unroll
+    for (int k = 0; k < NWL; ++k) {
+      const int i = min(tid + k * GB_NT, GB_U * H4 - 1);
+      const int u = i / H4, c = i - u * H4;
+      wreg[part][k] = *reinterpret_cast<const float4*>(&whh_t[(size_t)(j0 + u) * K + part * H + 4 * c]);
+    }
+#pragma unroll
+    for (int k = 0; k < NDL; ++k) {
+      const int i = min(tid + k * GB_NT, GB_E * H4 - 1);
+      const int e = min(i / H4, M - 1), c = i % H4;
+      dreg[part][k] = *reinterpret_cast<const float4*>(&dpre[(size_t)e * K + part * H + 4 * c]);
+    }
+  }
+  const int kq = tid / (GB_U * GB_E), u = (tid / GB_E) % GB_U, e = tid % GB_E;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int c0 = kq * (H4 / GB_KQ), c1 = c0 + H4 / GB_KQ;
+#pragma unroll
+  for (int part = 0; part < 3; ++part) {
+    if (part > 0) __syncthreads();   // the previous part has been read
+#pragma unroll
+    for (int k = 0; k < NWL; ++k) {
+      const int i = tid + k * GB_NT;
+      if (i < GB_U * H4) *reinterpret_cast<float4*>(&Ws[(i / H4) * LD + 4 * (i % H4)]) = wreg[part][k];
+    }
+#pragma unroll
+    for (int k = 0; k < NDL; ++k) {
+      const int i = tid + k * GB_NT;
+      if (i < GB_E * H4) *reinterpret_cast<float4*>(&Ds[(i / H4) * LD + 4 * (i % H4)]) = dreg[part][k];
+    }
+    __syncthreads();
+    const float* wr = Ws + u * LD;
+    const float* dr = Ds + e * LD;
+#pragma unroll 4
+    for (int c = c0; c < c1; ++c) {
+      const float4 w = *reinterpret_cast<const float4*>(wr + 4 * c);
+      const float4 d = *reinterpret_cast<const float4*>(dr + 4 * c);
+      a0 = fmaf(w.x, d.x, a0);
+      a1 = fmaf(w.y, d.y, a1);
+      a2 = fmaf(w.z, d.z, a2);
+      a3 = fmaf(w.w, d.w, a3);
+    }
+  }
+  P[(kq * GB_U + u) * GB_E + e] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (tid < GB_U * GB_E && e < M) {
+    const float rec = (P[(0 * GB_U + u) * GB_E + e] + P[(1 * GB_U + u) * GB_E + e]) + (P[(2 * GB_U + u) * GB_E + e] + P[(3 * GB_U + u) * GB_E + e]);
+    const size_t o = (size_t)e * H + j0 + u;
+    const float m = mask != nullptr ? mask[e] : 1.f;
+    out[o] = (a != nullptr ? a[o] : 0.f) + m * (rec + dhp[o]);
+  }
+}
+
 // Backward of policy_heads_kernel: one wave per row.  g_value, g_logp, g_ent_rows = dL/d(value | logp_act | entropy) per row.
 //   dz [M][ZS]: columns 0..A-1 = dL/dlogits, column A = dL/dvalue, rest 0   (ZS = A+1 rounded up to 4)
 //   dfeats [M][H] = sum_a dlogit_a * Wa[a] + dvalue * Wc
@@ -844,6 +918,16 @@ int m2h_gru_bwd_combine(const float* a, const float* b, const float* c, const fl
   M2H_REQUIRE(b && c && out && M > 0 && H > 0, "gru_bwd_combine: bad arguments");
   hipLaunchKernelGGL(gru_bwd_combine_kernel, dim3(grid_for((size_t)M * H)), dim3(256), 0, as_stream(stream), a, b, c, mask, out, M, H);
   return launch_status("gru_bwd_combine");
+}
+
+int m2h_gru_bwd_rec(const float* dpre, const float* whh_t, const float* a, const float* dhp, const float* mask, float* out, int M, int H,
+                    m2h_stream stream) {
+  M2H_REQUIRE(dpre && whh_t && dhp && out, "gru_bwd_rec: null pointer");
+  M2H_REQUIRE(M > 0 && M <= GB_E && H > 0 && H % 16 == 0 && H <= 512, "gru_bwd_rec: needs 1 <= M <= %d rows and H %% 16 == 0, H <= 512 (got M=%d, H=%d)",
+              GB_E, M, H);
+  const size_t lds = ((size_t)(GB_U + GB_E) * (H + 4) + GB_KQ * GB_U * GB_E) * sizeof(float);  // 42.3 KB at H = 512
+  hipLaunchKernelGGL(gru_bwd_rec_kernel, dim3(H / GB_U), dim3(GB_NT), lds, as_stream(stream), dpre, whh_t, a, dhp, mask, out, M, H);
+  return launch_status("gru_bwd_rec");
 }
 
 int m2h_policy_heads_bwd(const float* logp_all, const float* probs, const long long* actions, const float* g_value, const float* g_logp,

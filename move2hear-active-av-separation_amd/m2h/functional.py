@@ -266,6 +266,7 @@ class GRUSequence(torch.autograd.Function):
         dhp = torch.empty((N, H), device=dev)
         # W_hh^T as an [H][3H] "Linear" weight for the recurrent dgrad GEMM
         whh_t = pack_dgrad_weight(w_hh.detach().reshape(3 * H, H, 1, 1).contiguous(), 1, 0).view(H, 3 * H)
+        fused = N <= ops.GRU_STEP_MAX_ROWS and H % 16 == 0 and H <= 512
         dh = g_out[(T - 1) * N:T * N].clone()
         if g_hT is not None:
             dh = dh + g_hT  # tiny [N,H] add; hT is rarely used downstream
@@ -277,11 +278,15 @@ class GRUSequence(torch.autograd.Function):
                 _lib.check(lib.m2h_gru_gates_bwd(ops._ptr(gi[sl]), ops._ptr(gh[sl]), ops._ptr(b_hh), ops._ptr(hprev.contiguous()),
                                                  ops._ptr(masks[sl]), ops._ptr(dh), ops._ptr(dgi[sl]), ops._ptr(dpre[sl]), ops._ptr(dhp),
                                                  ops._ptr(hpm[sl]), N, H, ops._stream(x)), "m2h_gru_gates_bwd")
-                rec = _lin_nograd(dpre[sl], whh_t, None, "gru.hh.dgrad")  # dpre @ W_hh  [N,H]
                 nxt = torch.empty((N, H), device=dev)
                 a = g_out[(t - 1) * N:t * N] if t > 0 else None
-                _lib.check(lib.m2h_gru_bwd_combine(ops._ptr(a), ops._ptr(rec), ops._ptr(dhp), ops._ptr(masks[sl]), ops._ptr(nxt), N, H,
-                                                   ops._stream(x)), "m2h_gru_bwd_combine")
+                if fused:  # rollout width: recurrent product + combine in one launch
+                    _lib.check(lib.m2h_gru_bwd_rec(ops._ptr(dpre[sl]), ops._ptr(whh_t), ops._ptr(a), ops._ptr(dhp), ops._ptr(masks[sl]),
+                                                   ops._ptr(nxt), N, H, ops._stream(x)), "m2h_gru_bwd_rec")
+                else:
+                    rec = _lin_nograd(dpre[sl], whh_t, None, "gru.hh.dgrad")  # dpre @ W_hh  [N,H]
+                    _lib.check(lib.m2h_gru_bwd_combine(ops._ptr(a), ops._ptr(rec), ops._ptr(dhp), ops._ptr(masks[sl]), ops._ptr(nxt), N, H,
+                                                       ops._stream(x)), "m2h_gru_bwd_combine")
                 dh = nxt
         g_h0 = dh if ctx.needs_input_grad[1] else None
         # batched parameter / input gradients

@@ -15,6 +15,9 @@ from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config  # noqa: E402
 
 
 def main():
+    from m2h import ops
+    if "--bf16x3" in sys.argv:
+        ops.set_math_mode(ops.MATH_BF16X3)
     tr = PPOTrainer(near_target_config(), torch.device("cuda", 0))
     tr.setup()
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), 1).items()}
