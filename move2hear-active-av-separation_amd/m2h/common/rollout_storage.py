@@ -125,6 +125,7 @@ class RolloutStorageSep:
         self.num_steps = num_steps
         self.step = 0
         self.generation = 0  # bumped whenever stored observations change (keys PPO's separator-output cache)
+        self.row0_only_since = None  # generation before the last bump that changed nothing but row 0 (after_update)
 
     def to(self, device):
         for sensor in self.observations:
@@ -160,6 +161,8 @@ class RolloutStorageSep:
         self.prev_pred_monoFromMem[0].copy_(self.prev_pred_monoFromMem[-1])
         self.masks[0].copy_(self.masks[-1])
         if changed:
+            # only row 0 of the stored observations changed: a cache built for generation g - 1 needs row 0 refreshed, not rebuilt
+            self.row0_only_since = self.generation
             self.generation += 1
             self._last_after_update_gen = self.generation
             self._last_after_update_step = self.step

@@ -188,8 +188,21 @@ class PPO(nn.Module):
             return self._sep_cache[1]
         mix = rollouts_sep.observations["mixed_bin_audio_mag"][:-1]
         T, N = mix.shape[0], mix.shape[1]
-        obs = {"mixed_bin_audio_mag": mix.reshape(T * N, *mix.shape[2:]),
-               "target_class": rollouts_sep.observations["target_class"][:-1].reshape(T * N, -1)}
+        tcl = rollouts_sep.observations["target_class"][:-1]
+        prev = self._sep_cache
+        if (self.cache_separator_outputs and prev is not None and key[1] is not None and prev[0] == (key[0], key[1] - 1, key[2])
+                and getattr(rollouts_sep, "row0_only_since", None) == key[1] - 1):
+            # after_update() between two sub-updates copied the last stored observation into row 0 and touched nothing else
+            # (rollout_storage.py): refresh the N cached samples of that row instead of the T*N of the whole buffer
+            with torch.no_grad():
+                pm0 = self.actor_critic.get_binSepMasks({"mixed_bin_audio_mag": mix[0], "target_class": tcl[0]})
+                mono0 = self.actor_critic.convert_bin2mono(pm0, mixed_audio=mix[0])
+            prev[1][0][0].copy_(pm0)
+            prev[1][1][0].copy_(mono0)
+            val = (prev[1][0], prev[1][1])  # (the cached logging losses are whole-buffer means: dropped, recomputed once)
+            self._sep_cache = (key, val)
+            return val
+        obs = {"mixed_bin_audio_mag": mix.reshape(T * N, *mix.shape[2:]), "target_class": tcl.reshape(T * N, -1)}
         with torch.no_grad():
             pm = self.actor_critic.get_binSepMasks(obs)
             mono = self.actor_critic.convert_bin2mono(pm, mixed_audio=obs["mixed_bin_audio_mag"])

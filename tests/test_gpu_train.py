@@ -271,3 +271,45 @@ def test_update_sep_matches_reference_fixture(golden_dir, cache, views):
         d_mine = post[k].cpu() - sd[k]
         bad = ((d_ref - d_mine).abs() > 1e-4).float().mean().item()
         assert bad < 0.01, (k, bad)
+
+
+def test_update_sep_cache_follows_after_update_by_refreshing_row_zero(golden_dir):
+    """Between the six sub-updates of a cycle RolloutStorageSep.after_update() copies the last stored observation into row 0
+    (rollout_storage.py:386-390); the separator-output cache then refreshes that row only.  Three update_sep calls with
+    after_update() in between must give the losses of the uncached schedule (which re-runs the separators over the whole
+    buffer every epoch), and the cached outputs must equal a from-scratch evaluation of the buffer as it stands."""
+    from m2h.common.rollout_storage import RolloutStorageSep
+    from m2h.common.spaces import move2hear_observation_space
+    dev = _dev()
+    gold = np.load(os.path.join(golden_dir, "rl_updates.npz"))
+    T, N = int(gold["sep_T"]), int(gold["sep_N"])
+    obs_s = {k: torch.from_numpy(v).float() for k, v in synthetic.make_rl_observations((T + 1) * N, int(gold["sep_obs_seed"])).items()}
+    out = []
+    for cache in (True, False):
+        agent, pol, _sd = _agent(int(gold["seed_w"]), dev, cache)
+        rs = RolloutStorageSep(T, N, move2hear_observation_space())
+        g2 = torch.Generator().manual_seed(int(gold["sep_fill_seed"]))
+        for k in rs.observations:
+            rs.observations[k].copy_(obs_s[k].reshape(T + 1, N, *obs_s[k].shape[1:]))
+        rs.prev_pred_monoFromMem.copy_(torch.rand(T + 1, N, 512, 32, 1, generator=g2))
+        rs.masks.copy_((torch.rand(T + 1, N, 1, generator=g2) > 0.3).float())
+        rs.to(dev)
+        rs.full_batch_views = True
+        losses = []
+        for i in range(3):
+            torch.manual_seed(77 + i)
+            losses.append(agent.update_sep(rs))
+            rs.after_update()
+        out.append(losses)
+        if cache:
+            pm_c, mono_c = agent._separator_outputs(rs)[:2]   # refreshed for the state after the last after_update()
+            mix = rs.observations["mixed_bin_audio_mag"][:-1]
+            obs = {"mixed_bin_audio_mag": mix.reshape(T * N, *mix.shape[2:]), "target_class": rs.observations["target_class"][:-1].reshape(T * N, -1)}
+            with torch.no_grad():
+                pm_f = pol.get_binSepMasks(obs)
+                mono_f = pol.convert_bin2mono(pm_f, mixed_audio=obs["mixed_bin_audio_mag"])
+            assert _rel(pm_c.reshape(pm_f.shape), pm_f.cpu()) < 1e-6 and _rel(mono_c.reshape(mono_f.shape), mono_f.cpu()) < 1e-6
+            assert not torch.equal(pm_c[0], pm_c[1])
+    for la, lb in zip(*out):
+        for x, y in zip(la, lb):
+            assert abs(x - y) < 1e-5 * max(1.0, abs(y)), (out[0], out[1])
