@@ -60,6 +60,10 @@ struct IGemmP {
   int presplit;  // both operands arrive in the split32 layout
   int dst_split; // epilogue writes dst in the split32 layout (bf16x3 math, NHWC, N % 32 == 0)
   int pmaj;    // transposed conv: phase is folded into grid x (fastest) instead of grid z
+  // tap window of the scalar-decode loader: taps th0..th0+thn-1 x tw0..tw0+twn-1 are walked, the others lie in the zero
+  // padding for EVERY output pixel of this launch (tiny images: a 2-row input under a 4x4/s2/p1 conv, a 1-row input under a
+  // transposed conv) and are skipped: their products are exact zeros.  Kw = thn * twn * Ctot is the walked reduction length.
+  int th0, thn, tw0, twn, Kw;
   int S;       // split-K factor (grid y); S > 1: raw partial sums go to `ws`, the epilogue runs in splitk_epilogue_kernel
   float* ws;   // [phase][S][M][N] fp32 partial slabs (caller-owned workspace)
 };
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
   unsigned okmask[2] = {0u, 0u};
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  const int nk_all = (p.K + BK - 1) / BK;
+  const int nk_all = ((FAST ? p.Kw : p.K) + BK - 1) / BK;
   const int split = blockIdx.y;
   const int kt0 = (int)(((long)nk_all * split) / p.S);
   const int kt1 = (int)(((long)nk_all * (split + 1)) / p.S);
@@ -404,10 +408,10 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
     if constexpr (FAST) {
       u_kt = kt;
       const int k0 = kt * BK;
-      const int tap = p.ntap > 1 ? k0 / p.Ctot : 0;
+      const int tap = p.ntap > 1 ? k0 / p.Ctot : 0;   // index inside the tap window
       u_ci = k0 - tap * p.Ctot;
-      u_th = tap / p.ntw;
-      u_tw = tap - u_th * p.ntw;
+      u_th = p.th0 + tap / p.twn;
+      u_tw = p.tw0 + tap % p.twn;
       segment_rows();
 #pragma unroll
       for (int j = 0; j < BR; ++j)  // rows past N re-read row N-1 (their products are never stored): no mask on the weight side
@@ -425,8 +429,8 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
         if (u_ci == p.Ctot) {
           u_ci = 0;
           reseg = true;
-          if (++u_tw == p.ntw) {
-            u_tw = 0;
+          if (++u_tw == p.tw0 + p.twn) {
+            u_tw = p.tw0;
             ++u_th;
           }
         }
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
     if constexpr (FAST) {
       const bool second = u_ci >= p.C0 && p.src1 != nullptr;
       const char* baseA = reinterpret_cast<const char*>(second ? p.src1 + (u_ci - p.C0) : p.src0 + u_ci);  // uniform
-      const char* baseB = reinterpret_cast<const char*>(wbase + (size_t)u_kt * BK);                          // uniform
+      const char* baseB = reinterpret_cast<const char*>(wbase + (size_t)(u_th * p.ntw + u_tw) * p.Ctot + u_ci);  // uniform
 #pragma unroll
       for (int i = 0; i < AR; ++i) ra[set][i] = *reinterpret_cast<const f32x4*>(baseA + voffA[i]);
 #pragma unroll
@@ -929,6 +933,54 @@ int g_tapshare = 0;       // -1: never use the tap-sharing transposed-conv kerne
 int g_tap_bm = 0;         // 128: 128-output tiles only in the tap-sharing kernel
 int g_fast_loader = 0;    // -1: always use the generic (per-lane k decode) loader
 int g_narrow16 = 0;       // -1: never use the 16-wide (v_mfma_f32_16x16x4_f32) tile for N <= 16
+int g_tap_window = 0;     // -1: walk every tap even where a whole kernel row / column lies in the zero padding
+
+// Tap window (see IGemmP): the contiguous range of kernel rows / columns that reach inside the image for at least one output
+// pixel.  conv: ih = q*stride + off + t*mul, q in [0, Q); transposed conv: both sub-pixel phases (mul = -1, +1, off = 0) must agree.
+static void tap_range(int ntaps, int Q, int stride, int off, int mul, int extent, int& t0, int& tn) {
+  int lo = ntaps, hi = -1;
+  for (int t = 0; t < ntaps; ++t) {
+    bool any = false;
+    for (int q = 0; q < Q && !any; ++q) {
+      const int i = q * stride + off + t * mul;
+      any = i >= 0 && i < extent;
+    }
+    if (any) {
+      lo = t < lo ? t : lo;
+      hi = t > hi ? t : hi;
+    }
+  }
+  if (hi < 0) { t0 = 0; tn = ntaps; return; }   // nothing reaches the image: keep the full walk (all-zero result either way)
+  t0 = lo;
+  tn = hi - lo + 1;
+}
+
+static void tap_window(const m2h_conv_args& a, int& th0, int& thn, int& tw0, int& twn) {
+  th0 = 0; thn = a.nth; tw0 = 0; twn = a.ntw;
+  if (a.Hq > 64 || a.Wq > 4096 || g_tap_window < 0) return;   // large images: every tap is reached, skip the scan
+  if (a.conv_transpose) {
+    int a0, an, b0, bn;
+    tap_range(a.nth, a.Hq, 1, 0, -1, a.Hi, a0, an);
+    tap_range(a.nth, a.Hq, 1, 0, +1, a.Hi, b0, bn);
+    if (a0 == b0 && an == bn) { th0 = a0; thn = an; }
+    tap_range(a.ntw, a.Wq, 1, 0, -1, a.Wi, a0, an);
+    tap_range(a.ntw, a.Wq, 1, 0, +1, a.Wi, b0, bn);
+    if (a0 == b0 && an == bn) { tw0 = a0; twn = an; }
+  } else {
+    tap_range(a.nth, a.Hq, a.stride, a.offh, a.mulh, a.Hi, th0, thn);
+    tap_range(a.ntw, a.Wq, a.stride, a.offw, a.mulw, a.Wi, tw0, twn);
+  }
+}
+
+// Reduction length the launch will walk: the tap window applies to the scalar-decode loader only.
+static int walked_K(const m2h_conv_args& a) {
+  const int Ctot = a.C0 + a.C1;
+  const bool fast = g_fast_loader >= 0 && a.C0 % BK == 0 && a.C1 % BK == 0 && a.C0 > 0;
+  if (!fast) return a.nth * a.ntw * Ctot;
+  int th0, thn, tw0, twn;
+  tap_window(a, th0, thn, tw0, twn);
+  return thn * twn * Ctot;
+}
 
 // Tile choice: N picks the width; skinny M (rollout batches, GRU steps: weight-streaming bound, nothing to re-use along M)
 // gets 32- or 64-row tiles so that four times as many blocks stream the weights.
@@ -959,10 +1011,11 @@ static int splitk_for(long M, int N, int K, int phases, int BM, int BN) {
 static int choose_splitk(const IGemmP& p, int BM, int BN, size_t ws_bytes) {
   if (p.ws == nullptr || g_force_splitk < 0 || (p.N & 3) != 0) return 1;
   const int phases = p.convT ? 4 : 1;
-  int S = splitk_for(p.M, p.N, p.K, phases, BM, BN);
+  const int Kw = (g_fast_loader >= 0 && p.fast_ok) ? p.Kw : p.K;
+  int S = splitk_for(p.M, p.N, Kw, phases, BM, BN);
   if (g_force_splitk > 0) {
     S = g_force_splitk;
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = (Kw + BK - 1) / BK;
     if (S > nk / 2) S = nk / 2;
   }
   while (S > 1 && (size_t)phases * S * p.M * p.N * sizeof(float) > ws_bytes) --S;
@@ -1008,7 +1061,7 @@ size_t conv_igemm_workspace_bytes(const m2h_conv_args& a) {
   // the exact split-K scratch of the automatic choice for these arguments: phases * S * M * N floats
   const long M = (long)a.B * a.Hq * a.Wq;
   const int phases = a.conv_transpose ? 4 : 1;
-  const int K = a.nth * a.ntw * (a.C0 + a.C1);
+  const int K = walked_K(a);
   int BM, BN;
   pick_tile(M, a.N, BM, BN);
   const int S = splitk_for(M, a.N, K, phases, BM, BN);
@@ -1073,6 +1126,8 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
                  (size_t)a.N * p.K * 4 < lim) ? 1 : 0;
   }
   M2H_REQUIRE(p.K % 4 == 0, "conv_igemm: K must be a multiple of 4");
+  tap_window(a, p.th0, p.thn, p.tw0, p.twn);
+  p.Kw = p.thn * p.twn * p.Ctot;
   M2H_REQUIRE(!p.presplit || p.fast_ok, "conv_igemm: split32 operands need channel counts that are multiples of 32");
 
   p.ws = static_cast<float*>(a.workspace);

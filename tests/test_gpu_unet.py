@@ -329,3 +329,39 @@ def test_graphed_pair_replays_the_direct_result():
             assert torch.equal(m2, m3) and torch.equal(mono2, mono3) and not torch.equal(m2, m0)
         finally:
             ops.set_math_mode(ops.MATH_FP32)
+
+
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+def test_tap_window_skips_only_exact_zeros(math):
+    """Tiny images: a 2-row input under the 4x4/s2/p1 conv (the deepest encoder stage) and a 1-row input under the transposed
+    conv (the first decoder stage) have whole kernel rows / columns in the zero padding for EVERY output pixel; the engine
+    walks only the tap window that reaches the image.  The skipped products are exact zeros: results are bit-identical to the
+    full walk (knob 18 = -1), with and without split-K."""
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(3)
+    ops.set_math_mode(ops.MATH_BF16X3 if math == "bf16x3" else ops.MATH_FP32)
+    try:
+        for (B, H, W) in ((3, 2, 2), (14, 2, 2), (5, 2, 16), (2, 4, 4)):
+            x = torch.randn(B, H, W, 512, device=dev, generator=g)
+            wp = torch.randn(512, 16 * 512, device=dev, generator=g) * 0.02
+            sc, sh = torch.rand(512, device=dev, generator=g) + 0.5, torch.randn(512, device=dev, generator=g) * 0.1
+            outs = []
+            for knob in (0, -1):
+                ops.debug_set(18, knob)
+                outs.append(ops.unet_down_fwd(x, wp, sc, sh, 512).clone())
+            assert torch.equal(outs[0], outs[1]), ("down", B, H, W)
+        for (B, H, W) in ((3, 1, 1), (14, 1, 1), (4, 1, 8), (2, 2, 2)):
+            x = torch.randn(B, H, W, 512, device=dev, generator=g)
+            skip = torch.randn(B, H, W, 512, device=dev, generator=g) if H > 1 else None
+            c1 = 512 if skip is not None else 0
+            wp = torch.randn(4, 512, 4 * (512 + c1), device=dev, generator=g) * 0.02
+            sc, sh = torch.rand(512, device=dev, generator=g) + 0.5, torch.randn(512, device=dev, generator=g) * 0.1
+            outs = []
+            for knob in (0, -1):
+                ops.debug_set(18, knob)
+                outs.append(ops.unet_up_fwd(x, skip, wp, sc, sh, 512).clone())
+            assert torch.equal(outs[0], outs[1]), ("up", B, H, W)
+    finally:
+        ops.debug_set(18, 0)
+        ops.set_math_mode(ops.MATH_FP32)
