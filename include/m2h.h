@@ -276,6 +276,18 @@ typedef struct m2h_row_copy {
 } m2h_row_copy;
 int m2h_rows_copy(const m2h_row_copy* items, int n_items, const long long* idx, m2h_stream stream);
 
+/* idx = (pol_step, pol_step + 1, sep_step + 1), the device-resident step counters m2h_rows_copy addresses rows with, advanced as
+ * RolloutStoragePol/Sep.insert advance theirs: step = (step + 1) % num_steps (common/rollout_storage.py:96,390). */
+int m2h_step_index_advance(long long* idx, int T_pol, int T_sep, m2h_stream stream);
+
+/* Synthetic on-device vector env (m2h/envs/synthetic_env.py; stands where the simulator's pose update and sensor suite stand,
+ * habitat_audio/simulator_train.py:216-227,386-486).  m2h_synth_env_step: per env, action 0 moves to node + 1, 1 / 2 turn by
+ * +1 / +3 quarter turns (all modulo).  m2h_synth_env_observe: per item, row e of dst = row r(e) of src, r = node*4 + angle
+ * (items[i].src_slot == 0: cached frames) or audio_idx (src_slot == 1: spectrogram pool); items[i].bytes = one row. */
+int m2h_synth_env_step(const long long* actions, long long* node, long long* angle, int n_nodes, int N, m2h_stream stream);
+int m2h_synth_env_observe(const m2h_row_copy* items, int n_items, const long long* node, const long long* angle, const long long* audio_idx,
+                          int N, m2h_stream stream);
+
 /* STFT_L2_distance (common/eval_metrics.py:306-366) for nch channels: out[e] = sum_ch mean_{re/im,F,T} of the squared
  * distance between (gt_mag, pred_mag) x (cos, sin)(gt_phase); pred_mag = pred (use_mix 0) or (exp(mix)-1)*pred (use_mix 1).
  * pred/mix: [N][L][Cp]; gt_comps: [N][L][Cg] = per channel (mag, phase). */

@@ -529,6 +529,54 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(RowsCopyArgs a, const lo
   }
 }
 
+// Device-resident step counters of the two rollout storages, idx = (pol_step, pol_step + 1, sep_step + 1), advanced at the end
+// of a replayed rollout step (RolloutStoragePol/Sep.insert: step = (step + 1) % num_steps, common/rollout_storage.py:96,390).
+__global__ void step_index_advance_kernel(long long* __restrict__ idx, int T_pol, int T_sep) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const long long p = (idx[0] + 1) % T_pol;
+    const long long s = idx[2] % T_sep;   // idx[2] holds sep_step + 1
+    idx[0] = p;
+    idx[1] = p + 1;
+    idx[2] = s + 1;
+  }
+}
+
+// Synthetic vector env (m2h/envs/synthetic_env.py; stands in for the simulator's pose update, habitat_audio/simulator_train.py):
+// action 0 = MOVE_FORWARD (node + 1), 1 = TURN_LEFT (angle + 1), 2 = TURN_RIGHT (angle + 3), all modulo; one thread per env.
+__global__ void synth_env_step_kernel(const long long* __restrict__ actions, long long* __restrict__ node, long long* __restrict__ angle,
+                                      int n_nodes, int N) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const long long a = actions[e];
+  node[e] = (node[e] + (a == 0 ? 1 : 0)) % n_nodes;
+  angle[e] = (angle[e] + (a == 1 ? 1 : 0) + (a == 2 ? 3 : 0)) % 4;
+}
+
+// Batched row gathers: item i copies, for every env e < N, row index[sel_i][e] * mul_i + add[e] * ... of src_i to row e of dst_i.
+// Serves the synthetic env's observation lookup (cached frames indexed by node * 4 + angle, audio pool indexed per env): six
+// index_select launches as one.  index: [2][N] int64 = (frame index parts, audio index); frame row = node * 4 + angle.
+struct RowsGatherArgs {
+  m2h_row_copy item[M2H_ROWS_COPY_MAX];   // src_slot: 0 = frame index (node * 4 + angle), 1 = audio index; dst_slot unused
+};
+__global__ __launch_bounds__(256) void rows_gather_kernel(RowsGatherArgs a, const long long* __restrict__ node,
+                                                          const long long* __restrict__ angle, const long long* __restrict__ audio_idx) {
+  const m2h_row_copy it = a.item[blockIdx.z];
+  const int e = blockIdx.y;
+  const long long row = it.src_slot == 0 ? node[e] * 4 + angle[e] : audio_idx[e];
+  const char* src = static_cast<const char*>(it.src) + (size_t)row * it.bytes;
+  char* dst = static_cast<char*>(it.dst) + (size_t)e * it.bytes;
+  const size_t start = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  if (((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst) | it.bytes) & 15) == 0) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (size_t i = start; i < it.bytes / 16; i += stride) d4[i] = s4[i];
+  } else {
+    const uint32_t* s1 = reinterpret_cast<const uint32_t*>(src);
+    uint32_t* d1 = reinterpret_cast<uint32_t*>(dst);
+    for (size_t i = start; i < it.bytes / 4; i += stride) d1[i] = s1[i];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // training-side kernels: GRU / heads backward, losses, grad-norm clipping, Adam
 // ---------------------------------------------------------------------------------------------------------------
@@ -1032,6 +1080,35 @@ int m2h_rows_copy(const m2h_row_copy* items, int n_items, const long long* idx, 
   const int gx = (int)((big / 16 + 255) / 256 > 256 ? 256 : ((big / 16 + 255) / 256 < 1 ? 1 : (big / 16 + 255) / 256));
   hipLaunchKernelGGL(rows_copy_kernel, dim3(gx, n_items), dim3(256), 0, as_stream(stream), a, idx);
   return launch_status("rows_copy");
+}
+
+int m2h_step_index_advance(long long* idx, int T_pol, int T_sep, m2h_stream stream) {
+  M2H_REQUIRE(idx && T_pol > 0 && T_sep > 0, "step_index_advance: bad arguments");
+  hipLaunchKernelGGL(step_index_advance_kernel, dim3(1), dim3(64), 0, as_stream(stream), idx, T_pol, T_sep);
+  return launch_status("step_index_advance");
+}
+
+int m2h_synth_env_step(const long long* actions, long long* node, long long* angle, int n_nodes, int N, m2h_stream stream) {
+  M2H_REQUIRE(actions && node && angle && n_nodes > 0 && N > 0, "synth_env_step: bad arguments");
+  hipLaunchKernelGGL(synth_env_step_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), actions, node, angle, n_nodes, N);
+  return launch_status("synth_env_step");
+}
+
+int m2h_synth_env_observe(const m2h_row_copy* items, int n_items, const long long* node, const long long* angle, const long long* audio_idx,
+                          int N, m2h_stream stream) {
+  M2H_REQUIRE(items && n_items > 0 && n_items <= M2H_ROWS_COPY_MAX && node && angle && audio_idx && N > 0, "synth_env_observe: bad arguments");
+  RowsGatherArgs a;
+  size_t big = 0;
+  for (int i = 0; i < n_items; ++i) {
+    M2H_REQUIRE(items[i].src && items[i].dst && items[i].bytes > 0 && items[i].bytes % 4 == 0 && (items[i].src_slot == 0 || items[i].src_slot == 1),
+                "synth_env_observe: item %d: null pointer, size not a multiple of 4, or index selector not in {0, 1}", i);
+    a.item[i] = items[i];
+    big = items[i].bytes > big ? items[i].bytes : big;
+  }
+  size_t gx = (big / 16 + 255) / 256;
+  gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+  hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)gx, (unsigned)N, (unsigned)n_items), dim3(256), 0, as_stream(stream), a, node, angle, audio_idx);
+  return launch_status("synth_env_observe");
 }
 
 }  // extern "C"

@@ -175,6 +175,9 @@ SIGNATURES = {
     "m2h_gru_step": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_episode_stats_update": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_rows_copy": [_P, _I, _P, _P],
+    "m2h_step_index_advance": [_P, _I, _I, _P],
+    "m2h_synth_env_step": [_P, _P, _P, _I, _I, _P],
+    "m2h_synth_env_observe": [_P, _I, _P, _P, _P, _I, _P],
     "m2h_stft_l2": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
 }
 

@@ -47,6 +47,7 @@ class SyntheticVecEnv:
         self.node = torch.randint(0, n_nodes, (num_envs,), device=device, generator=g)
         self.angle = torch.randint(0, 4, (num_envs,), device=device, generator=g)
         self.t = 0  # all envs step in lockstep: host-side counter, no sync
+        self._consts = None
         self.pool = P
         # eval-only sensor (config/default.py: MIXED_BIN_AUDIO_PHASE_SENSOR is added by the eval configs): phases of the mixture
         self.include_phase = False
@@ -54,18 +55,17 @@ class SyntheticVecEnv:
                                  * 3.14159265).contiguous()
 
     def _obs(self):
+        names = ["rgb", "depth", "mixed_bin_audio_mag", "gt_bin_comps", "gt_mono_comps", "target_class"]
+        pools = [(self.frames_rgb, 0), (self.frames_depth, 0), (self.pool_mixed, 1), (self.pool_gt_bin, 1), (self.pool_gt_mono, 1),
+                 (self.pool_class, 1)]
+        if self.include_phase:
+            names.insert(0, "mixed_bin_audio_phase")
+            pools.insert(0, (self.pool_mixed_phase, 1))
+        if self.node.is_cuda:   # one launch for the whole lookup (m2h_synth_env_observe)
+            from .. import ops
+            return dict(zip(names, ops.synth_env_observe(pools, self.node, self.angle, self.audio_idx)))
         f = self.node * 4 + self.angle
-        a = self.audio_idx
-        extra = {"mixed_bin_audio_phase": self.pool_mixed_phase.index_select(0, a)} if self.include_phase else {}
-        return {
-            **extra,
-            "rgb": self.frames_rgb.index_select(0, f),
-            "depth": self.frames_depth.index_select(0, f),
-            "mixed_bin_audio_mag": self.pool_mixed.index_select(0, a),
-            "gt_bin_comps": self.pool_gt_bin.index_select(0, a),
-            "gt_mono_comps": self.pool_gt_mono.index_select(0, a),
-            "target_class": self.pool_class.index_select(0, a),
-        }
+        return {n: p.index_select(0, f if kind == 0 else self.audio_idx) for n, (p, kind) in zip(names, pools)}
 
     def reset(self):
         self.t = 0
@@ -83,19 +83,25 @@ class SyntheticVecEnv:
         tensors are updated in place and nothing host-side changes, so the trainer can capture this in a HIP graph
         (ppo_trainer.py); ``step`` = step_device + the host-side episode counter."""
         a = actions.reshape(-1)
-        fwd = (a == 0).long()
+        fwd = (a == 0).long() if not self.node.is_cuda else None
         if done:  # auto-reset: a new mixture and pose for every env
             self.audio_idx.copy_(torch.randint(0, self.pool, (self.num_envs,), device=self.device, generator=self._g))
             self.node.copy_(torch.randint(0, self.n_nodes, (self.num_envs,), device=self.device, generator=self._g))
             self.angle.copy_(torch.randint(0, 4, (self.num_envs,), device=self.device, generator=self._g))
+        elif self.node.is_cuda:
+            from .. import ops
+            ops.synth_env_step(a.contiguous(), self.node, self.angle, self.n_nodes)
         else:
             self.node.copy_((self.node + fwd) % self.n_nodes)
             self.angle.copy_((self.angle + (a == 1).long() + 3 * (a == 2).long()) % 4)
-        masks = torch.full((self.num_envs, 1), 0.0 if done else 1.0, device=self.device)
-        rewards = torch.zeros(self.num_envs, 1, device=self.device)  # nav reward (weight 0 in nearTarget.yaml:48-49)
-        infos = {"normalized_geo_distance_to_target_audio_source": torch.zeros(self.num_envs, 1, device=self.device),
-                 "geo_distance_to_target_audio_source": torch.zeros(self.num_envs, 1, device=self.device)}
-        return self._obs(), rewards, masks, infos
+        # constants (read-only for the caller): not-done flags, the zero navigation reward (weight 0 in nearTarget.yaml:48-49)
+        # and the two distance infos
+        c = self._consts
+        if c is None:
+            z = torch.zeros(self.num_envs, 1, device=self.device)
+            c = self._consts = {"zero": z, "one": torch.ones(self.num_envs, 1, device=self.device),
+                                "infos": {"normalized_geo_distance_to_target_audio_source": z, "geo_distance_to_target_audio_source": z}}
+        return self._obs(), c["zero"], (c["zero"] if done else c["one"]), c["infos"]
 
     @property
     def generator(self):

@@ -607,6 +607,44 @@ def rows_copy(items, idx):
             _lib.check(lib.m2h_rows_copy((_lib.RowCopy * len(chunk))(*chunk), len(chunk), _ptr(idx), _stream(idx)), "m2h_rows_copy")
 
 
+def step_index_advance(idx, t_pol, t_sep):
+    """(pol_step, pol_step + 1, sep_step + 1) -> the next step's, on the device (m2h_step_index_advance)."""
+    if idx.dtype != torch.int64 or not idx.is_cuda or idx.numel() != 3 or not idx.is_contiguous():
+        raise RuntimeError("m2h.step_index_advance: idx must be a contiguous int64 device tensor of 3 elements")
+    with torch.cuda.device(idx.device):
+        _lib.check(_lib.load().m2h_step_index_advance(_ptr(idx), int(t_pol), int(t_sep), _stream(idx)), "m2h_step_index_advance")
+
+
+def synth_env_step(actions, node, angle, n_nodes):
+    """In-place pose update of the synthetic env (m2h_synth_env_step).  actions / node / angle: int64 [N] device tensors."""
+    for t in (actions, node, angle):
+        _chk(t, "synth_env_step", torch.int64)
+    N = node.numel()
+    if actions.numel() != N or angle.numel() != N:
+        raise RuntimeError("m2h.synth_env_step: one action, node and angle per env")
+    with torch.cuda.device(node.device):
+        _lib.check(_lib.load().m2h_synth_env_step(_ptr(actions), _ptr(node), _ptr(angle), int(n_nodes), N, _stream(node)), "m2h_synth_env_step")
+
+
+def synth_env_observe(pools, node, angle, audio_idx):
+    """The synthetic env's observation lookup in one launch (m2h_synth_env_observe).  pools: list of (tensor [P, ...], kind) with
+    kind 0 = frames indexed by node * 4 + angle, 1 = audio pool indexed by audio_idx.  -> list of gathered [N, ...] tensors."""
+    for t in (node, angle, audio_idx):
+        _chk(t, "synth_env_observe", torch.int64)
+    N = node.numel()
+    outs, arr = [], []
+    for src, kind in pools:
+        if not src.is_cuda or not src.is_contiguous():
+            raise RuntimeError("m2h.synth_env_observe: pools must be contiguous device tensors")
+        dst = torch.empty((N,) + tuple(src.shape[1:]), device=src.device, dtype=src.dtype)
+        outs.append(dst)
+        arr.append(_lib.RowCopy(src.data_ptr(), dst.data_ptr(), src[0].numel() * src.element_size(), int(kind), -1))
+    with torch.cuda.device(node.device):
+        _lib.check(_lib.load().m2h_synth_env_observe((_lib.RowCopy * len(arr))(*arr), len(arr), _ptr(node), _ptr(angle), _ptr(audio_idx), N,
+                                                     _stream(node)), "m2h_synth_env_observe")
+    return outs
+
+
 def take_envs(src, perm, identity=False):
     """gather_envs, or -- when the caller knows the selection is ALL environments in storage order -- the same rows as a
     zero-copy view [T*N, ...] of the storage."""

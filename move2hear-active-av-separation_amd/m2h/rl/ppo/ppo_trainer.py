@@ -248,12 +248,7 @@ class PPOTrainer:
                 nxt = self._rollout_step_device(gs.cache, gs.idx, extra, done)
                 for dst, src in zip(gs.cache, nxt):
                     dst.copy_(src)
-                # advance the device-side step indices: ro_step <- (ro_step + 1) % T, rs_step likewise
-                nro = (gs.idx[0:1] + 1) % ro.num_steps
-                nrs = gs.idx[2:3] % rs.num_steps  # idx[2] holds rs_step + 1
-                gs.idx[0:1].copy_(nro)
-                gs.idx[1:2].copy_(nro + 1)
-                gs.idx[2:3].copy_(nrs + 1)
+                ops.step_index_advance(gs.idx, ro.num_steps, rs.num_steps)  # ro_step <- (ro_step + 1) % T, rs_step likewise
             if gs.pool is None:
                 gs.pool = g.pool()
             gs.graphs[key] = g
