@@ -32,7 +32,7 @@ int m2h_debug_set(int knob, int value) {
   else if (knob == 2) g_wide_stages = value;
   else if (knob == 3) g_skinny = value;
   else if (knob == 4) g_narrow16 = value;
-  else if (knob == 5 || knob == 6 || knob == 10 || knob == 12 || knob == 13 || knob == 17) {}  // retired experiments (block stagger, ping-pong wave groups, 256-row narrow tiles, direct-operand narrow kernel, prefetch distance 4 on skinny tiles, 128x256 / 256x128 one-block-per-CU tiles in bf16x3 math): measured no gain
+  else if (knob == 5 || knob == 6 || knob == 10 || knob == 12 || knob == 13 || knob == 17 || knob == 19 || knob == 20) {}  // retired experiments (block stagger, ping-pong wave groups, 256-row narrow tiles, direct-operand narrow kernel, prefetch distance 4 on skinny tiles, 128x256 / 256x128 one-block-per-CU tiles in bf16x3 math, no split-K under a k-tile count, in-launch split-K reduction by the last-arriving block): measured no gain
   else if (knob == 7) g_extra_lds = value;
   else if (knob == 8) g_phase_major = value;
   else if (knob == 9) g_fast_loader = value;
