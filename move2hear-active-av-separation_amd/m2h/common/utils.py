@@ -20,7 +20,16 @@ class CustomFixedCategorical:
         self._entropy = entropy
 
     def sample(self, sample_shape=torch.Size()):
-        return torch.multinomial(self.probs, 1, True)  # [M,1] int64, as Categorical.sample().unsqueeze(-1)
+        """[M,1] int64, the draw of ``Categorical.sample().unsqueeze(-1)`` == ``torch.multinomial(probs, 1, True)``.
+        For one sample per row torch.multinomial IS ``argmax(probs / Exp(1))`` with the exponential noise drawn from the tensor's
+        device generator (ATen multinomial_out: q = empty_like(probs).exponential_(1); q = probs / q; argmax(q, -1, keepdim)),
+        preceded by four validity checks of ``probs`` (eight tiny launches and two device asserts per call).  The same three
+        ops are issued here directly: same generator state in, same noise, same actions out
+        (tests/test_gpu_rl.py::test_sampling_is_torch_multinomial_bit_for_bit); the probabilities come from this build's own
+        softmax kernel, finite and normalised by construction."""
+        q = torch.empty_like(self.probs).exponential_(1)
+        torch.div(self.probs, q, out=q)
+        return torch.argmax(q, dim=-1, keepdim=True)
 
     def log_probs(self, actions):
         return ops.gather_logp(self._logp_all, actions.reshape(-1, 1).contiguous())

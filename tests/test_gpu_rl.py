@@ -268,3 +268,24 @@ def test_rows_copy_moves_rows_by_device_indices():
     assert torch.equal(small, exp_small)
     with pytest.raises(RuntimeError):
         ops.rows_copy([(v_small, big, -1, 0)], idx)
+
+
+def test_sampling_is_torch_multinomial_bit_for_bit():
+    """CustomFixedCategorical.sample (argmax(probs / Exp(1)) on the device generator) draws exactly torch.multinomial(probs, 1,
+    True) -- the reference's Categorical.sample (common/utils.py:16-24) -- for the same generator state, call after call, and
+    leaves the generator in the same state."""
+    from m2h.common.utils import CustomFixedCategorical
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    for M in (1, 14, 280):
+        probs = torch.softmax(torch.randn(M, 3, generator=g) * 2.0, dim=1).to(dev)
+        d = CustomFixedCategorical(torch.log(probs), probs, torch.zeros(M, device=dev))
+        torch.manual_seed(1234 + M)
+        ref = [torch.multinomial(probs, 1, True) for _ in range(5)]
+        ref_after = torch.rand(4, device=dev)
+        torch.manual_seed(1234 + M)
+        got = [d.sample() for _ in range(5)]
+        got_after = torch.rand(4, device=dev)
+        for a, b in zip(got, ref):
+            assert a.dtype == torch.int64 and a.shape == (M, 1) and torch.equal(a, b)
+        assert torch.equal(ref_after, got_after)
