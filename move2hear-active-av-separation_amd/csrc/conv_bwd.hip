@@ -10,6 +10,8 @@
 // chunks staged [m][n] / [m][k] in LDS (prefetched through registers); fragments are ds_read_b32 column reads
 // (consecutive lanes -> consecutive addresses, conflict free).  The pixel range is split over grid.z; partial tiles go to a
 // slab [split][N][Kpad] and an ordered reduce kernel sums them (deterministic, no atomics).
+#include <type_traits>
+
 #include "m2h_internal.h"
 
 namespace m2h {
@@ -267,6 +269,127 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
     }
 }
 
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution over 32-channel, 32-pixel-wide images (both AcousticMem convs,
+// rl/models/memory_nets.py:11-16, at 1.7 M pixels per update_sep epoch): the general kernel above gathers the nine taps of every
+// pixel separately (1.15 KB per pixel through L2 -> LDS, 4.4 TB/s at 441 us) and pads N = 16 to a 32-wide fragment.  Here a
+// reduction chunk is one IMAGE ROW: the three input rows it touches are staged once as a zero-padded 3 x 34-pixel patch (the
+// nine taps are row / column shifts of that patch: 400 B per pixel), each wave owns 8 of the row's 32 pixels and ALL nine
+// tap fragments of the output (no k padding: K = 288 exactly), and N <= 16 runs on v_mfma_f32_16x16x4_f32 (half the matrix
+// work).  The four waves' partial tiles meet through LDS in wave order; splits over rows go to the usual slab + ordered reduce.
+template <int FR>
+__global__ __launch_bounds__(256) void wgrad3x3_row_kernel(const WGradP p) {
+  constexpr int W = 32, C = 32, PW = W + 2;
+  constexpr int CS = FR == 32 ? 32 : 48;            // patch pixel stride (floats): conflict-free fragment reads for both shapes
+  constexpr int KH = 32 / FR;                       // channel halves per tap (16-wide fragments: 2)
+  constexpr int KF = 9 * KH;                        // accumulator fragments per wave
+  constexpr int MS = FR == 32 ? 2 : 4;              // pixels contracted per MFMA
+  constexpr int STEPS = 8 / MS;                     // a wave owns 8 pixels of the row
+  constexpr int NE = FR == 32 ? 16 : 4;
+  constexpr int NPL = (3 * PW * 8 + 255) / 256;     // 16-byte patch loads per thread (816 in all)
+  using AccT = typename std::conditional<FR == 32, f32x16, f32x4>::type;
+  __shared__ __attribute__((aligned(16))) float Ps[2][3 * PW * CS];
+  __shared__ __attribute__((aligned(16))) float Ys[2][W * FR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x;
+  const int c0 = (int)(((long)p.chunks * split) / p.S), c1 = (int)(((long)p.chunks * (split + 1)) / p.S);
+
+  f32x4 rp[NPL], ry;
+  unsigned okm = 0;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int yrow = tid / (FR / 4), yseg = tid % (FR / 4);      // dY: 32 rows x FR/4 segments (FR = 16: the first 128 threads)
+  auto load_chunk = [&](int c) {
+    const int b = c / p.Hq, q = c - b * p.Hq;
+    okm = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int i = tid + 256 * j;
+      const int l = i >> 3, seg = i & 7;
+      const int pr = l / PW, pc = l - pr * PW;
+      const int ih = q + pr - 1, iw = pc - 1;
+      const bool ok = i < 3 * PW * 8 && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)W;
+      const size_t off = ok ? ((size_t)(b * p.Hi + ih) * W + iw) * C + seg * 4 : (size_t)0;
+      rp[j] = *reinterpret_cast<const f32x4*>(p.src0 + off);
+      okm |= ok ? (1u << j) : 0u;
+    }
+    const bool yok = yrow < W && yseg * 4 < p.N;
+    ry = *reinterpret_cast<const f32x4*>(p.dy + (yok ? ((size_t)c * W + yrow) * p.ldy + yseg * 4 : (size_t)0));
+    okm |= yok ? (1u << 8) : 0u;
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int i = tid + 256 * j;
+      if (i < 3 * PW * 8) *reinterpret_cast<f32x4*>(&Ps[buf][(i >> 3) * CS + (i & 7) * 4]) = (okm & (1u << j)) ? rp[j] : zero4;
+    }
+    if (yrow < W) *reinterpret_cast<f32x4*>(&Ys[buf][yrow * FR + yseg * 4]) = (okm & (1u << 8)) ? ry : zero4;
+  };
+
+  AccT acc[KF];
+#pragma unroll
+  for (int f = 0; f < KF; ++f)
+#pragma unroll
+    for (int e = 0; e < NE; ++e) acc[f][e] = 0.f;
+  const int fi = lane & (FR - 1), fq = lane / FR;   // fragment row/column, pixel inside the MFMA's contraction
+  const int m0 = wave * 8;
+  auto compute = [&](int buf) {
+    float av[STEPS];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) av[st] = Ys[buf][(m0 + MS * st + fq) * FR + fi];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ty = t / 3, tx = t - 3 * ty;
+#pragma unroll
+      for (int h = 0; h < KH; ++h) {
+        float bv[STEPS];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) bv[st] = Ps[buf][(ty * PW + m0 + MS * st + fq + tx) * CS + h * FR + fi];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+          if constexpr (FR == 32)
+            acc[t * KH + h] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bv[st], acc[t * KH + h], 0, 0, 0);
+          else
+            acc[t * KH + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv[st], acc[t * KH + h], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  if (c0 < c1) {
+    load_chunk(c0);
+    store_chunk(0);
+    __syncthreads();
+    int cur = 0;
+    for (int c = c0; c + 1 < c1; ++c) {
+      load_chunk(c + 1);
+      compute(cur);
+      store_chunk(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+    compute(cur);
+  }
+  __syncthreads();   // the stages become the cross-wave scratch
+
+  // the four waves' partial tiles -> one tile, fragment by fragment: R[wave][n][k] in LDS, summed in wave order
+  float* R = &Ps[0][0];                               // 4 x FR x FR floats <= 16 KB
+  float* slab = p.ws + (size_t)split * p.N * p.Kpad;
+#pragma unroll
+  for (int f = 0; f < KF; ++f) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int n = FR == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : (lane >> 4) * 4 + e;
+      R[(wave * FR + n) * FR + fi] = acc[f][e];
+    }
+    __syncthreads();
+    for (int i = tid; i < FR * FR; i += 256) {
+      const int n = i / FR, kk = i - n * FR;
+      const float v = (R[i] + R[FR * FR + i]) + (R[2 * FR * FR + i] + R[3 * FR * FR + i]);
+      if (n < p.N) slab[(size_t)n * p.Kpad + (f / KH) * C + (f % KH) * FR + kk] = v;
+    }
+    __syncthreads();
+  }
+}
+
 // dw[n][k] = sum over splits, fixed order.  A block owns 64 consecutive k of one row n; its four waves each sum a quarter of
 // the splits (four loads in flight per lane), then the quarters are combined in wave order.  (One thread per element walking
 // all splits serially took 39 us for a 32 x 384 gradient with 512 splits: 36 blocks, one dependent load at a time.)
@@ -306,6 +429,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const WGradP p)
 }
 
 int g_wgrad_blocks = 0;  // tuning knob (m2h_debug_set 11): target block count of a weight-gradient launch
+int g_wgrad_row3x3 = 0;  // -1: never use the image-row 3x3 kernel (m2h_debug_set 21)
 
 // block shape for (N, K): n extent, k sub-tiles per block, blocks along k
 static void wgrad_cfg(int N, int K, int& bng, int& kt, int& ktiles) {
@@ -366,7 +490,16 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   const long nblk = (long)(p.S >= 8 ? (p.S + 7) / 8 * 8 : p.S) * p.ntiles * p.ktiles;
   M2H_REQUIRE(nblk < 0x7fffffffL, "conv_wgrad: grid too large");
   const dim3 grid((unsigned)nblk), blk(256);
-  if (bng == 128) hipLaunchKernelGGL((wgrad_kernel<128, 1, 2>), grid, blk, 0, st, p);
+  // 3x3 / stride 1 / pad 1 over 32-channel, 32-pixel-wide images (AcousticMem): one image row per reduction chunk
+  const bool row3x3 = g_wgrad_row3x3 >= 0 && a.nth == 3 && a.ntw == 3 && a.stride == 1 && a.mulh == 1 && a.mulw == 1 && a.offh == -1 &&
+                      a.offw == -1 && a.C0 == 32 && a.C1 == 0 && a.Wq == 32 && a.Wi == 32 && a.Hq == a.Hi && p.direct && a.N <= 32 &&
+                      a.N % 4 == 0 && ldy % 4 == 0 && p.ntiles * p.ktiles == 1;
+  if (row3x3) {
+    p.chunks = a.B * a.Hq;   // image rows
+    if (p.S > p.chunks) p.S = p.chunks;
+    if (a.N <= 16) hipLaunchKernelGGL((wgrad3x3_row_kernel<16>), dim3((unsigned)p.S), blk, 0, st, p);
+    else hipLaunchKernelGGL((wgrad3x3_row_kernel<32>), dim3((unsigned)p.S), blk, 0, st, p);
+  } else if (bng == 128) hipLaunchKernelGGL((wgrad_kernel<128, 1, 2>), grid, blk, 0, st, p);
   else if (kt == 1) hipLaunchKernelGGL((wgrad_kernel<32, 1, 2>), grid, blk, 0, st, p);
   else if (kt == 2) hipLaunchKernelGGL((wgrad_kernel<32, 2, 1>), grid, blk, 0, st, p);
   else hipLaunchKernelGGL((wgrad_kernel<32, 3, 1>), grid, blk, 0, st, p);

@@ -313,3 +313,28 @@ def test_update_sep_cache_follows_after_update_by_refreshing_row_zero(golden_dir
     for la, lb in zip(*out):
         for x, y in zip(la, lb):
             assert abs(x - y) < 1e-5 * max(1.0, abs(y)), (out[0], out[1])
+
+
+@pytest.mark.parametrize("N,B,H", [(32, 3, 32), (16, 3, 32), (16, 5, 8), (8, 2, 32)])
+def test_image_row_wgrad_kernel_matches_the_general_kernel_and_torch(N, B, H):
+    """The 3x3 / 32-channel / 32-wide weight-gradient kernel (one image row per reduction chunk, taps as shifts of one staged
+    patch, 16-wide MFMA for N <= 16) against the general gather kernel (knob 21 = -1) and torch autograd on the CPU."""
+    from m2h import functional as MF
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, H, 32, 32, generator=g)
+    dy = torch.randn(B, H, 32, N, generator=g)
+    w = torch.randn(N, 32, 3, 3, generator=g, requires_grad=True)
+    out = F.conv2d(x.permute(0, 3, 1, 2), w, None, 1, 1)
+    out.backward(dy.permute(0, 3, 1, 2))
+    ref = w.grad.permute(0, 2, 3, 1).reshape(N, 9 * 32)        # packed [n][(kh, kw, c)]
+    got = {}
+    for knob in (0, -1):
+        ops.debug_set(21, knob)
+        try:
+            got[knob] = MF.conv_wgrad(x.to(dev), None, dy.to(dev), N, 3, 3, 1, 1).cpu()
+        finally:
+            ops.debug_set(21, 0)
+    assert _rel(got[0], ref) < 2e-5 and _rel(got[-1], ref) < 2e-5
+    assert _rel(got[0], got[-1]) < 1e-5
