@@ -872,6 +872,126 @@ __global__ __launch_bounds__(256, 2) void convT_tap_kernel(const IGemmP p) {
   fused_epilogue<BM, BN, WM, WN, FR, AccT>(p, acc, As, Bs, ri_out, ri_bc, 0, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Image-row 3x3 convolution (fp32 MFMA): Conv2d(3x3, stride 1, pad 1) over 16- or 32-channel, 32-pixel-wide images with N <= 32
+// output channels -- AcousticMem's two convs (rl/models/memory_nets.py:11-16) and the input gradient of the second one, at the
+// 1.7 M pixels of an update_sep epoch.  The general engine fetches each pixel's nine taps separately (and its scalar loader
+// needs C % 32 == 0, so the 16-channel input gradient ran on the per-lane decode); here a block keeps the whole weight matrix
+// in LDS and walks chunks of FOUR image rows: the six input rows they touch are staged once as a zero-padded 6 x 34-pixel
+// patch, every tap is a row / column shift of it, each wave owns one image row (32 pixels) x all output channels, and N <= 16
+// runs on v_mfma_f32_16x16x4_f32.  Fragment reads are the 16-byte reads of the engine above (rows padded to C + 4 floats).
+// Tap t = (th, tw) reads the input at (q + offh + th*mulh, r + offw + tw*mulw): forward (mul 1, off -1) and input gradient
+// (mul -1, off 1) alike.  Epilogue: optional bias, ReLU / LeakyReLU, NHWC or de-sliced store.
+template <int FR, int C>
+__global__ __launch_bounds__(256, 2) void conv3x3_row_kernel(const IGemmP p) {
+  constexpr int W = 32, PW = W + 2, ROWS = 4, PR = ROWS + 2;
+  constexpr int CP = C + 4;                         // patch pixel stride (floats)
+  constexpr int K = 9 * C, KP = K + 4;              // weight row stride: an odd multiple of 4 floats mod 64, like CP (conflict-free 16-byte reads)
+  constexpr int GK = FR == 32 ? 8 : 16;             // k per fragment group (one 16-byte read per lane)
+  constexpr int NG = C / GK;                        // groups per tap
+  constexpr int FM = 32 / FR;                       // pixel fragments per wave (one image row)
+  constexpr int NE = FR == 32 ? 16 : 4;
+  constexpr int SEG = C / 4;                        // 16-byte segments per pixel
+  constexpr int NPL = (PR * PW * SEG + 255) / 256;  // patch loads per thread
+  using AccT = typename std::conditional<FR == 32, f32x16, f32x4>::type;
+  static_assert(NG >= 1 && (KP % 64) % 8 == 4 && (CP % 64) % 8 == 4, "tile shape");
+  __shared__ __attribute__((aligned(16))) float Wl[FR * KP];
+  __shared__ __attribute__((aligned(16))) float Pl[PR * PW * CP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & (FR - 1), fk = (lane / FR) * 4;
+  const int chunks = p.B * (p.Hq / ROWS);
+
+  // weights [N][K] -> LDS rows (rows past N: zeros), once per block
+  for (int i = tid; i < FR * (K / 4); i += 256) {
+    const int n = i / (K / 4), s4 = i - n * (K / 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.N) v = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * K + s4 * 4);
+    *reinterpret_cast<f32x4*>(&Wl[n * KP + s4 * 4]) = v;
+  }
+  int shift[9];                                     // patch offset of tap t relative to the output pixel's own patch position
+#pragma unroll
+  for (int t = 0; t < 9; ++t) shift[t] = (p.offh + (t / 3) * p.mulh) * PW + (p.offw + (t % 3) * p.mulw);
+
+  f32x4 rp[NPL];
+  unsigned okm = 0;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto load_chunk = [&](int c) {
+    const int b = c / (p.Hq / ROWS), q0 = (c - b * (p.Hq / ROWS)) * ROWS;
+    okm = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int i = tid + 256 * j;
+      const int l = i / SEG, seg = i - l * SEG;
+      const int pr = l / PW, pc = l - pr * PW;
+      const int ih = q0 + pr - 1, iw = pc - 1;
+      const bool ok = i < PR * PW * SEG && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)W;
+      const size_t off = ok ? ((size_t)(b * p.Hi + ih) * W + iw) * C + seg * 4 : (size_t)0;
+      rp[j] = *reinterpret_cast<const f32x4*>(p.src0 + off);
+      okm |= ok ? (1u << j) : 0u;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int i = tid + 256 * j;
+      if (i < PR * PW * SEG) *reinterpret_cast<f32x4*>(&Pl[(i / SEG) * CP + (i % SEG) * 4]) = (okm & (1u << j)) ? rp[j] : zero4;
+    }
+  };
+  const size_t plane = (size_t)p.Ho * p.Wo;
+  const int Cc = p.N >> 4;
+  for (int c = blockIdx.x; c < chunks; c += gridDim.x) {
+    if (c == (int)blockIdx.x) load_chunk(c);
+    __syncthreads();              // the previous chunk's fragment reads (and the weight stores) are done
+    store_chunk();
+    __syncthreads();
+    if (c + (int)gridDim.x < chunks) load_chunk(c + gridDim.x);   // next chunk's loads fly under this chunk's MFMAs
+    AccT acc[FM];
+#pragma unroll
+    for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+      for (int e = 0; e < NE; ++e) acc[mi][e] = 0.f;
+    const int prow0 = (wave + 1) * PW + 1;          // this wave's image row inside the patch, column 0
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const f32x4 bw = *reinterpret_cast<const f32x4*>(&Wl[frow * KP + t * C + g * GK + fk]);
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(&Pl[(prow0 + mi * FR + frow + shift[t]) * CP + g * GK + fk]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if constexpr (FR == 32)
+              acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bw[j], acc[mi], 0, 0, 0);
+            else
+              acc[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bw[j], acc[mi], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // epilogue: rows = pixels of image row (q0 + wave), columns = output channels
+    const int b = c / (p.Hq / ROWS), q = (c - b * (p.Hq / ROWS)) * ROWS + wave;
+    const int n = lane & (FR - 1);
+    const float sh = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
+    if (n < p.N) {
+#pragma unroll
+      for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int x = mi * FR + (FR == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : (lane >> 4) * 4 + e);
+          float v = acc[mi][e] + sh;
+          v = v > 0.f ? v : v * p.slope;
+          if (p.out_mode == M2H_OUT_NHWC) {
+            p.dst[((size_t)(b * p.Ho + q) * p.Wo + x) * p.ldc + n] = v;
+          } else {
+            const size_t out = (size_t)b * 16 * plane + (size_t)q * p.Wo + x;
+            p.dst[(out + (size_t)(n & 15) * plane) * Cc + (n >> 4)] = v;
+          }
+        }
+    }
+  }
+}
+
 // Split-K epilogue: sums the S partial slabs of one output element in a fixed order (deterministic) and applies the
 // same fused epilogue as the main kernel.  One thread = one GEMM row x 4 consecutive channels.
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IGemmP p) {
@@ -933,6 +1053,7 @@ int g_tapshare = 0;       // -1: never use the tap-sharing transposed-conv kerne
 int g_tap_bm = 0;         // 128: 128-output tiles only in the tap-sharing kernel
 int g_fast_loader = 0;    // -1: always use the generic (per-lane k decode) loader
 int g_narrow16 = 0;       // -1: never use the 16-wide (v_mfma_f32_16x16x4_f32) tile for N <= 16
+int g_row3x3 = 0;         // -1: never use the image-row 3x3 kernel
 int g_tap_window = 0;     // -1: walk every tap even where a whole kernel row / column lies in the zero padding
 
 // Tap window (see IGemmP): the contiguous range of kernel rows / columns that reach inside the image for at least one output
@@ -1160,6 +1281,20 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
 #undef M2H_TAP
       return launch_status("conv_igemm_f32 (tap-sharing convT)");
     }
+  }
+  // 3x3 / stride 1 / pad 1 over 16- or 32-channel, 32-pixel-wide images in fp32 math, many rows (AcousticMem in update_sep)
+  if (g_math_mode == 0 && g_row3x3 >= 0 && !p.convT && a.nth == 3 && a.ntw == 3 && a.stride == 1 && a.os == 1 && a.ph == 0 && a.pw == 0 &&
+      (a.mulh == 1 || a.mulh == -1) && a.offh == -a.mulh && a.mulw == a.mulh && a.offw == a.offh && a.C1 == 0 && (a.C0 == 16 || a.C0 == 32) &&
+      a.Wq == 32 && a.Wi == 32 && a.Hq == a.Hi && a.Ho == a.Hq && a.Wo == a.Wq && a.Hq % 4 == 0 && a.N <= 32 && a.N % 4 == 0 &&
+      a.scale == nullptr && a.cls_table == nullptr && a.head_w == nullptr && a.operand_format == 0 && (long)a.B * (a.Hq / 4) >= 512 &&
+      (a.out_mode == M2H_OUT_NHWC || a.N % 16 == 0)) {
+    const long chunks = (long)a.B * (a.Hq / 4);
+    const dim3 grid((unsigned)(chunks < 512 ? chunks : 512)), blk(256);
+    if (a.N <= 16 && a.C0 == 32) hipLaunchKernelGGL((conv3x3_row_kernel<16, 32>), grid, blk, 0, st, p);
+    else if (a.N <= 16) hipLaunchKernelGGL((conv3x3_row_kernel<16, 16>), grid, blk, 0, st, p);
+    else if (a.C0 == 32) hipLaunchKernelGGL((conv3x3_row_kernel<32, 32>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((conv3x3_row_kernel<32, 16>), grid, blk, 0, st, p);
+    return launch_status("conv_igemm_f32 (image-row 3x3)");
   }
   int BM, BN;
   pick_tile(M, p.N, BM, BN);

@@ -338,3 +338,42 @@ def test_image_row_wgrad_kernel_matches_the_general_kernel_and_torch(N, B, H):
             ops.debug_set(21, 0)
     assert _rel(got[0], ref) < 2e-5 and _rel(got[-1], ref) < 2e-5
     assert _rel(got[0], got[-1]) < 1e-5
+
+
+@pytest.mark.parametrize("N,C,B,deslice,grad", [(32, 32, 20, False, False), (16, 32, 20, True, False), (32, 16, 20, False, True), (16, 16, 17, False, False),
+                                                (8, 32, 16, False, False)])
+def test_image_row_conv3x3_kernel_matches_the_engine_and_torch(N, C, B, deslice, grad):
+    """The 3x3 / stride 1 image-row kernel (whole weight matrix in LDS, four image rows per chunk staged as one padded patch)
+    against the general engine (knob 22 = -1) and torch on the CPU: forward with ReLU, de-sliced store, and the input gradient
+    (taps walked backwards, 16 input channels)."""
+    from m2h import functional as MF
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(23)
+    H = 32
+    if grad:   # input gradient of Conv2d(N -> C): dy [B,H,W,C] -> dx [B,H,W,N]
+        w = torch.randn(C, N, 3, 3, generator=g) * 0.1
+        dy = torch.randn(B, H, 32, C, generator=g)
+        ref = F.conv_transpose2d(dy.permute(0, 3, 1, 2), w, None, 1, 1).permute(0, 2, 3, 1)
+        run = lambda: MF.conv_dgrad(dy.to(dev), w.to(dev), (H, 32), 1, 1)   # noqa: E731
+    else:
+        x = torch.randn(B, H, 32, C, generator=g)
+        w = torch.randn(N, C, 3, 3, generator=g) * 0.1
+        slope = 1.0 if deslice else 0.0
+        y = F.conv2d(x.permute(0, 3, 1, 2), w, None, 1, 1)
+        y = y if deslice else torch.relu(y)
+        if deslice:   # memory_nets.py:62-67: channel c*16+s, row h -> frequency row s*H + h, channel c
+            ref = y.view(B, N // 16, 16, H, 32).permute(0, 2, 3, 4, 1).reshape(B, 16 * H, 32, N // 16)
+        else:
+            ref = y.permute(0, 2, 3, 1)
+        wp = ops.pack_conv_weight_ex(w.to(dev).contiguous(), C, C)
+        run = lambda: ops.conv2d_nhwc(x.to(dev), wp, N, 3, 3, stride=1, pad=1, slope=slope, deslice=deslice)   # noqa: E731
+    got = {}
+    for knob in (0, -1):
+        ops.debug_set(22, knob)
+        try:
+            got[knob] = run().cpu()
+        finally:
+            ops.debug_set(22, 0)
+    assert got[0].shape == ref.shape
+    assert _rel(got[0], ref) < 2e-5 and _rel(got[-1], ref) < 2e-5 and _rel(got[0], got[-1]) < 1e-5
