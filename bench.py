@@ -427,7 +427,7 @@ def main():
         return
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # the host-core baseline is a single-GPU-run figure (rank 0, N = 1)
         cpu = cpu_baseline(sd, args.tm, args.cpu_seconds)
 
     value = world * args.batch * args.steps / elapsed

@@ -63,3 +63,62 @@ def test_cycle_with_rccl_group_side_stream_allreduce_and_graphs():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT, "port": port}], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+TWO_RANK = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "move2hear-active-av-separation_amd"))
+import numpy as np, torch, torch.distributed as dist
+from m2h import synthetic
+from m2h.rl.ppo import ddppo_utils as D
+from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config
+rank = int(sys.argv[1])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(%(port)d), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0")
+dev = torch.device("cuda", 0)            # both ranks share the box's one GPU; the collectives run over gloo
+torch.cuda.set_device(dev)
+dist.init_process_group("gloo", rank=rank, world_size=2)
+cfg = near_target_config(NUM_PROCESSES=3, num_steps=4, num_updates_per_cycle=2, ppo_epoch=2, MAX_EPISODE_STEPS=4)
+tr = PPOTrainer(cfg, dev, world_rank=rank, world_size=2)
+tr.setup()
+assert tr.agent._world == 2 and tr.agent._overlap()
+# different initial weights per rank: init_distributed must have replaced rank 1's by rank 0's
+w0 = {k: v.detach().cpu().clone() for k, v in tr.actor_critic.state_dict().items()}
+for c in range(3):
+    torch.manual_seed(100 * rank + c)     # different action samples per rank: only the averaged gradients keep the replicas equal
+    res = tr.train_cycle()
+stats = tr.all_reduce_stats()
+sd = {k: v.detach().cpu() for k, v in tr.actor_critic.state_dict().items()}
+flat = torch.cat([v.reshape(-1).double() for k, v in sorted(sd.items()) if v.dtype == torch.float32])
+init = torch.cat([v.reshape(-1).double() for k, v in sorted(w0.items()) if v.dtype == torch.float32])
+mine = torch.stack([flat.sum(), flat.abs().sum(), (flat * torch.arange(flat.numel(), dtype=torch.float64) %% 7).sum(), init.sum()])
+both = [torch.zeros_like(mine) for _ in range(2)]
+dist.all_gather(both, mine)
+assert torch.equal(both[0], both[1]), (both[0], both[1])                     # identical replicas after three cycles, identical start
+assert float((flat - init).abs().sum()) > 0                                  # and they did train
+obs_seed = tr.rollouts_pol.observations["rgb"].double().sum().cpu()
+seeds = [torch.zeros_like(obs_seed) for _ in range(2)]
+dist.all_gather(seeds, obs_seed)
+assert not torch.equal(seeds[0], seeds[1])                                   # each rank rolled out its own environments (seed + 3*rank)
+assert tr.agent._reducers["pol"].deferred_steps == 6 and tr._graph_state is not None and tr.agent._pol_graph.graph is not None
+assert float(stats[1]) == 2 * 3 * 3 * 2                                      # finished episodes summed over both ranks (3 cycles x 2 x 3 envs x 2 ranks)
+dist.barrier()
+dist.destroy_process_group()
+print("RANK_OK", rank)
+'''
+
+
+def test_two_ranks_train_identical_replicas_with_graphs_and_overlap():
+    """Two DD-PPO ranks (sharing the one GPU, collectives over gloo): rank-0 parameter broadcast, flat-gradient all-reduce with
+    the deferred side-stream step, distributed advantage statistics, HIP-graph rollouts / update epochs -- the replicas must
+    stay bit-identical while each rank samples its own actions in its own environments."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", TWO_RANK % {"root": ROOT, "port": port}, str(r)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("RANK_OK %d" % r) in o, o[-4000:]
