@@ -221,13 +221,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the m2h ops have no CPU path")
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (tests / one-GPU boxes only): M2H_BENCH_DEVICE pins every rank to one card, M2H_BENCH_BACKEND=gloo replaces
+    # RCCL (two ranks cannot share a GPU under RCCL); the driver's runs use neither
+    dev = torch.device("cuda", int(os.environ.get("M2H_BENCH_DEVICE", local_rank)))
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("M2H_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
 
     from m2h import ops
     pol, sd = make_policy(dev)
