@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--feeder-steps", type=int, default=10, help="timed batches of the GPU audio feeder leg (0 = skip)")
+    ap.add_argument("--feeder-batch", type=int, default=64)
     ap.add_argument("--no-far-target", action="store_true", help="skip the far-target / mixed-precision DD-PPO leg")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the pair kernel by kernel instead of replaying a HIP graph")
     ap.add_argument("--ddppo-cycles", type=int, default=2, help="timed DD-PPO cycles (0 = skip); one untimed warm-up cycle precedes them")
@@ -186,6 +188,47 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False):
         out["math"] = "bf16x3 products (fp32 tensors and accumulation) in every forward / input-gradient GEMM; weight gradients, reductions, Adam in fp32"
         out["mixed_precision_parity"] = mixed
     return out
+
+
+def run_feeder(args, dev, rank, with_cpu):
+    """Row N1 of SURVEY 8f: the waveform -> spectrogram feeder (RIR convolution, int16 round trip, mixing, three STFTs, RMS
+    normalisation; pretrain/datasets/dataset.py:162-228) on the GPU, batch = pretrain_passive.yaml's 64 clips of 1 s with two
+    sources each, synthetic audio of SURVEY 8d; beside it the numpy / scipy restatement of the same function on one host core
+    (the reference runs it on 60 loader workers)."""
+    from m2h.audio.feeder import BinauralFeeder
+    B, S, L, Lr = args.feeder_batch, 2, 16000, 16000
+    g = torch.Generator(device=dev).manual_seed(11 + rank)
+    mono = torch.clamp(torch.round(3000 * torch.randn(B, S, L, device=dev, generator=g)), -32768, 32767)
+    t = torch.arange(Lr, device=dev) / 16000.0
+    rir = torch.randn(B, S, Lr, 2, device=dev, generator=g) * torch.exp(-t / 0.05)[None, None, :, None]
+    rir = rir / rir.abs().amax(dim=(2, 3), keepdim=True) * 0.05
+    fd = BinauralFeeder(dev, gt_mono_mag_norm=1.2)
+    for _ in range(2):
+        fd.compute_audiospects(mono, rir)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.feeder_steps):
+        out = fd.compute_audiospects(mono, rir)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    res = {"metric": "feeder_clips_per_sec", "value": round(B * args.feeder_steps / el, 1), "unit": "1-s binaural clips/s", "batch": B,
+           "ms_per_batch": round(1e3 * el / args.feeder_steps, 3), "sources_per_clip": S, "out": [list(o.shape) for o in out],
+           "what": "BinauralFeeder.compute_audiospects: fftconvolve-same (rocFFT) of 2 sources x 2 ears, round -> int16 -> /32768, source mean, "
+                   "STFT(1023, 512) x 3 with |.|, log1p on the mixture, RMS-normalised GT mono magnitude"}
+    if with_cpu:   # (the oracle is imported by this cpu_baseline leg only)
+        if os.path.join(ROOT, "oracle") not in sys.path:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import m2h_oracle as O
+        mono_h, rir_h = mono[:4].cpu().numpy(), rir[:4].cpu().numpy()
+        torch.set_num_threads(1)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 3.0:
+            O.np_compute_audiospects(mono_h[n % 4], rir_h[n % 4], 1.2)
+            n += 1
+        res["cpu_baseline"] = {"value": round(n / (time.perf_counter() - t0), 1), "unit": "1-s binaural clips/s", "cores": 1, "kind": "port",
+                               "sample": "%d clips through oracle.np_compute_audiospects (numpy / scipy restatement), one thread" % n}
+    return res
 
 
 def run_passive_train(args, dev, rank):
@@ -423,6 +466,7 @@ def main():
     ddppo = run_ddppo(args, dev, rank, world, dist) if args.ddppo_cycles > 0 else None
     ddppo_far = run_ddppo(args, dev, rank, world, dist, far_target=True) if (args.ddppo_cycles > 0 and not args.no_far_target) else None
     ptrain = run_passive_train(args, dev, rank) if args.train_steps > 0 else None
+    feeder = run_feeder(args, dev, rank, with_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline)) if args.feeder_steps > 0 else None
 
     if rank != 0:
         if dist is not None:
@@ -455,6 +499,7 @@ def main():
         "ddppo": ddppo,
         "ddppo_far_target": ddppo_far,
         "passive_train": ptrain,
+        "feeder": feeder,
         "cpu_baseline": cpu,
         "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
         "layers": layers,
