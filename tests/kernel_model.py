@@ -205,3 +205,81 @@ def convT_tap_phase(x, wp_phase, ph, pw, bm=128):
                         acc += wt[:, th, tw, :] @ img[qi * W1 + r + tapoff]
                 out[b, q0 + qi, r] = acc
     return out
+
+
+def tap_range(ntaps, Q, stride, off, mul, extent):
+    """Mirror of tap_range() in csrc/conv_igemm.hip: first tap and count of the contiguous run of kernel rows (columns) that reach
+    inside the image for at least one of the Q output rows (columns)."""
+    valid = [t for t in range(ntaps) if any(0 <= q * stride + off + t * mul < extent for q in range(Q))]
+    if not valid:
+        return 0, ntaps
+    return valid[0], valid[-1] - valid[0] + 1
+
+
+def conv_with_tap_window(x, wp, N, stride, nth, ntw, off, Hq, Wq):
+    """Forward conv (mul 1) walking only the tap window, as the scalar-decode loader does: the skipped taps must be exact zeros.
+    x NHWC [B,Hi,Wi,C], wp [N][nth*ntw*C]."""
+    B, Hi, Wi, C = x.shape
+    th0, thn = tap_range(nth, Hq, stride, off, 1, Hi)
+    tw0, twn = tap_range(ntw, Wq, stride, off, 1, Wi)
+    out = np.zeros((B, Hq, Wq, N), np.float64)
+    for th in range(th0, th0 + thn):
+        for tw in range(tw0, tw0 + twn):
+            wk = wp[:, (th * ntw + tw) * C:(th * ntw + tw + 1) * C].astype(np.float64)
+            for q in range(Hq):
+                ih = q * stride + off + th
+                if not 0 <= ih < Hi:
+                    continue
+                for r in range(Wq):
+                    iw = r * stride + off + tw
+                    if 0 <= iw < Wi:
+                        out[:, q, r, :] += x[:, ih, iw, :].astype(np.float64) @ wk.T
+    return out, (th0, thn, tw0, twn)
+
+
+def conv3x3_row(x, wp, N, mul):
+    """Mirror of conv3x3_row_kernel's indexing (csrc/conv_igemm.hip): chunks of four image rows staged as a zero-padded 6 x 34
+    patch; tap t = (th, tw) reads the patch at the output pixel's own position shifted by (off + th*mul, off + tw*mul),
+    off = -mul (forward: mul 1; input gradient: mul -1).  x NHWC [B,H,32,C], wp [N][9*C]."""
+    B, H, W, C = x.shape
+    assert W == 32 and H % 4 == 0
+    PW = W + 2
+    off = -mul
+    out = np.zeros((B, H, W, N), np.float64)
+    for b in range(B):
+        for q0 in range(0, H, 4):
+            patch = np.zeros((6 * PW, C), np.float64)
+            for pr in range(6):
+                ih = q0 + pr - 1
+                if 0 <= ih < H:
+                    patch[pr * PW + 1:pr * PW + 1 + W] = x[b, ih]
+            for wave in range(4):
+                prow0 = (wave + 1) * PW + 1
+                for t in range(9):
+                    shift = (off + (t // 3) * mul) * PW + (off + (t % 3) * mul)
+                    a = patch[prow0 + shift:prow0 + shift + W]                      # [32 pixels][C]
+                    out[b, q0 + wave] += a @ wp[:, t * C:(t + 1) * C].astype(np.float64).T
+    return out
+
+
+def wgrad3x3_row(x, dy):
+    """Mirror of wgrad3x3_row_kernel's indexing (csrc/conv_bwd.hip): one image row per chunk staged as a zero-padded 3 x 34 patch,
+    each of the four waves takes 8 pixels, tap (ty, tx) reads patch row ty at column pixel + tx; -> dW packed [N][9*C]."""
+    B, H, W, C = x.shape
+    N = dy.shape[3]
+    assert W == 32
+    PW = W + 2
+    dw = np.zeros((N, 9 * C), np.float64)
+    for b in range(B):
+        for q in range(H):
+            patch = np.zeros((3 * PW, C), np.float64)
+            for pr in range(3):
+                ih = q + pr - 1
+                if 0 <= ih < H:
+                    patch[pr * PW + 1:pr * PW + 1 + W] = x[b, ih]
+            for wave in range(4):
+                m = np.arange(wave * 8, wave * 8 + 8)
+                for t in range(9):
+                    ty, tx = t // 3, t % 3
+                    dw[:, t * C:(t + 1) * C] += dy[b, q, m].astype(np.float64).T @ patch[ty * PW + m + tx]
+    return dw

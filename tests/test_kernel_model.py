@@ -72,3 +72,38 @@ def test_tap_sharing_kernel_indexing_matches_conv_transpose():
             ph, pw = phase >> 1, phase & 1
             got = KM.convT_tap_phase(xn, wp[phase], ph, pw, bm)
             assert np.allclose(got, ref[:, ph::2, pw::2, :], atol=1e-5), (B, H, W, bm, phase)
+
+
+def test_tap_window_and_image_row_indexing_match_torch():
+    """CPU: the host-side tap window (rows / columns of the kernel that lie in the padding for every output pixel) and the patch
+    indexing of the image-row 3x3 kernels, restated in numpy, against torch convolutions."""
+    import torch
+    import torch.nn.functional as F
+    g = np.random.default_rng(2)
+    # tap window: deepest encoder stage shapes (2-row input -> 1 output row) and a shape where nothing can be skipped
+    assert KM.tap_range(4, 1, 2, -1, 1, 2) == (1, 2) and KM.tap_range(4, 2, 2, -1, 1, 4) == (0, 4)
+    assert KM.tap_range(2, 1, 1, 0, -1, 1) == (0, 1) and KM.tap_range(2, 1, 1, 0, 1, 1) == (0, 1)      # transposed conv over a 1-row image
+    for (B, Hi, Wi, C, N) in ((2, 2, 2, 8, 5), (2, 2, 16, 8, 5), (1, 4, 4, 8, 5)):
+        x = g.standard_normal((B, Hi, Wi, C)).astype(np.float32)
+        w = (g.standard_normal((N, C, 4, 4)) * 0.1).astype(np.float32)
+        ref = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w), None, 2, 1).permute(0, 2, 3, 1).numpy()
+        got, win = KM.conv_with_tap_window(x, KM.pack_conv_weight(w), N, 2, 4, 4, -1, Hi // 2, Wi // 2)
+        assert np.abs(got - ref).max() < 1e-4, (B, Hi, Wi)
+        assert win[1] == (2 if Hi == 2 else 4) and win[3] == (2 if Wi == 2 else 4)
+    # image-row kernels: forward (mul 1), input gradient (mul -1, taps walked backwards), weight gradient
+    B, H, C, N = 2, 8, 16, 8
+    x = g.standard_normal((B, H, 32, C)).astype(np.float32)
+    w = (g.standard_normal((N, C, 3, 3)) * 0.1).astype(np.float32)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).requires_grad_(True)
+    wt = torch.from_numpy(w).requires_grad_(True)
+    y = F.conv2d(xt, wt, None, 1, 1)
+    fwd = KM.conv3x3_row(x, KM.pack_conv_weight(w), N, 1)
+    assert np.abs(fwd - y.detach().permute(0, 2, 3, 1).numpy()).max() < 1e-4
+    dy = g.standard_normal((B, H, 32, N)).astype(np.float32)
+    y.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    # input gradient = conv of dy with the (ci <-> co)-transposed weights, taps th -> offset 1 - th (m2h_pack_dgrad_weight order)
+    wd = np.ascontiguousarray(w.transpose(1, 2, 3, 0)).reshape(C, 9 * N)       # [ci][(th, tw, co)]
+    dx = KM.conv3x3_row(dy, wd, C, -1)
+    assert np.abs(dx - xt.grad.permute(0, 2, 3, 1).numpy()).max() < 1e-4
+    dw = KM.wgrad3x3_row(x, dy)
+    assert np.abs(dw - wt.grad.permute(0, 2, 3, 1).reshape(N, 9 * C).numpy()).max() < 2e-3
