@@ -190,7 +190,7 @@ int m2h_gru_gates(const float* gi, const float* gh_raw, const float* bhh, const 
 
 /* One whole GRU time step for M <= 16 rows (rnn_state_encoder.py:74-84 single_forward, and each step of seq_forward :86-137 at
  * the rollout width): gh_raw = hprev W_hh^T ([M][3H], written because the backward pass reads it) and the gate math of
- * m2h_gru_gates in one launch.  whh: [3H][H] (torch weight_hh_l0).  H % 4 == 0, H <= 512. */
+ * m2h_gru_gates in one launch.  whh: [3H][H] (torch weight_hh_l0).  H % 16 == 0. */
 int m2h_gru_step(const float* gi, const float* whh, const float* bhh, const float* hprev, const float* mask, float* gh_raw, float* hout,
                  int M, int H, m2h_stream stream);
 
@@ -330,7 +330,7 @@ int m2h_gru_gates_bwd(const float* gi, const float* gh_raw, const float* bhh, co
 int m2h_gru_bwd_combine(const float* a, const float* b, const float* c, const float* mask, float* out, int M, int H, m2h_stream stream);
 /* The recurrent half of one GRU backward step for M <= 16 rows in one launch: out = a + mask_row*(dpre W_hh + dhp), i.e. the
  * [M,3H]x[3H,H] product and m2h_gru_bwd_combine (torch autograd of rnn_state_encoder.py:86-137 at the rollout width).
- * whh_t: W_hh^T as [H][3H] (m2h_pack_dgrad_weight of weight_hh_l0); a may be NULL.  H % 16 == 0, H <= 512. */
+ * whh_t: W_hh^T as [H][3H] (m2h_pack_dgrad_weight of weight_hh_l0); a may be NULL.  H % 16 == 0. */
 int m2h_gru_bwd_rec(const float* dpre, const float* whh_t, const float* a, const float* dhp, const float* mask, float* out, int M, int H,
                     m2h_stream stream);
 

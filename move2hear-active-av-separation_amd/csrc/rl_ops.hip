@@ -114,92 +114,67 @@ __global__ __launch_bounds__(256) void gru_gates_kernel(const float* __restrict_
   }
 }
 
+typedef float f32x4_r __attribute__((ext_vector_type(4)));
+
+// Skinny dot products on the matrix pipe: D[m][r] = sum_k X[m][k] * Wr[k] for 16 rows m of X and 16 weight rows r, both operands
+// straight from global memory into v_mfma_f32_16x16x4_f32 registers (lane (row i, k-quarter kq) loads 16 bytes of its row = four
+// consecutive MFMAs' worth; no LDS staging, no barrier in the k-loop).  The block's four waves split the K/16 steps; the caller
+// sums their partial tiles through LDS.  Returns acc[e] = D[m = kq*4 + e][r = i] over this wave's steps.
+__device__ __forceinline__ f32x4_r skinny_dot16(const float* __restrict__ xrow, const float* __restrict__ wrow, int steps, int wave) {
+  const int s0 = (steps * wave) >> 2, s1 = (steps * (wave + 1)) >> 2;
+  f32x4_r acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int s = s0; s < s1; ++s) {
+    const f32x4_r a = *reinterpret_cast<const f32x4_r*>(xrow + 16 * s);
+    const f32x4_r b = *reinterpret_cast<const f32x4_r*>(wrow + 16 * s);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
 // One GRU time step for a handful of rows (M <= 16: the rollout's 14 envs, one step of the update's sequence pass) in ONE
 // launch: recurrent product gh_raw = h W_hh^T and the gate math of gru_gates_kernel.  At this size the product is a weight
 // stream (3H x H floats, 3 MB at H = 512) against 14 rows: a tiled-GEMM launch + its split-K reduce + the gate kernel spend
-// ~29 us on it, almost all launch and pipeline latency.  Here a block owns GRU_U hidden units = 3*GRU_U weight rows (r, z, n),
-// stages them and the hidden state in LDS (padded rows: conflict-free 16-byte reads) and thread (row, env) runs the H-long
-// dot product; the three gates of a unit meet through LDS.  gh_raw is written too (the backward pass reads it).
+// ~29 us on it, almost all launch and pipeline latency.  A block owns GRU_U hidden units = 3*GRU_U weight rows (r, z, n) and
+// runs their dot products with the 16 state rows through skinny_dot16; the three gates of a unit meet through LDS.  gh_raw is
+// written too (the backward pass reads it).  (First version: weights and state staged in LDS, one thread per (row, env) dot
+// product with broadcast LDS reads -- 12 us, bound by LDS bandwidth.)
 constexpr int GRU_U = 4;     // hidden units per block
 constexpr int GRU_E = 16;    // env slots per block (M <= 16)
-__global__ __launch_bounds__(3 * GRU_U * GRU_E) void gru_step_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
-                                                                   const float* __restrict__ bhh, const float* __restrict__ hprev,
-                                                                   const float* __restrict__ mask, float* __restrict__ gh_raw,
-                                                                   float* __restrict__ hout, int M, int H) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int LD = H + 4;                       // padded row (floats): consecutive rows start 4 banks apart
-  float* Ws = smem;                           // [3*GRU_U][LD]
-  float* Hs = smem + 3 * GRU_U * LD;          // [GRU_E][LD]
-  float* G = Hs + GRU_E * LD;                 // [3*GRU_U][GRU_E] raw gate products
-  const int tid = threadIdx.x;
+__global__ __launch_bounds__(256) void gru_step_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
+                                                       const float* __restrict__ bhh, const float* __restrict__ hprev,
+                                                       const float* __restrict__ mask, float* __restrict__ gh_raw,
+                                                       float* __restrict__ hout, int M, int H) {
+  __shared__ float R[4][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
   const int j0 = blockIdx.x * GRU_U;
-  const int H4 = H >> 2;
-  // all global loads of the block are issued before the first LDS store (a load-store loop would wait out one memory round
-  // trip per iteration): H <= 512 bounds the per-thread counts
-  constexpr int NT = 3 * GRU_U * GRU_E;                              // threads
-  constexpr int NW = (3 * GRU_U * 128 + NT - 1) / NT;                // 16-byte weight loads per thread at H = 512
-  constexpr int NH = (GRU_E * 128 + NT - 1) / NT;                    // 16-byte hidden-state loads per thread
-  float4 wreg[NW], hreg[NH];
-  // gate inputs of this thread's (unit, env) pair, fetched up front as well
-  const int gu = tid / GRU_E, ge = min(tid - gu * GRU_E, M - 1), gj = min(j0 + (gu % GRU_U), H - 1);
+  const int r = min(i, 3 * GRU_U - 1);                         // weight row of this lane: gate r / GRU_U, unit r % GRU_U
+  const float* wrow = whh + ((size_t)(r / GRU_U) * H + j0 + (r % GRU_U)) * H + 4 * kq;
+  const float* xrow = hprev + (size_t)min(i, M - 1) * H + 4 * kq;
+  // gate inputs of this thread's (unit, env) pair, fetched before the dot products
+  const int gu = (tid >> 4) & (GRU_U - 1), ge = min(tid & 15, M - 1), gj = j0 + gu;
   const float gmask = mask != nullptr ? mask[ge] : 1.f;
   const float gi_r = gi[(size_t)ge * 3 * H + gj], gi_z = gi[(size_t)ge * 3 * H + H + gj], gi_n = gi[(size_t)ge * 3 * H + 2 * H + gj];
   const float b_r = bhh[gj], b_z = bhh[H + gj], b_n = bhh[2 * H + gj];
+  const float hp_raw = hprev[(size_t)ge * H + gj];
+  const f32x4_r acc = skinny_dot16(xrow, wrow, H >> 4, wave);
 #pragma unroll
-  for (int k = 0; k < NW; ++k) {
-    const int i = min(tid + k * NT, 3 * GRU_U * H4 - 1);
-    const int r = i / H4, c = i - r * H4;
-    const int g = r / GRU_U, u = r - g * GRU_U;
-    wreg[k] = *reinterpret_cast<const float4*>(&whh[((size_t)g * H + (j0 + u)) * H + 4 * c]);
-  }
-#pragma unroll
-  for (int k = 0; k < NH; ++k) {
-    const int i = min(tid + k * NT, GRU_E * H4 - 1);
-    const int e = min(i / H4, M - 1), c = i % H4;
-    hreg[k] = *reinterpret_cast<const float4*>(&hprev[(size_t)e * H + 4 * c]);
-  }
-#pragma unroll
-  for (int k = 0; k < NW; ++k) {
-    const int i = tid + k * NT;
-    if (i < 3 * GRU_U * H4) *reinterpret_cast<float4*>(&Ws[(i / H4) * LD + 4 * (i % H4)]) = wreg[k];
-  }
-#pragma unroll
-  for (int k = 0; k < NH; ++k) {
-    const int i = tid + k * NT;
-    if (i < GRU_E * H4) *reinterpret_cast<float4*>(&Hs[(i / H4) * LD + 4 * (i % H4)]) = hreg[k];  // rows >= M: a copy of row M-1, never used
-  }
+  for (int e = 0; e < 4; ++e) R[wave][kq * 4 + e][i] = acc[e];   // [m][weight row]
   __syncthreads();
-  const int r = tid / GRU_E, e = tid - r * GRU_E;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  const float* wr = Ws + r * LD;
-  const float* hr = Hs + e * LD;
-#pragma unroll 4
-  for (int c = 0; c < H4; ++c) {
-    const float4 w = *reinterpret_cast<const float4*>(wr + 4 * c);
-    const float4 h = *reinterpret_cast<const float4*>(hr + 4 * c);
-    a0 = fmaf(w.x, h.x, a0);
-    a1 = fmaf(w.y, h.y, a1);
-    a2 = fmaf(w.z, h.z, a2);
-    a3 = fmaf(w.w, h.w, a3);
+  if (tid < 3 * GRU_U * GRU_E) {                                  // gh_raw: thread (weight row rr, env m)
+    const int rr = tid >> 4, m = tid & 15;
+    if (m < M) gh_raw[(size_t)m * 3 * H + (size_t)(rr / GRU_U) * H + j0 + (rr % GRU_U)] = (R[0][m][rr] + R[1][m][rr]) + (R[2][m][rr] + R[3][m][rr]);
   }
-  const float acc = (a0 + a1) + (a2 + a3);
-  G[r * GRU_E + e] = acc;
-  {
-    const int g = r / GRU_U, u = r - g * GRU_U;
-    if (e < M && j0 + u < H) gh_raw[(size_t)e * 3 * H + (size_t)g * H + j0 + u] = acc;
-  }
-  __syncthreads();
-  if (tid < GRU_U * GRU_E) {
-    const int u = tid / GRU_E, e2 = tid - u * GRU_E, j = j0 + u;
-    if (e2 < M && j < H) {
-      const float m = gmask;  // (tid < GRU_U * GRU_E: gu == u, ge == e2, gj == j)
-      const float gr = G[(0 * GRU_U + u) * GRU_E + e2], gz = G[(1 * GRU_U + u) * GRU_E + e2], gn = G[(2 * GRU_U + u) * GRU_E + e2];
-      const float rg = sigmoidf_(gi_r + (m * gr + b_r));
-      const float z = sigmoidf_(gi_z + (m * gz + b_z));
-      const float n = tanhf(gi_n + rg * (m * gn + b_n));
-      const float hp = m * Hs[e2 * LD + j];
-      hout[(size_t)e2 * H + j] = (1.f - z) * n + z * hp;
-    }
+  if (tid < GRU_U * GRU_E && (tid & 15) < M) {
+    const int u = tid >> 4, m = tid & 15;
+    auto tot = [&](int rr) { return (R[0][m][rr] + R[1][m][rr]) + (R[2][m][rr] + R[3][m][rr]); };
+    const float gr = tot(u), gz = tot(GRU_U + u), gn = tot(2 * GRU_U + u);
+    const float rg = sigmoidf_(gi_r + (gmask * gr + b_r));
+    const float z = sigmoidf_(gi_z + (gmask * gz + b_z));
+    const float n = tanhf(gi_n + rg * (gmask * gn + b_n));
+    hout[(size_t)m * H + j0 + u] = (1.f - z) * n + z * (gmask * hp_raw);
   }
 }
 
@@ -629,76 +604,29 @@ __global__ void gru_bwd_combine_kernel(const float* __restrict__ a, const float*
 }
 
 // Recurrent part of one GRU backward step for M <= 16 rows in one launch: out = a + mask * (dpre W_hh + dhp), i.e. the
-// [M,3H] x [3H,H] product (a 3 MB weight stream against 14 rows), and m2h_gru_bwd_combine.  Structure of gru_step_kernel: a
-// block owns 4 hidden units = 4 rows of W_hh^T; the 3H-long reduction is walked in three H-long parts (one per gate block),
-// each staged in LDS with the matching slice of dpre (41 KB in all); all global loads are issued before the first LDS store.
-// Thread (k-quarter, unit, env) sums a quarter of every part; the four quarters meet through LDS in a fixed order.
-constexpr int GB_U = 4, GB_E = 16, GB_KQ = 4, GB_NT = GB_U * GB_E * GB_KQ;
-__global__ __launch_bounds__(GB_NT) void gru_bwd_rec_kernel(const float* __restrict__ dpre, const float* __restrict__ whh_t,
-                                                           const float* __restrict__ a, const float* __restrict__ dhp,
-                                                           const float* __restrict__ mask, float* __restrict__ out, int M, int H) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int LD = H + 4;
-  float* Ws = smem;                  // [GB_U][LD]
-  float* Ds = Ws + GB_U * LD;        // [GB_E][LD]
-  float* P = Ds + GB_E * LD;         // [GB_KQ][GB_U][GB_E]
-  const int tid = threadIdx.x;
-  const int j0 = blockIdx.x * GB_U;
-  const int H4 = H >> 2, K = 3 * H;
-  constexpr int NWL = (GB_U * 128 + GB_NT - 1) / GB_NT;   // 16-byte loads per thread and part at H = 512
-  constexpr int NDL = (GB_E * 128 + GB_NT - 1) / GB_NT;
-  float4 wreg[3][NWL], dreg[3][NDL];
+// [M,3H] x [3H,H] product (a 3 MB weight stream against 14 rows) and m2h_gru_bwd_combine.  A block owns GB_U hidden units = GB_U rows
+// of W_hh^T and runs their 3H-long dot products with the 16 rows of dpre through skinny_dot16 (the 16-wide tile's other columns
+// repeat the last row); the four waves' partial tiles meet through LDS in wave order.
+constexpr int GB_U = 4, GB_E = 16;
+__global__ __launch_bounds__(256) void gru_bwd_rec_kernel(const float* __restrict__ dpre, const float* __restrict__ whh_t,
+                                                          const float* __restrict__ a, const float* __restrict__ dhp,
+                                                          const float* __restrict__ mask, float* __restrict__ out, int M, int H) {
+  __shared__ float R[4][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int j0 = blockIdx.x * GB_U, K = 3 * H;
+  const float* wrow = whh_t + (size_t)(j0 + min(i, GB_U - 1)) * K + 4 * kq;
+  const float* xrow = dpre + (size_t)min(i, M - 1) * K + 4 * kq;
+  const f32x4_r acc = skinny_dot16(xrow, wrow, K >> 4, wave);
 #pragma unroll
-  for (int part = 0; part < 3; ++part) {
-#pragma unroll
-    for (int k = 0; k < NWL; ++k) {
-      const int i = min(tid + k * GB_NT, GB_U * H4 - 1);
-      const int u = i / H4, c = i - u * H4;
-      wreg[part][k] = *reinterpret_cast<const float4*>(&whh_t[(size_t)(j0 + u) * K + part * H + 4 * c]);
-    }
-#pragma unroll
-    for (int k = 0; k < NDL; ++k) {
-      const int i = min(tid + k * GB_NT, GB_E * H4 - 1);
-      const int e = min(i / H4, M - 1), c = i % H4;
-      dreg[part][k] = *reinterpret_cast<const float4*>(&dpre[(size_t)e * K + part * H + 4 * c]);
-    }
-  }
-  const int kq = tid / (GB_U * GB_E), u = (tid / GB_E) % GB_U, e = tid % GB_E;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  const int c0 = kq * (H4 / GB_KQ), c1 = c0 + H4 / GB_KQ;
-#pragma unroll
-  for (int part = 0; part < 3; ++part) {
-    if (part > 0) __syncthreads();   // the previous part has been read
-#pragma unroll
-    for (int k = 0; k < NWL; ++k) {
-      const int i = tid + k * GB_NT;
-      if (i < GB_U * H4) *reinterpret_cast<float4*>(&Ws[(i / H4) * LD + 4 * (i % H4)]) = wreg[part][k];
-    }
-#pragma unroll
-    for (int k = 0; k < NDL; ++k) {
-      const int i = tid + k * GB_NT;
-      if (i < GB_E * H4) *reinterpret_cast<float4*>(&Ds[(i / H4) * LD + 4 * (i % H4)]) = dreg[part][k];
-    }
-    __syncthreads();
-    const float* wr = Ws + u * LD;
-    const float* dr = Ds + e * LD;
-#pragma unroll 4
-    for (int c = c0; c < c1; ++c) {
-      const float4 w = *reinterpret_cast<const float4*>(wr + 4 * c);
-      const float4 d = *reinterpret_cast<const float4*>(dr + 4 * c);
-      a0 = fmaf(w.x, d.x, a0);
-      a1 = fmaf(w.y, d.y, a1);
-      a2 = fmaf(w.z, d.z, a2);
-      a3 = fmaf(w.w, d.w, a3);
-    }
-  }
-  P[(kq * GB_U + u) * GB_E + e] = (a0 + a1) + (a2 + a3);
+  for (int e = 0; e < 4; ++e) R[wave][kq * 4 + e][i] = acc[e];
   __syncthreads();
-  if (tid < GB_U * GB_E && e < M) {
-    const float rec = (P[(0 * GB_U + u) * GB_E + e] + P[(1 * GB_U + u) * GB_E + e]) + (P[(2 * GB_U + u) * GB_E + e] + P[(3 * GB_U + u) * GB_E + e]);
-    const size_t o = (size_t)e * H + j0 + u;
-    const float m = mask != nullptr ? mask[e] : 1.f;
-    out[o] = (a != nullptr ? a[o] : 0.f) + m * (rec + dhp[o]);
+  if (tid < GB_U * GB_E && (tid & 15) < M) {
+    const int u = tid >> 4, m = tid & 15;
+    const float rec = (R[0][m][u] + R[1][m][u]) + (R[2][m][u] + R[3][m][u]);
+    const size_t o = (size_t)m * H + j0 + u;
+    const float mk = mask != nullptr ? mask[m] : 1.f;
+    out[o] = (a != nullptr ? a[o] : 0.f) + mk * (rec + dhp[o]);
   }
 }
 
@@ -894,11 +822,9 @@ int m2h_gru_gates(const float* gi, const float* gh_raw, const float* bhh, const 
 int m2h_gru_step(const float* gi, const float* whh, const float* bhh, const float* hprev, const float* mask, float* gh_raw, float* hout,
                  int M, int H, m2h_stream stream) {
   M2H_REQUIRE(gi && whh && bhh && hprev && gh_raw && hout, "gru_step: null pointer");
-  M2H_REQUIRE(M > 0 && M <= GRU_E && H > 0 && H % 4 == 0 && H <= 512, "gru_step: needs 1 <= M <= %d rows and H %% 4 == 0, H <= 512 (got M=%d, H=%d)",
+  M2H_REQUIRE(M > 0 && M <= GRU_E && H > 0 && H % 16 == 0, "gru_step: needs 1 <= M <= %d rows and H %% 16 == 0 (got M=%d, H=%d)",
               GRU_E, M, H);
-  const size_t lds = ((size_t)(3 * GRU_U + GRU_E) * (H + 4) + 3 * GRU_U * GRU_E) * sizeof(float);  // 58.6 KB at H = 512
-  hipLaunchKernelGGL(gru_step_kernel, dim3((H + GRU_U - 1) / GRU_U), dim3(3 * GRU_U * GRU_E), lds, as_stream(stream), gi, whh, bhh, hprev, mask,
-                     gh_raw, hout, M, H);
+  hipLaunchKernelGGL(gru_step_kernel, dim3(H / GRU_U), dim3(256), 0, as_stream(stream), gi, whh, bhh, hprev, mask, gh_raw, hout, M, H);
   return launch_status("gru_step");
 }
 
@@ -971,10 +897,9 @@ int m2h_gru_bwd_combine(const float* a, const float* b, const float* c, const fl
 int m2h_gru_bwd_rec(const float* dpre, const float* whh_t, const float* a, const float* dhp, const float* mask, float* out, int M, int H,
                     m2h_stream stream) {
   M2H_REQUIRE(dpre && whh_t && dhp && out, "gru_bwd_rec: null pointer");
-  M2H_REQUIRE(M > 0 && M <= GB_E && H > 0 && H % 16 == 0 && H <= 512, "gru_bwd_rec: needs 1 <= M <= %d rows and H %% 16 == 0, H <= 512 (got M=%d, H=%d)",
+  M2H_REQUIRE(M > 0 && M <= GB_E && H > 0 && H % 16 == 0, "gru_bwd_rec: needs 1 <= M <= %d rows and H %% 16 == 0 (got M=%d, H=%d)",
               GB_E, M, H);
-  const size_t lds = ((size_t)(GB_U + GB_E) * (H + 4) + GB_KQ * GB_U * GB_E) * sizeof(float);  // 42.3 KB at H = 512
-  hipLaunchKernelGGL(gru_bwd_rec_kernel, dim3(H / GB_U), dim3(GB_NT), lds, as_stream(stream), dpre, whh_t, a, dhp, mask, out, M, H);
+  hipLaunchKernelGGL(gru_bwd_rec_kernel, dim3(H / GB_U), dim3(256), 0, as_stream(stream), dpre, whh_t, a, dhp, mask, out, M, H);
   return launch_status("gru_bwd_rec");
 }
 

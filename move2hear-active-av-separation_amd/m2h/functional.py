@@ -239,7 +239,7 @@ class GRUSequence(torch.autograd.Function):
         out = torch.empty((T * N, H), device=x.device, dtype=torch.float32)
         gh = torch.empty((T * N, 3 * H), device=x.device, dtype=torch.float32)
         h = h0.contiguous()
-        fused = N <= ops.GRU_STEP_MAX_ROWS and H % 4 == 0 and H <= 512  # rollout width: the whole step is one launch
+        fused = N <= ops.GRU_STEP_MAX_ROWS and H % 16 == 0  # rollout width: the whole step is one launch
         whh, bhh = w_hh.detach().contiguous(), b_hh.detach()
         for t in range(T):
             sl = slice(t * N, (t + 1) * N)
@@ -266,7 +266,7 @@ class GRUSequence(torch.autograd.Function):
         dhp = torch.empty((N, H), device=dev)
         # W_hh^T as an [H][3H] "Linear" weight for the recurrent dgrad GEMM
         whh_t = pack_dgrad_weight(w_hh.detach().reshape(3 * H, H, 1, 1).contiguous(), 1, 0).view(H, 3 * H)
-        fused = N <= ops.GRU_STEP_MAX_ROWS and H % 16 == 0 and H <= 512
+        fused = N <= ops.GRU_STEP_MAX_ROWS and H % 16 == 0
         dh = g_out[(T - 1) * N:T * N].clone()
         if g_hT is not None:
             dh = dh + g_hT  # tiny [N,H] add; hT is rarely used downstream

@@ -289,3 +289,28 @@ def test_sampling_is_torch_multinomial_bit_for_bit():
         for a, b in zip(got, ref):
             assert a.dtype == torch.int64 and a.shape == (M, 1) and torch.equal(a, b)
         assert torch.equal(ref_after, got_after)
+
+
+@pytest.mark.parametrize("M,K,N,slope", [(14, 1536, 1536, 1.0), (1, 1536, 1536, 1.0), (16, 512, 512, 0.0), (5, 4608, 512, 0.0)])
+def test_skinny_linear_kernel_matches_the_engine_and_torch(M, K, N, slope):
+    """M <= 16 dense rows (Linear at the rollout width, full-spatial conv as Linear): both operands straight into the 16x16x4
+    fp32 MFMA, against the tiled engine (knob 23 = -1) and torch on the CPU."""
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) * 0.1
+    ref = x @ w.t() + b
+    ref = torch.relu(ref) if slope == 0.0 else ref
+    got = {}
+    for knob in (0, -1):
+        ops.debug_set(23, knob)
+        try:
+            if K == 4608:   # VisualCNN's fc: a 12x12x32 map under a 12x12 kernel (visual_cnn.py:140-141)
+                got[knob] = ops.conv2d_nhwc(x.view(M, 12, 12, 32).to(dev), w.to(dev), N, 12, 12, bias=b.to(dev), slope=slope).reshape(M, N).cpu()
+            else:
+                got[knob] = ops.linear(x.to(dev), w.to(dev), b.to(dev), slope=slope).cpu()
+        finally:
+            ops.debug_set(23, 0)
+    assert _rel(got[0], ref) < 2e-5 and _rel(got[-1], ref) < 2e-5 and _rel(got[0], got[-1]) < 1e-5
