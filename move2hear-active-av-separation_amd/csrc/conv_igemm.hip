@@ -994,39 +994,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_row_kernel(const IGemmP p) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Skinny dense GEMM, M <= 16 rows (fp32 MFMA): D[m][n] = act(scale[n] * sum_k X[m][k] W[n][k] + shift[n]) where every GEMM row is
-// one contiguous run of K floats -- nn.Linear at the rollout width (the GRU's input projection, 1536 x 1536), and the
-// full-spatial "conv as Linear" of VisualCNN / AudioCNN (visual_cnn.py:140-141: 4608 -> 512).  These are weight streams (9.4 MB
-// against 14 rows): the tiled engine needs split-K slabs and a reduce launch to occupy the chip (28 us for the pair).  Here a
-// block owns 16 output channels; BOTH operands go straight from global memory into v_mfma_f32_16x16x4_f32 registers (lane
-// (row, k-quarter) loads 16 bytes of its row: four consecutive MFMAs' worth; X is a few hundred KB and stays in L2), the four
-// waves split K, and their 16 x 16 partial tiles meet through 4 KB of LDS in wave order.  No LDS staging, no barrier in the k-loop.
-__global__ __launch_bounds__(256) void skinny_linear_kernel(const IGemmP p) {
+// one contiguous run of floats -- nn.Linear at the rollout width (the GRU's input projection, 1536 x 1536), the full-spatial
+// "conv as Linear" of VisualCNN / AudioCNN (visual_cnn.py:140-141: 4608 -> 512), and the two U-Net stages around the 1 x 1
+// bottleneck at the rollout batch: the deepest encoder conv (its tap window covers the whole 2 x 2 input: the sample IS the row)
+// and the first transposed conv (one tap per sub-pixel phase).  These are weight streams (4-17 MB against 14 rows): the tiled
+// engine needs split-K slabs and a reduce launch to occupy the chip (20-28 us per layer).  Here a block owns COLS output
+// channels of one phase; BOTH operands go straight from global memory into v_mfma_f32_16x16x4_f32 registers (lane (row,
+// k-quarter) loads 16 bytes of its row: four consecutive MFMAs' worth; X is a few hundred KB and stays in L2), the four waves
+// split K, and their partial tiles meet through 4 KB of LDS in wave order.  No LDS staging, no barrier in the k-loop.
+// COLS = 16 fills the MFMA tile; COLS = 4 (the other columns repeat the last row) quadruples the block count for N <= 512.
+// K is walked as thn segments of twn*Ctot floats: X contiguous, W at tap (th0 + seg, tw0) of its (nth x ntw x Ctot) row.
+template <int COLS>
+__global__ __launch_bounds__(256) void skinny_rows_kernel(const IGemmP p) {
   __shared__ float R[4][16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  const int n0 = blockIdx.x * 16;
-  const int steps = p.K >> 4;                                 // 16 k per step
+  const int nblk = (p.N + COLS - 1) / COLS;
+  const int phase = blockIdx.x / nblk;
+  const int n0 = (blockIdx.x - phase * nblk) * COLS;
+  const int L = p.twn * p.Ctot;                               // floats per segment
+  const int sps = L >> 4;                                     // 16-float steps per segment
+  const int steps = p.thn * sps;
   const int s0 = (steps * wave) >> 2, s1 = (steps * (wave + 1)) >> 2;
-  const float* xr = p.src0 + (size_t)min(i, p.M - 1) * p.K + 4 * kq;     // rows past M re-read row M-1 (never stored)
-  const float* wr = p.w + (size_t)min(n0 + i, p.N - 1) * p.K + 4 * kq;
+  const float* xr = p.src0 + (size_t)min(i, p.M - 1) * ((size_t)p.thn * L) + 4 * kq;   // rows past M re-read row M-1 (never stored)
+  const float* wr = p.w + ((size_t)phase * p.N + min(n0 + min(i, COLS - 1), p.N - 1)) * p.K + (size_t)p.tw0 * p.Ctot + 4 * kq;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int seg = s0 / sps, s = s0 - seg * sps;
 #pragma unroll 8
-  for (int s = s0; s < s1; ++s) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(xr + 16 * s);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(wr + 16 * s);
+  for (int t = s0; t < s1; ++t) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(xr + (size_t)seg * L + 16 * s);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(wr + (size_t)(p.th0 + seg) * p.ntw * p.Ctot + 16 * s);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+    if (++s == sps) {
+      s = 0;
+      ++seg;
+    }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) R[wave][kq * 4 + e][i] = acc[e];   // D[m = kq*4 + e][n = i]
+  for (int e = 0; e < 4; ++e) R[wave][kq * 4 + e][i] = acc[e];   // D[m = kq*4 + e][column i]
   __syncthreads();
-  const int m = tid >> 4, n = n0 + (tid & 15);
-  if (m < p.M && n < p.N) {
-    float x = (R[0][m][tid & 15] + R[1][m][tid & 15]) + (R[2][m][tid & 15] + R[3][m][tid & 15]);
+  const int m = tid >> 4, c = tid & 15, n = n0 + c;
+  if (m < p.M && c < COLS && n < p.N) {
+    float x = (R[0][m][c] + R[1][m][c]) + (R[2][m][c] + R[3][m][c]);
     const float sc = p.scale != nullptr ? p.scale[n] : 1.f;
     const float sh = p.shift != nullptr ? p.shift[n] : 0.f;
     x = x * sc + sh;
-    p.dst[(size_t)m * p.ldc + n] = x > 0.f ? x : x * p.slope;
+    const size_t pix = p.convT ? ((size_t)m * p.Ho + (phase >> 1)) * p.Wo + (phase & 1) : (size_t)m;
+    p.dst[pix * p.ldc + n] = x > 0.f ? x : x * p.slope;
   }
 }
 
@@ -1321,14 +1336,21 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
       return launch_status("conv_igemm_f32 (tap-sharing convT)");
     }
   }
-  // M <= 16 rows that are each one contiguous run of K floats (Linear; a conv whose kernel covers the whole image): weight streaming
-  if (g_skinny_linear >= 0 && M <= 16 && !p.convT && a.C1 == 0 && a.Hq == 1 && a.Wq == 1 && a.Ho == 1 && a.Wo == 1 && a.Hi == a.nth &&
-      a.Wi == a.ntw && a.offh == 0 && a.offw == 0 && a.mulh == 1 && a.mulw == 1 && a.os == 1 && a.ph == 0 && a.pw == 0 &&
-      p.K % 16 == 0 && a.N % 16 == 0 && a.out_mode == M2H_OUT_NHWC && a.cls_table == nullptr && a.head_w == nullptr &&
-      a.operand_format == 0 && (size_t)a.N * p.K >= (size_t)1 << 18 && a.N >= 64 * 16) {   // >= 64 blocks: N = 512 x K = 4608 (32
-                                                                                         // blocks of 295 KB) measured 30 vs 28 us
-    hipLaunchKernelGGL(skinny_linear_kernel, dim3((unsigned)(a.N / 16)), dim3(256), 0, st, p);
-    return launch_status("conv_igemm_f32 (skinny linear)");
+  // M <= 16 rows that are each one contiguous run of floats: Linear; a conv whose tap window covers the whole image and gives
+  // one output pixel; a transposed conv over a 1 x 1 image (one tap per phase).  Weight streaming on the skinny kernel.
+  if (g_math_mode == 0 && g_skinny_linear >= 0 && g_fast_loader >= 0 && p.fast_ok && M <= 16 && a.C1 == 0 && a.Hq == 1 && a.Wq == 1 && a.os >= 1 && a.N % 4 == 0 &&
+      a.out_mode == M2H_OUT_NHWC && a.cls_table == nullptr && a.head_w == nullptr && a.operand_format == 0 &&
+      (size_t)a.N * p.Kw * (p.convT ? 4 : 1) >= (size_t)1 << 18) {
+    bool dense;
+    if (p.convT) dense = a.Hi == 1 && a.Wi == 1 && p.thn == 1 && p.twn == 1 && p.th0 == 0 && p.tw0 == 0 && a.Ho == 2 && a.Wo == 2;
+    else dense = a.Ho == 1 && a.Wo == 1 && a.ph == 0 && a.pw == 0 && p.thn == a.Hi && p.twn == a.Wi && a.mulh == 1 && a.mulw == 1 &&
+                 a.offh + p.th0 == 0 && a.offw + p.tw0 == 0;
+    if (dense) {
+      const int phases = p.convT ? 4 : 1;
+      if (a.N * phases >= 64 * 16) hipLaunchKernelGGL((skinny_rows_kernel<16>), dim3((unsigned)(phases * ((a.N + 15) / 16))), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((skinny_rows_kernel<4>), dim3((unsigned)(phases * ((a.N + 3) / 4))), dim3(256), 0, st, p);
+      return launch_status("conv_igemm_f32 (skinny rows)");
+    }
   }
   // 3x3 / stride 1 / pad 1 over 16- or 32-channel, 32-pixel-wide images in fp32 math, many rows (AcousticMem in update_sep)
   if (g_math_mode == 0 && g_row3x3 >= 0 && !p.convT && a.nth == 3 && a.ntw == 3 && a.stride == 1 && a.os == 1 && a.ph == 0 && a.pw == 0 &&

@@ -341,6 +341,7 @@ def test_tap_window_skips_only_exact_zeros(math):
     dev = _dev()
     g = torch.Generator(device=dev).manual_seed(3)
     ops.set_math_mode(ops.MATH_BF16X3 if math == "bf16x3" else ops.MATH_FP32)
+    ops.debug_set(23, -1)   # keep the <= 16-row shapes on the tiled engine: this test isolates the tap window
     try:
         for (B, H, W) in ((3, 2, 2), (14, 2, 2), (5, 2, 16), (2, 4, 4)):
             x = torch.randn(B, H, W, 512, device=dev, generator=g)
@@ -364,4 +365,29 @@ def test_tap_window_skips_only_exact_zeros(math):
             assert torch.equal(outs[0], outs[1]), ("up", B, H, W)
     finally:
         ops.debug_set(18, 0)
+        ops.debug_set(23, 0)
         ops.set_math_mode(ops.MATH_FP32)
+
+
+def test_skinny_rows_kernel_on_the_bottleneck_stages():
+    """At the rollout batch the two U-Net stages around the 1 x 1 bottleneck are weight streams against <= 16 rows: the deepest
+    encoder conv (2 x 2 input, tap window = the whole image) and the first transposed conv (1 x 1 input, one tap per phase) run
+    on the skinny MFMA kernel; against the tiled engine (knob 23 = -1), including BN scale / shift and the activation."""
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(13)
+    for B in (1, 5, 14, 16):
+        x = torch.randn(B, 2, 2, 512, device=dev, generator=g)
+        wp = torch.randn(512, 16 * 512, device=dev, generator=g) * 0.02
+        sc, sh = torch.rand(512, device=dev, generator=g) + 0.5, torch.randn(512, device=dev, generator=g) * 0.1
+        x1 = torch.randn(B, 1, 1, 512, device=dev, generator=g)
+        wu = torch.randn(4, 512, 4 * 512, device=dev, generator=g) * 0.02
+        outs = {}
+        for knob in (0, -1):
+            ops.debug_set(23, knob)
+            try:
+                outs[knob] = (ops.unet_down_fwd(x, wp, sc, sh, 512).clone(), ops.unet_up_fwd(x1, None, wu, sc, sh, 512).clone())
+            finally:
+                ops.debug_set(23, 0)
+        for a, b in zip(outs[0], outs[-1]):
+            assert a.shape == b.shape and O.rel_l1(a.cpu(), b.cpu()) < 1e-5, B
