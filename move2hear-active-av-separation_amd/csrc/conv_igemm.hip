@@ -1045,6 +1045,126 @@ __global__ __launch_bounds__(256) void skinny_rows_kernel(const IGemmP p) {
   }
 }
 
+// Skinny implicit-GEMM conv for small pixel counts (M <= 256 rows per phase: the U-Net's deep stages at the rollout batch), fp32
+// MFMA, no LDS staging: a block computes a 16*MGB (pixels) x 16 (channels) tile of one phase; lane (row i, k-quarter) loads 16 bytes
+// of its weight row and of each of its MGB pixel rows (gathered per tap exactly as the engine above does, zero outside the image;
+// the activations are a few hundred KB and stay in L1 / L2) straight into v_mfma_f32_16x16x4_f32 registers; the four waves split
+// the walked reduction (tap window x both sources x channels) and meet through LDS in wave order; BN scale / shift, activation
+// and the NHWC store follow.  The tiled engine occupies the chip at these sizes only through split-K (slabs + a reduce launch,
+// 24-45 us per layer against 2-17 MB of weights); here the weights are streamed MG/MGB times and the activations N/16 times.
+template <int MGB>
+__global__ __launch_bounds__(256) void skinny_gather_kernel(const IGemmP p) {
+  __shared__ float R[4][MGB][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int NB = (p.N + 15) >> 4, MS = (p.MT + MGB - 1) / MGB;     // p.MT = 16-row groups of M
+  int L = blockIdx.x;
+  const int ms = L % MS;
+  L /= MS;
+  const int nb = L % NB, phase = L / NB;
+  int mulh = p.mulh, offh = p.offh, mulw = p.mulw, offw = p.offw, ph = p.ph, pw = p.pw;
+  const float* wbase = p.w;
+  if (p.convT) {
+    ph = phase >> 1;
+    pw = phase & 1;
+    mulh = 2 * ph - 1;
+    mulw = 2 * pw - 1;
+    offh = 0;
+    offw = 0;
+    wbase += (size_t)phase * p.N * p.K;
+  }
+  int qh[MGB], rw[MGB], bpix[MGB];
+#pragma unroll
+  for (int g = 0; g < MGB; ++g) {
+    const int m = (ms * MGB + g) * 16 + i;
+    qh[g] = rw[g] = -(1 << 24);
+    bpix[g] = 0;
+    if (m < p.M) {
+      int q, rr, b, out, bc;
+      decode_row(p, m, ph, pw, q, rr, b, out, bc);
+      qh[g] = q * p.stride + offh;
+      rw[g] = rr * p.stride + offw;
+      bpix[g] = b * p.Hi * p.Wi;
+    }
+  }
+  const float* wrow = wbase + (size_t)min(nb * 16 + i, p.N - 1) * p.K + 4 * kq;
+  const int spt = p.Ctot >> 4;                                   // 16-float steps per tap
+  const int steps = p.thn * p.twn * spt;
+  const int s0 = (steps * wave) >> 2, s1 = (steps * (wave + 1)) >> 2;
+  f32x4 acc[MGB];
+#pragma unroll
+  for (int g = 0; g < MGB; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
+  int tap = s0 / spt, ci = (s0 - tap * spt) * 16;
+  int th = p.th0 + tap / p.twn, tw = p.tw0 + tap % p.twn;
+  unsigned offA[MGB];                                            // float offset of the row's pixel at the current tap, per source stride
+  bool okA[MGB];
+  auto at_tap = [&]() {
+#pragma unroll
+    for (int g = 0; g < MGB; ++g) {
+      const int ih = qh[g] + th * mulh, iw = rw[g] + tw * mulw;
+      okA[g] = (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+      offA[g] = okA[g] ? (unsigned)(bpix[g] + ih * p.Wi + iw) : 0u;
+    }
+  };
+  at_tap();
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (int t = s0; t < s1;) {
+    // one run of steps inside the current (tap, source): addresses advance by 16 floats, no branches -> the loads of the next
+    // steps are issued under the MFMAs of the current ones
+    const bool second = ci >= p.C0;
+    const int seg_end = second ? p.Ctot : p.C0;                  // end of this source's channels
+    const int nrun = min(s1 - t, (seg_end - ci) >> 4);
+    const float* src = second ? p.src1 : p.src0;
+    const unsigned Cs = second ? p.C1 : p.C0, c = (second ? ci - p.C0 : ci) + 4 * kq;
+    const float* wp_ = wrow + (size_t)(th * p.ntw + tw) * p.Ctot + ci;
+    const float* ap[MGB];
+#pragma unroll
+    for (int g = 0; g < MGB; ++g) ap[g] = src + (size_t)offA[g] * Cs + c;   // (rows outside the image: pixel 0, masked below)
+#pragma unroll 4
+    for (int k = 0; k < nrun; ++k) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(wp_ + 16 * k);
+      f32x4 a[MGB];
+#pragma unroll
+      for (int g = 0; g < MGB; ++g) a[g] = *reinterpret_cast<const f32x4*>(ap[g] + 16 * k);
+#pragma unroll
+      for (int g = 0; g < MGB; ++g) {
+        const f32x4 av = okA[g] ? a[g] : zero4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b[j], acc[g], 0, 0, 0);
+      }
+    }
+    t += nrun;
+    ci += 16 * nrun;
+    if (ci == p.Ctot) {
+      ci = 0;
+      if (++tw == p.tw0 + p.twn) {
+        tw = p.tw0;
+        ++th;
+      }
+      at_tap();
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < MGB; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) R[wave][g][kq * 4 + e][i] = acc[g][e];    // D[row kq*4 + e][channel i]
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < MGB; ++g) {
+    const int r16 = tid >> 4, c16 = tid & 15;
+    const int m = (ms * MGB + g) * 16 + r16, n = nb * 16 + c16;
+    if (m < p.M && n < p.N) {
+      float x = (R[0][g][r16][c16] + R[1][g][r16][c16]) + (R[2][g][r16][c16] + R[3][g][r16][c16]);
+      const float sc = p.scale != nullptr ? p.scale[n] : 1.f;
+      const float sh = p.shift != nullptr ? p.shift[n] : 0.f;
+      x = x * sc + sh;
+      int q, rr, b, out, bc;
+      decode_row(p, m, ph, pw, q, rr, b, out, bc);
+      p.dst[(size_t)out * p.ldc + n] = x > 0.f ? x : x * p.slope;
+    }
+  }
+}
+
 // Split-K epilogue: sums the S partial slabs of one output element in a fixed order (deterministic) and applies the
 // same fused epilogue as the main kernel.  One thread = one GEMM row x 4 consecutive channels.
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IGemmP p) {
@@ -1107,6 +1227,7 @@ int g_tap_bm = 0;         // 128: 128-output tiles only in the tap-sharing kerne
 int g_fast_loader = 0;    // -1: always use the generic (per-lane k decode) loader
 int g_narrow16 = 0;       // -1: never use the 16-wide (v_mfma_f32_16x16x4_f32) tile for N <= 16
 int g_skinny_linear = 0;   // -1: never use the skinny dense kernel for M <= 16
+int g_skinny_gather = 0;   // -1: never use the skinny gather kernel for 16 < M <= 256
 int g_row3x3 = 0;         // -1: never use the image-row 3x3 kernel
 int g_tap_window = 0;     // -1: walk every tap even where a whole kernel row / column lies in the zero padding
 
@@ -1351,6 +1472,16 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
       else hipLaunchKernelGGL((skinny_rows_kernel<4>), dim3((unsigned)(phases * ((a.N + 3) / 4))), dim3(256), 0, st, p);
       return launch_status("conv_igemm_f32 (skinny rows)");
     }
+  }
+  // small pixel counts per phase (the U-Net's deep stages at the rollout batch): 32 x 16 tiles without LDS staging or split-K
+  if (g_math_mode == 0 && g_skinny_gather >= 0 && g_fast_loader >= 0 && p.fast_ok && M > 16 && M <= 256 && a.N % 16 == 0 &&
+      a.out_mode == M2H_OUT_NHWC && a.cls_table == nullptr && a.head_w == nullptr && a.operand_format == 0 && p.Ctot % 16 == 0 &&
+      (size_t)a.N * p.Kw * (p.convT ? 4 : 1) >= (size_t)1 << 19) {
+    const int phases = p.convT ? 4 : 1;
+    p.MT = (int)((M + 15) / 16);
+    const long blocks = (long)phases * (a.N / 16) * ((p.MT + 1) / 2);
+    hipLaunchKernelGGL((skinny_gather_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    return launch_status("conv_igemm_f32 (skinny gather)");
   }
   // 3x3 / stride 1 / pad 1 over 16- or 32-channel, 32-pixel-wide images in fp32 math, many rows (AcousticMem in update_sep)
   if (g_math_mode == 0 && g_row3x3 >= 0 && !p.convT && a.nth == 3 && a.ntw == 3 && a.stride == 1 && a.os == 1 && a.ph == 0 && a.pw == 0 &&

@@ -341,7 +341,8 @@ def test_tap_window_skips_only_exact_zeros(math):
     dev = _dev()
     g = torch.Generator(device=dev).manual_seed(3)
     ops.set_math_mode(ops.MATH_BF16X3 if math == "bf16x3" else ops.MATH_FP32)
-    ops.debug_set(23, -1)   # keep the <= 16-row shapes on the tiled engine: this test isolates the tap window
+    ops.debug_set(23, -1)   # keep the small-M shapes on the tiled engine (the skinny kernels split K over their four waves, so a
+    ops.debug_set(24, -1)   # shorter walk regroups the sums): this test isolates the tap window
     try:
         for (B, H, W) in ((3, 2, 2), (14, 2, 2), (5, 2, 16), (2, 4, 4)):
             x = torch.randn(B, H, W, 512, device=dev, generator=g)
@@ -366,6 +367,7 @@ def test_tap_window_skips_only_exact_zeros(math):
     finally:
         ops.debug_set(18, 0)
         ops.debug_set(23, 0)
+        ops.debug_set(24, 0)
         ops.set_math_mode(ops.MATH_FP32)
 
 
@@ -391,3 +393,33 @@ def test_skinny_rows_kernel_on_the_bottleneck_stages():
                 ops.debug_set(23, 0)
         for a, b in zip(outs[0], outs[-1]):
             assert a.shape == b.shape and O.rel_l1(a.cpu(), b.cpu()) < 1e-5, B
+
+
+def test_skinny_gather_kernel_on_the_deep_stages_at_the_rollout_batch():
+    """16 < M <= 256 pixels per phase (the U-Net's deep stages at 14 envs): 32 x 16 tiles with both operands straight into the
+    16x16x4 fp32 MFMA, taps gathered as the engine gathers them, two-source (skip) transposed convs included; against the tiled
+    engine (knob 24 = -1) with BN scale / shift and the activations."""
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(29)
+    cases = []
+    for (B, H, W, Ci, Co) in ((14, 4, 4, 256, 512), (14, 8, 8, 128, 256), (3, 4, 4, 256, 512), (5, 2, 16, 512, 512), (2, 16, 16, 64, 128)):
+        x = torch.randn(B, H, W, Ci, device=dev, generator=g)
+        wp = torch.randn(Co, 16 * Ci, device=dev, generator=g) * 0.03
+        sc, sh = torch.rand(Co, device=dev, generator=g) + 0.5, torch.randn(Co, device=dev, generator=g) * 0.1
+        cases.append(("down", (B, H, W, Ci, Co), lambda x=x, wp=wp, sc=sc, sh=sh, Co=Co: ops.unet_down_fwd(x, wp, sc, sh, Co)))
+    for (B, H, W, C0, C1, Co) in ((14, 2, 2, 512, 512, 256), (14, 4, 4, 256, 256, 128), (3, 2, 2, 512, 512, 256), (14, 1, 1, 512, 0, 512)):
+        x = torch.randn(B, H, W, C0, device=dev, generator=g)
+        skip = torch.randn(B, H, W, C1, device=dev, generator=g) if C1 else None
+        wp = torch.randn(4, Co, 4 * (C0 + C1), device=dev, generator=g) * 0.03
+        sc, sh = torch.rand(Co, device=dev, generator=g) + 0.5, torch.randn(Co, device=dev, generator=g) * 0.1
+        cases.append(("up", (B, H, W, C0, C1, Co), lambda x=x, skip=skip, wp=wp, sc=sc, sh=sh, Co=Co: ops.unet_up_fwd(x, skip, wp, sc, sh, Co)))
+    for kind, shape, fn in cases:
+        outs = {}
+        for knob in (0, -1):
+            ops.debug_set(24, knob)
+            try:
+                outs[knob] = fn().clone()
+            finally:
+                ops.debug_set(24, 0)
+        assert outs[0].shape == outs[-1].shape and O.rel_l1(outs[0].cpu(), outs[-1].cpu()) < 1e-5, (kind, shape)
