@@ -1004,9 +1004,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_row_kernel(const IGemmP p) {
 // split K, and their partial tiles meet through 4 KB of LDS in wave order.  No LDS staging, no barrier in the k-loop.
 // COLS = 16 fills the MFMA tile; COLS = 4 (the other columns repeat the last row) quadruples the block count for N <= 512.
 // K is walked as thn segments of twn*Ctot floats: X contiguous, W at tap (th0 + seg, tw0) of its (nth x ntw x Ctot) row.
-template <int COLS>
-__global__ __launch_bounds__(256) void skinny_rows_kernel(const IGemmP p) {
-  __shared__ float R[4][16][17];
+// NW = waves per block (4, 8 or 16): they split the walked reduction, so a long K over few blocks is a short chain per wave.
+template <int COLS, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_rows_kernel(const IGemmP p) {
+  __shared__ float R[NW][16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int nblk = (p.N + COLS - 1) / COLS;
@@ -1015,7 +1016,7 @@ __global__ __launch_bounds__(256) void skinny_rows_kernel(const IGemmP p) {
   const int L = p.twn * p.Ctot;                               // floats per segment
   const int sps = L >> 4;                                     // 16-float steps per segment
   const int steps = p.thn * sps;
-  const int s0 = (steps * wave) >> 2, s1 = (steps * (wave + 1)) >> 2;
+  const int s0 = (steps * wave) / NW, s1 = (steps * (wave + 1)) / NW;
   const float* xr = p.src0 + (size_t)min(i, p.M - 1) * ((size_t)p.thn * L) + 4 * kq;   // rows past M re-read row M-1 (never stored)
   const float* wr = p.w + ((size_t)phase * p.N + min(n0 + min(i, COLS - 1), p.N - 1)) * p.K + (size_t)p.tw0 * p.Ctot + 4 * kq;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1035,8 +1036,10 @@ __global__ __launch_bounds__(256) void skinny_rows_kernel(const IGemmP p) {
   for (int e = 0; e < 4; ++e) R[wave][kq * 4 + e][i] = acc[e];   // D[m = kq*4 + e][column i]
   __syncthreads();
   const int m = tid >> 4, c = tid & 15, n = n0 + c;
-  if (m < p.M && c < COLS && n < p.N) {
-    float x = (R[0][m][c] + R[1][m][c]) + (R[2][m][c] + R[3][m][c]);
+  if (tid < 256 && m < p.M && c < COLS && n < p.N) {
+    float x = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) x += R[w][m][c];              // wave order
     const float sc = p.scale != nullptr ? p.scale[n] : 1.f;
     const float sh = p.shift != nullptr ? p.shift[n] : 0.f;
     x = x * sc + sh;
@@ -1052,9 +1055,9 @@ __global__ __launch_bounds__(256) void skinny_rows_kernel(const IGemmP p) {
 // the walked reduction (tap window x both sources x channels) and meet through LDS in wave order; BN scale / shift, activation
 // and the NHWC store follow.  The tiled engine occupies the chip at these sizes only through split-K (slabs + a reduce launch,
 // 24-45 us per layer against 2-17 MB of weights); here the weights are streamed MG/MGB times and the activations N/16 times.
-template <int MGB>
-__global__ __launch_bounds__(256) void skinny_gather_kernel(const IGemmP p) {
-  __shared__ float R[4][MGB][16][17];
+template <int MGB, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_gather_kernel(const IGemmP p) {
+  __shared__ float R[NW][MGB][16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int NB = (p.N + 15) >> 4, MS = (p.MT + MGB - 1) / MGB;     // p.MT = 16-row groups of M
@@ -1090,7 +1093,7 @@ __global__ __launch_bounds__(256) void skinny_gather_kernel(const IGemmP p) {
   const float* wrow = wbase + (size_t)min(nb * 16 + i, p.N - 1) * p.K + 4 * kq;
   const int spt = p.Ctot >> 4;                                   // 16-float steps per tap
   const int steps = p.thn * p.twn * spt;
-  const int s0 = (steps * wave) >> 2, s1 = (steps * (wave + 1)) >> 2;
+  const int s0 = (steps * wave) / NW, s1 = (steps * (wave + 1)) / NW;
   f32x4 acc[MGB];
 #pragma unroll
   for (int g = 0; g < MGB; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
@@ -1153,8 +1156,10 @@ __global__ __launch_bounds__(256) void skinny_gather_kernel(const IGemmP p) {
   for (int g = 0; g < MGB; ++g) {
     const int r16 = tid >> 4, c16 = tid & 15;
     const int m = (ms * MGB + g) * 16 + r16, n = nb * 16 + c16;
-    if (m < p.M && n < p.N) {
-      float x = (R[0][g][r16][c16] + R[1][g][r16][c16]) + (R[2][g][r16][c16] + R[3][g][r16][c16]);
+    if (tid < 256 && m < p.M && n < p.N) {
+      float x = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) x += R[w][g][r16][c16];       // wave order
       const float sc = p.scale != nullptr ? p.scale[n] : 1.f;
       const float sh = p.shift != nullptr ? p.shift[n] : 0.f;
       x = x * sc + sh;
@@ -1277,6 +1282,9 @@ static int walked_K(const m2h_conv_args& a) {
   tap_window(a, th0, thn, tw0, twn);
   return thn * twn * Ctot;
 }
+
+// waves per block of the skinny kernels: keep a wave's chain of 16-float steps at about 16
+static int skinny_waves(int steps) { return steps > 160 ? 16 : (steps > 80 ? 8 : 4); }
 
 // Tile choice: N picks the width; skinny M (rollout batches, GRU steps: weight-streaming bound, nothing to re-use along M)
 // gets 32- or 64-row tiles so that four times as many blocks stream the weights.
@@ -1468,8 +1476,18 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
                  a.offh + p.th0 == 0 && a.offw + p.tw0 == 0;
     if (dense) {
       const int phases = p.convT ? 4 : 1;
-      if (a.N * phases >= 64 * 16) hipLaunchKernelGGL((skinny_rows_kernel<16>), dim3((unsigned)(phases * ((a.N + 15) / 16))), dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((skinny_rows_kernel<4>), dim3((unsigned)(phases * ((a.N + 3) / 4))), dim3(256), 0, st, p);
+      const int nw = skinny_waves(p.Kw / 16);
+      const bool wide = a.N * phases >= 64 * 16;
+      const dim3 grid((unsigned)(phases * (wide ? (a.N + 15) / 16 : (a.N + 3) / 4))), blk(64 * nw);
+#define M2H_SKINNY_ROWS(NW_)                                                                       \
+  do {                                                                                             \
+    if (wide) hipLaunchKernelGGL((skinny_rows_kernel<16, NW_>), grid, blk, 0, st, p);              \
+    else hipLaunchKernelGGL((skinny_rows_kernel<4, NW_>), grid, blk, 0, st, p);                    \
+  } while (0)
+      if (nw == 4) M2H_SKINNY_ROWS(4);
+      else if (nw == 8) M2H_SKINNY_ROWS(8);
+      else M2H_SKINNY_ROWS(16);
+#undef M2H_SKINNY_ROWS
       return launch_status("conv_igemm_f32 (skinny rows)");
     }
   }
@@ -1480,7 +1498,10 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
     const int phases = p.convT ? 4 : 1;
     p.MT = (int)((M + 15) / 16);
     const long blocks = (long)phases * (a.N / 16) * ((p.MT + 1) / 2);
-    hipLaunchKernelGGL((skinny_gather_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    const int nw = skinny_waves(p.Kw / 16);
+    if (nw == 4) hipLaunchKernelGGL((skinny_gather_kernel<2, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else if (nw == 8) hipLaunchKernelGGL((skinny_gather_kernel<2, 8>), dim3((unsigned)blocks), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((skinny_gather_kernel<2, 16>), dim3((unsigned)blocks), dim3(1024), 0, st, p);
     return launch_status("conv_igemm_f32 (skinny gather)");
   }
   // 3x3 / stride 1 / pad 1 over 16- or 32-channel, 32-pixel-wide images in fp32 math, many rows (AcousticMem in update_sep)
