@@ -1048,7 +1048,8 @@ __global__ __launch_bounds__(64 * NW) void skinny_rows_kernel(const IGemmP p) {
   }
 }
 
-// Skinny implicit-GEMM conv for small pixel counts (M <= 256 rows per phase: the U-Net's deep stages at the rollout batch), fp32
+// Skinny implicit-GEMM conv for small pixel counts (M <= 1024 rows per phase: the U-Net's deeper stages at the rollout batch, the
+// policy's Linear layers over a 280-sample update batch), fp32
 // MFMA, no LDS staging: a block computes a 16*MGB (pixels) x 16 (channels) tile of one phase; lane (row i, k-quarter) loads 16 bytes
 // of its weight row and of each of its MGB pixel rows (gathered per tap exactly as the engine above does, zero outside the image;
 // the activations are a few hundred KB and stay in L1 / L2) straight into v_mfma_f32_16x16x4_f32 registers; the four waves split
@@ -1491,10 +1492,10 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
       return launch_status("conv_igemm_f32 (skinny rows)");
     }
   }
-  // small pixel counts per phase (the U-Net's deep stages at the rollout batch): 32 x 16 tiles without LDS staging or split-K
-  if (g_math_mode == 0 && g_skinny_gather >= 0 && g_fast_loader >= 0 && p.fast_ok && M > 16 && M <= 256 && a.N % 16 == 0 &&
-      a.out_mode == M2H_OUT_NHWC && a.cls_table == nullptr && a.head_w == nullptr && a.operand_format == 0 && p.Ctot % 16 == 0 &&
-      (size_t)a.N * p.Kw * (p.convT ? 4 : 1) >= (size_t)1 << 19) {
+  // small pixel counts per phase (<= 1024; knob 24 > 0 overrides the limit): 32 x 16 tiles without LDS staging or split-K
+  if (g_math_mode == 0 && g_skinny_gather >= 0 && g_fast_loader >= 0 && p.fast_ok && M > 16 && M <= (g_skinny_gather > 0 ? g_skinny_gather : 1024) &&
+      a.N % 16 == 0 && a.out_mode == M2H_OUT_NHWC && a.cls_table == nullptr && a.head_w == nullptr && a.operand_format == 0 &&
+      p.Ctot % 16 == 0 && (size_t)a.N * p.Kw * (p.convT ? 4 : 1) >= (size_t)1 << 16) {
     const int phases = p.convT ? 4 : 1;
     p.MT = (int)((M + 15) / 16);
     const long blocks = (long)phases * (a.N / 16) * ((p.MT + 1) / 2);
