@@ -1,9 +1,11 @@
 """Adam + gradient-norm clipping over flat buffers, arithmetic in libm2h.so (K19/K20 of SURVEY 2.2).
 
-``FlatAdam`` is a ``torch.optim.Optimizer`` (so ``LambdaLR`` of ppo_trainer.py:711-718 drives its lr) whose parameters and
-gradients are views into two flat fp32 buffers: one sum-of-squares reduction gives the clip coefficient (kept on the device,
-no host sync), one kernel applies clip + Adam to all parameters, and -- for DD-PPO -- the flat gradient buffer is the single
-RCCL all-reduce payload (23.3 MB for the policy).  Semantics are torch.optim.Adam's (betas 0.9/0.999, no weight
+``FlatAdam`` is a ``torch.optim.Optimizer`` (so ``LambdaLR`` of ppo_trainer.py:711-718 drives its lr) whose parameters are views
+into one flat fp32 buffer; the gradients autograd leaves in ``p.grad`` are gathered into a second flat buffer by one batched
+copy (``m2h_rows_copy``: zero_grad() sets the grads to None, so autograd hands its gradient tensors over instead of launching one
+accumulation add per parameter into pre-zeroed storage -- 32 adds and a memset per policy epoch): one sum-of-squares reduction
+then gives the clip coefficient (kept on the device, no host sync), one kernel applies clip + Adam to all parameters, and -- for
+DD-PPO -- the flat gradient buffer is the single RCCL all-reduce payload (23.3 MB for the policy).  Semantics are torch.optim.Adam's (betas 0.9/0.999, no weight
 decay, no amsgrad) with eps from the config (1e-5, ppo.py:48-55) and nn.utils.clip_grad_norm_'s coefficient.
 """
 import torch
@@ -40,9 +42,15 @@ class FlatAdam(torch.optim.Optimizer):
                 k = p.numel()
                 self.flat_p[off:off + k].copy_(p.data.reshape(-1))
                 p.data = self.flat_p[off:off + k].view_as(p)          # parameter storage now lives in the flat buffer
-                p.grad = self.flat_g[off:off + k].view_as(p)          # autograd accumulates in place into the flat buffer
                 off += k
         self.n = n
+        self._offsets = []
+        off = 0
+        for p in ps:
+            self._offsets.append(off)
+            off += p.numel()
+        self._no_idx = torch.zeros(1, device=dev, dtype=torch.int64)      # rows_copy's index argument (no item uses an index)
+        self._gathered = True                                             # flat_g (zeros) is consistent with "no gradients yet"
         self._built = True
 
     def build(self):
@@ -51,18 +59,47 @@ class FlatAdam(torch.optim.Optimizer):
         if not self._built:
             self._build()
 
-    def zero_grad(self, set_to_none=False):
+    def zero_grad(self, set_to_none=True):
+        """Gradients to None (autograd then hands over its gradient tensors; they are gathered into the flat buffer by
+        grad_buffer() / step()).  set_to_none=False zeroes existing gradient tensors in place instead."""
         if not self._built:
             self._build()
-        self.flat_g.zero_()
-        for p in self._ps:  # re-attach views if something replaced them
-            if p.grad is None or p.grad.data_ptr() < self.flat_g.data_ptr() or p.grad.data_ptr() >= self.flat_g.data_ptr() + 4 * self.n:
-                raise RuntimeError("FlatAdam: a parameter's .grad no longer points into the flat buffer (was it set to None?)")
+        for p in self._ps:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+        self._gathered = False
+
+    @torch.no_grad()
+    def _gather(self):
+        """p.grad of every parameter -> its slice of the flat gradient buffer (one batched copy; None counts as zeros)."""
+        if self._gathered:
+            return
+        items, missing = [], False
+        for p, off in zip(self._ps, self._offsets):
+            g = p.grad
+            if g is None:
+                missing = True
+                continue
+            if g.dtype != torch.float32 or g.device != self.flat_g.device:
+                raise RuntimeError("FlatAdam: gradients must be fp32 tensors on the parameters' GPU")
+            dst = self.flat_g[off:off + p.numel()]
+            if g.data_ptr() == dst.data_ptr():
+                continue                                   # already a view of its slice
+            items.append((g.contiguous().view(-1), dst, -1, -1))
+        if missing:
+            self.flat_g.zero_()
+        if items:
+            ops.rows_copy(items, self._no_idx)
+        self._gathered = True
 
     def grad_buffer(self):
-        """The flat gradient (all-reduce payload)."""
+        """The flat gradient (all-reduce payload), gathered from the parameters' .grad."""
         if not self._built:
             self._build()
+        self._gather()
         return self.flat_g
 
     @torch.no_grad()
@@ -71,6 +108,8 @@ class FlatAdam(torch.optim.Optimizer):
         (1/world_size after a sum all-reduce; the clip norm is computed on the scaled gradient like DDP's averaged grads)."""
         if not self._built:
             raise RuntimeError("FlatAdam.step before zero_grad()/backward")
+        self._gather()
+        self._gathered = False   # the next step gathers afresh (gradients may be replaced without zero_grad: HIP-graph replays)
         g = self.param_groups[0]
         lr, eps, (b1, b2) = g["lr"], g["eps"], g["betas"]
         self.t += 1

@@ -164,7 +164,7 @@ def test_l1_loss_and_flat_adam_match_torch():
         om.zero_grad()
         for p_, q_, gg in zip(pt, pm, gs):
             p_.grad = gg.clone()
-            q_.grad.copy_(gg)
+            q_.grad = gg.to(dev)     # (FlatAdam gathers the gradients autograd leaves in .grad; every third step below: none)
         torch.nn.utils.clip_grad_norm_(pt, 0.5)
         ot.step()
         om.step(max_grad_norm=0.5)
