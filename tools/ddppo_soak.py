@@ -1,0 +1,14 @@
+import sys, time
+sys.path.insert(0, "move2hear-active-av-separation_amd")
+import numpy as np, torch
+from m2h import synthetic
+from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config
+tr = PPOTrainer(near_target_config(), torch.device("cuda", 0)); tr.setup()
+tr.actor_critic.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), 1).items()})
+for block in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        res = tr.train_cycle()
+    torch.cuda.synchronize()
+    print("cycles %d-%d: %.3f s/cycle, reserved %.2f GB, allocated %.2f GB, pol %s sep %s" % (10 * block, 10 * block + 9, (time.perf_counter() - t0) / 10,
+          torch.cuda.memory_reserved() / 2**30, torch.cuda.memory_allocated() / 2**30, [round(x, 4) for x in res["pol_losses"]], [round(x, 4) for x in res["sep_losses"]]))
