@@ -128,8 +128,13 @@ int m2h_conv_igemm_f32(const m2h_conv_args* args /* host */, m2h_stream stream);
  * (bit-reproducible) and applies the fused epilogue. */
 size_t m2h_conv_igemm_workspace_bytes(const m2h_conv_args* args /* host */);
 
-/* Tuning/debug knobs (process-wide, not for production use): knob 0 = force split-K factor (0 auto, -1 never),
- * knob 1 = force LDS stages of the narrow-N tile configs (0 auto, 1, 2). */
+/* Tuning/debug knobs (process-wide, not for production use; 0 = automatic everywhere): 0 force split-K factor (-1 never), 1 / 2 LDS
+ * stages of the narrow / wide tiles, 3 skinny-M tiles (-1 off), 4 16-wide MFMA tile (-1 off), 7 extra dynamic LDS, 8 phase-major
+ * transposed-conv order (-1 off), 9 scalar-decode loader (-1 off), 11 weight-gradient block target, 14 arithmetic (1 = bf16x3 split
+ * products; what ops.set_math_mode sets), 15 / 16 tap-sharing transposed-conv kernel (-1 off / tile), 18 tap window (-1 off), 21 / 22
+ * image-row 3x3 weight-gradient / conv kernels (-1 off), 23 skinny rows kernel for M <= 16 (-1 off), 24 skinny gather kernel (-1 off,
+ * > 0 = pixel limit).  The launches that take a specialised kernel say which in the source (csrc/conv_igemm.hip, conv_bwd.hip);
+ * retired experiment numbers are accepted and ignored. */
 int m2h_debug_set(int knob, int value);
 
 /*
