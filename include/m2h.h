@@ -262,10 +262,13 @@ typedef struct m2h_episode_stats {
   float* current_episode_bin_losses;
   float* current_episode_mono_losses;
   float* current_episode_monoFromMem_losses;
+  float* episode_ndgs; /* the env's two distance infos of the step that ends an episode (ppo_trainer.py:332-337, :434-435) */
+  float* episode_dgs;
 } m2h_episode_stats;
+/* ndgs / dgs: [N] normalised / absolute geodesic distance to the target reported by the env for this step; NULL = zeros. */
 int m2h_episode_stats_update(const m2h_episode_stats* st, const float* rewards, const float* dist_probs, const float* bin_losses,
-                             const float* mono_losses, const float* monoFromMem_losses, const float* not_done, int N, int A,
-                             m2h_stream stream);
+                             const float* mono_losses, const float* monoFromMem_losses, const float* not_done, const float* ndgs,
+                             const float* dgs, int N, int A, m2h_stream stream);
 
 /* Batched row copies with DEVICE-resident row indices: RolloutStoragePol.insert / RolloutStorageSep.insert and the rollout
  * step's reads of row `step` (common/rollout_storage.py:68-96, 372-390; ppo_trainer.py:262-300) when the step is replayed from

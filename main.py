@@ -23,7 +23,8 @@ def main():
     parser.add_argument("--run-type", choices=["train", "eval"], default="train")
     parser.add_argument("--exp-config", type=str, default=None, help="path to the experiment YAML")
     parser.add_argument("--model-dir", default=None)
-    parser.add_argument("--cycles", type=int, default=1, help="ppo: training cycles to run; passive: epochs")
+    parser.add_argument("--cycles", type=int, default=None,
+                        help="ppo: cap on the training cycles (default: NUM_UPDATES / num_updates_per_cycle, as the reference); passive: epochs (default 1)")
     parser.add_argument("--eval-ckpt", default=None, help="eval: checkpoint file (default: <model-dir>/data/ckpt.0.pth if present)")
     parser.add_argument("--eval-episodes", type=int, default=None, help="eval: episodes to aggregate (default: NUM_PROCESSES)")
     parser.add_argument("opts", default=None, nargs=argparse.REMAINDER, help="KEY VALUE overrides")
@@ -33,7 +34,22 @@ def main():
     config = get_config(args.exp_config, args.opts, args.model_dir, args.run_type, search_dirs=(".", os.path.dirname(args.exp_config or ".")))
     trainer_init = get_trainer(config.TRAINER_NAME)
     assert trainer_init is not None, f"{config.TRAINER_NAME} is not supported"
-    trainer = trainer_init(config, torch.device("cuda", 0))
+    if config.TRAINER_NAME == "ppo":
+        # one process per GPU: rendezvous from torch.distributed.run's variables (what init_distrib_slurm reads, ddppo_utils.py:117-165)
+        # BEFORE any other GPU work; world rank / size go to the trainer (per-rank seeds, parameter broadcast, gradient all-reduce)
+        from m2h.rl.ppo import ddppo_utils
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        device = torch.device("cuda", local_rank)
+        world_rank, world_size = 0, 1
+        if getattr(config, "use_ddppo", False):
+            os.environ.setdefault("MASTER_ADDR", str(getattr(config, "master_addr", "127.0.0.1")))
+            os.environ.setdefault("MASTER_PORT", str(getattr(config, "master_port", 8738)))
+            torch.cuda.set_device(device)
+            backend = {"nccl": "nccl", "gloo": "gloo"}[str(getattr(config, "ddppo_distrib_backend", "NCCL")).lower()]
+            _lr, world_rank, world_size = ddppo_utils.init_distrib(backend, device=device)
+        trainer = trainer_init(config, device, world_rank=world_rank, world_size=world_size)
+    else:
+        trainer = trainer_init(config, torch.device("cuda", 0))
     trainer.setup()
     if args.run_type == "eval":
         if config.TRAINER_NAME != "ppo":
@@ -48,13 +64,14 @@ def main():
         print(json.dumps(stats, indent=1))
         return
     if config.TRAINER_NAME == "passive":
-        for i, rec in enumerate(trainer.train(num_epochs=args.cycles)):
+        for i, rec in enumerate(trainer.train(num_epochs=args.cycles or 1)):
             print("epoch %d  train bin/mono %.4f %.4f   val %.4f %.4f" % (i, *rec["train"], *rec["val"]))
     else:
+        # the reference loop (ppo_trainer.py:730-1011): NUM_UPDATES / num_updates_per_cycle cycles, window statistics per policy
+        # update, ckpt.<k>.pth every CHECKPOINT_INTERVAL separator updates, written by world rank 0 only
         for i, rec in enumerate(trainer.train(args.cycles)):
-            print("cycle %d  %d env-steps in %.2f s  pol losses %s  sep losses %s" % (i, rec["env_steps"], rec["seconds"], rec["pol_losses"], rec["sep_losses"]))
-        if config.CHECKPOINT_FOLDER:
-            trainer.save_checkpoint("ckpt.0.pth")
+            if trainer.world_rank == 0:
+                print("cycle %d  %d env-steps in %.2f s  pol losses %s  sep losses %s" % (i, rec["env_steps"], rec["seconds"], rec["pol_losses"], rec["sep_losses"]))
 
 
 if __name__ == "__main__":

@@ -452,11 +452,14 @@ __global__ __launch_bounds__(1024) void stft_l2_kernel(const float* __restrict__
 // (cur += x; total += nd * (cur / steps); cur *= not_done), without fused multiply-adds.
 __global__ void episode_stats_kernel(m2h_episode_stats st, const float* __restrict__ rewards, const float* __restrict__ dist_probs,
                                      const float* __restrict__ bin_losses, const float* __restrict__ mono_losses,
-                                     const float* __restrict__ mem_losses, const float* __restrict__ not_done, int N, int A) {
+                                     const float* __restrict__ mem_losses, const float* __restrict__ not_done,
+                                     const float* __restrict__ ndgs, const float* __restrict__ dgs, int N, int A) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
   const float m = not_done[e];
   const float nd = 1.f - m;
+  if (ndgs) st.episode_ndgs[e] = __fadd_rn(st.episode_ndgs[e], __fmul_rn(nd, ndgs[e]));
+  if (dgs) st.episode_dgs[e] = __fadd_rn(st.episode_dgs[e], __fmul_rn(nd, dgs[e]));
   const float cr = __fadd_rn(st.current_episode_reward[e], rewards[e]);
   const float cs = __fadd_rn(st.current_episode_step[e], 1.f);
   const float cb = __fadd_rn(st.current_episode_bin_losses[e], bin_losses[e]);
@@ -980,14 +983,14 @@ int m2h_stft_l2(const float* mix, const float* pred, int Cp, const float* gt_com
 }
 
 int m2h_episode_stats_update(const m2h_episode_stats* st, const float* rewards, const float* dist_probs, const float* bin_losses,
-                             const float* mono_losses, const float* monoFromMem_losses, const float* not_done, int N, int A,
-                             m2h_stream stream) {
+                             const float* mono_losses, const float* monoFromMem_losses, const float* not_done, const float* ndgs,
+                             const float* dgs, int N, int A, m2h_stream stream) {
   M2H_REQUIRE(st && rewards && dist_probs && bin_losses && mono_losses && monoFromMem_losses && not_done && N > 0 && A > 0,
               "episode_stats_update: bad arguments");
   const float* const* fields = reinterpret_cast<const float* const*>(st);
   for (size_t i = 0; i < sizeof(m2h_episode_stats) / sizeof(float*); ++i) M2H_REQUIRE(fields[i], "episode_stats_update: null statistics tensor");
   hipLaunchKernelGGL(episode_stats_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), *st, rewards, dist_probs, bin_losses,
-                     mono_losses, monoFromMem_losses, not_done, N, A);
+                     mono_losses, monoFromMem_losses, not_done, ndgs, dgs, N, A);
   return launch_status("episode_stats_update");
 }
 

@@ -88,7 +88,7 @@ EPISODE_STATS_FIELDS = (
     "episode_rewards", "episode_counts", "episode_steps", "episode_dist_probs", "episode_bin_losses_allSteps",
     "episode_mono_losses_lastStep", "episode_mono_losses_allSteps", "episode_monoFromMem_losses_lastStep",
     "episode_monoFromMem_losses_allSteps", "current_episode_reward", "current_episode_step", "current_episode_dist_probs",
-    "current_episode_bin_losses", "current_episode_mono_losses", "current_episode_monoFromMem_losses")
+    "current_episode_bin_losses", "current_episode_mono_losses", "current_episode_monoFromMem_losses", "episode_ndgs", "episode_dgs")
 
 
 class EpisodeStats(ctypes.Structure):
@@ -173,7 +173,7 @@ SIGNATURES = {
     "m2h_sep_slice_input_fmt": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "m2h_gather_envs": [_P, _P, _P, _I, _I, _I, _Z, _P],
     "m2h_gru_step": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
-    "m2h_episode_stats_update": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "m2h_episode_stats_update": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_rows_copy": [_P, _I, _P, _P],
     "m2h_step_index_advance": [_P, _I, _I, _P],
     "m2h_synth_env_step": [_P, _P, _P, _I, _I, _P],

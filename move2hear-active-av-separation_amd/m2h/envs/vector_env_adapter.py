@@ -24,6 +24,7 @@ class HostVectorEnvAdapter:
         self.num_envs = envs.num_envs
         self.observation_spaces = envs.observation_spaces
         self.action_spaces = envs.action_spaces
+        self.last_dones = [False] * self.num_envs   # host copy of the last step's `dones` (the trainer's episode-step counter)
 
     def reset(self):
         return dict(batch_obs(self.envs.reset(), self.device))
@@ -32,6 +33,7 @@ class HostVectorEnvAdapter:
         """actions: [N,1] int64 device tensor (Policy.act).  -> (obs dict, rewards [N,1], not-done masks [N,1], infos)."""
         outputs = self.envs.step([int(a) for a in actions.reshape(-1).tolist()])          # ppo_trainer.py:323
         observations, rewards, dones, infos = [list(x) for x in zip(*outputs)]             # :326
+        self.last_dones = [bool(d) for d in dones]
         batch = dict(batch_obs(observations, self.device))                                  # :328
         masks = torch.tensor([[0.0] if done else [1.0] for done in dones], dtype=torch.float32, device=self.device)   # :329-331
         rew = torch.tensor(rewards, dtype=torch.float32, device=self.device).reshape(-1, 1)

@@ -561,9 +561,10 @@ def gather_envs(src, perm):
     return dst
 
 
-def episode_stats_update(stats, rewards, dist_probs, bin_losses, mono_losses, monoFromMem_losses, not_done):
-    """The per-episode bookkeeping of one rollout step (ppo_trainer.py:407-478) in one launch.  stats: object with the fifteen
-    [N,1] / [N,A] float tensors named in _lib.EPISODE_STATS_FIELDS, updated in place."""
+def episode_stats_update(stats, rewards, dist_probs, bin_losses, mono_losses, monoFromMem_losses, not_done, ndgs=None, dgs=None):
+    """The per-episode bookkeeping of one rollout step (ppo_trainer.py:407-478) in one launch.  stats: object with the seventeen
+    [N,1] / [N,A] float tensors named in _lib.EPISODE_STATS_FIELDS, updated in place.  ndgs / dgs: the env's distance infos of
+    this step ([N,1]; None = zeros)."""
     st = _lib.EpisodeStats()
     for name in _lib.EPISODE_STATS_FIELDS:
         t = getattr(stats, name)
@@ -575,9 +576,17 @@ def episode_stats_update(stats, rewards, dist_probs, bin_losses, mono_losses, mo
     N, A = ins[1].shape
     if any(t.numel() != N for t in ins[:1] + ins[2:]) or stats.episode_dist_probs.numel() != N * A or stats.episode_rewards.numel() != N:
         raise RuntimeError("m2h.episode_stats_update: per-env tensors must hold one value per env (dist_probs: [N, A])")
+    extra = []
+    for t in (ndgs, dgs):
+        if t is not None:
+            t = t.contiguous()
+            _chk(t, "episode_stats_update")
+            if t.numel() != N:
+                raise RuntimeError("m2h.episode_stats_update: ndgs / dgs must hold one value per env")
+        extra.append(t)
     with torch.cuda.device(ins[0].device):
-        _lib.check(_lib.load().m2h_episode_stats_update(ctypes.byref(st), *[_ptr(t) for t in ins], N, A, _stream(ins[0])),
-                   "m2h_episode_stats_update")
+        _lib.check(_lib.load().m2h_episode_stats_update(ctypes.byref(st), *[_ptr(t) for t in ins], *[_ptr(t) if t is not None else None for t in extra],
+                                                        N, A, _stream(ins[0])), "m2h_episode_stats_update")
 
 
 def rows_copy(items, idx):

@@ -55,6 +55,7 @@ class PPO(nn.Module):
         self.optimizer_sep = FlatAdam(sep_params, lr=lr_sep, eps=eps)
         self.device = next(actor_critic.parameters()).device
         self._world = 1
+        self._distributed = False
         self._sep_cache = None
         # overlap_grad_reduce: None = on when distributed (init_distributed), True = also at world size 1 (the side-stream
         # schedule without the collective; tests), False = the synchronous order of the reference
@@ -82,7 +83,7 @@ class PPO(nn.Module):
     def get_advantages(self, rollouts_pol):
         if not self.use_normalized_advantage:
             return ops.advantages(rollouts_pol.returns, rollouts_pol.value_preds, 0)[0]
-        if self._world > 1:
+        if self._distributed:   # DDPPO after init_distributed -- at world size 1 too (reference :311: get_advantages is re-bound)
             return self._get_advantages_distributed(rollouts_pol)
         return ops.advantages(rollouts_pol.returns, rollouts_pol.value_preds, 1, EPS_PPO)[0]
 
@@ -94,6 +95,7 @@ class PPO(nn.Module):
     def init_distributed(self, find_unused_params: bool = True) -> None:
         """Broadcast rank 0's parameters/buffers and switch gradient reduction on (reference :286-311)."""
         self._world = ddppo_utils.world_size()
+        self._distributed = True
         self.find_unused_params = find_unused_params
         ddppo_utils.broadcast_parameters(list(self.actor_critic.parameters()) + list(self.actor_critic.buffers()))
 
@@ -134,6 +136,7 @@ class PPO(nn.Module):
         if (self.use_hip_graphs and self._pol_updates > 1 and self.num_mini_batch == 1 and not ops.timing_enabled()
                 and getattr(rollouts_pol, "full_batch_views", False)):
             return self._update_pol_graph(rollouts_pol, advantages)  # (the first update runs kernel by kernel: warm-up)
+        self._pol_graph = None  # an eager epoch re-binds p.grad to fresh tensors: a graph captured earlier would write stale ones
         acc = torch.zeros(4, device=self.device)
         for _e in range(self.ppo_epoch):
             for _mb, sample in enumerate(rollouts_pol.recurrent_generator(advantages, self.num_mini_batch)):

@@ -3,8 +3,10 @@ around the m2h modules and the synthetic on-device environment.
 
 Kept: the schedule (num_updates_per_cycle x (num_steps rollout + update_pol), then num_updates_per_cycle x update_sep;
 :730-1011), _collect_rollout_step's data flow (:253-478), reward override incl. the extra reward at MAX_EPISODE_STEPS-2
-(:385-405), STFT-L2 bookkeeping (:407-420), linear LR / clip decay (:733-739, :711-718), per-rank seeding (:609-611), the
-stats all-reduces (:839-860).  Changed in mechanism only:
+(:385-405; its EFFECTIVE value, see _rollout_step_device), STFT-L2 bookkeeping (:407-420), linear LR / clip decay (:733-739,
+:711-718), per-rank seeding (:609-611), the stats all-reduces and window-of-N statistics (:790-977), the checkpoint interval
+(:1007-1009).  Pinned against the reference's own ``PPOTrainer.train`` run (tests/golden/trainer_*.npz, oracle/gen_trainer_golden.py;
+tests/test_gpu_trainer_golden.py).  Changed in mechanism only:
   * no host sync inside the rollout step: the env consumes device actions, rewards/losses/statistics stay on the device
     (the reference does ~50 ``.item()``/``.cpu()`` per step);
   * the separator outputs for the *next* observation, which the reference computes for the reward (:358-373), are re-used as
@@ -16,6 +18,7 @@ Out of scope: Habitat env construction, TensorBoard, the eval loop (:1015-1551).
 import os
 import time
 import warnings
+from collections import deque
 from types import SimpleNamespace
 
 import torch
@@ -38,6 +41,8 @@ def near_target_config(**over):
              use_linear_clip_decay=True, use_linear_lr_decay=True, sep_reward_weight=1.0, nav_reward_weight=0.0,
              extra_reward_multiplier=10.0, reward_window_size=50, use_ddppo=True, CHECKPOINT_FOLDER=None,
              switch_policy=False, time_thres_for_pol_switch=80, deterministic_eval=False,   # config/default.py:99-101
+             ddppo_distrib_backend="NCCL", master_port=8738, master_addr="127.0.0.1",       # config/default.py:94-97
+             short_rollout_threshold=1.0, sync_frac=0.6,  # nearTarget.yaml:58-59: at 1.0 the preemption of :775-781 never triggers; not built
              use_hip_graphs=True,       # build-side key: replay the rollout step and the update_pol epoch from HIP graphs (same kernels, same results)
              overlap_grad_reduce=None)  # build-side key: None = overlap the last all-reduce + step of an update when distributed
     c.update(over)
@@ -91,7 +96,7 @@ class PPOTrainer:
             m.eval()
             for p in m.parameters():
                 p.requires_grad_(False)
-        if cfg.use_ddppo and self.world_size > 1:
+        if cfg.use_ddppo:  # :639-640 -- at world size 1 too: DDPPO normalises advantages with the distributed (biased) variance
             self.agent.init_distributed(find_unused_params=True)
         N = self.envs.num_envs
         space = self.envs.observation_spaces[0]
@@ -110,8 +115,8 @@ class PPOTrainer:
         self.stats = SimpleNamespace(
             episode_rewards=z(N, 1), episode_counts=z(N, 1), episode_steps=z(N, 1), episode_dist_probs=z(N, 3),
             episode_bin_losses_allSteps=z(N, 1), episode_mono_losses_lastStep=z(N, 1), episode_mono_losses_allSteps=z(N, 1),
-            episode_monoFromMem_losses_lastStep=z(N, 1), episode_monoFromMem_losses_allSteps=z(N, 1),
-            current_episode_reward=z(N, 1), current_episode_step=z(N, 1), current_episode_dist_probs=z(N, 3),
+            episode_monoFromMem_losses_lastStep=z(N, 1), episode_monoFromMem_losses_allSteps=z(N, 1), episode_ndgs=z(N, 1),
+            episode_dgs=z(N, 1), current_episode_reward=z(N, 1), current_episode_step=z(N, 1), current_episode_dist_probs=z(N, 3),
             current_episode_bin_losses=z(N, 1), current_episode_mono_losses=z(N, 1), current_episode_monoFromMem_losses=z(N, 1))
         self._episode_step_host = 0
         # the reference steps the LR schedulers at the START of each sub-update (:733-735, :981-982); torch warns about that order
@@ -120,6 +125,10 @@ class PPOTrainer:
         self.lr_scheduler_sep = LambdaLR(self.agent.optimizer_sep, lr_lambda=lambda x: linear_decay(x, cfg.NUM_UPDATES))
         self.count_steps = 0
         self.num_updates_done = 0
+        self.num_sep_updates_done = 0
+        self.count_checkpoints = 0
+        self.windows = {}      # window-of-N statistics (:699-709): name -> deque of summed-over-ranks [N,*] tensors
+        self.scalars = []      # (count_steps, {tag: value}) per policy update: what the reference hands its TensorboardWriter
 
     # ------------------------------------------------------------------ rollout step (reference :253-478)
     def _separate(self, obs):
@@ -134,6 +143,7 @@ class PPOTrainer:
         update_sep); otherwise it is enqueued kernel by kernel."""
         cfg = self.config
         override = cfg.sep_reward_weight == 1.0 and cfg.nav_reward_weight == 0.0
+        # :395 reads env 0's step count (current_episode_step[0].item(): a host sync); it is known on the host here
         extra = override and self._episode_step_host == cfg.MAX_EPISODE_STEPS - 2
         on_device = hasattr(self.envs, "step_device")  # host-side envs (the real simulator) report `done` themselves
         done = self.envs.t + 1 >= self.envs.episode_len if on_device else None
@@ -147,7 +157,9 @@ class PPOTrainer:
         # host-side counters
         if on_device:
             self.envs.t = 0 if done else self.envs.t + 1
-        self._episode_step_host = (self._episode_step_host + 1) % cfg.MAX_EPISODE_STEPS
+            self._episode_step_host = 0 if done else self._episode_step_host + 1
+        else:  # the adapter has the step's `dones` on the host already (it built the not-done masks from them)
+            self._episode_step_host = 0 if self.envs.last_dones[0] else self._episode_step_host + 1
         return self.envs.num_envs
 
     def _rollout_step_device(self, cache, at, extra, done):
@@ -185,15 +197,21 @@ class PPOTrainer:
         next_pred_monoFromMem = ac.get_monoFromMem_masked(next_pred_mono, pred_monoFromMem, masks)
         if cfg.sep_reward_weight == 1.0 and cfg.nav_reward_weight == 0.0:  # :385-405
             nxt = ops.sq_stats(next_pred_monoFromMem, batch["gt_mono_comps"], 0)
-            cur = ops.sq_stats(pred_monoFromMem, step_observation["gt_mono_comps"], 0)
-            rewards = ops.rewards_from_stats(nxt, cur, masks, L, True)
             if extra:
-                rewards = rewards + ops.rewards_from_stats(nxt, None, masks, L, False, cfg.extra_reward_multiplier)
+                # What the reference computes on this step: override_rewards writes into the list it is given and returns that
+                # same list (env_utils.py:692-706), so the "extra" call (:396-402) overwrites the quality-improvement rewards and
+                # ``np.array(rewards) + np.array(rewards_extra)`` (:405) adds the list to itself: 2 x multiplier x util(next).
+                # Pinned by tests/golden/trainer_near.npz (the reference's own loop).
+                rewards = ops.rewards_from_stats(nxt, None, masks, L, False, 2.0 * cfg.extra_reward_multiplier)
+            else:
+                cur = ops.sq_stats(pred_monoFromMem, step_observation["gt_mono_comps"], 0)
+                rewards = ops.rewards_from_stats(nxt, cur, masks, L, True)
         # STFT-L2 bookkeeping (:407-420)
         bin_losses = ops.stft_l2(pred_binSepMasks, step_observation["gt_bin_comps"], 2, mix=step_observation["mixed_bin_audio_mag"])
         mono_losses = ops.stft_l2(pred_mono, step_observation["gt_mono_comps"], 1)
         monoFromMem_losses = ops.stft_l2(pred_monoFromMem, step_observation["gt_mono_comps"], 1)
-        ops.episode_stats_update(st, rewards, distribution_probs, bin_losses, mono_losses, monoFromMem_losses, masks)  # :421-478
+        ops.episode_stats_update(st, rewards, distribution_probs, bin_losses, mono_losses, monoFromMem_losses, masks,   # :421-478
+                                 infos.get("normalized_geo_distance_to_target_audio_source"), infos.get("geo_distance_to_target_audio_source"))
         pol_args = (batch, recurrent_hidden_states_pol, actions, actions_log_probs, values, rewards, masks)
         pol_kw = dict(pred_binSepMasks=pred_binSepMasks, pred_mono=pred_mono, pred_monoFromMem=pred_monoFromMem)
         if at is None:
@@ -235,7 +253,7 @@ class PPOTrainer:
             self.actor_critic._fence("mem")
             MF.refresh_pack_memos()
             gs.epoch = MF.param_epoch()
-            where = tuple(p.data_ptr() for p in self.actor_critic.parameters())
+            where = (ops.math_mode(),) + tuple(p.data_ptr() for p in self.actor_critic.parameters())
             if where != gs.where:  # a parameter was re-allocated (first build, .to(), ...): captured addresses are stale
                 gs.graphs.clear()
                 gs.where = where
@@ -274,8 +292,11 @@ class PPOTrainer:
         self._next_cache = None  # acoustic_mem changed: the cached next-step memory output is stale
         return out
 
-    def train_cycle(self):
-        """One cycle of the reference schedule (:730-1011): returns a dict of timings and losses."""
+    def train_cycle(self, log_stats=False, checkpoint=False):
+        """One cycle of the reference schedule (:730-1011): returns a dict of timings and losses.
+        log_stats: after every policy update compute the window-of-N statistics the reference writes to TensorBoard (:790-977;
+        one stats all-reduce + one small device->host read per update) and append them to ``self.scalars``.
+        checkpoint: save ``ckpt.<k>.pth`` whenever the separator update number is a multiple of CHECKPOINT_INTERVAL (:1007-1009)."""
         cfg = self.config
         t0 = time.perf_counter()
         steps = 0
@@ -285,16 +306,70 @@ class PPOTrainer:
                 self.lr_scheduler_pol.step()
             if cfg.use_linear_clip_decay:
                 self.agent.clip_param = cfg.clip_param * linear_decay(self.num_updates_done, cfg.NUM_UPDATES)
+            sub_steps = 0
             for _step in range(cfg.num_steps):
-                steps += self._collect_rollout_step()
+                sub_steps += self._collect_rollout_step()
+            steps += sub_steps
             pol_losses = self._update_pol()
             self.num_updates_done += 1
+            if log_stats:
+                self._log_window_stats(pol_losses, sub_steps)
         for _sub in range(cfg.num_updates_per_cycle):
             if cfg.use_linear_lr_decay:
                 self.lr_scheduler_sep.step()
             sep_losses = self._update_sep()
-        self.count_steps += steps
+            if checkpoint and self.world_rank == 0 and self.num_sep_updates_done % cfg.CHECKPOINT_INTERVAL == 0 and cfg.CHECKPOINT_FOLDER:
+                self.save_checkpoint("ckpt.%d.pth" % self.count_checkpoints)
+                self.count_checkpoints += 1
+            self.num_sep_updates_done += 1
+        if not log_stats:
+            self.count_steps += steps
         return {"env_steps": steps, "seconds": time.perf_counter() - t0, "pol_losses": pol_losses, "sep_losses": sep_losses}
+
+    _WINDOW_KEYS = (("count", "episode_counts"), ("reward", "episode_rewards"), ("step", "episode_steps"), ("dist_probs", "episode_dist_probs"),
+                    ("avg_bin_loss_allSteps", "episode_bin_losses_allSteps"), ("mono_loss_lastStep", "episode_mono_losses_lastStep"),
+                    ("mono_loss_allSteps", "episode_mono_losses_allSteps"), ("monoFromMem_loss_lastStep", "episode_monoFromMem_losses_lastStep"),
+                    ("monoFromMem_loss_allSteps", "episode_monoFromMem_losses_allSteps"),
+                    ("normalized_geo_distance_to_target_audio_source", "episode_ndgs"), ("geo_distance_to_target_audio_source", "episode_dgs"))
+    _SCALAR_TAGS = (("Environment/Reward", "reward"), ("Environment/Episode_length", "step"),
+                    ("Environment/STFT_L2_loss/mono_lastStep", "mono_loss_lastStep"), ("Environment/STFT_L2_loss/mono_avgAllSteps", "mono_loss_allSteps"),
+                    ("Environment/STFT_L2_loss/monoFromMem_lastStep", "monoFromMem_loss_lastStep"),
+                    ("Environment/STFT_L2_loss/monoFromMem_avgAllSteps", "monoFromMem_loss_allSteps"),
+                    ("Environment/Normalized_geo_distance_to_target_audio_source", "normalized_geo_distance_to_target_audio_source"),
+                    ("Environment/Geo_distance_to_target_audio_source", "geo_distance_to_target_audio_source"))
+
+    def _log_window_stats(self, pol_losses, steps_delta):
+        """The logging of one policy update (:790-977).  Every per-env statistic is summed over ranks (the reference stacks them
+        and all-reduces, :839-843; here they travel as ONE tensor together with the losses and the step count), pushed into a
+        window of ``reward_window_size`` updates, and the logged value is (newest - oldest) summed over envs divided by the
+        window's episode count (at least 1)."""
+        from . import ddppo_utils
+        cfg, st = self.config, self.stats
+        N = self.envs.num_envs
+        names = [n for _k, n in self._WINDOW_KEYS]
+        cols = torch.cat([getattr(st, n) for n in names], dim=1)                              # [N, 10 + A]
+        tail = torch.zeros(N, 4, device=self.device)
+        tail[0] = torch.tensor(list(pol_losses) + [float(steps_delta)], device=self.device)   # :861-866
+        packed = ddppo_utils.all_reduce_stats(torch.cat([cols, tail], dim=1)).cpu()           # the update's one extra host read
+        v_loss, a_loss, ent, d_steps = (packed[0, -4:] / torch.tensor([self.world_size] * 3 + [1.0])).tolist()
+        self.count_steps += d_steps
+        deltas, off = {}, 0
+        for key, name in self._WINDOW_KEYS:
+            w = getattr(st, name).shape[1]
+            cur = packed[:, off:off + w].clone()
+            off += w
+            win = self.windows.setdefault(key, deque(maxlen=cfg.reward_window_size))
+            win.append(cur)
+            d = (win[-1] - win[0]) if len(win) > 1 else win[0]
+            deltas[key] = d.sum(dim=0) if key == "dist_probs" else d.sum().item()
+        deltas["count"] = max(deltas["count"], 1.0)
+        sc = {tag: deltas[key] / deltas["count"] for tag, key in self._SCALAR_TAGS}
+        for i in range(deltas["dist_probs"].numel()):
+            sc["Policy/Action_prob_%d" % i] = (deltas["dist_probs"] / deltas["count"])[i].item()
+        sc.update({"Policy/Value_Loss": v_loss, "Policy/Action_Loss": a_loss, "Policy/Entropy": ent,
+                   "Policy/Learning_Rate": self.lr_scheduler_pol.get_last_lr()[0]})
+        self.scalars.append((self.count_steps, sc))
+        return sc
 
     def all_reduce_stats(self):
         """The per-update statistics all-reduces of :790-860, fused into one small collective."""
@@ -325,7 +400,15 @@ class PPOTrainer:
         from ... import functional as MF
         MF.bump_param_epoch()  # packed-weight memos key on the optimizer epoch
         self._next_cache = None
+        self._drop_graphs()    # the frozen separators' packed weights / folded-BN buffers are rebuilt at new addresses
         return out
+
+    def _drop_graphs(self):
+        """Forget every captured HIP graph (rollout step, update_pol epoch): they hold device addresses of packed weights and
+        of the arithmetic-mode-specific operand copies, which a weight load or ``ops.set_math_mode`` replaces."""
+        self._graph_state = None
+        if self.agent is not None:
+            self.agent._pol_graph = None
 
     @staticmethod
     def save_switch_checkpoint(path, nav_checkpoint, qual_improv_checkpoint):
@@ -372,7 +455,7 @@ class PPOTrainer:
                 raise RuntimeError("switch-policy checkpoint needs 'state_dict_nav' and 'state_dict_qualImprov' (save_switch_checkpoint)")
             acs = (self._policy_from_state_dict(ck["state_dict_nav"]), self._policy_from_state_dict(ck["state_dict_qualImprov"]))
             thres = int(time_thres_for_pol_switch if time_thres_for_pol_switch is not None else getattr(cfg, "time_thres_for_pol_switch", 80))
-        was_training = ac.training
+        training_flags = {m: m.training for m in ac.modules()}   # the frozen separators stay in eval mode inside a training policy (:557-577)
         ac.eval()
         N = self.envs.num_envs
         num_episodes = num_episodes or N
@@ -438,8 +521,8 @@ class PPOTrainer:
                         done_eps += 1
                     for t in (cur_mono, cur_mem, cur_rew, cur_steps):
                         t.mul_(not_done)
-        if was_training:
-            ac.train()
+        for m, flag in training_flags.items():
+            m.training = flag
         if had_phase is not None:
             self.envs.include_phase = had_phase
         self._next_cache = None
@@ -451,8 +534,12 @@ class PPOTrainer:
         agg["num_episodes"] = done_eps
         return agg
 
-    def train(self, num_cycles):
+    def train(self, num_cycles=None, log_stats=True, checkpoint=True):
+        """The reference's training loop (:730-1011): ``NUM_UPDATES / num_updates_per_cycle`` cycles (or ``num_cycles``), window
+        statistics after every policy update, a checkpoint every CHECKPOINT_INTERVAL separator updates (rank 0)."""
+        cfg = self.config
+        total = int(cfg.NUM_UPDATES / cfg.num_updates_per_cycle)
         out = []
-        for _ in range(num_cycles):
-            out.append(self.train_cycle())
+        for _ in range(total if num_cycles is None else min(int(num_cycles), total)):
+            out.append(self.train_cycle(log_stats=log_stats, checkpoint=checkpoint))
         return out

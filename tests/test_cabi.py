@@ -69,11 +69,11 @@ def test_rollout_structs_match_header_field_order():
     points are reported without a launch (negative return, message), so this runs without a GPU."""
     assert _struct_fields("m2h_episode_stats") == [f for f, _ in _lib.EpisodeStats._fields_] == list(_lib.EPISODE_STATS_FIELDS)
     assert _struct_fields("m2h_row_copy") == [f for f, _ in _lib.RowCopy._fields_]
-    assert ctypes.sizeof(_lib.RowCopy) == 32 and ctypes.sizeof(_lib.EpisodeStats) == 15 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_lib.RowCopy) == 32 and ctypes.sizeof(_lib.EpisodeStats) == 17 * ctypes.sizeof(ctypes.c_void_p)
     lib = _lib.load()
     assert lib.m2h_rows_copy(None, 0, None, None) < 0 and b"rows_copy" in lib.m2h_last_error()
     items = (_lib.RowCopy * 1)(_lib.RowCopy(8, 16, 6, -1, -1))   # size not a multiple of 4
     assert lib.m2h_rows_copy(items, 1, None, None) < 0 and b"multiple of 4" in lib.m2h_last_error()
     st = _lib.EpisodeStats()                                      # null statistics tensors
-    assert lib.m2h_episode_stats_update(ctypes.byref(st), 8, 8, 8, 8, 8, 8, 14, 3, None) < 0
+    assert lib.m2h_episode_stats_update(ctypes.byref(st), 8, 8, 8, 8, 8, 8, None, None, 14, 3, None) < 0
     assert lib.m2h_gru_step(8, 8, 8, 8, None, 8, 8, 17, 512, None) < 0 and b"gru_step" in lib.m2h_last_error()

@@ -203,7 +203,8 @@ def test_generic_conv_engine_matches_torch():
 
 def test_episode_stats_update_matches_the_elementwise_bookkeeping():
     """m2h_episode_stats_update == the reference's per-step bookkeeping (ppo_trainer.py:421-478) written as elementwise torch
-    ops, over several steps with episode ends on some envs, bit for bit."""
+    ops, over several steps with episode ends on some envs, bit for bit.  (The loop as a whole, on the reference's own run:
+    tests/test_gpu_trainer_golden.py.)"""
     from types import SimpleNamespace
     from m2h import _lib, ops
     dev = _dev()
@@ -214,7 +215,7 @@ def test_episode_stats_update_matches_the_elementwise_bookkeeping():
     for n in _lib.EPISODE_STATS_FIELDS:
         setattr(st, n, getattr(st, n).to(dev))
     for step in range(7):
-        rewards, bl, ml, fl = (torch.randn(N, 1, generator=g) for _ in range(4))
+        rewards, bl, ml, fl, ndg, dg = (torch.randn(N, 1, generator=g) for _ in range(6))
         probs = torch.softmax(torch.randn(N, A, generator=g), dim=1)
         masks = (torch.rand(N, 1, generator=g) > (0.4 if step in (2, 5) else 2.0)).float()
         if step == 6:
@@ -228,6 +229,8 @@ def test_episode_stats_update_matches_the_elementwise_bookkeeping():
         r.current_episode_monoFromMem_losses += fl
         nd = 1 - masks
         r.episode_rewards += nd * r.current_episode_reward
+        r.episode_ndgs += nd * ndg
+        r.episode_dgs += nd * dg
         r.episode_steps += nd * r.current_episode_step
         r.episode_counts += nd
         r.episode_dist_probs += nd * (r.current_episode_dist_probs / r.current_episode_step)
@@ -239,7 +242,7 @@ def test_episode_stats_update_matches_the_elementwise_bookkeeping():
         for name in ("current_episode_reward", "current_episode_step", "current_episode_bin_losses", "current_episode_mono_losses",
                      "current_episode_monoFromMem_losses", "current_episode_dist_probs"):
             getattr(r, name).mul_(masks)
-        ops.episode_stats_update(st, rewards.to(dev), probs.to(dev), bl.to(dev), ml.to(dev), fl.to(dev), masks.to(dev))
+        ops.episode_stats_update(st, rewards.to(dev), probs.to(dev), bl.to(dev), ml.to(dev), fl.to(dev), masks.to(dev), ndg.to(dev), dg.to(dev))
     for n in _lib.EPISODE_STATS_FIELDS:
         assert torch.equal(getattr(st, n).cpu(), getattr(ref, n)), n
 

@@ -1,0 +1,165 @@
+"""GPU: the m2h DD-PPO trainer against the REFERENCE's own training run (tests/golden/trainer_{near,far,ddp2}.npz, produced by
+oracle/gen_trainer_golden.py from the reference's ``PPOTrainer.train``).  Rows A15 / A18 / A19 / N4 of SURVEY 8.
+
+The same table-driven replay world runs on both sides; the actions the reference sampled (CPU mt19937 stream) are fed to the
+trainer in place of its own draws (device Philox stream -- ``test_sampling_is_torch_multinomial_bit_for_bit`` covers the draw
+itself), so the trajectories coincide and everything downstream is compared: per-step rewards (incl. the 2 x 10 x extra
+reward at MAX_EPISODE_STEPS - 2 and the zero at episode ends), values, log-probs, hidden states, stored separator outputs, all
+17 per-episode statistics, per-update losses / learning rates / clip ranges / returns, the window statistics the reference
+logs, the checkpoint schedule and the weights after two cycles.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import m2h_oracle_trainer as OT
+from trainer_golden_util import (check_run, check_scalars, check_updates, check_weights, load_fixture, make_env)
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _passive_ckpt(seed):
+    from m2h import synthetic
+    return {"actor_critic." + k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.passive_shapes(), seed).items()}
+
+
+def run_m2h(d, flat, replay, env_kind, graphs, rank=0, world=1, pre=""):
+    """Runs the product trainer over the fixture's schedule; returns a record shaped like the oracle's."""
+    from m2h.common import utils as CU
+    from m2h.envs.replay_env import ReplayVecEnv
+    from m2h.envs.vector_env_adapter import HostVectorEnvAdapter
+    from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config
+    dev = torch.device("cuda", 0)
+    keys = {k: flat[k] for k in ("num_updates_per_cycle", "hidden_size", "value_loss_coef", "entropy_coef", "lr_pol", "lr_sep", "clip_param", "ppo_epoch",
+                                 "num_mini_batch", "eps", "max_grad_norm", "num_steps", "use_gae", "gamma", "tau", "use_linear_clip_decay",
+                                 "use_linear_lr_decay", "sep_reward_weight", "nav_reward_weight", "extra_reward_multiplier", "reward_window_size",
+                                 "use_ddppo", "NUM_UPDATES", "CHECKPOINT_INTERVAL", "MAX_EPISODE_STEPS", "SEED", "NUM_PROCESSES")}
+    cfg = near_target_config(use_hip_graphs=graphs, **keys)
+    seed = flat["SEED"] + rank * flat["NUM_PROCESSES"]
+    if env_kind == "device":
+        envs = ReplayVecEnv(flat["NUM_PROCESSES"], dev, seed=seed, episode_len=flat["MAX_EPISODE_STEPS"], pool=replay["pool"],
+                            env_rewards=replay["env_rewards"])
+        state = lambda: envs.s.cpu().numpy().copy()  # noqa: E731
+    else:
+        host = make_env(flat, replay, rank)
+        envs = HostVectorEnvAdapter(host, dev)
+        state = lambda: host.s.copy()  # noqa: E731
+    tr = PPOTrainer(cfg, dev, world_rank=rank, world_size=world, envs=envs)
+    tr.setup(passive_state_dict=_passive_ckpt(replay["passive_seed"]))
+    forced = torch.zeros(flat["NUM_PROCESSES"], 1, dtype=torch.int64, device=dev)
+    actions = torch.from_numpy(d[pre + "step.actions"]).to(dev)
+    steps, saved = [], []
+    orig_sample, orig_step, orig_pol, orig_sep, orig_save = (CU.CustomFixedCategorical.sample, tr._collect_rollout_step, tr._update_pol, tr._update_sep,
+                                                             tr.save_checkpoint)
+    CU.CustomFixedCategorical.sample = lambda self, sample_shape=None: forced.clone()
+
+    def step():
+        forced.copy_(actions[len(steps)])
+        n = orig_step()
+        ro = tr.rollouts_pol
+        s = (ro.step - 1) % ro.num_steps
+        rec = {"rewards": ro.rewards[s], "values": ro.value_preds[s], "logp": ro.action_log_probs[s], "h": ro.recurrent_hidden_states_pol[s + 1],
+               "masks": ro.masks[s + 1], "actions": ro.actions[s]}
+        rec = {k: v.cpu().numpy().copy() for k, v in rec.items()}
+        rec.update(env_state=state(), pm_stats=OT.stats11(ro.pred_binSepMasks[s].cpu()), mono_stats=OT.stats11(ro.pred_mono[s].cpu()),
+                   mem_stats=OT.stats11(ro.prev_pred_monoFromMem[s + 1].cpu()))
+        for name in OT.STAT_NAMES:
+            rec["stat." + name] = getattr(tr.stats, name).cpu().numpy().copy()
+        steps.append(rec)
+        return n
+    pol, sep = [], []
+
+    def update_pol():
+        lr, clip = tr.agent.optimizer_pol.param_groups[0]["lr"], tr.agent.clip_param
+        out = orig_pol()
+        pol.append({"losses": np.array([out]), "lr": lr, "clip": clip, "returns": [tr.rollouts_pol.returns.cpu().clone()]})
+        return out
+
+    def update_sep():
+        lr = tr.agent.optimizer_sep.param_groups[0]["lr"]
+        out = orig_sep()
+        sep.append({"losses": np.array([out]), "lr": lr})
+        return out
+    tr._collect_rollout_step, tr._update_pol, tr._update_sep = step, update_pol, update_sep
+    tr.save_checkpoint = lambda name: saved.append((name, len(sep)))
+    cfg.CHECKPOINT_FOLDER = "unused"
+    try:
+        tr.train()
+    finally:
+        CU.CustomFixedCategorical.sample = orig_sample
+    graph_replays = 0 if tr._graph_state is None else len(tr._graph_state.graphs)
+    return {"steps": [steps], "pol": pol, "sep": sep, "ckpts": saved, "scalars": tr.scalars, "graphs": graph_replays, "trainer": tr,
+            "state_dict": {k: v.detach().cpu() for k, v in tr.actor_critic.state_dict().items()}}
+
+
+def check_all(d, rec, pre="", rank=0):
+    check_run(d, rec, 0, pre, step_tol=5e-5, skip=("probs",), stat_tol=2e-4)
+    check_updates(d, rec, pre, 0, 1)
+    if rank == 0:
+        check_scalars(d, rec, pre)
+    check_weights(d, rec, pre, tol=1e-4)
+
+
+@pytest.mark.parametrize("env_kind,graphs", [("device", True), ("device", False), ("host", False)])
+def test_near_target_training_matches_the_reference_run(env_kind, graphs):
+    d, flat, replay = load_fixture("trainer_near.npz")
+    rec = run_m2h(d, flat, replay, env_kind, graphs)
+    check_all(d, rec)
+    if graphs:   # the steps really were replayed: one graph per (extra-reward, episode-end) flag pair that occurred
+        assert rec["graphs"] == 3 and rec["trainer"].agent._pol_graph is not None
+    # the frozen separators' BatchNorm statistics are untouched by training
+    assert np.array_equal(rec["state_dict"]["binSep_enc.passive_sep_encoder.cnn.0.1.running_mean"].numpy(), d["frozen_bn_running_mean0"])
+
+
+def test_far_target_training_with_ragged_episodes_matches_the_reference_run():
+    """farTarget.yaml's reward wiring (the env's own reward, no override), episodes ending at different steps per env, non-zero
+    distance infos, through the host vector-env adapter (row N4)."""
+    d, flat, replay = load_fixture("trainer_far.npz")
+    rec = run_m2h(d, flat, replay, "host", False)
+    check_all(d, rec)
+    assert float(np.abs(d["step.stat.episode_ndgs"][-1]).sum()) > 0
+
+
+TWO_RANK = r'''
+import os, sys
+root = %(root)r
+for p in ("move2hear-active-av-separation_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(root, p))
+import torch, torch.distributed as dist
+rank = int(sys.argv[1])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(%(port)d), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0")
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=2)   # both ranks share the box's one GPU; collectives over gloo
+from trainer_golden_util import load_fixture
+from test_gpu_trainer_golden import run_m2h, check_all
+d, flat, replay = load_fixture("trainer_ddp2.npz")
+pre = "rank%%d." %% rank
+rec = run_m2h(d, flat, replay, "device", True, rank=rank, world=2, pre=pre)
+check_all(d, rec, pre, rank)
+assert rec["trainer"].agent._world == 2 and rec["trainer"].agent._reducers["pol"].deferred_steps == flat["NUM_UPDATES"]
+dist.barrier()
+dist.destroy_process_group()
+print("RANK_OK", rank)
+'''
+
+
+def test_two_rank_ddppo_matches_the_reference_ddp_run():
+    """Two DD-PPO ranks against the reference's two-rank DistributedDataParallel run (gloo, CPU): per-rank seeds and
+    environments, rank-0 broadcast, flat-gradient all-reduce averaged before clip + Adam (deferred last step on the side
+    stream), distributed advantage statistics, summed window statistics; per-rank losses and the weights of both replicas."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", TWO_RANK % {"root": ROOT, "port": port}, str(r)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("RANK_OK %d" % r) in o, o[-4000:]
