@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: passive U-Net separator pair (get_binSepMasks + convert_bin2mono), spectrograms/s.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: this process starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch of synthetic 512xTm binaural log-magnitude spectrograms
@@ -257,8 +257,42 @@ def run_passive_train(args, dev, rank):
             "what": "PassiveTrainer.train_batch: both U-Nets forward in train-mode BN, L1 losses, full backward, FlatAdam step"}
 
 
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: start N copies of this command, one rank per GPU, with the env-var rendezvous
+    torch.distributed.run would provide (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT: what the reference's
+    init_distrib_slurm reads, ddppo_utils.py:117-165).  Runs BEFORE anything in this process touches the GPU; this process only
+    waits.  Rank 0 prints the one JSON line on the inherited stdout.  Returns the exit code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:   # a failed rank leaves the others blocked in a collective: stop exactly the children started here
+                    q.terminate()
+        time.sleep(0.2)
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -274,6 +308,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("M2H_BENCH_BACKEND", "nccl")
         dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
+    ranks_observed = dist.get_world_size() if dist is not None else 1
+    if ranks_observed != args.gpus:
+        raise RuntimeError("bench.py --gpus %d but the process group has %d rank(s) (WORLD_SIZE=%s)" % (args.gpus, ranks_observed, os.environ.get("WORLD_SIZE")))
 
     from m2h import ops
     pol, sd = make_policy(dev)
@@ -481,7 +518,7 @@ def main():
     line = {
         "metric": "passive_unet_pair_spectrograms_per_sec",
         "value": round(value, 1), "unit": "spectrograms/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "ranks_observed": ranks_observed, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("bf16x3 (fp32 tensors; each product = hi*hi + hi*lo + lo*hi of bf16 halves on the bf16 MFMA pipe, fp32 accumulate)"

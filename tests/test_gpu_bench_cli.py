@@ -1,0 +1,33 @@
+"""GPU: ``python bench.py --gpus 2`` with no launcher starts its own two ranks (rehearsed on the box's one card: both ranks pinned
+to GPU 0, collectives over gloo -- the driver's runs use RCCL and one card per rank) and rank 0 prints one JSON line that says so."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_gpus_2_spawns_two_ranks_and_reports_them():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(M2H_BENCH_DEVICE="0", M2H_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--tm", "32",
+           "--ddppo-cycles", "1", "--no-far-target", "--train-steps", "0", "--feeder-steps", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_observed"] == 2 and line["scaling"] == "weak"
+    assert line["ddppo"]["n_gpus"] == 2 and line["ddppo"]["value"] > 0
+    assert line["roofline"]["frac"] > 0 and line["config"]["batch_per_gpu"] == 8
+
+
+def test_bench_refuses_a_rank_count_that_disagrees_with_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "process group has 1 rank" in r.stderr
