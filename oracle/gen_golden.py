@@ -392,7 +392,38 @@ def gen_passive_train(ref):
     print("passive_train: losses", losses)
 
 
-GENS = {"unet_tm32": gen_unet_tm32, "unet_tm256": gen_unet_tm256, "init": gen_init,
+def eval_clips(S, L, seed):
+    """Seeded float32 waveform sets (reference clip, estimate, left / right mixture) for the waveform-metric fixture; float32 is
+    what librosa.istft hands the reference's evaluate()."""
+    r = np.random.default_rng(seed)
+    t = np.arange(L) / 16000.0
+    ref_ = np.stack([0.2 * np.sin(2 * np.pi * r.uniform(200, 3000) * t) + 0.05 * r.standard_normal(L) + 0.01 for _ in range(S)])
+    other = 0.1 * r.standard_normal((S, L))
+    est = ref_ * r.uniform(0.5, 1.5, (S, 1)) + 0.03 * r.standard_normal((S, L)) - 0.02
+    ml, mr = ref_ + other, 0.8 * ref_ + 1.2 * other + 0.05
+    return [a.astype(np.float32) for a in (ref_, est, ml, mr)]
+
+
+def gen_eval_metrics(ref):
+    """N2 / A21 (the numpy half): the reference's evaluate() -> preprocess / evaluate_helper / scale_bss_eval
+    (common/eval_metrics.py:12-229) on seeded waveforms: the 11 scores per clip, float32 inputs (as from librosa.istft) and the
+    same clips in float64.  istft / compute_waveform_quality (:232-303) need librosa and stay unpinned."""
+    EM = ref["eval_metrics"]
+    order = ("si_sdr", "si_sir", "si_sar", "sd_sdr", "snr", "srr", "si_sdri", "sd_sdri", "snri", "si_siri", "si_sari")
+    out = {"seed": 11, "S": 6, "order": np.array(order)}
+    for L in (16000, 4097):
+        r_, e_, ml, mr = eval_clips(6, L, 11)
+        for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+            rows = []
+            for c in range(6):
+                sc = EM.evaluate([r_[c][None].astype(dt)], [e_[c][None].astype(dt)], [np.stack([ml[c], mr[c]]).astype(dt)])
+                rows.append([sc[k] for k in order])
+            out["scores_%s_L%d" % (tag, L)] = np.array(rows, np.float64)
+    np.savez_compressed(os.path.join(GOLD, "eval_metrics.npz"), meta=json.dumps(META), **out)
+    print("eval_metrics: si_sdr", out["scores_f32_L16000"][:, 0])
+
+
+GENS = {"eval_metrics": gen_eval_metrics, "unet_tm32": gen_unet_tm32, "unet_tm256": gen_unet_tm256, "init": gen_init,
         "rl_forward": gen_rl_forward, "rl_scalars": gen_rl_scalars, "rl_updates": gen_rl_updates, "passive_train": gen_passive_train}
 
 

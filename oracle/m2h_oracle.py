@@ -8,8 +8,11 @@ only as the checker / the reported CPU baseline; the product path (``m2h``) neve
 Pinning: the reference holds no tests or golden vectors for this path, so the
 oracle is pinned against outputs of the reference itself, produced in the build container by
 ``oracle/gen_golden.py`` (which imports the reference through ``oracle/_ref_import.py``) and
-committed under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks every function here against
-them, and ``tests/test_oracle_vs_reference.py`` re-checks live when ``/root/reference`` is present.
+committed under ``tests/golden/``; ``tests/test_oracle_golden.py``, ``test_oracle_rl_golden.py``,
+``test_oracle_passive_train.py`` and ``test_oracle_eval_metrics.py`` check every function here against them
+(the training loop on top of these functions: ``m2h_oracle_trainer.py`` / ``test_oracle_trainer_golden.py``).
+Unpinned: the librosa-based STFT / iSTFT restatements (``np_stft``, ``np_istft``, ``np_compute_audiospects``):
+librosa is not importable here and the reference holds no fixtures for them.
 
 All functions take a flat ``state_dict`` (name -> torch.Tensor, reference key names without the
 ``actor_critic.`` root) and plain tensors; no nn.Module, so nothing here can be mistaken for the

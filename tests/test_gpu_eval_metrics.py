@@ -35,6 +35,23 @@ def test_bss_metrics_kernel_matches_oracle(L):
         assert out[c, 1] > 60 and np.isfinite(out[c, 2])
 
 
+@pytest.mark.parametrize("L", [16000, 4097])
+def test_bss_metrics_kernel_matches_the_reference_evaluate_fixture(L, golden_dir):
+    """m2h_bss_metrics against the scores of the reference's own evaluate() (tests/golden/eval_metrics.npz): the well-conditioned
+    metrics to 2e-3 dB of the float64 reference values; the float32 reference run itself sits that far from them."""
+    import os
+    from m2h import ops
+    from test_oracle_eval_metrics import eval_clips
+    dev = torch.device("cuda", 0)
+    g = np.load(os.path.join(golden_dir, "eval_metrics.npz"))
+    ref, est, ml, mr = eval_clips(int(g["S"]), L, int(g["seed"]))
+    out = ops.bss_metrics(*[torch.from_numpy(a).to(dev) for a in (ref, est, ml, mr)]).cpu().numpy()
+    want = g["scores_f64_L%d" % L]
+    for j in WELL:
+        assert np.abs(out[:, j] - want[:, j]).max() < 2e-3, (O.BSS_METRIC_ORDER[j], out[:, j], want[:, j])
+    assert np.abs(g["scores_f32_L%d" % L][:, WELL] - want[:, WELL]).max() < 5e-3
+
+
 def test_compute_waveform_quality_end_to_end():
     """spectrograms -> iSTFT (GT phase) -> metrics, as eval_metrics.compute_waveform_quality, vs numpy istft + oracle metrics."""
     from m2h.audio.stft import STFT

@@ -1,5 +1,6 @@
-"""CPU: the waveform-metric restatement (oracle.np_waveform_metrics, following common/eval_metrics.py:12-196) against closed
-forms that do not share its code path, and the drop-in module's constants against the reference's."""
+"""CPU: the waveform-metric restatement (oracle.np_waveform_metrics, following common/eval_metrics.py:12-229) against the
+reference's own ``evaluate()`` (tests/golden/eval_metrics.npz, oracle/gen_golden.py::gen_eval_metrics), against closed forms that
+do not share its code path, and the drop-in module's constants against the reference's."""
 import os
 import sys
 
@@ -17,6 +18,31 @@ def _signals(seed, L=16000):
     est = 0.8 * s + 0.05 * r.standard_normal(L) + 0.01
     mix = np.stack([s + other, 0.9 * s + 1.1 * other - 0.03])
     return s, est, mix
+
+
+def eval_clips(S, L, seed):
+    """The fixture's seeded clips (same generator as oracle/gen_golden.py::eval_clips)."""
+    r = np.random.default_rng(seed)
+    t = np.arange(L) / 16000.0
+    ref_ = np.stack([0.2 * np.sin(2 * np.pi * r.uniform(200, 3000) * t) + 0.05 * r.standard_normal(L) + 0.01 for _ in range(S)])
+    other = 0.1 * r.standard_normal((S, L))
+    est = ref_ * r.uniform(0.5, 1.5, (S, 1)) + 0.03 * r.standard_normal((S, L)) - 0.02
+    ml, mr = ref_ + other, 0.8 * ref_ + 1.2 * other + 0.05
+    return [a.astype(np.float32) for a in (ref_, est, ml, mr)]
+
+
+def test_metrics_match_the_reference_evaluate_fixture():
+    """All 11 scores of the reference's evaluate() per clip, float32 (what it gets from librosa.istft) and float64 inputs."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "eval_metrics.npz"))
+    assert tuple(str(x) for x in g["order"]) == tuple(O.BSS_METRIC_ORDER)
+    for L in (16000, 4097):
+        ref_, est, ml, mr = eval_clips(int(g["S"]), L, int(g["seed"]))
+        for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+            want = g["scores_%s_L%d" % (tag, L)]
+            for c in range(len(ref_)):
+                got = O.np_waveform_metrics(ref_[c], est[c], np.stack([ml[c], mr[c]]), dtype=dt)
+                # same numpy operations in the same order: equal to the last bits (si_sir / si_sar included)
+                assert np.allclose(got, want[c], rtol=1e-6, atol=1e-6), (L, tag, c, got, want[c])
 
 
 def test_metrics_match_closed_forms_in_float64():
