@@ -106,8 +106,9 @@ typedef struct m2h_conv_args {
   size_t workspace_bytes; /* size of workspace; m2h_conv_igemm_workspace_bytes() says how much the launch can use */
   const float* head_w;    /* optional fused 1x1 head (N in {16,32}, M2H_OUT_DESLICE, workspace NULL): [N][N], applied after the */
   const float* head_b;    /*   activation; out = head_w . act(...) + head_b, stored de-sliced.  NULL = no head.                */
-  int operand_format;     /* bf16x3 math only, bit set of M2H_FMT_*: operands that already are in the split32 layout (below),  */
-                          /*   and whether dst is to be written in it.  0 = plain fp32 everywhere.                              */
+  int operand_format;     /* bit set of M2H_FMT_*: the arithmetic of THIS call (M2H_FMT_MATH_*; neither bit = the calling       */
+                          /*   thread's mode, m2h_set_math_mode) and, in bf16x3 math, which operands already are in the split32     */
+                          /*   layout (below) and whether dst is to be written in it.  0 = plain fp32 tensors, thread's arithmetic. */
 } m2h_conv_args;
 
 /* split32 layout (internal operand format of the bf16x3 math mode): every aligned group of 32 consecutive fp32 values of the
@@ -118,9 +119,22 @@ typedef struct m2h_conv_args {
 #define M2H_FMT_SRC_SPLIT 1
 #define M2H_FMT_W_SPLIT 2
 #define M2H_FMT_DST_SPLIT 4
+#define M2H_FMT_MATH_BF16X3 8 /* this call computes in bf16x3 split products, whatever the calling thread's mode */
+#define M2H_FMT_MATH_FP32 16  /* this call computes in fp32 MFMA, whatever the calling thread's mode */
 int m2h_split32(const float* src, float* dst, size_t count /* floats, multiple of 32 */, m2h_stream stream);
 
 int m2h_conv_igemm_f32(const m2h_conv_args* args /* host */, m2h_stream stream);
+
+/* Arithmetic of the igemm forward engine for launches made BY THE CALLING THREAD through entry points that carry no
+ * m2h_conv_args / m2h_unet_weights of their own (m2h_unet_down_fwd, m2h_unet_up_fwd, ...): M2H_MATH_FP32 (default: fp32 MFMA,
+ * exact fp32 products) or M2H_MATH_BF16X3 (fp32 operands split into bf16 hi + lo, products hi*hi + hi*lo + lo*hi on the bf16
+ * matrix pipe, fp32 accumulate; shapes the scalar loader takes).  The value is thread-local: the library holds no
+ * process-global arithmetic state, two host threads may run different modes side by side.  Calls that do carry a struct
+ * may pin their arithmetic there (M2H_FMT_MATH_*, m2h_unet_weights.math_mode) and then ignore this. */
+#define M2H_MATH_FP32 0
+#define M2H_MATH_BF16X3 1
+int m2h_set_math_mode(int mode);
+int m2h_get_math_mode(void);
 
 /* Bytes of split-K scratch the launch described by args would use (0 = the grid already fills the chip).
  * Small-M layers (deep U-Net stages, rollout batches) are split along K over up to 32 blocks; partial sums go
@@ -128,10 +142,11 @@ int m2h_conv_igemm_f32(const m2h_conv_args* args /* host */, m2h_stream stream);
  * (bit-reproducible) and applies the fused epilogue. */
 size_t m2h_conv_igemm_workspace_bytes(const m2h_conv_args* args /* host */);
 
-/* Tuning/debug knobs (process-wide, not for production use; 0 = automatic everywhere): 0 force split-K factor (-1 never), 1 / 2 LDS
+/* Tuning/debug knobs (process-wide, NOT part of the contract and not for production use: they only choose between kernels that
+ * compute the same values; 0 = automatic everywhere): 0 force split-K factor (-1 never), 1 / 2 LDS
  * stages of the narrow / wide tiles, 3 skinny-M tiles (-1 off), 4 16-wide MFMA tile (-1 off), 7 extra dynamic LDS, 8 phase-major
- * transposed-conv order (-1 off), 9 scalar-decode loader (-1 off), 11 weight-gradient block target, 14 arithmetic (1 = bf16x3 split
- * products; what ops.set_math_mode sets), 15 / 16 tap-sharing transposed-conv kernel (-1 off / tile), 18 tap window (-1 off), 21 / 22
+ * transposed-conv order (-1 off), 9 scalar-decode loader (-1 off), 11 weight-gradient block target, 14 = m2h_set_math_mode (kept
+ * for older callers; thread-local like it), 15 / 16 tap-sharing transposed-conv kernel (-1 off / tile), 18 tap window (-1 off), 21 / 22
  * image-row 3x3 weight-gradient / conv kernels (-1 off), 23 skinny rows kernel for M <= 16 (-1 off), 24 skinny gather kernel (-1 off,
  * > 0 = pixel limit).  The launches that take a specialised kernel say which in the source (csrc/conv_igemm.hip, conv_bwd.hip);
  * retired experiment numbers are accepted and ignored. */
@@ -448,6 +463,7 @@ typedef struct m2h_unet_weights {
   int n_out;                  /* 32 (binSep) or 16 (bin2mono) */
   int weights_split32;        /* bf16x3 math only: down_w / up_w are in the split32 layout (m2h_split32 of the packed weights); the runner
                                  then keeps every intermediate activation in split32 too, so no kernel converts operands in its k-loop */
+  int math_mode;              /* arithmetic of this call: 0 = the calling thread's (m2h_set_math_mode), 1 = fp32 MFMA, 2 = bf16x3 */
 } m2h_unet_weights;
 
 size_t m2h_unet_fwd_workspace_bytes(int B, int F, int T);

@@ -6,7 +6,8 @@ namespace m2h {
 thread_local char g_err[512] = {0};
 int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st);
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a);
-extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny, g_narrow16, g_extra_lds, g_phase_major, g_fast_loader, g_wgrad_blocks, g_math_mode, g_tapshare, g_tap_bm, g_tap_window, g_wgrad_row3x3, g_row3x3, g_skinny_linear, g_skinny_gather;
+extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny, g_narrow16, g_extra_lds, g_phase_major, g_fast_loader, g_wgrad_blocks, g_tapshare, g_tap_bm, g_tap_window, g_wgrad_row3x3, g_row3x3, g_skinny_linear, g_skinny_gather;
+extern thread_local int tl_math_mode;
 }  // namespace m2h
 
 using namespace m2h;
@@ -26,6 +27,14 @@ size_t m2h_conv_igemm_workspace_bytes(const m2h_conv_args* args) {
   return args != nullptr ? conv_igemm_workspace_bytes(*args) : 0;
 }
 
+int m2h_set_math_mode(int mode) {
+  M2H_REQUIRE(mode == M2H_MATH_FP32 || mode == M2H_MATH_BF16X3, "set_math_mode: mode must be M2H_MATH_FP32 or M2H_MATH_BF16X3");
+  tl_math_mode = mode;
+  return 0;
+}
+
+int m2h_get_math_mode(void) { return tl_math_mode; }
+
 int m2h_debug_set(int knob, int value) {
   if (knob == 0) g_force_splitk = value;
   else if (knob == 1) g_force_stages = value;
@@ -37,7 +46,7 @@ int m2h_debug_set(int knob, int value) {
   else if (knob == 8) g_phase_major = value;
   else if (knob == 9) g_fast_loader = value;
   else if (knob == 11) g_wgrad_blocks = value;
-  else if (knob == 14) g_math_mode = value;
+  else if (knob == 14) return m2h_set_math_mode(value);
   else if (knob == 15) g_tapshare = value;
   else if (knob == 16) g_tap_bm = value;
   else if (knob == 18) g_tap_window = value;
@@ -176,7 +185,9 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
   M2H_REQUIRE(B > 0 && F == 512 && T > 0 && T % 32 == 0, "unet_fwd: F must be 512 and T a multiple of 32 (got %d x %d)", F, T);
   M2H_REQUIRE(wts->n_out == 32 || wts->n_out == 16, "unet_fwd: n_out must be 32 or 16");
   M2H_REQUIRE((wts->cls_table == nullptr) == (cls_val == nullptr), "unet_fwd: class table / value mismatch");
-  M2H_REQUIRE(!wts->weights_split32 || g_math_mode == 1, "unet_fwd: split32 weights need the bf16x3 math mode");
+  M2H_REQUIRE(wts->math_mode >= 0 && wts->math_mode <= 2, "unet_fwd: math_mode must be 0 (thread's), 1 (fp32) or 2 (bf16x3)");
+  const int math = wts->math_mode == 0 ? tl_math_mode : wts->math_mode - 1;
+  M2H_REQUIRE(!wts->weights_split32 || math == 1, "unet_fwd: split32 weights need the bf16x3 math mode");
   const UnetLayout L = unet_layout(B, F, T, wts->n_out);
   M2H_REQUIRE(workspace_bytes >= L.total, "unet_fwd: workspace too small (%zu < %zu)", workspace_bytes, L.total);
   char* ws = static_cast<char*>(workspace);
@@ -198,8 +209,9 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
   };
   // with split32 weights every intermediate tensor lives in the split32 layout: producers write it, consumers copy it to LDS
   const int sp = wts->weights_split32 ? 1 : 0;
-  const int fmt_mid = sp ? (M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT | M2H_FMT_DST_SPLIT) : 0;
-  const int fmt_last = sp ? (M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT) : 0;
+  const int fmt_math = math == 1 ? M2H_FMT_MATH_BF16X3 : M2H_FMT_MATH_FP32;   // every launch of this call pinned to its arithmetic
+  const int fmt_mid = fmt_math | (sp ? (M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT | M2H_FMT_DST_SPLIT) : 0);
+  const int fmt_last = fmt_math | (sp ? (M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT) : 0);
   int rc = mark();
   if (rc) return rc;
   rc = m2h_sep_slice_input_fmt(mix, masks, x0, B, F, T, 2, sp, stream);

@@ -57,6 +57,7 @@ struct IGemmP {
   const float* head_w;  // fused 1x1 head (N <= 32, one n-tile): [N][N] weights applied to the activated tile, + head_b, de-sliced store
   const float* head_b;
   int fast_ok; // scalar-decode loader applicable (host check)
+  int math;      // arithmetic of this launch: 0 fp32 MFMA, 1 bf16x3 split products (args' M2H_FMT_MATH_* or the calling thread's mode)
   int presplit;  // both operands arrive in the split32 layout
   int dst_split; // epilogue writes dst in the split32 layout (bf16x3 math, NHWC, N % 32 == 0)
   int pmaj;    // transposed conv: phase is folded into grid x (fastest) instead of grid z
@@ -1227,7 +1228,7 @@ int g_wide_stages = 0;    // 1 | 2: LDS stage count of the 128x128 config (0 = 2
 int g_skinny = 0;         // -1: never use the 32/64-row tiles
 int g_extra_lds = 0;      // tuning experiment: dynamic LDS bytes added to every launch (lowers blocks/CU)
 int g_phase_major = 0;    // -1: transposed-conv phases as grid z (four passes over the input) instead of interleaved
-int g_math_mode = 0;      // 0: fp32 MFMA (exact fp32 products); 1: bf16x3 split products (scalar-loader shapes only)
+thread_local int tl_math_mode = 0;   // m2h_set_math_mode: the calling thread's arithmetic (0 fp32 MFMA, 1 bf16x3 split products)
 int g_tapshare = 0;       // -1: never use the tap-sharing transposed-conv kernel
 int g_tap_bm = 0;         // 128: 128-output tiles only in the tap-sharing kernel
 int g_fast_loader = 0;    // -1: always use the generic (per-lane k decode) loader
@@ -1339,9 +1340,9 @@ static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   const int phases = p.convT ? 4 : 1;
   p.pmaj = (p.convT && g_phase_major >= 0 && nblk * 4 <= 0x7fffffffL) ? 1 : 0;
   dim3 grid((unsigned)(p.pmaj ? nblk * 4 : nblk), (unsigned)p.S, p.pmaj ? 1 : phases);
-  if (fast && g_math_mode == 1 && p.presplit)
+  if (fast && p.math == 1 && p.presplit)
     hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1, 2>), grid, dim3(256), (size_t)g_extra_lds, st, p);
-  else if (fast && g_math_mode == 1)
+  else if (fast && p.math == 1)
     hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1, 1>), grid, dim3(256), (size_t)g_extra_lds, st, p);
   else if (fast)
     hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1>), grid, dim3(256), (size_t)g_extra_lds, st, p);
@@ -1410,7 +1411,11 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   p.head_w = a.head_w; p.head_b = a.head_b;
   {
     const int fmt = a.operand_format;
-    M2H_REQUIRE(fmt == 0 || g_math_mode == 1, "conv_igemm: operand_format needs the bf16x3 math mode");
+    M2H_REQUIRE((fmt & (M2H_FMT_MATH_BF16X3 | M2H_FMT_MATH_FP32)) != (M2H_FMT_MATH_BF16X3 | M2H_FMT_MATH_FP32),
+                "conv_igemm: operand_format names both arithmetic modes");
+    p.math = (fmt & M2H_FMT_MATH_BF16X3) ? 1 : (fmt & M2H_FMT_MATH_FP32) ? 0 : tl_math_mode;
+    M2H_REQUIRE((fmt & (M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT | M2H_FMT_DST_SPLIT)) == 0 || p.math == 1,
+                "conv_igemm: split32 operands need the bf16x3 math mode");
     const int both = M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT;
     M2H_REQUIRE((fmt & both) == 0 || (fmt & both) == both, "conv_igemm: sources and weights must be split32 together");
     p.presplit = (fmt & both) == both ? 1 : 0;
@@ -1438,7 +1443,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   p.ws = static_cast<float*>(a.workspace);
   const size_t wsb = a.workspace != nullptr ? a.workspace_bytes : 0;
   // narrow transposed convs in bf16x3 math: the four taps of a phase share one staged input image (convT_tap_kernel)
-  if (p.convT && g_math_mode == 1 && g_tapshare >= 0 && p.fast_ok && p.N <= 64 && a.Wq >= 32 && 128 % a.Wq == 0 &&
+  if (p.convT && p.math == 1 && g_tapshare >= 0 && p.fast_ok && p.N <= 64 && a.Wq >= 32 && 128 % a.Wq == 0 &&
       a.Hq % (128 / a.Wq) == 0 && g_force_splitk <= 0 && g_phase_major >= 0 && M >= 128L * 256) {
     // 256-output tiles when the image geometry and the block count allow (bytes per output: see the kernel)
     const bool big = g_tap_bm != 128 && p.N <= 32 && a.Hq % (256 / a.Wq) == 0 && M >= 256L * 512;   // N = 64: 93 KB LDS, one block per CU
@@ -1468,7 +1473,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   }
   // M <= 16 rows that are each one contiguous run of floats: Linear; a conv whose tap window covers the whole image and gives
   // one output pixel; a transposed conv over a 1 x 1 image (one tap per phase).  Weight streaming on the skinny kernel.
-  if (g_math_mode == 0 && g_skinny_linear >= 0 && g_fast_loader >= 0 && p.fast_ok && M <= 16 && a.C1 == 0 && a.Hq == 1 && a.Wq == 1 && a.os >= 1 && a.N % 4 == 0 &&
+  if (p.math == 0 && g_skinny_linear >= 0 && g_fast_loader >= 0 && p.fast_ok && M <= 16 && a.C1 == 0 && a.Hq == 1 && a.Wq == 1 && a.os >= 1 && a.N % 4 == 0 &&
       a.out_mode == M2H_OUT_NHWC && a.cls_table == nullptr && a.head_w == nullptr && a.operand_format == 0 &&
       (size_t)a.N * p.Kw * (p.convT ? 4 : 1) >= (size_t)1 << 18) {
     bool dense;
@@ -1493,7 +1498,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
     }
   }
   // small pixel counts per phase (<= 1024; knob 24 > 0 overrides the limit): 32 x 16 tiles without LDS staging or split-K
-  if (g_math_mode == 0 && g_skinny_gather >= 0 && g_fast_loader >= 0 && p.fast_ok && M > 16 && M <= (g_skinny_gather > 0 ? g_skinny_gather : 1024) &&
+  if (p.math == 0 && g_skinny_gather >= 0 && g_fast_loader >= 0 && p.fast_ok && M > 16 && M <= (g_skinny_gather > 0 ? g_skinny_gather : 1024) &&
       a.N % 16 == 0 && a.out_mode == M2H_OUT_NHWC && a.cls_table == nullptr && a.head_w == nullptr && a.operand_format == 0 &&
       p.Ctot % 16 == 0 && (size_t)a.N * p.Kw * (p.convT ? 4 : 1) >= (size_t)1 << 16) {
     const int phases = p.convT ? 4 : 1;
@@ -1506,7 +1511,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
     return launch_status("conv_igemm_f32 (skinny gather)");
   }
   // 3x3 / stride 1 / pad 1 over 16- or 32-channel, 32-pixel-wide images in fp32 math, many rows (AcousticMem in update_sep)
-  if (g_math_mode == 0 && g_row3x3 >= 0 && !p.convT && a.nth == 3 && a.ntw == 3 && a.stride == 1 && a.os == 1 && a.ph == 0 && a.pw == 0 &&
+  if (p.math == 0 && g_row3x3 >= 0 && !p.convT && a.nth == 3 && a.ntw == 3 && a.stride == 1 && a.os == 1 && a.ph == 0 && a.pw == 0 &&
       (a.mulh == 1 || a.mulh == -1) && a.offh == -a.mulh && a.mulw == a.mulh && a.offw == a.offh && a.C1 == 0 && (a.C0 == 16 || a.C0 == 32) &&
       a.Wq == 32 && a.Wi == 32 && a.Hq == a.Hi && a.Ho == a.Hq && a.Wo == a.Wq && a.Hq % 4 == 0 && a.N <= 32 && a.N % 4 == 0 &&
       a.scale == nullptr && a.cls_table == nullptr && a.head_w == nullptr && a.operand_format == 0 && (long)a.B * (a.Hq / 4) >= 512 &&

@@ -81,6 +81,7 @@ class UnetWeights(ctypes.Structure):
         ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p),
         ("n_out", ctypes.c_int),
         ("weights_split32", ctypes.c_int),
+        ("math_mode", ctypes.c_int),
     ]
 
 
@@ -121,6 +122,8 @@ SIGNATURES = {
     "m2h_conv_igemm_f32": [ctypes.POINTER(ConvArgs), _P],
     "m2h_conv_igemm_workspace_bytes": [ctypes.POINTER(ConvArgs)],
     "m2h_debug_set": [_I, _I],
+    "m2h_set_math_mode": [_I],
+    "m2h_get_math_mode": [],
     "m2h_unet_down_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P],
     "m2h_unet_up_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P],
     "m2h_unet_down_workspace_bytes": [_I, _I, _I, _I, _I],

@@ -15,6 +15,23 @@ import torch
 from . import _lib, ops
 
 
+def carries_math_mode(cls):
+    """Class decorator for the autograd Functions whose backward launches igemm-engine kernels: the forward records the calling
+    thread's arithmetic (ops.math_mode(), thread-local) and the backward -- which autograd runs on ITS thread -- computes in it."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx._m2h_math = ops.math_mode()
+        return fwd(ctx, *args)
+
+    def backward(ctx, *grads):
+        with ops.math_scope(ctx._m2h_math):
+            return bwd(ctx, *grads)
+
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
 def _conv_args(x, x2, n_out, kh, kw, stride, pad, Ho, Wo):
     B, H, W, C0 = x.shape
     a = _lib.ConvArgs()
@@ -154,6 +171,7 @@ def refresh_pack_memos():
             m.get(base if shape is None else base.view(shape), ci_pad)
 
 
+@carries_math_mode
 class Conv2dNHWC(torch.autograd.Function):
     """y = act(conv2d(cat(x, x2), w) + b) over NHWC activations; w, b in torch layout ([Co,Ci,KH,KW], [Co]).
     ``deslice``: the output is stored de-sliced in the reference's BHWC layout (memory_nets.py:62-67)."""
@@ -226,6 +244,7 @@ def _lin_nograd(x, w_nk, bias=None, name="linear"):
     return ops.linear(x, w_nk, bias, name=name)
 
 
+@carries_math_mode
 class GRUSequence(torch.autograd.Function):
     """h_t = GRUCell(x_t, h_{t-1} * mask_t) for t < T over N rows; x [T*N, I], h0 [N, H], masks [T*N] -> (out [T*N, H], hT).
     Covers single_forward (T = 1) and seq_forward (rnn_state_encoder.py:74-137).  Backward = BPTT with HIP kernels:
@@ -456,6 +475,7 @@ def _convT_phase_args(x, x2, Co, ph, pw):
     return a
 
 
+@carries_math_mode
 class ConvTranspose2dNHWC(torch.autograd.Function):
     """z = conv_transpose2d(cat(x, x2), w, stride 2, pad 1, 4x4) on NHWC (no bias / activation): forward = 4 sub-pixel phase
     GEMMs in one launch; backward: dgrad = an ordinary 4x4/s2/p1 conv of dz with w read as a conv weight (one launch per

@@ -3,6 +3,7 @@ HIP stream only; all arithmetic happens in libm2h.so.  Every function raises Run
 is missing or a tensor is not a contiguous fp32 CUDA(HIP) tensor -- there is no fallback.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -57,8 +58,8 @@ def debug_set(knob, value):
 
 
 MATH_FP32, MATH_BF16X3 = 0, 1
-_math_mode = 0
-FMT_SRC_SPLIT, FMT_W_SPLIT, FMT_DST_SPLIT = 1, 2, 4   # include/m2h.h M2H_FMT_*
+_tls = threading.local()   # the calling thread's arithmetic (mirrors libm2h's thread-local m2h_set_math_mode)
+FMT_SRC_SPLIT, FMT_W_SPLIT, FMT_DST_SPLIT, FMT_MATH_BF16X3, FMT_MATH_FP32 = 1, 2, 4, 8, 16   # include/m2h.h M2H_FMT_*
 
 
 def split32(t):
@@ -73,19 +74,37 @@ def split32(t):
 
 
 def set_math_mode(mode):
-    """Process-wide arithmetic of the igemm forward engine (m2h_debug_set knob 14).
+    """Arithmetic of the igemm forward engine for the CALLING THREAD (m2h_set_math_mode; no process-wide state: two threads may
+    run different modes side by side, tests/test_gpu_unet.py).  Backward passes run on autograd's threads: the autograd Functions
+    of m2h.functional carry the mode of their forward with them (functional.carries_math_mode).
     MATH_FP32 (default): fp32 matrix instructions, exact fp32 products.  MATH_BF16X3: fp32 operands split into bf16 hi + lo
     inside the kernel, products hi*hi + hi*lo + lo*hi on the bf16 matrix pipe with fp32 accumulation (~16 mantissa bits per
     product; tensors in HBM stay fp32).  Applies to shapes the scalar loader takes (channel counts multiples of 32)."""
-    global _math_mode
     if mode not in (MATH_FP32, MATH_BF16X3):
         raise ValueError("math mode must be ops.MATH_FP32 or ops.MATH_BF16X3")
-    debug_set(14, mode)
-    _math_mode = mode
+    _lib.check(_lib.load().m2h_set_math_mode(int(mode)), "m2h_set_math_mode")
+    _tls.math_mode = mode
 
 
 def math_mode():
-    return _math_mode
+    return getattr(_tls, "math_mode", MATH_FP32)
+
+
+class math_scope:
+    """``with ops.math_scope(mode):`` -- the calling thread computes in `mode` inside the block and in its previous mode after."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = math_mode()
+        if self.mode != self.prev:
+            set_math_mode(self.mode)
+
+    def __exit__(self, *exc):
+        if self.mode != self.prev:
+            set_math_mode(self.prev)
+        return False
 
 
 def _ptr(t):

@@ -286,6 +286,7 @@ def unet_forward(enc, dec, mix, masks=None, target_class=None, events=None):
         w.up_w[i], w.up_scale[i], w.up_shift[i] = wsel(wp).data_ptr(), scale.data_ptr(), shift.data_ptr()
     w.head_w, w.head_b, w.n_out = hw.data_ptr(), hb.data_ptr(), hco
     w.weights_split32 = 1 if split else 0
+    w.math_mode = 2 if split else 1   # this call's arithmetic, pinned (include/m2h.h)
     cls_val = None
     if table is not None:
         cls_val = (target_class.reshape(-1).to(torch.float32) + 1.0).contiguous()
