@@ -285,6 +285,41 @@ int m2h_episode_stats_update(const m2h_episode_stats* st, const float* rewards, 
                              const float* mono_losses, const float* monoFromMem_losses, const float* not_done, const float* ndgs,
                              const float* dgs, int N, int A, m2h_stream stream);
 
+/* The whole per-env bookkeeping of one rollout step (ppo_trainer.py:375-455) in one launch: reward (override_rewards /
+ * reward_util, env_utils.py:690-713; with extra_reward the step carries extra_mult x util(next), the effective value of
+ * ppo_trainer.py:395-405), the three STFT-L2 distances of eval_metrics.py:306-366 (binaural masks on exp(mix)-1, mono, mono from
+ * memory; GT phase on both sides) and the per-episode statistics update of m2h_episode_stats_update.  All spectrogram tensors are
+ * [N][L][C] with L = F*T bins: next_mem / mem / mono C = 1, masks / mix C = 2, gt_mono_comps C = 4 (magnitude at 0),
+ * gt_bin_comps C = 8 (magnitudes at 0 and 2).  rewards [N], losses [3][N] (bin, mono, mono-from-memory) are written; stats is
+ * updated in place.  partial: m2h_step_stats_workspace_bytes(N) bytes of scratch; tickets: N uint32 counters, zero before the
+ * first call (the kernel leaves them zero).  override_rewards = 0: rewards = env_rewards (farTarget.yaml: no override). */
+#define M2H_STEP_STATS_CHUNKS 16
+typedef struct m2h_step_stats_args {
+  const float* next_mem;            /* pred_monoFromMem of the NEXT observation (override only) */
+  const float* next_gt_mono_comps;  /* (override only) */
+  const float* mem;                 /* pred_monoFromMem of the current observation */
+  const float* gt_mono_comps;
+  const float* masks;               /* pred_binSepMasks */
+  const float* mix;                 /* mixed_bin_audio_mag */
+  const float* gt_bin_comps;
+  const float* mono;                /* pred_mono */
+  const float* not_done;            /* [N] */
+  const float* env_rewards;         /* [N], used when override_rewards == 0 */
+  const float* probs;               /* [N][A] action probabilities of the step */
+  const float* ndgs;                /* [N] or NULL */
+  const float* dgs;                 /* [N] or NULL */
+  float* rewards;                   /* [N] out */
+  float* losses;                    /* [3][N] out */
+  m2h_episode_stats stats;
+  float* partial;
+  unsigned* tickets;
+  int N, L, A;
+  int override_rewards, extra_reward;
+  float extra_mult;
+} m2h_step_stats_args;
+size_t m2h_step_stats_workspace_bytes(int N);
+int m2h_rollout_step_stats(const m2h_step_stats_args* args /* host */, m2h_stream stream);
+
 /* Batched row copies with DEVICE-resident row indices: RolloutStoragePol.insert / RolloutStorageSep.insert and the rollout
  * step's reads of row `step` (common/rollout_storage.py:68-96, 372-390; ppo_trainer.py:262-300) when the step is replayed from
  * a HIP graph and the host step counter cannot be baked into addresses.  Item i copies `bytes` bytes (multiple of 4) from

@@ -1228,6 +1228,7 @@ int g_wide_stages = 0;    // 1 | 2: LDS stage count of the 128x128 config (0 = 2
 int g_skinny = 0;         // -1: never use the 32/64-row tiles
 int g_extra_lds = 0;      // tuning experiment: dynamic LDS bytes added to every launch (lowers blocks/CU)
 int g_phase_major = 0;    // -1: transposed-conv phases as grid z (four passes over the input) instead of interleaved
+static constexpr int M2H_FMT_LAYOUT_BITS = M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT | M2H_FMT_DST_SPLIT;   // operand_format minus the M2H_FMT_MATH_* bits
 thread_local int tl_math_mode = 0;   // m2h_set_math_mode: the calling thread's arithmetic (0 fp32 MFMA, 1 bf16x3 split products)
 int g_tapshare = 0;       // -1: never use the tap-sharing transposed-conv kernel
 int g_tap_bm = 0;         // 128: 128-output tiles only in the tap-sharing kernel
@@ -1474,7 +1475,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   // M <= 16 rows that are each one contiguous run of floats: Linear; a conv whose tap window covers the whole image and gives
   // one output pixel; a transposed conv over a 1 x 1 image (one tap per phase).  Weight streaming on the skinny kernel.
   if (p.math == 0 && g_skinny_linear >= 0 && g_fast_loader >= 0 && p.fast_ok && M <= 16 && a.C1 == 0 && a.Hq == 1 && a.Wq == 1 && a.os >= 1 && a.N % 4 == 0 &&
-      a.out_mode == M2H_OUT_NHWC && a.cls_table == nullptr && a.head_w == nullptr && a.operand_format == 0 &&
+      a.out_mode == M2H_OUT_NHWC && a.cls_table == nullptr && a.head_w == nullptr && (a.operand_format & M2H_FMT_LAYOUT_BITS) == 0 &&
       (size_t)a.N * p.Kw * (p.convT ? 4 : 1) >= (size_t)1 << 18) {
     bool dense;
     if (p.convT) dense = a.Hi == 1 && a.Wi == 1 && p.thn == 1 && p.twn == 1 && p.th0 == 0 && p.tw0 == 0 && a.Ho == 2 && a.Wo == 2;
@@ -1499,7 +1500,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   }
   // small pixel counts per phase (<= 1024; knob 24 > 0 overrides the limit): 32 x 16 tiles without LDS staging or split-K
   if (p.math == 0 && g_skinny_gather >= 0 && g_fast_loader >= 0 && p.fast_ok && M > 16 && M <= (g_skinny_gather > 0 ? g_skinny_gather : 1024) &&
-      a.N % 16 == 0 && a.out_mode == M2H_OUT_NHWC && a.cls_table == nullptr && a.head_w == nullptr && a.operand_format == 0 &&
+      a.N % 16 == 0 && a.out_mode == M2H_OUT_NHWC && a.cls_table == nullptr && a.head_w == nullptr && (a.operand_format & M2H_FMT_LAYOUT_BITS) == 0 &&
       p.Ctot % 16 == 0 && (size_t)a.N * p.Kw * (p.convT ? 4 : 1) >= (size_t)1 << 16) {
     const int phases = p.convT ? 4 : 1;
     p.MT = (int)((M + 15) / 16);
@@ -1514,7 +1515,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   if (p.math == 0 && g_row3x3 >= 0 && !p.convT && a.nth == 3 && a.ntw == 3 && a.stride == 1 && a.os == 1 && a.ph == 0 && a.pw == 0 &&
       (a.mulh == 1 || a.mulh == -1) && a.offh == -a.mulh && a.mulw == a.mulh && a.offw == a.offh && a.C1 == 0 && (a.C0 == 16 || a.C0 == 32) &&
       a.Wq == 32 && a.Wi == 32 && a.Hq == a.Hi && a.Ho == a.Hq && a.Wo == a.Wq && a.Hq % 4 == 0 && a.N <= 32 && a.N % 4 == 0 &&
-      a.scale == nullptr && a.cls_table == nullptr && a.head_w == nullptr && a.operand_format == 0 && (long)a.B * (a.Hq / 4) >= 512 &&
+      a.scale == nullptr && a.cls_table == nullptr && a.head_w == nullptr && (a.operand_format & M2H_FMT_LAYOUT_BITS) == 0 && (long)a.B * (a.Hq / 4) >= 512 &&
       (a.out_mode == M2H_OUT_NHWC || a.N % 16 == 0)) {
     const long chunks = (long)a.B * (a.Hq / 4);
     const dim3 grid((unsigned)(chunks < 512 ? chunks : 512)), blk(256);

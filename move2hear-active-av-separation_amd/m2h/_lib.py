@@ -16,7 +16,7 @@ CSRC = os.path.join(_PKG_ROOT, "csrc")
 INCLUDE = os.path.join(_REPO_ROOT, "include")
 # M2H_LIB: kernel-tuning override -- load an experimental build of the same C-ABI (tools/build_variant.sh) instead of the in-tree one
 LIB_PATH = os.environ.get("M2H_LIB") or os.path.join(_HERE, "libm2h.so")
-SOURCES = ["conv_igemm.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "api.hip"]
+SOURCES = ["conv_igemm.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "rollout_fused.hip", "api.hip"]
 
 _lock = threading.Lock()
 _lib = None
@@ -31,17 +31,38 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """Compiles csrc/*.hip for gfx950 into m2h/libm2h.so (cross-compiles without a GPU)."""
+    """Compiles csrc/*.hip for gfx950 into m2h/libm2h.so (cross-compiles without a GPU).  One object per source under
+    csrc/build/, compiled in parallel and re-used while the source and the headers are older (force=True recompiles all)."""
     if not force and not _stale():
         return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, "-I" + CSRC]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+
+    def compile_one(src):
+        path, obj = os.path.join(CSRC, src), os.path.join(objdir, src + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), newest_header):
+            return obj
+        cmd = [hipcc] + flags + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stdout))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), 7)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout)
+        raise RuntimeError("hipcc link failed:\n" + r.stdout)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 
@@ -97,6 +118,15 @@ class EpisodeStats(ctypes.Structure):
     _fields_ = [(name, ctypes.c_void_p) for name in EPISODE_STATS_FIELDS]
 
 
+class StepStatsArgs(ctypes.Structure):
+    """Mirror of ``struct m2h_step_stats_args`` (include/m2h.h)."""
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("next_mem", "next_gt_mono_comps", "mem", "gt_mono_comps", "masks", "mix", "gt_bin_comps", "mono",
+                                                "not_done", "env_rewards", "probs", "ndgs", "dgs", "rewards", "losses")] +
+                [("stats", EpisodeStats), ("partial", ctypes.c_void_p), ("tickets", ctypes.c_void_p), ("N", ctypes.c_int), ("L", ctypes.c_int),
+                 ("A", ctypes.c_int), ("override_rewards", ctypes.c_int), ("extra_reward", ctypes.c_int), ("extra_mult", ctypes.c_float)])
+
+
+STEP_STATS_CHUNKS = 16
 ROWS_COPY_MAX = 32
 
 
@@ -177,6 +207,8 @@ SIGNATURES = {
     "m2h_gather_envs": [_P, _P, _P, _I, _I, _I, _Z, _P],
     "m2h_gru_step": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_episode_stats_update": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "m2h_step_stats_workspace_bytes": [_I],
+    "m2h_rollout_step_stats": [ctypes.POINTER(StepStatsArgs), _P],
     "m2h_rows_copy": [_P, _I, _P, _P],
     "m2h_step_index_advance": [_P, _I, _I, _P],
     "m2h_synth_env_step": [_P, _P, _P, _I, _I, _P],

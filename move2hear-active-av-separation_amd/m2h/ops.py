@@ -608,6 +608,49 @@ def episode_stats_update(stats, rewards, dist_probs, bin_losses, mono_losses, mo
                                                         N, A, _stream(ins[0])), "m2h_episode_stats_update")
 
 
+_step_stats_scratch = {}
+
+
+def rollout_step_stats(stats, next_mem, next_gt_mono_comps, mem, gt_mono_comps, masks, mix, gt_bin_comps, mono, not_done, probs,
+                       env_rewards=None, ndgs=None, dgs=None, override=True, extra=False, extra_mult=10.0):
+    """The per-env bookkeeping of one rollout step in ONE launch (m2h_rollout_step_stats): reward, the three STFT-L2 distances and
+    the per-episode statistics update (ppo_trainer.py:375-455).  Returns (rewards [N,1], losses [3,N]: bin / mono / mono-from-memory);
+    `stats` (the object of episode_stats_update) is updated in place.  Scratch (partial sums, tickets) is cached per (device, N)."""
+    a = _lib.StepStatsArgs()
+    N, A = probs.shape
+    L = mem.shape[1] * mem.shape[2]
+    tens = dict(next_mem=next_mem if override else None, next_gt_mono_comps=next_gt_mono_comps if override else None, mem=mem,
+                gt_mono_comps=gt_mono_comps, masks=masks, mix=mix, gt_bin_comps=gt_bin_comps, mono=mono, not_done=not_done,
+                env_rewards=None if override else env_rewards, probs=probs, ndgs=ndgs, dgs=dgs)
+    keep = []
+    for name, t in tens.items():
+        if t is not None:
+            t = t.contiguous()
+            _chk(t, "rollout_step_stats")
+            keep.append(t)
+            setattr(a, name, t.data_ptr())
+    if mem.numel() != N * L or masks.numel() != 2 * N * L or mix.numel() != 2 * N * L or gt_mono_comps.numel() != 4 * N * L or \
+            gt_bin_comps.numel() != 8 * N * L or mono.numel() != N * L or not_done.numel() != N:
+        raise RuntimeError("m2h.rollout_step_stats: tensor sizes do not match N = %d envs x L = %d bins" % (N, L))
+    for name in _lib.EPISODE_STATS_FIELDS:
+        t = getattr(stats, name)
+        _chk(t, "rollout_step_stats")
+        setattr(a.stats, name, t.data_ptr())
+    dev = mem.device
+    key = (dev.index, N)
+    scratch = _step_stats_scratch.get(key)
+    if scratch is None:
+        scratch = _step_stats_scratch[key] = (torch.empty(_lib.load().m2h_step_stats_workspace_bytes(N) // 4, device=dev),
+                                              torch.zeros(N, dtype=torch.int32, device=dev))
+    rewards = torch.empty((N, 1), device=dev)
+    losses = torch.empty((3, N), device=dev)
+    a.rewards, a.losses, a.partial, a.tickets = rewards.data_ptr(), losses.data_ptr(), scratch[0].data_ptr(), scratch[1].data_ptr()
+    a.N, a.L, a.A, a.override_rewards, a.extra_reward, a.extra_mult = N, L, A, int(bool(override)), int(bool(extra)), float(extra_mult)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().m2h_rollout_step_stats(ctypes.byref(a), _stream(mem)), "m2h_rollout_step_stats")
+    return rewards, losses
+
+
 def rows_copy(items, idx):
     """Batched row copies with device-resident row indices (m2h_rows_copy).  items: (src, dst, src_slot, dst_slot) with
     tensors; a slot >= 0 selects row idx[slot] along dim 0 of that tensor (the other side is then one whole row), a negative

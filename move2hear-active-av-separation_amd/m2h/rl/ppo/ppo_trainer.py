@@ -195,23 +195,18 @@ class PPOTrainer:
         # next-step predictions, needed for the reward of the present step (:358-373)
         next_pred_binSepMasks, next_pred_mono = self._separate(batch)
         next_pred_monoFromMem = ac.get_monoFromMem_masked(next_pred_mono, pred_monoFromMem, masks)
-        if cfg.sep_reward_weight == 1.0 and cfg.nav_reward_weight == 0.0:  # :385-405
-            nxt = ops.sq_stats(next_pred_monoFromMem, batch["gt_mono_comps"], 0)
-            if extra:
-                # What the reference computes on this step: override_rewards writes into the list it is given and returns that
-                # same list (env_utils.py:692-706), so the "extra" call (:396-402) overwrites the quality-improvement rewards and
-                # ``np.array(rewards) + np.array(rewards_extra)`` (:405) adds the list to itself: 2 x multiplier x util(next).
-                # Pinned by tests/golden/trainer_near.npz (the reference's own loop).
-                rewards = ops.rewards_from_stats(nxt, None, masks, L, False, 2.0 * cfg.extra_reward_multiplier)
-            else:
-                cur = ops.sq_stats(pred_monoFromMem, step_observation["gt_mono_comps"], 0)
-                rewards = ops.rewards_from_stats(nxt, cur, masks, L, True)
-        # STFT-L2 bookkeeping (:407-420)
-        bin_losses = ops.stft_l2(pred_binSepMasks, step_observation["gt_bin_comps"], 2, mix=step_observation["mixed_bin_audio_mag"])
-        mono_losses = ops.stft_l2(pred_mono, step_observation["gt_mono_comps"], 1)
-        monoFromMem_losses = ops.stft_l2(pred_monoFromMem, step_observation["gt_mono_comps"], 1)
-        ops.episode_stats_update(st, rewards, distribution_probs, bin_losses, mono_losses, monoFromMem_losses, masks,   # :421-478
-                                 infos.get("normalized_geo_distance_to_target_audio_source"), infos.get("geo_distance_to_target_audio_source"))
+        # rewards (:385-405), STFT-L2 bookkeeping (:407-420) and the per-episode statistics (:421-455): one launch
+        # (ops.rollout_step_stats).  On the extra-reward step the reference's override_rewards writes into the list it is given and
+        # returns that same list (env_utils.py:692-706), so the "extra" call (:396-402) overwrites the quality-improvement rewards
+        # and ``np.array(rewards) + np.array(rewards_extra)`` (:405) adds the list to itself: 2 x multiplier x util(next).
+        # Pinned by tests/golden/trainer_near.npz (the reference's own loop).
+        override = cfg.sep_reward_weight == 1.0 and cfg.nav_reward_weight == 0.0
+        rewards, _losses = ops.rollout_step_stats(
+            st, next_pred_monoFromMem, batch["gt_mono_comps"], pred_monoFromMem, step_observation["gt_mono_comps"], pred_binSepMasks,
+            step_observation["mixed_bin_audio_mag"], step_observation["gt_bin_comps"], pred_mono, masks, distribution_probs,
+            env_rewards=rewards, ndgs=infos.get("normalized_geo_distance_to_target_audio_source"),
+            dgs=infos.get("geo_distance_to_target_audio_source"), override=override, extra=extra,
+            extra_mult=2.0 * cfg.extra_reward_multiplier)
         pol_args = (batch, recurrent_hidden_states_pol, actions, actions_log_probs, values, rewards, masks)
         pol_kw = dict(pred_binSepMasks=pred_binSepMasks, pred_mono=pred_mono, pred_monoFromMem=pred_monoFromMem)
         if at is None:
@@ -219,6 +214,11 @@ class PPOTrainer:
             rs.insert(batch, masks, pred_monoFromMem=pred_monoFromMem)
         else:
             ops.rows_copy(ro.insert_items((0, 1), *pol_args, **pol_kw) + rs.insert_items(2, batch, masks, pred_monoFromMem=pred_monoFromMem), at)
+            # hand the next-observation separator outputs over to the following step's static buffers: one batched copy, AFTER the
+            # inserts above have read those buffers (they hold this step's outputs)
+            nxt = (next_pred_binSepMasks, next_pred_mono, next_pred_monoFromMem)
+            ops.rows_copy([(src.contiguous(), dst, -1, -1) for src, dst in zip(nxt, cache)], at)
+            return cache
         return next_pred_binSepMasks, next_pred_mono, next_pred_monoFromMem
 
     # ------------------------------------------------------------------ HIP-graph replay of the rollout step
@@ -263,9 +263,7 @@ class PPOTrainer:
             g = torch.cuda.CUDAGraph()
             g.register_generator_state(self.envs.generator)
             with torch.no_grad(), graphs.capture(g, pool=gs.pool):
-                nxt = self._rollout_step_device(gs.cache, gs.idx, extra, done)
-                for dst, src in zip(gs.cache, nxt):
-                    dst.copy_(src)
+                self._rollout_step_device(gs.cache, gs.idx, extra, done)   # (leaves the next step's separator outputs in gs.cache)
                 ops.step_index_advance(gs.idx, ro.num_steps, rs.num_steps)  # ro_step <- (ro_step + 1) % T, rs_step likewise
             if gs.pool is None:
                 gs.pool = g.pool()

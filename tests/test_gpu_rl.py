@@ -317,3 +317,55 @@ def test_skinny_linear_kernel_matches_the_engine_and_torch(M, K, N, slope):
         finally:
             ops.debug_set(23, 0)
     assert _rel(got[0], ref) < 2e-5 and _rel(got[-1], ref) < 2e-5 and _rel(got[0], got[-1]) < 1e-5
+
+
+@pytest.mark.parametrize("override,extra", [(True, False), (True, True), (False, False)])
+def test_fused_rollout_step_stats_matches_the_separate_kernels(override, extra):
+    """m2h_rollout_step_stats (one launch: rewards, three STFT-L2 distances, episode statistics) against the separate kernels it
+    replaces in the trainer (sq_stats, rewards_from_stats, stft_l2, episode_stats_update -- themselves pinned to the reference
+    fixtures above): rewards / losses to fp32 summation order, statistics accordingly; repeated launches are bit-identical (the
+    partial sums are added in slice order whatever the arrival order) and the ticket counters return to zero."""
+    from types import SimpleNamespace
+    from m2h import _lib, ops
+    dev = _dev()
+    N, A, L = 14, 3, 512 * 32
+    g = torch.Generator().manual_seed(31)
+    obs, nobs = _obs(N, 71, dev), _obs(N, 72, dev)
+    pm = torch.randn(N, 512, 32, 2, generator=g).to(dev)
+    mono, mem, nmem = (torch.rand(N, 512, 32, 1, generator=g).to(dev) for _ in range(3))
+    probs = torch.softmax(torch.randn(N, A, generator=g), 1).to(dev)
+    masks = (torch.rand(N, 1, generator=g) > 0.3).float().to(dev)
+    env_r, ndg, dg = (torch.randn(N, 1, generator=g).to(dev) for _ in range(3))
+    mk = lambda: SimpleNamespace(**{n: (torch.rand(N, A if "dist_probs" in n else 1, generator=torch.Generator().manual_seed(5)) + 1).to(dev)  # noqa: E731
+                                    for n in _lib.EPISODE_STATS_FIELDS})
+    ref, fused, fused2 = mk(), mk(), mk()
+    if override:
+        nxt = ops.sq_stats(nmem, nobs["gt_mono_comps"], 0)
+        if extra:
+            r_ref = ops.rewards_from_stats(nxt, None, masks, L, False, 20.0)
+        else:
+            r_ref = ops.rewards_from_stats(nxt, ops.sq_stats(mem, obs["gt_mono_comps"], 0), masks, L, True)
+    else:
+        r_ref = env_r
+    bl = ops.stft_l2(pm, obs["gt_bin_comps"], 2, mix=obs["mixed_bin_audio_mag"])
+    ml = ops.stft_l2(mono, obs["gt_mono_comps"], 1)
+    fl = ops.stft_l2(mem, obs["gt_mono_comps"], 1)
+    ops.episode_stats_update(ref, r_ref, probs, bl, ml, fl, masks, ndg, dg)
+    outs = []
+    for st in (fused, fused2):
+        outs.append(ops.rollout_step_stats(st, nmem, nobs["gt_mono_comps"], mem, obs["gt_mono_comps"], pm, obs["mixed_bin_audio_mag"],
+                                           obs["gt_bin_comps"], mono, masks, probs, env_rewards=env_r, ndgs=ndg, dgs=dg, override=override,
+                                           extra=extra, extra_mult=20.0))
+    (r, losses), (r2, losses2) = outs
+    assert torch.equal(r, r2) and torch.equal(losses, losses2)
+    for n in _lib.EPISODE_STATS_FIELDS:
+        assert torch.equal(getattr(fused, n), getattr(fused2, n)), n
+    close = lambda x, y: torch.allclose(x.cpu().reshape(-1), y.cpu().reshape(-1), rtol=2e-6, atol=1e-7)  # noqa: E731
+    # (the quality-improvement reward is a difference of two near-equal ratios: absolute tolerance of a few ulps of those ratios)
+    assert torch.allclose(r.cpu(), r_ref.cpu(), rtol=2e-6, atol=2e-6) and close(losses[0], bl) and close(losses[1], ml) and close(losses[2], fl)
+    if not override:
+        assert torch.equal(r, env_r)
+    assert float(r[masks == 0].abs().sum()) == 0 or not override
+    for n in _lib.EPISODE_STATS_FIELDS:
+        assert torch.allclose(getattr(fused, n).cpu(), getattr(ref, n).cpu(), rtol=3e-6, atol=3e-6), n
+    assert int(ops._step_stats_scratch[(dev.index, N)][1].abs().sum()) == 0

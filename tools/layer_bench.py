@@ -12,10 +12,26 @@ import torch  # noqa: E402
 from m2h import ops  # noqa: E402
 
 
+GRAPH = False
+
+
 def time_fn(fn, reps):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    if GRAPH:   # small launches are host-bound when enqueued from Python: capture `reps` launches once, time the replay
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -31,7 +47,10 @@ def main():
     ap.add_argument("--tm", type=int, default=256)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--variants", default="auto;splitk=-1;stages=2;splitk=-1,stages=2")
+    ap.add_argument("--graph", action="store_true", help="time a HIP-graph replay of the repetitions (launch-bound shapes)")
     a = ap.parse_args()
+    global GRAPH
+    GRAPH = a.graph
     dev = torch.device("cuda", 0)
     B, T = a.batch, a.tm
     layers = []
