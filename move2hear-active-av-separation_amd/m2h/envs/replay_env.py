@@ -96,6 +96,13 @@ class ReplayHostVecEnv:
             out.append((self._obs(e), reward, done, {INFO_KEYS[0]: float(ndg), INFO_KEYS[1]: float(dg)}))
         return out
 
+    def current_episodes(self):
+        """What the reference's evaluation loop reads of ``VectorEnvCustom.current_episodes()`` (ppo_trainer.py:1207-1213, :1440-1460):
+        scene id, episode id, goals / start position (none here)."""
+        from types import SimpleNamespace
+        return [SimpleNamespace(scene_id="replay/scene%d/scene%d.glb" % (e, e), episode_id=str(int(self.episode[e])), goals=[], info=[],
+                                start_position=[0.0, 0.0, 0.0]) for e in range(self.num_envs)]
+
     def close(self):
         pass
 

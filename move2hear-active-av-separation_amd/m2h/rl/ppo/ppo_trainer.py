@@ -431,7 +431,7 @@ class PPOTrainer:
         return ac.to(self.device).eval()
 
     def eval(self, num_episodes=None, checkpoint_path=None, waveform_metrics=("si_sdr",), deterministic=None,
-             switch_checkpoint_path=None, time_thres_for_pol_switch=None):
+             switch_checkpoint_path=None, time_thres_for_pol_switch=None, trace=None):
         """Evaluation loop of `_eval_checkpoint` (reference :1015-1551) on this trainer's vectorised env: eval-mode policy,
         deterministic or sampled actions (ppo_cfg.deterministic_eval), per-step STFT-L2 of the separated mono (:1369-1385),
         waveform metrics of the LAST step of each episode (:1400-1415) when the env provides `mixed_bin_audio_phase`, and the
@@ -440,7 +440,9 @@ class PPOTrainer:
         holding ``state_dict_nav`` and ``state_dict_qualImprov``; the navigation policy (with its own separators, memory and
         hidden state) acts for the first ``time_thres_for_pol_switch`` steps of an episode (config/default.py:101: 80), the
         quality-improvement policy afterwards; the memory is masked by the navigation policy's not-done flags throughout and the
-        quality-improvement policy's flags start tracking the env only once it acts (:1348-1360)."""
+        quality-improvement policy's flags start tracking the env only once it acts (:1348-1360).
+        trace: optional list; gets one (actions, mono STFT-L2, monoFromMem STFT-L2) tuple of host tensors per step (tests).
+        Pinned against the reference's own ``_eval_checkpoint`` run (tests/golden/trainer_eval.npz, one and two policies)."""
         import numpy as np
         from ...common import eval_metrics as EM
         cfg, ac = self.config, self.actor_critic
@@ -487,6 +489,8 @@ class PPOTrainer:
                 _db, d_mono = EM.STFT_L2_distance(obs["mixed_bin_audio_mag"], pm, obs["gt_bin_comps"], mono, obs["gt_mono_comps"])
                 d_mem = ops.stft_l2(mem, obs["gt_mono_comps"], 1)
                 last_obs, last_mono, last_mem = obs, mono, mem
+                if trace is not None:
+                    trace.append((actions.cpu(), d_mono.cpu(), d_mem.cpu()))
                 obs, rewards, not_done, _infos = self.envs.step(actions)
                 if qual:
                     not_done_q = not_done                                        # :1354-1359

@@ -50,9 +50,18 @@ STAT_NAMES = ("current_episode_reward", "current_episode_step", "current_episode
 
 
 class Cfg(dict):
-    """Attribute-access config with yacs' defrost/freeze (no-ops)."""
-    __getattr__ = dict.__getitem__
+    """Attribute-access config with yacs' defrost/freeze (no-ops) and clone."""
     __setattr__ = dict.__setitem__
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def clone(self):
+        import copy
+        return copy.deepcopy(self)
 
     def defrost(self):
         pass
@@ -103,6 +112,7 @@ def _slice_source(lines, start_pred, end_pred):
 class Recorder:
     def __init__(self):
         self.steps, self.acts, self.pol_updates, self.sep_updates, self.scalars, self.ckpts = [], [], [], [], [], []
+        self.log, self.l2 = [], []
 
     # TensorboardWriter stand-in
     def __call__(self, *a, **k):
@@ -118,8 +128,9 @@ class Recorder:
         self.scalars.append((tag, float(value), float(step)))
 
 
-def build_reference_trainer(ref, rec):
-    """exec the reference's PPOTrainer class statement (through the end of ``train``) and subclass it with the recorder."""
+def build_reference_trainer(ref, rec, whole_class=False):
+    """exec the reference's PPOTrainer class statement (through the end of ``train``; with whole_class through ``_eval_checkpoint``,
+    the end of the file) and subclass it with the recorder."""
     from collections import deque
     import contextlib, gzip, logging, pickle, random, time  # noqa: E401
     from typing import Dict
@@ -128,7 +139,8 @@ def build_reference_trainer(ref, rec):
     import habitat  # the stub registered by _ref_import
 
     lines = open(os.path.join(REF_ROOT, "audio_separation/rl/ppo/ppo_trainer.py")).read().split("\n")
-    cls_src = _slice_source(lines, lambda l: l.startswith("class PPOTrainer("), lambda l: l.startswith("    def _eval_checkpoint("))
+    cls_src = _slice_source(lines + ["#EOF"], lambda l: l.startswith("class PPOTrainer("),
+                            (lambda l: l == "#EOF") if whole_class else (lambda l: l.startswith("    def _eval_checkpoint(")))
     env_lines = open(os.path.join(REF_ROOT, "audio_separation/common/env_utils.py")).read().split("\n")
     rew_src = _slice_source(env_lines, lambda l: l.startswith("def override_rewards("), lambda l: l.strip() == "return reward") + "\n    return reward\n"
 
@@ -138,9 +150,24 @@ def build_reference_trainer(ref, rec):
             self.config = config
             self.flush_secs = 30
 
+        def _setup_eval_config(self, checkpoint_config):
+            # base_trainer.py:104-140 merges the checkpoint's config UNDER the evaluation config (yacs); the fixture's two configs
+            # carry the same values, so the merge is the evaluation config
+            return self.config.clone()
+
+    class RecordingLogger:
+        def __getattr__(self, name):
+            return lambda *a, **k: rec.log.append(" ".join(str(x) for x in a)) if name == "info" else None
+
+    def recording_l2(*a, **k):
+        out = ref["eval_metrics"].STFT_L2_distance(*a, **k)
+        rec.l2.append((out[0].numpy().copy(), out[1].numpy().copy()))
+        return out
+
     ns = {"contextlib": contextlib, "os": os, "time": time, "logging": logging, "deque": deque, "Dict": Dict, "json": json, "random": random,
           "pickle": pickle, "gzip": gzip, "np": np, "torch": torch, "LambdaLR": LambdaLR, "distrib": distrib,
-          "Config": habitat.Config, "logger": habitat.logger, "BaseRLTrainer": BaseRLTrainer, "F": torch.nn.functional,
+          "Config": habitat.Config, "logger": RecordingLogger(), "BaseRLTrainer": BaseRLTrainer, "F": torch.nn.functional, "tqdm": __import__("tqdm").tqdm,
+          "norm": np.linalg.norm, "baseline_registry": None,
           "construct_envs": lambda config, env_class, workers_ignore_signals=False: ReplayHostVecEnv(
               config.NUM_PROCESSES, seed=config.SEED, episode_len=config.TASK_CONFIG.ENVIRONMENT.MAX_EPISODE_STEPS,
               pool=config.REPLAY.pool, ragged=config.REPLAY.ragged, env_rewards=config.REPLAY.env_rewards),
@@ -148,7 +175,7 @@ def build_reference_trainer(ref, rec):
           "RolloutStoragePol": ref["rollout_storage"].RolloutStoragePol, "RolloutStorageSep": ref["rollout_storage"].RolloutStorageSep,
           "TensorboardWriter": rec, "add_signal_handlers": lambda: None, "init_distrib_slurm": ref["ddppo_utils"].init_distrib_slurm,
           "load_interrupted_state": lambda: None, "batch_obs": ref["utils"].batch_obs, "linear_decay": ref["utils"].linear_decay,
-          "STFT_L2_distance": ref["eval_metrics"].STFT_L2_distance, "compute_waveform_quality": None,
+          "STFT_L2_distance": recording_l2, "compute_waveform_quality": None,
           "Move2HearPolicy": ref["rl_policy"].Move2HearPolicy, "PPO": ref["ppo"].PPO, "DDPPO": ref["ppo"].DDPPO}
     exec(rew_src, ns)
     exec(cls_src, ns)
@@ -166,6 +193,8 @@ def build_reference_trainer(ref, rec):
 
     class Harness(Ref):
         def load_checkpoint(self, path, *a, **k):
+            if isinstance(path, dict):
+                return path
             sd = synthetic.make_state_dict(synthetic.passive_shapes(), self.config.REPLAY.passive_seed)
             return {"state_dict": {"actor_critic." + n: torch.from_numpy(np.asarray(v)) for n, v in sd.items()}}
 
@@ -174,13 +203,18 @@ def build_reference_trainer(ref, rec):
 
         def _setup_actor_critic_agent(self, world_rank=0):
             super()._setup_actor_critic_agent(world_rank=world_rank)
-            act = self.actor_critic.act
 
-            def recording_act(*a, **k):
-                out = act(*a, **k)
-                rec.acts.append(out)
-                return out
-            self.actor_critic.act = recording_act
+            def wrap(pol):
+                act = pol.act
+
+                def recording_act(*a, **k):
+                    out = act(*a, **k)
+                    rec.acts.append(out)
+                    return out
+                pol.act = recording_act
+            for name in ("actor_critic", "actor_critic_nav", "actor_critic_qualImprov"):
+                if getattr(self, name, None) is not None:
+                    wrap(getattr(self, name))
 
         def _collect_rollout_step(self, rollouts_pol, rollouts_sep, *stats):
             step = rollouts_pol.step
@@ -302,7 +336,63 @@ def gen_ddp(_=None):
     print("trainer_ddp2: replicas identical after training:", same, "rank losses", out["rank0.pol.losses"].tolist(), out["rank1.pol.losses"].tolist())
 
 
-GENS = {"near": gen_near, "far": gen_far, "ddp": gen_ddp}
+def eval_config(switch, deterministic, **over):
+    """config/test/nearTarget.yaml / farTarget.yaml at fixture size: one process, EVAL_EPISODE_COUNT episodes, no waveform metrics
+    (compute_waveform_quality needs librosa)."""
+    cfg = trainer_config(master_port=18750, NUM_PROCESSES=1, use_ddppo=True, **over)
+    cfg.RL.PPO.switch_policy = switch
+    cfg.RL.PPO.deterministic_eval = deterministic
+    cfg.RL.PPO.time_thres_for_pol_switch = 3
+    cfg.update(EVAL=Cfg(USE_CKPT_CONFIG=False, SPLIT="val"), EPS_SCENES=[], EVAL_EPISODE_COUNT=4, COMPUTE_EVAL_METRICS=False,
+               EVAL_METRICS_TO_COMPUTE=[], MODEL_DIR=cfg.CHECKPOINT_FOLDER, TENSORBOARD_DIR=cfg.CHECKPOINT_FOLDER, CMD_TRAILING_OPTS=[])
+    cfg.TASK_CONFIG.DATASET = Cfg(SPLIT="val", DATA_PATH="", VERSION="")
+    cfg.TASK_CONFIG.TASK.MEASUREMENTS = []
+    return cfg
+
+
+def _policy_ckpt(seed):
+    return {"actor_critic." + k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), seed).items()}
+
+
+def gen_eval(_=None):
+    """The reference's evaluation loop (_eval_checkpoint, ppo_trainer.py:1015-1551) on the replay env, one process: (a) one policy,
+    sampled actions; (b) the far-target evaluation with two policies (RL.PPO.switch_policy: navigation policy for the first
+    time_thres_for_pol_switch steps of an episode, quality-improvement policy after), deterministic actions.  Stored: per-step
+    STFT-L2 distances (both calls), actions, env states, the per-episode aggregates the loop logs."""
+    import re
+    ref = load_reference()
+    torch.set_num_threads(4)
+    out = {}
+    for tag, switch, det in (("single", False, False), ("switch", True, True)):
+        cfg = eval_config(switch, det, MAX_EPISODE_STEPS=6, SEED=5)
+        rec = Recorder()
+        T = build_reference_trainer(ref, rec, whole_class=True)
+        tr = T(cfg)
+        tr.device = torch.device("cpu")
+        if switch:
+            ckpt = {"state_dict_nav": _policy_ckpt(7), "config_nav": cfg, "state_dict_qualImprov": _policy_ckpt(8), "config_qualImprov": cfg}
+        else:
+            ckpt = {"state_dict": _policy_ckpt(7), "config": cfg}
+        tr._eval_checkpoint(ckpt, rec, 0)
+        out[tag + ".actions"] = np.array(tr.envs.actions_seen)
+        out[tag + ".mem_l2"] = np.array([float(m[1][0, 0]) for m in rec.l2[0::2]])       # first call of a step: (_, monoFromMem)
+        out[tag + ".bin_l2"] = np.array([float(m[0][0, 0]) for m in rec.l2[1::2]])       # second call: (bin, mono)
+        out[tag + ".mono_l2"] = np.array([float(m[1][0, 0]) for m in rec.l2[1::2]])
+        agg = {}
+        for line in rec.log:
+            m = re.match(r"(Mono|MonoFromMem) STFT L2 loss (at last step|over all steps) --- mean: ([-0-9.e]+), std: ([-0-9.e]+)", line)
+            if m:
+                agg[("mono" if m.group(1) == "Mono" else "monoFromMem") + "_loss_" + ("last_step" if "last" in m.group(2) else "all_steps")] = \
+                    [float(m.group(3)), float(m.group(4))]
+        assert len(agg) == 4, rec.log
+        for k, v in agg.items():
+            out[tag + ".agg." + k] = np.array(v)
+        out[tag + ".config"] = _cfg_record(cfg)
+        print("trainer_eval[%s]: %d steps, actions %s, aggregates %s" % (tag, len(out[tag + ".actions"]), out[tag + ".actions"].reshape(-1).tolist(), agg))
+    np.savez_compressed(os.path.join(GOLD, "trainer_eval.npz"), meta=json.dumps(META), **out)
+
+
+GENS = {"near": gen_near, "far": gen_far, "ddp": gen_ddp, "eval": gen_eval}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -366,3 +366,60 @@ def train(cfg, envs_per_rank, sd, forced_actions=None, distributed=True, on_step
     rec["state_dict"] = {kk: v.detach() for kk, v in sd.items()}
     rec["ranks"] = ranks
     return rec
+
+
+def eval_loop(cfg, envs, sds, num_episodes, deterministic, switch_thres=None, forced_actions=None):
+    """PPOTrainer._eval_checkpoint (ppo_trainer.py:1015-1551) for ONE process (the reference asserts NUM_PROCESSES == 1, :1052).
+    sds: [state dict] for one policy, or [navigation, quality-improvement] with ``switch_thres`` = RL.PPO.time_thres_for_pol_switch
+    (:1231-1312): the navigation policy acts for the first ``switch_thres`` steps of an episode, the quality-improvement policy
+    afterwards; the previous memory is masked with the NAVIGATION policy's not-done flags in both phases (:1276-1281) and the
+    quality-improvement policy's flags follow the env only while it acts (:1348-1360).
+    Returns per-step (actions, mono, monoFromMem STFT-L2) and the four aggregates the reference logs (:1484-1504)."""
+    N = envs.num_envs
+    assert N == 1
+    batch = batch_obs(envs.reset())
+    hs = [torch.zeros(1, N, cfg["hidden_size"]) for _ in sds]
+    nd = [torch.ones(N, 1) for _ in sds]
+    prev_mem = torch.zeros(N, 512, 32, 1)
+    steps, step_count, done_eps = [], 0, 0
+    last, allsteps = {"mono": [], "mem": []}, {"mono": [], "mem": []}
+    acc = {"mono": 0.0, "mem": 0.0}
+    while done_eps < num_episodes:
+        w = 0 if (switch_thres is None or step_count < switch_thres) else 1
+        sd = sds[w]
+        with torch.no_grad():
+            pm = O.get_binSepMasks(sd, batch["mixed_bin_audio_mag"], batch["target_class"])
+            mono = O.convert_bin2mono(sd, pm, batch["mixed_bin_audio_mag"])
+            mem = O.acoustic_mem(sd, mono, O.mask_prev_mem(prev_mem, nd[0]))
+            feats, h, _ = O.policy_net(sd, batch, hs[w], nd[w], pm, mono, mem)
+            _v, _lp_all, probs = O.heads(sd, feats)
+            if forced_actions is not None:
+                actions = forced_actions[len(steps)]
+            else:
+                actions = probs.argmax(dim=-1, keepdim=True) if deterministic else torch.multinomial(probs, 1, True)
+            hs[w] = h
+        prev_mem = mem
+        outputs = envs.step([a[0].item() for a in actions])
+        observations, _rewards, dones, _infos = [list(x) for x in zip(*outputs)]
+        masks = torch.tensor([[0.0] if d else [1.0] for d in dones])
+        nd[0] = masks
+        if w == 1:
+            nd[1] = masks
+        _b, d_mem = O.stft_l2_distance(batch["mixed_bin_audio_mag"], pm, batch["gt_bin_comps"], mem, batch["gt_mono_comps"])
+        _b, d_mono = O.stft_l2_distance(batch["mixed_bin_audio_mag"], pm, batch["gt_bin_comps"], mono, batch["gt_mono_comps"])
+        acc["mono"] += d_mono[0][0].item()
+        acc["mem"] += d_mem[0][0].item()
+        steps.append((actions.clone(), d_mono[0][0].item(), d_mem[0][0].item()))
+        batch = batch_obs(observations)
+        step_count += 1
+        if dones[0]:
+            last["mono"].append(d_mono[0][0].item())
+            last["mem"].append(d_mem[0][0].item())
+            allsteps["mono"].append(acc["mono"] / step_count)
+            allsteps["mem"].append(acc["mem"] / step_count)
+            acc = {"mono": 0.0, "mem": 0.0}
+            done_eps += 1
+            step_count = 0
+    agg = {"mono_loss_last_step": last["mono"], "mono_loss_all_steps": allsteps["mono"], "monoFromMem_loss_last_step": last["mem"],
+           "monoFromMem_loss_all_steps": allsteps["mem"]}
+    return steps, {k: (float(np.mean(v)), float(np.std(v))) for k, v in agg.items()}

@@ -125,6 +125,57 @@ def test_far_target_training_with_ragged_episodes_matches_the_reference_run():
     assert float(np.abs(d["step.stat.episode_ndgs"][-1]).sum()) > 0
 
 
+@pytest.mark.parametrize("tag", ["single", "switch"])
+def test_evaluation_loop_matches_the_reference_eval_run(tag, tmp_path):
+    """PPOTrainer.eval against the reference's own ``_eval_checkpoint`` (ppo_trainer.py:1015-1551) on the replay env, one process:
+    ``single`` = one policy with sampled actions (the reference's draws are fed in), ``switch`` = the far-target evaluation with
+    two policies and deterministic actions (nothing fed in: the argmax actions must coincide).  Per-step STFT-L2 distances and
+    the four per-episode aggregates the reference logs."""
+    import json
+    from m2h import synthetic
+    from m2h.common import utils as CU
+    from m2h.envs.replay_env import ReplayHostVecEnv
+    from m2h.envs.vector_env_adapter import HostVectorEnvAdapter
+    from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config
+    d = np.load(os.path.join(ROOT, "tests", "golden", "trainer_eval.npz"))
+    cfg_rec = json.loads(str(d[tag + ".config"]))
+    dev = torch.device("cuda", 0)
+    cfg = near_target_config(NUM_PROCESSES=1, MAX_EPISODE_STEPS=cfg_rec["MAX_EPISODE_STEPS"], SEED=cfg_rec["SEED"], use_hip_graphs=False,
+                             deterministic_eval=cfg_rec["PPO"]["deterministic_eval"],
+                             time_thres_for_pol_switch=cfg_rec["PPO"]["time_thres_for_pol_switch"])
+    host = ReplayHostVecEnv(1, seed=cfg.SEED, episode_len=cfg.MAX_EPISODE_STEPS, pool=cfg_rec["REPLAY"]["pool"])
+    tr = PPOTrainer(cfg, dev, envs=HostVectorEnvAdapter(host, dev))
+    tr.setup()
+    ck = lambda seed: {"actor_critic." + k: torch.from_numpy(np.asarray(v)) for k, v in  # noqa: E731
+                       synthetic.make_state_dict(synthetic.policy_shapes(), seed).items()}
+    trace = []
+    want_actions = d[tag + ".actions"]
+    if tag == "switch":
+        path = str(tmp_path / "switch.pth")
+        PPOTrainer.save_switch_checkpoint(path, {"state_dict": ck(7), "config": {}}, {"state_dict": ck(8), "config": {}})
+        agg = tr.eval(num_episodes=4, switch_checkpoint_path=path, waveform_metrics=(), trace=trace)
+    else:
+        path = str(tmp_path / "single.pth")
+        torch.save({"state_dict": ck(7), "config": {}}, path)
+        feed = iter(torch.from_numpy(want_actions).to(dev))
+        orig = CU.CustomFixedCategorical.sample
+        CU.CustomFixedCategorical.sample = lambda self, sample_shape=None: next(feed).reshape(1, 1).clone()
+        try:
+            agg = tr.eval(num_episodes=4, checkpoint_path=path, waveform_metrics=(), trace=trace)
+        finally:
+            CU.CustomFixedCategorical.sample = orig
+    assert len(trace) == len(want_actions) == 24 and agg["num_episodes"] == 4
+    assert np.array_equal(np.stack([t[0].numpy().reshape(-1) for t in trace]), want_actions)
+    assert host.actions_seen == want_actions.tolist()
+    mono = np.array([float(t[1]) for t in trace])
+    mem = np.array([float(t[2]) for t in trace])
+    assert np.abs(mono - d[tag + ".mono_l2"]).max() <= 2e-5 * np.abs(d[tag + ".mono_l2"]).max()
+    assert np.abs(mem - d[tag + ".mem_l2"]).max() <= 2e-5 * np.abs(d[tag + ".mem_l2"]).max()
+    for key in ("mono_loss_last_step", "mono_loss_all_steps", "monoFromMem_loss_last_step", "monoFromMem_loss_all_steps"):
+        want = d[tag + ".agg." + key]              # (mean, std) as the reference logs them: six decimals
+        assert abs(agg[key]["mean"] - want[0]) < 2e-5 * max(1, abs(want[0])) + 1e-6 and abs(agg[key]["std"] - want[1]) < 2e-5 + 1e-6, (key, agg[key], want)
+
+
 TWO_RANK = r'''
 import os, sys
 root = %(root)r

@@ -72,3 +72,26 @@ def test_oracle_two_rank_ddp_matches_reference_run():
     check_scalars(d, rec, "rank0.")
     check_weights(d, rec, "rank0.")
     check_weights(d, rec, "rank1.")
+
+
+@pytest.mark.parametrize("tag,forced", [("single", True), ("switch", False)])
+def test_oracle_eval_loop_matches_reference_eval_run(tag, forced):
+    """_eval_checkpoint (one policy / two policies with the switch at step 3) against tests/golden/trainer_eval.npz."""
+    import json
+    import os
+    from m2h import synthetic
+    from m2h.envs.replay_env import ReplayHostVecEnv
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trainer_eval.npz"))
+    cfg = json.loads(str(d[tag + ".config"]))
+    sd = lambda seed: {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), seed).items()}  # noqa: E731
+    env = ReplayHostVecEnv(1, seed=cfg["SEED"], episode_len=cfg["MAX_EPISODE_STEPS"], pool=cfg["REPLAY"]["pool"])
+    torch.set_num_threads(4)
+    fa = [torch.from_numpy(a).reshape(1, 1) for a in d[tag + ".actions"]] if forced else None
+    steps, agg = OT.eval_loop(dict(cfg["PPO"]), env, [sd(7), sd(8)] if tag == "switch" else [sd(7)], 4, cfg["PPO"]["deterministic_eval"],
+                              switch_thres=cfg["PPO"]["time_thres_for_pol_switch"] if tag == "switch" else None, forced_actions=fa)
+    assert np.array_equal(np.array([s[0].reshape(-1).numpy() for s in steps]), d[tag + ".actions"])
+    assert np.abs(np.array([s[1] for s in steps]) - d[tag + ".mono_l2"]).max() < 1e-5
+    assert np.abs(np.array([s[2] for s in steps]) - d[tag + ".mem_l2"]).max() < 1e-5
+    for k, (mean, std) in agg.items():
+        want = d[tag + ".agg." + k]
+        assert abs(mean - want[0]) < 2e-6 + 1e-5 * abs(want[0]) and abs(std - want[1]) < 2e-6 + 1e-5, (k, mean, std, want)
