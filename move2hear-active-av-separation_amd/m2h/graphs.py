@@ -19,6 +19,52 @@ def capture(graph, pool=None):
     return torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local")
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Fork / join of independent kernel chains onto side HIP streams.  At the rollout batch (14 envs) every kernel of the policy's
+# three encoders occupies a few of the chip's 256 CUs for 5-15 us; they depend on one another only inside an encoder, so the
+# three chains run side by side (captured into a HIP graph they become parallel branches).  Same kernels, same values.
+# ------------------------------------------------------------------------------------------------------------------
+_side_streams = {}
+parallel_branches = True     # module switch (tests / A-B measurements)
+
+
+def _tensors(x):
+    if torch.is_tensor(x):
+        yield x
+    elif isinstance(x, (tuple, list)):
+        for y in x:
+            yield from _tensors(y)
+
+
+def run_parallel(device, fns):
+    """Runs fns[0] on the current stream and fns[1:] on side streams that start after the work enqueued so far; the current
+    stream waits for all of them before this returns.  Tensors produced on a side stream are handed to the current stream
+    (allocator bookkeeping: ``record_stream``).  device None: plain sequential calls."""
+    if device is None or not parallel_branches or len(fns) == 1 or ops.timing_enabled():
+        return [f() for f in fns]
+    main = torch.cuda.current_stream(device)
+    key = (device.index, len(fns) - 1)
+    if key not in _side_streams:
+        _side_streams[key] = [torch.cuda.Stream(device) for _ in range(len(fns) - 1)]
+    fork = torch.cuda.Event()
+    fork.record(main)
+    outs, joins = [None] * len(fns), []
+    for i, s in enumerate(_side_streams[key], 1):
+        s.wait_event(fork)
+        with torch.cuda.stream(s):
+            outs[i] = fns[i]()
+            ev = torch.cuda.Event()
+            ev.record(s)
+        joins.append(ev)
+    outs[0] = fns[0]()
+    for ev in joins:
+        main.wait_event(ev)
+    for o in outs[1:]:
+        for t in _tensors(o):
+            t.record_stream(main)
+    return outs
+
+
 class GraphedSeparatorPair:
     def __init__(self, policy, observations):
         self.policy = policy
