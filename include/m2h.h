@@ -285,6 +285,26 @@ int m2h_episode_stats_update(const m2h_episode_stats* st, const float* rewards, 
                              const float* mono_losses, const float* monoFromMem_losses, const float* not_done, const float* ndgs,
                              const float* dgs, int N, int A, m2h_stream stream);
 
+/* Batched weight packing: up to M2H_PACK_BATCH_MAX tensors (re)packed by ONE launch; same index maps and results as the
+ * single-tensor entry points.  kind / p[]:
+ *   M2H_PACK_CONV      m2h_pack_conv_weight_ex:  p = {Co, Ci, KH, KW, ci_used, ci_out}     [Co][Ci][KH][KW] -> [Co][KH][KW][ci_out]
+ *   M2H_PACK_CONVT     m2h_pack_convT_weight:    p = {Ci, Co, -, -, -, -}                  [Ci][Co][4][4]   -> [4 phases][Co][2][2][Ci]
+ *   M2H_PACK_DGRAD     m2h_pack_dgrad_weight:    p = {Co, Ci, KH, KW, stride, pad}         -> [stride^2 phases][Ci][KH/s][KW/s][Co]
+ *   M2H_PACK_FC_DGRAD  input gradient of a full-spatial conv (a Linear over the flattened map, visual_cnn.py:140-141):
+ *                                                p = {Co, Ci, KH, KW, ci_used, ci_out}     -> [KH][KW][ci_out][Co] */
+#define M2H_PACK_BATCH_MAX 48
+#define M2H_PACK_CONV 0
+#define M2H_PACK_CONVT 1
+#define M2H_PACK_DGRAD 2
+#define M2H_PACK_FC_DGRAD 3
+typedef struct m2h_pack_item {
+  const float* src;
+  float* dst;
+  int kind;
+  int p[6];
+} m2h_pack_item;
+int m2h_pack_batch(const m2h_pack_item* items /* host */, int n_items, m2h_stream stream);
+
 /* The whole per-env bookkeeping of one rollout step (ppo_trainer.py:375-455) in one launch: reward (override_rewards /
  * reward_util, env_utils.py:690-713; with extra_reward the step carries extra_mult x util(next), the effective value of
  * ppo_trainer.py:395-405), the three STFT-L2 distances of eval_metrics.py:306-366 (binaural masks on exp(mix)-1, mono, mono from

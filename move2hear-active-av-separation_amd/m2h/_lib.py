@@ -16,7 +16,7 @@ CSRC = os.path.join(_PKG_ROOT, "csrc")
 INCLUDE = os.path.join(_REPO_ROOT, "include")
 # M2H_LIB: kernel-tuning override -- load an experimental build of the same C-ABI (tools/build_variant.sh) instead of the in-tree one
 LIB_PATH = os.environ.get("M2H_LIB") or os.path.join(_HERE, "libm2h.so")
-SOURCES = ["conv_igemm.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "rollout_fused.hip", "api.hip"]
+SOURCES = ["conv_igemm.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "rollout_fused.hip", "pack_batch.hip", "api.hip"]
 
 _lock = threading.Lock()
 _lib = None
@@ -126,6 +126,13 @@ class StepStatsArgs(ctypes.Structure):
                  ("A", ctypes.c_int), ("override_rewards", ctypes.c_int), ("extra_reward", ctypes.c_int), ("extra_mult", ctypes.c_float)])
 
 
+class PackItem(ctypes.Structure):
+    """Mirror of ``struct m2h_pack_item`` (include/m2h.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("kind", ctypes.c_int), ("p", ctypes.c_int * 6)]
+
+
+PACK_BATCH_MAX = 48
+PACK_CONV, PACK_CONVT, PACK_DGRAD, PACK_FC_DGRAD = 0, 1, 2, 3
 STEP_STATS_CHUNKS = 16
 ROWS_COPY_MAX = 32
 
@@ -209,6 +216,7 @@ SIGNATURES = {
     "m2h_episode_stats_update": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_step_stats_workspace_bytes": [_I],
     "m2h_rollout_step_stats": [ctypes.POINTER(StepStatsArgs), _P],
+    "m2h_pack_batch": [_P, _I, _P],
     "m2h_rows_copy": [_P, _I, _P, _P],
     "m2h_step_index_advance": [_P, _I, _I, _P],
     "m2h_synth_env_step": [_P, _P, _P, _I, _I, _P],

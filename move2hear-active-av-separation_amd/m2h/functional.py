@@ -70,13 +70,15 @@ def pack_dgrad_weight(w4d, stride, pad):
     return wp
 
 
-def conv_dgrad(dy, w4d, in_hw, stride, pad, ci_out=None):
-    """Input gradient [B,H,W,Ci] of Conv2d(w4d [Co,Ci,KH,KW], stride, pad) given the NHWC output gradient dy [B,Ho,Wo,Co]."""
+def conv_dgrad(dy, w4d, in_hw, stride, pad, ci_out=None, wp=None):
+    """Input gradient [B,H,W,Ci] of Conv2d(w4d [Co,Ci,KH,KW], stride, pad) given the NHWC output gradient dy [B,Ho,Wo,Co].
+    wp: the weight's phase matrices (m2h_pack_dgrad_weight) when the caller keeps them packed."""
     B, Ho, Wo, Co = dy.shape
     _, Ci, KH, KW = w4d.shape
     H, W = in_hw
     s = stride
-    wp = pack_dgrad_weight(w4d, s, pad)
+    if wp is None:
+        wp = pack_dgrad_weight(w4d, s, pad)
     dx = torch.empty((B, H, W, Ci), device=dy.device, dtype=torch.float32)
     lib = _lib.load()
     with torch.cuda.device(dy.device):
@@ -141,34 +143,106 @@ _pack_memos = weakref.WeakSet()
 
 
 class _PackMemo:
-    """Packed forward weights per (data_ptr, version, optimizer epoch): re-packed only when the weights may have changed, and
-    then IN PLACE, so the packed buffer keeps its address for as long as the weight keeps its shape (a captured HIP graph
-    holds that address; refresh_pack_memos() brings every memo up to date before a replay)."""
+    """Packed operands of ONE weight tensor: the forward pack (Conv2d [Co][KH*KW*ci_pad] / ConvTranspose2d [4][Co][4*Cin]) and,
+    once a backward pass has asked for it, the input-gradient pack.  Each is re-packed only when the weights may have changed
+    (data_ptr, version counter, optimizer epoch) and then IN PLACE, so a packed buffer keeps its address for as long as the
+    weight keeps its shape (a captured HIP graph holds that address).  refresh_pack_memos() brings every memo up to date with
+    ONE batched launch (m2h_pack_batch) -- before a graph replay, and at the top of a training step so that the step's own
+    forward / backward calls all hit."""
 
     def __init__(self):
-        self.key, self.val, self.src = None, None, None
+        self.fwd = [None, None, None]   # [key, packed tensor, spec]
+        self.bwd = [None, None, None]
+        self.src = None                 # (Parameter, view shape or None): how to find the weight again at refresh time
         _pack_memos.add(self)
 
+    # compatibility with callers that look at the forward pack directly
+    @property
+    def key(self):
+        return self.fwd[0]
+
+    @property
+    def val(self):
+        return self.fwd[1]
+
+    @staticmethod
+    def _wkey(w):
+        return (w.data_ptr(), w._version, _param_epoch)
+
+    @staticmethod
+    def _plan(w, spec):
+        """(shape of the packed tensor, m2h_pack_batch kind, p[6]) for a weight and a pack spec."""
+        if spec[0] == "conv":            # Conv2d forward: [Co][Ci][KH][KW] -> [Co][KH*KW*ci_pad]
+            Co, Ci, KH, KW = w.shape
+            return (Co, KH * KW * spec[1]), _lib.PACK_CONV, (Co, Ci, KH, KW, Ci, spec[1])
+        if spec[0] == "convT":           # ConvTranspose2d forward: [Cin][Co][4][4] -> [4][Co][4*Cin]
+            Cin, Co = w.shape[0], w.shape[1]
+            return (4, Co, 4 * Cin), _lib.PACK_CONVT, (Cin, Co, 0, 0, 0, 0)
+        if spec[0] == "dgrad":           # Conv2d input gradient: stride^2 phase matrices
+            Co, Ci, KH, KW = w.shape
+            st, pad = spec[1], spec[2]
+            return (st * st, Ci, (KH // st) * (KW // st) * Co), _lib.PACK_DGRAD, (Co, Ci, KH, KW, st, pad)
+        if spec[0] == "fc_dgrad":        # full-spatial conv (a Linear): dX = dY @ Wp as one GEMM, Wp^T [KH*KW*c_in][Co]
+            Co, Ci, KH, KW = w.shape
+            return (KH * KW * spec[1], Co), _lib.PACK_FC_DGRAD, (Co, Ci, KH, KW, Ci, spec[1])
+        if spec[0] == "convT_dgrad":     # ConvTranspose2d input gradient = a Conv2d with the weight read as [out=Cin][in=Co]
+            Cin, Co = w.shape[0], w.shape[1]
+            return (Cin, 16 * Co), _lib.PACK_CONV, (Cin, Co, 4, 4, Co, Co)
+        raise ValueError(spec)
+
+    def _item(self, slot, w, spec):
+        """Pack item for `slot` (self.fwd / self.bwd) if it is stale for weight w, else None; marks the slot fresh."""
+        key = self._wkey(w) + tuple(spec)
+        if slot[0] == key:
+            return None
+        shape, kind, prm = self._plan(w, spec)
+        wd = w.detach()
+        if not wd.is_contiguous():
+            wd = wd.contiguous()
+        if slot[1] is None or tuple(slot[1].shape) != shape or slot[1].device != wd.device:
+            slot[1] = torch.empty(shape, device=wd.device, dtype=torch.float32)
+        slot[0], slot[2] = key, tuple(spec)
+        self.src = (w._base, tuple(w.shape)) if w._base is not None else (w, None)
+        return (kind, wd, slot[1], prm)
+
+    def _get(self, slot, w, spec):
+        item = self._item(slot, w, spec)
+        if item is not None:
+            ops.pack_batch([item])
+        return slot[1]
+
     def get(self, w, ci_pad):
-        key = (w.data_ptr(), w._version, ci_pad, _param_epoch)
-        if key != self.key:
-            wd = w.detach().contiguous()
-            reuse = self.val is not None and self.key is not None and self.key[2] == ci_pad and self.val.device == wd.device \
-                and self.val.shape[0] == wd.shape[0] and self.val.shape[1] == wd.shape[2] * wd.shape[3] * ci_pad
-            self.val = ops.pack_conv_weight_ex(wd, w.shape[1], ci_pad, out=self.val if reuse else None)
-            self.key = key
-            # the Parameter (whose storage FlatAdam may move into its flat buffer) rather than a view of its old storage
-            self.src = (w._base, tuple(w.shape), ci_pad) if w._base is not None else (w, None, ci_pad)
-        return self.val
+        return self._get(self.fwd, w, ("conv", ci_pad))
+
+    def get_convT(self, w):
+        return self._get(self.fwd, w, ("convT",))
+
+    def get_bwd(self, w, spec):
+        return self._get(self.bwd, w, spec)
+
+    def stale_items(self):
+        if self.src is None:
+            return []
+        base, shape = self.src
+        w = base if shape is None else base.view(shape)
+        out = []
+        for slot in (self.fwd, self.bwd):
+            if slot[2] is not None:
+                item = self._item(slot, w, slot[2])
+                if item is not None:
+                    out.append(item)
+        return out
 
 
 def refresh_pack_memos():
-    """Re-packs (in place) every memo whose source weights changed since it was packed.  Called before a HIP-graph replay:
-    the graph reads the packed buffers by address and contains no pack kernels."""
+    """Re-packs (in place) every packed operand whose source weights changed since it was packed, with one batched launch per
+    48 tensors.  Called before a HIP-graph replay (the graph reads the packed buffers by address and contains no pack kernels)
+    and at the top of a captured training step."""
+    items = []
     for m in list(_pack_memos):
-        if m.src is not None:
-            base, shape, ci_pad = m.src
-            m.get(base if shape is None else base.view(shape), ci_pad)
+        items += m.stale_items()
+    if items:
+        ops.pack_batch(items)
 
 
 @carries_math_mode
@@ -184,6 +258,7 @@ class Conv2dNHWC(torch.autograd.Function):
         y = ops.conv2d_nhwc(x, wp, Co, KH, KW, stride=stride, pad=pad, bias=b.detach() if b is not None else None, slope=slope, x2=x2,
                             deslice=deslice, name=name)
         ctx.cfg = (stride, pad, slope, deslice, Ci, KH, KW, Co)
+        ctx.memo = memo
         ctx.has_x2 = x2 is not None
         ctx.save_for_backward(x, x2 if x2 is not None else x.new_empty(0), w, y if slope != 1.0 else x.new_empty(0))
         return y
@@ -216,11 +291,15 @@ class Conv2dNHWC(torch.autograd.Function):
                 # full-spatial conv (a Linear over the NCHW-flattened map, visual_cnn.py:140-141): dX = dY @ Wp as ONE GEMM.
                 # The generic phase formulation would walk KH*KW taps per input pixel with a single valid one (144x the work).
                 c_in = x.shape[3]
-                wp = ops.pack_conv_weight_ex(w.detach().contiguous(), Ci, c_in)          # [Co][(h,w,c)]
-                wt = pack_dgrad_weight(wp.view(Co, KH * KW * c_in, 1, 1), 1, 0).view(KH * KW * c_in, Co)
+                if ctx.memo is not None:
+                    wt = ctx.memo.get_bwd(w, ("fc_dgrad", c_in))                         # [(h,w,c)][Co]
+                else:
+                    wp = ops.pack_conv_weight_ex(w.detach().contiguous(), Ci, c_in)      # [Co][(h,w,c)]
+                    wt = pack_dgrad_weight(wp.view(Co, KH * KW * c_in, 1, 1), 1, 0).view(KH * KW * c_in, Co)
                 gx = ops.linear(dy.view(B, Co), wt, None, name="fc.dgrad").view(B, KH, KW, c_in)
             else:
-                gx = conv_dgrad(dy, w.detach().contiguous(), (x.shape[1], x.shape[2]), stride, pad)
+                wpd = ctx.memo.get_bwd(w, ("dgrad", stride, pad)) if ctx.memo is not None else None
+                gx = conv_dgrad(dy, w.detach().contiguous(), (x.shape[1], x.shape[2]), stride, pad, wp=wpd)
             if gx.shape[3] != x.shape[3]:  # channel-padded input (VisualCNN 3 -> 4): padded channels carry no gradient
                 gx = torch.nn.functional.pad(gx, (0, x.shape[3] - gx.shape[3]))
         return gx, gx2, gw, gb, None, None, None, None, None, None
@@ -484,16 +563,9 @@ class ConvTranspose2dNHWC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x2, w, memo):
         Cin, Co = w.shape[0], w.shape[1]
-        key_ok = memo is not None
-        if key_ok:
-            k = (w.data_ptr(), w._version, _param_epoch)
-            if memo.key != k:
-                memo.val = ops.pack_convT_weight(w.detach().contiguous())
-                memo.key = k
-            wp = memo.val
-        else:
-            wp = ops.pack_convT_weight(w.detach().contiguous())
+        wp = memo.get_convT(w) if memo is not None else ops.pack_convT_weight(w.detach().contiguous())
         z = ops.unet_up_fwd_raw(x, x2, wp, Co)
+        ctx.memo = memo
         ctx.has_x2 = x2 is not None
         ctx.save_for_backward(x, x2 if x2 is not None else x.new_empty(0), w)
         return z
@@ -508,7 +580,8 @@ class ConvTranspose2dNHWC(torch.autograd.Function):
         B, H, W, _ = x.shape
         gx = gx2 = gw = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
-            wconv = ops.pack_conv_weight(w.detach().contiguous())  # [Cin][4][4][Co]: w read as a Conv2d weight [out=Cin][in=Co]
+            # [Cin][4][4][Co]: w read as a Conv2d weight [out=Cin][in=Co]
+            wconv = ctx.memo.get_bwd(w, ("convT_dgrad",)) if ctx.memo is not None else ops.pack_conv_weight(w.detach().contiguous())
             if ctx.needs_input_grad[0]:
                 gx = ops.conv2d_nhwc(dz, wconv[:C0].contiguous(), C0, 4, 4, stride=2, pad=1, slope=1.0, name="convT.dgrad")
             if x2 is not None and ctx.needs_input_grad[1]:

@@ -608,6 +608,25 @@ def episode_stats_update(stats, rewards, dist_probs, bin_losses, mono_losses, mo
                                                         N, A, _stream(ins[0])), "m2h_episode_stats_update")
 
 
+def pack_batch(items):
+    """Batched weight packing (m2h_pack_batch): items = (kind, src weight tensor, dst packed tensor, p[6]); one launch per 48."""
+    if not items:
+        return
+    lib = _lib.load()
+    dev = items[0][1].device
+    for i0 in range(0, len(items), _lib.PACK_BATCH_MAX):
+        chunk = items[i0:i0 + _lib.PACK_BATCH_MAX]
+        arr = (_lib.PackItem * len(chunk))()
+        for j, (kind, src, dst, prm) in enumerate(chunk):
+            _chk(src, "pack_batch(src)")
+            _chk(dst, "pack_batch(dst)")
+            arr[j].src, arr[j].dst, arr[j].kind = src.data_ptr(), dst.data_ptr(), int(kind)
+            for k in range(6):
+                arr[j].p[k] = int(prm[k])
+        with torch.cuda.device(dev):
+            _lib.check(lib.m2h_pack_batch(arr, len(chunk), _stream(items[0][1])), "m2h_pack_batch")
+
+
 _step_stats_scratch = {}
 
 

@@ -101,9 +101,10 @@ class PassiveTrainer:
         for dst, src in zip(gs.inputs, (mixed_audio, gt_bin_mag, gt_mono_mag, target_class)):
             dst.copy_(src)
         if gs.graph is None:
-            MF.bump_param_epoch()  # every packed-weight memo misses during the capture: the pack kernels become graph nodes
-            g = torch.cuda.CUDAGraph()
+            MF.bump_param_epoch()  # every packed-weight memo is stale at the capture: the ONE batched pack launch below becomes
+            g = torch.cuda.CUDAGraph()  # the graph's first node (the warm-up step has told every memo which packs it needs)
             with graphs.capture(g):
+                MF.refresh_pack_memos()
                 mix, gtb, gtm, tc = gs.inputs
                 masks = self.actor_critic.get_binSepMasks({"mixed_bin_audio_mag": mix, "target_class": tc})
                 mono = self.actor_critic.convert_bin2mono(masks.detach(), mixed_audio=mix)

@@ -377,3 +377,36 @@ def test_image_row_conv3x3_kernel_matches_the_engine_and_torch(N, C, B, deslice,
             ops.debug_set(22, 0)
     assert got[0].shape == ref.shape
     assert _rel(got[0], ref) < 2e-5 and _rel(got[-1], ref) < 2e-5 and _rel(got[0], got[-1]) < 1e-5
+
+
+def test_batched_pack_equals_the_single_tensor_packs():
+    """m2h_pack_batch (one launch, LDS-tiled transposes) against the single-tensor pack entry points, bit for bit, for every
+    kind and the shapes the models use (incl. channel padding, 8x8 / 12x12 taps, stride-4 / stride-2 / stride-1 input gradients)."""
+    from m2h import _lib, functional as MF, ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(12)
+    items, want = [], []
+    for (Co, Ci, KH, KW, cpad) in [(64, 33, 4, 4, 36), (512, 256, 4, 4, 256), (32, 3, 8, 8, 4), (64, 32, 4, 4, 32), (512, 32, 12, 12, 32), (32, 64, 2, 2, 64)]:
+        w = torch.randn(Co, Ci, KH, KW, generator=g).to(dev)
+        dst = torch.empty(Co, KH * KW * cpad, device=dev)
+        items.append((_lib.PACK_CONV, w, dst, (Co, Ci, KH, KW, Ci, cpad)))
+        want.append(ops.pack_conv_weight_ex(w, Ci, cpad))
+    for (Ci, Co) in [(512, 512), (128, 32), (1024, 256), (64, 16)]:
+        w = torch.randn(Ci, Co, 4, 4, generator=g).to(dev)
+        dst = torch.empty(4, Co, 4 * Ci, device=dev)
+        items.append((_lib.PACK_CONVT, w, dst, (Ci, Co, 0, 0, 0, 0)))
+        want.append(ops.pack_convT_weight(w))
+    for (Co, Ci, K, st, pad) in [(64, 32, 4, 2, 1), (32, 32, 8, 4, 0), (32, 32, 3, 1, 1), (64, 32, 4, 2, 0), (32, 64, 2, 1, 0), (512, 64, 4, 2, 1)]:
+        w = torch.randn(Co, Ci, K, K, generator=g).to(dev)
+        dst = torch.empty(st * st, Ci, (K // st) * (K // st) * Co, device=dev)
+        items.append((_lib.PACK_DGRAD, w, dst, (Co, Ci, K, K, st, pad)))
+        want.append(MF.pack_dgrad_weight(w, st, pad))
+    for (Co, Ci, K, cpad) in [(512, 32, 12, 32), (512, 32, 1, 32), (128, 3, 2, 4)]:
+        w = torch.randn(Co, Ci, K, K, generator=g).to(dev)
+        dst = torch.empty(K * K * cpad, Co, device=dev)
+        items.append((_lib.PACK_FC_DGRAD, w, dst, (Co, Ci, K, K, Ci, cpad)))
+        wp = ops.pack_conv_weight_ex(w, Ci, cpad)
+        want.append(MF.pack_dgrad_weight(wp.view(Co, K * K * cpad, 1, 1), 1, 0).view(K * K * cpad, Co))
+    ops.pack_batch(items)
+    for (kind, _w, dst, prm), ref in zip(items, want):
+        assert torch.equal(dst.reshape(-1), ref.reshape(-1)), (kind, prm)
