@@ -7,6 +7,8 @@ read from the two static outputs.  Same kernels, same values as the direct calls
 gap.  The arithmetic mode (ops.set_math_mode) and the weights' packed buffers are fixed at capture: re-capture after changing
 either (``stale()`` tells).
 """
+import os
+
 import torch
 
 from . import ops
@@ -20,12 +22,15 @@ def capture(graph, pool=None):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# Fork / join of independent kernel chains onto side HIP streams.  At the rollout batch (14 envs) every kernel of the policy's
-# three encoders occupies a few of the chip's 256 CUs for 5-15 us; they depend on one another only inside an encoder, so the
-# three chains run side by side (captured into a HIP graph they become parallel branches).  Same kernels, same values.
+# Fork / join of independent kernel chains onto side HIP streams (captured into a HIP graph they become parallel branches).
+# Same kernels, same values.  OFF by default (M2H_PARALLEL_BRANCHES=1 switches it on): measured on the policy's three encoders,
+# whose kernels each occupy a few of the chip's 256 CUs for 5-15 us -- with a device sync between the phases of a DD-PPO cycle the
+# update_pol epochs gained 5 % (60 -> 57 ms per cycle), but in the free-running cycle (bench.py, no syncs) the multi-stream
+# graph replays cost 9 % of the whole cycle (9 420 -> 8 600 env-steps/s), and at the rollout width (14 rows) the cross-stream
+# edges alone cost more than the overlap returns (rollout 75 -> 88 ms per cycle).
 # ------------------------------------------------------------------------------------------------------------------
 _side_streams = {}
-parallel_branches = True     # module switch (tests / A-B measurements)
+parallel_branches = os.environ.get("M2H_PARALLEL_BRANCHES", "0") == "1"     # module switch (tests / A-B measurements)
 
 
 def _tensors(x):

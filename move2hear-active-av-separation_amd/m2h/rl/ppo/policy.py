@@ -81,10 +81,8 @@ class PolicyNet(Net):
 
     def forward(self, observations, rnn_hidden_states, masks, pred_binSepMasks=None, pred_mono=None, pred_monoFromMem=None):
         from ... import graphs
-        # The three encoders are independent kernel chains.  Over an update batch (T*N = 280 rows) they run side by side on three
-        # HIP streams (graphs.run_parallel: update_pol 60 -> 57 ms per cycle); at the rollout width (N = 14) the cross-stream
-        # edges of the replayed graph cost more than the overlap returns (rollout 75 -> 88 ms per cycle, measured), so a step's
-        # encoders stay one chain.
+        # The three encoders are independent kernel chains; graphs.run_parallel can put them on three HIP streams for update
+        # batches (opt-in, measured slower end to end: see m2h/graphs.py), sequential otherwise.
         x = graphs.run_parallel(pred_mono.device if pred_mono.shape[0] >= 64 else None, [
             lambda: self.visual_encoder(observations),
             lambda: self.bin_encoder(observations, pred_binSepMasks=pred_binSepMasks),
