@@ -16,7 +16,7 @@ CSRC = os.path.join(_PKG_ROOT, "csrc")
 INCLUDE = os.path.join(_REPO_ROOT, "include")
 # M2H_LIB: kernel-tuning override -- load an experimental build of the same C-ABI (tools/build_variant.sh) instead of the in-tree one
 LIB_PATH = os.environ.get("M2H_LIB") or os.path.join(_HERE, "libm2h.so")
-SOURCES = ["conv_igemm.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "rollout_fused.hip", "pack_batch.hip", "api.hip"]
+SOURCES = ["conv_igemm.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "rollout_fused.hip", "pack_batch.hip", "fftconv.hip", "api.hip"]
 
 _lock = threading.Lock()
 _lib = None
@@ -217,6 +217,7 @@ SIGNATURES = {
     "m2h_step_stats_workspace_bytes": [_I],
     "m2h_rollout_step_stats": [ctypes.POINTER(StepStatsArgs), _P],
     "m2h_pack_batch": [_P, _I, _P],
+    "m2h_fftconv_full": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "m2h_rows_copy": [_P, _I, _P, _P],
     "m2h_step_index_advance": [_P, _I, _I, _P],
     "m2h_synth_env_step": [_P, _P, _P, _I, _I, _P],

@@ -7,11 +7,13 @@ per source: fftconvolve(mono, rir[:, ch], mode="same") for the two ears -> np.ro
 GT binaural magnitude and the RMS-normalised GT mono magnitude; the mean of the sources' binaural waveforms gives
 log1p(|STFT|) of the mixture.
 
-Stages: the two length-32768 real FFTs of the linear convolution are rocFFT transforms reached through torch.fft (a plain
-library transform, like a library GEMM); the frequency-domain product is a torch complex multiply; the "same" window, integer
-rounding, mixing (m2h_feeder_round_mix), the STFTs (DFT-as-GEMM on the igemm engine, m2h.audio.stft) and the RMS
-normalisation (m2h_rms_normalize) are HIP kernels of libm2h.
+Stages, all HIP kernels of libm2h (no library math): the linear convolution is m2h_fftconv_full -- real FFTs of 32 768 points as
+packed 16 384-point complex radix-2 transforms held in LDS, one workgroup per (clip, source), spectrum product and inverse in the
+same launch (csrc/fftconv.hip; round 1 went through rocFFT via torch.fft); the "same" window, integer rounding and mixing
+(m2h_feeder_round_mix), the STFTs (DFT-as-GEMM on the igemm engine, m2h.audio.stft) and the RMS normalisation
+(m2h_rms_normalize).
 """
+import numpy as np
 import torch
 
 from .. import _lib, ops
@@ -30,6 +32,15 @@ class BinauralFeeder:
         self.device = device
         self.stft = STFT(device)
         self.gt_mono_mag_norm = float(gt_mono_mag_norm)   # SIMULATOR.AUDIO.GT_MONO_MAG_NORM (config/default.py:198)
+        self._twiddles = {}
+
+    def _twiddle_table(self, nfft):
+        """exp(-2 pi i k / nfft), k < nfft/2, as interleaved fp32 (built in float64 on the host once per length: setup data)."""
+        if nfft not in self._twiddles:
+            k = np.arange(nfft // 2, dtype=np.float64)
+            t = np.stack([np.cos(2.0 * np.pi * k / nfft), -np.sin(2.0 * np.pi * k / nfft)], axis=1).astype(np.float32)
+            self._twiddles[nfft] = torch.from_numpy(t).to(self.device).contiguous()
+        return self._twiddles[nfft]
 
     def convolve_round(self, mono, rirs):
         """mono [B, S, L] (int16-valued fp32), rirs [B, S, Lr, 2] fp32 -> per-source binaural waveforms [S][B, 2, L] after the
@@ -38,15 +49,20 @@ class BinauralFeeder:
             raise RuntimeError("m2h.BinauralFeeder: inputs must be fp32 GPU tensors")
         B, S, L = mono.shape
         Lr = rirs.shape[2]
-        nfft = _next_pow2(L + Lr - 1)
+        nfft = max(_next_pow2(L + Lr - 1), 2048)
+        if nfft > 32768:
+            raise NotImplementedError("m2h.BinauralFeeder: a %d + %d - 1 point convolution needs a %d-point transform; the in-LDS FFT "
+                                      "of m2h_fftconv_full holds at most 32768 points" % (L, Lr, nfft))
         start = (Lr - 1) // 2                                  # scipy.signal.fftconvolve(mode="same"): centred on the first input
         lib = _lib.load()
         mix = torch.empty((B, 2, L), device=mono.device)
         per_source = []
+        mono, rirs = mono.contiguous(), rirs.contiguous()
         with torch.cuda.device(mono.device):
-            X = torch.fft.rfft(mono, n=nfft, dim=2)                                   # [B, S, nfft/2+1]
-            H = torch.fft.rfft(rirs.permute(0, 1, 3, 2).contiguous(), n=nfft, dim=3)  # [B, S, 2, nfft/2+1]
-            full = torch.fft.irfft(X.unsqueeze(2) * H, n=nfft, dim=3).contiguous()    # [B, S, 2, nfft]
+            full = torch.empty((B, S, 2, nfft), device=mono.device)
+            xspec = torch.empty((B * S, nfft), device=mono.device)                    # [B*S][nfft/2] complex scratch
+            _lib.check(lib.m2h_fftconv_full(ops._ptr(mono), ops._ptr(rirs), ops._ptr(self._twiddle_table(nfft)), ops._ptr(xspec), ops._ptr(full),
+                                            B * S, L, Lr, nfft.bit_length() - 1, ops._stream(mono)), "m2h_fftconv_full")
             for s in range(S):
                 fs = full[:, s].contiguous()                                          # [B, 2, nfft]
                 out = torch.empty((B, 2, L), device=mono.device)

@@ -54,3 +54,28 @@ def test_round_half_even_and_int16_wrap():
     want = np.round(vals.astype(np.float64)).astype(np.int64).astype(np.int16).astype(np.float32) / 32768
     assert np.array_equal(out.cpu().numpy()[0], want)
     assert np.array_equal(mix.cpu().numpy()[0], want)
+
+
+@pytest.mark.parametrize("L,Lr", [(16000, 16000), (900, 1000), (4000, 2049)])
+def test_fftconv_full_matches_numpy_convolution(L, Lr):
+    """m2h_fftconv_full (hand-written in-LDS FFTs) against the float64 direct convolution, every output sample, for the feeder's
+    lengths and two shorter transforms (other template instances)."""
+    from m2h import _lib, ops
+    from m2h.audio.feeder import BinauralFeeder, _next_pow2
+    dev = torch.device("cuda", 0)
+    mono, rir = _inputs(3, 2, L, Lr, 9)
+    nfft = max(_next_pow2(L + Lr - 1), 2048)
+    fd = BinauralFeeder(dev)
+    m, r = torch.from_numpy(mono).to(dev), torch.from_numpy(rir).to(dev)
+    full = torch.empty((3, 2, 2, nfft), device=dev)
+    xspec = torch.empty((6, nfft), device=dev)
+    _lib.check(_lib.load().m2h_fftconv_full(ops._ptr(m), ops._ptr(r), ops._ptr(fd._twiddle_table(nfft)), ops._ptr(xspec), ops._ptr(full), 6, L, Lr,
+                                            nfft.bit_length() - 1, ops._stream(m)), "m2h_fftconv_full")
+    got = full.cpu().numpy()
+    for b in range(3):
+        for s in range(2):
+            for ear in range(2):
+                want = np.convolve(mono[b, s].astype(np.float64), rir[b, s, :, ear].astype(np.float64))
+                err = np.abs(got[b, s, ear, :L + Lr - 1] - want).max()
+                assert err <= 2e-6 * np.abs(want).max() * np.sqrt(np.log2(nfft)), (b, s, ear, err, np.abs(want).max())
+                assert np.abs(got[b, s, ear, L + Lr - 1:]).max() <= 1e-5 * np.abs(want).max()   # the zero tail of the circular result
