@@ -213,7 +213,7 @@ def run_feeder(args, dev, rank, with_cpu):
     el = time.perf_counter() - t0
     res = {"metric": "feeder_clips_per_sec", "value": round(B * args.feeder_steps / el, 1), "unit": "1-s binaural clips/s", "batch": B,
            "ms_per_batch": round(1e3 * el / args.feeder_steps, 3), "sources_per_clip": S, "out": [list(o.shape) for o in out],
-           "what": "BinauralFeeder.compute_audiospects: fftconvolve-same (rocFFT) of 2 sources x 2 ears, round -> int16 -> /32768, source mean, "
+           "what": "BinauralFeeder.compute_audiospects: fftconvolve-same (hand-written in-LDS FFTs, m2h_fftconv_full) of 2 sources x 2 ears, round -> int16 -> /32768, source mean, "
                    "STFT(1023, 512) x 3 with |.|, log1p on the mixture, RMS-normalised GT mono magnitude"}
     if with_cpu:   # (the oracle is imported by this cpu_baseline leg only)
         if os.path.join(ROOT, "oracle") not in sys.path:

@@ -289,7 +289,7 @@ int m2h_episode_stats_update(const m2h_episode_stats* st, const float* rewards, 
  * rirs [CS][Lr][2] -> full [CS][2][N], N = 2^log2n >= L + Lr - 1 (scipy.signal.fftconvolve in pretrain/datasets/dataset.py:180,
  * habitat_audio/simulator_train.py:419; the "same" window and the int16 round trip follow in m2h_feeder_round_mix).  Hand-written
  * radix-2 FFTs in LDS, one workgroup per pair (N <= 2^15: the packed N/2-point complex transform is 128 KB).
- * twiddles: [N/2] complex fp32 exp(-2 pi i k / N) (interleaved re, im; caller-built); xspec: [CS][N/2] complex fp32 scratch. */
+ * twiddles: [N/2] complex fp32 exp(-2 pi i k / N) (interleaved re, im; caller-built); xspec: [CS][2][N/2] complex fp32 scratch (2 N floats per pair). */
 int m2h_fftconv_full(const float* mono, const float* rirs, const float* twiddles, float* xspec, float* full, int CS, int L, int Lr,
                      int log2n, m2h_stream stream);
 

@@ -66,6 +66,8 @@ __global__ __launch_bounds__(1024) void fftconv_kernel(const float* __restrict__
   cf* z = reinterpret_cast<cf*>(smem);
   constexpr int M = 1 << LOGM, N = 2 * M;
   const int cs = blockIdx.x, tid = threadIdx.x;
+  const int ear0 = blockIdx.y;   // one workgroup per (clip, source, ear): 2 x CS workgroups fill the chip at the feeder's batch (64 x 2
+                                 // sources); each redoes the clip's own transform (3 transforms per workgroup instead of 5 in one)
   auto br = [](int k) { return (int)(__brev((unsigned)k) >> (32 - LOGM)); };
 
   // ---- spectrum of the mono clip (packed, bit-reversed), kept in global scratch for the two ears ----
@@ -73,12 +75,12 @@ __global__ __launch_bounds__(1024) void fftconv_kernel(const float* __restrict__
   for (int m = tid; m < M; m += 1024) z[m] = {2 * m < L ? x[2 * m] : 0.f, 2 * m + 1 < L ? x[2 * m + 1] : 0.f};
   __syncthreads();
   fft_dif<LOGM>(z, tw);
-  cf* zx = xspec + (size_t)cs * M;
+  cf* zx = xspec + ((size_t)cs * 2 + ear0) * M;
   for (int m = tid; m < M; m += 1024) zx[m] = z[m];
   __threadfence();   // the block reads zx back below (other threads' elements): stores drained to L2 before the barrier
   __syncthreads();
 
-  for (int ear = 0; ear < 2; ++ear) {
+  for (int ear = ear0; ear <= ear0; ++ear) {
     const float* h = rirs + (size_t)cs * Lr * 2 + ear;
     for (int m = tid; m < M; m += 1024) z[m] = {2 * m < Lr ? h[(size_t)(2 * m) * 2] : 0.f, 2 * m + 1 < Lr ? h[(size_t)(2 * m + 1) * 2] : 0.f};
     __syncthreads();
@@ -131,7 +133,7 @@ static int launch_fftconv(const float* mono, const float* rirs, const float* tw,
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail((int)e, "fftconv_same: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(kern, dim3(CS), dim3(1024), lds, st, mono, rirs, reinterpret_cast<const cf*>(tw), reinterpret_cast<cf*>(xspec), full, L, Lr);
+  hipLaunchKernelGGL(kern, dim3(CS, 2), dim3(1024), lds, st, mono, rirs, reinterpret_cast<const cf*>(tw), reinterpret_cast<cf*>(xspec), full, L, Lr);
   return launch_status("fftconv_same");
 }
 

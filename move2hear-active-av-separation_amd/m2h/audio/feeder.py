@@ -60,7 +60,7 @@ class BinauralFeeder:
         mono, rirs = mono.contiguous(), rirs.contiguous()
         with torch.cuda.device(mono.device):
             full = torch.empty((B, S, 2, nfft), device=mono.device)
-            xspec = torch.empty((B * S, nfft), device=mono.device)                    # [B*S][nfft/2] complex scratch
+            xspec = torch.empty((B * S, 2 * nfft), device=mono.device)                # [B*S][2 ears][nfft/2] complex scratch
             _lib.check(lib.m2h_fftconv_full(ops._ptr(mono), ops._ptr(rirs), ops._ptr(self._twiddle_table(nfft)), ops._ptr(xspec), ops._ptr(full),
                                             B * S, L, Lr, nfft.bit_length() - 1, ops._stream(mono)), "m2h_fftconv_full")
             for s in range(S):

@@ -68,7 +68,7 @@ def test_fftconv_full_matches_numpy_convolution(L, Lr):
     fd = BinauralFeeder(dev)
     m, r = torch.from_numpy(mono).to(dev), torch.from_numpy(rir).to(dev)
     full = torch.empty((3, 2, 2, nfft), device=dev)
-    xspec = torch.empty((6, nfft), device=dev)
+    xspec = torch.empty((6, 2 * nfft), device=dev)
     _lib.check(_lib.load().m2h_fftconv_full(ops._ptr(m), ops._ptr(r), ops._ptr(fd._twiddle_table(nfft)), ops._ptr(xspec), ops._ptr(full), 6, L, Lr,
                                             nfft.bit_length() - 1, ops._stream(m)), "m2h_fftconv_full")
     got = full.cpu().numpy()
