@@ -204,3 +204,58 @@ def test_far_target_schedule_runs_with_env_rewards():
     assert float(tr.rollouts_pol.rewards.abs().sum()) == 0.0           # the synthetic env's nav reward is zero and is NOT overridden
     assert float(tr.stats.episode_counts.sum()) == 2                    # 8 steps per env, episodes of 6 -> one finished episode each
     assert not torch.equal(tr.actor_critic.state_dict()["critic.fc.weight"].cpu(), sd["critic.fc.weight"])
+
+
+def test_eval_between_training_cycles_leaves_frozen_separators_untouched():
+    """eval() on a training trainer must restore the per-module training flags -- the frozen separators stay in eval
+    mode (ppo_trainer.py:557-577), so a later train_cycle neither takes the train-mode BatchNorm path nor updates their running
+    statistics, and the captured rollout graphs stay valid."""
+    tr, _ = _trainer()
+    torch.manual_seed(11)
+    tr.train_cycle()
+    ac = tr.actor_critic
+    flags = {n: m.training for n, m in ac.named_modules()}
+    bufs = {k: v.detach().cpu().clone() for k, v in ac.state_dict().items() if "Sep_" in k or "bin2mono_" in k}
+    tr.eval(num_episodes=3, waveform_metrics=())
+    assert {n: m.training for n, m in ac.named_modules()} == flags
+    assert ac.training and not ac.binSep_enc.training and not ac.bin2mono_dec.training
+    torch.manual_seed(12)
+    res = tr.train_cycle()
+    assert all(np.isfinite(res["pol_losses"]))
+    post = ac.state_dict()
+    for k, v in bufs.items():
+        assert torch.equal(post[k].cpu(), v), k   # weights, BN running statistics and num_batches_tracked of the frozen separators
+
+
+def test_loading_weights_after_graph_capture_invalidates_the_graphs():
+    """load_state_dict() after the rollout / update graphs were captured: the graphs hold addresses of packed weights
+    and folded-BN buffers that the load replaces, so they must be dropped.  A trainer that trained, then loaded checkpoint W,
+    must continue exactly like a fresh trainer that loaded W."""
+    w = {"actor_critic." + k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), 9).items()}
+
+    def run(pretrain):
+        tr, _ = _trainer(use_hip_graphs=True)
+        if pretrain:
+            for c in range(2):
+                torch.manual_seed(70 + c)
+                tr.train_cycle()
+            assert tr._graph_state is not None and tr.agent._pol_graph is not None
+        tr.load_state_dict(w)
+        assert tr._graph_state is None and tr.agent._pol_graph is None
+        return tr
+
+    tr_a = run(True)
+    # the frozen separators are a function of the weights alone: feed both trainers the same observation
+    obs = {k: v[0].clone() for k, v in tr_a.rollouts_pol.observations.items()}
+    outs = []
+    for tr in (tr_a, run(False)):
+        with torch.no_grad():
+            pm = tr.actor_critic.get_binSepMasks(obs)
+            outs.append((pm.cpu(), tr.actor_critic.convert_bin2mono(pm, mixed_audio=obs["mixed_bin_audio_mag"]).cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # and the trainer keeps training from the loaded weights through freshly captured graphs
+    torch.manual_seed(5)
+    tr_a.train_cycle()
+    torch.manual_seed(6)
+    res = tr_a.train_cycle()
+    assert tr_a._graph_state is not None and all(np.isfinite(res["pol_losses"]))
