@@ -265,12 +265,14 @@ __device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM /
 // reads are byte-for-byte those of the fp32 path.  Measured end to end on the U-Net pair: rel-L1 1e-5 vs the fp32 reference
 // (plain bf16 operands: 4e-3..6e-3, outside the 1e-3 contract).
 template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32, int FAST = 0, int SPLIT = 0>
-__global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGemmP p) {
-  static_assert(WM * WN == 4, "4 waves per block");
+__global__ __launch_bounds__(64 * WM * WN, (SPLIT && WM * WN == 4) ? 2 : 1) void igemm_f32_kernel(const IGemmP p) {
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per block");
+  constexpr int NT = 64 * WM * WN;           // threads per block
+  constexpr int RPP = NT / 8;                // tile rows staged per pass (a row = 8 threads x 16 bytes)
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
   constexpr int FM = TM / FR, FN = TN / FR;  // MFMA fragments per wave
-  constexpr int BNS = BN < 32 ? 32 : BN;     // staged weight rows (256 threads = 32 rows x 8 segments)
-  constexpr int AR = BM / 32, BR = BNS / 32; // staged rows per thread
+  constexpr int BNS = BN < RPP ? RPP : BN;   // staged weight rows (a pass stages RPP rows)
+  constexpr int AR = BM / RPP, BR = BNS / RPP; // staged rows per thread
   constexpr int GK = FR == 32 ? 8 : 16;      // k covered by one fragment group (one 16-byte read per lane)
   constexpr int NG = BK / GK;                // fragment groups per k-tile
   constexpr int NE = FR == 32 ? 16 : 4;      // accumulator elements per lane
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int seg = tid & 7;    // 16-byte segment inside the 128-byte k-tile row
-  const int srow = tid >> 3;  // 0..31
+  const int srow = tid >> 3;  // 0..RPP-1
 
   // ---- block -> (m-tile, n-tile): siblings (same m-tile) run back to back on one XCD ----
   const int L = blockIdx.x;
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
   }
 
   // ---- per-row (output pixel) bookkeeping, once per block ----
-  for (int r = threadIdx.x; r < BM; r += 256) {
+  for (int r = threadIdx.x; r < BM; r += NT) {
     const int m = m0 + r;
     int qh = -(1 << 24), rw = -(1 << 24), bpix = 0, out = -1, bc = 0;
     if (m < p.M) {
@@ -343,9 +345,9 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
   int a_qh[AR], a_rw[AR], a_bpix[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    a_qh[i] = ri_qh[srow + 32 * i];
-    a_rw[i] = ri_rw[srow + 32 * i];
-    a_bpix[i] = ri_bpix[srow + 32 * i];
+    a_qh[i] = ri_qh[srow + RPP * i];
+    a_rw[i] = ri_rw[srow + RPP * i];
+    a_bpix[i] = ri_bpix[srow + RPP * i];
   }
 
   AccT acc[FM][FN];
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
       segment_rows();
 #pragma unroll
       for (int j = 0; j < BR; ++j)  // rows past N re-read row N-1 (their products are never stored): no mask on the weight side
-        voffB[j] = ((unsigned)min(n0 + srow + 32 * j, p.N - 1) * (unsigned)p.K + (unsigned)(seg * 4)) * 4u;
+        voffB[j] = ((unsigned)min(n0 + srow + RPP * j, p.N - 1) * (unsigned)p.K + (unsigned)(seg * 4)) * 4u;
     } else {
       seek_generic(kt);
     }
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
     okmask[set] = ok ? (okmask[set] | (1u << i)) : (okmask[set] & ~(1u << i));
   };
   auto load_b = [&](int set, int j) {
-    const int n = n0 + srow + 32 * j;
+    const int n = n0 + srow + RPP * j;
     const bool ok = t_kok && n < p.N;
     const unsigned off = ok ? (unsigned)n * (unsigned)p.K + (unsigned)ld_k : 0u;
     rb[set][j] = *reinterpret_cast<const f32x4*>(wbase + off);
@@ -512,17 +514,17 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void igemm_f32_kernel(const IGe
     for (int i = 0; i < AR; ++i) {
       const f32x4 v = (okmask[set] & (1u << i)) ? ra[set][i] : zero4;
       if constexpr (SPLIT == 1)
-        store_split(&As[buf][(srow + 32 * i) * LDK], v);
+        store_split(&As[buf][(srow + RPP * i) * LDK], v);
       else
-        *reinterpret_cast<f32x4*>(&As[buf][(srow + 32 * i) * LDK + seg * 4]) = v;
+        *reinterpret_cast<f32x4*>(&As[buf][(srow + RPP * i) * LDK + seg * 4]) = v;
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
       const f32x4 v = (FAST || (okmask[set] & (1u << (8 + j)))) ? rb[set][j] : zero4;
       if constexpr (SPLIT == 1)
-        store_split(&Bs[buf][(srow + 32 * j) * LDK], v);
+        store_split(&Bs[buf][(srow + RPP * j) * LDK], v);
       else
-        *reinterpret_cast<f32x4*>(&Bs[buf][(srow + 32 * j) * LDK + seg * 4]) = v;
+        *reinterpret_cast<f32x4*>(&Bs[buf][(srow + RPP * j) * LDK + seg * 4]) = v;
     }
   };
 
@@ -1329,6 +1331,28 @@ static int choose_splitk(const IGemmP& p, int BM, int BN, size_t ws_bytes) {
   return S < 1 ? 1 : S;
 }
 
+int g_big_tile = 0;   // -1: never use the 256 x 128 eight-wave tile; > 0: minimum tile count for it (m2h_debug_set 26)
+
+// 256 x 128 tile, 8 waves, two LDS stages, bf16x3 math on scalar-loader shapes only (no split-K: chosen when the tiles fill the chip)
+static int launch_big(IGemmP& p, size_t ws_bytes, hipStream_t st) {
+  constexpr int BM = 256, BN = 128;
+  (void)ws_bytes;
+  p.MT = (p.M + BM - 1) / BM;
+  p.NT = (p.N + BN - 1) / BN;
+  p.S = 1;
+  const long mtpad = ((long)p.MT + 7) / 8 * 8;
+  const long nblk = mtpad * p.NT;
+  if (nblk * 4 > 0x7fffffffL) return fail(-1, "conv_igemm: grid too large (%ld blocks)", nblk);
+  const int phases = p.convT ? 4 : 1;
+  p.pmaj = (p.convT && g_phase_major >= 0) ? 1 : 0;
+  dim3 grid((unsigned)(p.pmaj ? nblk * 4 : nblk), 1, p.pmaj ? 1 : phases);
+  if (p.presplit)
+    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, 4, 2, 2, 32, 1, 2>), grid, dim3(512), 0, st, p);
+  else
+    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, 4, 2, 2, 32, 1, 1>), grid, dim3(512), 0, st, p);
+  return launch_status("conv_igemm_f32 (256x128)");
+}
+
 template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32>
 static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   const bool fast = g_fast_loader >= 0 && p.fast_ok;
@@ -1341,14 +1365,15 @@ static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   const int phases = p.convT ? 4 : 1;
   p.pmaj = (p.convT && g_phase_major >= 0 && nblk * 4 <= 0x7fffffffL) ? 1 : 0;
   dim3 grid((unsigned)(p.pmaj ? nblk * 4 : nblk), (unsigned)p.S, p.pmaj ? 1 : phases);
+  const dim3 blk(64 * WM * WN);
   if (fast && p.math == 1 && p.presplit)
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1, 2>), grid, dim3(256), (size_t)g_extra_lds, st, p);
+    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1, 2>), grid, blk, (size_t)g_extra_lds, st, p);
   else if (fast && p.math == 1)
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1, 1>), grid, dim3(256), (size_t)g_extra_lds, st, p);
+    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1, 1>), grid, blk, (size_t)g_extra_lds, st, p);
   else if (fast)
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1>), grid, dim3(256), (size_t)g_extra_lds, st, p);
+    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1>), grid, blk, (size_t)g_extra_lds, st, p);
   else
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 0>), grid, dim3(256), (size_t)g_extra_lds, st, p);
+    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 0>), grid, blk, (size_t)g_extra_lds, st, p);
   int rc = launch_status("conv_igemm_f32");
   if (rc != 0 || p.S == 1) return rc;
   const long total = (long)p.M * (p.N >> 2);
@@ -1524,6 +1549,14 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
     else if (a.C0 == 32) hipLaunchKernelGGL((conv3x3_row_kernel<32, 32>), grid, blk, 0, st, p);
     else hipLaunchKernelGGL((conv3x3_row_kernel<32, 16>), grid, blk, 0, st, p);
     return launch_status("conv_igemm_f32 (image-row 3x3)");
+  }
+  // bf16x3 math, wide N, enough work for one 256 x 128 tile per CU: eight waves (4 x 2 wave tiles of 64 x 64) share one staged
+  // pair of operand tiles.  The 128 x 128 kernel at two blocks per CU is bound by the chip's aggregate L2 -> LDS operand stream
+  // (PMC: ~8.5 TB/s of L2 reads with the matrix pipe 36 % and the LDS 39 % busy; one block per CU is only 7 % slower than two);
+  // the larger tile reads 384 operand rows per 256 x 128 outputs instead of 512.
+  if (p.math == 1 && g_big_tile >= 0 && g_fast_loader >= 0 && p.fast_ok && p.N % 128 == 0 && g_force_splitk <= 0) {
+    const long tiles = ((M + 255) / 256) * (p.N / 128) * (p.convT ? 4 : 1);
+    if (tiles >= (g_big_tile > 0 ? g_big_tile : 224)) return launch_big(p, wsb, st);
   }
   int BM, BN;
   pick_tile(M, p.N, BM, BN);

@@ -77,11 +77,11 @@ def main():
 
     variants = []
     for v in a.variants.split(";"):
-        kn = {i: 0 for i in range(25)}
+        kn = {i: 0 for i in list(range(25)) + [26]}
         if v != "auto":
             for kv in v.split(","):
                 k, val = kv.split("=")
-                kn[{"splitk": 0, "stages": 1, "wide": 2, "skinny": 3, "n16": 4, "stagger": 5, "pp": 6, "lds": 7, "pmaj": 8, "fast": 9, "math": 14, "tap": 15, "tapbm": 16, "gather": 24}[k]] = int(val)
+                kn[{"splitk": 0, "stages": 1, "wide": 2, "skinny": 3, "n16": 4, "stagger": 5, "pp": 6, "lds": 7, "pmaj": 8, "fast": 9, "math": 14, "tap": 15, "tapbm": 16, "gather": 24, "big": 26}[k]] = int(val)
         variants.append((v, kn))
 
     print("%-12s %10s %8s %6s | " % ("layer", "M", "K", "N") + " | ".join("%22s" % v for v, _ in variants))
@@ -119,7 +119,7 @@ def main():
             tot[vi] += us
             cells.append("%9.1f us %6.1f TF/s" % (us, flops / us / 1e6))
         print("%-12s %10d %8d %6d | " % (name, M, K, co) + " | ".join(cells))
-    for k in range(25):
+    for k in list(range(25)) + [26]:
         ops.debug_set(k, 0)
     print("%-12s %26s | " % ("total(us)", "") + " | ".join("%22.1f" % t for t in tot))
 
