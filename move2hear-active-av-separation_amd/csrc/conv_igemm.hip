@@ -1333,9 +1333,10 @@ static int choose_splitk(const IGemmP& p, int BM, int BN, size_t ws_bytes) {
 
 int g_big_tile = 0;   // -1: never use the 256 x 128 eight-wave tile; > 0: minimum tile count for it (m2h_debug_set 26)
 
-// 256 x 128 tile, 8 waves, two LDS stages, bf16x3 math on scalar-loader shapes only (no split-K: chosen when the tiles fill the chip)
+// 256 x BN tile, 8 waves, two LDS stages, bf16x3 math on scalar-loader shapes only (no split-K: chosen when the tiles fill the chip)
+template <int BN>
 static int launch_big(IGemmP& p, size_t ws_bytes, hipStream_t st) {
-  constexpr int BM = 256, BN = 128;
+  constexpr int BM = 256;
   (void)ws_bytes;
   p.MT = (p.M + BM - 1) / BM;
   p.NT = (p.N + BN - 1) / BN;
@@ -1553,10 +1554,11 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   // bf16x3 math, wide N, enough work for one 256 x 128 tile per CU: eight waves (4 x 2 wave tiles of 64 x 64) share one staged
   // pair of operand tiles.  The 128 x 128 kernel at two blocks per CU is bound by the chip's aggregate L2 -> LDS operand stream
   // (PMC: ~8.5 TB/s of L2 reads with the matrix pipe 36 % and the LDS 39 % busy; one block per CU is only 7 % slower than two);
-  // the larger tile reads 384 operand rows per 256 x 128 outputs instead of 512.
+  // the larger tile reads 384 operand rows per 256 x 128 outputs instead of 512.  (A 256 x 64 tile for the 64-wide first encoder
+  // stage measured slower: 252 vs 235 us.)
   if (p.math == 1 && g_big_tile >= 0 && g_fast_loader >= 0 && p.fast_ok && p.N % 128 == 0 && g_force_splitk <= 0) {
     const long tiles = ((M + 255) / 256) * (p.N / 128) * (p.convT ? 4 : 1);
-    if (tiles >= (g_big_tile > 0 ? g_big_tile : 224)) return launch_big(p, wsb, st);
+    if (tiles >= (g_big_tile > 0 ? g_big_tile : 224)) return launch_big<128>(p, wsb, st);
   }
   int BM, BN;
   pick_tile(M, p.N, BM, BN);
