@@ -148,7 +148,8 @@ size_t m2h_conv_igemm_workspace_bytes(const m2h_conv_args* args /* host */);
  * transposed-conv order (-1 off), 9 scalar-decode loader (-1 off), 11 weight-gradient block target, 14 = m2h_set_math_mode (kept
  * for older callers; thread-local like it), 15 / 16 tap-sharing transposed-conv kernel (-1 off / tile), 18 tap window (-1 off), 21 / 22
  * image-row 3x3 weight-gradient / conv kernels (-1 off), 23 skinny rows kernel for M <= 16 (-1 off), 24 skinny gather kernel (-1 off,
- * > 0 = pixel limit), 26 the 256 x 128 eight-wave tile of the bf16x3 arithmetic (-1 off, > 0 = minimum tile count).  The launches that take a specialised kernel say which in the source (csrc/conv_igemm.hip, conv_bwd.hip);
+ * > 0 = pixel limit), 26 the 256 x 128 eight-wave tile of the bf16x3 arithmetic (-1 off, > 0 = minimum tile count), 27 the LDS-DMA engine for split32 operands
+ * (csrc/conv_dma.hip; -1 off, 1 / 2 = its 128 x 128 / 256 x 128 tile only).  The launches that take a specialised kernel say which in the source (csrc/conv_igemm.hip, conv_bwd.hip);
  * retired experiment numbers are accepted and ignored. */
 int m2h_debug_set(int knob, int value);
 

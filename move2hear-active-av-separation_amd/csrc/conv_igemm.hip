@@ -21,9 +21,7 @@
 //
 // Block -> tile map: n-tiles of one m-tile are consecutive on one XCD (blocks b and b+8 share an XCD's
 // L2), so the gathered A panel is fetched from HBM once and re-read from L2 by its sibling n-tiles.
-#include <type_traits>
-
-#include "m2h_internal.h"
+#include "igemm_common.h"
 
 #ifndef M2H_SCHED
 #define M2H_SCHED 0  // instruction-interleave experiment selector for the k-loop (0 = compiler default)
@@ -31,223 +29,11 @@
 
 namespace m2h {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct IGemmP {
-  const float* src0;
-  const float* src1;
-  int C0, C1, Ctot;
-  int B, Hi, Wi;
-  int Hq, Wq;
-  int stride;
-  int ntw, ntap;
-  int mulh, offh, mulw, offw;
-  int convT;
-  const float* w;
-  int N, K;
-  const float* scale;
-  const float* shift;
-  float slope;
-  const float* cls_table;
-  const float* cls_val;
-  float* dst;
-  int Ho, Wo, os, ph, pw, ldc, out_mode;
-  int M, MT, NT;
-  const float* head_w;  // fused 1x1 head (N <= 32, one n-tile): [N][N] weights applied to the activated tile, + head_b, de-sliced store
-  const float* head_b;
-  int fast_ok; // scalar-decode loader applicable (host check)
-  int math;      // arithmetic of this launch: 0 fp32 MFMA, 1 bf16x3 split products (args' M2H_FMT_MATH_* or the calling thread's mode)
-  int presplit;  // both operands arrive in the split32 layout
-  int dst_split; // epilogue writes dst in the split32 layout (bf16x3 math, NHWC, N % 32 == 0)
-  int pmaj;    // transposed conv: phase is folded into grid x (fastest) instead of grid z
-  // tap window of the scalar-decode loader: taps th0..th0+thn-1 x tw0..tw0+twn-1 are walked, the others lie in the zero
-  // padding for EVERY output pixel of this launch (tiny images: a 2-row input under a 4x4/s2/p1 conv, a 1-row input under a
-  // transposed conv) and are skipped: their products are exact zeros.  Kw = thn * twn * Ctot is the walked reduction length.
-  int th0, thn, tw0, twn, Kw;
-  int S;       // split-K factor (grid y); S > 1: raw partial sums go to `ws`, the epilogue runs in splitk_epilogue_kernel
-  float* ws;   // [phase][S][M][N] fp32 partial slabs (caller-owned workspace)
-};
-
 #ifdef M2H_CLOCK_DIAG
 // Diagnostic build only (tools/clock_diag.py): shader-clock vs 100 MHz real-time stamps around the k-loop of each block, to read
 // the clock the chip holds under this kernel (MI355X_MICROARCH.md, DVFS give-back item 6).  Never compiled into libm2h.so.
 __device__ unsigned long long g_clock_dbg[8192][6];
 #endif
-
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int BK = 32;   // k-tile depth (floats)
-constexpr int LDK = 36;  // padded LDS row (floats): 144 B, keeps 16-B alignment, conflict-free b128 reads
-
-// Row bookkeeping shared by the main kernel and the split-K epilogue: output pixel offset and class id of GEMM row m.
-__device__ __forceinline__ void decode_row(const IGemmP& p, int m, int ph, int pw, int& q, int& rr, int& b, int& out, int& bc) {
-  rr = m % p.Wq;
-  const int t = m / p.Wq;
-  q = t % p.Hq;
-  b = t / p.Hq;
-  const int oh = q * p.os + ph, ow = rr * p.os + pw;
-  if (p.out_mode == M2H_OUT_NHWC)
-    out = (b * p.Ho + oh) * p.Wo + ow;
-  else
-    out = b * 16 * p.Ho * p.Wo + oh * p.Wo + ow;
-  const int ch = (oh == 0) ? 0 : ((oh == p.Ho - 1) ? 2 : 1);
-  const int cw = (ow == 0) ? 0 : ((ow == p.Wo - 1) ? 2 : 1);
-  bc = b * 16 + ch * 3 + cw;
-}
-
-// Fused epilogue shared by the LDS-staged kernel and the tap-sharing transposed-conv kernel: class-plane bias, BN scale/shift
-// or bias, LeakyReLU/ReLU and the NHWC / de-sliced store; with head_w, the last decoder stage's 1x1 head on the on-chip tile.
-// As0 / Bs0: LDS scratch of at least BM*LDK and max(BN,32)*LDK floats (the main loop's tiles, free by now).
-template <int BM, int BN, int WM, int WN, int FR, typename AccT>
-__device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM / WM / FR][BN / WN / FR], float* As0, float* Bs0,
-                                               const int* ri_out, const int* ri_bc, int n0, int tid) {
-  constexpr int TM = BM / WM, TN = BN / WN;
-  constexpr int FM = TM / FR, FN = TN / FR;
-  constexpr int GK = FR == 32 ? 8 : 16;
-  constexpr int NE = FR == 32 ? 16 : 4;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int frow = lane & (FR - 1);
-  const int fk = (lane / FR) * 4;
-  auto row_of = [&](int e) { return FR == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : (lane >> 4) * 4 + e; };
-  const int col = lane & (FR - 1);
-  if constexpr (BN <= 32 && WM == 4) {
-    if (p.head_w != nullptr) {
-      // Last decoder stage + head in one kernel (separator_cnn.py:133-134,163-168): y = ReLU(BN(convT)) stays on chip, a second
-      // small MFMA pass applies the 1x1 conv, the result is transposed through LDS and stored de-sliced with one contiguous
-      // (s, pixel-run) segment per wave instruction instead of 4-byte scatters.
-      constexpr int LDT = BM + 1;    // [n'][m] staging stride: conflict-free column writes
-      constexpr int NGH = FR / GK;   // fragment groups of the FR-deep head contraction
-      float* Y = As0;
-      float* Wh = Bs0;
-      __syncthreads();  // every wave is done with the main loop's LDS tiles
-      {
-        const int n = col;
-        const float scn = (p.scale != nullptr && n < p.N) ? p.scale[n] : 1.f;
-        const float shn = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < FM; ++mi)
-#pragma unroll
-          for (int e = 0; e < NE; ++e) {
-            const int lrow = wm * TM + mi * FR + row_of(e);
-            float v = 0.f;
-            if (n < p.N) {
-              v = acc[mi][0][e] * scn + shn;
-              v = v > 0.f ? v : v * p.slope;
-            }
-            Y[lrow * LDK + n] = v;
-          }
-        for (int idx = tid; idx < FR * FR; idx += 256) {  // FR x FR head matrix, zero padded
-          const int n2 = idx / FR, k = idx % FR;
-          Wh[n2 * LDK + k] = (n2 < p.N && k < p.N) ? p.head_w[n2 * p.N + k] : 0.f;
-        }
-      }
-      __syncthreads();
-      AccT acc2[FM];
-#pragma unroll
-      for (int mi = 0; mi < FM; ++mi)
-#pragma unroll
-        for (int e = 0; e < NE; ++e) acc2[mi][e] = 0.f;
-#pragma unroll
-      for (int g = 0; g < NGH; ++g) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(&Wh[frow * LDK + g * GK + fk]);
-#pragma unroll
-        for (int mi = 0; mi < FM; ++mi) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(&Y[(wm * TM + mi * FR + frow) * LDK + g * GK + fk]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if constexpr (FR == 32)
-              acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc2[mi], 0, 0, 0);
-            else
-              acc2[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc2[mi], 0, 0, 0);
-          }
-        }
-      }
-      __syncthreads();  // Y fully consumed before it is overwritten by the transposed staging
-      float* Tt = Y;
-      const float hb = col < p.N ? p.head_b[col] : 0.f;
-#pragma unroll
-      for (int mi = 0; mi < FM; ++mi)
-#pragma unroll
-        for (int e = 0; e < NE; ++e) Tt[col * LDT + wm * TM + mi * FR + row_of(e)] = acc2[mi][e] + hb;
-      __syncthreads();
-      const size_t plane2 = (size_t)p.Ho * p.Wo;
-      const int Cc2 = p.N >> 4;
-#pragma unroll
-      for (int it = 0; it < 16 * BM / 256; ++it) {
-        const int i = tid + 256 * it;
-        const int s = i / BM, m = i % BM;
-        const int out = ri_out[m];
-        if (out < 0) continue;
-        float* dptr = p.dst + ((size_t)out + (size_t)s * plane2) * Cc2;
-        if (Cc2 == 2) {
-          float2 v2;
-          v2.x = Tt[s * LDT + m];
-          v2.y = Tt[(16 + s) * LDT + m];
-          *reinterpret_cast<float2*>(dptr) = v2;
-        } else {
-          dptr[0] = Tt[s * LDT + m];
-        }
-      }
-      return;
-    }
-  }
-  float sc[FN], sh[FN];
-  int nn[FN];
-#pragma unroll
-  for (int ni = 0; ni < FN; ++ni) {
-    const int n = n0 + wn * TN + ni * FR + col;
-    nn[ni] = n;
-    sc[ni] = (p.scale != nullptr && n < p.N) ? p.scale[n] : 1.f;
-    sh[ni] = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
-  }
-  const size_t plane = (size_t)p.Ho * p.Wo;
-  const int Cc = p.N >> 4;
-#pragma unroll
-  for (int mi = 0; mi < FM; ++mi) {
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int lrow = wm * TM + mi * FR + row_of(e);
-      const int out = ri_out[lrow];
-      if (out < 0) continue;
-      const int bc = ri_bc[lrow];
-      float cv = 0.f;
-      const float* ctab = nullptr;
-      if (p.cls_table != nullptr) {
-        cv = p.cls_val[bc >> 4];
-        ctab = p.cls_table + (size_t)(bc & 15) * p.N;
-      }
-#pragma unroll
-      for (int ni = 0; ni < FN; ++ni) {
-        const int n = nn[ni];
-        if (n >= p.N) continue;
-        float v = acc[mi][ni][e];
-        if (ctab != nullptr) v += cv * ctab[n];
-        v = v * sc[ni] + sh[ni];
-        v = v > 0.f ? v : v * p.slope;
-        if (p.out_mode == M2H_OUT_NHWC) {
-          if (p.dst_split) {
-            // split32 store: lanes (n even, n odd) pair up; the even lane writes both hi halves, the odd lane both lo halves
-            const __bf16 hb = (__bf16)v;
-            const __bf16 lb = (__bf16)(v - (float)hb);
-            const unsigned h16 = __builtin_bit_cast(unsigned short, hb), l16 = __builtin_bit_cast(unsigned short, lb);
-            const unsigned ph_ = __shfl_xor(h16, 1, 64), pl_ = __shfl_xor(l16, 1, 64);
-            const unsigned word = (n & 1) ? (pl_ | (l16 << 16)) : (h16 | (ph_ << 16));
-            unsigned* drow = reinterpret_cast<unsigned*>(p.dst + (size_t)out * p.ldc + (n & ~31));
-            drow[((n & 1) ? 16 : 0) + ((n & 31) >> 1)] = word;
-          } else {
-            p.dst[(size_t)out * p.ldc + n] = v;
-          }
-        } else {
-          const int c = n >> 4, s = n & 15;
-          p.dst[((size_t)out + (size_t)s * plane) * Cc + c] = v;
-        }
-      }
-    }
-  }
-}
 
 // FR = MFMA fragment edge: 32 (v_mfma_f32_32x32x2_f32, 8 k per 16-byte LDS read) or 16 (v_mfma_f32_16x16x4_f32, 16 k per read;
 // used for N <= 16 so that a 16-channel layer does not pay for a half-empty 32-wide tile).  Same FLOP rate per cycle.
@@ -674,12 +460,14 @@ __global__ __launch_bounds__(64 * WM * WN, (SPLIT && WM * WN == 4) ? 2 : 1) void
 // one LDS image.  Per thread the global offsets are fixed for the whole kernel (only a uniform channel base advances).
 // Requires: conv_transpose, FAST channels, 128 % Wq == 0, Wq >= 32, Hq % (128 / Wq) == 0.  Tile, accumulators and epilogue
 // (incl. the fused head) are those of igemm_f32_kernel<128, BN, 4, 1, *, FR, 1, 1>.
-template <int BN, int FR, int PRE = 0, int BM = 128>   // PRE: operands already in the split32 layout (plain copies into LDS)
-__global__ __launch_bounds__(256, 2) void convT_tap_kernel(const IGemmP p) {
+template <int BN, int FR, int PRE = 0, int BM = 128, int WM = 4>   // PRE: operands already in the split32 layout (plain copies into LDS)
+__global__ __launch_bounds__(64 * WM, WM == 4 ? 2 : 1) void convT_tap_kernel(const IGemmP p) {
   // BM = 256 (two image rows of 128, ...): the staged image grows by one row instead of doubling and the weight rows are
   // shared by twice the outputs -- the kernel is bound by L2 -> LDS traffic (PMC: 49 % of wave cycles parked on waits,
   // matrix pipe 24 % busy), so bytes per output are what counts.
-  constexpr int WM = 4, WN = 1;
+  // WM = 8 (512 threads, one block per CU, twice the outputs per block): the same wave tiles, but the staged image has one halo
+  // row per 2 x as many rows and the weight rows serve 2 x the outputs: ~25 % fewer L2 -> LDS bytes per output.
+  constexpr int WN = 1, NT = 64 * WM, RPP = NT / 8;
   constexpr int TM = BM / WM;                    // rows per wave
   constexpr int FM = TM / FR, FN = BN / FR;
   constexpr int GK = FR == 32 ? 8 : 16;
@@ -687,10 +475,10 @@ __global__ __launch_bounds__(256, 2) void convT_tap_kernel(const IGemmP p) {
   constexpr int NE = FR == 32 ? 16 : 4;
   using AccT = typename std::conditional<FR == 32, f32x16, f32x4>::type;
   constexpr int PMAX = (BM / 128 + 1) * 129;     // staged input pixels: (R+1)*(Wq+1) <= this for Wq in {32, 64, 128}
-  constexpr int AR = (PMAX * 8 + 255) / 256;     // 16-byte loads per thread for the input image
+  constexpr int AR = (PMAX * 8 + NT - 1) / NT;   // 16-byte loads per thread for the input image
   constexpr int BROWS = 4 * BN;                  // weight rows per chunk (4 taps x BN channels)
-  constexpr int BRL = BROWS * 8 / 256;           // loads per thread for them
-  static_assert(BROWS * 8 % 256 == 0 && FM >= 1 && FN >= 1, "tile shape");
+  constexpr int BRL = BROWS * 8 / NT;            // loads per thread for them
+  static_assert(BROWS * 8 % NT == 0 && FM >= 1 && FN >= 1, "tile shape");
   __shared__ __attribute__((aligned(16))) float As[PMAX * LDK];
   __shared__ __attribute__((aligned(16))) float Bs[BROWS * LDK];
   __shared__ int ri_out[BM], ri_bc[BM];
@@ -719,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void convT_tap_kernel(const IGemmP p) {
   const int b0 = m0 / (p.Hq * Wq);
   const int q0 = (m0 / Wq) % p.Hq;
 
-  for (int r = tid; r < BM; r += 256) {
+  for (int r = tid; r < BM; r += NT) {
     const int m = m0 + r;
     int out = -1, bc = 0;
     if (m < p.M) {
@@ -735,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void convT_tap_kernel(const IGemmP p) {
   unsigned voffA[AR], voffB[BRL];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    const int l = srow + 32 * i;
+    const int l = srow + RPP * i;
     const int qi = l / W1, rr = l - qi * W1;
     const int ih = q0 + qi + hoff, iw = rr + woff;
     const bool ok = l < P && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi && b0 < p.B;
@@ -743,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void convT_tap_kernel(const IGemmP p) {
   }
 #pragma unroll
   for (int j = 0; j < BRL; ++j) {
-    const int row = srow + 32 * j;               // tap * BN + n
+    const int row = srow + RPP * j;               // tap * BN + n
     const int tap = row / BN, n = min(row - tap * BN, p.N - 1);   // rows past N re-read row N-1 (never stored)
     voffB[j] = ((unsigned)n * (unsigned)p.K + (unsigned)(tap * p.Ctot + seg * 4)) * 4u;
   }
@@ -803,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void convT_tap_kernel(const IGemmP p) {
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      const int l = srow + 32 * i;
+      const int l = srow + RPP * i;
       if (l < PMAX) {
         const f32x4 v = pixA[i] >= 0 ? ra[i] : zero4;
         if constexpr (PRE)
@@ -815,9 +603,9 @@ __global__ __launch_bounds__(256, 2) void convT_tap_kernel(const IGemmP p) {
 #pragma unroll
     for (int j = 0; j < BRL; ++j) {
       if constexpr (PRE)
-        *reinterpret_cast<f32x4*>(&Bs[(srow + 32 * j) * LDK + seg * 4]) = rb[j];
+        *reinterpret_cast<f32x4*>(&Bs[(srow + RPP * j) * LDK + seg * 4]) = rb[j];
       else
-        store_split(&Bs[(srow + 32 * j) * LDK], rb[j]);
+        store_split(&Bs[(srow + RPP * j) * LDK], rb[j]);
     }
   };
   auto mfma_bf16 = [&](const f32x4& a, const f32x4& b, AccT& c) {
@@ -1317,7 +1105,7 @@ static int splitk_for(long M, int N, int K, int phases, int BM, int BN) {
   return S < 1 ? 1 : (int)S;
 }
 
-static int choose_splitk(const IGemmP& p, int BM, int BN, size_t ws_bytes) {
+int choose_splitk(const IGemmP& p, int BM, int BN, size_t ws_bytes) {
   if (p.ws == nullptr || g_force_splitk < 0 || (p.N & 3) != 0) return 1;
   const int phases = p.convT ? 4 : 1;
   const int Kw = (g_fast_loader >= 0 && p.fast_ok) ? p.Kw : p.K;
@@ -1473,8 +1261,13 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   if (p.convT && p.math == 1 && g_tapshare >= 0 && p.fast_ok && p.N <= 64 && a.Wq >= 32 && 128 % a.Wq == 0 &&
       a.Hq % (128 / a.Wq) == 0 && g_force_splitk <= 0 && g_phase_major >= 0 && M >= 128L * 256) {
     // 256-output tiles when the image geometry and the block count allow (bytes per output: see the kernel)
-    const bool big = g_tap_bm != 128 && p.N <= 32 && a.Hq % (256 / a.Wq) == 0 && M >= 256L * 512;   // N = 64: 93 KB LDS, one block per CU
-    const int bm = big ? 256 : 128;
+    // eight-wave blocks (one per CU): 256-output tiles for N = 64 by default (pair_ab, headline pair: 3.392 -> 3.364 ms); the
+    // 512-output tiles for N <= 32 measured no gain (3.388 / 3.388) and stay behind m2h_debug_set 16 = 512 (128 / 256 = the
+    // four-wave tiles only)
+    const int bm8 = p.N <= 32 ? 512 : 256;
+    const bool wave8 = (g_tap_bm == 512 || (g_tap_bm == 0 && p.N > 32)) && bm8 / a.Wq >= 1 && a.Hq % (bm8 / a.Wq) == 0 && M >= (long)bm8 * 512;
+    const bool big = !wave8 && g_tap_bm != 128 && p.N <= 32 && a.Hq % (256 / a.Wq) == 0 && M >= 256L * 512;   // N = 64, 4 waves: 93 KB LDS, one block per CU
+    const int bm = wave8 ? bm8 : big ? 256 : 128;
     p.MT = (int)((M + bm - 1) / bm);
     p.NT = 1;
     p.S = 1;
@@ -1483,18 +1276,23 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
     // 32-wide stage uses this kernel only with split32 operands (runner) or when forced
     const int w = (p.N <= 16 && g_narrow16 >= 0) ? 16 : (p.N <= 32 ? 32 : 64);
     if (nblk <= 0x7fffffffL && (w != 32 || g_tapshare > 0 || p.presplit)) {
-      const dim3 grid((unsigned)nblk), blk(256);
-#define M2H_TAP(BN_, FR_)                                                                                   \
-  do {                                                                                                      \
-    if (p.presplit && big) hipLaunchKernelGGL((convT_tap_kernel<BN_, FR_, 1, 256>), grid, blk, 0, st, p);    \
-    else if (p.presplit) hipLaunchKernelGGL((convT_tap_kernel<BN_, FR_, 1, 128>), grid, blk, 0, st, p);      \
-    else if (big) hipLaunchKernelGGL((convT_tap_kernel<BN_, FR_, 0, 256>), grid, blk, 0, st, p);             \
-    else hipLaunchKernelGGL((convT_tap_kernel<BN_, FR_, 0, 128>), grid, blk, 0, st, p);                      \
+      const dim3 grid((unsigned)nblk), blk(wave8 ? 512 : 256);
+#define M2H_TAP_P(BN_, FR_, PRE_)                                                                                  \
+  do {                                                                                                             \
+    if (wave8) hipLaunchKernelGGL((convT_tap_kernel<BN_, FR_, PRE_, (BN_ <= 32 ? 512 : 256), 8>), grid, blk, 0, st, p); \
+    else if (big) hipLaunchKernelGGL((convT_tap_kernel<BN_, FR_, PRE_, 256>), grid, blk, 0, st, p);               \
+    else hipLaunchKernelGGL((convT_tap_kernel<BN_, FR_, PRE_, 128>), grid, blk, 0, st, p);                        \
+  } while (0)
+#define M2H_TAP(BN_, FR_)                       \
+  do {                                          \
+    if (p.presplit) M2H_TAP_P(BN_, FR_, 1);     \
+    else M2H_TAP_P(BN_, FR_, 0);                \
   } while (0)
       if (w == 16) M2H_TAP(16, 16);
       else if (w == 32) M2H_TAP(32, 32);
       else M2H_TAP(64, 32);
 #undef M2H_TAP
+#undef M2H_TAP_P
       return launch_status("conv_igemm_f32 (tap-sharing convT)");
     }
   }
@@ -1556,6 +1354,17 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   // (PMC: ~8.5 TB/s of L2 reads with the matrix pipe 36 % and the LDS 39 % busy; one block per CU is only 7 % slower than two);
   // the larger tile reads 384 operand rows per 256 x 128 outputs instead of 512.  (A 256 x 64 tile for the 64-wide first encoder
   // stage measured slower: 252 vs 235 us.)
+  if (g_fast_loader >= 0 && g_force_splitk <= 0) {   // split32 operands, wide N: the LDS-DMA engine (conv_dma.hip)
+    const int rc = launch_igemm_dma(p, wsb, st);
+    if (rc != -2) {
+      if (rc != 0 || p.S == 1) return rc;
+      const long total = (long)p.M * (p.N >> 2);
+      long g = (total + 255) / 256;
+      if (g > 4096) g = 4096;
+      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g, p.convT ? 4 : 1), dim3(256), 0, st, p);
+      return launch_status("conv_igemm_f32 split-K epilogue");
+    }
+  }
   if (p.math == 1 && g_big_tile >= 0 && g_fast_loader >= 0 && p.fast_ok && p.N % 128 == 0 && g_force_splitk <= 0) {
     const long tiles = ((M + 255) / 256) * (p.N / 128) * (p.convT ? 4 : 1);
     if (tiles >= (g_big_tile > 0 ? g_big_tile : 224)) return launch_big<128>(p, wsb, st);

@@ -1,0 +1,232 @@
+// Declarations shared by the implicit-GEMM translation units (conv_igemm.hip: the register-staged engine and its dispatch;
+// conv_dma.hip: the LDS-DMA engine for split32 operands): launch parameters, row decode and the fused epilogue.
+#pragma once
+#include <type_traits>
+
+#include "m2h_internal.h"
+
+namespace m2h {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct IGemmP {
+  const float* src0;
+  const float* src1;
+  int C0, C1, Ctot;
+  int B, Hi, Wi;
+  int Hq, Wq;
+  int stride;
+  int ntw, ntap;
+  int mulh, offh, mulw, offw;
+  int convT;
+  const float* w;
+  int N, K;
+  const float* scale;
+  const float* shift;
+  float slope;
+  const float* cls_table;
+  const float* cls_val;
+  float* dst;
+  int Ho, Wo, os, ph, pw, ldc, out_mode;
+  int M, MT, NT;
+  const float* head_w;  // fused 1x1 head (N <= 32, one n-tile): [N][N] weights applied to the activated tile, + head_b, de-sliced store
+  const float* head_b;
+  int fast_ok; // scalar-decode loader applicable (host check)
+  int math;      // arithmetic of this launch: 0 fp32 MFMA, 1 bf16x3 split products (args' M2H_FMT_MATH_* or the calling thread's mode)
+  int presplit;  // both operands arrive in the split32 layout
+  int dst_split; // epilogue writes dst in the split32 layout (bf16x3 math, NHWC, N % 32 == 0)
+  int pmaj;    // transposed conv: phase is folded into grid x (fastest) instead of grid z
+  // tap window of the scalar-decode loader: taps th0..th0+thn-1 x tw0..tw0+twn-1 are walked, the others lie in the zero
+  // padding for EVERY output pixel of this launch (tiny images: a 2-row input under a 4x4/s2/p1 conv, a 1-row input under a
+  // transposed conv) and are skipped: their products are exact zeros.  Kw = thn * twn * Ctot is the walked reduction length.
+  int th0, thn, tw0, twn, Kw;
+  int S;       // split-K factor (grid y); S > 1: raw partial sums go to `ws`, the epilogue runs in splitk_epilogue_kernel
+  float* ws;   // [phase][S][M][N] fp32 partial slabs (caller-owned workspace)
+};
+
+
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BK = 32;   // k-tile depth (floats)
+constexpr int LDK = 36;  // padded LDS row (floats): 144 B, keeps 16-B alignment, conflict-free b128 reads
+
+// Row bookkeeping shared by the main kernel and the split-K epilogue: output pixel offset and class id of GEMM row m.
+__device__ __forceinline__ void decode_row(const IGemmP& p, int m, int ph, int pw, int& q, int& rr, int& b, int& out, int& bc) {
+  rr = m % p.Wq;
+  const int t = m / p.Wq;
+  q = t % p.Hq;
+  b = t / p.Hq;
+  const int oh = q * p.os + ph, ow = rr * p.os + pw;
+  if (p.out_mode == M2H_OUT_NHWC)
+    out = (b * p.Ho + oh) * p.Wo + ow;
+  else
+    out = b * 16 * p.Ho * p.Wo + oh * p.Wo + ow;
+  const int ch = (oh == 0) ? 0 : ((oh == p.Ho - 1) ? 2 : 1);
+  const int cw = (ow == 0) ? 0 : ((ow == p.Wo - 1) ? 2 : 1);
+  bc = b * 16 + ch * 3 + cw;
+}
+
+// Fused epilogue shared by the LDS-staged kernel and the tap-sharing transposed-conv kernel: class-plane bias, BN scale/shift
+// or bias, LeakyReLU/ReLU and the NHWC / de-sliced store; with head_w, the last decoder stage's 1x1 head on the on-chip tile.
+// As0 / Bs0: LDS scratch of at least BM*LDK and max(BN,32)*LDK floats (the main loop's tiles, free by now).
+template <int BM, int BN, int WM, int WN, int FR, typename AccT>
+__device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM / WM / FR][BN / WN / FR], float* As0, float* Bs0,
+                                               const int* ri_out, const int* ri_bc, int n0, int tid) {
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int FM = TM / FR, FN = TN / FR;
+  constexpr int GK = FR == 32 ? 8 : 16;
+  constexpr int NE = FR == 32 ? 16 : 4;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int frow = lane & (FR - 1);
+  const int fk = (lane / FR) * 4;
+  auto row_of = [&](int e) { return FR == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : (lane >> 4) * 4 + e; };
+  const int col = lane & (FR - 1);
+  constexpr int NTE = 64 * WM * WN;   // threads of the calling block
+  if constexpr (BN <= 32 && WN == 1) {
+    if (p.head_w != nullptr) {
+      // Last decoder stage + head in one kernel (separator_cnn.py:133-134,163-168): y = ReLU(BN(convT)) stays on chip, a second
+      // small MFMA pass applies the 1x1 conv, the result is transposed through LDS and stored de-sliced with one contiguous
+      // (s, pixel-run) segment per wave instruction instead of 4-byte scatters.
+      constexpr int LDT = BM + 1;    // [n'][m] staging stride: conflict-free column writes
+      constexpr int NGH = FR / GK;   // fragment groups of the FR-deep head contraction
+      float* Y = As0;
+      float* Wh = Bs0;
+      __syncthreads();  // every wave is done with the main loop's LDS tiles
+      {
+        const int n = col;
+        const float scn = (p.scale != nullptr && n < p.N) ? p.scale[n] : 1.f;
+        const float shn = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const int lrow = wm * TM + mi * FR + row_of(e);
+            float v = 0.f;
+            if (n < p.N) {
+              v = acc[mi][0][e] * scn + shn;
+              v = v > 0.f ? v : v * p.slope;
+            }
+            Y[lrow * LDK + n] = v;
+          }
+        for (int idx = tid; idx < FR * FR; idx += NTE) {  // FR x FR head matrix, zero padded
+          const int n2 = idx / FR, k = idx % FR;
+          Wh[n2 * LDK + k] = (n2 < p.N && k < p.N) ? p.head_w[n2 * p.N + k] : 0.f;
+        }
+      }
+      __syncthreads();
+      AccT acc2[FM];
+#pragma unroll
+      for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) acc2[mi][e] = 0.f;
+#pragma unroll
+      for (int g = 0; g < NGH; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&Wh[frow * LDK + g * GK + fk]);
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(&Y[(wm * TM + mi * FR + frow) * LDK + g * GK + fk]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if constexpr (FR == 32)
+              acc2[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc2[mi], 0, 0, 0);
+            else
+              acc2[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc2[mi], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();  // Y fully consumed before it is overwritten by the transposed staging
+      float* Tt = Y;
+      const float hb = col < p.N ? p.head_b[col] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) Tt[col * LDT + wm * TM + mi * FR + row_of(e)] = acc2[mi][e] + hb;
+      __syncthreads();
+      const size_t plane2 = (size_t)p.Ho * p.Wo;
+      const int Cc2 = p.N >> 4;
+#pragma unroll
+      for (int it = 0; it < 16 * BM / NTE; ++it) {
+        const int i = tid + NTE * it;
+        const int s = i / BM, m = i % BM;
+        const int out = ri_out[m];
+        if (out < 0) continue;
+        float* dptr = p.dst + ((size_t)out + (size_t)s * plane2) * Cc2;
+        if (Cc2 == 2) {
+          float2 v2;
+          v2.x = Tt[s * LDT + m];
+          v2.y = Tt[(16 + s) * LDT + m];
+          *reinterpret_cast<float2*>(dptr) = v2;
+        } else {
+          dptr[0] = Tt[s * LDT + m];
+        }
+      }
+      return;
+    }
+  }
+  float sc[FN], sh[FN];
+  int nn[FN];
+#pragma unroll
+  for (int ni = 0; ni < FN; ++ni) {
+    const int n = n0 + wn * TN + ni * FR + col;
+    nn[ni] = n;
+    sc[ni] = (p.scale != nullptr && n < p.N) ? p.scale[n] : 1.f;
+    sh[ni] = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
+  }
+  const size_t plane = (size_t)p.Ho * p.Wo;
+  const int Cc = p.N >> 4;
+#pragma unroll
+  for (int mi = 0; mi < FM; ++mi) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int lrow = wm * TM + mi * FR + row_of(e);
+      const int out = ri_out[lrow];
+      if (out < 0) continue;
+      const int bc = ri_bc[lrow];
+      float cv = 0.f;
+      const float* ctab = nullptr;
+      if (p.cls_table != nullptr) {
+        cv = p.cls_val[bc >> 4];
+        ctab = p.cls_table + (size_t)(bc & 15) * p.N;
+      }
+#pragma unroll
+      for (int ni = 0; ni < FN; ++ni) {
+        const int n = nn[ni];
+        if (n >= p.N) continue;
+        float v = acc[mi][ni][e];
+        if (ctab != nullptr) v += cv * ctab[n];
+        v = v * sc[ni] + sh[ni];
+        v = v > 0.f ? v : v * p.slope;
+        if (p.out_mode == M2H_OUT_NHWC) {
+          if (p.dst_split) {
+            // split32 store: lanes (n even, n odd) pair up; the even lane writes both hi halves, the odd lane both lo halves
+            const __bf16 hb = (__bf16)v;
+            const __bf16 lb = (__bf16)(v - (float)hb);
+            const unsigned h16 = __builtin_bit_cast(unsigned short, hb), l16 = __builtin_bit_cast(unsigned short, lb);
+            const unsigned ph_ = __shfl_xor(h16, 1, 64), pl_ = __shfl_xor(l16, 1, 64);
+            const unsigned word = (n & 1) ? (pl_ | (l16 << 16)) : (h16 | (ph_ << 16));
+            unsigned* drow = reinterpret_cast<unsigned*>(p.dst + (size_t)out * p.ldc + (n & ~31));
+            drow[((n & 1) ? 16 : 0) + ((n & 31) >> 1)] = word;
+          } else {
+            p.dst[(size_t)out * p.ldc + n] = v;
+          }
+        } else {
+          const int c = n >> 4, s = n & 15;
+          p.dst[((size_t)out + (size_t)s * plane) * Cc + c] = v;
+        }
+      }
+    }
+  }
+}
+
+// conv_igemm.hip: split-K factor of a launch on BM x BN tiles (the one rule of both engines: equal factors keep their results bit-identical)
+int choose_splitk(const IGemmP& p, int BM, int BN, size_t ws_bytes);
+extern int g_big_tile;
+
+// conv_dma.hip: LDS-DMA engine; returns -2 when the launch is not one of its shapes (the caller falls through), 0 / error otherwise
+int launch_igemm_dma(IGemmP& p, size_t ws_bytes, hipStream_t st);
+
+}  // namespace m2h

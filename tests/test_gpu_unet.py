@@ -200,8 +200,8 @@ def test_error_behaviour():
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
 def test_whole_network_runner_is_bitwise_the_module_chain(mode):
-    """m2h_unet_fwd (one C call per U-Net) gives bit-identical results to the encoder/decoder module chain in both arithmetic
-    modes.  In bf16x3 the runner works on split32 weights and keeps its intermediates in split32 (no operand conversion in any
+    """m2h_unet_fwd (one C call per U-Net) gives the results of the encoder/decoder module chain in both arithmetic modes: bit-identical
+    wherever the two run the same kernels (fp32; bf16x3 with the LDS-DMA engine switched off), to fp32 summation order otherwise.  In bf16x3 the runner works on split32 weights and keeps its intermediates in split32 (no operand conversion in any
     k-loop) while the module chain converts inside the kernels: hi/lo are the same values either way.  tm 256 reaches the
     tap-sharing kernel and the long-M tiles."""
     from m2h import ops
@@ -218,7 +218,20 @@ def test_whole_network_runner_is_bitwise_the_module_chain(mode):
                 fast_mono = pol.convert_bin2mono(fast_m, mixed_audio=obs["mixed_bin_audio_mag"])
                 chain_m = pol.binSep_dec(*pol.binSep_enc(obs))
                 chain_mono = pol.bin2mono_dec(*pol.bin2mono_enc(chain_m, mixed_audio=obs["mixed_bin_audio_mag"]))
-            assert torch.equal(fast_m, chain_m) and torch.equal(fast_mono, chain_mono)
+            if mode == "fp32":
+                assert torch.equal(fast_m, chain_m) and torch.equal(fast_mono, chain_mono)
+            else:
+                # the runner's wide layers run on the LDS-DMA engine (16x16x32 MFMAs: 32 channels per accumulation step), the
+                # module chain on the register engine (32x32x16: 16 per step): same products, fp32 sums in a different order
+                assert O.rel_l1(fast_m.cpu(), chain_m.cpu()) < 1e-5 and O.rel_l1(fast_mono.cpu(), chain_mono.cpu()) < 1e-5
+                ops.debug_set(27, -1)     # without it the two paths are the same kernels on the same values: bit-identical
+                try:
+                    with torch.no_grad():
+                        reg_m = pol.get_binSepMasks(obs)
+                        reg_mono = pol.convert_bin2mono(reg_m, mixed_audio=obs["mixed_bin_audio_mag"])
+                finally:
+                    ops.debug_set(27, 0)
+                assert torch.equal(reg_m, chain_m) and torch.equal(reg_mono, chain_mono)
         # the event-recording entry point: same result, 11 positive kernel durations
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
         for e in evs:
@@ -229,6 +242,49 @@ def test_whole_network_runner_is_bitwise_the_module_chain(mode):
         torch.cuda.synchronize()
         assert torch.equal(m_ev, fast_m)
         assert all(evs[i].elapsed_time(evs[i + 1]) > 0 for i in range(11))
+    finally:
+        ops.set_math_mode(ops.MATH_FP32)
+
+
+@pytest.mark.parametrize("B,tm", [(3, 32), (1, 256), (5, 64)])
+def test_dma_engine_matches_register_engine(B, tm):
+    """The LDS-DMA engine (csrc/conv_dma.hip: split32 operands DMA'd into an LDS ring, fragments read through a row permutation)
+    against the register-staged engine on the whole runner pair -- plain and transposed convs, the skip concat's second source,
+    zero-padded borders, rows past M, the class plane, split32 output.  Forced on every wide layer (m2h_debug_set 27 = 2 / 1: its
+    256 x 128 / 128 x 128 tile, the latter with split-K slabs) since the test batches are too small for the automatic choice.
+    With 32x32x16 fragments (knob 28 = 32) the two engines run the same products in the same order: bit-identical; with the
+    default 16x16x32 fragments the fp32 sums associate differently: equal to summation order."""
+    from m2h import ops
+    dev = _dev()
+    pol, _ = _policy(3, dev)
+    mixed, tc = synthetic.make_passive_inputs(B, tm, 70 + B)
+    obs = {"mixed_bin_audio_mag": torch.from_numpy(mixed).to(dev), "target_class": torch.from_numpy(tc).to(dev)}
+
+    def run(dma, shape, splitk=0):
+        ops.debug_set(27, dma)
+        ops.debug_set(28, shape)
+        ops.debug_set(0, splitk)
+        try:
+            with torch.no_grad():
+                m = pol.get_binSepMasks(obs)
+                return m, pol.convert_bin2mono(m, mixed_audio=obs["mixed_bin_audio_mag"])
+        finally:
+            ops.debug_set(27, 0)
+            ops.debug_set(28, 0)
+            ops.debug_set(0, 0)
+
+    ops.set_math_mode(ops.MATH_BF16X3)
+    try:
+        for tile in (2, 1):
+            sk = -1 if tile == 2 else 0     # the 256 x 128 tile never splits K: compare it with the register engine's unsplit sums
+            ref = run(-1, 0, sk)
+            same = run(tile, 32, sk)
+            assert torch.equal(same[0], ref[0]) and torch.equal(same[1], ref[1])
+            got = run(tile, 0, sk)
+            assert O.rel_l1(got[0].cpu(), ref[0].cpu()) < 1e-5 and O.rel_l1(got[1].cpu(), ref[1].cpu()) < 1e-5   # contract: 1e-3
+            assert not torch.equal(got[0], ref[0])     # the engine really ran (another summation order)
+            again = run(tile, 0, sk)
+            assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1])
     finally:
         ops.set_math_mode(ops.MATH_FP32)
 

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Diagnostic (not product): builds a copy of libm2h with -DM2H_CLOCK_DIAG, runs one split32 U-Net layer on the LDS-DMA engine
+back to back for ~2 s and prints the shader clock the chip holds inside its k-loop (delta s_memtime / delta s_memrealtime x
+100 MHz) and the cycles per k-tile.  usage: python tools/clock_diag_dma.py [knob27 values, e.g. 0 5 4]"""
+import ctypes
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "move2hear-active-av-separation_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from m2h import _lib  # noqa: E402
+
+diag = "/tmp/libm2h_diag.so"
+cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DM2H_CLOCK_DIAG", "-I" + _lib.INCLUDE, "-I" + _lib.CSRC]
+cmd += [os.path.join(_lib.CSRC, s) for s in _lib.SOURCES] + ["-o", diag]
+subprocess.check_call(cmd)
+_lib.LIB_PATH = diag
+from m2h import ops  # noqa: E402
+
+lib = _lib.load()
+lib.m2h_diag_read_clocks_dma.argtypes = [ctypes.c_void_p, ctypes.c_int]
+dev = torch.device("cuda", 0)
+knobs = [int(v) for v in sys.argv[1:]] or [0]
+ops.set_math_mode(ops.MATH_BF16X3)
+fmt = ops.FMT_SRC_SPLIT | ops.FMT_W_SPLIT | ops.FMT_DST_SPLIT
+for (B, H, W, Ci, Co, label) in [(256, 8, 64, 128, 256, "down2 K=2048 N=256"), (256, 16, 128, 64, 128, "down1 K=1024 N=128")]:
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = ops.split32(torch.randn(B, H, W, Ci, device=dev, generator=g))
+    wp = ops.split32(torch.randn(Co, 16 * Ci, device=dev, generator=g) * 0.05)
+    sc = torch.ones(Co, device=dev)
+    sh = torch.zeros(Co, device=dev)
+    nk = 16 * Ci // 32
+    for kv in knobs:
+        ops.debug_set(27, kv)
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < 2.0:
+            for _ in range(50):
+                ops.conv2d_nhwc(x, wp, Co, 4, 4, stride=2, pad=1, bias=sh, scale=sc, slope=0.2, operand_format=fmt)
+            torch.cuda.synchronize()
+            n += 50
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.conv2d_nhwc(x, wp, Co, 4, 4, stride=2, pad=1, bias=sh, scale=sc, slope=0.2, operand_format=fmt)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        nb = 2048
+        buf = np.zeros((nb, 2), np.uint64)
+        lib.m2h_diag_read_clocks_dma(buf.ctypes.data, nb)
+        b = buf[buf[:, 1] > 0]
+        clk = b[:, 0].astype(np.float64) / b[:, 1].astype(np.float64) * 0.1
+        print("%s knob27=%d: %.1f us/launch, %d blocks stamped; in-kernel clock median %.3f GHz (min %.3f max %.3f); k-loop cycles median %.0f = %.0f per k-tile"
+              % (label, kv, us, len(b), np.median(clk), clk.min(), clk.max(), np.median(b[:, 0]), np.median(b[:, 0]) / nk))
+    ops.debug_set(27, 0)
