@@ -25,6 +25,9 @@
 
 namespace m2h {
 
+int g_dma64 = 0;      // m2h_debug_set 29: 1 = 64-wide plain convs on this engine too (256 x 64 tile).  Off: the first encoder stage
+                      // has only 16 k-tiles per tile, each a new tap (row offsets recomputed every tile), and one block per CU
+                      // does not hide its ring fill / epilogue: 251 vs 218 us (pair_ab --layers, B = 256)
 int g_dma_shape = 0;   // m2h_debug_set 28: 32 = v_mfma_f32_32x32x16_bf16 fragments instead of 16x16x32
 int g_dma = 0;   // m2h_debug_set 27: -1 never use this engine; 1 = 128x128 tiles only, 2 = 256x128 only (tuning)
 
@@ -32,7 +35,7 @@ __device__ __attribute__((aligned(128))) float g_zero_page[2048 + 32];   // 8 Ki
 
 #ifdef M2H_CLOCK_DIAG
 // Diagnostic build only (tools/clock_diag_dma.py): shader-clock vs 100 MHz real-time stamps around the k-loop of each block.
-__device__ unsigned long long g_clock_dbg_dma[8192][2];
+__device__ unsigned long long g_clock_dbg_dma[8192][8];   // [0] k-loop shader clocks, [1] k-loop real time, [2..6] real-time milestones
 #endif
 
 namespace {
@@ -108,6 +111,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
   const int nt = idx - (idx / p.NT) * p.NT;
   if (mt >= p.MT) return;
   const int m0 = mt * BM, n0 = nt * BN;
+#ifdef M2H_CLOCK_DIAG
+  const unsigned long long dbg_s0 = __builtin_amdgcn_s_memrealtime();
+#endif
   int mulh = p.mulh, offh = p.offh, mulw = p.mulw, offw = p.offw, ph = p.ph, pw = p.pw;
   const float* wbase = p.w;
   if (p.convT) {
@@ -266,12 +272,12 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
 #pragma unroll
   for (int d = 0; d < NST; ++d)
     if (d < nk) issue_tile();
-#ifdef M2H_CLOCK_DIAG
-  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
   if (nk >= 3) wait_and_barrier(Y2{});   // tile 0 has landed
   else if (nk == 2) wait_and_barrier(Y1{});
   else wait_and_barrier(Y0{});
+#ifdef M2H_CLOCK_DIAG
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   int cs = 0;   // stage of tile t
   if constexpr (FR == 32) {
     // fragments of one k-step (16 of the tile's 32 channels): hi and lo halves of FM pixel and FN channel fragments
@@ -414,6 +420,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
   if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 8192) {
     g_clock_dbg_dma[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - dbg_t0;
     g_clock_dbg_dma[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+    g_clock_dbg_dma[blockIdx.x][2] = dbg_s0;
+    g_clock_dbg_dma[blockIdx.x][3] = dbg_r0;
+    g_clock_dbg_dma[blockIdx.x][4] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
   const auto row_of = [&](int e) { return FR == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : (lane >> 4) * 4 + e; };
@@ -436,7 +445,10 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
     return;
   }
   __syncthreads();   // row bookkeeping visible (already ordered by the k-loop's barriers when nk >= 1; kept for nk == 0)
-  fused_epilogue<BM, BN, WM, WN, FR, AccT>(p, acc, reinterpret_cast<float*>(smem), reinterpret_cast<float*>(smem) + BM * LDK, ri_out, ri_bc, n0, tid);
+  fused_epilogue<BM, BN, WM, WN, FR, AccT, NST * ST_BYTES>(p, acc, reinterpret_cast<float*>(smem), reinterpret_cast<float*>(smem) + BM * LDK, ri_out, ri_bc, n0, tid);
+#ifdef M2H_CLOCK_DIAG
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 8192) g_clock_dbg_dma[blockIdx.x][5] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, int NST, int FR>
@@ -466,11 +478,18 @@ static int launch_dma_cfg(IGemmP& p, int S, hipStream_t st) {
 int launch_igemm_dma(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   if (g_dma < 0 || p.math != 1 || !p.presplit || !p.fast_ok || p.head_w != nullptr || p.N % 64 != 0 || p.Kw % BK != 0) return -2;
   if ((size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 > 8192) return -2;   // zero page covers one pixel's channels
-  if (p.N % 128 != 0) return -2;   // 64-wide layers: register engine / tap-sharing kernel for now
   if (p.M <= 64) return -2;        // skinny M: the 32- / 64-row weight-streaming tiles of the register engine
+  const int phases = p.convT ? 4 : 1;
+  if (p.N == 64) {                 // the 64-wide first encoder stage (a transposed 64-wide stage takes the tap-sharing kernel first)
+    const long t = (((long)p.M + 255) / 256) * phases;
+    if (g_dma == 1 || (g_dma != 2 && (g_dma64 <= 0 || t < 224))) return -2;   // off by default: measured slower (see g_dma64)
+    return g_dma_shape == 32 ? launch_dma_cfg<256, 64, 4, 2, 3, 32>(p, 1, st) : launch_dma_cfg<256, 64, 4, 2, 3, 16>(p, 1, st);
+  }
+  if (p.N % 128 != 0) return -2;
   // tile and split-K factor: the register engine's own rules (conv_igemm_f32), so that the two engines agree bit for bit
-  const long t256 = (((long)p.M + 255) / 256) * (p.N / 128) * (p.convT ? 4 : 1);
-  if (g_dma != 1 && g_big_tile >= 0 && (g_dma == 2 || t256 >= (g_big_tile > 0 ? g_big_tile : 224))) return g_dma_shape == 32 ? launch_dma_cfg<256, 128, 4, 2, 3, 32>(p, 1, st) : launch_dma_cfg<256, 128, 4, 2, 3, 16>(p, 1, st);
+  const long t256 = (((long)p.M + 255) / 256) * (p.N / 128) * phases;
+  if (g_dma != 1 && g_big_tile >= 0 && (g_dma == 2 || t256 >= (g_big_tile > 0 ? g_big_tile : 224)))
+    return g_dma_shape == 32 ? launch_dma_cfg<256, 128, 4, 2, 3, 32>(p, 1, st) : launch_dma_cfg<256, 128, 4, 2, 3, 16>(p, 1, st);
   // fewer tiles: the 128 x 128 tile at two blocks per CU of the register engine is faster than this engine's one block per CU
   // (pair_ab --layers, B = 256: down3 125 vs 147 us, down4 47 vs 53, up0 52 vs 59); m2h_debug_set 27 = 1 forces it here
   if (g_dma != 1) return -2;
@@ -480,7 +499,7 @@ int launch_igemm_dma(IGemmP& p, size_t ws_bytes, hipStream_t st) {
 
 #ifdef M2H_CLOCK_DIAG
 extern "C" int m2h_diag_read_clocks_dma(unsigned long long* host_out, int nblocks) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock_dbg_dma), (size_t)nblocks * 2 * sizeof(unsigned long long));
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock_dbg_dma), (size_t)nblocks * 8 * sizeof(unsigned long long));
 }
 #endif
 

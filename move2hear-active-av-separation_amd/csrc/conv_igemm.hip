@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64 * WM * WN, (SPLIT && WM * WN == 4) ? 2 : 1) void
   }
 
   // ---- fused epilogue ----
-  fused_epilogue<BM, BN, WM, WN, FR, AccT>(p, acc, &As[0][0], &Bs[0][0], ri_out, ri_bc, n0, tid);
+  fused_epilogue<BM, BN, WM, WN, FR, AccT, NSTAGE * BM * LDK * 4>(p, acc, &As[0][0], &Bs[0][0], ri_out, ri_bc, n0, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(64 * WM, WM == 4 ? 2 : 1) void convT_tap_kernel(con
   compute_chunk();
   __syncthreads();     // the staged image becomes the epilogue's scratch
 
-  fused_epilogue<BM, BN, WM, WN, FR, AccT>(p, acc, As, Bs, ri_out, ri_bc, 0, tid);
+  fused_epilogue<BM, BN, WM, WN, FR, AccT, PMAX * LDK * 4>(p, acc, As, Bs, ri_out, ri_bc, 0, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1257,8 +1257,13 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
 
   p.ws = static_cast<float*>(a.workspace);
   const size_t wsb = a.workspace != nullptr ? a.workspace_bytes : 0;
+  // narrow transposed convs on split32 operands: all four phases from one staged patch (convt_quad.hip)
+  if (p.convT && p.presplit && g_force_splitk <= 0 && g_phase_major >= 0) {
+    const int rc = launch_convT_quad(p, st);
+    if (rc != -2) return rc;
+  }
   // narrow transposed convs in bf16x3 math: the four taps of a phase share one staged input image (convT_tap_kernel)
-  if (p.convT && p.math == 1 && g_tapshare >= 0 && p.fast_ok && p.N <= 64 && a.Wq >= 32 && 128 % a.Wq == 0 &&
+  if (p.convT && p.math == 1 && g_tapshare >= 0 && p.fast_ok && p.N <= (g_tapshare == 2 ? 32 : 64) && a.Wq >= 32 && 128 % a.Wq == 0 &&
       a.Hq % (128 / a.Wq) == 0 && g_force_splitk <= 0 && g_phase_major >= 0 && M >= 128L * 256) {
     // 256-output tiles when the image geometry and the block count allow (bytes per output: see the kernel)
     // eight-wave blocks (one per CU): 256-output tiles for N = 64 by default (pair_ab, headline pair: 3.392 -> 3.364 ms); the

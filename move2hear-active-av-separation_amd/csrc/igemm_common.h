@@ -69,10 +69,93 @@ __device__ __forceinline__ void decode_row(const IGemmP& p, int m, int ph, int p
   bc = b * 16 + ch * 3 + cw;
 }
 
+// Coalesced store of an activated NHWC tile (fp32 rows, or the split32 layout with dst_split): the accumulator layout of the MFMAs gives every
+// lane single 4-byte words scattered over rows (32-byte runs per row and store instruction), which cost 14-15 us per 256 x 128
+// tile (in-kernel stamps, tools/clock_diag_dma.py) -- a quarter of a short-K layer.  Here the tile goes through LDS: each lane
+// writes its words into a [rows][BN * 4 + 16 bytes] image (RPASS rows per pass, as many as the scratch holds), then the block
+// copies whole rows out with 16 bytes per lane: full 128-byte lines, 4 x fewer store instructions.  Values are those of the
+// element-wise path bit for bit.  scratch: SCRATCH bytes of LDS the main loop no longer needs.
+template <int BM, int BN, int WM, int WN, int FR, int SCRATCH, typename AccT>
+__device__ __forceinline__ void nhwc_tile_store(const IGemmP& p, AccT (&acc)[BM / WM / FR][BN / WN / FR], char* scratch, const int* ri_out,
+                                                   const int* ri_bc, int n0, int tid) {
+  constexpr int NTH = 64 * WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int FM = TM / FR, FN = TN / FR;
+  constexpr int NE = FR == 32 ? 16 : 4;
+  constexpr int RP = BN * 4 + 16;                     // row pitch (bytes): 16-byte aligned for the b128 copy-out reads
+  constexpr int RMAX = SCRATCH / RP;
+  constexpr int RPASS = RMAX >= BM ? BM : (RMAX >= BM / 2 ? BM / 2 : (RMAX >= BM / 4 ? BM / 4 : BM / 8));
+  constexpr int NPASS = BM / RPASS;
+  constexpr int PIECES = BN / 4;                      // 16-byte pieces per row
+  static_assert(RPASS * RP <= SCRATCH && RPASS % 32 == 0 && BN % 32 == 0, "scratch too small for the tile store");
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int col = lane & (FR - 1);
+  auto row_of = [&](int e) { return FR == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : (lane >> 4) * 4 + e; };
+  float sc[FN], sh[FN];
+  int nn[FN], woff[FN];
+#pragma unroll
+  for (int ni = 0; ni < FN; ++ni) {
+    const int nl = wn * TN + ni * FR + col;           // column inside the tile
+    const int n = n0 + nl;
+    nn[ni] = n;
+    sc[ni] = (p.scale != nullptr && n < p.N) ? p.scale[n] : 1.f;
+    sh[ni] = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
+    woff[ni] = (nl & ~31) * 4 + ((nl & 1) ? 64 : 0) + ((nl & 31) >> 1) * 4;   // this lane's word: even n the hi pair, odd n the lo pair
+  }
+  __syncthreads();   // every wave is done with the main loop's LDS
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+    for (int mi = 0; mi < FM; ++mi) {
+      if ((wm * TM + mi * FR) / RPASS != pass) continue;   // wave-uniform: a fragment's rows lie in one pass (RPASS % 32 == 0)
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int lrow = wm * TM + mi * FR + row_of(e);
+        float cv = 0.f;
+        const float* ctab = nullptr;
+        if (p.cls_table != nullptr) {
+          const int bc = ri_bc[lrow];
+          cv = p.cls_val[bc >> 4];
+          ctab = p.cls_table + (size_t)(bc & 15) * p.N;
+        }
+        char* rowp = scratch + (lrow - pass * RPASS) * RP;
+#pragma unroll
+        for (int ni = 0; ni < FN; ++ni) {
+          const int n = nn[ni];
+          float v = acc[mi][ni][e];
+          if (ctab != nullptr && n < p.N) v += cv * ctab[n];
+          v = v * sc[ni] + sh[ni];
+          v = v > 0.f ? v : v * p.slope;
+          if (!p.dst_split) {   // plain fp32 rows
+            *reinterpret_cast<float*>(rowp + (wn * TN + ni * FR + col) * 4) = v;
+            continue;
+          }
+          const __bf16 hb = (__bf16)v;
+          const __bf16 lb = (__bf16)(v - (float)hb);
+          const unsigned h16 = __builtin_bit_cast(unsigned short, hb), l16 = __builtin_bit_cast(unsigned short, lb);
+          // the neighbour lane's (n ^ 1) halves by a DPP quad permute [1,0,3,2]: no LDS round trip (__shfl_xor is a ds_bpermute)
+          const unsigned both = h16 | (l16 << 16);
+          const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)both, 0xB1, 0xF, 0xF, true);
+          *reinterpret_cast<unsigned*>(rowp + woff[ni]) = (n & 1) ? ((other >> 16) | (l16 << 16)) : (h16 | (other << 16));
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < RPASS * PIECES; idx += NTH) {
+      const int r = idx / PIECES, pc = idx - r * PIECES;
+      const int out = ri_out[pass * RPASS + r];
+      if (out >= 0 && n0 + pc * 4 < p.N)   // N % 4 == 0: a piece is inside the row or outside it
+        *reinterpret_cast<f32x4*>(p.dst + (size_t)out * p.ldc + n0 + pc * 4) = *reinterpret_cast<const f32x4*>(scratch + r * RP + pc * 16);
+    }
+    if (pass + 1 < NPASS) __syncthreads();
+  }
+}
+
 // Fused epilogue shared by the LDS-staged kernel and the tap-sharing transposed-conv kernel: class-plane bias, BN scale/shift
 // or bias, LeakyReLU/ReLU and the NHWC / de-sliced store; with head_w, the last decoder stage's 1x1 head on the on-chip tile.
 // As0 / Bs0: LDS scratch of at least BM*LDK and max(BN,32)*LDK floats (the main loop's tiles, free by now).
-template <int BM, int BN, int WM, int WN, int FR, typename AccT>
+template <int BM, int BN, int WM, int WN, int FR, typename AccT, int SCRATCH = 0>   // SCRATCH: bytes of LDS at As0 (0: unknown)
 __device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM / WM / FR][BN / WN / FR], float* As0, float* Bs0,
                                                const int* ri_out, const int* ri_bc, int n0, int tid) {
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -167,6 +250,12 @@ __device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM /
       return;
     }
   }
+  if constexpr (SCRATCH >= 32 * (BN * 4 + 16) && BN % 32 == 0 && BM % 32 == 0) {
+    if (p.out_mode == M2H_OUT_NHWC && p.N % 4 == 0 && p.ldc % 4 == 0 && (reinterpret_cast<size_t>(p.dst) & 15) == 0) {   // NHWC tile: whole rows through LDS
+      nhwc_tile_store<BM, BN, WM, WN, FR, SCRATCH, AccT>(p, acc, reinterpret_cast<char*>(As0), ri_out, ri_bc, n0, tid);
+      return;
+    }
+  }
   float sc[FN], sh[FN];
   int nn[FN];
 #pragma unroll
@@ -228,5 +317,8 @@ extern int g_big_tile;
 
 // conv_dma.hip: LDS-DMA engine; returns -2 when the launch is not one of its shapes (the caller falls through), 0 / error otherwise
 int launch_igemm_dma(IGemmP& p, size_t ws_bytes, hipStream_t st);
+
+// convt_quad.hip: four-phase transposed-conv kernel (split32 operands, N <= 64); -2 when the launch is not one of its shapes
+int launch_convT_quad(IGemmP& p, hipStream_t st);
 
 }  // namespace m2h

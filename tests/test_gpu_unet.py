@@ -260,10 +260,11 @@ def test_dma_engine_matches_register_engine(B, tm):
     mixed, tc = synthetic.make_passive_inputs(B, tm, 70 + B)
     obs = {"mixed_bin_audio_mag": torch.from_numpy(mixed).to(dev), "target_class": torch.from_numpy(tc).to(dev)}
 
-    def run(dma, shape, splitk=0):
+    def run(dma, shape, splitk=0, quad=-1):
         ops.debug_set(27, dma)
         ops.debug_set(28, shape)
         ops.debug_set(0, splitk)
+        ops.debug_set(30, quad)
         try:
             with torch.no_grad():
                 m = pol.get_binSepMasks(obs)
@@ -272,6 +273,7 @@ def test_dma_engine_matches_register_engine(B, tm):
             ops.debug_set(27, 0)
             ops.debug_set(28, 0)
             ops.debug_set(0, 0)
+            ops.debug_set(30, 0)
 
     ops.set_math_mode(ops.MATH_BF16X3)
     try:
@@ -285,6 +287,14 @@ def test_dma_engine_matches_register_engine(B, tm):
             assert not torch.equal(got[0], ref[0])     # the engine really ran (another summation order)
             again = run(tile, 0, sk)
             assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1])
+        # the four-phase transposed-conv kernel (csrc/convt_quad.hip) on every decoder stage it takes (m2h_debug_set 30 = 1: also below
+        # its block-count threshold), the other layers on the register engine: its sums run (chunk, half, tap) instead of (chunk, tap, half)
+        ref = run(-1, 0)
+        quad = run(-1, 0, 0, 1)
+        assert O.rel_l1(quad[0].cpu(), ref[0].cpu()) < 1e-5 and O.rel_l1(quad[1].cpu(), ref[1].cpu()) < 1e-5
+        assert torch.equal(quad[0], ref[0]) == (tm < 64)     # its stages are at least 32 pixels wide: tm >= 64
+        quad2 = run(-1, 0, 0, 1)
+        assert torch.equal(quad2[0], quad[0]) and torch.equal(quad2[1], quad[1])
     finally:
         ops.set_math_mode(ops.MATH_FP32)
 

@@ -52,10 +52,13 @@ for (B, H, W, Ci, Co, label) in [(256, 8, 64, 128, 256, "down2 K=2048 N=256"), (
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
         nb = 2048
-        buf = np.zeros((nb, 2), np.uint64)
+        buf = np.zeros((nb, 8), np.uint64)
         lib.m2h_diag_read_clocks_dma(buf.ctypes.data, nb)
         b = buf[buf[:, 1] > 0]
         clk = b[:, 0].astype(np.float64) / b[:, 1].astype(np.float64) * 0.1
         print("%s knob27=%d: %.1f us/launch, %d blocks stamped; in-kernel clock median %.3f GHz (min %.3f max %.3f); k-loop cycles median %.0f = %.0f per k-tile"
               % (label, kv, us, len(b), np.median(clk), clk.min(), clk.max(), np.median(b[:, 0]), np.median(b[:, 0]) / nk))
+        f = b.astype(np.float64)
+        print("    per workgroup (us, median): setup + ring fill %.2f, k-loop %.2f, epilogue %.2f; first start -> last end %.1f"
+              % (np.median(f[:, 3] - f[:, 2]) / 100, np.median(f[:, 4] - f[:, 3]) / 100, np.median(f[:, 5] - f[:, 4]) / 100, (f[:, 5].max() - f[:, 2].min()) / 100))
     ops.debug_set(27, 0)
