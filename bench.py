@@ -332,7 +332,7 @@ def main():
 
     from m2h.rl.models.separator_cnn import unet_forward, UNET_KERNEL_NAMES
 
-    def unet_kernel_meta(n_out, with_masks, with_class):
+    def unet_kernel_meta(n_out, with_masks, with_class, mode):
         """(name, instantiation, M, N, K, algorithmic flops, algorithmic bytes) of the 11 kernels of one U-Net at this batch."""
         B, T = args.batch, args.tm
         metas = [("sep_slice_input", "sep_slice_input", None, None, None, 0.0, (3 if with_masks else 2) * B * 512 * T * 2 * 4.0)]
@@ -342,7 +342,7 @@ def main():
             M, N, K = B * (H // 2) * (W // 2), enc[i + 1], 16 * enc[i]
             fl = 2.0 * M * N * 16 * (enc[i] + (1 if (i == 0 and with_class) else 0))
             by = 4.0 * (B * H * W * enc[i] + M * N + N * K)
-            metas.append(("unet_down_fwd", ops.igemm_config(N), M, N, K, fl, by))
+            metas.append(("unet_down_fwd", ops.unet_kernel_name(M, N, False, True) if mode == "bf16x3" else ops.igemm_config(N), M, N, K, fl, by))
             H //= 2
             W //= 2
         c0, c1, co = [512, 512, 256, 128, 64], [0, 512, 256, 128, 64], [512, 256, 128, 64, n_out]
@@ -351,12 +351,14 @@ def main():
             fl = 2.0 * M * N * (K + (N if i == 4 else 0))                    # last stage carries the 1x1 head
             outel = M * N if i < 4 else B * 512 * T * (n_out // 16)
             by = 4.0 * (B * H * W * (c0[i] + c1[i]) + outel + 4 * N * K)
-            metas.append(("unet_up_fwd" if i < 4 else "unet_up_head_fwd", ops.igemm_config(N), M, N, K, fl, by))
+            metas.append(("unet_up_fwd" if i < 4 else "unet_up_head_fwd",
+                          ops.unet_kernel_name(M, N, True, True) if mode == "bf16x3" else ops.igemm_config(N), M, N, K, fl, by))
             H *= 2
             W *= 2
         return metas
 
-    META = {"binSep": unet_kernel_meta(32, False, True), "bin2mono": unet_kernel_meta(16, True, False)}
+    META = {m: {"binSep": unet_kernel_meta(32, False, True, m), "bin2mono": unet_kernel_meta(16, True, False, m)} for m in ("bf16x3", "fp32")}
+    current_mode = [args.math]
 
     def step_events(sink):
         """the same pair through the same one-call runner, which records an event around each of its 11 kernels"""
@@ -372,7 +374,7 @@ def main():
             enc, dec = pol.bin2mono_enc.passive_sep_encoder, pol.bin2mono_dec.passive_sep_decoder
             mono = unet_forward(enc, dec, mix, masks, events=evs[1])
         for which, ev in zip(("binSep", "bin2mono"), evs):
-            for i, (name, inst, M, N, K, fl, by) in enumerate(META[which]):
+            for i, (name, inst, M, N, K, fl, by) in enumerate(META[current_mode[0]][which]):
                 sink.append((name, {"kernel": inst, "M": M, "N": N, "K": K, "flops": fl, "bytes": by}, ev[i], ev[i + 1]))
         return masks, mono
 
@@ -381,6 +383,7 @@ def main():
     def timed_run(mode, steps, warmup, with_events):
         """W untimed + K timed steps of the pair in the given math mode -> (elapsed s, HIP-event sink or None)."""
         ops.set_math_mode(ops.MATH_BF16X3 if mode == "bf16x3" else ops.MATH_FP32)
+        current_mode[0] = mode
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
@@ -436,8 +439,11 @@ def main():
         if mode == "bf16x3":
             # every algorithmic product is three bf16 MFMA products: the ceiling of this formulation is a third of the bf16 peak
             peak = PEAK_BF16 / 3.0
-            kern = ("m2h::igemm_f32_kernel<..., SPLIT=1> (all instantiations): fp32 operands split to bf16 hi+lo on the way into LDS, "
-                    "hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16, fp32 accumulate")
+            kern = ("the implicit-GEMM conv kernels of csrc/ in bf16x3 math on split32 operands (fp32 values as bf16 hi + lo pairs; "
+                    "hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, fp32 accumulate): m2h::igemm_dma_kernel<256,128> "
+                    "(LDS-DMA engine: the wide stages), m2h::igemm_f32_kernel<..., SPLIT=2> (register-staged engine) and "
+                    "m2h::convT_tap_kernel (narrow transposed stages); `achieved` is over all of them, `dominant_instantiation` the "
+                    "one with the largest share of the step")
         else:
             peak = PEAK_F32_MFMA_TFLOPS
             kern = "m2h::igemm_f32_kernel (all instantiations; MFMA f32 32x32x2 / 16x16x4 implicit-GEMM conv)"
