@@ -25,6 +25,7 @@
 
 namespace m2h {
 
+int g_dma_korder = 0;   // m2h_debug_set 31: 1 = the register engine's (tap, chunk) k-tile order (bit-identical sums with 32x32x16 fragments)
 int g_dma64 = 0;      // m2h_debug_set 29: 1 = 64-wide plain convs on this engine too (256 x 64 tile).  Off: the first encoder stage
                       // has only 16 k-tiles per tile, each a new tap (row offsets recomputed every tile), and one block per CU
                       // does not hide its ring fill / epilogue: 251 vs 218 us (pair_ab --layers, B = 256)
@@ -169,8 +170,30 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
   const int kt0 = (int)(((long)nk_all * split) / p.S);
   const int kt1 = (int)(((long)nk_all * (split + 1)) / p.S);
   const int nk = kt1 - kt0;
+  // Order of the k-tiles (p.korder; any order gives the same sums up to fp32 association):
+  //   0  (tap, chunk)                 the register engine's order;
+  //   1  (chunk, tap)                 the taps of one 32-channel chunk in consecutive tiles;
+  //   2  (class, chunk, tap in class) 4x4 / stride-2 conv: the four taps (th, tw) of one parity class (th & 1, tw & 1) read the
+  //                                   SAME input pixels (as neighbouring output positions), so they run in consecutive tiles.
+  // In 1 and 2 every re-read of an input line follows its first read within a few tiles, while the line is still in the XCD's
+  // L2; in the (tap, chunk) order the re-reads are C/32 .. 8 C/32 tiles apart and come back from beyond L2 (PMC: 2 x FETCH_SIZE
+  // + WRITE_SIZE = 1.9 x the algorithmic bytes per launch).
+  const int nch = p.Ctot / BK, ntw_w = p.thn * p.twn;
+  const int J = p.korder == 0 ? 1 : (p.korder == 1 ? ntw_w : 4);
+  int w_a, w_c, w_j;     // outer index (tap / 0 / class), chunk, inner tap index
   int u_th, u_tw, u_ci;
-  auto segment_rows = [&]() {
+  auto decode_walk = [&]() {
+    u_ci = w_c * BK;
+    if (p.korder == 0) {
+      u_th = p.th0 + w_a / p.twn;
+      u_tw = p.tw0 + w_a % p.twn;
+    } else if (p.korder == 1) {
+      u_th = p.th0 + w_j / p.twn;
+      u_tw = p.tw0 + w_j % p.twn;
+    } else {
+      u_th = (w_a >> 1) + 2 * (w_j >> 1);
+      u_tw = (w_a & 1) + 2 * (w_j & 1);
+    }
     const int dh = u_th * mulh, dw = u_tw * mulw;
     const bool second = u_ci >= p.C0 && p.src1 != nullptr;
     const int Cs = second ? p.C1 : p.C0;
@@ -184,12 +207,11 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
     }
   };
   {
-    const int k0 = kt0 * BK;
-    const int tap = p.ntap > 1 ? k0 / p.Ctot : 0;
-    u_ci = k0 - tap * p.Ctot;
-    u_th = p.th0 + tap / p.twn;
-    u_tw = p.tw0 + tap % p.twn;
-    segment_rows();
+    w_j = kt0 % J;
+    const int t = kt0 / J;
+    w_c = t % nch;
+    w_a = t / nch;
+    decode_walk();
   }
   int issued = 0;   // tiles issued so far (the next one goes to stage issued % NST)
   int istage = 0;
@@ -211,17 +233,14 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
     ++issued;
     istage = istage + 1 == NST ? 0 : istage + 1;
     // advance to the next tile
-    u_ci += BK;
-    bool reseg = u_ci == p.C0 && p.src1 != nullptr;
-    if (u_ci == p.Ctot) {
-      u_ci = 0;
-      reseg = true;
-      if (++u_tw == p.tw0 + p.twn) {
-        u_tw = p.tw0;
-        ++u_th;
+    if (++w_j == J) {
+      w_j = 0;
+      if (++w_c == nch) {
+        w_c = 0;
+        ++w_a;
       }
     }
-    if (reseg && issued < nk) segment_rows();   // wave-uniform branch
+    if (issued < nk) decode_walk();
   };
 
   AccT acc[FM][FN];
@@ -478,6 +497,7 @@ static int launch_dma_cfg(IGemmP& p, int S, hipStream_t st) {
 int launch_igemm_dma(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   if (g_dma < 0 || p.math != 1 || !p.presplit || !p.fast_ok || p.head_w != nullptr || p.N % 64 != 0 || p.Kw % BK != 0) return -2;
   if ((size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 > 8192) return -2;   // zero page covers one pixel's channels
+  p.korder = g_dma_korder == 1 ? 0 : ((!p.convT && p.stride == 2 && p.ntap == 16 && p.thn == 4 && p.twn == 4 && p.th0 == 0 && p.tw0 == 0) ? 2 : 1);
   if (p.M <= 64) return -2;        // skinny M: the 32- / 64-row weight-streaming tiles of the register engine
   const int phases = p.convT ? 4 : 1;
   if (p.N == 64) {                 // the 64-wide first encoder stage (a transposed 64-wide stage takes the tap-sharing kernel first)

@@ -36,6 +36,7 @@ struct IGemmP {
   int math;      // arithmetic of this launch: 0 fp32 MFMA, 1 bf16x3 split products (args' M2H_FMT_MATH_* or the calling thread's mode)
   int presplit;  // both operands arrive in the split32 layout
   int dst_split; // epilogue writes dst in the split32 layout (bf16x3 math, NHWC, N % 32 == 0)
+  int korder;  // LDS-DMA engine: order of the k-tiles (conv_dma.hip)
   int pmaj;    // transposed conv: phase is folded into grid x (fastest) instead of grid z
   // tap window of the scalar-decode loader: taps th0..th0+thn-1 x tw0..tw0+twn-1 are walked, the others lie in the zero
   // padding for EVERY output pixel of this launch (tiny images: a 2-row input under a 4x4/s2/p1 conv, a 1-row input under a
