@@ -146,10 +146,12 @@ size_t m2h_conv_igemm_workspace_bytes(const m2h_conv_args* args /* host */);
  * compute the same values; 0 = automatic everywhere): 0 force split-K factor (-1 never), 1 / 2 LDS
  * stages of the narrow / wide tiles, 3 skinny-M tiles (-1 off), 4 16-wide MFMA tile (-1 off), 7 extra dynamic LDS, 8 phase-major
  * transposed-conv order (-1 off), 9 scalar-decode loader (-1 off), 11 weight-gradient block target, 14 = m2h_set_math_mode (kept
- * for older callers; thread-local like it), 15 / 16 tap-sharing transposed-conv kernel (-1 off / tile), 18 tap window (-1 off), 21 / 22
+ * for older callers; thread-local like it), 15 / 16 tap-sharing transposed-conv kernel (-1 off, 2 = only for N <= 32 / tile: 128, 256, 512), 18 tap window (-1 off), 21 / 22
  * image-row 3x3 weight-gradient / conv kernels (-1 off), 23 skinny rows kernel for M <= 16 (-1 off), 24 skinny gather kernel (-1 off,
  * > 0 = pixel limit), 26 the 256 x 128 eight-wave tile of the bf16x3 arithmetic (-1 off, > 0 = minimum tile count), 27 the LDS-DMA engine for split32 operands
- * (csrc/conv_dma.hip; -1 off, 1 / 2 = its 128 x 128 / 256 x 128 tile only).  The launches that take a specialised kernel say which in the source (csrc/conv_igemm.hip, conv_bwd.hip);
+ * (csrc/conv_dma.hip; -1 off, 1 / 2 = its 128 x 128 / 256 x 128 tile only, below the tile-count threshold too), 28 = 32: 32x32x16 instead of
+ * 16x16x32 MFMA fragments there, 29 = 1: its 256 x 64 tile for 64-wide plain convs, 31 = 1: the register engine's (tap, chunk) k-tile order there,
+ * 30 = 1: the four-phase transposed-conv kernel (csrc/convt_quad.hip).  The launches that take a specialised kernel say which in the source (csrc/conv_igemm.hip, conv_bwd.hip);
  * retired experiment numbers are accepted and ignored. */
 int m2h_debug_set(int knob, int value);
 
