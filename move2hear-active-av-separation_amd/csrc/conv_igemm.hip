@@ -1359,6 +1359,10 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   // (PMC: ~8.5 TB/s of L2 reads with the matrix pipe 36 % and the LDS 39 % busy; one block per CU is only 7 % slower than two);
   // the larger tile reads 384 operand rows per 256 x 128 outputs instead of 512.  (A 256 x 64 tile for the 64-wide first encoder
   // stage measured slower: 252 vs 235 us.)
+  if (g_fast_loader >= 0 && g_force_splitk <= 0) {   // the first encoder stage on split32 operands: weights in registers (conv_bres.hip)
+    const int rc = launch_conv_bres(p, st);
+    if (rc != -2) return rc;
+  }
   if (g_fast_loader >= 0 && g_force_splitk <= 0) {   // split32 operands, wide N: the LDS-DMA engine (conv_dma.hip)
     const int rc = launch_igemm_dma(p, wsb, st);
     if (rc != -2) {

@@ -261,7 +261,8 @@ def test_dma_engine_matches_register_engine(B, tm):
     mixed, tc = synthetic.make_passive_inputs(B, tm, 70 + B)
     obs = {"mixed_bin_audio_mag": torch.from_numpy(mixed).to(dev), "target_class": torch.from_numpy(tc).to(dev)}
 
-    def run(dma, shape, splitk=0, quad=-1, korder=0):
+    def run(dma, shape, splitk=0, quad=-1, korder=0, bres=-1):
+        ops.debug_set(32, bres)
         ops.debug_set(31, korder)
         ops.debug_set(27, dma)
         ops.debug_set(28, shape)
@@ -277,6 +278,7 @@ def test_dma_engine_matches_register_engine(B, tm):
             ops.debug_set(0, 0)
             ops.debug_set(30, 0)
             ops.debug_set(31, 0)
+            ops.debug_set(32, 0)
 
     ops.set_math_mode(ops.MATH_BF16X3)
     try:
@@ -298,6 +300,13 @@ def test_dma_engine_matches_register_engine(B, tm):
         assert torch.equal(quad[0], ref[0]) == (tm < 64)     # its stages are at least 32 pixels wide: tm >= 64
         quad2 = run(-1, 0, 0, 1)
         assert torch.equal(quad2[0], quad[0]) and torch.equal(quad2[1], quad[1])
+        # the first encoder stage with its weights in registers (csrc/conv_bres.hip; m2h_debug_set 32 = 1: also below its tile-count
+        # threshold): persistent workgroups over runs of m-tiles, 16x16x32 fragments, taps in parity-class order
+        bres = run(-1, 0, 0, -1, 0, 1)
+        assert O.rel_l1(bres[0].cpu(), ref[0].cpu()) < 1e-5 and O.rel_l1(bres[1].cpu(), ref[1].cpu()) < 1e-5
+        assert not torch.equal(bres[0], ref[0])
+        bres2 = run(-1, 0, 0, -1, 0, 1)
+        assert torch.equal(bres2[0], bres[0]) and torch.equal(bres2[1], bres[1])
     finally:
         ops.set_math_mode(ops.MATH_FP32)
 
