@@ -25,7 +25,7 @@
 
 namespace m2h {
 
-int g_dma_korder = 0;   // m2h_debug_set 31: 1 = the register engine's (tap, chunk) k-tile order (bit-identical sums with 32x32x16 fragments)
+int g_dma_korder = 0;   // m2h_debug_set 31: 2 = the L2-friendly k-tile orders below instead of the register engine's (tap, chunk)
 int g_dma64 = 0;      // m2h_debug_set 29: 1 = 64-wide plain convs on this engine too (256 x 64 tile).  Off: the first encoder stage
                       // has only 16 k-tiles per tile, each a new tap (row offsets recomputed every tile), and one block per CU
                       // does not hide its ring fill / epilogue: 251 vs 218 us (pair_ab --layers, B = 256)
@@ -177,11 +177,28 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
   //                                   SAME input pixels (as neighbouring output positions), so they run in consecutive tiles.
   // In 1 and 2 every re-read of an input line follows its first read within a few tiles, while the line is still in the XCD's
   // L2; in the (tap, chunk) order the re-reads are C/32 .. 8 C/32 tiles apart and come back from beyond L2 (PMC: 2 x FETCH_SIZE
-  // + WRITE_SIZE = 1.9 x the algorithmic bytes per launch).
+  // + WRITE_SIZE = 1.9 x the algorithmic bytes per launch).  But orders 1 and 2 change the tap on EVERY tile, and the row
+  // pointers (bounds checks + 64-bit address per staged row) have to be rebuilt whenever the tap changes: measured on the
+  // benchmark step (pair_ab) order 0 = 3.125 ms, orders 1 / 2 = 3.218 ms; with the rebuild forced on every tile for both,
+  // 3.262 against 3.245 ms.  The locality is worth 0.5 %, the per-tile rebuild costs 3 %: order 0 is the default
+  // (m2h_debug_set 31 = 2 selects 1 / 2).
   const int nch = p.Ctot / BK, ntw_w = p.thn * p.twn;
   const int J = p.korder == 0 ? 1 : (p.korder == 1 ? ntw_w : 4);
   int w_a, w_c, w_j;     // outer index (tap / 0 / class), chunk, inner tap index
   int u_th, u_tw, u_ci;
+  auto rebuild_rows = [&]() {   // row pointers of the current (tap, source)
+    const bool second = u_ci >= p.C0 && p.src1 != nullptr;
+    const int dh = u_th * mulh, dw = u_tw * mulw;
+    const int Cs = second ? p.C1 : p.C0;
+    const char* base = reinterpret_cast<const char*>(second ? p.src1 : p.src0);
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+      const int ih = a_qh[i] + dh, iw = a_rw[i] + dw;
+      const bool ok = (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+      const size_t off = (size_t)(unsigned)(a_bpix[i] + ih * p.Wi + iw) * (unsigned)Cs * 4u;
+      ptrA[i] = ((ok && DBG != 3 && DBG != 6) ? base + off : zero) + pieceA[i];
+    }
+  };
   auto decode_walk = [&]() {
     u_ci = w_c * BK;
     if (p.korder == 0) {
@@ -194,17 +211,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
       u_th = (w_a >> 1) + 2 * (w_j >> 1);
       u_tw = (w_a & 1) + 2 * (w_j & 1);
     }
-    const int dh = u_th * mulh, dw = u_tw * mulw;
-    const bool second = u_ci >= p.C0 && p.src1 != nullptr;
-    const int Cs = second ? p.C1 : p.C0;
-    const char* base = reinterpret_cast<const char*>(second ? p.src1 : p.src0);
-#pragma unroll
-    for (int i = 0; i < AG; ++i) {
-      const int ih = a_qh[i] + dh, iw = a_rw[i] + dw;
-      const bool ok = (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-      const size_t off = (size_t)(unsigned)(a_bpix[i] + ih * p.Wi + iw) * (unsigned)Cs * 4u;
-      ptrA[i] = ((ok && DBG != 3 && DBG != 6) ? base + off : zero) + pieceA[i];
-    }
+    rebuild_rows();
   };
   {
     w_j = kt0 % J;
@@ -233,14 +240,28 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
     ++issued;
     istage = istage + 1 == NST ? 0 : istage + 1;
     // advance to the next tile
-    if (++w_j == J) {
-      w_j = 0;
-      if (++w_c == nch) {
-        w_c = 0;
-        ++w_a;
+    if (p.korder == 0) {   // (tap, chunk): increments only; the row pointers are rebuilt when the tap or the source changes
+      u_ci += BK;
+      bool reseg = u_ci == p.C0 && p.src1 != nullptr;
+      if (u_ci == p.Ctot) {
+        u_ci = 0;
+        reseg = true;
+        if (++u_tw == p.tw0 + p.twn) {
+          u_tw = p.tw0;
+          ++u_th;
+        }
       }
+      if (reseg && issued < nk) rebuild_rows();
+    } else {
+      if (++w_j == J) {
+        w_j = 0;
+        if (++w_c == nch) {
+          w_c = 0;
+          ++w_a;
+        }
+      }
+      if (issued < nk) decode_walk();
     }
-    if (issued < nk) decode_walk();
   };
 
   AccT acc[FM][FN];
@@ -497,7 +518,7 @@ static int launch_dma_cfg(IGemmP& p, int S, hipStream_t st) {
 int launch_igemm_dma(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   if (g_dma < 0 || p.math != 1 || !p.presplit || !p.fast_ok || p.head_w != nullptr || p.N % 64 != 0 || p.Kw % BK != 0) return -2;
   if ((size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 > 8192) return -2;   // zero page covers one pixel's channels
-  p.korder = g_dma_korder == 1 ? 0 : ((!p.convT && p.stride == 2 && p.ntap == 16 && p.thn == 4 && p.twn == 4 && p.th0 == 0 && p.tw0 == 0) ? 2 : 1);
+  p.korder = g_dma_korder != 2 ? 0 : ((!p.convT && p.stride == 2 && p.ntap == 16 && p.thn == 4 && p.twn == 4 && p.th0 == 0 && p.tw0 == 0) ? 2 : 1);
   if (p.M <= 64) return -2;        // skinny M: the 32- / 64-row weight-streaming tiles of the register engine
   const int phases = p.convT ? 4 : 1;
   if (p.N == 64) {                 // the 64-wide first encoder stage (a transposed 64-wide stage takes the tap-sharing kernel first)

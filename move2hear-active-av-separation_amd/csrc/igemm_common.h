@@ -116,15 +116,16 @@ __device__ __forceinline__ void nhwc_tile_store(const IGemmP& p, AccT (&acc)[BM 
     }
   }
   __syncthreads();   // every wave is done with the main loop's LDS
-#pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass) {
+  // one pass of element work; SPLIT (split32 words vs fp32 rows) and CLS (class plane) are compile-time so that the inner loop has no branch
+  auto fill = [&](int pass, auto split_c, auto cls_c) {
+    constexpr bool SPLIT = decltype(split_c)::value, CLS = decltype(cls_c)::value;
 #pragma unroll
     for (int mi = 0; mi < FM; ++mi) {
       if ((wm * TM + mi * FR) / RPASS != pass) continue;   // wave-uniform: a fragment's rows lie in one pass (RPASS % 32 == 0)
       // the rows' class values first, as one batch of loads (a load per row inside the element loop serialises LDS -> global -> use)
       float cvs[NE];
       int clss[NE];
-      if (p.cls_table != nullptr) {
+      if constexpr (CLS) {
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
           const int bc = ri_bc[wm * TM + mi * FR + row_of(e)];
@@ -135,44 +136,46 @@ __device__ __forceinline__ void nhwc_tile_store(const IGemmP& p, AccT (&acc)[BM 
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         const int lrow = wm * TM + mi * FR + row_of(e);
-        float cv = 0.f;
-        const float* ctab = nullptr;
-        int cls = 0;
-        if (p.cls_table != nullptr) {
-          cv = cvs[e];
-          cls = clss[e];
-          ctab = p.cls_table + (size_t)cls * p.N;
-        }
         char* rowp = scratch + (lrow - pass * RPASS) * RP;
 #pragma unroll
         for (int ni = 0; ni < FN; ++ni) {
           const int n = nn[ni];
           float v = acc[mi][ni][e];
-          if constexpr (FN <= 2) {
-            if (ctab != nullptr) {
+          if constexpr (CLS) {
+            if constexpr (FN <= 2) {
               float tv = ct[0][ni];
 #pragma unroll
-              for (int c = 1; c < 9; ++c) tv = cls == c ? ct[c][ni] : tv;
-              v += cv * tv;
+              for (int c = 1; c < 9; ++c) tv = clss[e] == c ? ct[c][ni] : tv;
+              v += cvs[e] * tv;
+            } else {
+              if (n < p.N) v += cvs[e] * p.cls_table[(size_t)clss[e] * p.N + n];
             }
-          } else {
-            if (ctab != nullptr && n < p.N) v += cv * ctab[n];
           }
           v = v * sc[ni] + sh[ni];
           v = v > 0.f ? v : v * p.slope;
-          if (!p.dst_split) {   // plain fp32 rows
+          if constexpr (!SPLIT) {   // plain fp32 rows
             *reinterpret_cast<float*>(rowp + (wn * TN + ni * FR + col) * 4) = v;
-            continue;
+          } else {
+            const __bf16 hb = (__bf16)v;
+            const __bf16 lb = (__bf16)(v - (float)hb);
+            const unsigned h16 = __builtin_bit_cast(unsigned short, hb), l16 = __builtin_bit_cast(unsigned short, lb);
+            // the neighbour lane's (n ^ 1) halves by a DPP quad permute [1,0,3,2]: no LDS round trip (__shfl_xor is a ds_bpermute)
+            const unsigned both = h16 | (l16 << 16);
+            const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)both, 0xB1, 0xF, 0xF, true);
+            *reinterpret_cast<unsigned*>(rowp + woff[ni]) = (n & 1) ? ((other >> 16) | (l16 << 16)) : (h16 | (other << 16));
           }
-          const __bf16 hb = (__bf16)v;
-          const __bf16 lb = (__bf16)(v - (float)hb);
-          const unsigned h16 = __builtin_bit_cast(unsigned short, hb), l16 = __builtin_bit_cast(unsigned short, lb);
-          // the neighbour lane's (n ^ 1) halves by a DPP quad permute [1,0,3,2]: no LDS round trip (__shfl_xor is a ds_bpermute)
-          const unsigned both = h16 | (l16 << 16);
-          const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)both, 0xB1, 0xF, 0xF, true);
-          *reinterpret_cast<unsigned*>(rowp + woff[ni]) = (n & 1) ? ((other >> 16) | (l16 << 16)) : (h16 | (other << 16));
         }
       }
+    }
+  };
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    if (p.dst_split) {
+      if (p.cls_table != nullptr) fill(pass, std::true_type{}, std::true_type{});
+      else fill(pass, std::true_type{}, std::false_type{});
+    } else {
+      if (p.cls_table != nullptr) fill(pass, std::false_type{}, std::true_type{});
+      else fill(pass, std::false_type{}, std::false_type{});
     }
     __syncthreads();
     for (int idx = tid; idx < RPASS * PIECES; idx += NTH) {

@@ -252,9 +252,9 @@ def test_dma_engine_matches_register_engine(B, tm):
     against the register-staged engine on the whole runner pair -- plain and transposed convs, the skip concat's second source,
     zero-padded borders, rows past M, the class plane, split32 output.  Forced on every wide layer (m2h_debug_set 27 = 2 / 1: its
     256 x 128 / 128 x 128 tile, the latter with split-K slabs) since the test batches are too small for the automatic choice.
-    With 32x32x16 fragments (knob 28 = 32) and the (tap, chunk) k-tile order (knob 31 = 1) the two engines run the same products in
-    the same order: bit-identical; with the default 16x16x32 fragments and the L2-friendly tile order the fp32 sums associate
-    differently: equal to summation order."""
+    With 32x32x16 fragments (knob 28 = 32) the two engines run the same products in the same order: bit-identical; with the
+    default 16x16x32 fragments, or the L2-friendly k-tile orders (knob 31 = 2), the fp32 sums associate differently: equal to
+    summation order."""
     from m2h import ops
     dev = _dev()
     pol, _ = _policy(3, dev)
@@ -285,7 +285,9 @@ def test_dma_engine_matches_register_engine(B, tm):
         for tile in (2, 1):
             sk = -1 if tile == 2 else 0     # the 256 x 128 tile never splits K: compare it with the register engine's unsplit sums
             ref = run(-1, 0, sk)
-            same = run(tile, 32, sk, korder=1)     # the register engine's k-tile order and MFMA shape
+            same = run(tile, 32, sk)               # the register engine's MFMA shape (and its k-tile order: the default)
+            other = run(tile, 32, sk, korder=2)    # the L2-friendly k-tile orders: the same products, summed in another order
+            assert O.rel_l1(other[0].cpu(), ref[0].cpu()) < 1e-5 and O.rel_l1(other[1].cpu(), ref[1].cpu()) < 1e-5
             assert torch.equal(same[0], ref[0]) and torch.equal(same[1], ref[1])
             got = run(tile, 0, sk)
             assert O.rel_l1(got[0].cpu(), ref[0].cpu()) < 1e-5 and O.rel_l1(got[1].cpu(), ref[1].cpu()) < 1e-5   # contract: 1e-3
