@@ -151,7 +151,7 @@ size_t m2h_conv_igemm_workspace_bytes(const m2h_conv_args* args /* host */);
  * > 0 = pixel limit), 26 the 256 x 128 eight-wave tile of the bf16x3 arithmetic (-1 off, > 0 = minimum tile count), 27 the LDS-DMA engine for split32 operands
  * (csrc/conv_dma.hip; -1 off, 1 / 2 = its 128 x 128 / 256 x 128 tile only, below the tile-count threshold too), 28 = 32: 32x32x16 instead of
  * 16x16x32 MFMA fragments there, 29 = 1: its 256 x 64 tile for 64-wide plain convs, 31 = 2: the L2-friendly (chunk, tap) / parity-class k-tile orders there (default: the register engine's (tap, chunk)),
- * 30 = 1: the four-phase transposed-conv kernel (csrc/convt_quad.hip), 32 = 1: the weights-in-registers first encoder stage (csrc/conv_bres.hip).  The launches that take a specialised kernel say which in the source (csrc/conv_igemm.hip, conv_bwd.hip);
+ * 30: the four-phase transposed-conv kernel (csrc/convt_quad.hip; -1 off, 1 = wherever its shape conditions hold), 32 = 1: the weights-in-registers first encoder stage (csrc/conv_bres.hip).  The launches that take a specialised kernel say which in the source (csrc/conv_igemm.hip, conv_bwd.hip);
  * retired experiment numbers are accepted and ignored. */
 int m2h_debug_set(int knob, int value);
 

@@ -16,13 +16,15 @@
 // 4 x (25 + 16) KB for the same outputs in the per-phase kernel at BN = 32.
 // Pipeline, waits and the bank-conflict-free row permutation follow conv_dma.hip (pieces of a 64-byte row r sit at
 // piece ^ ((r >> 2) & 3)); the epilogue is fused_epilogue (incl. the 1x1 head and the de-sliced store), run once per phase.
+// Measured (B = 256): N = 64 243 -> 224 us (two 32-wide n-tiles), N = 32 + head 334 -> 305 us, N = 16 + head (padded to 32
+// columns) 254 -> 290 us: used for N in (16, 64].
 // Requires: conv_transpose, split32 operands, C0 / C1 multiples of 32, 256 % Wq == 0, 32 <= Wq <= 128, Hq % (256 / Wq) == 0,
 // N <= 64.
 #include "igemm_common.h"
 
 namespace m2h {
 
-int g_quad = 0;   // m2h_debug_set 30: 1 = use this kernel where its shape conditions hold (off by default: see the measurements above)
+int g_quad = 0;   // m2h_debug_set 30: -1 never use this kernel; 1 = wherever its shape conditions hold (also N <= 16 and few output blocks)
 
 extern __device__ float g_zero_page_quad[];
 __device__ __attribute__((aligned(128))) float g_zero_page_quad[2048 + 32];
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(512, 1) void convT_quad_kernel(const IGemmP p) {
         ri_bc[r] = bc;
       }
       __syncthreads();
-      fused_epilogue<BM, BN, WM, WN, 32, AccT>(p, acc[ph], reinterpret_cast<float*>(s_patch), reinterpret_cast<float*>(s_patch) + BM * LDK + 64,
+      fused_epilogue<BM, BN, WM, WN, 32, AccT, NST * PATCH_BYTES>(p, acc[ph], reinterpret_cast<float*>(s_patch), reinterpret_cast<float*>(s_patch) + BM * LDK + 64,
                                                  ri_out, ri_bc, n0, tid);
       QSTAMP(4 + ph);
       self(self, std::integral_constant<int, ph + 1>{});
@@ -351,9 +353,13 @@ __global__ __launch_bounds__(512, 1) void convT_quad_kernel(const IGemmP p) {
 }
 
 int launch_convT_quad(IGemmP& p, hipStream_t st) {
-  if (g_quad <= 0 || !p.convT || p.math != 1 || !p.presplit || !p.fast_ok || p.N > 64) return -2;
+  if (g_quad < 0 || !p.convT || p.math != 1 || !p.presplit || !p.fast_ok || p.N > 64) return -2;
   if (p.Wq < 32 || p.Wq > 128 || 256 % p.Wq != 0 || p.Hq % (256 / p.Wq) != 0 || p.Ctot % 32 != 0 || p.M % 256 != 0) return -2;
   if (p.head_w != nullptr && p.N > 32) return -2;      // the fused head lives on the 32-wide tile
+  if (g_quad == 0) {
+    if (p.N <= 16) return -2;                                            // padded to 32 columns: 290 vs 254 us on the tap-sharing kernel
+    if ((long)p.M * ((p.N + 31) / 32) < 256L * 224) return -2;           // too few output blocks to fill the chip
+  }
   p.MT = p.M / 256;
   p.NT = (p.N + 31) / 32;   // 64 wide: two 32-wide n-tiles per output block (four phases x 64 x 32 accumulators per wave do not fit)
   p.S = 1;

@@ -40,6 +40,8 @@ def unet_kernel_name(M, N, transposed, split32):
     rows = M // phases
     if split32 and N % 128 == 0 and rows > 64 and ((rows + 255) // 256) * (N // 128) * phases >= 224:
         return "igemm_dma<256,128>"
+    if transposed and 16 < N <= 64 and split32 and (rows // 256) * ((N + 31) // 32) >= 224:
+        return "igemm_convT_quad<%d>" % (64 if N > 32 else 32)
     if transposed and N <= 64:
         return "igemm_convT_tap<%d>" % (64 if N > 32 else (32 if N > 16 else 16))
     return igemm_config(N)
