@@ -332,19 +332,24 @@ __global__ __launch_bounds__(512, 1) void convT_quad_kernel(const IGemmP p) {
 
   QSTAMP(3);
   // ---- epilogue: one pass of the fused epilogue per phase (row bookkeeping of that phase; the patch buffers are its scratch) ----
+  // row bookkeeping once per block (phase (0, 0)); phase (ph, pw) writes the pixel ph rows / pw columns further (decode_row's
+  // out = ... + (2 q + ph) Wo + 2 r + pw in both output layouts; the border class is not used by transposed stages)
+  int ri_base[1];
+  __syncthreads();
+  if (tid < BM) {
+    int q, rr, b, out, bc;
+    decode_row(p, m0 + tid, 0, 0, q, rr, b, out, bc);
+    ri_base[0] = out;
+    ri_bc[tid] = bc;
+  }
   auto phase_out = [&](auto self, auto phc) -> void {
     constexpr int ph = decltype(phc)::value;
     if constexpr (ph < 4) {
-      __syncthreads();
-      for (int r = tid; r < BM; r += 512) {
-        int q, rr, b, out, bc;
-        decode_row(p, m0 + r, ph >> 1, ph & 1, q, rr, b, out, bc);
-        ri_out[r] = out;
-        ri_bc[r] = bc;
-      }
+      if constexpr (ph > 0) __syncthreads();     // the previous phase is done with the row table
+      if (tid < BM) ri_out[tid] = ri_base[0] + (ph >> 1) * p.Wo + (ph & 1);
       __syncthreads();
       fused_epilogue<BM, BN, WM, WN, 32, AccT, NST * PATCH_BYTES>(p, acc[ph], reinterpret_cast<float*>(s_patch), reinterpret_cast<float*>(s_patch) + BM * LDK + 64,
-                                                 ri_out, ri_bc, n0, tid);
+                                                 ri_out, ri_bc, n0, tid, ph == 0);
       QSTAMP(4 + ph);
       self(self, std::integral_constant<int, ph + 1>{});
     }

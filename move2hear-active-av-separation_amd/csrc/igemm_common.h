@@ -193,7 +193,8 @@ __device__ __forceinline__ void nhwc_tile_store(const IGemmP& p, AccT (&acc)[BM 
 // As0 / Bs0: LDS scratch of at least BM*LDK and max(BN,32)*LDK floats (the main loop's tiles, free by now).
 template <int BM, int BN, int WM, int WN, int FR, typename AccT, int SCRATCH = 0>   // SCRATCH: bytes of LDS at As0 (0: unknown)
 __device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM / WM / FR][BN / WN / FR], float* As0, float* Bs0,
-                                               const int* ri_out, const int* ri_bc, int n0, int tid) {
+                                               const int* ri_out, const int* ri_bc, int n0, int tid, bool stage_head = true) {
+  // stage_head = false: the head matrix already sits at Bs0 (a caller running several tiles of one launch through this epilogue)
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int FM = TM / FR, FN = TN / FR;
   constexpr int GK = FR == 32 ? 8 : 16;
@@ -231,10 +232,11 @@ __device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM /
             }
             Y[lrow * LDK + n] = v;
           }
-        for (int idx = tid; idx < FR * FR; idx += NTE) {  // FR x FR head matrix, zero padded
-          const int n2 = idx / FR, k = idx % FR;
-          Wh[n2 * LDK + k] = (n2 < p.N && k < p.N) ? p.head_w[n2 * p.N + k] : 0.f;
-        }
+        if (stage_head)
+          for (int idx = tid; idx < FR * FR; idx += NTE) {  // FR x FR head matrix, zero padded
+            const int n2 = idx / FR, k = idx % FR;
+            Wh[n2 * LDK + k] = (n2 < p.N && k < p.N) ? p.head_w[n2 * p.N + k] : 0.f;
+          }
       }
       __syncthreads();
       AccT acc2[FM];
