@@ -342,7 +342,7 @@ def main():
             M, N, K = B * (H // 2) * (W // 2), enc[i + 1], 16 * enc[i]
             fl = 2.0 * M * N * 16 * (enc[i] + (1 if (i == 0 and with_class) else 0))
             by = 4.0 * (B * H * W * enc[i] + M * N + N * K)
-            metas.append(("unet_down_fwd", ops.unet_kernel_name(M, N, False, True) if mode == "bf16x3" else ops.igemm_config(N), M, N, K, fl, by))
+            metas.append(("unet_down_fwd", ops.unet_kernel_name(M, N, False, True, K) if mode == "bf16x3" else ops.igemm_config(N), M, N, K, fl, by))
             H //= 2
             W //= 2
         c0, c1, co = [512, 512, 256, 128, 64], [0, 512, 256, 128, 64], [512, 256, 128, 64, n_out]
@@ -441,8 +441,8 @@ def main():
             peak = PEAK_BF16 / 3.0
             kern = ("the implicit-GEMM conv kernels of csrc/ in bf16x3 math on split32 operands (fp32 values as bf16 hi + lo pairs; "
                     "hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, fp32 accumulate): m2h::igemm_dma_kernel<256,128> "
-                    "(LDS-DMA engine: the wide stages), m2h::igemm_f32_kernel<..., SPLIT=2> (register-staged engine) and "
-                    "m2h::convT_tap_kernel (narrow transposed stages); `achieved` is over all of them, `dominant_instantiation` the "
+                    "(LDS-DMA engine: the wide stages), m2h::igemm_f32_kernel<..., SPLIT=2> (register-staged engine), "
+                    "m2h::convT_quad_kernel / m2h::convT_tap_kernel (narrow transposed stages); `achieved` is over all of them, `dominant_instantiation` the "
                     "one with the largest share of the step")
         else:
             peak = PEAK_F32_MFMA_TFLOPS

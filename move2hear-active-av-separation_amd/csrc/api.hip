@@ -6,7 +6,7 @@ namespace m2h {
 thread_local char g_err[512] = {0};
 int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st);
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a);
-extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny, g_narrow16, g_extra_lds, g_phase_major, g_fast_loader, g_wgrad_blocks, g_tapshare, g_tap_bm, g_tap_window, g_wgrad_row3x3, g_row3x3, g_skinny_linear, g_skinny_gather, g_big_tile, g_dma, g_dma_shape, g_dma64, g_quad, g_dma_korder, g_bres;
+extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny, g_narrow16, g_extra_lds, g_phase_major, g_fast_loader, g_wgrad_blocks, g_tapshare, g_tap_bm, g_tap_window, g_wgrad_row3x3, g_row3x3, g_skinny_linear, g_skinny_gather, g_big_tile, g_dma, g_dma_shape, g_dma64, g_quad, g_dma_korder, g_bres, g_dma_split2;
 extern thread_local int tl_math_mode;
 }  // namespace m2h
 
@@ -61,6 +61,7 @@ int m2h_debug_set(int knob, int value) {
   else if (knob == 30) g_quad = value;
   else if (knob == 31) g_dma_korder = value;
   else if (knob == 32) g_bres = value;
+  else if (knob == 34) g_dma_split2 = value;
   else return fail(-1, "debug_set: unknown knob %d", knob);
   return 0;
 }

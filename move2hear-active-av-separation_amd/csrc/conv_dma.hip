@@ -25,6 +25,7 @@
 
 namespace m2h {
 
+int g_dma_split2 = 0;   // m2h_debug_set 34: -1 = no two-way split-K on the 256 x 128 tile
 int g_dma_korder = 0;   // m2h_debug_set 31: 2 = the L2-friendly k-tile orders below instead of the register engine's (tap, chunk)
 int g_dma64 = 0;      // m2h_debug_set 29: 1 = 64-wide plain convs on this engine too (256 x 64 tile).  Off: the first encoder stage
                       // has only 16 k-tiles per tile, each a new tap (row offsets recomputed every tile), and one block per CU
@@ -531,6 +532,14 @@ int launch_igemm_dma(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   const long t256 = (((long)p.M + 255) / 256) * (p.N / 128) * phases;
   if (g_dma != 1 && g_big_tile >= 0 && (g_dma == 2 || t256 >= (g_big_tile > 0 ? g_big_tile : 224)))
     return g_dma_shape == 32 ? launch_dma_cfg<256, 128, 4, 2, 3, 32>(p, 1, st) : launch_dma_cfg<256, 128, 4, 2, 3, 16>(p, 1, st);
+  // half the chip's worth of 256 x 128 tiles and a long reduction (the fourth encoder stage at the benchmark batch: 128 tiles,
+  // K = 4096): two K-halves per tile into split-K slabs + the ordered reduce kernel
+  {
+    const int nk = p.Kw / BK;
+    if (g_dma == 0 && g_big_tile >= 0 && g_dma_split2 >= 0 && t256 * 2 >= 224 && nk >= 64 && p.ws != nullptr && (p.N & 3) == 0 &&
+        (size_t)phases * 2 * p.M * p.N * sizeof(float) <= ws_bytes)
+      return g_dma_shape == 32 ? launch_dma_cfg<256, 128, 4, 2, 3, 32>(p, 2, st) : launch_dma_cfg<256, 128, 4, 2, 3, 16>(p, 2, st);
+  }
   // fewer tiles: the 128 x 128 tile at two blocks per CU of the register engine is faster than this engine's one block per CU
   // (pair_ab --layers, B = 256: down3 125 vs 147 us, down4 47 vs 53, up0 52 vs 59); m2h_debug_set 27 = 1 forces it here
   if (g_dma != 1) return -2;
