@@ -215,11 +215,14 @@ __device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM /
       constexpr int NGH = FR / GK;   // fragment groups of the FR-deep head contraction
       float* Y = As0;
       float* Wh = Bs0;
+      // this lane's per-channel constants first: their load latency runs under the barrier instead of behind it (the loads cannot
+      // move across __syncthreads by themselves; at four epilogue passes per workgroup they were ~1 us of each)
+      const float scn = (p.scale != nullptr && col < p.N) ? p.scale[col] : 1.f;
+      const float shn = (p.shift != nullptr && col < p.N) ? p.shift[col] : 0.f;
+      const float hb = col < p.N ? p.head_b[col] : 0.f;
       __syncthreads();  // every wave is done with the main loop's LDS tiles
       {
         const int n = col;
-        const float scn = (p.scale != nullptr && n < p.N) ? p.scale[n] : 1.f;
-        const float shn = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < FM; ++mi)
 #pragma unroll
@@ -261,7 +264,6 @@ __device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM /
       }
       __syncthreads();  // Y fully consumed before it is overwritten by the transposed staging
       float* Tt = Y;
-      const float hb = col < p.N ? p.head_b[col] : 0.f;
 #pragma unroll
       for (int mi = 0; mi < FM; ++mi)
 #pragma unroll
