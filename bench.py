@@ -321,7 +321,7 @@ def main():
     graphed = None if args.no_graph else GraphedSeparatorPair(pol, obs)
 
     def step():
-        """one pass of the pair over the resident batch; by default replayed from a HIP graph (the same 22 kernels, captured
+        """one pass of the pair over the resident batch; by default replayed from a HIP graph (the same kernels, captured
         once per arithmetic mode) -- --no-graph enqueues them through the two m2h_unet_fwd calls instead"""
         if graphed is not None:
             return graphed()
@@ -535,7 +535,7 @@ def main():
                    "batch_per_gpu": args.batch, "n_freq": 512, "time_frames": args.tm, "parallelism": "dp%d (batch-sharded, no collective)" % world,
                    "weights": "synthetic (m2h.synthetic seed 1), reference architecture 33.47 M params",
                    "launch": ("two m2h_unet_fwd calls per step (22 kernels enqueued one by one)" if args.no_graph else
-                              "HIP graph: the step's 22 kernels captured once per arithmetic mode, replayed every step (m2h.graphs)")},
+                              "HIP graph: the step's kernels (2 input slices, 20 convs, the split-K reduces of the deep stages) captured once per arithmetic mode, replayed every step (m2h.graphs)")},
         "roofline": roofline,
         "other_math_mode": other_mode,
         "math_mode_parity": parity,
