@@ -1219,6 +1219,9 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   IGemmP p;
   p.src0 = a.src0; p.src1 = a.src1; p.C0 = a.C0; p.C1 = a.C1; p.Ctot = a.C0 + a.C1;
   p.B = a.B; p.Hi = a.Hi; p.Wi = a.Wi; p.Hq = a.Hq; p.Wq = a.Wq; p.stride = a.stride;
+  p.wq_sh = (a.Wq & (a.Wq - 1)) == 0 ? __builtin_ctz((unsigned)a.Wq) : -1;
+  p.hq_sh = (a.Hq & (a.Hq - 1)) == 0 ? __builtin_ctz((unsigned)a.Hq) : -1;
+  p.korder = 0;
   p.ntw = a.ntw; p.ntap = a.nth * a.ntw;
   p.mulh = a.mulh; p.offh = a.offh; p.mulw = a.mulw; p.offw = a.offw; p.convT = a.conv_transpose ? 1 : 0;
   p.w = a.wp; p.N = a.N; p.K = p.ntap * p.Ctot;

@@ -37,6 +37,7 @@ struct IGemmP {
   int presplit;  // both operands arrive in the split32 layout
   int dst_split; // epilogue writes dst in the split32 layout (bf16x3 math, NHWC, N % 32 == 0)
   int korder;  // LDS-DMA engine: order of the k-tiles (conv_dma.hip)
+  int wq_sh, hq_sh;   // log2 of Wq / Hq when they are powers of two, else -1 (decode_row)
   int pmaj;    // transposed conv: phase is folded into grid x (fastest) instead of grid z
   // tap window of the scalar-decode loader: taps th0..th0+thn-1 x tw0..tw0+twn-1 are walked, the others lie in the zero
   // padding for EVERY output pixel of this launch (tiny images: a 2-row input under a 4x4/s2/p1 conv, a 1-row input under a
@@ -56,10 +57,17 @@ constexpr int LDK = 36;  // padded LDS row (floats): 144 B, keeps 16-B alignment
 
 // Row bookkeeping shared by the main kernel and the split-K epilogue: output pixel offset and class id of GEMM row m.
 __device__ __forceinline__ void decode_row(const IGemmP& p, int m, int ph, int pw, int& q, int& rr, int& b, int& out, int& bc) {
-  rr = m % p.Wq;
-  const int t = m / p.Wq;
-  q = t % p.Hq;
-  b = t / p.Hq;
+  if (p.wq_sh >= 0 && p.hq_sh >= 0) {   // power-of-two pixel grid (every U-Net stage): shifts instead of three integer divisions
+    rr = m & (p.Wq - 1);
+    const int t = m >> p.wq_sh;
+    q = t & (p.Hq - 1);
+    b = t >> p.hq_sh;
+  } else {
+    rr = m % p.Wq;
+    const int t = m / p.Wq;
+    q = t % p.Hq;
+    b = t / p.Hq;
+  }
   const int oh = q * p.os + ph, ow = rr * p.os + pw;
   if (p.out_mode == M2H_OUT_NHWC)
     out = (b * p.Ho + oh) * p.Wo + ow;
