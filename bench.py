@@ -117,6 +117,37 @@ def cpu_baseline(sd, tm, seconds):
                       % (n, bs, tm, best_n, ncpu, el)}
 
 
+def ddppo_roofline(env_steps_per_s_per_job, s_per_cycle, far_target):
+    """Achieved-fraction object of the DD-PPO leg (BASELINE config 3 / 5).  FLOP figures per env-step: algorithmic = SURVEY 8d's
+    reference schedule (13.8 GFLOP: 24 + 2 U-Net pair passes per env-step dominate); executed = what this build runs after the two
+    result-preserving re-uses of DESIGN section 5 (separator outputs cached per stored observation: one pair pass per env-step in the
+    rollout + one per stored sample per update_sep cycle, AcousticMem fwd+bwd x 24, policy fwd + 4 x fwd/bwd).  Kernel time and
+    launch counts cannot be read from inside the process: they come from the committed rocprofv3 --kernel-trace --stats summary of
+    this leg (profiles/rNN_ddppo_summary.json, tools/profile_round3.sh) when present."""
+    algorithmic = 13.8
+    # rollout: ONE pair pass + one memory pass per env-step (the next observation's outputs serve the following step) + policy forward;
+    # update_pol: 4 epochs x (forward + backward ~ 3x forward); update_sep: one pair pass per stored sample per cycle (cached) +
+    # 24 x AcousticMem forward + backward
+    executed = (0.4226 + 0.0283 + 0.0545) + 4 * 3 * 0.0545 + (0.4226 + 24 * 3 * 0.0283)
+    out = {"bound": "launch latency (kernels of 5-20 us at 14 rows; see DESIGN 3.2c)", "unit": "TFLOP/s",
+           "algorithmic_gflop_per_env_step": algorithmic, "executed_gflop_per_env_step": round(executed, 3),
+           "achieved_algorithmic": round(algorithmic * env_steps_per_s_per_job / 1e3, 2),
+           "achieved": round(executed * env_steps_per_s_per_job / 1e3, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+           "frac": round(executed * env_steps_per_s_per_job / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+           "note": "per job (all ranks); peak = one GPU's fp32 MFMA peak x n_gpus is the fair ceiling at N > 1"}
+    for r in (3, 2):
+        path = os.path.join(ROOT, "profiles", "r%02d_ddppo_summary.json" % r)
+        if os.path.exists(path):
+            with open(path) as f:
+                sj = json.load(f).get("far_target" if far_target else "near_target")
+            if sj:
+                out.update(launches_per_cycle=sj.get("launches_per_cycle"), kernel_ms_per_cycle=sj.get("kernel_ms_per_cycle"),
+                           kernel_time_share=(round(sj["kernel_ms_per_cycle"] / (1e3 * s_per_cycle), 3) if sj.get("kernel_ms_per_cycle") else None),
+                           profile_source=sj.get("source"))
+            break
+    return out
+
+
 def run_ddppo(args, dev, rank, world, dist, far_target=False):
     """Second figure of BASELINE.json's metric: DD-PPO env-steps/s on the reference schedule (nearTarget.yaml: 14 envs/rank,
     T=20, 6 policy updates + 6 separator updates per cycle, 4 epochs, 1 minibatch) with the synthetic on-device env.
@@ -133,24 +164,65 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False):
         tr = PPOTrainer(cfg, dev, world_rank=rank, world_size=world)
         tr.setup()
         tr.actor_critic.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_state_dict(syn.policy_shapes(), 1).items()})
+        from m2h.rl.ppo import ddppo_utils
         tr.train_cycle()  # warm-up (allocator, pack caches, lazy optimizer buffers, graph capture)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
+        phase_events = []
+        coll = ddppo_utils.collective_log(True)
         t0 = time.perf_counter()
         steps = 0
         last = None
         for _ in range(args.ddppo_cycles):
-            last = tr.train_cycle()
+            last = tr.train_cycle(phase_events=phase_events)
             steps += last["env_steps"]
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         el = time.perf_counter() - t0
+        ddppo_utils.collective_log(False)
         if dist is not None:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
+        # per-cycle phase times on the compute stream and the gradient all-reduces wherever they ran (compute or side stream)
+        phases = {}
+        for name, e0, e1 in phase_events:
+            phases[name] = phases.get(name, 0.0) + e0.elapsed_time(e1)
+        breakdown = {k + "_ms": round(v / args.ddppo_cycles, 3) for k, v in phases.items()}
+        breakdown["grad_allreduce_ms"] = round(sum(e0.elapsed_time(e1) for e0, e1, _b in coll) / args.ddppo_cycles, 3)
+        breakdown["grad_allreduce_count"] = len(coll) // max(1, args.ddppo_cycles)
+        breakdown["grad_allreduce_payload_bytes"] = sorted({b for _e0, _e1, b in coll}, reverse=True)
+        pol_bytes = tr.agent.optimizer_pol.flat_g.numel() * 4
+        breakdown["policy_grad_bytes"] = pol_bytes
+        # one stand-alone all-reduce of the policy's flat gradient size, timed alone (RCCL over xGMI when world > 1)
+        standalone_us = 0.0
+        if dist is not None:
+            buf = torch.zeros(pol_bytes // 4, device=dev)
+            for _ in range(2):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dist.all_reduce(buf)
+            e1.record()
+            torch.cuda.synchronize()
+            standalone_us = 1e3 * e0.elapsed_time(e1) / 5
+            del buf
+        breakdown["allreduce_23MB_us"] = round(standalone_us, 1)
+        breakdown["what"] = ("HIP-event time per cycle of the three phases on the compute stream (6 x rollout of 20 steps, 6 x update_pol, 6 x update_sep) and of the "
+                             "flat-gradient all-reduces on the stream each ran on (the last one of every update on the side stream, under the next phase); "
+                             "allreduce_23MB_us = a stand-alone all-reduce of the policy gradient's size; all zero-collective at one rank")
+        props = torch.cuda.get_device_properties(dev)
+        ident = {"rank": rank, "device_index": dev.index, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+                 "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))}
+        if dist is not None:
+            idents = [None] * world
+            dist.all_gather_object(idents, ident)
+        else:
+            idents = [ident]
         mixed = None
         if far_target:
             # the same evaluate_actions batch (the policy storage as it stands) in both arithmetic modes
@@ -183,6 +255,8 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False):
            "separator_output_reuse": "frozen eval-mode U-Net outputs computed once per stored observation and re-used by the 24 "
                                      "update_sep passes and by the next rollout step (result-preserving; SURVEY D13)",
            "last_pol_losses": [round(x, 5) for x in last["pol_losses"]], "last_sep_losses": [round(x, 5) for x in last["sep_losses"]],
+           "phases": breakdown, "devices": idents, "distinct_devices": len({(d["uuid"], d["pci_bus_id"]) for d in idents}),
+           "roofline": ddppo_roofline(world * steps / el, el / args.ddppo_cycles, far_target),
            "reference_cpu_env_steps_per_sec_survey_probe": 4.3}
     if far_target:
         out["math"] = "bf16x3 products (fp32 tensors and accumulation) in every forward / input-gradient GEMM; weight gradients, reductions, Adam in fp32"

@@ -225,6 +225,13 @@ int m2h_policy_heads(const float* feats, const float* Wa, const float* ba, const
                      int M, int H, int A, m2h_stream stream);
 int m2h_gather_logp(const float* logp_all, const long long* actions, float* out, int M, int A, m2h_stream stream);
 
+/* CustomFixedCategorical.sample (common/utils.py:16-24) with the noise supplied by the caller: the single-draw path of
+ * torch.multinomial(probs, 1, True) is argmax(probs / q), q ~ Exp(1) drawn from the tensor's generator -- on the reference's
+ * CPU path the default mt19937 generator.  The host draws q there (same call, same stream position), ships it to the device,
+ * and this kernel does the rest: actions[row] = first index of max_j probs[row][j] / noise[row][j] (IEEE fp32 division, ties to
+ * the lowest index as ATen's CPU argmax).  probs, noise [M][A] fp32, actions [M] int64.  A <= 64. */
+int m2h_sample_actions(const float* probs, const float* noise, long long* actions, int M, int A, m2h_stream stream);
+
 /* RolloutStoragePol.compute_returns (common/rollout_storage.py:155-180).  rewards [T][N], value_preds [T+1][N] (row T is
  * overwritten by next_value when use_gae), masks [T+1][N], next_value [N], returns [T+1][N]. */
 int m2h_gae_returns(const float* rewards, float* value_preds, const float* masks, const float* next_value, float* returns, int T,

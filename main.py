@@ -24,7 +24,7 @@ def main():
     parser.add_argument("--exp-config", type=str, default=None, help="path to the experiment YAML")
     parser.add_argument("--model-dir", default=None)
     parser.add_argument("--cycles", type=int, default=None,
-                        help="ppo: cap on the training cycles (default: NUM_UPDATES / num_updates_per_cycle, as the reference); passive: epochs (default 1)")
+                        help="ppo: cap on the training cycles (default: NUM_UPDATES / num_updates_per_cycle, as the reference); passive: epochs (default: the YAML's NUM_EPOCHS)")
     parser.add_argument("--eval-ckpt", default=None, help="eval: checkpoint file (default: <model-dir>/data/ckpt.0.pth if present)")
     parser.add_argument("--eval-episodes", type=int, default=None, help="eval: episodes to aggregate (default: NUM_PROCESSES)")
     parser.add_argument("opts", default=None, nargs=argparse.REMAINDER, help="KEY VALUE overrides")
@@ -64,7 +64,8 @@ def main():
         print(json.dumps(stats, indent=1))
         return
     if config.TRAINER_NAME == "passive":
-        for i, rec in enumerate(trainer.train(num_epochs=args.cycles or 1)):
+        # --cycles absent: the YAML's NUM_EPOCHS, as the reference's passive loop (passive_trainer.py:252-257)
+        for i, rec in enumerate(trainer.train(num_epochs=args.cycles)):
             print("epoch %d  train bin/mono %.4f %.4f   val %.4f %.4f" % (i, *rec["train"], *rec["val"]))
     else:
         # the reference loop (ppo_trainer.py:730-1011): NUM_UPDATES / num_updates_per_cycle cycles, window statistics per policy
@@ -72,6 +73,13 @@ def main():
         for i, rec in enumerate(trainer.train(args.cycles)):
             if trainer.world_rank == 0:
                 print("cycle %d  %d env-steps in %.2f s  pol losses %s  sep losses %s" % (i, rec["env_steps"], rec["seconds"], rec["pol_losses"], rec["sep_losses"]))
+        # every rank: a digest of the replica it ends with (DD-PPO keeps the replicas bit-identical; a desynchronised run shows here)
+        import hashlib
+        h = hashlib.sha1()
+        for k, v in sorted(trainer.actor_critic.state_dict().items()):
+            h.update(k.encode())
+            h.update(v.detach().cpu().contiguous().numpy().tobytes())
+        print("rank %d of %d: final weights sha1 %s" % (trainer.world_rank, trainer.world_size, h.hexdigest()), flush=True)
 
 
 if __name__ == "__main__":

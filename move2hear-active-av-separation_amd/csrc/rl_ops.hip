@@ -231,6 +231,21 @@ __global__ void gather_logp_kernel(const float* __restrict__ logp_all, const lon
   if (i < M) out[i] = logp_all[i * A + (int)actions[i]];
 }
 
+// argmax(probs / noise) per row: the single-draw path of torch.multinomial with caller-supplied Exp(1) noise (m2h_sample_actions).
+// Correctly rounded fp32 division (hipcc's default), NaN counts as the maximum and ties keep the lowest index, as ATen's argmax.
+__global__ void sample_actions_kernel(const float* __restrict__ probs, const float* __restrict__ noise, long long* __restrict__ actions,
+                                      int M, int A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  float best = probs[i * A] / noise[i * A];
+  int arg = 0;
+  for (int j = 1; j < A; ++j) {
+    const float q = probs[i * A + j] / noise[i * A + j];
+    if (!(best != best) && (q > best || q != q)) { best = q; arg = j; }
+  }
+  actions[i] = arg;
+}
+
 // GAE / discounted-return scan: one thread per env, T steps backwards.  rewards [T,N], value_preds [T+1,N] (row T is
 // overwritten with next_value when use_gae), masks [T+1,N], returns [T+1,N].
 __global__ void gae_returns_kernel(const float* __restrict__ rewards, float* __restrict__ value_preds, const float* __restrict__ masks,
@@ -839,6 +854,12 @@ int m2h_policy_heads(const float* feats, const float* Wa, const float* ba, const
   hipLaunchKernelGGL(policy_heads_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), feats, Wa, ba, Wc, bc, actions, value,
                      logp_all, probs, entropy, logp_act, M, H, A);
   return launch_status("policy_heads");
+}
+
+int m2h_sample_actions(const float* probs, const float* noise, long long* actions, int M, int A, m2h_stream stream) {
+  M2H_REQUIRE(probs && noise && actions && M > 0 && A > 0 && A <= 64, "sample_actions: bad arguments");
+  hipLaunchKernelGGL(sample_actions_kernel, dim3((M + 255) / 256), dim3(256), 0, as_stream(stream), probs, noise, actions, M, A);
+  return launch_status("sample_actions");
 }
 
 int m2h_gather_logp(const float* logp_all, const long long* actions, float* out, int M, int A, m2h_stream stream) {

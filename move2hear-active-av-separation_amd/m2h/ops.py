@@ -469,6 +469,20 @@ def gather_logp(logp_all, actions):
     return out
 
 
+def sample_actions(probs, noise):
+    """argmax(probs / noise) per row -> [M,1] int64: torch.multinomial(probs, 1, True) given its Exp(1) noise."""
+    _chk(probs, "sample_actions")
+    _chk(noise, "sample_actions(noise)")
+    if noise.shape != probs.shape:
+        raise RuntimeError("m2h sample_actions: noise %s does not match probs %s" % (tuple(noise.shape), tuple(probs.shape)))
+    M, A = probs.shape
+    out = torch.empty((M, 1), dtype=torch.int64, device=probs.device)
+    lib = _lib.load()
+    with torch.cuda.device(probs.device):
+        _lib.check(lib.m2h_sample_actions(_ptr(probs), _ptr(noise), _ptr(out), M, A, _stream(probs)), "m2h_sample_actions")
+    return out
+
+
 def gae_returns(rewards, value_preds, masks, next_value, returns, use_gae, gamma, tau):
     """In place on value_preds[-1] and returns (RolloutStoragePol.compute_returns).  Shapes [T,N,1]/[T+1,N,1]/[N,1]."""
     for t in (rewards, value_preds, masks, next_value, returns):

@@ -52,12 +52,32 @@ def broadcast_parameters(tensors, src=0):
             dist.broadcast(t.data, src)
 
 
+_COLLECTIVE_LOG = None
+
+
+def collective_log(enable=True):
+    """Diagnostics (bench.py): while enabled every gradient all-reduce on a GPU tensor is bracketed by two timing events on the
+    stream it is enqueued on (the compute stream, or GradReduceStep's side stream) and logged as (start, end, payload bytes).
+    Returns the list being filled (None when disabled); the caller reads the events after a device synchronize."""
+    global _COLLECTIVE_LOG
+    _COLLECTIVE_LOG = [] if enable else None
+    return _COLLECTIVE_LOG
+
+
 def reduce_gradients(flat_grad):
     """Sum all-reduce of the flat gradient buffer; returns the scale (1/world) the optimizer applies before clipping."""
     w = world_size()
     if w == 1:
         return 1.0
-    dist.all_reduce(flat_grad)
+    log = _COLLECTIVE_LOG
+    if log is not None and flat_grad.is_cuda:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dist.all_reduce(flat_grad)
+        e1.record()
+        log.append((e0, e1, flat_grad.numel() * flat_grad.element_size()))
+    else:
+        dist.all_reduce(flat_grad)
     return 1.0 / w
 
 

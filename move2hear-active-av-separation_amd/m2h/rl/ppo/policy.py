@@ -149,11 +149,28 @@ class Policy(nn.Module):
         self._fence("mem")
         return self.acoustic_mem.forward_masked(pred_mono, prev_pred_monoFromMem, masks)
 
+    # action sampling (common/utils.py): None = noise from the device generator; a HostNoise = noise from the CPU default generator
+    _host_noise = None
+
+    def set_action_sampling(self, mode):
+        """"device": torch.multinomial's draw on the device generator (throughput default).  "cpu_generator": the same draw with
+        its Exp(1) noise taken from the CPU default generator, i.e. the actions of the reference PyTorch-CPU path for the same
+        seed (common/utils.py:16-24 on a CPU policy)."""
+        from ...common.utils import HostNoise
+        if mode not in ("device", "cpu_generator"):
+            raise ValueError("action_sampling must be 'device' or 'cpu_generator', got %r" % (mode,))
+        self._host_noise = HostNoise(next(self.parameters()).device) if mode == "cpu_generator" else None
+
+    def stage_action_noise(self, rows):
+        """cpu_generator mode: draw the next step's noise and enqueue its upload (called ahead of a graph replay that samples)."""
+        if self._host_noise is not None:
+            self._host_noise.stage(rows, self.dim_actions)
+
     def _heads(self, feats, actions=None):
         a, c = self.action_dist.linear, self.critic.fc
         acts = actions.reshape(-1).contiguous() if actions is not None else None
         value, logp_act, ent, probs, logp_all = MF.PolicyHeads.apply(feats, a.weight, a.bias, c.weight, c.bias, acts)
-        return value, CustomFixedCategorical(logp_all, probs, ent), (logp_act if actions is not None else None)
+        return value, CustomFixedCategorical(logp_all, probs, ent, self._host_noise), (logp_act if actions is not None else None)
 
     def evaluate_rows(self, observations, rnn_hidden_states_pol, masks, action, pred_binSepMasks=None, pred_mono=None,
                       pred_monoFromMem=None):

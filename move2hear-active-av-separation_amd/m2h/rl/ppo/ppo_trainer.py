@@ -44,7 +44,9 @@ def near_target_config(**over):
              ddppo_distrib_backend="NCCL", master_port=8738, master_addr="127.0.0.1",       # config/default.py:94-97
              short_rollout_threshold=1.0, sync_frac=0.6,  # nearTarget.yaml:58-59: at 1.0 the preemption of :775-781 never triggers; not built
              use_hip_graphs=True,       # build-side key: replay the rollout step and the update_pol epoch from HIP graphs (same kernels, same results)
-             overlap_grad_reduce=None)  # build-side key: None = overlap the last all-reduce + step of an update when distributed
+             overlap_grad_reduce=None,  # build-side key: None = overlap the last all-reduce + step of an update when distributed
+             action_sampling="device")  # build-side key: "device" = multinomial noise from the device generator; "cpu_generator" = from
+    #                                     the CPU default generator: the reference PyTorch-CPU run's actions from the seed alone
     c.update(over)
     return SimpleNamespace(**c)
 
@@ -80,6 +82,7 @@ class PPOTrainer:
             hidden_size=cfg.hidden_size, extra_rgb=cfg.EXTRA_RGB, extra_depth=cfg.EXTRA_DEPTH, use_ddppo=cfg.use_ddppo,
             world_rank=self.world_rank)
         self.actor_critic.to(self.device)
+        self.actor_critic.set_action_sampling(getattr(cfg, "action_sampling", "device"))
         cls = DDPPO if cfg.use_ddppo else PPO
         self.agent = cls(actor_critic=self.actor_critic, clip_param=cfg.clip_param, ppo_epoch=cfg.ppo_epoch,
                          num_mini_batch=cfg.num_mini_batch, value_loss_coef=cfg.value_loss_coef,
@@ -268,6 +271,7 @@ class PPOTrainer:
             if gs.pool is None:
                 gs.pool = g.pool()
             gs.graphs[key] = g
+        self.actor_critic.stage_action_noise(self.envs.num_envs)  # cpu_generator sampling: this step's noise, drawn on the host
         g.replay()
         gs.expect = ((ro.step + 1) % ro.num_steps, (rs.step + 1) % rs.num_steps)
 
@@ -290,8 +294,11 @@ class PPOTrainer:
         self._next_cache = None  # acoustic_mem changed: the cached next-step memory output is stale
         return out
 
-    def train_cycle(self, log_stats=False, checkpoint=False):
+    def train_cycle(self, log_stats=False, checkpoint=False, phase_events=None):
         """One cycle of the reference schedule (:730-1011): returns a dict of timings and losses.
+        phase_events: optional list; gets one (phase, start event, end event) triple per rollout / update_pol / update_sep of the
+        cycle, recorded on the compute stream (bench.py's per-phase breakdown; deferred optimizer steps run on the side stream and
+        show up in ddppo_utils.collective_log instead).
         log_stats: after every policy update compute the window-of-N statistics the reference writes to TensorBoard (:790-977;
         one stats all-reduce + one small device->host read per update) and append them to ``self.scalars``.
         checkpoint: save ``ckpt.<k>.pth`` whenever the separator update number is a multiple of CHECKPOINT_INTERVAL (:1007-1009)."""
@@ -305,17 +312,24 @@ class PPOTrainer:
             if cfg.use_linear_clip_decay:
                 self.agent.clip_param = cfg.clip_param * linear_decay(self.num_updates_done, cfg.NUM_UPDATES)
             sub_steps = 0
+            e0 = self._mark(phase_events)
             for _step in range(cfg.num_steps):
                 sub_steps += self._collect_rollout_step()
             steps += sub_steps
+            e1 = self._mark(phase_events)
             pol_losses = self._update_pol()
+            if phase_events is not None:
+                phase_events += [("rollout", e0, e1), ("update_pol", e1, self._mark(phase_events))]
             self.num_updates_done += 1
             if log_stats:
                 self._log_window_stats(pol_losses, sub_steps)
         for _sub in range(cfg.num_updates_per_cycle):
             if cfg.use_linear_lr_decay:
                 self.lr_scheduler_sep.step()
+            e0 = self._mark(phase_events)
             sep_losses = self._update_sep()
+            if phase_events is not None:
+                phase_events.append(("update_sep", e0, self._mark(phase_events)))
             if checkpoint and self.world_rank == 0 and self.num_sep_updates_done % cfg.CHECKPOINT_INTERVAL == 0 and cfg.CHECKPOINT_FOLDER:
                 self.save_checkpoint("ckpt.%d.pth" % self.count_checkpoints)
                 self.count_checkpoints += 1
@@ -323,6 +337,13 @@ class PPOTrainer:
         if not log_stats:
             self.count_steps += steps
         return {"env_steps": steps, "seconds": time.perf_counter() - t0, "pol_losses": pol_losses, "sep_losses": sep_losses}
+
+    def _mark(self, sink):
+        if sink is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
 
     _WINDOW_KEYS = (("count", "episode_counts"), ("reward", "episode_rewards"), ("step", "episode_steps"), ("dist_probs", "episode_dist_probs"),
                     ("avg_bin_loss_allSteps", "episode_bin_losses_allSteps"), ("mono_loss_lastStep", "episode_mono_losses_lastStep"),
@@ -428,7 +449,9 @@ class PPOTrainer:
         if not sd:
             raise RuntimeError("checkpoint state_dict has no 'actor_critic.*' keys")
         ac.load_state_dict(sd, strict=True)
-        return ac.to(self.device).eval()
+        ac = ac.to(self.device).eval()
+        ac.set_action_sampling(getattr(cfg, "action_sampling", "device"))
+        return ac
 
     def eval(self, num_episodes=None, checkpoint_path=None, waveform_metrics=("si_sdr",), deterministic=None,
              switch_checkpoint_path=None, time_thres_for_pol_switch=None, trace=None):

@@ -1,7 +1,7 @@
 """Import harness for the *reference* Move2Hear python modules (TEST INFRASTRUCTURE ONLY).
 
-Used only by ``oracle/gen_golden.py`` and by ``tests/test_oracle_vs_reference.py`` in the build
-container, where ``/root/reference`` is mounted read-only.  It never travels to the GPU box: the
+Used only by the fixture generators ``oracle/gen_golden.py`` and ``oracle/gen_trainer_golden.py`` in the build
+container, where ``/root/reference`` is mounted read-only (the tests compare against the committed fixtures they write).  It never travels to the GPU box: the
 reference tree does not exist there and nothing under ``-m gpu``, ``smoke()`` or ``bench.py``
 imports this file.
 

@@ -1,6 +1,6 @@
 """Generates tests/golden/trainer_*.npz by running the REFERENCE's own training loop (build container only).
 
-    python oracle/gen_trainer_golden.py [--only near|far|ddp]
+    python oracle/gen_trainer_golden.py [--only near|far|ddp|eval]      (no argument: all four, one child process each)
 
 What runs is the reference's ``PPOTrainer`` -- ``train`` (ppo_trainer.py:579-1013), ``_collect_rollout_step`` (:253-478),
 ``_update_pol`` / ``_update_sep`` (:480-541), ``_setup_actor_critic_agent`` (:54-222), ``_load_pretrained_passive_separators``
@@ -399,7 +399,13 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    for name, fn in GENS.items():
-        if a.only and a.only not in name:
-            continue
-        fn()
+    if a.only:
+        for name, fn in GENS.items():
+            if a.only in name:
+                fn()
+    else:
+        # every generator in a process of its own: the reference's trainer initialises the default process group (use_ddppo) and
+        # never destroys it, so two generators cannot share an interpreter
+        import subprocess
+        for name in GENS:
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--only", name], check=True)

@@ -1,12 +1,14 @@
 """GPU: the m2h DD-PPO trainer against the REFERENCE's own training run (tests/golden/trainer_{near,far,ddp2}.npz, produced by
 oracle/gen_trainer_golden.py from the reference's ``PPOTrainer.train``).  Rows A15 / A18 / A19 / N4 of SURVEY 8.
 
-The same table-driven replay world runs on both sides; the actions the reference sampled (CPU mt19937 stream) are fed to the
-trainer in place of its own draws (device Philox stream -- ``test_sampling_is_torch_multinomial_bit_for_bit`` covers the draw
-itself), so the trajectories coincide and everything downstream is compared: per-step rewards (incl. the 2 x 10 x extra
-reward at MAX_EPISODE_STEPS - 2 and the zero at episode ends), values, log-probs, hidden states, stored separator outputs, all
-17 per-episode statistics, per-update losses / learning rates / clip ranges / returns, the window statistics the reference
-logs, the checkpoint schedule and the weights after two cycles.
+The same table-driven replay world runs on both sides and NOTHING of the reference's trajectory is fed in: the trainer samples
+its own actions in ``action_sampling="cpu_generator"`` mode -- the Exp(1) noise of torch.multinomial's single-draw path drawn on
+the CPU default generator (mt19937) at the reference's stream position (policy init, one draw per step, one randperm per
+epoch), divided and arg-maxed on the device (m2h_sample_actions) -- so from the seed alone the sampled actions must equal the
+reference-CPU run's, bit for bit, and with them everything downstream: per-step rewards (incl. the 2 x 10 x extra reward at
+MAX_EPISODE_STEPS - 2 and the zero at episode ends), values, log-probs, hidden states, stored separator outputs, all 17
+per-episode statistics, per-update losses / learning rates / clip ranges / returns, the window statistics the reference logs,
+the checkpoint schedule and the weights after two cycles.
 """
 import os
 import subprocess
@@ -29,8 +31,7 @@ def _passive_ckpt(seed):
 
 
 def run_m2h(d, flat, replay, env_kind, graphs, rank=0, world=1, pre=""):
-    """Runs the product trainer over the fixture's schedule; returns a record shaped like the oracle's."""
-    from m2h.common import utils as CU
+    """Runs the product trainer over the fixture's schedule (its own sampled actions); returns a record shaped like the oracle's."""
     from m2h.envs.replay_env import ReplayVecEnv
     from m2h.envs.vector_env_adapter import HostVectorEnvAdapter
     from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config
@@ -39,7 +40,7 @@ def run_m2h(d, flat, replay, env_kind, graphs, rank=0, world=1, pre=""):
                                  "num_mini_batch", "eps", "max_grad_norm", "num_steps", "use_gae", "gamma", "tau", "use_linear_clip_decay",
                                  "use_linear_lr_decay", "sep_reward_weight", "nav_reward_weight", "extra_reward_multiplier", "reward_window_size",
                                  "use_ddppo", "NUM_UPDATES", "CHECKPOINT_INTERVAL", "MAX_EPISODE_STEPS", "SEED", "NUM_PROCESSES")}
-    cfg = near_target_config(use_hip_graphs=graphs, **keys)
+    cfg = near_target_config(use_hip_graphs=graphs, action_sampling="cpu_generator", **keys)
     seed = flat["SEED"] + rank * flat["NUM_PROCESSES"]
     if env_kind == "device":
         envs = ReplayVecEnv(flat["NUM_PROCESSES"], dev, seed=seed, episode_len=flat["MAX_EPISODE_STEPS"], pool=replay["pool"],
@@ -51,15 +52,10 @@ def run_m2h(d, flat, replay, env_kind, graphs, rank=0, world=1, pre=""):
         state = lambda: host.s.copy()  # noqa: E731
     tr = PPOTrainer(cfg, dev, world_rank=rank, world_size=world, envs=envs)
     tr.setup(passive_state_dict=_passive_ckpt(replay["passive_seed"]))
-    forced = torch.zeros(flat["NUM_PROCESSES"], 1, dtype=torch.int64, device=dev)
-    actions = torch.from_numpy(d[pre + "step.actions"]).to(dev)
     steps, saved = [], []
-    orig_sample, orig_step, orig_pol, orig_sep, orig_save = (CU.CustomFixedCategorical.sample, tr._collect_rollout_step, tr._update_pol, tr._update_sep,
-                                                             tr.save_checkpoint)
-    CU.CustomFixedCategorical.sample = lambda self, sample_shape=None: forced.clone()
+    orig_step, orig_pol, orig_sep = tr._collect_rollout_step, tr._update_pol, tr._update_sep
 
     def step():
-        forced.copy_(actions[len(steps)])
         n = orig_step()
         ro = tr.rollouts_pol
         s = (ro.step - 1) % ro.num_steps
@@ -88,10 +84,7 @@ def run_m2h(d, flat, replay, env_kind, graphs, rank=0, world=1, pre=""):
     tr._collect_rollout_step, tr._update_pol, tr._update_sep = step, update_pol, update_sep
     tr.save_checkpoint = lambda name: saved.append((name, len(sep)))
     cfg.CHECKPOINT_FOLDER = "unused"
-    try:
-        tr.train()
-    finally:
-        CU.CustomFixedCategorical.sample = orig_sample
+    tr.train()
     graph_replays = 0 if tr._graph_state is None else len(tr._graph_state.graphs)
     return {"steps": [steps], "pol": pol, "sep": sep, "ckpts": saved, "scalars": tr.scalars, "graphs": graph_replays, "trainer": tr,
             "state_dict": {k: v.detach().cpu() for k, v in tr.actor_critic.state_dict().items()}}
@@ -128,12 +121,12 @@ def test_far_target_training_with_ragged_episodes_matches_the_reference_run():
 @pytest.mark.parametrize("tag", ["single", "switch"])
 def test_evaluation_loop_matches_the_reference_eval_run(tag, tmp_path):
     """PPOTrainer.eval against the reference's own ``_eval_checkpoint`` (ppo_trainer.py:1015-1551) on the replay env, one process:
-    ``single`` = one policy with sampled actions (the reference's draws are fed in), ``switch`` = the far-target evaluation with
-    two policies and deterministic actions (nothing fed in: the argmax actions must coincide).  Per-step STFT-L2 distances and
-    the four per-episode aggregates the reference logs."""
+    ``single`` = one policy with sampled actions (cpu_generator mode: seed, policy construction, then one draw per step, as
+    :1031-1089 -- the reference's actions must come out of the seed alone), ``switch`` = the far-target evaluation with two
+    policies and deterministic actions (the argmax actions must coincide).  Per-step STFT-L2 distances and the four
+    per-episode aggregates the reference logs."""
     import json
     from m2h import synthetic
-    from m2h.common import utils as CU
     from m2h.envs.replay_env import ReplayHostVecEnv
     from m2h.envs.vector_env_adapter import HostVectorEnvAdapter
     from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config
@@ -141,7 +134,7 @@ def test_evaluation_loop_matches_the_reference_eval_run(tag, tmp_path):
     cfg_rec = json.loads(str(d[tag + ".config"]))
     dev = torch.device("cuda", 0)
     cfg = near_target_config(NUM_PROCESSES=1, MAX_EPISODE_STEPS=cfg_rec["MAX_EPISODE_STEPS"], SEED=cfg_rec["SEED"], use_hip_graphs=False,
-                             deterministic_eval=cfg_rec["PPO"]["deterministic_eval"],
+                             deterministic_eval=cfg_rec["PPO"]["deterministic_eval"], action_sampling="cpu_generator",
                              time_thres_for_pol_switch=cfg_rec["PPO"]["time_thres_for_pol_switch"])
     host = ReplayHostVecEnv(1, seed=cfg.SEED, episode_len=cfg.MAX_EPISODE_STEPS, pool=cfg_rec["REPLAY"]["pool"])
     tr = PPOTrainer(cfg, dev, envs=HostVectorEnvAdapter(host, dev))
@@ -157,13 +150,7 @@ def test_evaluation_loop_matches_the_reference_eval_run(tag, tmp_path):
     else:
         path = str(tmp_path / "single.pth")
         torch.save({"state_dict": ck(7), "config": {}}, path)
-        feed = iter(torch.from_numpy(want_actions).to(dev))
-        orig = CU.CustomFixedCategorical.sample
-        CU.CustomFixedCategorical.sample = lambda self, sample_shape=None: next(feed).reshape(1, 1).clone()
-        try:
-            agg = tr.eval(num_episodes=4, checkpoint_path=path, waveform_metrics=(), trace=trace)
-        finally:
-            CU.CustomFixedCategorical.sample = orig
+        agg = tr.eval(num_episodes=4, checkpoint_path=path, waveform_metrics=(), trace=trace)
     assert len(trace) == len(want_actions) == 24 and agg["num_episodes"] == 4
     assert np.array_equal(np.stack([t[0].numpy().reshape(-1) for t in trace]), want_actions)
     assert host.actions_seen == want_actions.tolist()
