@@ -537,6 +537,8 @@ typedef struct m2h_unet_weights {
   int weights_split32;        /* bf16x3 math only: down_w / up_w are in the split32 layout (m2h_split32 of the packed weights); the runner
                                  then keeps every intermediate activation in split32 too, so no kernel converts operands in its k-loop */
   int math_mode;              /* arithmetic of this call: 0 = the calling thread's (m2h_set_math_mode), 1 = fp32 MFMA, 2 = bf16x3 */
+  const void* down0_strip;    /* first-stage weights in the strip kernel's register image (m2h_pack_strip_conv1) or NULL.  With it, split32
+                                 weights and T % 64 == 0 the runner replaces the slice kernel + first encoder stage by m2h_strip_conv1_fwd */
 } m2h_unet_weights;
 
 size_t m2h_unet_fwd_workspace_bytes(int B, int F, int T);
@@ -546,11 +548,24 @@ int m2h_unet_fwd(const m2h_unet_weights* w /* host */, const float* mix, const f
                  int B, int F, int T, void* workspace, size_t workspace_bytes, m2h_stream stream);
 /* Same, recording caller-created events (hipEvent_t handles, e.g. torch.cuda.Event.cuda_event) on `stream` before the first
  * kernel and after each of the 11 kernels: events[0..11] (n_events must be 12).  Kernel i ran between events[i] and
- * events[i+1]: 0 slice, 1-5 encoder stages, 6-9 decoder stages, 10 last stage + head. */
+ * events[i+1]: 0 slice, 1-5 encoder stages, 6-9 decoder stages, 10 last stage + head.  When the strip kernel takes the slice and
+ * the first stage together (down0_strip), interval 0 is empty and interval 1 is that one kernel. */
 #define M2H_UNET_FWD_EVENTS 12
 int m2h_unet_fwd_events(const m2h_unet_weights* w /* host */, const float* mix, const float* masks, const float* cls_val, float* out,
                         int B, int F, int T, void* workspace, size_t workspace_bytes, void* const* events, int n_events,
                         m2h_stream stream);
+/* Strip-walker kernel of the first encoder stage (csrc/conv_strip.hip; bf16x3 arithmetic): the 16-way frequency slice
+ * (separator_cnn.py:85-90), for bin2mono the pre-op log1p(clamp0(mask (exp(mix) - 1))) (:77-79), the (target_class + 1) plane
+ * (:93-99, as cls_val[b] * cls_table[border class][n]) and Conv2d(4x4, s2, p1) + BN(eval) + LeakyReLU (:5-12, :101-105) in ONE
+ * launch: mix / masks [B][512][T][2] fp32 -> dst split32 NHWC [B][16][T/2][64].  A workgroup walks a strip of 32 output columns
+ * down the image with a rolling window of input rows in LDS (every input byte fetched once) and the whole weight matrix in
+ * registers.  wreg: m2h_pack_strip_conv1 of the torch weight [64][Ci >= 32][4][4] (m2h_strip_conv1_weight_bytes() bytes).
+ * F = 512, T % 64 == 0. */
+size_t m2h_strip_conv1_weight_bytes(void);
+int m2h_pack_strip_conv1(const float* w, int Ci, void* out, m2h_stream stream);
+int m2h_strip_conv1_fwd(const float* mix, const float* masks, const void* wreg, const float* scale, const float* shift,
+                        const float* cls_table, const float* cls_val, float* dst, int B, int F, int T, float slope, m2h_stream stream);
+
 /* m2h_sep_slice_input with the output written in the split32 layout when split_out != 0 (C == 2 only). */
 int m2h_sep_slice_input_fmt(const float* mix, const float* masks, float* out, int B, int F, int T, int C, int split_out, m2h_stream stream);
 

@@ -6,7 +6,7 @@ namespace m2h {
 thread_local char g_err[512] = {0};
 int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st);
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a);
-extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny, g_narrow16, g_extra_lds, g_phase_major, g_fast_loader, g_wgrad_blocks, g_tapshare, g_tap_bm, g_tap_window, g_wgrad_row3x3, g_row3x3, g_skinny_linear, g_skinny_gather, g_big_tile, g_dma, g_dma_shape, g_dma64, g_quad, g_dma_korder, g_bres, g_dma_split2;
+extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny, g_narrow16, g_extra_lds, g_phase_major, g_fast_loader, g_wgrad_blocks, g_tapshare, g_tap_bm, g_tap_window, g_wgrad_row3x3, g_row3x3, g_skinny_linear, g_skinny_gather, g_big_tile, g_dma, g_dma_shape, g_dma64, g_quad, g_dma_korder, g_bres, g_dma_split2, g_strip;
 extern thread_local int tl_math_mode;
 }  // namespace m2h
 
@@ -62,6 +62,7 @@ int m2h_debug_set(int knob, int value) {
   else if (knob == 31) g_dma_korder = value;
   else if (knob == 32) g_bres = value;
   else if (knob == 34) g_dma_split2 = value;
+  else if (knob == 35) g_strip = value;
   else return fail(-1, "debug_set: unknown knob %d", knob);
   return 0;
 }
@@ -222,13 +223,26 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
   const int fmt_last = fmt_math | (sp ? (M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT) : 0);
   int rc = mark();
   if (rc) return rc;
-  rc = m2h_sep_slice_input_fmt(mix, masks, x0, B, F, T, 2, sp, stream);
-  if (rc) return rc;
+  // slice + first encoder stage as one strip-walker launch (csrc/conv_strip.hip) where its shape conditions hold
+  const bool strip0 = sp && wts->down0_strip != nullptr && T % 64 == 0 && g_strip >= 0;
+  if (!strip0) {
+    rc = m2h_sep_slice_input_fmt(mix, masks, x0, B, F, T, 2, sp, stream);
+    if (rc) return rc;
+  }
   if ((rc = mark())) return rc;
   int h = F / 16, w = T;
   const float* cur = x0;
   for (int i = 0; i < 5; ++i) {
     M2H_REQUIRE(h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "unet_fwd: stage %d input %d x %d", i, h, w);
+    if (i == 0 && strip0) {
+      if ((rc = m2h_strip_conv1_fwd(mix, masks, wts->down0_strip, wts->down_scale[0], wts->down_shift[0], wts->cls_table, cls_val, e[0], B, F, T,
+                                    0.2f, stream)))
+        return rc;
+      if ((rc = mark())) return rc;
+      cur = e[0];
+      h /= 2; w /= 2;
+      continue;
+    }
     m2h_conv_args a = down_args(cur, wts->down_w[i], wts->down_scale[i], wts->down_shift[i], i == 0 ? wts->cls_table : nullptr,
                                 i == 0 ? cls_val : nullptr, e[i], B, h, w, kEnc[i], kEnc[i + 1]);
     a.workspace = sk; a.workspace_bytes = skb; a.operand_format = fmt_mid;

@@ -1,0 +1,580 @@
+// Strip-walker kernels (gfx950, bf16x3 math, split32 tensors): the two HBM-bound ends of the separator U-Nets at batch --
+//   * conv1_strip_kernel      the 16-way frequency slice (+ the bin2mono pre-op) FUSED with the first encoder stage
+//                             Conv2d(32(+class plane) -> 64, 4x4, s2, p1) + BN(eval) + LeakyReLU   (separator_cnn.py:73-105)
+//   * convT_last_strip_kernel the last decoder stage ConvTranspose2d(64 + 64 skip -> 32 | 16, 4x4, s2, p1) + BN(eval) + ReLU with
+//                             the 1x1 head and the de-sliced BHWC store                            (separator_cnn.py:128-135,153-168)
+// Both layers have a short reduction (K = 512) against a large image, so they are bound by bytes, not by the matrix pipe: at the
+// benchmark shape (B = 256, 512 x 256) the first stage reads 268 MB (536 MB with masks) and writes 134 MB for 34 GFLOP, the last
+// reads 268 MB and writes 268 / 134 MB for 69 / 34 GFLOP.  The tiled engines re-stage every input pixel once per tap that touches
+// it (4 x) and re-read the weights per tile; the slice was a separate 268 MB round trip through HBM.
+//
+// Structure shared by both kernels.  A workgroup owns a STRIP of 32 output columns of one image and walks down its rows with a
+// rolling window of input rows in LDS, so every input byte is fetched from global memory once per workgroup (+ a 2-column halo):
+//   * the next step's input rows are loaded into REGISTERS at the top of a step (plain 16-byte global loads, in flight under the
+//     step's MFMAs) and written to the LDS ring at its end -- converted on the way for the first stage (fp32 BHWC -> bf16 hi / lo
+//     in the kernel's own channel order: that IS the slice);
+//   * the layer's whole weight matrix lives in REGISTERS for the kernel's lifetime: 128 KB (first stage) / 256 | 128 KB (last
+//     stage) spread over the workgroup's waves as 16 B-fragments of v_mfma_f32_16x16x32_bf16 (hi + lo = 128 VGPRs per wave); a
+//     wave owns 16 output channels (first stage) or one sub-pixel phase x 16 channels (last stage) and multiplies EVERY pixel of
+//     the strip row against them.  No weight traffic in the loop at all;
+//   * A fragments come from the LDS patch: pixel records of 128 B ([hi 32 ch | lo 32 ch], eight 16-byte pieces), consecutive
+//     pixels of a plane 128 B apart, read with ds_read_b128 at any pixel shift without bank conflicts: piece j of pixel i sits at
+//     slot (j' + (i >> 1)) & 7 (j' = 0,4,1,5 for the hi pieces, 2,6,3,7 for the lo ones), and MFMA row m of a 16-pixel fragment is
+//     pixel RHO(m) of it (rows 8-11 and 12-15 swapped) -- with the lane groups a ds_read_b128 is served in ({0-3, 12-15, 20-27},
+//     ...: MI355X_MICROARCH.md, LDS) every group then covers the sixteen 16-byte bank slots exactly once;
+//   * the stride-2 first stage keeps even and odd input columns in two planes, so a tap's pixels are consecutive records;
+//   * results leave through an LDS image as whole contiguous runs (16 bytes per lane).
+// Jobs (image, strip) are dealt to a persistent grid of two workgroups per CU (the second covers the first's barriers).
+#include <type_traits>
+
+#include "igemm_common.h"
+
+namespace m2h {
+
+int g_strip = 0;   // m2h_debug_set 35: -1 = the runner never takes the strip-walker kernels (A/B against the tiled engines)
+
+namespace {
+
+constexpr int SW = 32;            // output columns of a strip
+constexpr int PX = SW + 2;        // staged pixel records per plane (one halo record each side)
+constexpr int PLANE = PX * 128;   // bytes of a plane
+
+__device__ __forceinline__ int rho16(int m) { return m < 8 ? m : (m < 12 ? m + 4 : m - 4); }
+// byte offset of piece-slot `ps` of pixel record i inside a plane
+__device__ __forceinline__ int px_addr(int i, int ps) { return i * 128 + (((ps + (i >> 1)) & 7) << 4); }
+__device__ __forceinline__ int pslot_hi(int kg) { return (kg >> 1) + ((kg & 1) << 2); }   // 0, 4, 1, 5
+__device__ __forceinline__ int pslot_lo(int kg) { return 2 + (kg >> 1) + ((kg & 1) << 2); }   // 2, 6, 3, 7
+
+__device__ __forceinline__ f32x4 mfma16(const f32x4& a, const f32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// fp32 -> (bf16 hi, bf16 lo) with x = hi + lo to 2^-17 relative (the split32 convention of the engines)
+__device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
+  hi = __builtin_convertvector(v, bf16x4);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// First encoder stage fused with the slice.
+//   input   mix / masks [B][512][T][2] fp32 (BHWC as the reference hands it over); network pixel (b, h, w) has the 32 channels
+//           (c, s) = mix[b][s * 32 + h][w][c]  (separator_cnn.py:85-90)
+//   output  split32 NHWC [B][16][T/2][64]
+// K order inside a tap: k' = kg * 8 + sb * 4 + t * 2 + c  <->  s = 4 kg + 2 t + sb, channel c * 16 + s of the reference: what a
+// loader lane holds after two 16-byte loads of two frequency rows is then one aligned 8-byte piece of a pixel record.  The weights
+// are packed to match (m2h_pack_strip_conv1).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct StripConv1P {
+  const float* mix;
+  const float* masks;
+  const f32x4* wreg;        // [wave 4][tap 16][hi, lo][lane 64] 16-byte B fragments
+  const float* scale;
+  const float* shift;
+  const float* cls_table;   // [9][64] or null
+  const float* cls_val;     // [B]
+  float* dst;
+  int B, T, Wq, strips, jobs;
+  float slope;
+};
+
+template <bool MASKED>
+__global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p) {
+  constexpr int ROW = 2 * PLANE;   // a row slot: even-column plane, odd-column plane
+  __shared__ __attribute__((aligned(1024))) char s_ring[4 * ROW];
+  __shared__ __attribute__((aligned(16))) char s_out[SW * 256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kg = lane >> 4;
+
+  // ---- the layer's weights: this wave's 16 output channels, all 16 taps ----
+  f32x4 Bh[16], Bl[16];
+  {
+    const f32x4* w = p.wreg + (size_t)wave * (16 * 2 * 64) + lane;
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
+      Bh[tap] = w[(tap * 2 + 0) * 64];
+      Bl[tap] = w[(tap * 2 + 1) * 64];
+    }
+  }
+  // ---- A fragment addresses inside a row slot: input column 2 r + tw - 1 = patch column 2 (r - r0) + tw + 1 ----
+  int a_hi[2][4], a_lo[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int tw = 0; tw < 4; ++tw) {
+      const int i = 16 * mt + rho16(m) + ((tw + 1) >> 1);
+      const int pl = ((tw + 1) & 1) * PLANE;
+      a_hi[mt][tw] = pl + px_addr(i, pslot_hi(kg));
+      a_lo[mt][tw] = pl + px_addr(i, pslot_lo(kg));
+    }
+  // ---- epilogue constants of this lane's output channel ----
+  const int n = wave * 16 + m;
+  const float sc = p.scale[n], sh = p.shift[n];
+  const int gp = kg == 2 ? 3 : (kg == 3 ? 2 : kg);   // accumulator rows 4 kg + j are pixels 4 gp + j of the fragment (RHO)
+  const int o_word = (n >> 5) * 128 + ((n & 1) ? 64 : 0) + ((n & 31) >> 1) * 4;   // this lane's word of a split32 pixel record
+  // ---- loader lanes: wave = kg of the pieces it writes; lane = (sb, pixel pair ii); halo lanes 0..15 = (h, t, sb, side) ----
+  const int sb = lane >> 5, ii = lane & 31;
+  const int hh = (lane >> 3) & 1, ht = (lane >> 2) & 1, hsb = (lane >> 1) & 1, hside = lane & 1;
+  const int w_hi = px_addr(ii + 1, pslot_hi(wave)) + sb * 8, w_lo = px_addr(ii + 1, pslot_lo(wave)) + sb * 8;
+  const int hw_i = hside ? PX - 1 : 0;
+  const int hw_hi = px_addr(hw_i, pslot_hi(wave)) + hsb * 8 + ht * 4, hw_lo = px_addr(hw_i, pslot_lo(wave)) + hsb * 8 + ht * 4;
+
+  for (int job = blockIdx.x; job < p.jobs; job += gridDim.x) {
+    const int b = job / p.strips;
+    const int r0 = (job - b * p.strips) * SW;
+    const size_t img = (size_t)b * 512 * p.T * 2;
+    const bool has_l = r0 > 0, has_r = r0 + SW < p.Wq;
+    const float cv = p.cls_table != nullptr ? p.cls_val[b] : 0.f;
+
+    f32x4 pre[2][2], preh;          // prefetched pair of rows: [h][t] main float4s and the halo float4
+    f32x4 prm[2][2], prmh;          // the masks beside them (MASKED)
+    auto load_pair = [&](int k) {   // rows 2k-1, 2k of the sliced image -> registers
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int hi_ = 2 * k - 1 + h;
+        const bool okr = (unsigned)hi_ < 32u;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int s = 4 * wave + 2 * t + sb;
+          const size_t off = img + ((size_t)(s * 32 + hi_) * p.T + 2 * r0 + 2 * ii) * 2;
+          pre[h][t] = okr ? *reinterpret_cast<const f32x4*>(p.mix + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (MASKED) prm[h][t] = okr ? *reinterpret_cast<const f32x4*>(p.masks + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      preh = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (MASKED) prmh = preh;
+      if (lane < 16) {
+        const int hi_ = 2 * k - 1 + hh;
+        const int s = 4 * wave + 2 * ht + hsb;
+        const bool ok = (unsigned)hi_ < 32u && (hside ? has_r : has_l);
+        const size_t off = img + ((size_t)(s * 32 + hi_) * p.T + 2 * r0 + (hside ? 2 * SW : -2)) * 2;
+        if (ok) {
+          preh = *reinterpret_cast<const f32x4*>(p.mix + off);
+          if constexpr (MASKED) prmh = *reinterpret_cast<const f32x4*>(p.masks + off);
+        }
+      }
+    };
+    auto store_pair = [&](int k) {   // registers -> row slots (2k) & 3, (2k + 1) & 3, converted to bf16 hi / lo records
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        char* row = s_ring + ((2 * k + h) & 3) * ROW;
+        f32x4 v0 = pre[h][0], v1 = pre[h][1];
+        if constexpr (MASKED) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v0[e] = masked_log_mag(v0[e], prm[h][0][e]);
+            v1[e] = masked_log_mag(v1[e], prm[h][1][e]);
+          }
+          if ((unsigned)(2 * k - 1 + h) >= 32u) {   // a padding row stays zero whatever the pre-op makes of zeros
+            v0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            v1 = v0;
+          }
+        }
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {   // the pair's even column -> plane 0, odd column -> plane 1
+          const f32x4 v = {v0[2 * px], v0[2 * px + 1], v1[2 * px], v1[2 * px + 1]};
+          bf16x4 hi, lo;
+          split4(v, hi, lo);
+          *reinterpret_cast<bf16x4*>(row + px * PLANE + w_hi) = hi;
+          *reinterpret_cast<bf16x4*>(row + px * PLANE + w_lo) = lo;
+        }
+      }
+      if (lane < 16) {
+        char* row = s_ring + ((2 * k + hh) & 3) * ROW;
+        f32x4 v = preh;
+        if constexpr (MASKED) {
+          const bool ok = (unsigned)(2 * k - 1 + hh) < 32u && (hside ? has_r : has_l);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ok ? masked_log_mag(v[e], prmh[e]) : 0.f;
+        }
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          *reinterpret_cast<bf16x2_t*>(row + px * PLANE + hw_hi) = bf16x2_t{hi[2 * px], hi[2 * px + 1]};
+          *reinterpret_cast<bf16x2_t*>(row + px * PLANE + hw_lo) = bf16x2_t{lo[2 * px], lo[2 * px + 1]};
+        }
+      }
+    };
+
+    // ---- prologue: rows -1 .. 2 ----
+    load_pair(0);
+    store_pair(0);
+    load_pair(1);
+    store_pair(1);
+    __syncthreads();
+
+    // one output row q (QP = q & 1 fixes the ring slots at compile time): rows 2q-1 .. 2q+2 = slots (2 QP + th) & 3
+    auto step = [&](int q, auto qpc) {
+      constexpr int QP = decltype(qpc)::value;
+      if (q + 2 <= 16) load_pair(q + 2);   // consumed behind this step's MFMAs
+      float ct[3] = {0.f, 0.f, 0.f};
+      if (p.cls_table != nullptr) {
+        const int ch = q == 0 ? 0 : (q == 15 ? 2 : 1);
+#pragma unroll
+        for (int cw = 0; cw < 3; ++cw) ct[cw] = p.cls_table[(ch * 3 + cw) * 64 + n];
+      }
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int th = 0; th < 4; ++th) {
+        const char* row = s_ring + ((2 * QP + th) & 3) * ROW;
+#pragma unroll
+        for (int tw = 0; tw < 4; ++tw) {
+          const int tap = th * 4 + tw;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const f32x4 ah = *reinterpret_cast<const f32x4*>(row + a_hi[mt][tw]);
+            const f32x4 al = *reinterpret_cast<const f32x4*>(row + a_lo[mt][tw]);
+            acc[mt] = mfma16(al, Bh[tap], acc[mt]);
+            acc[mt] = mfma16(ah, Bl[tap], acc[mt]);
+            acc[mt] = mfma16(ah, Bh[tap], acc[mt]);
+          }
+        }
+      }
+      // ---- epilogue: class plane, BN, LeakyReLU, split32 record into the out image ----
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int po = 16 * mt + 4 * gp + j;
+          const int r = r0 + po;
+          float v = acc[mt][j];
+          const float tv = r == 0 ? ct[0] : (r == p.Wq - 1 ? ct[2] : ct[1]);
+          v += cv * tv;
+          v = v * sc + sh;
+          v = v > 0.f ? v : v * p.slope;
+          const __bf16 hb = (__bf16)v;
+          const __bf16 lb = (__bf16)(v - (float)hb);
+          const unsigned h16 = __builtin_bit_cast(unsigned short, hb), l16 = __builtin_bit_cast(unsigned short, lb);
+          const unsigned both = h16 | (l16 << 16);
+          const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)both, 0xB1, 0xF, 0xF, true);   // lane ^ 1: channel n ^ 1
+          *reinterpret_cast<unsigned*>(s_out + po * 256 + o_word) = (n & 1) ? ((other >> 16) | (l16 << 16)) : (h16 | (other << 16));
+        }
+      __syncthreads();   // every wave is done with rows 2q-1, 2q; the out image is complete
+      {
+        float* drow = p.dst + ((size_t)(b * 16 + q) * p.Wq + r0) * 64;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int idx = tid + 256 * u;
+          *reinterpret_cast<f32x4*>(drow + idx * 4) = *reinterpret_cast<const f32x4*>(s_out + idx * 16);
+        }
+      }
+      if (q + 2 <= 16) store_pair(q + 2);   // into the slots rows 2q-1, 2q leave
+      __syncthreads();
+    };
+    for (int q = 0; q < 16; q += 2) {
+      step(q, std::integral_constant<int, 0>{});
+      step(q + 1, std::integral_constant<int, 1>{});
+    }
+  }
+}
+
+// weights [Co = 64][Ci >= 32][4][4] fp32 (torch Conv2d layout; input channel c * 16 + s) -> the kernel's register image
+__global__ void pack_strip_conv1_kernel(const float* __restrict__ w, int Ci, f32x4* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (wave, tap, part, lane)
+  if (idx >= 4 * 16 * 2 * 64) return;
+  const int lane = idx & 63, part = (idx >> 6) & 1, tap = (idx >> 7) & 15, wave = idx >> 11;
+  const int n = wave * 16 + (lane & 15), kg = lane >> 4;
+  const int kh = tap >> 2, kw = tap & 3;
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int sb = e >> 2, t = (e >> 1) & 1, c = e & 1;
+    const int s = 4 * kg + 2 * t + sb;
+    const float x = w[(((size_t)n * Ci + (c * 16 + s)) * 4 + kh) * 4 + kw];
+    const __bf16 hi = (__bf16)x;
+    o[e] = part == 0 ? hi : (__bf16)(x - (float)hi);
+  }
+  out[idx] = __builtin_bit_cast(f32x4, o);
+}
+
+int launch_strip_conv1(const float* mix, const float* masks, const void* wreg, const float* scale, const float* shift, const float* cls_table,
+                       const float* cls_val, float* dst, int B, int T, float slope, hipStream_t st) {
+  StripConv1P p;
+  p.mix = mix; p.masks = masks; p.wreg = static_cast<const f32x4*>(wreg); p.scale = scale; p.shift = shift;
+  p.cls_table = cls_table; p.cls_val = cls_val; p.dst = dst;
+  p.B = B; p.T = T; p.Wq = T / 2; p.strips = p.Wq / SW; p.jobs = B * p.strips; p.slope = slope;
+  const int grid = p.jobs < 512 ? p.jobs : 512;
+  if (masks != nullptr) hipLaunchKernelGGL((conv1_strip_kernel<true>), dim3(grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((conv1_strip_kernel<false>), dim3(grid), dim3(256), 0, st, p);
+  return launch_status("strip_conv1");
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Last decoder stage + head.
+//   inputs  src0 (the previous decoder stage) and src1 (the first encoder stage's skip), split32 NHWC [B][Hq][Wq][64] each: the
+//           concatenation (separator_cnn.py:160-161) is the order of the four 32-channel chunks
+//   weights the engines' split32 transposed-conv pack [phase 4][N][tap 4][128] (m2h_pack_convT_weight + m2h_split32), read once
+//           into registers: wave (phase, n-tile) holds its 4 taps x 4 chunks
+//   output  BHWC [B][16 * 2 Hq][2 Wq][N / 16] fp32 after BN(eval) + ReLU, the 1x1 head (:134) and the de-slice (:163-168)
+// Sub-pixel phase (ph, pw) of output block (q, r) is pixel (2q + ph, 2r + pw); its tap (th, tw) reads input pixel
+// (q + th (2 ph - 1), r + tw (2 pw - 1)) (conv_igemm.hip).  A wave therefore reads two row slots and two column shifts only.
+// The head runs on the matrix pipe too: the activated tile goes to LDS as bf16 hi / lo records (all N channels of a pixel side by
+// side, whichever wave made them), wave (phase, 16-position half) multiplies its records with the head matrix (bf16x3 like the
+// rest) and writes the de-sliced image Z[s][row][column][c], rotated by 2 s floats per row against bank conflicts; the
+// workgroup copies Z out as 512- / 256-byte runs.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct StripLastP {
+  const float* src0;
+  const float* src1;
+  const float* w;
+  const float* scale;
+  const float* shift;
+  const float* head_w;   // [N][N] fp32
+  const float* head_b;   // [N]
+  float* dst;
+  int B, Hq, Wq, strips, jobs;
+  float slope;
+};
+
+template <int N>
+__global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kernel(const StripLastP p) {
+  constexpr int NT = N / 16, NW = 4 * NT, NTH = 64 * NW;
+  constexpr int Cc = N / 16;                 // output channels after the de-slice
+  constexpr int ROWB = 4 * PLANE;            // a row slot: four 32-channel chunk planes
+  constexpr int NF4 = 2 * PX * 16;           // 16-byte pieces of one input row of the strip (both sources)
+  constexpr int LPT = (NF4 + NTH - 1) / NTH; // loads per thread and row
+  constexpr int ZROW = 64 * Cc;              // floats of one de-sliced output run
+  __shared__ __attribute__((aligned(1024))) char s_ring[3 * ROWB];
+  __shared__ __attribute__((aligned(1024))) char s_y[4 * SW * 128];
+  __shared__ __attribute__((aligned(16))) float s_z[32 * ZROW];
+  __shared__ __attribute__((aligned(16))) f32x4 s_wh[NT * 2 * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int phase = wave / NT, nt = wave % NT;     // main loop role
+  const int ph = phase >> 1, pw = phase & 1;
+  const int sy = 2 * ph - 1, sx = 2 * pw - 1;
+  const int m = lane & 15, kg = lane >> 4;
+  const int gp = kg == 2 ? 3 : (kg == 3 ? 2 : kg);
+
+  // ---- weights of (phase, n-tile): 4 taps x 4 chunks, hi and lo ----
+  f32x4 Bh[16], Bl[16];
+  {
+    const char* wrow = reinterpret_cast<const char*>(p.w) + ((size_t)(phase * N + nt * 16 + m) * 512) * 4 + kg * 16;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {   // t = tap * 4 + chunk: 128 bytes apart
+      Bh[t] = *reinterpret_cast<const f32x4*>(wrow + t * 128);
+      Bl[t] = *reinterpret_cast<const f32x4*>(wrow + t * 128 + 64);
+    }
+  }
+  // ---- head matrix as B fragments in LDS (lane-linear), Y cleared once (N = 16 never writes its upper channel pieces) ----
+  for (int i = tid; i < NT * 64; i += NTH) {
+    const int hn = i >> 6, l = i & 63;
+    const int n2 = hn * 16 + (l & 15), k0 = (l >> 4) * 8;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = (k0 + e) < N ? p.head_w[n2 * N + k0 + e] : 0.f;
+      hi[e] = (__bf16)x;
+      lo[e] = (__bf16)(x - (float)hi[e]);
+    }
+    s_wh[(hn * 2 + 0) * 64 + l] = __builtin_bit_cast(f32x4, hi);
+    s_wh[(hn * 2 + 1) * 64 + l] = __builtin_bit_cast(f32x4, lo);
+  }
+  for (int i = tid; i < 4 * SW * 8; i += NTH) reinterpret_cast<f32x4*>(s_y)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- A fragment offsets inside a row slot (column shifts 0 and sx), without the chunk plane ----
+  int a_off[2][2][2];   // [mt][tw][hi, lo]
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int tw = 0; tw < 2; ++tw) {
+      const int i = 16 * mt + rho16(m) + 1 + tw * sx;
+      a_off[mt][tw][0] = px_addr(i, pslot_hi(kg));
+      a_off[mt][tw][1] = px_addr(i, pslot_lo(kg));
+    }
+  // ---- epilogue constants ----
+  const int n = nt * 16 + m;
+  const float sc = p.scale[n], sh = p.shift[n];
+  const int y_word = phase * (SW * 128) + ((n & 7) >> 1) * 4;   // + px_addr(position, piece slot of channel n: hi for even n, lo for odd)
+  const int y_ps = (n & 1) ? pslot_lo(n >> 3) : pslot_hi(n >> 3);
+  // head role: wave -> (phase, 16-position half) for N = 32, (phase, both halves) for N = 16
+  const int h_phase = N == 32 ? (wave >> 1) : wave;
+  const int h_ph = h_phase >> 1, h_pw = h_phase & 1;
+  float hb[NT];
+#pragma unroll
+  for (int hn = 0; hn < NT; ++hn) hb[hn] = p.head_b[hn * 16 + m];
+  // ---- loader: this thread's pieces of an input row ----
+  int l_lds[LPT], l_glb[LPT], l_px[LPT];
+#pragma unroll
+  for (int u = 0; u < LPT; ++u) {
+    const int f = tid + NTH * u;
+    const int src = f / (PX * 16), rem = f - src * (PX * 16);
+    const int px = rem >> 4, pc = rem & 15;
+    const int chunk = src * 2 + (pc >> 3), piece = pc & 7;
+    l_px[u] = f < NF4 ? px : -1;
+    l_glb[u] = src * 2 + 0;   // placeholder, set below
+    l_lds[u] = chunk * PLANE + px_addr(px, piece < 4 ? pslot_hi(piece) : pslot_lo(piece - 4));
+    l_glb[u] = (src << 28) | (px * 64 + pc * 4);   // source in the top bits, float offset from the strip row's first record
+  }
+
+  for (int job = blockIdx.x; job < p.jobs; job += gridDim.x) {
+    const int b = job / p.strips;
+    const int r0 = (job - b * p.strips) * SW;
+    const bool has_l = r0 > 0, has_r = r0 + SW < p.Wq;
+
+    f32x4 pre[LPT];
+    auto load_row = [&](int h) {
+      const bool okr = (unsigned)h < (unsigned)p.Hq;
+      const long rowoff = ((long)(b * p.Hq + h) * p.Wq + (r0 - 1)) * 64;
+#pragma unroll
+      for (int u = 0; u < LPT; ++u) {
+        const int px = l_px[u];
+        const bool ok = okr && px >= 0 && (px > 0 || has_l) && (px < PX - 1 || has_r);
+        const float* base = (l_glb[u] >> 28) ? p.src1 : p.src0;
+        pre[u] = ok ? *reinterpret_cast<const f32x4*>(base + rowoff + (l_glb[u] & 0x0fffffff)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    auto store_row = [&](int h) {
+      char* row = s_ring + ((h + 3) % 3) * ROWB;
+#pragma unroll
+      for (int u = 0; u < LPT; ++u)
+        if (l_px[u] >= 0) *reinterpret_cast<f32x4*>(row + l_lds[u]) = pre[u];
+    };
+
+    // ---- prologue: rows -1, 0, 1 ----
+    load_row(-1);
+    store_row(-1);
+    load_row(0);
+    store_row(0);
+    load_row(1);
+    store_row(1);
+    __syncthreads();
+
+    for (int q = 0; q < p.Hq; ++q) {
+      load_row(q + 2);   // consumed behind this step's MFMAs (a row past the image is zeros)
+      const int base0 = ((q + 3) % 3) * ROWB, basey = ((q + sy + 3) % 3) * ROWB;
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int th = 0; th < 2; ++th)
+#pragma unroll
+        for (int tw = 0; tw < 2; ++tw) {
+          const int rb = th ? basey : base0;
+          int ad[2][2];
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            ad[mt][0] = rb + a_off[mt][tw][0];
+            ad[mt][1] = rb + a_off[mt][tw][1];
+          }
+#pragma unroll
+          for (int kc = 0; kc < 4; ++kc) {
+            const int t = (th * 2 + tw) * 4 + kc;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              const f32x4 ah = *reinterpret_cast<const f32x4*>(s_ring + kc * PLANE + ad[mt][0]);
+              const f32x4 al = *reinterpret_cast<const f32x4*>(s_ring + kc * PLANE + ad[mt][1]);
+              acc[mt] = mfma16(al, Bh[t], acc[mt]);
+              acc[mt] = mfma16(ah, Bl[t], acc[mt]);
+              acc[mt] = mfma16(ah, Bh[t], acc[mt]);
+            }
+          }
+        }
+      // ---- BN + ReLU, the activated tile as bf16 hi / lo records in Y[phase][position] ----
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int po = 16 * mt + 4 * gp + j;
+          float v = acc[mt][j] * sc + sh;
+          v = v > 0.f ? v : v * p.slope;
+          const __bf16 hbv = (__bf16)v;
+          const __bf16 lbv = (__bf16)(v - (float)hbv);
+          const unsigned h16 = __builtin_bit_cast(unsigned short, hbv), l16 = __builtin_bit_cast(unsigned short, lbv);
+          const unsigned both = h16 | (l16 << 16);
+          const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)both, 0xB1, 0xF, 0xF, true);
+          *reinterpret_cast<unsigned*>(s_y + y_word + px_addr(po, y_ps)) = (n & 1) ? ((other >> 16) | (l16 << 16)) : (h16 | (other << 16));
+        }
+      __syncthreads();   // Y complete; every wave is done with row q - 1
+      // ---- head: z = Wh y + hb for this wave's (phase, positions), de-sliced into Z ----
+      {
+        const char* yp = s_y + h_phase * (SW * 128);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          if (N == 32 && mt != (wave & 1)) continue;   // wave-uniform
+          const int pos = 16 * mt + rho16(m);
+          const f32x4 ah = *reinterpret_cast<const f32x4*>(yp + px_addr(pos, pslot_hi(kg)));
+          const f32x4 al = *reinterpret_cast<const f32x4*>(yp + px_addr(pos, pslot_lo(kg)));
+          f32x4 z[NT];
+#pragma unroll
+          for (int hn = 0; hn < NT; ++hn) {
+            const f32x4 bh = s_wh[(hn * 2 + 0) * 64 + lane], bl = s_wh[(hn * 2 + 1) * 64 + lane];
+            z[hn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            z[hn] = mfma16(al, bh, z[hn]);
+            z[hn] = mfma16(ah, bl, z[hn]);
+            z[hn] = mfma16(ah, bh, z[hn]);
+          }
+          // lane (s = m, rows 4 kg + j): positions 16 mt + 4 gp + j, output column 2 position + pw, run (s, ph)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ow = 2 * (16 * mt + 4 * gp + j) + h_pw;
+            float* zr = s_z + (m * 2 + h_ph) * ZROW + ((ow * Cc + 2 * m) & (ZROW - 1));
+            if constexpr (N == 32) *reinterpret_cast<float2*>(zr) = float2{z[0][j] + hb[0], z[1][j] + hb[1]};
+            else *zr = z[0][j] + hb[0];
+          }
+        }
+      }
+      store_row(q + 2);   // into the slot row q - 1 leaves
+      __syncthreads();    // Z complete, ring updated
+      {
+        // 32 runs (s, row parity) of 64 output columns: ZROW floats = 512 / 256 contiguous bytes each
+        constexpr int F2 = 32 * ZROW / 2;   // float2 pieces
+#pragma unroll
+        for (int u = 0; u < F2 / NTH; ++u) {
+          const int idx = tid + NTH * u;
+          const int rs = idx / (ZROW / 2), c2 = idx - rs * (ZROW / 2);
+          const int s = rs >> 1, oh = 2 * q + (rs & 1);
+          const float2 v = *reinterpret_cast<const float2*>(s_z + rs * ZROW + ((2 * c2 + 2 * s) & (ZROW - 1)));
+          float* d = p.dst + (((size_t)b * (32 * p.Hq) + (size_t)s * (2 * p.Hq) + oh) * (2 * p.Wq) + 2 * r0) * Cc + 2 * c2;
+          *reinterpret_cast<float2*>(d) = v;
+        }
+      }
+    }
+    __syncthreads();   // the last copy-out has read Z / the ring is free for the next job's prologue
+  }
+}
+
+int launch_strip_last(const StripLastP& p, int N, hipStream_t st) {
+  if (N == 32) hipLaunchKernelGGL((convT_last_strip_kernel<32>), dim3(p.jobs < 256 ? p.jobs : 256), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL((convT_last_strip_kernel<16>), dim3(p.jobs < 512 ? p.jobs : 512), dim3(256), 0, st, p);
+  return launch_status("strip_convT_last");
+}
+
+}  // namespace m2h
+
+using namespace m2h;
+
+extern "C" {
+
+size_t m2h_strip_conv1_weight_bytes(void) { return (size_t)4 * 16 * 2 * 64 * 16; }
+
+int m2h_pack_strip_conv1(const float* w, int Ci, void* out, m2h_stream stream) {
+  M2H_REQUIRE(w && out && Ci >= 32, "pack_strip_conv1: bad arguments");
+  hipLaunchKernelGGL(pack_strip_conv1_kernel, dim3(32), dim3(256), 0, as_stream(stream), w, Ci, static_cast<f32x4*>(out));
+  return launch_status("pack_strip_conv1");
+}
+
+int m2h_strip_conv1_fwd(const float* mix, const float* masks, const void* wreg, const float* scale, const float* shift,
+                        const float* cls_table, const float* cls_val, float* dst, int B, int F, int T, float slope, m2h_stream stream) {
+  M2H_REQUIRE(mix && wreg && scale && shift && dst, "strip_conv1: null pointer");
+  M2H_REQUIRE(B > 0 && F == 512 && T >= 64 && T % 64 == 0, "strip_conv1: F must be 512 and T a multiple of 64 (got %d x %d)", F, T);
+  M2H_REQUIRE((cls_table == nullptr) == (cls_val == nullptr), "strip_conv1: class table / value mismatch");
+  M2H_REQUIRE((size_t)B * 512 * T * 2 < (1ull << 31), "strip_conv1: input too large for 32-bit pixel arithmetic");
+  return launch_strip_conv1(mix, masks, wreg, scale, shift, cls_table, cls_val, dst, B, T, slope, as_stream(stream));
+}
+
+int m2h_strip_last_fwd(const float* x, const float* skip, const float* wp_split32, const float* scale, const float* shift, const float* head_w,
+                       const float* head_b, float* out, int B, int H, int W, int Co, m2h_stream stream) {
+  M2H_REQUIRE(x && skip && wp_split32 && scale && shift && head_w && head_b && out, "strip_last: null pointer");
+  M2H_REQUIRE(B > 0 && H >= 1 && W >= 32 && W % 32 == 0 && (Co == 32 || Co == 16), "strip_last: W must be a multiple of 32 and Co 32 or 16 (got %d x %d, %d)", H, W, Co);
+  M2H_REQUIRE((long)B * H * W * 64 < (1L << 31), "strip_last: input too large for 32-bit pixel arithmetic");
+  StripLastP p;
+  p.src0 = x; p.src1 = skip; p.w = wp_split32; p.scale = scale; p.shift = shift; p.head_w = head_w; p.head_b = head_b; p.dst = out;
+  p.B = B; p.Hq = H; p.Wq = W; p.strips = W / SW; p.jobs = B * p.strips; p.slope = 0.f;
+  return launch_strip_last(p, Co, as_stream(stream));
+}
+
+}  // extern "C"

@@ -47,17 +47,6 @@ __global__ __launch_bounds__(256) void sep_slice_input_kernel(const float* __res
 // reads with 4-byte gathers (64-byte pieces per wave instruction) and ran at 3.5 TB/s of the ~5.5 TB/s a copy reaches.
 typedef __bf16 bf16x4_s __attribute__((ext_vector_type(4)));
 
-// log1p(max(m * (exp(x) - 1), 0)) (separator_cnn.py:77-79) on the hardware transcendental units: v_exp_f32 / v_log_f32 (~1 ulp)
-// and log1p(z) = log(u) * z / (u - 1), u = fl(1 + z), which gives back the bits that rounding 1 + z loses (exact z when u == 1).
-// The library expf + log1pf cost ~100 instructions per element and made the masked slice ALU-bound (230 us at the headline
-// shape against 80 us for the unmasked one); relative error of this form ~3e-7, four orders inside the 1e-3 contract.
-__device__ __forceinline__ float masked_log_mag(float x, float m) {
-  const float z = fmaxf(m * (__expf(x) - 1.f), 0.f);
-  const float u = 1.f + z;
-  const float d = u - 1.f;
-  return d == 0.f ? z : __logf(u) * __fdividef(z, d);
-}
-
 __global__ __launch_bounds__(256) void sep_slice_input_c2_kernel(const float* __restrict__ mix, const float* __restrict__ masks,
                                                                  float* __restrict__ out, int B, int F, int T, int split_out) {
   constexpr int TT = 64, LD = 132;

@@ -16,7 +16,7 @@ CSRC = os.path.join(_PKG_ROOT, "csrc")
 INCLUDE = os.path.join(_REPO_ROOT, "include")
 # M2H_LIB: kernel-tuning override -- load an experimental build of the same C-ABI (tools/build_variant.sh) instead of the in-tree one
 LIB_PATH = os.environ.get("M2H_LIB") or os.path.join(_HERE, "libm2h.so")
-SOURCES = ["conv_igemm.hip", "conv_dma.hip", "convt_quad.hip", "conv_bres.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "rollout_fused.hip", "pack_batch.hip", "fftconv.hip", "api.hip"]
+SOURCES = ["conv_igemm.hip", "conv_dma.hip", "convt_quad.hip", "conv_strip.hip", "conv_bres.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "rollout_fused.hip", "pack_batch.hip", "fftconv.hip", "api.hip"]
 
 _lock = threading.Lock()
 _lib = None
@@ -103,6 +103,7 @@ class UnetWeights(ctypes.Structure):
         ("n_out", ctypes.c_int),
         ("weights_split32", ctypes.c_int),
         ("math_mode", ctypes.c_int),
+        ("down0_strip", ctypes.c_void_p),
     ]
 
 
@@ -212,6 +213,9 @@ SIGNATURES = {
     "m2h_unet_fwd": [ctypes.POINTER(UnetWeights), _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P],
     "m2h_unet_fwd_events": [ctypes.POINTER(UnetWeights), _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P, _I, _P],
     "m2h_sep_slice_input_fmt": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "m2h_strip_conv1_weight_bytes": [],
+    "m2h_pack_strip_conv1": [_P, _I, _P, _P],
+    "m2h_strip_conv1_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
     "m2h_gather_envs": [_P, _P, _P, _I, _I, _I, _Z, _P],
     "m2h_gru_step": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_episode_stats_update": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
@@ -249,7 +253,7 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_size_t if name.endswith("workspace_bytes") else ctypes.c_int
+            fn.restype = ctypes.c_size_t if name.endswith("_bytes") else ctypes.c_int
         lib.m2h_last_error.argtypes = []
         lib.m2h_last_error.restype = ctypes.c_char_p
         _lib = lib

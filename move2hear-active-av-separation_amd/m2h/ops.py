@@ -79,6 +79,32 @@ _tls = threading.local()   # the calling thread's arithmetic (mirrors libm2h's t
 FMT_SRC_SPLIT, FMT_W_SPLIT, FMT_DST_SPLIT, FMT_MATH_BF16X3, FMT_MATH_FP32 = 1, 2, 4, 8, 16   # include/m2h.h M2H_FMT_*
 
 
+def pack_strip_conv1(w):
+    """torch Conv2d weight [64][Ci >= 32][4][4] of the first encoder stage -> the strip kernel's register image (csrc/conv_strip.hip)."""
+    _chk(w, "pack_strip_conv1")
+    if w.dim() != 4 or w.shape[0] != 64 or w.shape[1] < 32 or tuple(w.shape[2:]) != (4, 4):
+        raise RuntimeError("m2h.pack_strip_conv1: expected a [64, >=32, 4, 4] weight, got %s" % (tuple(w.shape),))
+    lib = _lib.load()
+    out = torch.empty(lib.m2h_strip_conv1_weight_bytes() // 4, device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.m2h_pack_strip_conv1(_ptr(w), int(w.shape[1]), _ptr(out), _stream(w)), "m2h_pack_strip_conv1")
+    return out
+
+
+def strip_conv1_fwd(mix, masks, wreg, scale, shift, cls_table=None, cls_val=None, slope=0.2):
+    """Slice (+ bin2mono pre-op) + first encoder stage in one strip-walker launch: mix / masks [B,512,T,2] -> split32 NHWC
+    [B,16,T/2,64] (bf16x3 arithmetic; include/m2h.h m2h_strip_conv1_fwd)."""
+    _chk(mix, "strip_conv1_fwd")
+    B, F, T, C = mix.shape
+    if C != 2:
+        raise RuntimeError("m2h.strip_conv1_fwd: expected [B,512,T,2]")
+    out = torch.empty((B, 16, T // 2, 64), device=mix.device, dtype=torch.float32)
+    with torch.cuda.device(mix.device):
+        _lib.check(_lib.load().m2h_strip_conv1_fwd(_ptr(mix), _ptr(masks), _ptr(wreg), _ptr(scale), _ptr(shift), _ptr(cls_table), _ptr(cls_val),
+                                                   _ptr(out), B, F, T, float(slope), _stream(mix)), "m2h_strip_conv1_fwd")
+    return out
+
+
 def split32(t):
     """fp32 tensor (innermost dimension a multiple of 32) -> same-shape tensor in the split32 layout of include/m2h.h."""
     _chk(t, "split32")

@@ -257,6 +257,15 @@ def _split32_of(wp):
     return sp
 
 
+def _strip_conv1_of(enc, wp):
+    """The first stage's weights in the strip kernel's register image, cached on the packed-weight tensor (rebuilt with it)."""
+    sw = getattr(wp, "_m2h_strip", None)
+    if sw is None:
+        sw = ops.pack_strip_conv1(enc.cnn[0][0].weight.detach().contiguous())
+        wp._m2h_strip = sw
+    return sw
+
+
 def unet_forward(enc, dec, mix, masks=None, target_class=None, events=None):
     """Eval-mode forward of one encoder/decoder pair through the whole-network C runner (m2h_unet_fwd): same kernels and
     values as ``dec(*enc(...))``, one host call instead of ~13.  enc: PassiveSepEncCNN, dec: PassiveSepDecCNN.
@@ -287,6 +296,7 @@ def unet_forward(enc, dec, mix, masks=None, target_class=None, events=None):
     w.head_w, w.head_b, w.n_out = hw.data_ptr(), hb.data_ptr(), hco
     w.weights_split32 = 1 if split else 0
     w.math_mode = 2 if split else 1   # this call's arithmetic, pinned (include/m2h.h)
+    w.down0_strip = _strip_conv1_of(enc, downs[0][0]).data_ptr() if (split and T % 64 == 0) else None
     cls_val = None
     if table is not None:
         cls_val = (target_class.reshape(-1).to(torch.float32) + 1.0).contiguous()
