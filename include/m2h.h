@@ -549,7 +549,8 @@ int m2h_unet_fwd(const m2h_unet_weights* w /* host */, const float* mix, const f
 /* Same, recording caller-created events (hipEvent_t handles, e.g. torch.cuda.Event.cuda_event) on `stream` before the first
  * kernel and after each of the 11 kernels: events[0..11] (n_events must be 12).  Kernel i ran between events[i] and
  * events[i+1]: 0 slice, 1-5 encoder stages, 6-9 decoder stages, 10 last stage + head.  When the strip kernel takes the slice and
- * the first stage together (down0_strip), interval 0 is empty and interval 1 is that one kernel. */
+ * the first stage together (down0_strip), interval 0 is empty and interval 1 is that one kernel; interval 10 is then
+ * m2h_strip_last_fwd. */
 #define M2H_UNET_FWD_EVENTS 12
 int m2h_unet_fwd_events(const m2h_unet_weights* w /* host */, const float* mix, const float* masks, const float* cls_val, float* out,
                         int B, int F, int T, void* workspace, size_t workspace_bytes, void* const* events, int n_events,
@@ -565,6 +566,15 @@ size_t m2h_strip_conv1_weight_bytes(void);
 int m2h_pack_strip_conv1(const float* w, int Ci, void* out, m2h_stream stream);
 int m2h_strip_conv1_fwd(const float* mix, const float* masks, const void* wreg, const float* scale, const float* shift,
                         const float* cls_table, const float* cls_val, float* dst, int B, int F, int T, float slope, m2h_stream stream);
+
+/* Strip-walker kernel of the last decoder stage + head (csrc/conv_strip.hip; bf16x3 arithmetic): cat(x, skip) ->
+ * ConvTranspose2d(128 -> Co, 4x4, s2, p1) + BN(eval) + ReLU (separator_cnn.py:15-24,128-133,156-161), the biased 1x1 conv (:134)
+ * and the de-slice to BHWC (:163-168) in ONE launch: x, skip split32 NHWC [B][H][W][64]; wp_split32 = m2h_split32 of
+ * m2h_pack_convT_weight ([4][Co][4 * 128]); out [B][32 H][2 W][Co / 16] fp32.  Same structure as m2h_strip_conv1_fwd: strips of
+ * 32 columns, a rolling window of three input rows in LDS, all weights in registers (wave = sub-pixel phase x 16 channels), the
+ * head on the matrix pipe from an LDS image of the activated tile.  W % 32 == 0, Co 32 or 16. */
+int m2h_strip_last_fwd(const float* x, const float* skip, const float* wp_split32, const float* scale, const float* shift, const float* head_w,
+                       const float* head_b, float* out, int B, int H, int W, int Co, m2h_stream stream);
 
 /* m2h_sep_slice_input with the output written in the split32 layout when split_out != 0 (C == 2 only). */
 int m2h_sep_slice_input_fmt(const float* mix, const float* masks, float* out, int B, int F, int T, int C, int split_out, m2h_stream stream);

@@ -262,7 +262,13 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
     cur = d[i];
     h *= 2; w *= 2;
   }
-  // last stage + 1x1 head + de-slice in one kernel
+  // last stage + 1x1 head + de-slice in one kernel: the strip walker where its shape conditions hold
+  if (sp && T % 64 == 0 && g_strip >= 0 && wts->down0_strip != nullptr) {
+    M2H_REQUIRE(wts->head_w != nullptr && wts->head_b != nullptr, "unet_fwd: null head");
+    if ((rc = m2h_strip_last_fwd(cur, e[0], wts->up_w[4], wts->up_scale[4], wts->up_shift[4], wts->head_w, wts->head_b, out, B, h, w, dco[4], stream)))
+      return rc;
+    return mark();
+  }
   m2h_conv_args a = up_args(cur, e[0], wts->up_w[4], wts->up_scale[4], wts->up_shift[4], out, B, h, w, c0[4], c1[4], dco[4]);
   a.out_mode = M2H_OUT_DESLICE;
   a.head_w = wts->head_w;

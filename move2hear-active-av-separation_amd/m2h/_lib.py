@@ -216,6 +216,7 @@ SIGNATURES = {
     "m2h_strip_conv1_weight_bytes": [],
     "m2h_pack_strip_conv1": [_P, _I, _P, _P],
     "m2h_strip_conv1_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "m2h_strip_last_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "m2h_gather_envs": [_P, _P, _P, _I, _I, _I, _Z, _P],
     "m2h_gru_step": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_episode_stats_update": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],

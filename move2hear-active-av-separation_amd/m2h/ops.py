@@ -105,6 +105,21 @@ def strip_conv1_fwd(mix, masks, wreg, scale, shift, cls_table=None, cls_val=None
     return out
 
 
+def strip_last_fwd(x, skip, wp_split32, scale, shift, head_w, head_b, Co):
+    """Last decoder stage + head + de-slice in one strip-walker launch: x, skip split32 NHWC [B,H,W,64] -> BHWC
+    [B,32H,2W,Co/16] (bf16x3 arithmetic; include/m2h.h m2h_strip_last_fwd)."""
+    _chk(x, "strip_last_fwd")
+    _chk(skip, "strip_last_fwd(skip)")
+    B, H, W, C = x.shape
+    if C != 64 or tuple(skip.shape) != tuple(x.shape):
+        raise RuntimeError("m2h.strip_last_fwd: expected two [B,H,W,64] tensors")
+    out = torch.empty((B, 32 * H, 2 * W, Co // 16), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().m2h_strip_last_fwd(_ptr(x), _ptr(skip), _ptr(wp_split32), _ptr(scale), _ptr(shift), _ptr(head_w), _ptr(head_b),
+                                                  _ptr(out), B, H, W, int(Co), _stream(x)), "m2h_strip_last_fwd")
+    return out
+
+
 def split32(t):
     """fp32 tensor (innermost dimension a multiple of 32) -> same-shape tensor in the split32 layout of include/m2h.h."""
     _chk(t, "split32")
