@@ -142,17 +142,19 @@ int m2h_get_math_mode(void);
  * (bit-reproducible) and applies the fused epilogue. */
 size_t m2h_conv_igemm_workspace_bytes(const m2h_conv_args* args /* host */);
 
-/* Tuning/debug knobs (process-wide, NOT part of the contract and not for production use: they only choose between kernels that
- * compute the same values; 0 = automatic everywhere): 0 force split-K factor (-1 never), 1 / 2 LDS
- * stages of the narrow / wide tiles, 3 skinny-M tiles (-1 off), 4 16-wide MFMA tile (-1 off), 7 extra dynamic LDS, 8 phase-major
- * transposed-conv order (-1 off), 9 scalar-decode loader (-1 off), 11 weight-gradient block target, 14 = m2h_set_math_mode (kept
- * for older callers; thread-local like it), 15 / 16 tap-sharing transposed-conv kernel (-1 off, 2 = only for N <= 32 / tile: 128, 256, 512), 18 tap window (-1 off), 21 / 22
- * image-row 3x3 weight-gradient / conv kernels (-1 off), 23 skinny rows kernel for M <= 16 (-1 off), 24 skinny gather kernel (-1 off,
- * > 0 = pixel limit), 26 the 256 x 128 eight-wave tile of the bf16x3 arithmetic (-1 off, > 0 = minimum tile count), 27 the LDS-DMA engine for split32 operands
- * (csrc/conv_dma.hip; -1 off, 1 / 2 = its 128 x 128 / 256 x 128 tile only, below the tile-count threshold too), 28 = 32: 32x32x16 instead of
- * 16x16x32 MFMA fragments there, 29 = 1: its 256 x 64 tile for 64-wide plain convs, 31 = 2: the L2-friendly (chunk, tap) / parity-class k-tile orders there (default: the register engine's (tap, chunk)),
- * 30: the four-phase transposed-conv kernel (csrc/convt_quad.hip; -1 off, 1 = wherever its shape conditions hold), 32 = 1: the weights-in-registers first encoder stage (csrc/conv_bres.hip).  The launches that take a specialised kernel say which in the source (csrc/conv_igemm.hip, conv_bwd.hip);
- * retired experiment numbers are accepted and ignored. */
+/* Tuning / test knobs -- NOT part of the contract, not for production use: they only choose between kernels that compute the
+ * same values (0 = automatic everywhere), process-wide, set before the launches they are to affect.  tests/ use them to pit one
+ * engine against another; tools/ for A/B timing.  0 force split-K factor (-1 never), 1 / 2 LDS stages of the narrow / wide tiles,
+ * 3 skinny-M tiles (-1 off), 4 16-wide MFMA tile (-1 off), 7 extra dynamic LDS, 8 phase-major transposed-conv order (-1 off),
+ * 9 scalar-decode loader (-1 off), 11 weight-gradient block target, 14 = m2h_set_math_mode (kept for older callers; thread-local
+ * like it), 15 / 16 tap-sharing transposed-conv kernel (-1 off, 2 = only for N <= 32 / tile: 128, 256, 512), 18 tap window (-1
+ * off), 21 / 22 image-row 3x3 weight-gradient / conv kernels (-1 off), 23 skinny rows kernel for M <= 16 (-1 off), 24 skinny
+ * gather kernel (-1 off, > 0 = pixel limit), 26 the 256 x 128 eight-wave tile of the bf16x3 arithmetic (-1 off, > 0 = minimum
+ * tile count), 27 the LDS-DMA engine for split32 operands (csrc/conv_dma.hip; -1 off, 2 = below the tile-count threshold too),
+ * 28 = 32: 32x32x16 instead of 16x16x32 MFMA fragments there, 30 the four-phase transposed-conv kernel (csrc/convt_quad.hip; -1
+ * off, 1 = wherever its shape conditions hold), 34 = -1: no two-K-halves launch of the LDS-DMA engine, 35 = -1: the whole-network
+ * runner does not take the strip-walker kernels (csrc/conv_strip.hip).  Numbers of experiments that were measured and removed
+ * (5, 6, 10, 12, 13, 17, 19, 20, 29, 31, 32) are accepted and ignored. */
 int m2h_debug_set(int knob, int value);
 
 /*

@@ -6,7 +6,7 @@ namespace m2h {
 thread_local char g_err[512] = {0};
 int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st);
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a);
-extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny, g_narrow16, g_extra_lds, g_phase_major, g_fast_loader, g_wgrad_blocks, g_tapshare, g_tap_bm, g_tap_window, g_wgrad_row3x3, g_row3x3, g_skinny_linear, g_skinny_gather, g_big_tile, g_dma, g_dma_shape, g_dma64, g_quad, g_dma_korder, g_bres, g_dma_split2, g_strip;
+extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny, g_narrow16, g_extra_lds, g_phase_major, g_fast_loader, g_wgrad_blocks, g_tapshare, g_tap_bm, g_tap_window, g_wgrad_row3x3, g_row3x3, g_skinny_linear, g_skinny_gather, g_big_tile, g_dma, g_dma_shape, g_quad, g_dma_split2, g_strip;
 extern thread_local int tl_math_mode;
 }  // namespace m2h
 
@@ -41,7 +41,7 @@ int m2h_debug_set(int knob, int value) {
   else if (knob == 2) g_wide_stages = value;
   else if (knob == 3) g_skinny = value;
   else if (knob == 4) g_narrow16 = value;
-  else if (knob == 5 || knob == 6 || knob == 10 || knob == 12 || knob == 13 || knob == 17 || knob == 19 || knob == 20) {}  // retired experiments (block stagger, ping-pong wave groups, 256-row narrow tiles, direct-operand narrow kernel, prefetch distance 4 on skinny tiles, 128x256 / 256x128 one-block-per-CU tiles in bf16x3 math, no split-K under a k-tile count, in-launch split-K reduction by the last-arriving block): measured no gain
+  else if (knob == 5 || knob == 6 || knob == 10 || knob == 12 || knob == 13 || knob == 17 || knob == 19 || knob == 20 || knob == 29 || knob == 31 || knob == 32) {}  // retired experiments (block stagger, ping-pong wave groups, 256-row narrow tiles, direct-operand narrow kernel, prefetch distance 4 on skinny tiles, 128x256 / 256x128 one-block-per-CU tiles in bf16x3 math, no split-K under a k-tile count, in-launch split-K reduction by the last-arriving block, the LDS-DMA engine's 256x64 tile and L2-friendly k-tile orders, the weights-in-registers first stage that the strip-walker kernel replaced): measured no gain, code removed
   else if (knob == 7) g_extra_lds = value;
   else if (knob == 8) g_phase_major = value;
   else if (knob == 9) g_fast_loader = value;
@@ -57,10 +57,7 @@ int m2h_debug_set(int knob, int value) {
   else if (knob == 26) g_big_tile = value;
   else if (knob == 27) g_dma = value;
   else if (knob == 28) g_dma_shape = value;
-  else if (knob == 29) g_dma64 = value;
   else if (knob == 30) g_quad = value;
-  else if (knob == 31) g_dma_korder = value;
-  else if (knob == 32) g_bres = value;
   else if (knob == 34) g_dma_split2 = value;
   else if (knob == 35) g_strip = value;
   else return fail(-1, "debug_set: unknown knob %d", knob);

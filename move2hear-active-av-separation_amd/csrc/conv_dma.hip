@@ -26,12 +26,8 @@
 namespace m2h {
 
 int g_dma_split2 = 0;   // m2h_debug_set 34: -1 = no two-way split-K on the 256 x 128 tile
-int g_dma_korder = 0;   // m2h_debug_set 31: 2 = the L2-friendly k-tile orders below instead of the register engine's (tap, chunk)
-int g_dma64 = 0;      // m2h_debug_set 29: 1 = 64-wide plain convs on this engine too (256 x 64 tile).  Off: the first encoder stage
-                      // has only 16 k-tiles per tile, each a new tap (row offsets recomputed every tile), and one block per CU
-                      // does not hide its ring fill / epilogue: 251 vs 218 us (pair_ab --layers, B = 256)
 int g_dma_shape = 0;   // m2h_debug_set 28: 32 = v_mfma_f32_32x32x16_bf16 fragments instead of 16x16x32
-int g_dma = 0;   // m2h_debug_set 27: -1 never use this engine; 1 = 128x128 tiles only, 2 = 256x128 only (tuning)
+int g_dma = 0;   // m2h_debug_set 27: -1 never use this engine; 2 = also below its tile-count threshold (tests)
 
 __device__ __attribute__((aligned(128))) float g_zero_page[2048 + 32];   // 8 KiB + one row: source of padding rows at any channel offset
 
@@ -171,21 +167,10 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
   const int kt0 = (int)(((long)nk_all * split) / p.S);
   const int kt1 = (int)(((long)nk_all * (split + 1)) / p.S);
   const int nk = kt1 - kt0;
-  // Order of the k-tiles (p.korder; any order gives the same sums up to fp32 association):
-  //   0  (tap, chunk)                 the register engine's order;
-  //   1  (chunk, tap)                 the taps of one 32-channel chunk in consecutive tiles;
-  //   2  (class, chunk, tap in class) 4x4 / stride-2 conv: the four taps (th, tw) of one parity class (th & 1, tw & 1) read the
-  //                                   SAME input pixels (as neighbouring output positions), so they run in consecutive tiles.
-  // In 1 and 2 every re-read of an input line follows its first read within a few tiles, while the line is still in the XCD's
-  // L2; in the (tap, chunk) order the re-reads are C/32 .. 8 C/32 tiles apart and come back from beyond L2 (PMC: 2 x FETCH_SIZE
-  // + WRITE_SIZE = 1.9 x the algorithmic bytes per launch).  But orders 1 and 2 change the tap on EVERY tile, and the row
-  // pointers (bounds checks + 64-bit address per staged row) have to be rebuilt whenever the tap changes: measured on the
-  // benchmark step (pair_ab) order 0 = 3.125 ms, orders 1 / 2 = 3.218 ms; with the rebuild forced on every tile for both,
-  // 3.262 against 3.245 ms.  The locality is worth 0.5 %, the per-tile rebuild costs 3 %: order 0 is the default
-  // (m2h_debug_set 31 = 2 selects 1 / 2).
-  const int nch = p.Ctot / BK, ntw_w = p.thn * p.twn;
-  const int J = p.korder == 0 ? 1 : (p.korder == 1 ? ntw_w : 4);
-  int w_a, w_c, w_j;     // outer index (tap / 0 / class), chunk, inner tap index
+  // k-tiles run in (tap, chunk) order, the register engine's: increments only, and the staged rows' pointers (bounds checks + a
+  // 64-bit address per row) are rebuilt only when the tap or the source changes.  (Orders that keep the re-reads of an input line
+  // within a few tiles -- (chunk, tap), and (parity class, chunk, tap in class) for the stride-2 convs -- were built and measured
+  // in round 2: the locality was worth 0.5 % of the step, the per-tile pointer rebuild cost 3 %; removed.)
   int u_th, u_tw, u_ci;
   auto rebuild_rows = [&]() {   // row pointers of the current (tap, source)
     const bool second = u_ci >= p.C0 && p.src1 != nullptr;
@@ -200,26 +185,13 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
       ptrA[i] = ((ok && DBG != 3 && DBG != 6) ? base + off : zero) + pieceA[i];
     }
   };
-  auto decode_walk = [&]() {
-    u_ci = w_c * BK;
-    if (p.korder == 0) {
-      u_th = p.th0 + w_a / p.twn;
-      u_tw = p.tw0 + w_a % p.twn;
-    } else if (p.korder == 1) {
-      u_th = p.th0 + w_j / p.twn;
-      u_tw = p.tw0 + w_j % p.twn;
-    } else {
-      u_th = (w_a >> 1) + 2 * (w_j >> 1);
-      u_tw = (w_a & 1) + 2 * (w_j & 1);
-    }
-    rebuild_rows();
-  };
   {
-    w_j = kt0 % J;
-    const int t = kt0 / J;
-    w_c = t % nch;
-    w_a = t / nch;
-    decode_walk();
+    const int nch = p.Ctot / BK;
+    const int w_a = kt0 / nch;
+    u_ci = (kt0 - w_a * nch) * BK;
+    u_th = p.th0 + w_a / p.twn;
+    u_tw = p.tw0 + w_a % p.twn;
+    rebuild_rows();
   }
   int issued = 0;   // tiles issued so far (the next one goes to stage issued % NST)
   int istage = 0;
@@ -240,29 +212,18 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
     }
     ++issued;
     istage = istage + 1 == NST ? 0 : istage + 1;
-    // advance to the next tile
-    if (p.korder == 0) {   // (tap, chunk): increments only; the row pointers are rebuilt when the tap or the source changes
-      u_ci += BK;
-      bool reseg = u_ci == p.C0 && p.src1 != nullptr;
-      if (u_ci == p.Ctot) {
-        u_ci = 0;
-        reseg = true;
-        if (++u_tw == p.tw0 + p.twn) {
-          u_tw = p.tw0;
-          ++u_th;
-        }
+    // advance to the next tile: the row pointers are rebuilt when the tap or the source changes
+    u_ci += BK;
+    bool reseg = u_ci == p.C0 && p.src1 != nullptr;
+    if (u_ci == p.Ctot) {
+      u_ci = 0;
+      reseg = true;
+      if (++u_tw == p.tw0 + p.twn) {
+        u_tw = p.tw0;
+        ++u_th;
       }
-      if (reseg && issued < nk) rebuild_rows();
-    } else {
-      if (++w_j == J) {
-        w_j = 0;
-        if (++w_c == nch) {
-          w_c = 0;
-          ++w_a;
-        }
-      }
-      if (issued < nk) decode_walk();
     }
+    if (reseg && issued < nk) rebuild_rows();
   };
 
   AccT acc[FM][FN];
@@ -514,37 +475,34 @@ static int launch_dma_cfg(IGemmP& p, int S, hipStream_t st) {
   return launch_status("conv_igemm_f32 (LDS-DMA engine)");
 }
 
-// Shapes of this engine: bf16x3 math on split32 operands, scalar k decode (channel counts multiples of 32), N a multiple of 64,
-// no fused head.  Tile: 256 x 128 when that fills the chip, else 128 x 128 with split-K slabs when even those leave CUs idle.
+// the two-way split-K launch of the 256 x 128 tile (see launch_igemm_dma): shape rule shared with conv_igemm_workspace_bytes
+bool dma_split2_rule(long M, int N, int Kw, int phases, bool ws_present, size_t ws_bytes) {
+  const long t256 = ((M + 255) / 256) * (N / 128) * phases;
+  return g_dma == 0 && g_big_tile >= 0 && g_dma_split2 >= 0 && N % 128 == 0 && t256 < 224 && t256 * 2 >= 224 && Kw / BK >= 64 && ws_present &&
+         (size_t)phases * 2 * M * N * sizeof(float) <= ws_bytes;
+}
+static bool dma_split2_applies(const IGemmP& p, size_t ws_bytes) {
+  return dma_split2_rule(p.M, p.N, p.Kw, p.convT ? 4 : 1, p.ws != nullptr, ws_bytes);
+}
+
+// Shapes of this engine: bf16x3 math on split32 operands, scalar k decode (channel counts multiples of 32), N a multiple of 128,
+// no fused head, enough 256 x 128 tiles to fill the chip (or half of it with a long reduction: two K-halves per tile).  Everything
+// else -- fewer tiles, 64-wide layers -- is faster on the register engine's two blocks per CU (round 2: down3 125 vs 147 us on this
+// engine's 128 x 128 tile, the first encoder stage 218 vs 251 us on its 256 x 64 tile; both tiles removed).
 int launch_igemm_dma(IGemmP& p, size_t ws_bytes, hipStream_t st) {
-  if (g_dma < 0 || p.math != 1 || !p.presplit || !p.fast_ok || p.head_w != nullptr || p.N % 64 != 0 || p.Kw % BK != 0) return -2;
+  if (g_dma < 0 || p.math != 1 || !p.presplit || !p.fast_ok || p.head_w != nullptr || p.N % 128 != 0 || p.Kw % BK != 0) return -2;
   if ((size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 > 8192) return -2;   // zero page covers one pixel's channels
-  p.korder = g_dma_korder != 2 ? 0 : ((!p.convT && p.stride == 2 && p.ntap == 16 && p.thn == 4 && p.twn == 4 && p.th0 == 0 && p.tw0 == 0) ? 2 : 1);
   if (p.M <= 64) return -2;        // skinny M: the 32- / 64-row weight-streaming tiles of the register engine
   const int phases = p.convT ? 4 : 1;
-  if (p.N == 64) {                 // the 64-wide first encoder stage (a transposed 64-wide stage takes the tap-sharing kernel first)
-    const long t = (((long)p.M + 255) / 256) * phases;
-    if (g_dma == 1 || (g_dma != 2 && (g_dma64 <= 0 || t < 224))) return -2;   // off by default: measured slower (see g_dma64)
-    return g_dma_shape == 32 ? launch_dma_cfg<256, 64, 4, 2, 3, 32>(p, 1, st) : launch_dma_cfg<256, 64, 4, 2, 3, 16>(p, 1, st);
-  }
-  if (p.N % 128 != 0) return -2;
   // tile and split-K factor: the register engine's own rules (conv_igemm_f32), so that the two engines agree bit for bit
   const long t256 = (((long)p.M + 255) / 256) * (p.N / 128) * phases;
-  if (g_dma != 1 && g_big_tile >= 0 && (g_dma == 2 || t256 >= (g_big_tile > 0 ? g_big_tile : 224)))
+  if (g_big_tile >= 0 && (g_dma == 2 || t256 >= (g_big_tile > 0 ? g_big_tile : 224)))
     return g_dma_shape == 32 ? launch_dma_cfg<256, 128, 4, 2, 3, 32>(p, 1, st) : launch_dma_cfg<256, 128, 4, 2, 3, 16>(p, 1, st);
   // half the chip's worth of 256 x 128 tiles and a long reduction (the fourth encoder stage at the benchmark batch: 128 tiles,
   // K = 4096): two K-halves per tile into split-K slabs + the ordered reduce kernel
-  {
-    const int nk = p.Kw / BK;
-    if (g_dma == 0 && g_big_tile >= 0 && g_dma_split2 >= 0 && t256 * 2 >= 224 && nk >= 64 && p.ws != nullptr && (p.N & 3) == 0 &&
-        (size_t)phases * 2 * p.M * p.N * sizeof(float) <= ws_bytes)
-      return g_dma_shape == 32 ? launch_dma_cfg<256, 128, 4, 2, 3, 32>(p, 2, st) : launch_dma_cfg<256, 128, 4, 2, 3, 16>(p, 2, st);
-  }
-  // fewer tiles: the 128 x 128 tile at two blocks per CU of the register engine is faster than this engine's one block per CU
-  // (pair_ab --layers, B = 256: down3 125 vs 147 us, down4 47 vs 53, up0 52 vs 59); m2h_debug_set 27 = 1 forces it here
-  if (g_dma != 1) return -2;
-  const int S = choose_splitk(p, 128, 128, ws_bytes);
-  return g_dma_shape == 32 ? launch_dma_cfg<128, 128, 2, 2, 3, 32>(p, S, st) : launch_dma_cfg<128, 128, 2, 2, 3, 16>(p, S, st);
+  if (dma_split2_applies(p, ws_bytes))
+    return g_dma_shape == 32 ? launch_dma_cfg<256, 128, 4, 2, 3, 32>(p, 2, st) : launch_dma_cfg<256, 128, 4, 2, 3, 16>(p, 2, st);
+  return -2;
 }
 
 #ifdef M2H_CLOCK_DIAG

@@ -1186,8 +1186,18 @@ size_t conv_igemm_workspace_bytes(const m2h_conv_args& a) {
   int BM, BN;
   pick_tile(M, a.N, BM, BN);
   const int S = splitk_for(M, a.N, K, phases, BM, BN);
-  if (S <= 1) return 0;
-  return (size_t)phases * S * M * a.N * sizeof(float);
+  size_t bytes = S <= 1 ? 0 : (size_t)phases * S * M * a.N * sizeof(float);
+  // split32 operands in bf16x3 math: the LDS-DMA engine's two-K-halves launch of the 256 x 128 tile (conv_dma.hip) takes its slabs
+  // from this workspace too -- report them, so that a caller who sizes the workspace by this function gets the same kernel (and the
+  // same fp32 summation order) as the whole-network runner, whose scratch is the maximum over its stages
+  const int both = M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT;
+  const int math = (a.operand_format & M2H_FMT_MATH_BF16X3) ? 1 : (a.operand_format & M2H_FMT_MATH_FP32) ? 0 : tl_math_mode;
+  if (math == 1 && (a.operand_format & both) == both && a.head_w == nullptr && a.C0 % BK == 0 && a.C1 % BK == 0 && M > 64 && g_force_splitk <= 0 &&
+      g_fast_loader >= 0) {
+    const size_t need = (size_t)phases * 2 * M * a.N * sizeof(float);
+    if (dma_split2_rule(M, a.N, K, phases, true, need) && need > bytes) bytes = need;
+  }
+  return bytes;
 }
 
 int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
@@ -1221,7 +1231,6 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   p.B = a.B; p.Hi = a.Hi; p.Wi = a.Wi; p.Hq = a.Hq; p.Wq = a.Wq; p.stride = a.stride;
   p.wq_sh = (a.Wq & (a.Wq - 1)) == 0 ? __builtin_ctz((unsigned)a.Wq) : -1;
   p.hq_sh = (a.Hq & (a.Hq - 1)) == 0 ? __builtin_ctz((unsigned)a.Hq) : -1;
-  p.korder = 0;
   p.ntw = a.ntw; p.ntap = a.nth * a.ntw;
   p.mulh = a.mulh; p.offh = a.offh; p.mulw = a.mulw; p.offw = a.offw; p.convT = a.conv_transpose ? 1 : 0;
   p.w = a.wp; p.N = a.N; p.K = p.ntap * p.Ctot;
@@ -1362,10 +1371,6 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   // (PMC: ~8.5 TB/s of L2 reads with the matrix pipe 36 % and the LDS 39 % busy; one block per CU is only 7 % slower than two);
   // the larger tile reads 384 operand rows per 256 x 128 outputs instead of 512.  (A 256 x 64 tile for the 64-wide first encoder
   // stage measured slower: 252 vs 235 us.)
-  if (g_fast_loader >= 0 && g_force_splitk <= 0) {   // the first encoder stage on split32 operands: weights in registers (conv_bres.hip)
-    const int rc = launch_conv_bres(p, st);
-    if (rc != -2) return rc;
-  }
   if (g_fast_loader >= 0 && g_force_splitk <= 0) {   // split32 operands, wide N: the LDS-DMA engine (conv_dma.hip)
     const int rc = launch_igemm_dma(p, wsb, st);
     if (rc != -2) {

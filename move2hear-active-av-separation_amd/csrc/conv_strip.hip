@@ -17,11 +17,13 @@
 //     stage) spread over the workgroup's waves as 16 B-fragments of v_mfma_f32_16x16x32_bf16 (hi + lo = 128 VGPRs per wave); a
 //     wave owns 16 output channels (first stage) or one sub-pixel phase x 16 channels (last stage) and multiplies EVERY pixel of
 //     the strip row against them.  No weight traffic in the loop at all;
-//   * A fragments come from the LDS patch: pixel records of 128 B ([hi 32 ch | lo 32 ch], eight 16-byte pieces), consecutive
-//     pixels of a plane 128 B apart, read with ds_read_b128 at any pixel shift without bank conflicts: piece j of pixel i sits at
-//     slot (j' + (i >> 1)) & 7 (j' = 0,4,1,5 for the hi pieces, 2,6,3,7 for the lo ones), and MFMA row m of a 16-pixel fragment is
-//     pixel RHO(m) of it (rows 8-11 and 12-15 swapped) -- with the lane groups a ds_read_b128 is served in ({0-3, 12-15, 20-27},
-//     ...: MI355X_MICROARCH.md, LDS) every group then covers the sixteen 16-byte bank slots exactly once;
+//   * A fragments come from the LDS patch: per pixel a 64-byte hi record and, PART bytes further, a 64-byte lo record (32
+//     channels as bf16 each, four 16-byte pieces), consecutive pixels of a plane 64 B apart, read with ds_read_b128 at any pixel
+//     shift without bank conflicts: piece j of pixel i sits at slot (j + (i >> 1)) & 3 -- with the lane groups a ds_read_b128 is
+//     served in ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) every group then covers the sixteen 16-byte bank slots
+//     exactly once (tests/test_kernel_model.py checks the map for every shift); the lo fragment's address is the hi one plus a
+//     constant, so a fragment pair costs one address register.  Fragment reads run two (tap, pixel-fragment) groups ahead of the
+//     MFMAs that consume them (three register sets, compiler-counted lgkmcnt waits);
 //   * the stride-2 first stage keeps even and odd input columns in two planes, so a tap's pixels are consecutive records;
 //   * results leave through an LDS image as whole contiguous runs (16 bytes per lane).
 // Jobs (image, strip) are dealt to a persistent grid of two workgroups per CU (the second covers the first's barriers).
@@ -33,17 +35,33 @@ namespace m2h {
 
 int g_strip = 0;   // m2h_debug_set 35: -1 = the runner never takes the strip-walker kernels (A/B against the tiled engines)
 
+#ifdef M2H_CLOCK_DIAG
+// Diagnostic build only (tools/clock_diag_strip.py): shader-clock cycles every wave spends in each part of its steps, summed
+// over the kernel, per workgroup and wave: [0] load issue, [1] MFMA loop, [2] epilogue, [3] first barrier, [4] head / copy-out,
+// [5] ring store, [6] second barrier, [7] copy-out behind it; [8] = prologues, [9] = kernel total.
+__device__ unsigned long long g_clock_dbg_strip[1024][8][10];
+#define SDIAG_DECL unsigned long long sd_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long sd_t = __builtin_amdgcn_s_memtime(); const unsigned long long sd_t0 = sd_t
+#define SDIAG(i) do { const unsigned long long sd_n = __builtin_amdgcn_s_memtime(); sd_acc[i] += sd_n - sd_t; sd_t = sd_n; } while (0)
+#define SDIAG_END do { sd_acc[9] = __builtin_amdgcn_s_memtime() - sd_t0; if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) for (int i_ = 0; i_ < 10; ++i_) g_clock_dbg_strip[blockIdx.x][threadIdx.x >> 6][i_] = sd_acc[i_]; } while (0)
+#else
+#define SDIAG_DECL do { } while (0)
+#define SDIAG(i) do { } while (0)
+#define SDIAG_END do { } while (0)
+#endif
+
 namespace {
 
 constexpr int SW = 32;            // output columns of a strip
 constexpr int PX = SW + 2;        // staged pixel records per plane (one halo record each side)
-constexpr int PLANE = PX * 128;   // bytes of a plane
+constexpr int PART = PX * 64;     // bytes of the hi (or lo) records of a plane
+constexpr int PLANE = 2 * PART;   // a plane: hi records, then lo records
 
-__device__ __forceinline__ int rho16(int m) { return m < 8 ? m : (m < 12 ? m + 4 : m - 4); }
-// byte offset of piece-slot `ps` of pixel record i inside a plane
-__device__ __forceinline__ int px_addr(int i, int ps) { return i * 128 + (((ps + (i >> 1)) & 7) << 4); }
-__device__ __forceinline__ int pslot_hi(int kg) { return (kg >> 1) + ((kg & 1) << 2); }   // 0, 4, 1, 5
-__device__ __forceinline__ int pslot_lo(int kg) { return 2 + (kg >> 1) + ((kg & 1) << 2); }   // 2, 6, 3, 7
+// byte offset of 16-byte piece j (8 channels) of pixel record i inside the hi part of a plane (lo: + PART)
+__device__ __forceinline__ int px_addr(int i, int j) { return i * 64 + (((j + (i >> 1)) & 3) << 4); }
+
+struct Frag {
+  f32x4 h, l;
+};
 
 __device__ __forceinline__ f32x4 mfma16(const f32x4& a, const f32x4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -84,9 +102,12 @@ __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p
   constexpr int ROW = 2 * PLANE;   // a row slot: even-column plane, odd-column plane
   __shared__ __attribute__((aligned(1024))) char s_ring[4 * ROW];
   __shared__ __attribute__((aligned(16))) char s_out[SW * 256];
+  __shared__ __attribute__((aligned(16))) float s_cls[9 * 64];   // the class plane's border table (read per step: no global load in the loop)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, kg = lane >> 4;
+  if (p.cls_table != nullptr)
+    for (int i = tid; i < 9 * 64; i += 256) s_cls[i] = p.cls_table[i];
 
   // ---- the layer's weights: this wave's 16 output channels, all 16 taps ----
   f32x4 Bh[16], Bl[16];
@@ -98,78 +119,78 @@ __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p
       Bl[tap] = w[(tap * 2 + 1) * 64];
     }
   }
-  // ---- A fragment addresses inside a row slot: input column 2 r + tw - 1 = patch column 2 (r - r0) + tw + 1 ----
-  int a_hi[2][4], a_lo[2][4];
+  // ---- A fragment addresses inside a row slot: input column 2 r + tw - 1 = patch column 2 (r - r0) + tw + 1: plane (tw + 1) & 1,
+  // record (r - r0) + ((tw + 1) >> 1) ----
+  int a_ad[2][4];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int tw = 0; tw < 4; ++tw) {
-      const int i = 16 * mt + rho16(m) + ((tw + 1) >> 1);
-      const int pl = ((tw + 1) & 1) * PLANE;
-      a_hi[mt][tw] = pl + px_addr(i, pslot_hi(kg));
-      a_lo[mt][tw] = pl + px_addr(i, pslot_lo(kg));
-    }
-  // ---- epilogue constants of this lane's output channel ----
-  const int n = wave * 16 + m;
-  const float sc = p.scale[n], sh = p.shift[n];
-  const int gp = kg == 2 ? 3 : (kg == 3 ? 2 : kg);   // accumulator rows 4 kg + j are pixels 4 gp + j of the fragment (RHO)
-  const int o_word = (n >> 5) * 128 + ((n & 1) ? 64 : 0) + ((n & 31) >> 1) * 4;   // this lane's word of a split32 pixel record
-  // ---- loader lanes: wave = kg of the pieces it writes; lane = (sb, pixel pair ii); halo lanes 0..15 = (h, t, sb, side) ----
+    for (int tw = 0; tw < 4; ++tw) a_ad[mt][tw] = ((tw + 1) & 1) * PLANE + px_addr(16 * mt + m + ((tw + 1) >> 1), kg);
+  // ---- epilogue constants.  The weights are the MFMA's A operand (rows = channels) and the pixels its B operand (columns), so a
+  // lane's four accumulator values are channels n0 .. n0 + 3 of ONE pixel (16 mt + m): an aligned 8-byte run of its split32 record
+  const int n0 = wave * 16 + 4 * kg;
+  const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0), sh4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
+  const int o_byte = m * 256 + (n0 >> 5) * 128 + (n0 & 31) * 2;   // hi run of pixel m's record in the out image (lo: + 64; mt: + 16 * 256)
+  // ---- loader lanes: wave = the piece (8 channels) it writes; lane = (sb, pixel pair ii); halo lanes 0..15 = (h, t, sb, side) ----
   const int sb = lane >> 5, ii = lane & 31;
   const int hh = (lane >> 3) & 1, ht = (lane >> 2) & 1, hsb = (lane >> 1) & 1, hside = lane & 1;
-  const int w_hi = px_addr(ii + 1, pslot_hi(wave)) + sb * 8, w_lo = px_addr(ii + 1, pslot_lo(wave)) + sb * 8;
-  const int hw_i = hside ? PX - 1 : 0;
-  const int hw_hi = px_addr(hw_i, pslot_hi(wave)) + hsb * 8 + ht * 4, hw_lo = px_addr(hw_i, pslot_lo(wave)) + hsb * 8 + ht * 4;
+  const int w_ad = px_addr(ii + 1, wave) + sb * 8;
+  const int hw_ad = px_addr(hside ? PX - 1 : 0, wave) + hsb * 8 + ht * 4;
 
+  struct Pre {               // a prefetched pair of rows: [h][t] main float4s and the halo float4 (+ the masks beside them)
+    f32x4 v[2][2], vh;
+    f32x4 k[MASKED ? 2 : 1][MASKED ? 2 : 1], kh;
+  };
+
+  SDIAG_DECL;
   for (int job = blockIdx.x; job < p.jobs; job += gridDim.x) {
     const int b = job / p.strips;
     const int r0 = (job - b * p.strips) * SW;
-    const size_t img = (size_t)b * 512 * p.T * 2;
+    const float* mixb = p.mix + (size_t)b * 512 * p.T * 2;     // this image (uniform); lane offsets below are 32-bit
+    const float* maskb = MASKED ? p.masks + (size_t)b * 512 * p.T * 2 : nullptr;
     const bool has_l = r0 > 0, has_r = r0 + SW < p.Wq;
     const float cv = p.cls_table != nullptr ? p.cls_val[b] : 0.f;
+    int l_off[2];    // [t]: frequency row s * 32 (s = 4 wave + 2 t + sb), column pair ii of the strip
+#pragma unroll
+    for (int t = 0; t < 2; ++t) l_off[t] = ((4 * wave + 2 * t + sb) * 32 * p.T + 2 * r0 + 2 * ii) * 2;
+    const int lh_off = ((4 * wave + 2 * ht + hsb) * 32 * p.T + 2 * r0 + (hside ? 2 * SW : -2)) * 2;
+    const bool lh_ok = lane < 16 && (hside ? has_r : has_l);
+    // border class of this lane's pixel (16 mt + m) along the row: 0 first column of the image, 2 last, 1 inside
+    const int cw0 = (m == 0 && !has_l) ? 0 : 1, cw1 = (m == 15 && !has_r) ? 2 : 1;
+    SDIAG(9);
 
-    f32x4 pre[2][2], preh;          // prefetched pair of rows: [h][t] main float4s and the halo float4
-    f32x4 prm[2][2], prmh;          // the masks beside them (MASKED)
-    auto load_pair = [&](int k) {   // rows 2k-1, 2k of the sliced image -> registers
+    auto load_pair = [&](int k, Pre& pr) {   // rows 2k-1, 2k of the sliced image -> registers
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int hi_ = 2 * k - 1 + h;
-        const bool okr = (unsigned)hi_ < 32u;
+        const bool okr = (unsigned)hi_ < 32u;      // uniform
+        const int rowterm = hi_ * p.T * 2;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const int s = 4 * wave + 2 * t + sb;
-          const size_t off = img + ((size_t)(s * 32 + hi_) * p.T + 2 * r0 + 2 * ii) * 2;
-          pre[h][t] = okr ? *reinterpret_cast<const f32x4*>(p.mix + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-          if constexpr (MASKED) prm[h][t] = okr ? *reinterpret_cast<const f32x4*>(p.masks + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+          pr.v[h][t] = okr ? *reinterpret_cast<const f32x4*>(mixb + (l_off[t] + rowterm)) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (MASKED) pr.k[h][t] = okr ? *reinterpret_cast<const f32x4*>(maskb + (l_off[t] + rowterm)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
-      preh = f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (MASKED) prmh = preh;
-      if (lane < 16) {
+      pr.vh = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (MASKED) pr.kh = pr.vh;
+      {
         const int hi_ = 2 * k - 1 + hh;
-        const int s = 4 * wave + 2 * ht + hsb;
-        const bool ok = (unsigned)hi_ < 32u && (hside ? has_r : has_l);
-        const size_t off = img + ((size_t)(s * 32 + hi_) * p.T + 2 * r0 + (hside ? 2 * SW : -2)) * 2;
-        if (ok) {
-          preh = *reinterpret_cast<const f32x4*>(p.mix + off);
-          if constexpr (MASKED) prmh = *reinterpret_cast<const f32x4*>(p.masks + off);
+        if (lh_ok && (unsigned)hi_ < 32u) {
+          pr.vh = *reinterpret_cast<const f32x4*>(mixb + (lh_off + hi_ * p.T * 2));
+          if constexpr (MASKED) pr.kh = *reinterpret_cast<const f32x4*>(maskb + (lh_off + hi_ * p.T * 2));
         }
       }
     };
-    auto store_pair = [&](int k) {   // registers -> row slots (2k) & 3, (2k + 1) & 3, converted to bf16 hi / lo records
+    auto store_pair = [&](int k, Pre& pr) {   // registers -> row slots (2k) & 3, (2k + 1) & 3, converted to bf16 hi / lo records
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         char* row = s_ring + ((2 * k + h) & 3) * ROW;
-        f32x4 v0 = pre[h][0], v1 = pre[h][1];
-        if constexpr (MASKED) {
+        f32x4 v0 = pr.v[h][0], v1 = pr.v[h][1];
+        if constexpr (MASKED) {   // (a padding row holds zeros in both: the pre-op of (0, 0) is 0)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v0[e] = masked_log_mag(v0[e], prm[h][0][e]);
-            v1[e] = masked_log_mag(v1[e], prm[h][1][e]);
-          }
-          if ((unsigned)(2 * k - 1 + h) >= 32u) {   // a padding row stays zero whatever the pre-op makes of zeros
-            v0 = f32x4{0.f, 0.f, 0.f, 0.f};
-            v1 = v0;
+            v0[e] = masked_log_mag(v0[e], pr.k[h][0][e]);
+            v1[e] = masked_log_mag(v1[e], pr.k[h][1][e]);
           }
         }
 #pragma unroll
@@ -177,83 +198,92 @@ __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p
           const f32x4 v = {v0[2 * px], v0[2 * px + 1], v1[2 * px], v1[2 * px + 1]};
           bf16x4 hi, lo;
           split4(v, hi, lo);
-          *reinterpret_cast<bf16x4*>(row + px * PLANE + w_hi) = hi;
-          *reinterpret_cast<bf16x4*>(row + px * PLANE + w_lo) = lo;
+          *reinterpret_cast<bf16x4*>(row + px * PLANE + w_ad) = hi;
+          *reinterpret_cast<bf16x4*>(row + px * PLANE + PART + w_ad) = lo;
         }
       }
       if (lane < 16) {
         char* row = s_ring + ((2 * k + hh) & 3) * ROW;
-        f32x4 v = preh;
+        f32x4 v = pr.vh;
         if constexpr (MASKED) {
-          const bool ok = (unsigned)(2 * k - 1 + hh) < 32u && (hside ? has_r : has_l);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ok ? masked_log_mag(v[e], prmh[e]) : 0.f;
+          for (int e = 0; e < 4; ++e) v[e] = masked_log_mag(v[e], pr.kh[e]);
         }
         bf16x4 hi, lo;
         split4(v, hi, lo);
 #pragma unroll
         for (int px = 0; px < 2; ++px) {
           typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-          *reinterpret_cast<bf16x2_t*>(row + px * PLANE + hw_hi) = bf16x2_t{hi[2 * px], hi[2 * px + 1]};
-          *reinterpret_cast<bf16x2_t*>(row + px * PLANE + hw_lo) = bf16x2_t{lo[2 * px], lo[2 * px + 1]};
+          *reinterpret_cast<bf16x2_t*>(row + px * PLANE + hw_ad) = bf16x2_t{hi[2 * px], hi[2 * px + 1]};
+          *reinterpret_cast<bf16x2_t*>(row + px * PLANE + PART + hw_ad) = bf16x2_t{lo[2 * px], lo[2 * px + 1]};
         }
       }
     };
 
-    // ---- prologue: rows -1 .. 2 ----
-    load_pair(0);
-    store_pair(0);
-    load_pair(1);
-    store_pair(1);
+    Pre pre;
+    {   // ---- prologue: rows -1 .. 2, both pairs' loads in flight together ----
+      Pre pre1;
+      load_pair(0, pre);
+      load_pair(1, pre1);
+      store_pair(0, pre);
+      store_pair(1, pre1);
+    }
     __syncthreads();
+    SDIAG(8);
 
     // one output row q (QP = q & 1 fixes the ring slots at compile time): rows 2q-1 .. 2q+2 = slots (2 QP + th) & 3
     auto step = [&](int q, auto qpc) {
       constexpr int QP = decltype(qpc)::value;
-      if (q + 2 <= 16) load_pair(q + 2);   // consumed behind this step's MFMAs
-      float ct[3] = {0.f, 0.f, 0.f};
+      if (q + 2 <= 16) load_pair(q + 2, pre);   // consumed behind this step's MFMAs
+      f32x4 shc[2] = {sh4, sh4};   // shift with the class plane folded in: (acc + cv t) sc + sh = acc sc + (cv t sc + sh)
       if (p.cls_table != nullptr) {
         const int ch = q == 0 ? 0 : (q == 15 ? 2 : 1);
-#pragma unroll
-        for (int cw = 0; cw < 3; ++cw) ct[cw] = p.cls_table[(ch * 3 + cw) * 64 + n];
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(s_cls + (ch * 3 + cw0) * 64 + n0);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(s_cls + (ch * 3 + cw1) * 64 + n0);
+        shc[0] = (cv * t0) * sc4 + sh4;
+        shc[1] = (cv * t1) * sc4 + sh4;
       }
+      SDIAG(0);
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      {
+        // 32 groups g = (th, tw, mt) of one fragment pair and three MFMAs; the reads run DEPTH groups ahead
+        constexpr int G = 32, DEPTH = 2;
+        Frag f[DEPTH + 1];
 #pragma unroll
-      for (int th = 0; th < 4; ++th) {
-        const char* row = s_ring + ((2 * QP + th) & 3) * ROW;
-#pragma unroll
-        for (int tw = 0; tw < 4; ++tw) {
-          const int tap = th * 4 + tw;
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            const f32x4 ah = *reinterpret_cast<const f32x4*>(row + a_hi[mt][tw]);
-            const f32x4 al = *reinterpret_cast<const f32x4*>(row + a_lo[mt][tw]);
-            acc[mt] = mfma16(al, Bh[tap], acc[mt]);
-            acc[mt] = mfma16(ah, Bl[tap], acc[mt]);
-            acc[mt] = mfma16(ah, Bh[tap], acc[mt]);
+        for (int g = 0; g < G + DEPTH; ++g) {
+          if (g < G) {
+            const int th = g >> 3, tw = (g >> 1) & 3, mt = g & 1;
+            const char* src = s_ring + ((2 * QP + th) & 3) * ROW + a_ad[mt][tw];
+            f[g % (DEPTH + 1)].h = *reinterpret_cast<const f32x4*>(src);
+            f[g % (DEPTH + 1)].l = *reinterpret_cast<const f32x4*>(src + PART);
           }
+          __builtin_amdgcn_sched_barrier(0);
+          if (g >= DEPTH) {
+            const int c = g - DEPTH;
+            const int tap = c >> 1, mt = c & 1;
+            const Frag& a = f[c % (DEPTH + 1)];
+            acc[mt] = mfma16(Bh[tap], a.l, acc[mt]);   // rows = this wave's channels, columns = the fragment's pixels
+            acc[mt] = mfma16(Bl[tap], a.h, acc[mt]);
+            acc[mt] = mfma16(Bh[tap], a.h, acc[mt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+      SDIAG(1);
       // ---- epilogue: class plane, BN, LeakyReLU, split32 record into the out image ----
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt) {
+        f32x4 v = acc[mt] * sc4 + shc[mt];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int po = 16 * mt + 4 * gp + j;
-          const int r = r0 + po;
-          float v = acc[mt][j];
-          const float tv = r == 0 ? ct[0] : (r == p.Wq - 1 ? ct[2] : ct[1]);
-          v += cv * tv;
-          v = v * sc + sh;
-          v = v > 0.f ? v : v * p.slope;
-          const __bf16 hb = (__bf16)v;
-          const __bf16 lb = (__bf16)(v - (float)hb);
-          const unsigned h16 = __builtin_bit_cast(unsigned short, hb), l16 = __builtin_bit_cast(unsigned short, lb);
-          const unsigned both = h16 | (l16 << 16);
-          const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)both, 0xB1, 0xF, 0xF, true);   // lane ^ 1: channel n ^ 1
-          *reinterpret_cast<unsigned*>(s_out + po * 256 + o_word) = (n & 1) ? ((other >> 16) | (l16 << 16)) : (h16 | (other << 16));
-        }
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], v[j] * p.slope);   // LeakyReLU, 0 <= slope <= 1
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<bf16x4*>(s_out + mt * (16 * 256) + o_byte) = hi;
+        *reinterpret_cast<bf16x4*>(s_out + mt * (16 * 256) + o_byte + 64) = lo;
+      }
+      SDIAG(2);
       __syncthreads();   // every wave is done with rows 2q-1, 2q; the out image is complete
+      SDIAG(3);
       {
         float* drow = p.dst + ((size_t)(b * 16 + q) * p.Wq + r0) * 64;
 #pragma unroll
@@ -262,14 +292,18 @@ __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p
           *reinterpret_cast<f32x4*>(drow + idx * 4) = *reinterpret_cast<const f32x4*>(s_out + idx * 16);
         }
       }
-      if (q + 2 <= 16) store_pair(q + 2);   // into the slots rows 2q-1, 2q leave
+      SDIAG(4);
+      if (q + 2 <= 16) store_pair(q + 2, pre);   // into the slots rows 2q-1, 2q leave
+      SDIAG(5);
       __syncthreads();
+      SDIAG(6);
     };
     for (int q = 0; q < 16; q += 2) {
       step(q, std::integral_constant<int, 0>{});
       step(q + 1, std::integral_constant<int, 1>{});
     }
   }
+  SDIAG_END;
 }
 
 // weights [Co = 64][Ci >= 32][4][4] fp32 (torch Conv2d layout; input channel c * 16 + s) -> the kernel's register image
@@ -315,8 +349,7 @@ int launch_strip_conv1(const float* mix, const float* masks, const void* wreg, c
 // (q + th (2 ph - 1), r + tw (2 pw - 1)) (conv_igemm.hip).  A wave therefore reads two row slots and two column shifts only.
 // The head runs on the matrix pipe too: the activated tile goes to LDS as bf16 hi / lo records (all N channels of a pixel side by
 // side, whichever wave made them), wave (phase, 16-position half) multiplies its records with the head matrix (bf16x3 like the
-// rest) and writes the de-sliced image Z[s][row][column][c], rotated by 2 s floats per row against bank conflicts; the
-// workgroup copies Z out as 512- / 256-byte runs.
+// rest) and writes the de-sliced image Z[s][row][column][c]; the workgroup copies Z out as 512- / 256-byte runs.
 // ---------------------------------------------------------------------------------------------------------------------------
 struct StripLastP {
   const float* src0;
@@ -340,7 +373,7 @@ __global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kern
   constexpr int LPT = (NF4 + NTH - 1) / NTH; // loads per thread and row
   constexpr int ZROW = 64 * Cc;              // floats of one de-sliced output run
   __shared__ __attribute__((aligned(1024))) char s_ring[3 * ROWB];
-  __shared__ __attribute__((aligned(1024))) char s_y[4 * SW * 128];
+  __shared__ __attribute__((aligned(1024))) char s_y[4 * SW * 128];   // Y[phase]: 32 positions x (64 B hi + 64 B lo)
   __shared__ __attribute__((aligned(16))) float s_z[32 * ZROW];
   __shared__ __attribute__((aligned(16))) f32x4 s_wh[NT * 2 * 64];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -349,7 +382,6 @@ __global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kern
   const int ph = phase >> 1, pw = phase & 1;
   const int sy = 2 * ph - 1, sx = 2 * pw - 1;
   const int m = lane & 15, kg = lane >> 4;
-  const int gp = kg == 2 ? 3 : (kg == 3 ? 2 : kg);
 
   // ---- weights of (phase, n-tile): 4 taps x 4 chunks, hi and lo ----
   f32x4 Bh[16], Bl[16];
@@ -378,26 +410,25 @@ __global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kern
   for (int i = tid; i < 4 * SW * 8; i += NTH) reinterpret_cast<f32x4*>(s_y)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- A fragment offsets inside a row slot (column shifts 0 and sx), without the chunk plane ----
-  int a_off[2][2][2];   // [mt][tw][hi, lo]
+  int a_off[2][2];   // [mt][tw]
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int tw = 0; tw < 2; ++tw) {
-      const int i = 16 * mt + rho16(m) + 1 + tw * sx;
-      a_off[mt][tw][0] = px_addr(i, pslot_hi(kg));
-      a_off[mt][tw][1] = px_addr(i, pslot_lo(kg));
-    }
-  // ---- epilogue constants ----
-  const int n = nt * 16 + m;
-  const float sc = p.scale[n], sh = p.shift[n];
-  const int y_word = phase * (SW * 128) + ((n & 7) >> 1) * 4;   // + px_addr(position, piece slot of channel n: hi for even n, lo for odd)
-  const int y_ps = (n & 1) ? pslot_lo(n >> 3) : pslot_hi(n >> 3);
+    for (int tw = 0; tw < 2; ++tw) a_off[mt][tw] = px_addr(16 * mt + m + 1 + tw * sx, kg);
+  // ---- epilogue constants.  The weights are the MFMA's A operand (rows = channels), the positions its B operand (columns): a
+  // lane's four accumulator values are channels n0 .. n0 + 3 of ONE position (16 mt + m): an aligned 8-byte run of its Y record
+  const int n0 = nt * 16 + 4 * kg;
+  const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0), sh4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
+  constexpr int YPART = SW * 64;   // Y[phase]: 32 hi records, then 32 lo records
+  int y_ad[2];                     // hi run of this lane's channels in the record of position 16 mt + m (lo: + YPART)
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) y_ad[mt] = phase * (2 * YPART) + px_addr(16 * mt + m, n0 >> 3) + (n0 & 7) * 2;
   // head role: wave -> (phase, 16-position half) for N = 32, (phase, both halves) for N = 16
   const int h_phase = N == 32 ? (wave >> 1) : wave;
   const int h_ph = h_phase >> 1, h_pw = h_phase & 1;
-  float hb[NT];
+  f32x4 hb[NT];   // head bias of this lane's output rows c * 16 + s, s = 4 kg + j
 #pragma unroll
-  for (int hn = 0; hn < NT; ++hn) hb[hn] = p.head_b[hn * 16 + m];
+  for (int hn = 0; hn < NT; ++hn) hb[hn] = *reinterpret_cast<const f32x4*>(p.head_b + hn * 16 + 4 * kg);
   // ---- loader: this thread's pieces of an input row ----
   int l_lds[LPT], l_glb[LPT], l_px[LPT];
 #pragma unroll
@@ -408,14 +439,16 @@ __global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kern
     const int chunk = src * 2 + (pc >> 3), piece = pc & 7;
     l_px[u] = f < NF4 ? px : -1;
     l_glb[u] = src * 2 + 0;   // placeholder, set below
-    l_lds[u] = chunk * PLANE + px_addr(px, piece < 4 ? pslot_hi(piece) : pslot_lo(piece - 4));
+    l_lds[u] = chunk * PLANE + (piece < 4 ? 0 : PART) + px_addr(px, piece & 3);
     l_glb[u] = (src << 28) | (px * 64 + pc * 4);   // source in the top bits, float offset from the strip row's first record
   }
 
+  SDIAG_DECL;
   for (int job = blockIdx.x; job < p.jobs; job += gridDim.x) {
     const int b = job / p.strips;
     const int r0 = (job - b * p.strips) * SW;
     const bool has_l = r0 > 0, has_r = r0 + SW < p.Wq;
+    SDIAG(9);
 
     f32x4 pre[LPT];
     auto load_row = [&](int h) {
@@ -444,81 +477,92 @@ __global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kern
     load_row(1);
     store_row(1);
     __syncthreads();
+    SDIAG(8);
 
     for (int q = 0; q < p.Hq; ++q) {
       load_row(q + 2);   // consumed behind this step's MFMAs (a row past the image is zeros)
+      SDIAG(0);
       const int base0 = ((q + 3) % 3) * ROWB, basey = ((q + sy + 3) % 3) * ROWB;
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      {
+        // 32 groups g = (tap, chunk, mt) of one fragment pair and three MFMAs; the reads run DEPTH groups ahead
+        constexpr int G = 32, DEPTH = 2;
+        int ad[2][2][2];   // [th][tw][mt]: row slot + column shift
 #pragma unroll
-      for (int th = 0; th < 2; ++th)
+        for (int th = 0; th < 2; ++th)
 #pragma unroll
-        for (int tw = 0; tw < 2; ++tw) {
-          const int rb = th ? basey : base0;
-          int ad[2][2];
+          for (int tw = 0; tw < 2; ++tw)
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            ad[mt][0] = rb + a_off[mt][tw][0];
-            ad[mt][1] = rb + a_off[mt][tw][1];
+            for (int mt = 0; mt < 2; ++mt) ad[th][tw][mt] = (th ? basey : base0) + a_off[mt][tw];
+        Frag f[DEPTH + 1];
+#pragma unroll
+        for (int g = 0; g < G + DEPTH; ++g) {
+          if (g < G) {
+            const int tap = g >> 3, kc = (g >> 1) & 3, mt = g & 1;
+            const char* src = s_ring + kc * PLANE + ad[tap >> 1][tap & 1][mt];
+            f[g % (DEPTH + 1)].h = *reinterpret_cast<const f32x4*>(src);
+            f[g % (DEPTH + 1)].l = *reinterpret_cast<const f32x4*>(src + PART);
           }
-#pragma unroll
-          for (int kc = 0; kc < 4; ++kc) {
-            const int t = (th * 2 + tw) * 4 + kc;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-              const f32x4 ah = *reinterpret_cast<const f32x4*>(s_ring + kc * PLANE + ad[mt][0]);
-              const f32x4 al = *reinterpret_cast<const f32x4*>(s_ring + kc * PLANE + ad[mt][1]);
-              acc[mt] = mfma16(al, Bh[t], acc[mt]);
-              acc[mt] = mfma16(ah, Bl[t], acc[mt]);
-              acc[mt] = mfma16(ah, Bh[t], acc[mt]);
-            }
+          __builtin_amdgcn_sched_barrier(0);
+          if (g >= DEPTH) {
+            const int c = g - DEPTH;
+            const int t = c >> 1, mt = c & 1;
+            const Frag& a = f[c % (DEPTH + 1)];
+            acc[mt] = mfma16(Bh[t], a.l, acc[mt]);   // rows = this wave's channels, columns = the fragment's positions
+            acc[mt] = mfma16(Bl[t], a.h, acc[mt]);
+            acc[mt] = mfma16(Bh[t], a.h, acc[mt]);
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
+      }
+      SDIAG(1);
       // ---- BN + ReLU, the activated tile as bf16 hi / lo records in Y[phase][position] ----
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt) {
+        f32x4 v = acc[mt] * sc4 + sh4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int po = 16 * mt + 4 * gp + j;
-          float v = acc[mt][j] * sc + sh;
-          v = v > 0.f ? v : v * p.slope;
-          const __bf16 hbv = (__bf16)v;
-          const __bf16 lbv = (__bf16)(v - (float)hbv);
-          const unsigned h16 = __builtin_bit_cast(unsigned short, hbv), l16 = __builtin_bit_cast(unsigned short, lbv);
-          const unsigned both = h16 | (l16 << 16);
-          const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)both, 0xB1, 0xF, 0xF, true);
-          *reinterpret_cast<unsigned*>(s_y + y_word + px_addr(po, y_ps)) = (n & 1) ? ((other >> 16) | (l16 << 16)) : (h16 | (other << 16));
-        }
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], v[j] * p.slope);   // ReLU (slope 0)
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        *reinterpret_cast<bf16x4*>(s_y + y_ad[mt]) = hi;
+        *reinterpret_cast<bf16x4*>(s_y + y_ad[mt] + YPART) = lo;
+      }
+      SDIAG(2);
       __syncthreads();   // Y complete; every wave is done with row q - 1
+      SDIAG(3);
       // ---- head: z = Wh y + hb for this wave's (phase, positions), de-sliced into Z ----
       {
-        const char* yp = s_y + h_phase * (SW * 128);
+        const char* yp = s_y + h_phase * (2 * YPART);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           if (N == 32 && mt != (wave & 1)) continue;   // wave-uniform
-          const int pos = 16 * mt + rho16(m);
-          const f32x4 ah = *reinterpret_cast<const f32x4*>(yp + px_addr(pos, pslot_hi(kg)));
-          const f32x4 al = *reinterpret_cast<const f32x4*>(yp + px_addr(pos, pslot_lo(kg)));
+          const int pos = 16 * mt + m;
+          const f32x4 ah = *reinterpret_cast<const f32x4*>(yp + px_addr(pos, kg));
+          const f32x4 al = *reinterpret_cast<const f32x4*>(yp + YPART + px_addr(pos, kg));
           f32x4 z[NT];
 #pragma unroll
           for (int hn = 0; hn < NT; ++hn) {
             const f32x4 bh = s_wh[(hn * 2 + 0) * 64 + lane], bl = s_wh[(hn * 2 + 1) * 64 + lane];
-            z[hn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            z[hn] = mfma16(al, bh, z[hn]);
-            z[hn] = mfma16(ah, bl, z[hn]);
-            z[hn] = mfma16(ah, bh, z[hn]);
+            z[hn] = hb[hn];
+            z[hn] = mfma16(bh, al, z[hn]);   // rows = head outputs c * 16 + s (c = hn), columns = positions
+            z[hn] = mfma16(bl, ah, z[hn]);
+            z[hn] = mfma16(bh, ah, z[hn]);
           }
-          // lane (s = m, rows 4 kg + j): positions 16 mt + 4 gp + j, output column 2 position + pw, run (s, ph)
+          // lane: position 16 mt + m -> output column 2 position + pw; rows s = 4 kg + j of run (s, ph)
+          const int ow = 2 * (16 * mt + m) + h_pw;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int ow = 2 * (16 * mt + 4 * gp + j) + h_pw;
-            float* zr = s_z + (m * 2 + h_ph) * ZROW + ((ow * Cc + 2 * m) & (ZROW - 1));
-            if constexpr (N == 32) *reinterpret_cast<float2*>(zr) = float2{z[0][j] + hb[0], z[1][j] + hb[1]};
-            else *zr = z[0][j] + hb[0];
+            float* zr = s_z + ((4 * kg + j) * 2 + h_ph) * ZROW + ow * Cc;
+            if constexpr (N == 32) *reinterpret_cast<float2*>(zr) = float2{z[0][j], z[1][j]};
+            else *zr = z[0][j];
           }
         }
       }
+      SDIAG(4);
       store_row(q + 2);   // into the slot row q - 1 leaves
+      SDIAG(5);
       __syncthreads();    // Z complete, ring updated
+      SDIAG(6);
       {
         // 32 runs (s, row parity) of 64 output columns: ZROW floats = 512 / 256 contiguous bytes each
         constexpr int F2 = 32 * ZROW / 2;   // float2 pieces
@@ -527,14 +571,16 @@ __global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kern
           const int idx = tid + NTH * u;
           const int rs = idx / (ZROW / 2), c2 = idx - rs * (ZROW / 2);
           const int s = rs >> 1, oh = 2 * q + (rs & 1);
-          const float2 v = *reinterpret_cast<const float2*>(s_z + rs * ZROW + ((2 * c2 + 2 * s) & (ZROW - 1)));
+          const float2 v = *reinterpret_cast<const float2*>(s_z + rs * ZROW + 2 * c2);
           float* d = p.dst + (((size_t)b * (32 * p.Hq) + (size_t)s * (2 * p.Hq) + oh) * (2 * p.Wq) + 2 * r0) * Cc + 2 * c2;
           *reinterpret_cast<float2*>(d) = v;
         }
       }
+      SDIAG(7);
     }
     __syncthreads();   // the last copy-out has read Z / the ring is free for the next job's prologue
   }
+  SDIAG_END;
 }
 
 int launch_strip_last(const StripLastP& p, int N, hipStream_t st) {
@@ -542,6 +588,12 @@ int launch_strip_last(const StripLastP& p, int N, hipStream_t st) {
   else hipLaunchKernelGGL((convT_last_strip_kernel<16>), dim3(p.jobs < 512 ? p.jobs : 512), dim3(256), 0, st, p);
   return launch_status("strip_convT_last");
 }
+
+#ifdef M2H_CLOCK_DIAG
+extern "C" int m2h_diag_read_clocks_strip(unsigned long long* host_out, int nblocks) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock_dbg_strip), (size_t)nblocks * 80 * sizeof(unsigned long long));
+}
+#endif
 
 }  // namespace m2h
 

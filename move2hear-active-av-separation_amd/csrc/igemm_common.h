@@ -36,7 +36,6 @@ struct IGemmP {
   int math;      // arithmetic of this launch: 0 fp32 MFMA, 1 bf16x3 split products (args' M2H_FMT_MATH_* or the calling thread's mode)
   int presplit;  // both operands arrive in the split32 layout
   int dst_split; // epilogue writes dst in the split32 layout (bf16x3 math, NHWC, N % 32 == 0)
-  int korder;  // LDS-DMA engine: order of the k-tiles (conv_dma.hip)
   int wq_sh, hq_sh;   // log2 of Wq / Hq when they are powers of two, else -1 (decode_row)
   int pmaj;    // transposed conv: phase is folded into grid x (fastest) instead of grid z
   // tap window of the scalar-decode loader: taps th0..th0+thn-1 x tw0..tw0+twn-1 are walked, the others lie in the zero
@@ -369,7 +368,7 @@ int launch_igemm_dma(IGemmP& p, size_t ws_bytes, hipStream_t st);
 // convt_quad.hip: four-phase transposed-conv kernel (split32 operands, N <= 64); -2 when the launch is not one of its shapes
 int launch_convT_quad(IGemmP& p, hipStream_t st);
 
-// conv_bres.hip: the first encoder stage with its weights in registers (split32, 32 -> 64 channels); -2 when not that shape
-int launch_conv_bres(IGemmP& p, hipStream_t st);
+// conv_dma.hip: shape rule of the engine's two-way split-K launch (the fourth encoder stage at the benchmark batch)
+bool dma_split2_rule(long M, int N, int Kw, int phases, bool ws_present, size_t ws_bytes);
 
 }  // namespace m2h

@@ -283,3 +283,36 @@ def wgrad3x3_row(x, dy):
                     ty, tx = t // 3, t % 3
                     dw[:, t * C:(t + 1) * C] += dy[b, q, m].astype(np.float64).T @ patch[ty * PW + m + tx]
     return dw
+
+
+# ---- strip-walker kernels (csrc/conv_strip.hip): LDS patch addressing and the first stage's channel order ----
+DS_READ_B128_GROUPS = ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31],
+                       [32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59], [36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63])
+
+
+def strip_px_addr(i, j):
+    """byte offset of 16-byte piece j of pixel record i inside the hi part of a plane (px_addr in conv_strip.hip)."""
+    return i * 64 + (((j + (i >> 1)) & 3) << 4)
+
+
+def strip_read_conflict_degree(i0):
+    """Worst number of distinct addresses on one 16-byte bank slot among the lanes the LDS serves together, for a ds_read_b128 of
+    the A fragment whose first pixel record is i0: lane l reads record i0 + (l & 15), piece l >> 4 (MFMA 16x16x32 operand layout)."""
+    worst = 0
+    for group in DS_READ_B128_GROUPS:
+        slots = {}
+        for lane in group:
+            a = strip_px_addr(i0 + (lane & 15), lane >> 4)
+            slots.setdefault((a // 16) % 16, set()).add(a)
+        worst = max(worst, max(len(v) for v in slots.values()))
+    return worst
+
+
+def strip_conv1_k_order():
+    """Reference input channel (c * 16 + s) held at position k' of a tap's 32-deep reduction in the first-stage strip kernel:
+    k' = kg * 8 + sb * 4 + t * 2 + c  <->  s = 4 kg + 2 t + sb."""
+    order = []
+    for k in range(32):
+        kg, sb, t, c = k >> 3, (k >> 2) & 1, (k >> 1) & 1, k & 1
+        order.append(c * 16 + 4 * kg + 2 * t + sb)
+    return order

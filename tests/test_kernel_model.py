@@ -107,3 +107,18 @@ def test_tap_window_and_image_row_indexing_match_torch():
     assert np.abs(dx - xt.grad.permute(0, 2, 3, 1).numpy()).max() < 1e-4
     dw = KM.wgrad3x3_row(x, dy)
     assert np.abs(dw - wt.grad.permute(0, 2, 3, 1).reshape(N, 9 * C).numpy()).max() < 2e-3
+
+
+def test_strip_kernel_lds_map_is_conflict_free_and_the_channel_order_is_a_permutation():
+    """csrc/conv_strip.hip: the A-fragment reads of the strip-walker kernels hit every 16-byte bank slot exactly once per LDS
+    lane group at EVERY pixel shift (taps shift the window by one record, fragments start at multiples of 16 records, the halo
+    record adds one), records of one plane never overlap, and the first stage's in-kernel channel order covers all 32 channels."""
+    for i0 in range(0, 64):
+        assert KM.strip_read_conflict_degree(i0) == 1, i0
+    seen = set()
+    for i in range(34):
+        for j in range(4):
+            a = KM.strip_px_addr(i, j)
+            assert a % 16 == 0 and i * 64 <= a < (i + 1) * 64 and a not in seen
+            seen.add(a)
+    assert sorted(KM.strip_conv1_k_order()) == list(range(32))
