@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--ddppo-cycles", type=int, default=2, help="timed DD-PPO cycles (0 = skip); one untimed warm-up cycle precedes them")
     ap.add_argument("--math", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the conv engine in the timed U-Net pair: fp32 MFMA (exact products) or bf16x3 split products")
+    ap.add_argument("--no-other-mode", action="store_true",
+                    help="skip the pass in the other arithmetic (and the parity figure between the two): a profile of this run then holds the headline mode's kernels only")
     ap.add_argument("--train-steps", type=int, default=10, help="timed passive pre-training steps (0 = skip)")
     ap.add_argument("--train-batch", type=int, default=64, help="pretrain_passive.yaml BATCH_SIZE")
     ap.add_argument("--train-tm", type=int, default=32, help="time frames of the training clips (32 = 1 s, the reference's)")
@@ -406,17 +408,34 @@ def main():
 
     from m2h.rl.models.separator_cnn import unet_forward, UNET_KERNEL_NAMES
 
-    def unet_kernel_meta(n_out, with_masks, with_class, mode):
-        """(name, instantiation, M, N, K, algorithmic flops, algorithmic bytes) of the 11 kernels of one U-Net at this batch."""
+    def stage_labels(mode):
+        """The kernel each of the 11 stages of both U-Nets really launches at this shape, asked of the library (m2h_unet_fwd_stage_kernel)."""
+        ops.set_math_mode(ops.MATH_BF16X3 if mode == "bf16x3" else ops.MATH_FP32)
+        out = {}
+        with torch.no_grad():
+            enc, dec = pol.binSep_enc.passive_sep_encoder, pol.binSep_dec.passive_sep_decoder
+            masks = unet_forward(enc, dec, mix, None, tc)
+            out["binSep"] = ops.unet_stage_kernels()
+            enc, dec = pol.bin2mono_enc.passive_sep_encoder, pol.bin2mono_dec.passive_sep_decoder
+            unet_forward(enc, dec, mix, masks)
+            out["bin2mono"] = ops.unet_stage_kernels()
+        return out
+
+    def unet_kernel_meta(n_out, with_masks, with_class, labels):
+        """(name, kernel label, M, N, K, algorithmic flops, algorithmic bytes) of the 11 stages of one U-Net at this batch."""
         B, T = args.batch, args.tm
-        metas = [("sep_slice_input", "sep_slice_input", None, None, None, 0.0, (3 if with_masks else 2) * B * 512 * T * 2 * 4.0)]
+        fused0 = labels[0].startswith("(no launch")           # the strip kernel takes the slice and the first stage together
+        in_bytes = (2 if with_masks else 1) * B * 512 * T * 2 * 4.0
+        metas = [("sep_slice_input", labels[0], None, None, None, 0.0, 0.0 if fused0 else in_bytes + B * 512 * T * 2 * 4.0)]
         enc = [32, 64, 128, 256, 512, 512]
         H, W = 32, T
         for i in range(5):
             M, N, K = B * (H // 2) * (W // 2), enc[i + 1], 16 * enc[i]
             fl = 2.0 * M * N * 16 * (enc[i] + (1 if (i == 0 and with_class) else 0))
             by = 4.0 * (B * H * W * enc[i] + M * N + N * K)
-            metas.append(("unet_down_fwd", ops.unet_kernel_name(M, N, False, True, K) if mode == "bf16x3" else ops.igemm_config(N), M, N, K, fl, by))
+            if i == 0 and fused0:
+                by = in_bytes + 4.0 * (M * N + N * K)
+            metas.append(("unet_down_fwd", labels[1 + i], M, N, K, fl, by))
             H //= 2
             W //= 2
         c0, c1, co = [512, 512, 256, 128, 64], [0, 512, 256, 128, 64], [512, 256, 128, 64, n_out]
@@ -425,13 +444,16 @@ def main():
             fl = 2.0 * M * N * (K + (N if i == 4 else 0))                    # last stage carries the 1x1 head
             outel = M * N if i < 4 else B * 512 * T * (n_out // 16)
             by = 4.0 * (B * H * W * (c0[i] + c1[i]) + outel + 4 * N * K)
-            metas.append(("unet_up_fwd" if i < 4 else "unet_up_head_fwd",
-                          ops.unet_kernel_name(M, N, True, True) if mode == "bf16x3" else ops.igemm_config(N), M, N, K, fl, by))
+            metas.append(("unet_up_fwd" if i < 4 else "unet_up_head_fwd", labels[6 + i], M, N, K, fl, by))
             H *= 2
             W *= 2
         return metas
 
-    META = {m: {"binSep": unet_kernel_meta(32, False, True, m), "bin2mono": unet_kernel_meta(16, True, False, m)} for m in ("bf16x3", "fp32")}
+    META = {}
+    for m_ in ((args.math,) if args.no_other_mode else ("bf16x3", "fp32")):
+        lab = stage_labels(m_)
+        META[m_] = {"binSep": unet_kernel_meta(32, False, True, lab["binSep"]), "bin2mono": unet_kernel_meta(16, True, False, lab["bin2mono"])}
+    ops.set_math_mode(ops.MATH_FP32)
     current_mode = [args.math]
 
     def step_events(sink):
@@ -497,7 +519,7 @@ def main():
             pl["ms"] += ms
             pl["flops"] += meta.get("flops", 0.0)
             pl["n"] += 1
-        igemm = {k: v for k, v in fam.items() if k.startswith("igemm")}
+        igemm = {k: v for k, v in fam.items() if v["flops"] > 0}   # every conv kernel (the implicit-GEMM engines and the strip walkers)
         tot_ms = sum(v["ms"] for v in igemm.values())
         tot_fl = sum(v["flops"] for v in igemm.values())
         dom = max(igemm.items(), key=lambda kv: kv[1]["ms"])
@@ -505,7 +527,7 @@ def main():
         # HBM traffic of the dominant instantiation: PMC counters cannot be read from inside this process, so the per-launch
         # figure of the committed rocprofv3 --pmc passes over this same command is reported (null when the file is absent)
         traffic, traffic_src = None, None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_pmc_hbm_traffic.json" % r) for r in (2, 1)) if os.path.exists(q)), None)
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_pmc_hbm_traffic.json" % r) for r in (3, 2, 1)) if os.path.exists(q)), None)
         if tpath is not None:
             with open(tpath) as f:
                 tj = json.load(f).get(mode, {})
@@ -513,11 +535,12 @@ def main():
         if mode == "bf16x3":
             # every algorithmic product is three bf16 MFMA products: the ceiling of this formulation is a third of the bf16 peak
             peak = PEAK_BF16 / 3.0
-            kern = ("the implicit-GEMM conv kernels of csrc/ in bf16x3 math on split32 operands (fp32 values as bf16 hi + lo pairs; "
+            kern = ("the conv kernels of csrc/ in bf16x3 math on split32 operands (fp32 values as bf16 hi + lo pairs; "
                     "hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, fp32 accumulate): m2h::igemm_dma_kernel<256,128> "
-                    "(LDS-DMA engine: the wide stages), m2h::igemm_f32_kernel<..., SPLIT=2> (register-staged engine), "
-                    "m2h::convT_quad_kernel / m2h::convT_tap_kernel (narrow transposed stages); `achieved` is over all of them, `dominant_instantiation` the "
-                    "one with the largest share of the step")
+                    "(LDS-DMA engine: the wide stages), m2h::igemm_f32_kernel<..., SPLIT=2> (register-staged engine: the deep stages), "
+                    "m2h::convT_quad_kernel (the 64-wide transposed stage), m2h::conv1_strip_kernel / m2h::convT_last_strip_kernel (strip walkers: "
+                    "slice + first stage, last stage + head); `achieved` is over all of them, `dominant_instantiation` the one with the largest "
+                    "share of the step; labels come from the library (m2h_unet_fwd_stage_kernel)")
         else:
             peak = PEAK_F32_MFMA_TFLOPS
             kern = "m2h::igemm_f32_kernel (all instantiations; MFMA f32 32x32x2 / 16x16x4 implicit-GEMM conv)"
@@ -558,27 +581,30 @@ def main():
         roofline, layers = account(sink, args.steps, args.math)
         evented_ms = round(1e3 * ev_elapsed / args.steps, 3)
         roofline["evented_pass_ms_per_step"] = evented_ms
-    o_steps = max(2, args.steps // 3)
-    o_elapsed, _ = timed_run(other, o_steps, 1, False)
-    o_roof = None
-    if not args.no_kernel_timing:
-        _e, o_sink = timed_run(other, o_steps, 1, True)
-        o_roof, _ = account(o_sink, o_steps, other)
+    other_mode, parity = None, None
+    if not args.no_other_mode:
+        o_steps = max(2, args.steps // 3)
+        o_elapsed, _ = timed_run(other, o_steps, 1, False)
+        o_roof = None
+        if not args.no_kernel_timing:
+            _e, o_sink = timed_run(other, o_steps, 1, True)
+            o_roof, _ = account(o_sink, o_steps, other)
+        ops.set_math_mode(ops.MATH_FP32)
+        m_a, mono_a = (t.clone() for t in step())  # (graph replays return their static output buffers)
+        ops.set_math_mode(ops.MATH_BF16X3)
+        m_b, mono_b = (t.clone() for t in step())
+        ops.set_math_mode(ops.MATH_FP32)
+        em = torch.expm1(mix)
+        rel = lambda x, y: float(((x - y).abs().sum() / y.abs().sum()).item())  # noqa: E731
+        other_mode = {
+            "math": other, "value": round(world * args.batch * o_steps / o_elapsed, 1), "unit": "spectrograms/s", "steps": o_steps,
+            "ms_per_step": round(1e3 * o_elapsed / o_steps, 3),
+            "roofline": {k: o_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms_per_step", "dominant_instantiation")} if o_roof else None,
+        }
+        parity = {"what": "rel-L1 of the bf16x3 result against the fp32-MFMA result on the benchmark batch (contract: 1e-3 vs the reference)",
+                  "pred_bin": rel(m_b * em, m_a * em), "pred_mono": rel(mono_b, mono_a)}
+        del m_a, m_b, mono_a, mono_b, em
     ops.set_math_mode(ops.MATH_FP32)
-    m_a, mono_a = (t.clone() for t in step())  # (graph replays return their static output buffers)
-    ops.set_math_mode(ops.MATH_BF16X3)
-    m_b, mono_b = (t.clone() for t in step())
-    ops.set_math_mode(ops.MATH_FP32)
-    em = torch.expm1(mix)
-    rel = lambda x, y: float(((x - y).abs().sum() / y.abs().sum()).item())  # noqa: E731
-    other_mode = {
-        "math": other, "value": round(world * args.batch * o_steps / o_elapsed, 1), "unit": "spectrograms/s", "steps": o_steps,
-        "ms_per_step": round(1e3 * o_elapsed / o_steps, 3),
-        "roofline": {k: o_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms_per_step", "dominant_instantiation")} if o_roof else None,
-    }
-    parity = {"what": "rel-L1 of the bf16x3 result against the fp32-MFMA result on the benchmark batch (contract: 1e-3 vs the reference)",
-              "pred_bin": rel(m_b * em, m_a * em), "pred_mono": rel(mono_b, mono_a)}
-    del m_a, m_b, mono_a, mono_b, em
 
     ddppo = run_ddppo(args, dev, rank, world, dist) if args.ddppo_cycles > 0 else None
     ddppo_far = run_ddppo(args, dev, rank, world, dist, far_target=True) if (args.ddppo_cycles > 0 and not args.no_far_target) else None
@@ -609,7 +635,7 @@ def main():
                    "batch_per_gpu": args.batch, "n_freq": 512, "time_frames": args.tm, "parallelism": "dp%d (batch-sharded, no collective)" % world,
                    "weights": "synthetic (m2h.synthetic seed 1), reference architecture 33.47 M params",
                    "launch": ("two m2h_unet_fwd calls per step (22 kernels enqueued one by one)" if args.no_graph else
-                              "HIP graph: the step's kernels (2 input slices, 20 convs, the split-K reduces of the deep stages) captured once per arithmetic mode, replayed every step (m2h.graphs)")},
+                              "HIP graph: the step's kernels (20 convs -- the first of each U-Net with the input slice fused in --, the split-K reduces of the deep stages) captured once per arithmetic mode, replayed every step (m2h.graphs)")},
         "roofline": roofline,
         "other_math_mode": other_mode,
         "math_mode_parity": parity,

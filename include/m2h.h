@@ -557,6 +557,12 @@ int m2h_unet_fwd(const m2h_unet_weights* w /* host */, const float* mix, const f
 int m2h_unet_fwd_events(const m2h_unet_weights* w /* host */, const float* mix, const float* masks, const float* cls_val, float* out,
                         int B, int F, int T, void* workspace, size_t workspace_bytes, void* const* events, int n_events,
                         m2h_stream stream);
+/* Which kernel ran: the label of the calling thread's most recent launch through this library (thread-local, like the error
+ * string), and the labels of the 11 stages of its most recent m2h_unet_fwd / m2h_unet_fwd_events call (stage numbering as the
+ * event intervals above).  For benchmark tables and profiles -- the dispatch rules live in the library, not in its callers. */
+const char* m2h_last_kernel(void);
+const char* m2h_unet_fwd_stage_kernel(int stage);
+
 /* Strip-walker kernel of the first encoder stage (csrc/conv_strip.hip; bf16x3 arithmetic): the 16-way frequency slice
  * (separator_cnn.py:85-90), for bin2mono the pre-op log1p(clamp0(mask (exp(mix) - 1))) (:77-79), the (target_class + 1) plane
  * (:93-99, as cls_val[b] * cls_table[border class][n]) and Conv2d(4x4, s2, p1) + BN(eval) + LeakyReLU (:5-12, :101-105) in ONE

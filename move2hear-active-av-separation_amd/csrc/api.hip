@@ -4,6 +4,8 @@
 
 namespace m2h {
 thread_local char g_err[512] = {0};
+thread_local const char* tl_last_launch = "";
+thread_local const char* tl_unet_stage[11] = {"", "", "", "", "", "", "", "", "", "", ""};
 int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st);
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a);
 extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny, g_narrow16, g_extra_lds, g_phase_major, g_fast_loader, g_wgrad_blocks, g_tapshare, g_tap_bm, g_tap_window, g_wgrad_row3x3, g_row3x3, g_skinny_linear, g_skinny_gather, g_big_tile, g_dma, g_dma_shape, g_quad, g_dma_split2, g_strip;
@@ -26,6 +28,10 @@ int m2h_conv_igemm_f32(const m2h_conv_args* args, m2h_stream stream) {
 size_t m2h_conv_igemm_workspace_bytes(const m2h_conv_args* args) {
   return args != nullptr ? conv_igemm_workspace_bytes(*args) : 0;
 }
+
+const char* m2h_last_kernel(void) { return tl_last_launch; }
+
+const char* m2h_unet_fwd_stage_kernel(int stage) { return (stage >= 0 && stage < 11) ? tl_unet_stage[stage] : ""; }
 
 int m2h_set_math_mode(int mode) {
   M2H_REQUIRE(mode == M2H_MATH_FP32 || mode == M2H_MATH_BF16X3, "set_math_mode: mode must be M2H_MATH_FP32 or M2H_MATH_BF16X3");
@@ -207,8 +213,11 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
   void* sk = ws + L.splitk;
   const size_t skb = L.total - L.splitk;
   hipStream_t st = as_stream(stream);
-  int ev = 0;
+  int ev = 0, stage_no = 0;
   auto mark = [&]() -> int {
+    if (stage_no > 0 && stage_no <= 11) tl_unet_stage[stage_no - 1] = tl_last_launch;   // the stage that just went out
+    ++stage_no;
+    tl_last_launch = "(no launch: fused into the next stage)";
     if (events == nullptr) return 0;
     const hipError_t err = hipEventRecord(static_cast<hipEvent_t>(events[ev++]), st);
     return err == hipSuccess ? 0 : fail((int)err, "unet_fwd: hipEventRecord failed: %s", hipGetErrorString(err));

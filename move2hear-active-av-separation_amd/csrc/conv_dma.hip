@@ -472,7 +472,7 @@ static int launch_dma_cfg(IGemmP& p, int S, hipStream_t st) {
   else
 #endif
   hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NST, FR>), grid, dim3(64 * WM * WN), 0, st, p);
-  return launch_status("conv_igemm_f32 (LDS-DMA engine)");
+  return launch_status(BM == 256 && BN == 128 ? "igemm_dma<256,128>" : "igemm_dma");
 }
 
 // the two-way split-K launch of the 256 x 128 tile (see launch_igemm_dma): shape rule shared with conv_igemm_workspace_bytes

@@ -21,6 +21,8 @@
 //
 // Block -> tile map: n-tiles of one m-tile are consecutive on one XCD (blocks b and b+8 share an XCD's
 // L2), so the gathered A panel is fetched from HBM once and re-read from L2 by its sibling n-tiles.
+#include <string>
+
 #include "igemm_common.h"
 
 #ifndef M2H_SCHED
@@ -1139,7 +1141,7 @@ static int launch_big(IGemmP& p, size_t ws_bytes, hipStream_t st) {
     hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, 4, 2, 2, 32, 1, 2>), grid, dim3(512), 0, st, p);
   else
     hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, 4, 2, 2, 32, 1, 1>), grid, dim3(512), 0, st, p);
-  return launch_status("conv_igemm_f32 (256x128)");
+  return launch_status("igemm_f32<256,128> (eight waves)");
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int FR = 32>
@@ -1163,13 +1165,17 @@ static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
     hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1>), grid, blk, (size_t)g_extra_lds, st, p);
   else
     hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 0>), grid, blk, (size_t)g_extra_lds, st, p);
-  int rc = launch_status("conv_igemm_f32");
+  static const std::string label = "igemm_f32<" + std::to_string(BM) + "," + std::to_string(BN) + ">";   // one per instantiation
+  int rc = launch_status(label.c_str());
   if (rc != 0 || p.S == 1) return rc;
   const long total = (long)p.M * (p.N >> 2);
   long g = (total + 255) / 256;
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g, phases), dim3(256), 0, st, p);
-  return launch_status("conv_igemm_f32 split-K epilogue");
+  static const std::string label_sk = label + " + split-K reduce";
+  rc = launch_status("conv_igemm_f32 split-K epilogue");
+  tl_last_launch = label_sk.c_str();
+  return rc;
 }
 
 #ifdef M2H_CLOCK_DIAG
@@ -1310,7 +1316,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
       else M2H_TAP(64, 32);
 #undef M2H_TAP
 #undef M2H_TAP_P
-      return launch_status("conv_igemm_f32 (tap-sharing convT)");
+      return launch_status(w == 16 ? "igemm_convT_tap<16>" : (w == 32 ? "igemm_convT_tap<32>" : "igemm_convT_tap<64>"));
     }
   }
   // M <= 16 rows that are each one contiguous run of floats: Linear; a conv whose tap window covers the whole image and gives
@@ -1379,7 +1385,9 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
       long g = (total + 255) / 256;
       if (g > 4096) g = 4096;
       hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g, p.convT ? 4 : 1), dim3(256), 0, st, p);
-      return launch_status("conv_igemm_f32 split-K epilogue");
+      const int rc2 = launch_status("conv_igemm_f32 split-K epilogue");
+      tl_last_launch = "igemm_dma<256,128> + split-K reduce";
+      return rc2;
     }
   }
   if (p.math == 1 && g_big_tile >= 0 && g_fast_loader >= 0 && p.fast_ok && p.N % 128 == 0 && g_force_splitk <= 0) {

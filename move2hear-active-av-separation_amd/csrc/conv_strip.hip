@@ -334,7 +334,7 @@ int launch_strip_conv1(const float* mix, const float* masks, const void* wreg, c
   const int grid = p.jobs < 512 ? p.jobs : 512;
   if (masks != nullptr) hipLaunchKernelGGL((conv1_strip_kernel<true>), dim3(grid), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((conv1_strip_kernel<false>), dim3(grid), dim3(256), 0, st, p);
-  return launch_status("strip_conv1");
+  return launch_status(masks != nullptr ? "strip_conv1<masked>" : "strip_conv1");
 }
 
 
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kern
 int launch_strip_last(const StripLastP& p, int N, hipStream_t st) {
   if (N == 32) hipLaunchKernelGGL((convT_last_strip_kernel<32>), dim3(p.jobs < 256 ? p.jobs : 256), dim3(512), 0, st, p);
   else hipLaunchKernelGGL((convT_last_strip_kernel<16>), dim3(p.jobs < 512 ? p.jobs : 512), dim3(256), 0, st, p);
-  return launch_status("strip_convT_last");
+  return launch_status(N == 32 ? "strip_convT_last<32>" : "strip_convT_last<16>");
 }
 
 #ifdef M2H_CLOCK_DIAG

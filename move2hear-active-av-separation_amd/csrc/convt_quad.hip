@@ -371,7 +371,7 @@ int launch_convT_quad(IGemmP& p, hipStream_t st) {
   const int per = (p.MT + 7) / 8;
   const dim3 grid((unsigned)(per * 8 * p.NT)), blk(512);
   hipLaunchKernelGGL((convT_quad_kernel<32>), grid, blk, 0, st, p);
-  return launch_status("conv_igemm_f32 (four-phase transposed conv)");
+  return launch_status(p.N > 32 ? "igemm_convT_quad<64>" : "igemm_convT_quad<32>");
 }
 
 #ifdef M2H_CLOCK_DIAG

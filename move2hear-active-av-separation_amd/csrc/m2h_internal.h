@@ -18,8 +18,13 @@ inline int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// Label of the calling thread's most recent kernel launch (the `what` of launch_status: every launch site names its kernel family):
+// read back by m2h_last_kernel / m2h_unet_fwd_stage_kernel, so that benchmark tables name the kernel that really ran.
+extern thread_local const char* tl_last_launch;
+
 // Launch errors: sticky error is consumed so that a later call does not inherit it.
 inline int launch_status(const char* what) {
+  tl_last_launch = what;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
   return 0;

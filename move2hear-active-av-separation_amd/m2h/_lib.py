@@ -213,6 +213,8 @@ SIGNATURES = {
     "m2h_unet_fwd": [ctypes.POINTER(UnetWeights), _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P],
     "m2h_unet_fwd_events": [ctypes.POINTER(UnetWeights), _P, _P, _P, _P, _I, _I, _I, _P, _Z, _P, _I, _P],
     "m2h_sep_slice_input_fmt": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "m2h_last_kernel": [],
+    "m2h_unet_fwd_stage_kernel": [_I],
     "m2h_strip_conv1_weight_bytes": [],
     "m2h_pack_strip_conv1": [_P, _I, _P, _P],
     "m2h_strip_conv1_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
@@ -254,7 +256,7 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_size_t if name.endswith("_bytes") else ctypes.c_int
+            fn.restype = ctypes.c_size_t if name.endswith("_bytes") else (ctypes.c_char_p if name in ("m2h_last_kernel", "m2h_unet_fwd_stage_kernel") else ctypes.c_int)
         lib.m2h_last_error.argtypes = []
         lib.m2h_last_error.restype = ctypes.c_char_p
         _lib = lib

@@ -32,21 +32,16 @@ def igemm_config(N):
     return "igemm_f32<128,128>" if N > 64 else ("igemm_f32<128,64>" if N > 32 else ("igemm_f32<128,32>" if N > 16 else "igemm_f32<128,16>"))
 
 
-def unet_kernel_name(M, N, transposed, split32, K=0):
-    """Label of the kernel family conv_igemm_f32 (csrc/conv_igemm.hip) launches for one U-Net stage in bf16x3 math: M GEMM rows
-    over all sub-pixel phases, N output channels.  Mirrors the dispatch rules (benchmark accounting only: a wrong label moves a
-    layer's time between rows of bench.py's per-kernel table, not the measurement)."""
-    phases = 4 if transposed else 1
-    rows = M // phases
-    if split32 and N % 128 == 0 and rows > 64:
-        t256 = ((rows + 255) // 256) * (N // 128) * phases
-        if t256 >= 224 or (not transposed and 2 * t256 >= 224 and K // 32 >= 64):   # the second: two K-halves per tile (split-K slabs)
-            return "igemm_dma<256,128>"
-    if transposed and 16 < N <= 64 and split32 and (rows // 256) * ((N + 31) // 32) >= 224:
-        return "igemm_convT_quad<%d>" % (64 if N > 32 else 32)
-    if transposed and N <= 64:
-        return "igemm_convT_tap<%d>" % (64 if N > 32 else (32 if N > 16 else 16))
-    return igemm_config(N)
+def last_kernel():
+    """Label of the calling thread's most recent launch through libm2h (m2h_last_kernel)."""
+    return _lib.load().m2h_last_kernel().decode()
+
+
+def unet_stage_kernels():
+    """Labels of the 11 stages of the calling thread's most recent m2h_unet_fwd call (slice, 5 encoder stages, 4 decoder stages,
+    last stage + head): the kernels the library's dispatch really launched."""
+    lib = _lib.load()
+    return [lib.m2h_unet_fwd_stage_kernel(i).decode() for i in range(11)]
 
 
 def _timed(name, meta, dev, fn):

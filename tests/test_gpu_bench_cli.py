@@ -24,6 +24,16 @@ def test_bench_gpus_2_spawns_two_ranks_and_reports_them():
     assert line["n_gpus"] == 2 and line["ranks_observed"] == 2 and line["scaling"] == "weak"
     assert line["ddppo"]["n_gpus"] == 2 and line["ddppo"]["value"] > 0
     assert line["roofline"]["frac"] > 0 and line["config"]["batch_per_gpu"] == 8
+    # what a first real SCALE run needs to be diagnosable: per-phase GPU time, the gradient all-reduces (count, payload, time on
+    # the stream they ran on), a stand-alone all-reduce of the policy gradient's size, and who ran where
+    ph = line["ddppo"]["phases"]
+    assert ph["rollout_ms"] > 0 and ph["update_pol_ms"] > 0 and ph["update_sep_ms"] > 0
+    assert ph["grad_allreduce_count"] == 48 and ph["grad_allreduce_ms"] > 0 and ph["allreduce_23MB_us"] > 0   # 6 x 4 policy + 6 x 4 memory steps per cycle
+    assert ph["policy_grad_bytes"] in ph["grad_allreduce_payload_bytes"] and ph["policy_grad_bytes"] > 20e6
+    devs = line["ddppo"]["devices"]
+    assert [d["rank"] for d in devs] == [0, 1] and all(d["name"] for d in devs) and line["ddppo"]["distinct_devices"] == 1   # (both ranks share the box's card here)
+    rf = line["ddppo"]["roofline"]
+    assert rf["algorithmic_gflop_per_env_step"] == 13.8 and 0 < rf["frac"] < 1 and rf["executed_gflop_per_env_step"] > 3
 
 
 def test_bench_refuses_a_rank_count_that_disagrees_with_gpus():
