@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-other-mode", action="store_true",
                     help="skip the pass in the other arithmetic (and the parity figure between the two): a profile of this run then holds the headline mode's kernels only")
     ap.add_argument("--train-steps", type=int, default=10, help="timed passive pre-training steps (0 = skip)")
+    ap.add_argument("--train-math", choices=["fp32", "bf16x3"], default="fp32",
+                    help="arithmetic of the forward / input-gradient GEMMs of the passive training leg (weight gradients, BatchNorm, Adam stay fp32)")
     ap.add_argument("--train-batch", type=int, default=64, help="pretrain_passive.yaml BATCH_SIZE")
     ap.add_argument("--train-tm", type=int, default=32, help="time frames of the training clips (32 = 1 s, the reference's)")
     return ap.parse_args()
@@ -311,23 +313,28 @@ def run_passive_train(args, dev, rank):
     """Secondary figure of SURVEY 8d config 2: the passive pre-training step (train-mode BN forward, U-Net backward, Adam) on
     the reference's batch (pretrain_passive.yaml: 64 clips of 512x32) with the synthetic feeder; replicas only across GPUs
     (train-mode BN), so every rank runs the same-size job and the rate is per replica."""
+    from m2h import ops
     from m2h.pretrain.passive.passive_trainer import PassiveTrainer, passive_config
     cfg = passive_config(BATCH_SIZE=args.train_batch, TM=args.train_tm, SEED=3 + rank)
-    tr = PassiveTrainer(cfg, dev)
-    tr.setup()
-    batch = tr.feeders["train"].batch()
-    for _ in range(2):
-        tr.train_batch(*batch)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.train_steps):
-        losses = tr.train_batch(*batch)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    ops.set_math_mode(ops.MATH_BF16X3 if args.train_math == "bf16x3" else ops.MATH_FP32)
+    try:
+        tr = PassiveTrainer(cfg, dev)
+        tr.setup()
+        batch = tr.feeders["train"].batch()
+        for _ in range(2):
+            tr.train_batch(*batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            losses = tr.train_batch(*batch)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    finally:
+        ops.set_math_mode(ops.MATH_FP32)
     gf = (0.4226 if args.train_tm == 32 else 0.4226 * args.train_tm / 32) * 3.0   # SURVEY 8d: training step ~ 3x the forward
     return {"metric": "passive_train_spectrograms_per_sec", "value": round(args.train_batch * args.train_steps / el, 1),
             "unit": "spectrograms/s", "ms_per_step": round(1e3 * el / args.train_steps, 3), "batch": args.train_batch,
-            "time_frames": args.train_tm, "steps": args.train_steps,
+            "time_frames": args.train_tm, "steps": args.train_steps, "math": args.train_math,
             "algorithmic_tflops": round(gf * args.train_batch * args.train_steps / el / 1e3, 2),
             "last_losses": [round(float(x), 5) for x in losses],
             "what": "PassiveTrainer.train_batch: both U-Nets forward in train-mode BN, L1 losses, full backward, FlatAdam step"}

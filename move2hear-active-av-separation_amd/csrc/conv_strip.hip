@@ -63,6 +63,17 @@ struct Frag {
   f32x4 h, l;
 };
 
+// Job (image, strip) of a persistent workgroup's iteration: the strips of one image go to workgroups with equal blockIdx % 8 --
+// one XCD under the round-robin placement (speed only, never correctness: MI355X_MICROARCH.md) -- at consecutive slots, so the
+// halo columns two neighbouring strips both read are served by one L2 instead of being fetched from HBM twice (PMC, first version:
+// FETCH_SIZE 1.38 x the input bytes on the first stage with image-major order over all XCDs).  Needs gridDim.x % 8 == 0.
+__device__ __forceinline__ int strip_job(int linear, int strips, int jobs) {
+  const int xcd = linear & 7, y = linear >> 3;
+  const int img = (y / strips) * 8 + xcd;
+  const int job = img * strips + (y % strips);
+  return job < jobs ? job : -1;
+}
+
 __device__ __forceinline__ f32x4 mfma16(const f32x4& a, const f32x4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -93,7 +104,7 @@ struct StripConv1P {
   const float* cls_table;   // [9][64] or null
   const float* cls_val;     // [B]
   float* dst;
-  int B, T, Wq, strips, jobs;
+  int B, T, Wq, strips, jobs, jobs_padded;   // jobs_padded: linear job slots incl. the images a partial group of 8 leaves empty
   float slope;
 };
 
@@ -101,7 +112,8 @@ template <bool MASKED>
 __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p) {
   constexpr int ROW = 2 * PLANE;   // a row slot: even-column plane, odd-column plane
   __shared__ __attribute__((aligned(1024))) char s_ring[4 * ROW];
-  __shared__ __attribute__((aligned(16))) char s_out[SW * 256];
+  constexpr int OPX = 256 + 16;    // out image: a pixel's 256-byte split32 record + 16 B (the 16 lanes of a store step two bank slots each, not one)
+  __shared__ __attribute__((aligned(16))) char s_out[SW * OPX];
   __shared__ __attribute__((aligned(16))) float s_cls[9 * 64];   // the class plane's border table (read per step: no global load in the loop)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p
   // lane's four accumulator values are channels n0 .. n0 + 3 of ONE pixel (16 mt + m): an aligned 8-byte run of its split32 record
   const int n0 = wave * 16 + 4 * kg;
   const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0), sh4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
-  const int o_byte = m * 256 + (n0 >> 5) * 128 + (n0 & 31) * 2;   // hi run of pixel m's record in the out image (lo: + 64; mt: + 16 * 256)
+  const int o_byte = m * OPX + (n0 >> 5) * 128 + (n0 & 31) * 2;   // hi run of pixel m's record in the out image (lo: + 64; mt: + 16 * OPX)
   // ---- loader lanes: wave = the piece (8 channels) it writes; lane = (sb, pixel pair ii); halo lanes 0..15 = (h, t, sb, side) ----
   const int sb = lane >> 5, ii = lane & 31;
   const int hh = (lane >> 3) & 1, ht = (lane >> 2) & 1, hsb = (lane >> 1) & 1, hside = lane & 1;
@@ -143,7 +155,9 @@ __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p
   };
 
   SDIAG_DECL;
-  for (int job = blockIdx.x; job < p.jobs; job += gridDim.x) {
+  for (int lin = blockIdx.x; lin < p.jobs_padded; lin += gridDim.x) {
+    const int job = strip_job(lin, p.strips, p.jobs);
+    if (job < 0) continue;   // uniform
     const int b = job / p.strips;
     const int r0 = (job - b * p.strips) * SW;
     const float* mixb = p.mix + (size_t)b * 512 * p.T * 2;     // this image (uniform); lane offsets below are 32-bit
@@ -278,8 +292,8 @@ __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], v[j] * p.slope);   // LeakyReLU, 0 <= slope <= 1
         bf16x4 hi, lo;
         split4(v, hi, lo);
-        *reinterpret_cast<bf16x4*>(s_out + mt * (16 * 256) + o_byte) = hi;
-        *reinterpret_cast<bf16x4*>(s_out + mt * (16 * 256) + o_byte + 64) = lo;
+        *reinterpret_cast<bf16x4*>(s_out + mt * (16 * OPX) + o_byte) = hi;
+        *reinterpret_cast<bf16x4*>(s_out + mt * (16 * OPX) + o_byte + 64) = lo;
       }
       SDIAG(2);
       __syncthreads();   // every wave is done with rows 2q-1, 2q; the out image is complete
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int idx = tid + 256 * u;
-          *reinterpret_cast<f32x4*>(drow + idx * 4) = *reinterpret_cast<const f32x4*>(s_out + idx * 16);
+          *reinterpret_cast<f32x4*>(drow + idx * 4) = *reinterpret_cast<const f32x4*>(s_out + (idx >> 4) * OPX + (idx & 15) * 16);
         }
       }
       SDIAG(4);
@@ -331,7 +345,8 @@ int launch_strip_conv1(const float* mix, const float* masks, const void* wreg, c
   p.mix = mix; p.masks = masks; p.wreg = static_cast<const f32x4*>(wreg); p.scale = scale; p.shift = shift;
   p.cls_table = cls_table; p.cls_val = cls_val; p.dst = dst;
   p.B = B; p.T = T; p.Wq = T / 2; p.strips = p.Wq / SW; p.jobs = B * p.strips; p.slope = slope;
-  const int grid = p.jobs < 512 ? p.jobs : 512;
+  p.jobs_padded = (B + 7) / 8 * 8 * p.strips;
+  const int grid = p.jobs_padded < 512 ? p.jobs_padded : 512;   // a multiple of 8 (strip_job)
   if (masks != nullptr) hipLaunchKernelGGL((conv1_strip_kernel<true>), dim3(grid), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((conv1_strip_kernel<false>), dim3(grid), dim3(256), 0, st, p);
   return launch_status(masks != nullptr ? "strip_conv1<masked>" : "strip_conv1");
@@ -360,7 +375,7 @@ struct StripLastP {
   const float* head_w;   // [N][N] fp32
   const float* head_b;   // [N]
   float* dst;
-  int B, Hq, Wq, strips, jobs;
+  int B, Hq, Wq, strips, jobs, jobs_padded;
   float slope;
 };
 
@@ -444,7 +459,9 @@ __global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kern
   }
 
   SDIAG_DECL;
-  for (int job = blockIdx.x; job < p.jobs; job += gridDim.x) {
+  for (int lin = blockIdx.x; lin < p.jobs_padded; lin += gridDim.x) {
+    const int job = strip_job(lin, p.strips, p.jobs);
+    if (job < 0) continue;   // uniform
     const int b = job / p.strips;
     const int r0 = (job - b * p.strips) * SW;
     const bool has_l = r0 > 0, has_r = r0 + SW < p.Wq;
@@ -584,8 +601,8 @@ __global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kern
 }
 
 int launch_strip_last(const StripLastP& p, int N, hipStream_t st) {
-  if (N == 32) hipLaunchKernelGGL((convT_last_strip_kernel<32>), dim3(p.jobs < 256 ? p.jobs : 256), dim3(512), 0, st, p);
-  else hipLaunchKernelGGL((convT_last_strip_kernel<16>), dim3(p.jobs < 512 ? p.jobs : 512), dim3(256), 0, st, p);
+  if (N == 32) hipLaunchKernelGGL((convT_last_strip_kernel<32>), dim3(p.jobs_padded < 256 ? p.jobs_padded : 256), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL((convT_last_strip_kernel<16>), dim3(p.jobs_padded < 512 ? p.jobs_padded : 512), dim3(256), 0, st, p);
   return launch_status(N == 32 ? "strip_convT_last<32>" : "strip_convT_last<16>");
 }
 
@@ -626,6 +643,7 @@ int m2h_strip_last_fwd(const float* x, const float* skip, const float* wp_split3
   StripLastP p;
   p.src0 = x; p.src1 = skip; p.w = wp_split32; p.scale = scale; p.shift = shift; p.head_w = head_w; p.head_b = head_b; p.dst = out;
   p.B = B; p.Hq = H; p.Wq = W; p.strips = W / SW; p.jobs = B * p.strips; p.slope = 0.f;
+  p.jobs_padded = (B + 7) / 8 * 8 * p.strips;
   return launch_strip_last(p, Co, as_stream(stream));
 }
 
