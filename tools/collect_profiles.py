@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Copies the summaries of tools/profile_round3.sh (gpurun_out/r03) into profiles/ (tracked) and derives the two JSON files bench.py
+reads back: r03_pmc_hbm_traffic.json (HBM bytes per launch of every headline kernel: 2 x FETCH_SIZE + WRITE_SIZE, the guide's
+gfx950 correction for wide coalesced reads) and r03_ddppo_summary.json (launches and kernel time per DD-PPO cycle).
+usage: python tools/collect_profiles.py [gpurun_out/r03]"""
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r03")
+DST = os.path.join(ROOT, "profiles")
+
+
+def copy(src, dst):
+    if os.path.exists(os.path.join(SRC, src)):
+        shutil.copyfile(os.path.join(SRC, src), os.path.join(DST, dst))
+
+
+copy("bench/bench_kernel_stats.csv", "r03_bench_kernel_stats.csv")
+copy("ddppo/dd_kernel_stats.csv", "r03_ddppo_kernel_stats.csv")
+copy("ptrain/pt_kernel_stats.csv", "r03_passive_train_kernel_stats.csv")
+copy("feeder/fd_kernel_stats.csv", "r03_feeder_kernel_stats.csv")
+copy("bench_line_under_rocprof.json", "r03_bench_line_under_rocprof.json")
+copy("pmc_sq_tcc.txt", "r03_pmc_sq_tcc.txt")
+
+
+def pmc(path):
+    out, name = {}, None
+    if not os.path.exists(path):
+        return out
+    for line in open(path):
+        m = re.match(r"^(\S.*?)\s+calls=(\d+)", line)
+        if m:
+            name = m.group(1).replace("void ", "")
+            continue
+        m = re.match(r"^\s+(\w+)\s+total=\S+\s+per_call=(\S+)", line)
+        if m and name:
+            out[name] = float(m.group(2))
+    return out
+
+
+fetch, write = pmc(os.path.join(SRC, "pmc_FETCH_SIZE.txt")), pmc(os.path.join(SRC, "pmc_WRITE_SIZE.txt"))
+with open(os.path.join(DST, "r03_pmc_hbm_traffic.txt"), "w") as f:
+    for part in ("pmc_FETCH_SIZE.txt", "pmc_WRITE_SIZE.txt"):
+        if os.path.exists(os.path.join(SRC, part)):
+            f.write("==== %s (rocprofv3 --pmc, KiB; bench.py --steps 2 --warmup 1 --no-other-mode --no-graph) ====\n" % part)
+            f.write(open(os.path.join(SRC, part)).read())
+kern = {}
+for name in fetch:
+    if name.startswith("m2h::") and name in write:
+        kern[name] = {"fetch_kib_per_launch_raw": fetch[name], "fetch_correction": 2.0, "write_kib_per_launch": write[name],
+                      "traffic_bytes_per_launch": int((2.0 * fetch[name] + write[name]) * 1024)}
+dom = next((k for k in kern if k.startswith("m2h::igemm_dma_kernel")), None)
+src = "profiles/r03_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1 --no-other-mode --no-graph; tools/profile_round3.sh)"
+traffic = {"bf16x3": dict(kern.get(dom, {}), source=src, kernel=dom), "per_kernel": kern}
+with open(os.path.join(DST, "r03_pmc_hbm_traffic.json"), "w") as f:
+    json.dump(traffic, f, indent=1)
+
+stats = os.path.join(SRC, "ddppo", "dd_kernel_stats.csv")
+if os.path.exists(stats):
+    rows = list(csv.DictReader(open(stats)))
+    launches = sum(int(r["Calls"]) for r in rows)
+    ms = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
+    cycles = 3.0   # one warm-up + two timed cycles (bench.py --ddppo-cycles 2); set-up launches are a few hundred of the total
+    top = [(r["Name"].split("(")[0].replace("void ", ""), int(r["Calls"]), round(float(r["Percentage"]), 2)) for r in rows[:10]]
+    summ = {"near_target": {"launches_per_cycle": int(launches / cycles), "kernel_ms_per_cycle": round(ms / cycles, 2), "top10": top,
+                            "source": "profiles/r03_ddppo_kernel_stats.csv (rocprofv3 --kernel-trace --stats, bench.py --ddppo-cycles 2 --no-far-target: three cycles incl. warm-up)"}}
+    with open(os.path.join(DST, "r03_ddppo_summary.json"), "w") as f:
+        json.dump(summ, f, indent=1)
+print(json.dumps({k: v["traffic_bytes_per_launch"] for k, v in kern.items()}, indent=1))
