@@ -368,9 +368,11 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
       constexpr int ni = decltype(nic)::value;
 #pragma unroll
       for (int mi = decltype(lo)::value; mi < decltype(hi)::value; ++mi) {
-        mfma(al[mi], bh[ni], acc[mi][ni]);
-        mfma(ah[mi], bl[ni], acc[mi][ni]);
-        mfma(ah[mi], bh[ni], acc[mi][ni]);
+        // the weights as the A operand (rows = channels), the pixels as B (columns): a lane ends up with four consecutive
+        // channels of one pixel (igemm_common.h nhwc_tile_store_T); same products, same k order, same sums
+        mfma(bh[ni], al[mi], acc[mi][ni]);
+        mfma(bl[ni], ah[mi], acc[mi][ni]);
+        mfma(bh[ni], ah[mi], acc[mi][ni]);
       }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -428,6 +430,29 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
   }
 #endif
   const auto row_of = [&](int e) { return FR == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : (lane >> 4) * 4 + e; };
+  if constexpr (FR == 16) {
+    // transposed accumulators: acc[mi][ni] = channels n0 + wn TN + 16 ni + 4 (lane >> 4) + {0..3} of pixel m0 + wm TM + 16 mi + (lane & 15)
+    if (p.S > 1) {   // split-K: raw partial sums to the slab [phase][split][M][N], 16 bytes per lane
+      float* slab = p.ws + ((size_t)(phase * p.S + split) * p.M) * p.N;
+#pragma unroll
+      for (int mi = 0; mi < FM; ++mi) {
+        const int m = m0 + wm * TM + mi * 16 + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < FN; ++ni) {
+          const int n = n0 + wn * TN + ni * 16 + 4 * (lane >> 4);
+          if (n < p.N) *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + n) = acc[mi][ni];
+        }
+      }
+      return;
+    }
+    __syncthreads();
+    nhwc_tile_store_T<BM, BN, WM, WN, 16, NST * ST_BYTES, AccT>(p, acc, smem, ri_out, n0, tid);
+#ifdef M2H_CLOCK_DIAG
+    if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 8192) g_clock_dbg_dma[blockIdx.x][5] = __builtin_amdgcn_s_memrealtime();
+#endif
+    return;
+  }
   if (p.S > 1) {
     // split-K: raw partial sums to the slab [phase][split][M][N]; BN / activation / store happen in splitk_epilogue_kernel
     float* slab = p.ws + ((size_t)(phase * p.S + split) * p.M) * p.N;
@@ -491,6 +516,7 @@ static bool dma_split2_applies(const IGemmP& p, size_t ws_bytes) {
 // engine's 128 x 128 tile, the first encoder stage 218 vs 251 us on its 256 x 64 tile; both tiles removed).
 int launch_igemm_dma(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   if (g_dma < 0 || p.math != 1 || !p.presplit || !p.fast_ok || p.head_w != nullptr || p.N % 128 != 0 || p.Kw % BK != 0) return -2;
+  if (p.out_mode != M2H_OUT_NHWC || p.cls_table != nullptr || p.ldc % 4 != 0 || (reinterpret_cast<size_t>(p.dst) & 15) != 0) return -2;   // whole rows through LDS (nhwc_tile_store_T)
   if ((size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 > 8192) return -2;   // zero page covers one pixel's channels
   if (p.M <= 64) return -2;        // skinny M: the 32- / 64-row weight-streaming tiles of the register engine
   const int phases = p.convT ? 4 : 1;

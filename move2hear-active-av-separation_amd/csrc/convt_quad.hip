@@ -77,7 +77,7 @@ __device__ __forceinline__ void wait_vm_barrier() {
 
 }  // namespace
 
-template <int BN>
+template <int BN, bool HEAD>   // HEAD: the fused 1x1 head's epilogue (pixels as MFMA rows); without it the accumulators are transposed
 __global__ __launch_bounds__(512, 1) void convT_quad_kernel(const IGemmP p) {
   constexpr int BM = 256, NW = 8;
   constexpr int WN = BN / 32, WM = NW / WN;      // 64 wide: 4 x 2 waves of 64 x 32; 32 wide: 8 x 1 waves of 32 x 32
@@ -239,9 +239,15 @@ __global__ __launch_bounds__(512, 1) void convT_quad_kernel(const IGemmP p) {
       const int pl = u & 1, prod = u >> 1;
       AccT& c = acc[jt * PPT + pl][0][0];
       if constexpr (M2H_QUAD_DBG == 1) continue;
-      if (prod == 0) mfma(f.al[pl], f.bh[pl], c);
-      else if (prod == 1) mfma(f.ah[pl], f.bl[pl], c);
-      else mfma(f.ah[pl], f.bh[pl], c);
+      if constexpr (HEAD) {
+        if (prod == 0) mfma(f.al[pl], f.bh[pl], c);
+        else if (prod == 1) mfma(f.ah[pl], f.bl[pl], c);
+        else mfma(f.ah[pl], f.bh[pl], c);
+      } else {   // the weights as the A operand: a lane holds runs of four channels of one pixel (igemm_common.h nhwc_tile_store_T)
+        if (prod == 0) mfma(f.bh[pl], f.al[pl], c);
+        else if (prod == 1) mfma(f.bl[pl], f.ah[pl], c);
+        else mfma(f.bh[pl], f.ah[pl], c);
+      }
     }
   };
   using C0 = std::integral_constant<int, 0>;
@@ -348,8 +354,11 @@ __global__ __launch_bounds__(512, 1) void convT_quad_kernel(const IGemmP p) {
       if constexpr (ph > 0) __syncthreads();     // the previous phase is done with the row table
       if (tid < BM) ri_out[tid] = ri_base[0] + (ph >> 1) * p.Wo + (ph & 1);
       __syncthreads();
-      fused_epilogue<BM, BN, WM, WN, 32, AccT, NST * PATCH_BYTES>(p, acc[ph], reinterpret_cast<float*>(s_patch), reinterpret_cast<float*>(s_patch) + BM * LDK + 64,
-                                                 ri_out, ri_bc, n0, tid, ph == 0);
+      if constexpr (HEAD)
+        fused_epilogue<BM, BN, WM, WN, 32, AccT, NST * PATCH_BYTES>(p, acc[ph], reinterpret_cast<float*>(s_patch), reinterpret_cast<float*>(s_patch) + BM * LDK + 64,
+                                                   ri_out, ri_bc, n0, tid, ph == 0);
+      else
+        nhwc_tile_store_T<BM, BN, WM, WN, 32, NST * PATCH_BYTES, AccT>(p, acc[ph], s_patch, ri_out, n0, tid);
       QSTAMP(4 + ph);
       self(self, std::integral_constant<int, ph + 1>{});
     }
@@ -370,7 +379,10 @@ int launch_convT_quad(IGemmP& p, hipStream_t st) {
   p.S = 1;
   const int per = (p.MT + 7) / 8;
   const dim3 grid((unsigned)(per * 8 * p.NT)), blk(512);
-  hipLaunchKernelGGL((convT_quad_kernel<32>), grid, blk, 0, st, p);
+  // without a head the tile leaves through nhwc_tile_store_T: whole NHWC rows, 16-byte pieces
+  const bool plain = p.head_w == nullptr && p.out_mode == M2H_OUT_NHWC && p.N % 4 == 0 && p.ldc % 4 == 0 && (reinterpret_cast<size_t>(p.dst) & 15) == 0;
+  if (plain) hipLaunchKernelGGL((convT_quad_kernel<32, false>), grid, blk, 0, st, p);
+  else hipLaunchKernelGGL((convT_quad_kernel<32, true>), grid, blk, 0, st, p);
   return launch_status(p.N > 32 ? "igemm_convT_quad<64>" : "igemm_convT_quad<32>");
 }
 

@@ -195,6 +195,80 @@ __device__ __forceinline__ void nhwc_tile_store(const IGemmP& p, AccT (&acc)[BM 
   }
 }
 
+// The same store for TRANSPOSED accumulators: kernels that feed the weights as the MFMA's A operand and the pixels as its B operand
+// (conv_dma.hip with 16x16x32 fragments, convt_quad.hip without the fused head; the strip-walker kernels do the same) hold per
+// lane runs of FOUR CONSECUTIVE CHANNELS of ONE pixel -- 16x16: acc[mi][ni] = channels 16 ni + 4 (lane >> 4) + j of pixel 16 mi +
+// (lane & 15); 32x32: acc[mi][ni][4 g + j] = channels 32 ni + 8 g + 4 (lane >> 5) + j of pixel 32 mi + (lane & 31) -- so BN /
+// activation / hi-lo split are vector operations and one 8- or 16-byte LDS write per run, instead of a DPP exchange, ~20 scalar
+// VALU and a 4-byte write per VALUE.  Same values, same LDS image, same copy-out.  No class plane (the first encoder stage never
+// runs here).
+template <int BM, int BN, int WM, int WN, int FR, int SCRATCH, typename AccT>
+__device__ __forceinline__ void nhwc_tile_store_T(const IGemmP& p, AccT (&acc)[BM / WM / FR][BN / WN / FR], char* scratch, const int* ri_out,
+                                                     int n0, int tid) {
+  constexpr int NTH = 64 * WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int FM = TM / FR, FN = TN / FR;
+  constexpr int NG = FR == 32 ? 4 : 1;          // runs of four channels per fragment and lane
+  constexpr int RP = BN * 4 + 16;
+  constexpr int RMAX = SCRATCH / RP;
+  constexpr int RPASS = RMAX >= BM ? BM : (RMAX >= BM / 2 ? BM / 2 : (RMAX >= BM / 4 ? BM / 4 : BM / 8));
+  constexpr int NPASS = BM / RPASS;
+  constexpr int PIECES = BN / 4;
+  static_assert(RPASS * RP <= SCRATCH && RPASS % FR == 0 && BN % 32 == 0, "scratch too small for the tile store");
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int px = lane & (FR - 1), cq = lane / FR;
+  f32x4 sc[FN][NG], sh[FN][NG];
+  int nl[FN][NG];
+#pragma unroll
+  for (int ni = 0; ni < FN; ++ni)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      nl[ni][g] = wn * TN + ni * FR + (FR == 32 ? 8 * g : 0) + 4 * cq;   // first of the run's four columns inside the tile (N % 4 == 0)
+      const int n = n0 + nl[ni][g];
+      const bool in = n < p.N;
+      sc[ni][g] = (p.scale != nullptr && in) ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+      sh[ni][g] = (p.shift != nullptr && in) ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  __syncthreads();   // every wave is done with the main loop's LDS
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+    for (int mi = 0; mi < FM; ++mi) {
+      if ((wm * TM + mi * FR) / RPASS != pass) continue;   // wave-uniform
+      char* rowp = scratch + (wm * TM + mi * FR + px - pass * RPASS) * RP;
+#pragma unroll
+      for (int ni = 0; ni < FN; ++ni)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][4 * g + j];
+          v = v * sc[ni][g] + sh[ni][g];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+          if (p.dst_split) {
+            const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+            const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+            char* w = rowp + (nl[ni][g] & ~31) * 4 + (nl[ni][g] & 31) * 2;
+            *reinterpret_cast<bf16x4*>(w) = hi;
+            *reinterpret_cast<bf16x4*>(w + 64) = lo;
+          } else {
+            *reinterpret_cast<f32x4*>(rowp + nl[ni][g] * 4) = v;
+          }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < RPASS * PIECES; idx += NTH) {
+      const int r = idx / PIECES, pc = idx - r * PIECES;
+      const int out = ri_out[pass * RPASS + r];
+      if (out >= 0 && n0 + pc * 4 < p.N)
+        *reinterpret_cast<f32x4*>(p.dst + (size_t)out * p.ldc + n0 + pc * 4) = *reinterpret_cast<const f32x4*>(scratch + r * RP + pc * 16);
+    }
+    if (pass + 1 < NPASS) __syncthreads();
+  }
+}
+
 // Fused epilogue shared by the LDS-staged kernel and the tap-sharing transposed-conv kernel: class-plane bias, BN scale/shift
 // or bias, LeakyReLU/ReLU and the NHWC / de-sliced store; with head_w, the last decoder stage's 1x1 head on the on-chip tile.
 // As0 / Bs0: LDS scratch of at least BM*LDK and max(BN,32)*LDK floats (the main loop's tiles, free by now).

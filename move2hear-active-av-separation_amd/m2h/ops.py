@@ -701,7 +701,7 @@ def rollout_step_stats(stats, next_mem, next_gt_mono_comps, mem, gt_mono_comps, 
                        env_rewards=None, ndgs=None, dgs=None, override=True, extra=False, extra_mult=10.0):
     """The per-env bookkeeping of one rollout step in ONE launch (m2h_rollout_step_stats): reward, the three STFT-L2 distances and
     the per-episode statistics update (ppo_trainer.py:375-455).  Returns (rewards [N,1], losses [3,N]: bin / mono / mono-from-memory);
-    `stats` (the object of episode_stats_update) is updated in place.  Scratch (partial sums, tickets) is cached per (device, N)."""
+    `stats` (the object of episode_stats_update) is updated in place.  Scratch (partial sums, tickets) is cached per (device, stream, N)."""
     a = _lib.StepStatsArgs()
     N, A = probs.shape
     L = mem.shape[1] * mem.shape[2]
@@ -723,7 +723,10 @@ def rollout_step_stats(stats, next_mem, next_gt_mono_comps, mem, gt_mono_comps, 
         _chk(t, "rollout_step_stats")
         setattr(a.stats, name, t.data_ptr())
     dev = mem.device
-    key = (dev.index, N)
+    # the last-arriver protocol of the kernel assumes exclusive use of its tickets and partial slabs while a launch is in flight:
+    # launches on ONE stream are ordered, so the scratch is per (device, stream, N) -- two trainers, or a graph replay beside an
+    # eager step on another stream, never share it (a captured graph holds the addresses of the scratch of its capture stream)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, N)
     scratch = _step_stats_scratch.get(key)
     if scratch is None:
         scratch = _step_stats_scratch[key] = (torch.empty(_lib.load().m2h_step_stats_workspace_bytes(N) // 4, device=dev),

@@ -157,7 +157,7 @@ class PPO(nn.Module):
         gs = self._pol_graph
         self.optimizer_pol.build()
         sig = (id(rollouts_pol), rollouts_pol.rewards.data_ptr(), tuple(advantages.shape), float(self.value_loss_coef),
-               float(self.entropy_coef), bool(self.use_clipped_value_loss),
+               float(self.entropy_coef), bool(self.use_clipped_value_loss), ops.math_mode(),
                tuple(p.data_ptr() for p in self.optimizer_pol.param_groups[0]["params"]))
         if gs is None or gs.sig != sig:
             from types import SimpleNamespace

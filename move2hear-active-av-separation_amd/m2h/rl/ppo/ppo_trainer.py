@@ -260,7 +260,7 @@ class PPOTrainer:
             if where != gs.where:  # a parameter was re-allocated (first build, .to(), ...): captured addresses are stale
                 gs.graphs.clear()
                 gs.where = where
-        key = (bool(extra), bool(done))
+        key = (bool(extra), bool(done), ops.math_mode())   # (a graph is the kernels of ONE arithmetic: a mode change captures anew)
         g = gs.graphs.get(key)
         if g is None:
             g = torch.cuda.CUDAGraph()
