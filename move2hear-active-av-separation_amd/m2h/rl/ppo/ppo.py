@@ -224,10 +224,10 @@ class PPO(nn.Module):
         sep_frozen = not any(p.requires_grad for m in (self.actor_critic.binSep_enc, self.actor_critic.binSep_dec,
                                                         self.actor_critic.bin2mono_enc, self.actor_critic.bin2mono_dec)
                              for p in m.parameters())
-        if not sep_frozen:
-            raise NotImplementedError("m2h PPO.update_sep: training the passive separators inside RL is not built "
-                                      "(shipped configs freeze them, ppo_trainer.py:557-577)")
-        cached = self._separator_outputs(rollouts_sep) if self.cache_separator_outputs else None
+        # separators a caller left unfrozen (the reference's own trainer never does: ppo_trainer.py:557-577, :637-638): update_sep
+        # still runs them under no_grad, in whatever mode the modules are in, and back-propagates only the memory's loss (:184-195,
+        # :226); every pass of the reference is then made (no cached outputs: train-mode BatchNorm would move its statistics)
+        cached = self._separator_outputs(rollouts_sep) if (self.cache_separator_outputs and sep_frozen) else None
         for _e in range(self.ppo_epoch):
             needed = ("mixed_bin_audio_mag", "gt_mono_comps", "gt_bin_comps", "target_class")  # what this update reads
             gen = rollouts_sep.recurrent_generator(self.num_mini_batch, with_perm=True, sensors=needed)

@@ -45,6 +45,7 @@ def near_target_config(**over):
              short_rollout_threshold=1.0, sync_frac=0.6,  # nearTarget.yaml:58-59: at 1.0 the preemption of :775-781 never triggers; not built
              use_hip_graphs=True,       # build-side key: replay the rollout step and the update_pol epoch from HIP graphs (same kernels, same results)
              overlap_grad_reduce=None,  # build-side key: None = overlap the last all-reduce + step of an update when distributed
+             pretrained_passive_separators_ckpt="", train_passive_separators=False,   # nearTarget.yaml:23-24 (accepted; see setup())
              action_sampling="device")  # build-side key: "device" = multinomial noise from the device generator; "cpu_generator" = from
     #                                     the CPU default generator: the reference PyTorch-CPU run's actions from the seed alone
     c.update(over)
@@ -88,13 +89,17 @@ class PPOTrainer:
                          num_mini_batch=cfg.num_mini_batch, value_loss_coef=cfg.value_loss_coef,
                          bin_separation_loss_coef=cfg.bin_separation_loss_coef, mono_conversion_loss_coef=cfg.mono_conversion_loss_coef,
                          entropy_coef=cfg.entropy_coef, lr_pol=cfg.lr_pol, lr_sep=cfg.lr_sep, eps=cfg.eps,
-                         max_grad_norm=cfg.max_grad_norm, freeze_passive_separators=True,
+                         max_grad_norm=cfg.max_grad_norm,
+                         freeze_passive_separators=not bool(getattr(cfg, "train_passive_separators", False)),   # :72-73 (stored, read nowhere)
                          overlap_grad_reduce=getattr(cfg, "overlap_grad_reduce", None),
                          use_hip_graphs=bool(getattr(cfg, "use_hip_graphs", False)))
         self.actor_critic.train()
         if passive_state_dict is not None:
             self.agent.load_pretrained_passive_separators(passive_state_dict)
-        for name in ("binSep_enc", "binSep_dec", "bin2mono_enc", "bin2mono_dec"):  # :557-577
+        # the separators are frozen whatever RL.PPO.train_passive_separators says: the reference's train() always runs
+        # _load_pretrained_passive_separators (:637-638), which freezes unconditionally (:557-577); the flag derived from the key
+        # (:72-73) is stored by PPO and read nowhere.  Pinned by tests/golden/trainer_unfrozen.npz (the reference run with the key True).
+        for name in ("binSep_enc", "binSep_dec", "bin2mono_enc", "bin2mono_dec"):
             m = getattr(self.actor_critic, name)
             m.eval()
             for p in m.parameters():

@@ -1,6 +1,6 @@
 """Generates tests/golden/trainer_*.npz by running the REFERENCE's own training loop (build container only).
 
-    python oracle/gen_trainer_golden.py [--only near|far|ddp|eval]      (no argument: all four, one child process each)
+    python oracle/gen_trainer_golden.py [--only near|far|ddp|eval|unfrozen]      (no argument: all four, one child process each)
 
 What runs is the reference's ``PPOTrainer`` -- ``train`` (ppo_trainer.py:579-1013), ``_collect_rollout_step`` (:253-478),
 ``_update_pol`` / ``_update_sep`` (:480-541), ``_setup_actor_critic_agent`` (:54-222), ``_load_pretrained_passive_separators``
@@ -285,6 +285,11 @@ def run_reference(cfg, out_path=None):
                 out["postsample." + k] = flat[idx].numpy().copy()
     frozen = sd["binSep_enc.passive_sep_encoder.cnn.0.1.running_mean"]
     out["frozen_bn_running_mean0"] = frozen.numpy().copy()
+    if cfg.RL.PPO.train_passive_separators:   # the separators' BatchNorm buffers after training (they are what moves) and a weight (it must not)
+        for k, t in sd.items():
+            if k.startswith(("binSep_", "bin2mono_")) and ".cnn.0.1." in k and ("running_" in k or "num_batches_tracked" in k):
+                out["bn." + k] = t.numpy().copy()
+        out["sepw.binSep_enc.passive_sep_encoder.cnn.0.0.weight"] = sd["binSep_enc.passive_sep_encoder.cnn.0.0.weight"].numpy().copy()
     if out_path is not None:
         np.savez_compressed(out_path, **out)
     return out
@@ -310,6 +315,17 @@ def gen_far(_=None):
     out = run_reference(cfg)
     np.savez_compressed(os.path.join(GOLD, "trainer_far.npz"), meta=json.dumps(META), config=_cfg_record(cfg), **out)
     print("trainer_far: rewards", out["step.rewards"].reshape(len(out["step.rewards"]), -1)[:6].tolist(), "counts", out["step.stat.episode_counts"][-1].reshape(-1).tolist())
+
+
+def gen_unfrozen(_=None):
+    """RL.PPO.train_passive_separators = True (ppo_trainer.py:72-73).  What the reference then does: exactly what it does with False --
+    train() loads and freezes the separators unconditionally (:637-638, :557-577) and the flag derived from the key is stored by PPO
+    (ppo.py:46) and read nowhere.  The fixture pins that: BatchNorm buffers and a separator weight after training, next to the usual
+    trajectory / loss / weight records.  Two cycles."""
+    cfg = trainer_config(master_port=18745, train_passive_separators=True, NUM_UPDATES=4)
+    out = run_reference(cfg)
+    np.savez_compressed(os.path.join(GOLD, "trainer_unfrozen.npz"), meta=json.dumps(META), config=_cfg_record(cfg), **out)
+    print("trainer_unfrozen: sep losses", out["sep.losses"].tolist(), "bn tracked", int(out["bn.binSep_enc.passive_sep_encoder.cnn.0.1.num_batches_tracked"]))
 
 
 def _ddp_rank(rank, world, tmp):
@@ -392,7 +408,7 @@ def gen_eval(_=None):
     np.savez_compressed(os.path.join(GOLD, "trainer_eval.npz"), meta=json.dumps(META), **out)
 
 
-GENS = {"near": gen_near, "far": gen_far, "ddp": gen_ddp, "eval": gen_eval}
+GENS = {"near": gen_near, "far": gen_far, "ddp": gen_ddp, "eval": gen_eval, "unfrozen": gen_unfrozen}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

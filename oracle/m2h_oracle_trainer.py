@@ -157,14 +157,23 @@ class Rank:
         self.last_act = None
 
 
+def separate(sd, cfg, mix, target_class):
+    """One pass of the separator pair as the trainer's call sites make it (ppo_trainer.py:297-304, :358-366; ppo.py:184-195), under
+    no_grad with eval-mode BatchNorm -- whatever RL.PPO.train_passive_separators says: train() always calls
+    _load_pretrained_passive_separators (:637-638), which puts the four separator modules in eval mode and clears requires_grad
+    unconditionally (:557-577); the freeze_passive_separators flag derived from the key (:72-73) is stored by PPO.__init__
+    (ppo.py:46) and read nowhere.  Pinned by tests/golden/trainer_unfrozen.npz (the reference run with the key set to True)."""
+    pm = O.get_binSepMasks(sd, mix, target_class)
+    return pm, O.convert_bin2mono(sd, pm, mix)
+
+
 def collect_rollout_step(sd, cfg, rk, forced_actions=None):
     """ppo_trainer.py:253-478 for one rank.  forced_actions: [N,1] int64 to take instead of sampling (the action's log-prob
     is still this policy's)."""
     ro, rs, st = rk.ro, rk.rs, rk.stats
     with torch.no_grad():
         obs = {k: v[ro.step] for k, v in ro.observations.items()}                                       # :292-294
-        pm = O.get_binSepMasks(sd, obs["mixed_bin_audio_mag"], obs["target_class"])                     # :297-300
-        mono = O.convert_bin2mono(sd, pm, obs["mixed_bin_audio_mag"])                                   # :301-304
+        pm, mono = separate(sd, cfg, obs["mixed_bin_audio_mag"], obs["target_class"])                   # :297-304
         mem = O.acoustic_mem(sd, mono, O.mask_prev_mem(ro.prev_pred_monoFromMem[ro.step], ro.masks[ro.step]))   # :307-318
         feats, h, _ = O.policy_net(sd, obs, ro.recurrent_hidden_states_pol[ro.step], ro.masks[ro.step], pm, mono, mem)
         values, logp_all, probs = O.heads(sd, feats)                                                    # :321-335 (Policy.act)
@@ -178,8 +187,7 @@ def collect_rollout_step(sd, cfg, rk, forced_actions=None):
     ndgs = torch.tensor([[i[INFO_KEYS[0]]] for i in infos])
     dgs = torch.tensor([[i[INFO_KEYS[1]]] for i in infos])
     with torch.no_grad():                                                                               # :357-373
-        npm = O.get_binSepMasks(sd, batch["mixed_bin_audio_mag"], batch["target_class"])
-        nmono = O.convert_bin2mono(sd, npm, batch["mixed_bin_audio_mag"])
+        npm, nmono = separate(sd, cfg, batch["mixed_bin_audio_mag"], batch["target_class"])
         nmem = O.acoustic_mem(sd, nmono, O.mask_prev_mem(mem, masks))
     gt_mono = obs["gt_mono_comps"][..., 0::2][..., :1]
     ngt_mono = batch["gt_mono_comps"][..., 0::2][..., :1]
@@ -257,8 +265,7 @@ def update_sep(sd, opt, ranks, cfg):
             opt.zero_grad()
             for r, (obs_b, _mem_b, prev_b, m_b) in enumerate(samples):
                 with torch.no_grad():
-                    pm = O.get_binSepMasks(sd, obs_b["mixed_bin_audio_mag"], obs_b["target_class"])
-                    mono = O.convert_bin2mono(sd, pm, obs_b["mixed_bin_audio_mag"])
+                    pm, mono = separate(sd, cfg, obs_b["mixed_bin_audio_mag"], obs_b["target_class"])
                 mem = O.acoustic_mem(sd, mono, O.mask_prev_mem(prev_b, m_b))
                 gt_bin, gt_mono = O.gt_mags(obs_b)
                 mem_loss = F.l1_loss(mem, gt_mono)

@@ -39,7 +39,7 @@ def run_m2h(d, flat, replay, env_kind, graphs, rank=0, world=1, pre=""):
     keys = {k: flat[k] for k in ("num_updates_per_cycle", "hidden_size", "value_loss_coef", "entropy_coef", "lr_pol", "lr_sep", "clip_param", "ppo_epoch",
                                  "num_mini_batch", "eps", "max_grad_norm", "num_steps", "use_gae", "gamma", "tau", "use_linear_clip_decay",
                                  "use_linear_lr_decay", "sep_reward_weight", "nav_reward_weight", "extra_reward_multiplier", "reward_window_size",
-                                 "use_ddppo", "NUM_UPDATES", "CHECKPOINT_INTERVAL", "MAX_EPISODE_STEPS", "SEED", "NUM_PROCESSES")}
+                                 "use_ddppo", "NUM_UPDATES", "CHECKPOINT_INTERVAL", "MAX_EPISODE_STEPS", "SEED", "NUM_PROCESSES", "train_passive_separators")}
     cfg = near_target_config(use_hip_graphs=graphs, action_sampling="cpu_generator", **keys)
     seed = flat["SEED"] + rank * flat["NUM_PROCESSES"]
     if env_kind == "device":
@@ -107,6 +107,21 @@ def test_near_target_training_matches_the_reference_run(env_kind, graphs):
         assert rec["graphs"] == 3 and rec["trainer"].agent._pol_graph is not None
     # the frozen separators' BatchNorm statistics are untouched by training
     assert np.array_equal(rec["state_dict"]["binSep_enc.passive_sep_encoder.cnn.0.1.running_mean"].numpy(), d["frozen_bn_running_mean0"])
+
+
+def test_train_passive_separators_key_changes_nothing_as_in_the_reference():
+    """RL.PPO.train_passive_separators = True (ppo_trainer.py:72-73): the reference's train() freezes the separators all the same
+    (:637-638, :557-577) and PPO never reads the flag it stores (ppo.py:46) -- the reference run with the key set is the fixture; the
+    product with the key set reproduces it: same trajectory, losses and weights, separator BatchNorm buffers and weights untouched,
+    the step still replayed from HIP graphs."""
+    d, flat, replay = load_fixture("trainer_unfrozen.npz")
+    assert flat["train_passive_separators"] is True
+    rec = run_m2h(d, flat, replay, "device", True)
+    check_all(d, rec)
+    assert rec["graphs"] >= 2 and rec["trainer"].agent.freeze_passive_separators is False
+    for k in d.files:
+        if k.startswith(("bn.", "sepw.")):
+            assert np.array_equal(rec["state_dict"][k.split(".", 1)[1]].numpy(), d[k]), k
 
 
 def test_far_target_training_with_ragged_episodes_matches_the_reference_run():

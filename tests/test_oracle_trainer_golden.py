@@ -41,7 +41,7 @@ def run_oracle(d, flat, replay, world=1, forced=True, pre=("",)):
     return rec
 
 
-@pytest.mark.parametrize("name", ["trainer_near.npz", "trainer_far.npz"])
+@pytest.mark.parametrize("name", ["trainer_near.npz", "trainer_far.npz", "trainer_unfrozen.npz"])
 def test_oracle_training_loop_matches_reference_run(name):
     d, flat, replay = load_fixture(name)
     rec = run_oracle(d, flat, replay)
@@ -49,6 +49,18 @@ def test_oracle_training_loop_matches_reference_run(name):
     check_updates(d, rec, "", 0, 1)
     check_scalars(d, rec)
     check_weights(d, rec, "")
+    if name == "trainer_unfrozen.npz":
+        # RL.PPO.train_passive_separators = True in the reference run: the separators are frozen all the same (ppo_trainer.py:637-638,
+        # :557-577): their BatchNorm buffers and weights after training are the loaded checkpoint's
+        assert flat["train_passive_separators"] is True
+        sd0 = initial_state_dict(flat["SEED"], replay["passive_seed"])
+        n = 0
+        for k in d.files:
+            if k.startswith(("bn.", "sepw.")):
+                name_ = k.split(".", 1)[1]
+                assert np.array_equal(d[k], sd0[name_].numpy()) and np.array_equal(rec["state_dict"][name_].numpy(), d[k]), k
+                n += 1
+        assert n == 13
     if name == "trainer_near.npz":
         # the extra-reward step (episode step MAX_EPISODE_STEPS - 2 = 3, global steps 3, 8, 13) carries 2 x 10 x util(next)
         r = d["step.rewards"].reshape(len(d["step.rewards"]), -1)
