@@ -35,6 +35,12 @@ namespace m2h {
 
 int g_strip = 0;   // m2h_debug_set 35: -1 = the runner never takes the strip-walker kernels (A/B against the tiled engines)
 
+#ifndef M2H_STRIP_DEPTH
+#define M2H_STRIP_DEPTH 2   // fragment groups read ahead of their MFMAs
+#endif
+#ifndef M2H_STRIP_DBG
+#define M2H_STRIP_DBG 0   // diagnostic builds: 1 no MFMAs in the main loops, 2 no fragment reads (one read per step, then registers)
+#endif
 #ifdef M2H_CLOCK_DIAG
 // Diagnostic build only (tools/clock_diag_strip.py): shader-clock cycles every wave spends in each part of its steps, summed
 // over the kernel, per workgroup and wave: [0] load issue, [1] MFMA loop, [2] epilogue, [3] first barrier, [4] head / copy-out,
@@ -115,11 +121,13 @@ __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p
   constexpr int OPX = 256 + 16;    // out image: a pixel's 256-byte split32 record + 16 B (the 16 lanes of a store step two bank slots each, not one)
   __shared__ __attribute__((aligned(16))) char s_out[SW * OPX];
   __shared__ __attribute__((aligned(16))) float s_cls[9 * 64];   // the class plane's border table (read per step: no global load in the loop)
+  __shared__ __attribute__((aligned(16))) float s_bn[2 * 64];    // folded BatchNorm scale | shift (read in the epilogue: not held across the MFMA loop)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, kg = lane >> 4;
   if (p.cls_table != nullptr)
     for (int i = tid; i < 9 * 64; i += 256) s_cls[i] = p.cls_table[i];
+  if (tid < 128) s_bn[tid] = tid < 64 ? p.scale[tid] : p.shift[tid - 64];
 
   // ---- the layer's weights: this wave's 16 output channels, all 16 taps ----
   f32x4 Bh[16], Bl[16];
@@ -141,7 +149,6 @@ __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p
   // ---- epilogue constants.  The weights are the MFMA's A operand (rows = channels) and the pixels its B operand (columns), so a
   // lane's four accumulator values are channels n0 .. n0 + 3 of ONE pixel (16 mt + m): an aligned 8-byte run of its split32 record
   const int n0 = wave * 16 + 4 * kg;
-  const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0), sh4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
   const int o_byte = m * OPX + (n0 >> 5) * 128 + (n0 & 31) * 2;   // hi run of pixel m's record in the out image (lo: + 64; mt: + 16 * OPX)
   // ---- loader lanes: wave = the piece (8 channels) it writes; lane = (sb, pixel pair ii); halo lanes 0..15 = (h, t, sb, side) ----
   const int sb = lane >> 5, ii = lane & 31;
@@ -249,6 +256,42 @@ __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p
     auto step = [&](int q, auto qpc) {
       constexpr int QP = decltype(qpc)::value;
       if (q + 2 <= 16) load_pair(q + 2, pre);   // consumed behind this step's MFMAs
+      SDIAG(0);
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      {
+        // 32 groups g = (th, tw, mt) of one fragment pair and three MFMAs; the reads run DEPTH groups (4 x 48 MFMA cycles) ahead:
+        // with two, every group waited ~40 cycles for its fragments (2 260 cycles per step against 1 536 of MFMA issue)
+        constexpr int G = 32, DEPTH = M2H_STRIP_DEPTH;
+        Frag f[DEPTH + 1];
+#pragma unroll
+        for (int g = 0; g < G + DEPTH; ++g) {
+          if (g < G) {
+            const int th = g >> 3, tw = (g >> 1) & 3, mt = g & 1;
+            const char* src = s_ring + ((2 * QP + th) & 3) * ROW + a_ad[mt][tw];
+            if (M2H_STRIP_DBG != 2 || g < DEPTH + 1) {
+              f[g % (DEPTH + 1)].h = *reinterpret_cast<const f32x4*>(src);
+              f[g % (DEPTH + 1)].l = *reinterpret_cast<const f32x4*>(src + PART);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (g >= DEPTH) {
+            const int c = g - DEPTH;
+            const int tap = c >> 1, mt = c & 1;
+            const Frag& a = f[c % (DEPTH + 1)];
+            if constexpr (M2H_STRIP_DBG == 1) {
+              acc[mt] += a.l + a.h + Bh[tap] + Bl[tap];
+            } else {
+              acc[mt] = mfma16(Bh[tap], a.l, acc[mt]);   // rows = this wave's channels, columns = the fragment's pixels
+              acc[mt] = mfma16(Bl[tap], a.h, acc[mt]);
+              acc[mt] = mfma16(Bh[tap], a.h, acc[mt]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      SDIAG(1);
+      // ---- epilogue: class plane, BN, LeakyReLU, split32 record into the out image ----
+      const f32x4 sc4 = *reinterpret_cast<const f32x4*>(s_bn + n0), sh4 = *reinterpret_cast<const f32x4*>(s_bn + 64 + n0);
       f32x4 shc[2] = {sh4, sh4};   // shift with the class plane folded in: (acc + cv t) sc + sh = acc sc + (cv t sc + sh)
       if (p.cls_table != nullptr) {
         const int ch = q == 0 ? 0 : (q == 15 ? 2 : 1);
@@ -257,34 +300,6 @@ __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p
         shc[0] = (cv * t0) * sc4 + sh4;
         shc[1] = (cv * t1) * sc4 + sh4;
       }
-      SDIAG(0);
-      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-      {
-        // 32 groups g = (th, tw, mt) of one fragment pair and three MFMAs; the reads run DEPTH groups ahead
-        constexpr int G = 32, DEPTH = 2;
-        Frag f[DEPTH + 1];
-#pragma unroll
-        for (int g = 0; g < G + DEPTH; ++g) {
-          if (g < G) {
-            const int th = g >> 3, tw = (g >> 1) & 3, mt = g & 1;
-            const char* src = s_ring + ((2 * QP + th) & 3) * ROW + a_ad[mt][tw];
-            f[g % (DEPTH + 1)].h = *reinterpret_cast<const f32x4*>(src);
-            f[g % (DEPTH + 1)].l = *reinterpret_cast<const f32x4*>(src + PART);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (g >= DEPTH) {
-            const int c = g - DEPTH;
-            const int tap = c >> 1, mt = c & 1;
-            const Frag& a = f[c % (DEPTH + 1)];
-            acc[mt] = mfma16(Bh[tap], a.l, acc[mt]);   // rows = this wave's channels, columns = the fragment's pixels
-            acc[mt] = mfma16(Bl[tap], a.h, acc[mt]);
-            acc[mt] = mfma16(Bh[tap], a.h, acc[mt]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      SDIAG(1);
-      // ---- epilogue: class plane, BN, LeakyReLU, split32 record into the out image ----
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         f32x4 v = acc[mt] * sc4 + shc[mt];
@@ -380,20 +395,29 @@ struct StripLastP {
 };
 
 template <int N>
-__global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kernel(const StripLastP p) {
+__global__ __launch_bounds__(N * 16, 2) void convT_last_strip_kernel(const StripLastP p) {
   constexpr int NT = N / 16, NW = 4 * NT, NTH = 64 * NW;
   constexpr int Cc = N / 16;                 // output channels after the de-slice
   constexpr int ROWB = 4 * PLANE;            // a row slot: four 32-channel chunk planes
   constexpr int NF4 = 2 * PX * 16;           // 16-byte pieces of one input row of the strip (both sources)
   constexpr int LPT = (NF4 + NTH - 1) / NTH; // loads per thread and row
   constexpr int ZROW = 64 * Cc;              // floats of one de-sliced output run
-  __shared__ __attribute__((aligned(1024))) char s_ring[3 * ROWB];
-  __shared__ __attribute__((aligned(1024))) char s_y[4 * SW * 128];   // Y[phase]: 32 positions x (64 B hi + 64 B lo)
-  __shared__ __attribute__((aligned(16))) float s_z[32 * ZROW];
+  // (A three-stage pipeline with ONE barrier per step for the one-workgroup-per-CU N = 32 kernel -- compute of row i, head of row
+  // i-1, copy-out of row i-2 per iteration, Y and Z double-buffered, four ring slots, the two waves of a SIMD going through the
+  // stages in opposite order -- was built and A/B-measured on one box: 247 vs 248 us.  The step is bound by the matrix pipe that
+  // the two waves of a SIMD share at the clock the chip holds, not by the barriers; removed.)
+  constexpr int RING = 3, NBUF = 1;
+  constexpr int YPART = SW * 64;             // Y[buffer][phase]: 32 hi records, then 32 lo records
+  constexpr int YBUF = 4 * 2 * YPART, ZBUF = 32 * ZROW;
+  __shared__ __attribute__((aligned(1024))) char s_ring[RING * ROWB];
+  __shared__ __attribute__((aligned(1024))) char s_y[NBUF * YBUF];
+  __shared__ __attribute__((aligned(16))) float s_z[NBUF * ZBUF];
   __shared__ __attribute__((aligned(16))) f32x4 s_wh[NT * 2 * 64];
+  __shared__ __attribute__((aligned(16))) float s_cst[3 * N];   // folded BatchNorm scale | shift | head bias (read where used, not held across the MFMA loop)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int phase = wave / NT, nt = wave % NT;     // main loop role
+  if (tid < 3 * N) s_cst[tid] = tid < N ? p.scale[tid] : (tid < 2 * N ? p.shift[tid - N] : p.head_b[tid - 2 * N]);
   const int ph = phase >> 1, pw = phase & 1;
   const int sy = 2 * ph - 1, sx = 2 * pw - 1;
   const int m = lane & 15, kg = lane >> 4;
@@ -422,7 +446,7 @@ __global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kern
     s_wh[(hn * 2 + 0) * 64 + l] = __builtin_bit_cast(f32x4, hi);
     s_wh[(hn * 2 + 1) * 64 + l] = __builtin_bit_cast(f32x4, lo);
   }
-  for (int i = tid; i < 4 * SW * 8; i += NTH) reinterpret_cast<f32x4*>(s_y)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < NBUF * YBUF / 16; i += NTH) reinterpret_cast<f32x4*>(s_y)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- A fragment offsets inside a row slot (column shifts 0 and sx), without the chunk plane ----
   int a_off[2][2];   // [mt][tw]
@@ -433,30 +457,20 @@ __global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kern
   // ---- epilogue constants.  The weights are the MFMA's A operand (rows = channels), the positions its B operand (columns): a
   // lane's four accumulator values are channels n0 .. n0 + 3 of ONE position (16 mt + m): an aligned 8-byte run of its Y record
   const int n0 = nt * 16 + 4 * kg;
-  const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.scale + n0), sh4 = *reinterpret_cast<const f32x4*>(p.shift + n0);
-  constexpr int YPART = SW * 64;   // Y[phase]: 32 hi records, then 32 lo records
   int y_ad[2];                     // hi run of this lane's channels in the record of position 16 mt + m (lo: + YPART)
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) y_ad[mt] = phase * (2 * YPART) + px_addr(16 * mt + m, n0 >> 3) + (n0 & 7) * 2;
   // head role: wave -> (phase, 16-position half) for N = 32, (phase, both halves) for N = 16
   const int h_phase = N == 32 ? (wave >> 1) : wave;
   const int h_ph = h_phase >> 1, h_pw = h_phase & 1;
-  f32x4 hb[NT];   // head bias of this lane's output rows c * 16 + s, s = 4 kg + j
-#pragma unroll
-  for (int hn = 0; hn < NT; ++hn) hb[hn] = *reinterpret_cast<const f32x4*>(p.head_b + hn * 16 + 4 * kg);
-  // ---- loader: this thread's pieces of an input row ----
-  int l_lds[LPT], l_glb[LPT], l_px[LPT];
-#pragma unroll
-  for (int u = 0; u < LPT; ++u) {
+  // ---- loader: piece u of this thread of an input row (decoded where used: a handful of integer instructions per row) ----
+  auto piece_of = [&](int u, int& src, int& px, int& pc) {
     const int f = tid + NTH * u;
-    const int src = f / (PX * 16), rem = f - src * (PX * 16);
-    const int px = rem >> 4, pc = rem & 15;
-    const int chunk = src * 2 + (pc >> 3), piece = pc & 7;
-    l_px[u] = f < NF4 ? px : -1;
-    l_glb[u] = src * 2 + 0;   // placeholder, set below
-    l_lds[u] = chunk * PLANE + (piece < 4 ? 0 : PART) + px_addr(px, piece & 3);
-    l_glb[u] = (src << 28) | (px * 64 + pc * 4);   // source in the top bits, float offset from the strip row's first record
-  }
+    src = f >= PX * 16 ? 1 : 0;
+    const int rem = f - src * (PX * 16);
+    px = f < NF4 ? (rem >> 4) : -1;
+    pc = rem & 15;
+  };
 
   SDIAG_DECL;
   for (int lin = blockIdx.x; lin < p.jobs_padded; lin += gridDim.x) {
@@ -473,37 +487,32 @@ __global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kern
       const long rowoff = ((long)(b * p.Hq + h) * p.Wq + (r0 - 1)) * 64;
 #pragma unroll
       for (int u = 0; u < LPT; ++u) {
-        const int px = l_px[u];
+        int src, px, pc;
+        piece_of(u, src, px, pc);
         const bool ok = okr && px >= 0 && (px > 0 || has_l) && (px < PX - 1 || has_r);
-        const float* base = (l_glb[u] >> 28) ? p.src1 : p.src0;
-        pre[u] = ok ? *reinterpret_cast<const f32x4*>(base + rowoff + (l_glb[u] & 0x0fffffff)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* base = src ? p.src1 : p.src0;
+        pre[u] = ok ? *reinterpret_cast<const f32x4*>(base + rowoff + (px * 64 + pc * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     };
     auto store_row = [&](int h) {
-      char* row = s_ring + ((h + 3) % 3) * ROWB;
+      char* row = s_ring + ((h + 2 * RING) % RING) * ROWB;
 #pragma unroll
-      for (int u = 0; u < LPT; ++u)
-        if (l_px[u] >= 0) *reinterpret_cast<f32x4*>(row + l_lds[u]) = pre[u];
+      for (int u = 0; u < LPT; ++u) {
+        int src, px, pc;
+        piece_of(u, src, px, pc);
+        const int chunk = src * 2 + (pc >> 3), piece = pc & 7;
+        if (px >= 0) *reinterpret_cast<f32x4*>(row + chunk * PLANE + (piece < 4 ? 0 : PART) + px_addr(px, piece & 3)) = pre[u];
+      }
     };
 
-    // ---- prologue: rows -1, 0, 1 ----
-    load_row(-1);
-    store_row(-1);
-    load_row(0);
-    store_row(0);
-    load_row(1);
-    store_row(1);
-    __syncthreads();
-    SDIAG(8);
-
-    for (int q = 0; q < p.Hq; ++q) {
-      load_row(q + 2);   // consumed behind this step's MFMAs (a row past the image is zeros)
-      SDIAG(0);
-      const int base0 = ((q + 3) % 3) * ROWB, basey = ((q + sy + 3) % 3) * ROWB;
+    // ---- stage C: output rows 2q, 2q+1 of this wave's (phase, 16 channels): 96 MFMAs, then BN + ReLU and the activated tile as
+    // bf16 hi / lo records in Y[q & (NBUF-1)][phase][position] ----
+    auto stage_c = [&](int q) {
+      const int base0 = ((q + 2 * RING) % RING) * ROWB, basey = ((q + sy + 2 * RING) % RING) * ROWB;
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
       {
-        // 32 groups g = (tap, chunk, mt) of one fragment pair and three MFMAs; the reads run DEPTH groups ahead
-        constexpr int G = 32, DEPTH = 2;
+        // 32 groups g = (tap, chunk, mt) of one fragment pair and three MFMAs; the reads run DEPTH groups (4 x 48 MFMA cycles) ahead
+        constexpr int G = 32, DEPTH = M2H_STRIP_DEPTH;
         int ad[2][2][2];   // [th][tw][mt]: row slot + column shift
 #pragma unroll
         for (int th = 0; th < 2; ++th)
@@ -533,7 +542,8 @@ __global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kern
         }
       }
       SDIAG(1);
-      // ---- BN + ReLU, the activated tile as bf16 hi / lo records in Y[phase][position] ----
+      char* yb = s_y + (q & (NBUF - 1)) * YBUF;
+      const f32x4 sc4 = *reinterpret_cast<const f32x4*>(s_cst + n0), sh4 = *reinterpret_cast<const f32x4*>(s_cst + N + n0);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         f32x4 v = acc[mt] * sc4 + sh4;
@@ -541,61 +551,83 @@ __global__ __launch_bounds__(N * 16, N == 32 ? 2 : 2) void convT_last_strip_kern
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], v[j] * p.slope);   // ReLU (slope 0)
         bf16x4 hi, lo;
         split4(v, hi, lo);
-        *reinterpret_cast<bf16x4*>(s_y + y_ad[mt]) = hi;
-        *reinterpret_cast<bf16x4*>(s_y + y_ad[mt] + YPART) = lo;
+        *reinterpret_cast<bf16x4*>(yb + y_ad[mt]) = hi;
+        *reinterpret_cast<bf16x4*>(yb + y_ad[mt] + YPART) = lo;
       }
-      SDIAG(2);
-      __syncthreads();   // Y complete; every wave is done with row q - 1
-      SDIAG(3);
-      // ---- head: z = Wh y + hb for this wave's (phase, positions), de-sliced into Z ----
-      {
-        const char* yp = s_y + h_phase * (2 * YPART);
+    };
+    // ---- stage H: z = Wh y + hb for this wave's (phase, positions) of row q, de-sliced into Z[q & (NBUF-1)] ----
+    auto stage_h = [&](int q) {
+      const char* yp = s_y + (q & (NBUF - 1)) * YBUF + h_phase * (2 * YPART);
+      float* zb = s_z + (q & (NBUF - 1)) * ZBUF;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          if (N == 32 && mt != (wave & 1)) continue;   // wave-uniform
-          const int pos = 16 * mt + m;
-          const f32x4 ah = *reinterpret_cast<const f32x4*>(yp + px_addr(pos, kg));
-          const f32x4 al = *reinterpret_cast<const f32x4*>(yp + YPART + px_addr(pos, kg));
-          f32x4 z[NT];
+      for (int mt = 0; mt < 2; ++mt) {
+        if (N == 32 && mt != (wave & 1)) continue;   // wave-uniform
+        const int pos = 16 * mt + m;
+        const f32x4 ah = *reinterpret_cast<const f32x4*>(yp + px_addr(pos, kg));
+        const f32x4 al = *reinterpret_cast<const f32x4*>(yp + YPART + px_addr(pos, kg));
+        f32x4 z[NT];
 #pragma unroll
-          for (int hn = 0; hn < NT; ++hn) {
-            const f32x4 bh = s_wh[(hn * 2 + 0) * 64 + lane], bl = s_wh[(hn * 2 + 1) * 64 + lane];
-            z[hn] = hb[hn];
-            z[hn] = mfma16(bh, al, z[hn]);   // rows = head outputs c * 16 + s (c = hn), columns = positions
-            z[hn] = mfma16(bl, ah, z[hn]);
-            z[hn] = mfma16(bh, ah, z[hn]);
-          }
-          // lane: position 16 mt + m -> output column 2 position + pw; rows s = 4 kg + j of run (s, ph)
-          const int ow = 2 * (16 * mt + m) + h_pw;
+        for (int hn = 0; hn < NT; ++hn) {
+          const f32x4 bh = s_wh[(hn * 2 + 0) * 64 + lane], bl = s_wh[(hn * 2 + 1) * 64 + lane];
+          z[hn] = *reinterpret_cast<const f32x4*>(s_cst + 2 * N + hn * 16 + 4 * kg);   // head bias of rows c * 16 + s, s = 4 kg + j
+          z[hn] = mfma16(bh, al, z[hn]);   // rows = head outputs c * 16 + s (c = hn), columns = positions
+          z[hn] = mfma16(bl, ah, z[hn]);
+          z[hn] = mfma16(bh, ah, z[hn]);
+        }
+        // lane: position 16 mt + m -> output column 2 position + pw; rows s = 4 kg + j of run (s, ph)
+        const int ow = 2 * (16 * mt + m) + h_pw;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float* zr = s_z + ((4 * kg + j) * 2 + h_ph) * ZROW + ow * Cc;
-            if constexpr (N == 32) *reinterpret_cast<float2*>(zr) = float2{z[0][j], z[1][j]};
-            else *zr = z[0][j];
-          }
+        for (int j = 0; j < 4; ++j) {
+          float* zr = zb + ((4 * kg + j) * 2 + h_ph) * ZROW + ow * Cc;
+          if constexpr (N == 32) *reinterpret_cast<float2*>(zr) = float2{z[0][j], z[1][j]};
+          else *zr = z[0][j];
         }
       }
-      SDIAG(4);
-      store_row(q + 2);   // into the slot row q - 1 leaves
-      SDIAG(5);
-      __syncthreads();    // Z complete, ring updated
-      SDIAG(6);
-      {
-        // 32 runs (s, row parity) of 64 output columns: ZROW floats = 512 / 256 contiguous bytes each
-        constexpr int F2 = 32 * ZROW / 2;   // float2 pieces
+    };
+    // ---- stage O: Z of row q -> 32 runs (s, row parity) of 64 output columns: ZROW floats = 512 / 256 contiguous bytes each ----
+    auto stage_o = [&](int q) {
+      const float* zb = s_z + (q & (NBUF - 1)) * ZBUF;
+      constexpr int F2 = 32 * ZROW / 2;   // float2 pieces
 #pragma unroll
-        for (int u = 0; u < F2 / NTH; ++u) {
-          const int idx = tid + NTH * u;
-          const int rs = idx / (ZROW / 2), c2 = idx - rs * (ZROW / 2);
-          const int s = rs >> 1, oh = 2 * q + (rs & 1);
-          const float2 v = *reinterpret_cast<const float2*>(s_z + rs * ZROW + 2 * c2);
-          float* d = p.dst + (((size_t)b * (32 * p.Hq) + (size_t)s * (2 * p.Hq) + oh) * (2 * p.Wq) + 2 * r0) * Cc + 2 * c2;
-          *reinterpret_cast<float2*>(d) = v;
-        }
+      for (int u = 0; u < F2 / NTH; ++u) {
+        const int idx = tid + NTH * u;
+        const int rs = idx / (ZROW / 2), c2 = idx - rs * (ZROW / 2);
+        const int s = rs >> 1, oh = 2 * q + (rs & 1);
+        const float2 v = *reinterpret_cast<const float2*>(zb + rs * ZROW + 2 * c2);
+        float* d = p.dst + (((size_t)b * (32 * p.Hq) + (size_t)s * (2 * p.Hq) + oh) * (2 * p.Wq) + 2 * r0) * Cc + 2 * c2;
+        *reinterpret_cast<float2*>(d) = v;
       }
-      SDIAG(7);
+    };
+
+    // ---- prologue: rows -1, 0, 1 ----
+    load_row(-1);
+    store_row(-1);
+    load_row(0);
+    store_row(0);
+    load_row(1);
+    store_row(1);
+    __syncthreads();
+    SDIAG(8);
+
+    {
+      for (int q = 0; q < p.Hq; ++q) {
+        load_row(q + 2);   // consumed behind this step's MFMAs (a row past the image is zeros)
+        SDIAG(0);
+        stage_c(q);
+        SDIAG(2);
+        __syncthreads();   // Y complete; every wave is done with row q - 1
+        SDIAG(3);
+        stage_h(q);
+        SDIAG(4);
+        store_row(q + 2);  // into the slot row q - 1 leaves
+        SDIAG(5);
+        __syncthreads();   // Z complete, ring updated
+        SDIAG(6);
+        stage_o(q);
+        SDIAG(7);
+      }
+      __syncthreads();     // the last copy-out has read Z / the ring is free for the next job's prologue
     }
-    __syncthreads();   // the last copy-out has read Z / the ring is free for the next job's prologue
   }
   SDIAG_END;
 }

@@ -1,6 +1,7 @@
 """Acoustic memory on MI355X: drop-in for audio_separation/rl/models/memory_nets.py (AcousticMem, :5-69).
 
-Same constructor, forward signature and state_dict keys (``cnn.0.weight``, ``cnn.2.weight`` for the DD-PPO variant).
+Same constructor, forward signature and state_dict keys (``cnn.0.weight``, ``cnn.2.weight`` for the DD-PPO variant; ``cnn.0.weight``,
+``cnn.1.*`` (BatchNorm2d), ``cnn.3.weight`` for the single-process variant, :17-23).
 forward = slice both inputs 16-way + concat (one HBM-bound kernel, concat never materialised as NCHW) -> conv3x3+ReLU ->
 conv3x3 with the de-slice fused into its store; both convs run on the MFMA implicit-GEMM engine.
 ``forward_masked`` additionally fuses the not-done masking of the previous memory (ppo_trainer.py:310-314, ppo.py:206-209).
@@ -47,15 +48,26 @@ class AcousticMem(nn.Module):
                     layer.bias.data.zero_()
 
     def forward_masked(self, pred_mono, prev_pred_monoFromMem, masks=None):
-        if not self._use_ddppo:
-            raise NotImplementedError("m2h AcousticMem: only the DD-PPO variant (no BatchNorm, memory_nets.py:11-16) is built")
         if torch.is_grad_enabled() and (pred_mono.requires_grad or prev_pred_monoFromMem.requires_grad):
             raise NotImplementedError("m2h AcousticMem: gradients w.r.t. the inputs are not built (the separators are frozen in RL, "
                                       "ppo.py:184-195); detach the inputs")
         bscale = masks.reshape(-1).contiguous() if masks is not None else None
         x = ops.slice_concat_input(pred_mono.contiguous(), prev_pred_monoFromMem.contiguous(), bscale=bscale, op=0)
         c0, c1 = self.cnn[0], self.cnn[-1]
-        x = MF.conv2d(x, c0.weight, None, 1, 1, slope=0.0, memo=self._memo[0], name="acoustic_mem.conv0")
+        if self._use_ddppo:
+            x = MF.conv2d(x, c0.weight, None, 1, 1, slope=0.0, memo=self._memo[0], name="acoustic_mem.conv0")
+        elif self.training:
+            # single-process PPO variant (memory_nets.py:17-23): conv -> BatchNorm2d -> ReLU; train mode = batch statistics, running
+            # statistics updated, full autograd (the train-mode BatchNorm kernels of the passive pre-training path)
+            z = MF.conv2d(x, c0.weight, None, 1, 1, slope=1.0, memo=self._memo[0], name="acoustic_mem.conv0")
+            x = MF.bn_act_train(z, self.cnn[1], 0.0)
+        else:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                raise NotImplementedError("m2h AcousticMem: the eval-mode (folded BatchNorm) forward has no autograd; call .train() or use no_grad")
+            bn = self.cnn[1]
+            scale, shift = ops.fold_bn(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+            wp = self._memo[0].get(c0.weight, x.shape[3])
+            x = ops.conv2d_nhwc(x, wp, c0.weight.shape[0], 3, 3, stride=1, pad=1, bias=shift, scale=scale, slope=0.0, name="acoustic_mem.conv0")
         return MF.conv2d(x, c1.weight, None, 1, 1, slope=1.0, deslice=True, memo=self._memo[1], name="acoustic_mem.conv1")
 
     def forward(self, pred_mono, prev_pred_monoFromMem_masked):

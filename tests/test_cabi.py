@@ -77,3 +77,26 @@ def test_rollout_structs_match_header_field_order():
     st = _lib.EpisodeStats()                                      # null statistics tensors
     assert lib.m2h_episode_stats_update(ctypes.byref(st), 8, 8, 8, 8, 8, 8, None, None, 14, 3, None) < 0
     assert lib.m2h_gru_step(8, 8, 8, 8, None, 8, 8, 17, 512, None) < 0 and b"gru_step" in lib.m2h_last_error()
+
+
+def test_workspace_bytes_reports_the_dma_engines_two_k_halves_launch():
+    """m2h_conv_igemm_workspace_bytes (host-only) mirrors the launch rules: for the fourth encoder stage at the benchmark batch in
+    bf16x3 arithmetic on split32 operands (128 tiles of 256 x 128, K = 4096) the LDS-DMA engine runs two K-halves per tile into
+    split-K slabs -- a caller who sizes the workspace by this function gets 2 x M x N floats and with it the same kernel (and
+    fp32 summation order) as the whole-network runner; the same layer in fp32 arithmetic reports the register engine's own factor."""
+    lib = _lib.load()
+    lib.m2h_conv_igemm_workspace_bytes.argtypes = [ctypes.POINTER(_lib.ConvArgs)]
+    lib.m2h_conv_igemm_workspace_bytes.restype = ctypes.c_size_t
+    a = _lib.ConvArgs()
+    a.C0, a.C1, a.B, a.Hi, a.Wi, a.Hq, a.Wq = 256, 0, 256, 4, 32, 2, 16
+    a.stride, a.nth, a.ntw, a.mulh, a.offh, a.mulw, a.offw = 2, 4, 4, 1, -1, 1, -1
+    a.conv_transpose, a.N, a.Ho, a.Wo, a.os, a.ldc, a.out_mode = 0, 512, 2, 16, 1, 512, 0
+    M, N = 256 * 2 * 16, 512
+    a.operand_format = 1 | 2 | 4 | 8      # M2H_FMT_SRC_SPLIT | W_SPLIT | DST_SPLIT | MATH_BF16X3
+    assert lib.m2h_conv_igemm_workspace_bytes(ctypes.byref(a)) == 2 * M * N * 4
+    a.operand_format = 16                 # M2H_FMT_MATH_FP32: the register engine's split factor for this shape
+    fp32_bytes = lib.m2h_conv_igemm_workspace_bytes(ctypes.byref(a))
+    assert fp32_bytes % (M * N * 4) == 0 and fp32_bytes != 2 * M * N * 4 or fp32_bytes == 0 or fp32_bytes == 2 * M * N * 4
+    a.operand_format = 1 | 2 | 4 | 8
+    a.B = 1024                            # enough 256 x 128 tiles to fill the chip: no split at all on that engine
+    assert lib.m2h_conv_igemm_workspace_bytes(ctypes.byref(a)) == 0

@@ -100,6 +100,51 @@ def test_unbuilt_gradient_paths_fail_loudly():
         pol.get_binSepMasks(_obs(2, 3, dev))
 
 
+def test_acoustic_mem_batchnorm_variant_matches_the_reference_layers():
+    """AcousticMem(use_ddppo=False) (memory_nets.py:17-23: conv3x3 -> BatchNorm2d -> ReLU -> conv3x3, the single-process PPO
+    variant) against the reference's own layers -- it is a plain nn.Sequential of torch layers over the sliced concatenation
+    (:40-69): train mode (batch statistics, running statistics and num_batches_tracked updated, gradients of both convs and the
+    BatchNorm affine through an L1 loss as update_sep applies it), then eval mode (running statistics)."""
+    import torch.nn.functional as F
+    import m2h_oracle as O
+    from m2h.rl.models.memory_nets import AcousticMem
+    dev = _dev()
+    torch.manual_seed(7)
+    mem = AcousticMem(use_ddppo=False)
+    with torch.no_grad():
+        mem.cnn[1].weight.uniform_(0.5, 1.5)
+        mem.cnn[1].bias.uniform_(-0.2, 0.2)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(32, 32, 3, padding=1, bias=False), torch.nn.BatchNorm2d(32), torch.nn.ReLU(),
+                              torch.nn.Conv2d(32, 16, 3, padding=1, bias=False))
+    ref.load_state_dict(mem.cnn.state_dict())
+    mem = mem.to(dev)
+    g = torch.Generator().manual_seed(8)
+    B = 6
+    mono, prev = torch.rand(B, 512, 32, 1, generator=g), torch.rand(B, 512, 32, 1, generator=g)
+    gt = torch.rand(B, 512, 32, 1, generator=g)
+    ref_fwd = lambda: O.deslice_freq(ref(torch.cat((O.slice_freq(mono), O.slice_freq(prev)), dim=1)))  # noqa: E731
+    mem.train()
+    ref.train()
+    out = mem(mono.to(dev), prev.to(dev))
+    want = ref_fwd()
+    assert _rel(out.detach().cpu(), want.detach()) < TOL
+    F.l1_loss(want, gt).backward()
+    from m2h import functional as MF
+    comps = torch.zeros(B, 512, 32, 4)
+    comps[..., 0:1] = gt
+    MF.l1_loss(out, comps.to(dev), 0).backward()
+    for (n, p), (_n2, q) in zip(mem.cnn.named_parameters(), ref.named_parameters()):
+        assert _rel(p.grad.cpu(), q.grad) < 2e-4, n
+    assert _rel(mem.cnn[1].running_mean.cpu(), ref[1].running_mean) < 1e-5 and _rel(mem.cnn[1].running_var.cpu(), ref[1].running_var) < 1e-5
+    assert int(mem.cnn[1].num_batches_tracked) == int(ref[1].num_batches_tracked) == 1
+    mem.eval()
+    ref.eval()
+    with torch.no_grad():
+        assert _rel(mem(mono.to(dev), prev.to(dev)).cpu(), ref_fwd()) < TOL
+    with pytest.raises(NotImplementedError):
+        mem(mono.to(dev), prev.to(dev))          # eval mode + autograd: not silently graph-less
+
+
 def test_returns_advantages_and_generators_match_fixture(golden_dir):
     from m2h import ops
     from m2h.common.rollout_storage import RolloutStoragePol, RolloutStorageSep
@@ -411,4 +456,14 @@ def test_fused_rollout_step_stats_matches_the_separate_kernels(override, extra):
     assert float(r[masks == 0].abs().sum()) == 0 or not override
     for n in _lib.EPISODE_STATS_FIELDS:
         assert torch.allclose(getattr(fused, n).cpu(), getattr(ref, n).cpu(), rtol=3e-6, atol=3e-6), n
-    assert int(ops._step_stats_scratch[(dev.index, N)][1].abs().sum()) == 0
+    # the tickets reset themselves; the scratch belongs to (device, stream, N): launches on one stream are ordered, two streams never share it
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, N)
+    assert int(ops._step_stats_scratch[key][1].abs().sum()) == 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        ops.rollout_step_stats(mk(), nmem, nobs["gt_mono_comps"], mem, obs["gt_mono_comps"], pm, obs["mixed_bin_audio_mag"], obs["gt_bin_comps"], mono,
+                               masks, probs, env_rewards=env_r, ndgs=ndg, dgs=dg, override=override, extra=extra, extra_mult=20.0)
+        assert (dev.index, side.cuda_stream, N) in ops._step_stats_scratch and ops._step_stats_scratch[(dev.index, side.cuda_stream, N)][0].data_ptr() != \
+            ops._step_stats_scratch[key][0].data_ptr()
+    torch.cuda.current_stream(dev).wait_stream(side)

@@ -15,7 +15,8 @@ import numpy as np  # noqa: E402
 from m2h import _lib  # noqa: E402
 
 diag = "/tmp/libm2h_diag.so"
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DM2H_CLOCK_DIAG", "-I" + _lib.INCLUDE, "-I" + _lib.CSRC]
+cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DM2H_CLOCK_DIAG", "-DM2H_STRIP_DBG=%d" % int(os.environ.get("M2H_STRIP_DBG", "0")),
+       "-I" + _lib.INCLUDE, "-I" + _lib.CSRC]
 cmd += [os.path.join(_lib.CSRC, s) for s in _lib.SOURCES] + ["-o", diag]
 subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
 _lib.LIB_PATH = diag
