@@ -153,7 +153,8 @@ size_t m2h_conv_igemm_workspace_bytes(const m2h_conv_args* args /* host */);
  * tile count), 27 the LDS-DMA engine for split32 operands (csrc/conv_dma.hip; -1 off, 2 = below the tile-count threshold too),
  * 28 = 32: 32x32x16 instead of 16x16x32 MFMA fragments there, 30 the four-phase transposed-conv kernel (csrc/convt_quad.hip; -1
  * off, 1 = wherever its shape conditions hold), 34 = -1: no two-K-halves launch of the LDS-DMA engine, 35 = -1: the whole-network
- * runner does not take the strip-walker kernels (csrc/conv_strip.hip).  Numbers of experiments that were measured and removed
+ * runner does not take the strip-walker kernels (csrc/conv_strip.hip), 36 the shared-patch LDS-DMA engine (csrc/conv_patch.hip; -1
+ * off, 2 = below the tile-count threshold too).  Numbers of experiments that were measured and removed
  * (5, 6, 10, 12, 13, 17, 19, 20, 29, 31, 32) are accepted and ignored. */
 int m2h_debug_set(int knob, int value);
 

@@ -8,7 +8,7 @@ thread_local const char* tl_last_launch = "";
 thread_local const char* tl_unet_stage[11] = {"", "", "", "", "", "", "", "", "", "", ""};
 int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st);
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a);
-extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny, g_narrow16, g_extra_lds, g_phase_major, g_fast_loader, g_wgrad_blocks, g_tapshare, g_tap_bm, g_tap_window, g_wgrad_row3x3, g_row3x3, g_skinny_linear, g_skinny_gather, g_big_tile, g_dma, g_dma_shape, g_quad, g_dma_split2, g_strip;
+extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny, g_narrow16, g_extra_lds, g_phase_major, g_fast_loader, g_wgrad_blocks, g_tapshare, g_tap_bm, g_tap_window, g_wgrad_row3x3, g_row3x3, g_skinny_linear, g_skinny_gather, g_big_tile, g_dma, g_dma_shape, g_quad, g_dma_split2, g_strip, g_patch;
 extern thread_local int tl_math_mode;
 }  // namespace m2h
 
@@ -66,6 +66,7 @@ int m2h_debug_set(int knob, int value) {
   else if (knob == 30) g_quad = value;
   else if (knob == 34) g_dma_split2 = value;
   else if (knob == 35) g_strip = value;
+  else if (knob == 36) g_patch = value;
   else return fail(-1, "debug_set: unknown knob %d", knob);
   return 0;
 }

@@ -22,6 +22,7 @@
 // product order (lo*hi, hi*lo, hi*hi), split-K slabs and the fused epilogue -- is that of igemm_f32_kernel<.., SPLIT = 2>: the
 // two engines give bit-identical results on the same launch (tests/test_gpu_unet.py::test_dma_engine_matches_register_engine).
 #include "igemm_common.h"
+#include "lds_dma.h"
 
 namespace m2h {
 
@@ -35,38 +36,6 @@ __device__ __attribute__((aligned(128))) float g_zero_page[2048 + 32];   // 8 Ki
 // Diagnostic build only (tools/clock_diag_dma.py): shader-clock vs 100 MHz real-time stamps around the k-loop of each block.
 __device__ unsigned long long g_clock_dbg_dma[8192][8];   // [0] k-loop shader clocks, [1] k-loop real time, [2..6] real-time milestones
 #endif
-
-namespace {
-
-// CNT LDS-DMA loads of 16 bytes per lane: lane l of load i writes LDS bytes [dst + i*step + 16 l, +16) from src[i] (per-lane
-// pointers).  M0 (the DMA's LDS base) is written and restored inside the statement (cdna_hip_programming.md, inline-asm rules);
-// the compiler does not count these loads: completion is waited for with explicit vmcnt below.
-template <int CNT>
-__device__ __forceinline__ void glds16_run(const char* const* src, unsigned dst, unsigned step) {
-  unsigned keep;
-  static_assert(CNT == 1 || CNT == 2 || CNT == 4, "load count");
-  if constexpr (CNT == 1)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src[0]), "s"(dst)
-                 : "memory");
-  else if constexpr (CNT == 2)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                 "s_add_u32 m0, m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src[0]), "v"(src[1]), "s"(dst), "s"(step)
-                 : "memory", "scc");
-  else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
-                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "s"(dst), "s"(step)
-                 : "memory", "scc");
-}
-
-}  // namespace
 
 template <int BM, int BN, int WM, int WN, int NST, int FR = 32, int DBG = 0>   // FR: MFMA shape 32x32x16 / 16x16x32; DBG (diagnostic builds only): 3 / 6 operands from one cached page, 4 no MFMAs, 5 no loads
 __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP p) {
@@ -207,7 +176,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
       for (int i = 0; i < AG; ++i) sa[i] = ptrA[i] + cofs;
 #pragma unroll
       for (int j = 0; j < BG; ++j) sb[j] = ptrB[j] + kofs;
-      glds16_run<AG>(sa, sbase, NW * 1024u);
+      if (!((DBG == 7 || DBG == 8) && (issued & 3) != 0)) glds16_run<AG>(sa, sbase, NW * 1024u);   // 7 / 8: the pixel rows of one tile in four (timing of a shared patch)
       glds16_run<BG>(sb, sbase + A_BYTES, NW * 1024u);
     }
     ++issued;
@@ -252,7 +221,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
   };
   auto wait_and_barrier = [&](auto younger) {   // younger: tiles issued after the one being waited for (compile-time)
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(decltype(younger)::value * LPT) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(decltype(younger)::value * (DBG == 8 ? BG : LPT)) : "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
   using Y0 = std::integral_constant<int, 0>;
@@ -494,6 +463,8 @@ static int launch_dma_cfg(IGemmP& p, int S, hipStream_t st) {
   else if (g_dma == 4) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 4>), grid, dim3(64 * WM * WN), 0, st, p);
   else if (g_dma == 5) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 5>), grid, dim3(64 * WM * WN), 0, st, p);
   else if (g_dma == 6) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 6>), grid, dim3(64 * WM * WN), 0, st, p);
+  else if (g_dma == 7) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 7>), grid, dim3(64 * WM * WN), 0, st, p);
+  else if (g_dma == 8) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 8>), grid, dim3(64 * WM * WN), 0, st, p);
   else
 #endif
   hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NST, FR>), grid, dim3(64 * WM * WN), 0, st, p);

@@ -1378,6 +1378,8 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   // the larger tile reads 384 operand rows per 256 x 128 outputs instead of 512.  (A 256 x 64 tile for the 64-wide first encoder
   // stage measured slower: 252 vs 235 us.)
   if (g_fast_loader >= 0 && g_force_splitk <= 0) {   // split32 operands, wide N: the LDS-DMA engine (conv_dma.hip)
+    const int rcp = launch_igemm_patch(p, st);
+    if (rcp != -2) return rcp;
     const int rc = launch_igemm_dma(p, wsb, st);
     if (rc != -2) {
       if (rc != 0 || p.S == 1) return rc;

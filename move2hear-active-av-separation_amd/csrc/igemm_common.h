@@ -439,6 +439,9 @@ extern int g_big_tile;
 // conv_dma.hip: LDS-DMA engine; returns -2 when the launch is not one of its shapes (the caller falls through), 0 / error otherwise
 int launch_igemm_dma(IGemmP& p, size_t ws_bytes, hipStream_t st);
 
+// conv_patch.hip: shared-patch LDS-DMA engine (4x4/s2 convs and transposed-conv phases, N % 128 == 0); -2 when not one of its shapes
+int launch_igemm_patch(IGemmP& p, hipStream_t st);
+
 // convt_quad.hip: four-phase transposed-conv kernel (split32 operands, N <= 64); -2 when the launch is not one of its shapes
 int launch_convT_quad(IGemmP& p, hipStream_t st);
 

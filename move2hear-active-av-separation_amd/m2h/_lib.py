@@ -16,7 +16,7 @@ CSRC = os.path.join(_PKG_ROOT, "csrc")
 INCLUDE = os.path.join(_REPO_ROOT, "include")
 # M2H_LIB: kernel-tuning override -- load an experimental build of the same C-ABI (tools/build_variant.sh) instead of the in-tree one
 LIB_PATH = os.environ.get("M2H_LIB") or os.path.join(_HERE, "libm2h.so")
-SOURCES = ["conv_igemm.hip", "conv_dma.hip", "convt_quad.hip", "conv_strip.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "rollout_fused.hip", "pack_batch.hip", "fftconv.hip", "api.hip"]
+SOURCES = ["conv_igemm.hip", "conv_dma.hip", "conv_patch.hip", "convt_quad.hip", "conv_strip.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "rollout_fused.hip", "pack_batch.hip", "fftconv.hip", "api.hip"]
 
 _lock = threading.Lock()
 _lib = None
@@ -26,7 +26,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "m2h_internal.h"), os.path.join(CSRC, "igemm_common.h"), os.path.join(INCLUDE, "m2h.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "m2h_internal.h"), os.path.join(CSRC, "igemm_common.h"), os.path.join(CSRC, "lds_dma.h"), os.path.join(INCLUDE, "m2h.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
