@@ -543,9 +543,10 @@ def main():
             # every algorithmic product is three bf16 MFMA products: the ceiling of this formulation is a third of the bf16 peak
             peak = PEAK_BF16 / 3.0
             kern = ("the conv kernels of csrc/ in bf16x3 math on split32 operands (fp32 values as bf16 hi + lo pairs; "
-                    "hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, fp32 accumulate): m2h::igemm_dma_kernel<256,128> "
-                    "(LDS-DMA engine: the wide stages), m2h::igemm_f32_kernel<..., SPLIT=2> (register-staged engine: the deep stages), "
-                    "m2h::convT_quad_kernel (the 64-wide transposed stage), m2h::conv1_strip_kernel / m2h::convT_last_strip_kernel (strip walkers: "
+                    "hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, fp32 accumulate): m2h::igemm_patch_kernel "
+                    "(shared-patch LDS-DMA engine, 256x128 and 512x64 tiles: the wide stages and the 64-wide transposed stage), "
+                    "m2h::igemm_dma_kernel<256,128> (LDS-DMA engine, two K-halves: the fourth encoder stage), m2h::igemm_f32_kernel<..., SPLIT=2> "
+                    "(register-staged engine: the deepest stages), m2h::conv1_strip_kernel / m2h::convT_last_strip_kernel (strip walkers: "
                     "slice + first stage, last stage + head); `achieved` is over all of them, `dominant_instantiation` the one with the largest "
                     "share of the step; labels come from the library (m2h_unet_fwd_stage_kernel)")
         else:

@@ -1275,6 +1275,11 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
 
   p.ws = static_cast<float*>(a.workspace);
   const size_t wsb = a.workspace != nullptr ? a.workspace_bytes : 0;
+  // split32 operands, 4x4/s2 conv or transposed conv, N a multiple of 64, a chip's worth of tiles: the shared-patch engine (conv_patch.hip)
+  if (p.presplit && g_fast_loader >= 0 && g_force_splitk <= 0 && g_phase_major >= 0) {
+    const int rc = launch_igemm_patch(p, st);
+    if (rc != -2) return rc;
+  }
   // narrow transposed convs on split32 operands: all four phases from one staged patch (convt_quad.hip)
   if (p.convT && p.presplit && g_force_splitk <= 0 && g_phase_major >= 0) {
     const int rc = launch_convT_quad(p, st);
@@ -1378,8 +1383,6 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   // the larger tile reads 384 operand rows per 256 x 128 outputs instead of 512.  (A 256 x 64 tile for the 64-wide first encoder
   // stage measured slower: 252 vs 235 us.)
   if (g_fast_loader >= 0 && g_force_splitk <= 0) {   // split32 operands, wide N: the LDS-DMA engine (conv_dma.hip)
-    const int rcp = launch_igemm_patch(p, st);
-    if (rcp != -2) return rcp;
     const int rc = launch_igemm_dma(p, wsb, st);
     if (rc != -2) {
       if (rc != 0 || p.S == 1) return rc;

@@ -1,4 +1,4 @@
-// Shared-patch LDS-DMA engine (gfx950, bf16x3 math, split32 operands): the 256 x 128 tile of conv_dma.hip for the two layer
+// Shared-patch LDS-DMA engine (gfx950, bf16x3 math, split32 operands): the eight-wave tile of conv_dma.hip for the two layer
 // shapes of the separator U-Nets' wide stages -- Conv2d(4, 2, 1) (separator_cnn.py:5-13,46-52) and one phase of
 // ConvTranspose2d(4, 2, 1) (separator_cnn.py:15-24,128-135) -- with the pixel operand staged ONCE per four taps.
 //
@@ -8,58 +8,90 @@
 //     conv   tap (2a + gh, 2b + gw) of output (oh, ow)  reads  P[oh + a][ow + b],  P[i][j] = in(2i + gh - 1, 2j + gw - 1)
 //     convT  tap (th, tw) of phase (ph, pw), pixel (q, r) reads  P[q + a][r + b],    P[i][j] = in(i + ph - 1, j + pw - 1),
 //                                                              a = ph ? th : 1 - th,  b = pw ? tw : 1 - tw
-// So a block stages the (rows + 1) x (W + 1) patch P of its 256 output pixels once per (class, chunk) -- 297 to 340 rows of
-// 128 B instead of 4 x 256 -- and the four taps read their fragments from it at a row shift a (W + 1) + b.  Measured on the
-// old engine with three of four pixel-row DMAs dropped (tools/clock_diag_dma.py, knob 7): the operand stream into the CU, not the
-// matrix pipe, was what the k-tile waited for (2 390 -> 2 236 cycles per k-tile and a 5 % higher clock under the lighter
-// memory traffic); every re-read of an input line now comes from LDS instead of from beyond L2.
+// So a block stages the patch P of its output pixels once per (class, chunk) and the four taps read their fragments from it at a
+// row shift.  Measured on the old engine with three of four pixel-row DMAs dropped (tools/clock_diag_dma.py, knob 7): the
+// operand stream into the CU, not the matrix pipe, was what the k-tile waited for (2 390 -> 2 236 cycles per k-tile and a 5 %
+// higher clock under the lighter memory traffic); every re-read of an input line now comes from LDS instead of from beyond L2.
 //
-// LDS: two patch buffers of 48 KB (384 rows: six 8-row DMA groups per wave, rows past the patch copy zeros) + a ring of three
-// 16 KB weight stages = 144 KB; rows unpadded with the piece permutation of conv_dma.hip (LDS piece j of row r holds split32
-// piece j ^ ((r >> 1) & 7)): a 16-lane group of a ds_read_b128 reads 16 CONSECUTIVE patch rows at any shift (fragments start at
-// multiples of 16 output columns and W is a multiple of 16, so a fragment never crosses the end of a patch row), which is the
-// conflict-free case of that permutation.
+// Two patch forms:
+//   WHOLE = 1  the tile holds whole images (H W divides the tile's pixel count; every decoder stage and the deeper encoder
+//              stages).  A tile row spans the image's width and its rows span the image's height, so every halo pixel of P is
+//              zero padding: only the data pixels are staged -- patch row m = the input pixel under output pixel m: in(k, l) for a
+//              transposed conv, in(2k + 1 - gh, 2l + 1 - gw) for class (gh, gw) of a conv -- and a fragment row that falls off
+//              its image reads one shared 128-byte row of zeros instead (per-lane edge flags against the tap's direction).
+//   WHOLE = 0  a tile is some rows of a larger image (down1 at 256 frames: 4 of 8 rows): the (rows + 1) x (W + 1) patch with
+//              its halo row (data of the neighbouring tile, or padding) and halo column staged as rows of their own, 297 to 340
+//              rows in a 384-row buffer (rows past the patch copy zeros).
+// Tiles: 256 x 128 (4 x 2 waves) for N % 128 == 0, 512 x 64 (8 x 1 waves) for the 64-wide decoder stage; wave tile 64 x 64.
+//
+// LDS: two patch buffers + a ring of three weight stages (+ the zero row), rows unpadded with the piece permutation of
+// conv_dma.hip (LDS piece j of row r holds split32 piece j ^ ((r >> 1) & 7)): a 16-lane group of a ds_read_b128 reads 16
+// CONSECUTIVE patch rows at any shift, the conflict-free case of that permutation (WHOLE = 0: fragments start at multiples of 16
+// output columns and W is a multiple of 16, so a fragment never crosses the end of a patch row).
 //
 // Pipeline: as conv_dma.hip's 16x16x32 path (fragment reads half a tile ahead, one barrier in the middle of each k-tile,
 // counted vmcnt waits, straight-line steady state), unrolled over the four taps of a patch: the weights of tile t+3 are issued in
 // tile t, the patch of class/chunk s+1 in the first tile of s (behind that tile's weights, so the counts are compile-time:
-// 2, 8, 8, 2 loads may stay in flight at the four barriers).
+// BG, BG + AG, BG + AG, BG loads may stay in flight at the four barriers).
 // k order: (class, chunk, tap) -- another summation order than the (tap, chunk) of the other engines (rel-L1 ~1e-6 between them).
 #include "igemm_common.h"
 #include "lds_dma.h"
 
 namespace m2h {
 
-int g_patch = 0;   // m2h_debug_set 36: -1 never use this engine; 2 = also below its tile-count threshold (tests)
+int g_patch = 0;   // m2h_debug_set 36: -1 never use this engine; 2 = also below its tile-count threshold (tests); 3 = as 2, and the whole-image patch wherever it fits
 
 __device__ __attribute__((aligned(128))) float g_zero_page_patch[2048 + 32];   // 8 KiB + one row: source of padding rows at any channel offset
 
+#ifdef M2H_CLOCK_DIAG
+// Diagnostic build only (tools/clock_diag_dma.py patch ...): shader-clock vs 100 MHz real-time stamps around the k-loop of each block.
+__device__ unsigned long long g_clock_dbg_patch[8192][8];   // [0] k-loop shader clocks, [1] k-loop real time, [2..5] real-time milestones
+#endif
+
 namespace {
 
-constexpr int PBM = 256, PBN = 128, PWM = 4, PWN = 2, PNW = PWM * PWN;
-constexpr int PA_ROWS = 384, PA_BYTES = PA_ROWS * 128, PB_BYTES = PBN * 128, PNSTB = 3;
-constexpr int PSMEM = 2 * PA_BYTES + PNSTB * PB_BYTES;
+constexpr int PNW = 8;          // waves per block
+constexpr int PHALO_ROWS = 384;  // WHOLE = 0: rows of a patch buffer
+constexpr int PNSTB = 3;        // weight stages
 
 struct PatchGeo {
-  int W1;         // patch row length W + 1
-  int seg_rows;   // patch rows of one segment: (rows + 1) (W + 1)
+  int W1;         // patch row length: W + 1 (WHOLE = 0) / W
+  int seg_rows;   // patch rows of one segment: (rows + 1) (W + 1) / rows W
   int nseg;       // segments (images) per tile
   int w_sh;       // log2 W
   int seg_sh;     // log2 of the output pixels per segment
+  int rows;       // output rows per segment
+};
+
+template <int WM, int WN, int WHOLE>
+struct PatchCfg {
+  static constexpr int BM = 64 * WM, BN = 64 * WN;
+  static constexpr int A_ROWS = WHOLE ? BM : PHALO_ROWS;
+  static constexpr int A_BYTES = A_ROWS * 128, B_BYTES = BN * 128;
+  static constexpr int PIPE = 2 * A_BYTES + PNSTB * B_BYTES;     // bytes of the main loop's buffers (the zero row follows)
+  static constexpr int STORE = BM * (BN * 4 + 16);               // the epilogue's row image (nhwc_tile_store_T, one pass)
+  static constexpr int SCRATCH = PIPE > STORE ? PIPE : STORE;
+  static constexpr int SMEM = SCRATCH + 128;
 };
 
 }  // namespace
 
+template <int WM, int WN, int WHOLE, int DBG>   // DBG (diagnostic builds only): 4 no MFMAs, 5 no loads
 __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p, const PatchGeo g) {
-  constexpr int FM = 4, FN = 4, AG = PA_ROWS / (8 * PNW), BG = PBN / (8 * PNW);
-  static_assert(AG == 6 && BG == 2, "DMA groups per wave");
-  __shared__ __attribute__((aligned(1024))) char smem[PSMEM];
-  __shared__ int ri_out[PBM];
+  using Cfg = PatchCfg<WM, WN, WHOLE>;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, A_BYTES = Cfg::A_BYTES, B_BYTES = Cfg::B_BYTES;
+  constexpr int FM = 4, FN = 4, AG = Cfg::A_ROWS / (8 * PNW), BG = BN / (8 * PNW);
+  constexpr int B_OFF = 2 * A_BYTES, ZERO_OFF = Cfg::SCRATCH;
+  static_assert(WM * WN == PNW && (WHOLE || BM == 256), "tile shape");
+  static_assert(AG == 4 || AG == 6 || AG == 8, "patch DMA groups per wave");
+  static_assert(BG == 1 || BG == 2, "weight DMA groups per wave");
+  __shared__ __attribute__((aligned(1024))) char smem[Cfg::SMEM];
+  __shared__ int ri_out[BM];
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / PWN, wn = wave % PWN;
+  const int wm = wave / WN, wn = wave % WN;
   const int lrow = lane >> 3;
   const int frow = lane & 15, half = lane >> 4;
 
@@ -75,44 +107,45 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   const int mt = (idx / p.NT) * 8 + xcd;
   const int nt = idx - (idx / p.NT) * p.NT;
   if (mt >= p.MT) return;
-  const int m0 = mt * PBM, n0 = nt * PBN;
+  const int m0 = mt * BM, n0 = nt * BN;
+#ifdef M2H_CLOCK_DIAG
+  const unsigned long long dbg_s0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int ph = p.convT ? phase >> 1 : 0, pw = p.convT ? phase & 1 : 0;
   const float* wbase = p.w + (p.convT ? (size_t)phase * p.N * p.K : 0);
 
-  if (tid < PBM) {
-    const int m = m0 + tid;
+  for (int r = tid; r < BM; r += 64 * PNW) {
+    const int m = m0 + r;
     int q, rr, b, out = -1, bc;
     if (m < p.M) decode_row(p, m, ph, pw, q, rr, b, out, bc);
-    ri_out[tid] = out;
+    ri_out[r] = out;
   }
+  if (WHOLE && tid < 32) reinterpret_cast<float*>(smem + ZERO_OFF)[tid] = 0.f;
 
   // ---- the patch rows this lane feeds (fixed for the whole kernel) ----
   const int b0 = m0 >> (g.w_sh + p.hq_sh);
-  const int q0 = (m0 >> g.w_sh) & (p.Hq - 1);   // 0 when a tile holds whole images
+  const int q0 = WHOLE ? 0 : (m0 >> g.w_sh) & (p.Hq - 1);   // first output row of the tile inside its image
   const int sm = p.convT ? 1 : 2;
-  int a_ih[AG], a_iw[AG], a_pix[AG], pieceA[AG];
+  int a_hw[AG], a_pix[AG];   // (input row, column) at class offset 0, packed; image base pixel (-1: no such row)
 #pragma unroll
   for (int i = 0; i < AG; ++i) {
-    const int grp = wave + PNW * i;
-    const int pr = grp * 8 + lrow;
+    const int pr = (wave + PNW * i) * 8 + lrow;
     const int seg = pr / g.seg_rows;
     const int w = pr - seg * g.seg_rows;
     const int ii = w / g.W1, jj = w - ii * g.W1;
     const int b = b0 + seg;
-    a_ih[i] = (q0 + ii) * sm;
-    a_iw[i] = jj * sm;
+    a_hw[i] = (((q0 + ii) * sm) << 16) | (jj * sm);
     a_pix[i] = (seg < g.nseg && b < p.B) ? b * p.Hi * p.Wi : -1;
-    pieceA[i] = ((lane & 7) ^ (((grp & 1) << 2) | (lrow >> 1))) * 16;
   }
+  // LDS piece (lane & 7) of row r = 8 grp + lrow holds split32 piece (lane & 7) ^ ((r >> 1) & 7); grp = wave + 8 i has wave's parity
+  const int piece_ofs = ((lane & 7) ^ (((wave & 1) << 2) | (lrow >> 1))) * 16;
   const char* zero = reinterpret_cast<const char*>(g_zero_page_patch);
   const char* ptrA[AG];
   const char* ptrB[BG];
 #pragma unroll
   for (int j = 0; j < BG; ++j) {
-    const int grp = wave + PNW * j;
-    const int r = grp * 8 + lrow;
-    const int piece = (lane & 7) ^ (((grp & 1) << 2) | (lrow >> 1));
-    ptrB[j] = reinterpret_cast<const char*>(wbase) + ((size_t)min(n0 + r, p.N - 1) * p.K) * 4 + piece * 16;
+    const int r = (wave + PNW * j) * 8 + lrow;
+    ptrB[j] = reinterpret_cast<const char*>(wbase) + ((size_t)min(n0 + r, p.N - 1) * p.K) * 4 + piece_ofs;   // rows past N re-read row N-1 (never stored)
   }
 
   // ---- the two operand streams (uniform state) ----
@@ -125,25 +158,29 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
     const bool second = a_ci >= p.C0 && p.src1 != nullptr;
     const int Cs = second ? p.C1 : p.C0;
     const char* base = reinterpret_cast<const char*>(second ? p.src1 : p.src0);
-    const int dh = p.convT ? ph - 1 : (a_cls >> 1) - 1, dw = p.convT ? pw - 1 : (a_cls & 1) - 1;
+    const int gh = p.convT ? ph : a_cls >> 1, gw = p.convT ? pw : a_cls & 1;
+    const int dh = WHOLE ? (p.convT ? 0 : 1 - gh) : gh - 1, dw = WHOLE ? (p.convT ? 0 : 1 - gw) : gw - 1;
 #pragma unroll
     for (int i = 0; i < AG; ++i) {
-      const int ih = a_ih[i] + dh, iw = a_iw[i] + dw;
+      const int ih = (a_hw[i] >> 16) + dh, iw = (a_hw[i] & 0xffff) + dw;
       const bool ok = a_pix[i] >= 0 && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
       const size_t off = (size_t)(unsigned)(a_pix[i] + ih * p.Wi + iw) * (unsigned)Cs * 4u;
-      ptrA[i] = (ok ? base + off : zero) + pieceA[i];
+      ptrA[i] = (ok ? base + off : zero) + piece_ofs;
     }
   };
   rebuild_rows();
   auto issue_patch = [&]() {
     const bool second = a_ci >= p.C0 && p.src1 != nullptr;
     const unsigned cofs = (unsigned)(second ? a_ci - p.C0 : a_ci) * 4u;
-    const unsigned dst = lds0 + (unsigned)a_buf * PA_BYTES + (unsigned)wave * 1024u;
+    const unsigned dst = lds0 + (unsigned)a_buf * A_BYTES + (unsigned)wave * 1024u;
     const char* sa[AG];
 #pragma unroll
     for (int i = 0; i < AG; ++i) sa[i] = ptrA[i] + cofs;
-    glds16_run<4>(sa, dst, PNW * 1024u);
-    glds16_run<2>(sa + 4, dst + 4u * PNW * 1024u, PNW * 1024u);
+    if constexpr (DBG != 5) {
+      glds16_run<4>(sa, dst, PNW * 1024u);
+      if constexpr (AG == 6) glds16_run<2>(sa + 4, dst + 4u * PNW * 1024u, PNW * 1024u);
+      if constexpr (AG == 8) glds16_run<4>(sa + 4, dst + 4u * PNW * 1024u, PNW * 1024u);
+    }
     a_buf ^= 1;
     ++a_issued;
     a_ci += BK;
@@ -161,11 +198,11 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
     const int th = p.convT ? (ph ? a : 1 - a) : 2 * a + (b_cls >> 1);
     const int tw = p.convT ? (pw ? b : 1 - b) : 2 * b + (b_cls & 1);
     const unsigned kofs = (unsigned)((th * p.ntw + tw) * p.Ctot + b_ci) * 4u;
-    const unsigned dst = lds0 + 2u * PA_BYTES + (unsigned)b_stage * PB_BYTES + (unsigned)wave * 1024u;
+    const unsigned dst = lds0 + (unsigned)B_OFF + (unsigned)b_stage * B_BYTES + (unsigned)wave * 1024u;
     const char* sb[BG];
 #pragma unroll
     for (int j = 0; j < BG; ++j) sb[j] = ptrB[j] + kofs;
-    glds16_run<BG>(sb, dst, PNW * 1024u);
+    if constexpr (DBG != 5) glds16_run<BG>(sb, dst, PNW * 1024u);
     b_stage = b_stage + 1 == PNSTB ? 0 : b_stage + 1;
     if (++b_tap == 4) {
       b_tap = 0;
@@ -184,37 +221,40 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
     for (int ni = 0; ni < FN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- fragment addresses ----
-  // pixels: patch row of output pixel (wm 64 + 16 mi + frow) at shift 0; weights: as igemm_dma_kernel's 16x16x32 path
-  int prow0[FM];
+  // pixels: patch row of output pixel (wm 64 + 16 mi + frow) at shift 0, and (WHOLE) which image edges it lies on: bit 0 top,
+  // 1 bottom, 2 left, 3 right; weights: as igemm_dma_kernel's 16x16x32 path
+  int prow0[FM], edge[FM];
 #pragma unroll
   for (int mi = 0; mi < FM; ++mi) {
     const int ml = wm * 64 + mi * 16 + frow;
     const int seg = ml >> g.seg_sh;
     const int rem = ml & ((1 << g.seg_sh) - 1);
-    prow0[mi] = seg * g.seg_rows + (rem >> g.w_sh) * g.W1 + (rem & ((1 << g.w_sh) - 1));
+    const int il = rem >> g.w_sh, jl = rem & ((1 << g.w_sh) - 1);
+    prow0[mi] = seg * g.seg_rows + il * g.W1 + jl;
+    edge[mi] = (il == 0 ? 1 : 0) | (il == g.rows - 1 ? 2 : 0) | (jl == 0 ? 4 : 0) | (jl == (1 << g.w_sh) - 1 ? 8 : 0);
   }
   const int fx = (frow >> 1) & 7;
   const int offH = (half ^ fx) * 16, offL = ((4 + half) ^ fx) * 16;
-  const int b_row = 2 * PA_BYTES + (wn * 64 + frow) * 128;
+  const int b_row = B_OFF + (wn * 64 + frow) * 128;
   f32x4 ah[FM], al[FM], bh[FN], bl[FN];
-  auto load_a = [&](int buf, int shift, auto lo, auto hi) {
-    const char* sa = smem + buf * PA_BYTES;
+  auto load_a = [&](int buf, int shift, int kill, auto lo, auto hi) {
 #pragma unroll
     for (int mi = decltype(lo)::value; mi < decltype(hi)::value; ++mi) {
       const int row = prow0[mi] + shift;
-      const int ad = (row << 7) | (((half ^ (row >> 1)) & 7) << 4);
-      ah[mi] = *reinterpret_cast<const f32x4*>(sa + ad);
-      al[mi] = *reinterpret_cast<const f32x4*>(sa + (ad ^ 64));
+      int ad = buf * A_BYTES + ((row << 7) | (((half ^ (row >> 1)) & 7) << 4));
+      if (WHOLE) ad = (edge[mi] & kill) ? ZERO_OFF : ad;
+      ah[mi] = *reinterpret_cast<const f32x4*>(smem + ad);
+      al[mi] = *reinterpret_cast<const f32x4*>(smem + (ad ^ 64));
     }
   };
   auto load_b = [&](int stage, auto nic) {
     constexpr int ni = decltype(nic)::value;
-    const char* sb = smem + stage * PB_BYTES + b_row;
+    const char* sb = smem + stage * B_BYTES + b_row;
     bh[ni] = *reinterpret_cast<const f32x4*>(sb + ni * 16 * 128 + offH);
     bl[ni] = *reinterpret_cast<const f32x4*>(sb + ni * 16 * 128 + offL);
   };
   auto mfma = [&](const f32x4& a, const f32x4& b, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    if constexpr (DBG != 4) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   };
   auto mfma_col = [&](auto lo, auto hi, auto nic) {   // weights as the A operand: a lane ends up with four consecutive channels of one pixel
     constexpr int ni = decltype(nic)::value;
@@ -242,29 +282,58 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(decltype(cnt)::value) : "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
+  // tap tt = 2 a + b of class cls: row shift of its fragments and (WHOLE) the edges past which they read zeros
   const int W1 = g.W1;
-  auto shift_of = [&](int tt) { return (tt >> 1) * W1 + (tt & 1); };
+  auto tap_geo = [&](int cls, int tt, int& shift, int& kill) {
+    const int a = tt >> 1, b = tt & 1;
+    if (WHOLE) {
+      const int gh = p.convT ? ph : cls >> 1, gw = p.convT ? pw : cls & 1;
+      shift = (a - 1 + gh) * W1 + (b - 1 + gw);   // rows / columns -1, 0 (gh = 0) or 0, +1 (gh = 1) of the pixel's own
+      kill = ((a == 0 && gh == 0) ? 1 : 0) | ((a == 1 && gh == 1) ? 2 : 0) | ((b == 0 && gw == 0) ? 4 : 0) | ((b == 1 && gw == 1) ? 8 : 0);
+    } else {
+      shift = a * W1 + b;
+      kill = 0;
+    }
+  };
 
   // ---- pipeline ----
   issue_patch();
   issue_weights();
   issue_weights();
   issue_weights();
-  wait_and_barrier(std::integral_constant<int, 2 * BG>{});   // patch 0 and the weights of tile 0 have landed (also orders ri_out)
-  int cs = 0, ab = 0;   // weight stage / patch buffer of the current tile
-  load_a(0, 0, I0{}, IH{});
+  wait_and_barrier(std::integral_constant<int, 2 * BG>{});   // patch 0 and the weights of tile 0 have landed (also orders ri_out, the zero row)
+  int cs = 0, ab = 0;        // weight stage / patch buffer of the current tile
+  int c_cls = 0, c_ci = 0;   // class / chunk of the current patch
+#ifdef M2H_CLOCK_DIAG
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  {
+    int sh, kl;
+    tap_geo(0, 0, sh, kl);
+    load_a(0, sh, kl, I0{}, IH{});
+  }
   for_ni([&](auto nic) { load_b(0, nic); });
   // tile tt of a patch: upper pixel fragments | MFMAs of the lower ones | wait + barrier | lower fragments of the next tile |
   // MFMAs of the upper ones, the next tile's weight fragments replacing this tile's one by one, the DMA issues among them
   auto body = [&](auto ttc, auto cnt, auto issue_w, auto issue_p) {
     constexpr int TT = decltype(ttc)::value;
     const int ns = cs + 1 == PNSTB ? 0 : cs + 1;
-    load_a(ab, shift_of(TT), IH{}, IF{});
+    int sh, kl;
+    tap_geo(c_cls, TT, sh, kl);
+    load_a(ab, sh, kl, IH{}, IF{});
     __builtin_amdgcn_sched_barrier(0);
     for_ni([&](auto nic) { mfma_col(I0{}, IH{}, nic); });
     wait_and_barrier(cnt);
-    const int nab = TT == 3 ? ab ^ 1 : ab;
-    load_a(nab, shift_of((TT + 1) & 3), I0{}, IH{});
+    int nab = ab;
+    if constexpr (TT == 3) {   // the next tile opens the next patch
+      nab = ab ^ 1;
+      if (++c_ci == nch) {
+        c_ci = 0;
+        ++c_cls;
+      }
+    }
+    tap_geo(c_cls, (TT + 1) & 3, sh, kl);
+    load_a(nab, sh, kl, I0{}, IH{});
     __builtin_amdgcn_sched_barrier(0);
     for_ni([&](auto nic) {
       mfma_col(IH{}, IF{}, nic);
@@ -282,33 +351,68 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   using T2 = std::integral_constant<int, 2>;
   using T3 = std::integral_constant<int, 3>;
   using C0 = std::integral_constant<int, 0>;
-  using C2 = std::integral_constant<int, BG>;
-  using C8 = std::integral_constant<int, BG + AG>;
+  using CW = std::integral_constant<int, BG>;
+  using CP = std::integral_constant<int, BG + AG>;
   using Y = std::true_type;
   using N = std::false_type;
   for (int s = 0; s + 1 < NS; ++s) {
-    body(T0{}, C2{}, Y{}, Y{});   // in flight at the barrier: the weights of t+2
-    body(T1{}, C8{}, Y{}, N{});   // the weights of t+2 and the next patch
-    body(T2{}, C8{}, Y{}, N{});   // the next patch and the weights of t+2 (the patch is the older: both stay)
-    body(T3{}, C2{}, Y{}, N{});   // the weights of t+2; the next patch (older than the awaited weights) has landed
+    body(T0{}, CW{}, Y{}, Y{});   // in flight at the barrier: the weights of t+2
+    body(T1{}, CP{}, Y{}, N{});   // the weights of t+2 and the next patch
+    body(T2{}, CP{}, Y{}, N{});   // the next patch and the weights of t+2 (the patch is the older: both stay)
+    body(T3{}, CW{}, Y{}, N{});   // the weights of t+2; the next patch (older than the awaited weights) has landed
   }
-  body(T0{}, C2{}, Y{}, N{});     // last patch: the last weight tile is issued here
-  body(T1{}, C2{}, N{}, N{});
+  body(T0{}, CW{}, Y{}, N{});     // last patch: the last weight tile is issued here
+  body(T1{}, CW{}, N{}, N{});
   body(T2{}, C0{}, N{}, N{});
-  load_a(ab, shift_of(3), IH{}, IF{});
+  {
+    int sh, kl;
+    tap_geo(c_cls, 3, sh, kl);
+    load_a(ab, sh, kl, IH{}, IF{});
+  }
   for_ni([&](auto nic) { mfma_col(I0{}, IF{}, nic); });
 
+#ifdef M2H_CLOCK_DIAG
+  if (tid == 0 && blockIdx.x < 8192) {
+    g_clock_dbg_patch[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - dbg_t0;
+    g_clock_dbg_patch[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+    g_clock_dbg_patch[blockIdx.x][2] = dbg_s0;
+    g_clock_dbg_patch[blockIdx.x][3] = dbg_r0;
+    g_clock_dbg_patch[blockIdx.x][4] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   __syncthreads();
-  nhwc_tile_store_T<PBM, PBN, PWM, PWN, 16, PSMEM, f32x4>(p, acc, smem, ri_out, n0, tid);
+  nhwc_tile_store_T<BM, BN, WM, WN, 16, Cfg::SCRATCH, f32x4>(p, acc, smem, ri_out, n0, tid);
+#ifdef M2H_CLOCK_DIAG
+  if (tid == 0 && blockIdx.x < 8192) g_clock_dbg_patch[blockIdx.x][5] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
-// Shapes: what launch_igemm_dma takes at split-K 1, restricted to the two window geometries above with the whole window reached,
-// power-of-two pixel grids of width 16 / 32 / 64 and a patch of at most 384 rows.  Returns -2 otherwise (the caller falls through).
+template <int WM, int WN, int WHOLE>
+static int launch_patch_cfg(IGemmP& p, const PatchGeo& g, hipStream_t st) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  p.MT = (p.M + BM - 1) / BM;
+  p.NT = p.N / BN;
+  p.S = 1;
+  p.pmaj = p.convT ? 1 : 0;
+  const long nblk = ((long)p.MT + 7) / 8 * 8 * p.NT * (p.convT ? 4 : 1);
+  if (nblk > 0x7fffffffL) return -2;
+  const dim3 grid((unsigned)nblk), blk(64 * PNW);
+#ifdef M2H_CLOCK_DIAG
+  if (g_patch == 4) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 4>), grid, blk, 0, st, p, g);
+  else if (g_patch == 5) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 5>), grid, blk, 0, st, p, g);
+  else
+#endif
+  hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 0>), grid, blk, 0, st, p, g);
+  return launch_status(BN == 128 ? "igemm_patch<256,128>" : "igemm_patch<512,64>");
+}
+
+// Shapes: what launch_igemm_dma takes at split-K 1 (plus 64-wide layers), restricted to the two window geometries above with the
+// whole window reached and power-of-two pixel grids: whole images per tile (any width), or -- 256 x 128 tile -- some rows of an
+// image 16 / 32 / 64 pixels wide with a patch of at most 384 rows.  Returns -2 otherwise (the caller falls through).
 int launch_igemm_patch(IGemmP& p, hipStream_t st) {
-  if (g_patch < 0 || p.math != 1 || !p.presplit || !p.fast_ok || p.head_w != nullptr || p.N % 128 != 0 || p.Kw != p.K) return -2;
+  if (g_patch < 0 || p.math != 1 || !p.presplit || !p.fast_ok || p.head_w != nullptr || p.N % 64 != 0 || p.Kw != p.K) return -2;
   if (p.out_mode != M2H_OUT_NHWC || p.cls_table != nullptr || p.ldc % 4 != 0 || (reinterpret_cast<size_t>(p.dst) & 15) != 0) return -2;
-  if ((size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 > 8192) return -2;
-  if (p.wq_sh < 0 || p.hq_sh < 0 || (p.Wq != 16 && p.Wq != 32 && p.Wq != 64)) return -2;
+  if ((size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 > 8192 || p.M <= 64 || p.wq_sh < 0 || p.hq_sh < 0 || p.Hi >= 32768 || p.Wi >= 32768) return -2;
   if (p.convT) {
     if (p.ntap != 4 || p.ntw != 2 || p.thn != 2 || p.twn != 2 || p.Hq != p.Hi || p.Wq != p.Wi) return -2;
   } else {
@@ -317,26 +421,36 @@ int launch_igemm_patch(IGemmP& p, hipStream_t st) {
       return -2;
   }
   const int phases = p.convT ? 4 : 1;
-  const long t256 = (((long)p.M + 255) / 256) * (p.N / 128) * phases;
-  if (g_patch != 2 && t256 < 224) return -2;
+  const bool wide = p.N % 128 == 0;
+  const int BM = wide ? 256 : 512;
+  const long tiles = (((long)p.M + BM - 1) / BM) * (p.N / (wide ? 128 : 64)) * phases;
+  if (g_patch < 2 && tiles < 224) return -2;
   PatchGeo g;
   const int img = p.Hq * p.Wq;
-  const int rows = img >= PBM ? PBM / p.Wq : p.Hq;   // output rows per segment
-  if (img >= PBM ? (p.Hq % rows != 0) : (PBM % img != 0)) return -2;
-  g.nseg = img >= PBM ? 1 : PBM / img;
-  g.W1 = p.Wq + 1;
-  g.seg_rows = (rows + 1) * g.W1;
   g.w_sh = p.wq_sh;
-  g.seg_sh = __builtin_ctz((unsigned)(rows * p.Wq));
-  if (g.nseg * g.seg_rows > PA_ROWS) return -2;
-  p.MT = (p.M + PBM - 1) / PBM;
-  p.NT = p.N / PBN;
-  p.S = 1;
-  p.pmaj = p.convT ? 1 : 0;
-  const long nblk = ((long)p.MT + 7) / 8 * 8 * p.NT * phases;
-  if (nblk > 0x7fffffffL) return -2;
-  hipLaunchKernelGGL(igemm_patch_kernel, dim3((unsigned)nblk), dim3(64 * PNW), 0, st, p, g);
-  return launch_status("igemm_patch<256,128>");
+  const int hrows = img >= BM ? BM / p.Wq : p.Hq;   // halo patch: output rows per segment
+  const bool halo_ok = wide && (p.Wq == 16 || p.Wq == 32 || p.Wq == 64) && (img >= BM ? 1 : BM / img) * (hrows + 1) * (p.Wq + 1) <= PHALO_ROWS;
+  if (img <= BM && (g_patch == 3 || !halo_ok)) {   // whole images per tile (where both forms fit, the halo patch measured 3-4 % faster: pair_ab, down2 81.7 vs 85.0 us, up2 153 vs 157)
+    g.nseg = BM / img;
+    g.rows = p.Hq;
+    g.W1 = p.Wq;
+    g.seg_rows = img;
+    g.seg_sh = p.hq_sh + p.wq_sh;
+    return wide ? launch_patch_cfg<4, 2, 1>(p, g, st) : launch_patch_cfg<8, 1, 1>(p, g, st);
+  }
+  if (!halo_ok) return -2;
+  g.nseg = img >= BM ? 1 : BM / img;
+  g.rows = hrows;
+  g.W1 = p.Wq + 1;
+  g.seg_rows = (g.rows + 1) * g.W1;
+  g.seg_sh = __builtin_ctz((unsigned)(g.rows * p.Wq));
+  return launch_patch_cfg<4, 2, 0>(p, g, st);
 }
+
+#ifdef M2H_CLOCK_DIAG
+extern "C" int m2h_diag_read_clocks_patch(unsigned long long* host_out, int nblocks) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock_dbg_patch), (size_t)nblocks * 8 * sizeof(unsigned long long));
+}
+#endif
 
 }  // namespace m2h

@@ -14,7 +14,8 @@ from m2h import synthetic
 
 pytestmark = pytest.mark.gpu
 
-LABEL = "igemm_patch<256,128>"
+LABEL = "igemm_patch<256,128>"     # N a multiple of 128
+LABEL64 = "igemm_patch<512,64>"    # the 64-wide decoder stage
 
 
 def _dev():
@@ -56,22 +57,29 @@ def _layer(x, x2, wp, Co, transposed, scale, shift, slope):
     return unsplit32(out), ops.last_kernel()
 
 
-# (B, H, W of the input, C0, C1, Co, transposed): the four wide stages of the U-Net at 256 / 128 / 64 frames and odd batches --
-# one segment per tile (5 x 65, 9 x 33 and 17 x 17 patch rows), two and four images per tile (rows past M, a segment past the batch)
+# (B, H, W of the input, C0, C1, Co, transposed): the stages of the U-Net the engine takes at 256 / 128 / 64 frames and odd batches --
+# part of an image per tile (halo patch: 5 x 65, 9 x 33 rows) and whole images per tile (1, 2, 4, 8, 16 of them: rows past M, images
+# past the batch, every image edge), both tiles
 CASES = [
-    (2, 16, 128, 64, 0, 128, False),     # down1 at 256 frames: 8 x 64 outputs, 4 rows per tile
+    (2, 16, 128, 64, 0, 128, False),     # down1 at 256 frames: 8 x 64 outputs, 4 rows per tile (halo patch)
+    (1, 32, 64, 32, 0, 128, False),      # 16 x 32 outputs, 8 rows per tile (halo patch)
     (3, 8, 64, 128, 0, 256, False),      # down2 at 256 frames: 4 x 32 outputs, two images per tile, odd batch, two n-tiles
     (5, 8, 32, 128, 0, 256, False),      # down2 at 128 frames: 4 x 16 outputs, four images per tile, ragged
-    (1, 32, 32, 32, 0, 128, False),      # 16 x 16 outputs, 16 rows per tile
-    (3, 4, 32, 256, 256, 256, True),     # up1 at 256 frames: two sources, two images per tile, odd batch
-    (1, 8, 64, 128, 128, 128, True),     # up2 at 256 frames
+    (1, 32, 32, 32, 0, 128, False),      # 16 x 16 outputs, one image per tile
+    (5, 4, 16, 64, 0, 128, False),       # 2 x 8 outputs, sixteen images per tile
+    (3, 4, 32, 256, 256, 256, True),     # up2 at 256 frames: two sources, two images per tile, odd batch
+    (9, 2, 16, 128, 128, 256, True),     # up1 at 256 frames: 2 x 16 grid, eight images per tile, ragged
     (2, 8, 16, 64, 32, 128, True),       # 16 wide, two images per tile, unequal sources
-    (2, 16, 16, 96, 0, 128, True),       # one source, 16 rows per tile
+    (2, 16, 16, 96, 0, 128, True),       # one source, one image per tile
+    (1, 8, 64, 128, 128, 64, True),      # up3 at 256 frames: the 512 x 64 tile, one image per tile
+    (3, 8, 32, 64, 64, 64, True),        # up3 at 128 frames: two images per tile, odd batch
+    (5, 4, 8, 32, 32, 64, True),         # 8 wide, sixteen images per tile
 ]
 
 
+@pytest.mark.parametrize("knob", [2, 3])   # 2: the engine's own choice of patch form; 3: the whole-image form wherever it fits
 @pytest.mark.parametrize("B,H,W,C0,C1,Co,transposed", CASES)
-def test_patch_engine_layer_matches_torch_and_the_dma_engine(B, H, W, C0, C1, Co, transposed):
+def test_patch_engine_layer_matches_torch_and_the_dma_engine(B, H, W, C0, C1, Co, transposed, knob):
     from m2h import ops
     dev = _dev()
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + W + C0)
@@ -93,7 +101,7 @@ def test_patch_engine_layer_matches_torch_and_the_dma_engine(B, H, W, C0, C1, Co
     args = (nhwc(x), nhwc(x2) if C1 else None, wp, Co, transposed, scale.to(dev), shift.to(dev), slope)
     ops.set_math_mode(ops.MATH_BF16X3)
     try:
-        ops.debug_set(36, 2)          # the engine also below its tile-count threshold
+        ops.debug_set(36, knob)       # the engine also below its tile-count threshold
         got, label = _layer(*args)
         again, _ = _layer(*args)
         ops.debug_set(36, -1)
@@ -103,7 +111,7 @@ def test_patch_engine_layer_matches_torch_and_the_dma_engine(B, H, W, C0, C1, Co
         ops.debug_set(36, 0)
         ops.debug_set(27, 0)
         ops.set_math_mode(ops.MATH_FP32)
-    assert label == LABEL and ref_label.startswith("igemm_dma")
+    assert label == (LABEL if Co % 128 == 0 else LABEL64) and not ref_label.startswith("igemm_patch")
     got, ref = got.cpu().permute(0, 3, 1, 2), ref.cpu().permute(0, 3, 1, 2)
     assert got.shape == want.shape
     assert O.rel_l1(got, want) < 1e-5 and (got - want).abs().max() < 2e-4 * want.abs().max()   # every pixel: borders, seams, both sources
@@ -143,8 +151,12 @@ def test_runner_with_the_patch_engine_matches_the_dma_engine_and_the_oracle(B, t
         again = run(2)
     finally:
         ops.set_math_mode(ops.MATH_FP32)
-    assert LABEL not in ref[2]
-    assert got[2].count(LABEL) == (3 if tm >= 128 else 1)   # down1, down2, up2 (up1's 2 x 16 grid needs 408 patch rows; at 64 frames down2's and up2's grids are 8 wide)
+    # stages (1-5 encoder, 6-9 decoder) the engine takes when forced: the two window geometries with the whole window reached
+    # (not down4 / up0: 1 x 8 pixel rows), more than 64 GEMM rows
+    taken = {i for i, lb in enumerate(got[2]) if lb.startswith("igemm_patch")}
+    assert not any(lb.startswith("igemm_patch") for lb in ref[2])
+    assert taken == ({2, 3, 4, 7, 8, 9} if tm >= 128 else {2, 9}), got[2]
+    assert got[2][9] == LABEL64 and got[2][2] == LABEL
     assert O.rel_l1(got[0].cpu(), ref[0].cpu()) < 1e-5 and O.rel_l1(got[1].cpu(), ref[1].cpu()) < 1e-5
     assert not torch.equal(got[0], ref[0])
     assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1])

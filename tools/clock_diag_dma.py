@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic (not product): builds a copy of libm2h with -DM2H_CLOCK_DIAG, runs one split32 U-Net layer on the LDS-DMA engine
 back to back for ~2 s and prints the shader clock the chip holds inside its k-loop (delta s_memtime / delta s_memrealtime x
-100 MHz) and the cycles per k-tile.  usage: python tools/clock_diag_dma.py [knob27 values, e.g. 0 5 4]"""
+100 MHz) and the cycles per k-tile.  usage: python tools/clock_diag_dma.py [knob27 values, e.g. 0 5 4]
+       python tools/clock_diag_dma.py patch [knob36 values, e.g. 0 5 4]     (the shared-patch engine, csrc/conv_patch.hip)"""
 import ctypes
 import os
 import subprocess
@@ -23,9 +24,15 @@ _lib.LIB_PATH = diag
 from m2h import ops  # noqa: E402
 
 lib = _lib.load()
-lib.m2h_diag_read_clocks_dma.argtypes = [ctypes.c_void_p, ctypes.c_int]
+argv = sys.argv[1:]
+patch = bool(argv) and argv[0] == "patch"
+if patch:
+    argv = argv[1:]
+reader = lib.m2h_diag_read_clocks_patch if patch else lib.m2h_diag_read_clocks_dma
+reader.argtypes = [ctypes.c_void_p, ctypes.c_int]
+KNOB = 36 if patch else 27
 dev = torch.device("cuda", 0)
-knobs = [int(v) for v in sys.argv[1:]] or [0]
+knobs = [int(v) for v in argv] or [0]
 ops.set_math_mode(ops.MATH_BF16X3)
 fmt = ops.FMT_SRC_SPLIT | ops.FMT_W_SPLIT | ops.FMT_DST_SPLIT
 for (B, H, W, Ci, Co, label) in [(256, 8, 64, 128, 256, "down2 K=2048 N=256"), (256, 16, 128, 64, 128, "down1 K=1024 N=128")]:
@@ -36,7 +43,9 @@ for (B, H, W, Ci, Co, label) in [(256, 8, 64, 128, 256, "down2 K=2048 N=256"), (
     sh = torch.zeros(Co, device=dev)
     nk = 16 * Ci // 32
     for kv in knobs:
-        ops.debug_set(27, kv)
+        ops.debug_set(KNOB, kv)
+        if not patch:
+            ops.debug_set(36, -1)
         t0 = time.time()
         n = 0
         while time.time() - t0 < 2.0:
@@ -53,12 +62,13 @@ for (B, H, W, Ci, Co, label) in [(256, 8, 64, 128, 256, "down2 K=2048 N=256"), (
         us = e0.elapsed_time(e1) / 20 * 1e3
         nb = 2048
         buf = np.zeros((nb, 8), np.uint64)
-        lib.m2h_diag_read_clocks_dma(buf.ctypes.data, nb)
+        reader(buf.ctypes.data, nb)
         b = buf[buf[:, 1] > 0]
         clk = b[:, 0].astype(np.float64) / b[:, 1].astype(np.float64) * 0.1
-        print("%s knob27=%d: %.1f us/launch, %d blocks stamped; in-kernel clock median %.3f GHz (min %.3f max %.3f); k-loop cycles median %.0f = %.0f per k-tile"
+        print("%s knob=%d: %.1f us/launch, %d blocks stamped; in-kernel clock median %.3f GHz (min %.3f max %.3f); k-loop cycles median %.0f = %.0f per k-tile"
               % (label, kv, us, len(b), np.median(clk), clk.min(), clk.max(), np.median(b[:, 0]), np.median(b[:, 0]) / nk))
         f = b.astype(np.float64)
         print("    per workgroup (us, median): setup + ring fill %.2f, k-loop %.2f, epilogue %.2f; first start -> last end %.1f"
               % (np.median(f[:, 3] - f[:, 2]) / 100, np.median(f[:, 4] - f[:, 3]) / 100, np.median(f[:, 5] - f[:, 4]) / 100, (f[:, 5].max() - f[:, 2].min()) / 100))
-    ops.debug_set(27, 0)
+    ops.debug_set(KNOB, 0)
+    ops.debug_set(36, 0)
