@@ -1184,6 +1184,15 @@ extern "C" int m2h_diag_read_clocks(unsigned long long* host_out, int nblocks) {
 }
 #endif
 
+// the ordered reduce + epilogue over the split-K slabs of an LDS-DMA / shared-patch launch (p.S slabs per phase)
+static int launch_splitk_reduce(const IGemmP& p, hipStream_t st) {
+  const long total = (long)p.M * (p.N >> 2);
+  long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g, p.convT ? 4 : 1), dim3(256), 0, st, p);
+  return launch_status("conv_igemm_f32 split-K epilogue");
+}
+
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a) {
   // the exact split-K scratch of the automatic choice for these arguments: phases * S * M * N floats
   const long M = (long)a.B * a.Hq * a.Wq;
@@ -1277,8 +1286,13 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   const size_t wsb = a.workspace != nullptr ? a.workspace_bytes : 0;
   // split32 operands, 4x4/s2 conv or transposed conv, N a multiple of 64, a chip's worth of tiles: the shared-patch engine (conv_patch.hip)
   if (p.presplit && g_fast_loader >= 0 && g_force_splitk <= 0 && g_phase_major >= 0) {
-    const int rc = launch_igemm_patch(p, st);
-    if (rc != -2) return rc;
+    const int rc = launch_igemm_patch(p, wsb, st);
+    if (rc != -2) {
+      if (rc != 0 || p.S == 1) return rc;
+      const int rc2 = launch_splitk_reduce(p, st);
+      tl_last_launch = "igemm_patch<256,128> + split-K reduce";
+      return rc2;
+    }
   }
   // narrow transposed convs on split32 operands: all four phases from one staged patch (convt_quad.hip)
   if (p.convT && p.presplit && g_force_splitk <= 0 && g_phase_major >= 0) {
@@ -1386,11 +1400,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
     const int rc = launch_igemm_dma(p, wsb, st);
     if (rc != -2) {
       if (rc != 0 || p.S == 1) return rc;
-      const long total = (long)p.M * (p.N >> 2);
-      long g = (total + 255) / 256;
-      if (g > 4096) g = 4096;
-      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g, p.convT ? 4 : 1), dim3(256), 0, st, p);
-      const int rc2 = launch_status("conv_igemm_f32 split-K epilogue");
+      const int rc2 = launch_splitk_reduce(p, st);
       tl_last_launch = "igemm_dma<256,128> + split-K reduce";
       return rc2;
     }

@@ -151,9 +151,12 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   // ---- the two operand streams (uniform state) ----
   // patches: s = 0 .. NS-1 in (class, chunk) order (conv: class = (gh, gw) of the window; transposed conv: one class, the chunks
   // of both concatenated sources); weights: k-tiles t = 4 s + tt, tt = 2 a + b
+  // split-K (S = 2, convs only): grid y = the half of the window's classes (gh = 0 / 1), raw partial sums to the slabs
   const int nch = p.Ctot / BK;
-  const int NS = (p.convT ? 1 : 4) * nch;
-  int a_cls = 0, a_ci = 0, a_issued = 0, a_buf = 0;
+  const int split = blockIdx.y;
+  const int cls0 = p.S == 2 ? 2 * split : 0;
+  const int NS = (p.convT ? 1 : (p.S == 2 ? 2 : 4)) * nch;
+  int a_cls = cls0, a_ci = 0, a_issued = 0, a_buf = 0;
   auto rebuild_rows = [&]() {
     const bool second = a_ci >= p.C0 && p.src1 != nullptr;
     const int Cs = second ? p.C1 : p.C0;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
     }
     if (reseg && a_issued < NS) rebuild_rows();
   };
-  int b_cls = 0, b_ci = 0, b_tap = 0, b_stage = 0;
+  int b_cls = cls0, b_ci = 0, b_tap = 0, b_stage = 0;
   auto issue_weights = [&]() {
     const int a = b_tap >> 1, b = b_tap & 1;
     const int th = p.convT ? (ph ? a : 1 - a) : 2 * a + (b_cls >> 1);
@@ -303,13 +306,13 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   issue_weights();
   wait_and_barrier(std::integral_constant<int, 2 * BG>{});   // patch 0 and the weights of tile 0 have landed (also orders ri_out, the zero row)
   int cs = 0, ab = 0;        // weight stage / patch buffer of the current tile
-  int c_cls = 0, c_ci = 0;   // class / chunk of the current patch
+  int c_cls = cls0, c_ci = 0;   // class / chunk of the current patch
 #ifdef M2H_CLOCK_DIAG
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   {
     int sh, kl;
-    tap_geo(0, 0, sh, kl);
+    tap_geo(cls0, 0, sh, kl);
     load_a(0, sh, kl, I0{}, IH{});
   }
   for_ni([&](auto nic) { load_b(0, nic); });
@@ -380,6 +383,20 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
     g_clock_dbg_patch[blockIdx.x][4] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
+  if (p.S > 1) {   // raw partial sums to the slab [split][M][N], 16 bytes per lane; BN / activation / store in splitk_epilogue_kernel
+    float* slab = p.ws + ((size_t)split * p.M) * p.N;
+#pragma unroll
+    for (int mi = 0; mi < FM; ++mi) {
+      const int m = m0 + wm * 64 + mi * 16 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < FN; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + 4 * half;
+        if (n < p.N) *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + n) = acc[mi][ni];
+      }
+    }
+    return;
+  }
   __syncthreads();
   nhwc_tile_store_T<BM, BN, WM, WN, 16, Cfg::SCRATCH, f32x4>(p, acc, smem, ri_out, n0, tid);
 #ifdef M2H_CLOCK_DIAG
@@ -388,28 +405,28 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
 }
 
 template <int WM, int WN, int WHOLE>
-static int launch_patch_cfg(IGemmP& p, const PatchGeo& g, hipStream_t st) {
+static int launch_patch_cfg(IGemmP& p, const PatchGeo& g, int S, hipStream_t st) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   p.MT = (p.M + BM - 1) / BM;
   p.NT = p.N / BN;
-  p.S = 1;
+  p.S = S;
   p.pmaj = p.convT ? 1 : 0;
   const long nblk = ((long)p.MT + 7) / 8 * 8 * p.NT * (p.convT ? 4 : 1);
   if (nblk > 0x7fffffffL) return -2;
-  const dim3 grid((unsigned)nblk), blk(64 * PNW);
+  const dim3 grid((unsigned)nblk, (unsigned)S), blk(64 * PNW);
 #ifdef M2H_CLOCK_DIAG
   if (g_patch == 4) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 4>), grid, blk, 0, st, p, g);
   else if (g_patch == 5) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 5>), grid, blk, 0, st, p, g);
   else
 #endif
   hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 0>), grid, blk, 0, st, p, g);
-  return launch_status(BN == 128 ? "igemm_patch<256,128>" : "igemm_patch<512,64>");
+  return launch_status(BN == 64 ? "igemm_patch<512,64>" : S == 2 ? "igemm_patch<256,128> (two K-halves)" : "igemm_patch<256,128>");
 }
 
 // Shapes: what launch_igemm_dma takes at split-K 1 (plus 64-wide layers), restricted to the two window geometries above with the
 // whole window reached and power-of-two pixel grids: whole images per tile (any width), or -- 256 x 128 tile -- some rows of an
 // image 16 / 32 / 64 pixels wide with a patch of at most 384 rows.  Returns -2 otherwise (the caller falls through).
-int launch_igemm_patch(IGemmP& p, hipStream_t st) {
+int launch_igemm_patch(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   if (g_patch < 0 || p.math != 1 || !p.presplit || !p.fast_ok || p.head_w != nullptr || p.N % 64 != 0 || p.Kw != p.K) return -2;
   if (p.out_mode != M2H_OUT_NHWC || p.cls_table != nullptr || p.ldc % 4 != 0 || (reinterpret_cast<size_t>(p.dst) & 15) != 0) return -2;
   if ((size_t)(p.C0 > p.C1 ? p.C0 : p.C1) * 4 > 8192 || p.M <= 64 || p.wq_sh < 0 || p.hq_sh < 0 || p.Hi >= 32768 || p.Wi >= 32768) return -2;
@@ -424,7 +441,13 @@ int launch_igemm_patch(IGemmP& p, hipStream_t st) {
   const bool wide = p.N % 128 == 0;
   const int BM = wide ? 256 : 512;
   const long tiles = (((long)p.M + BM - 1) / BM) * (p.N / (wide ? 128 : 64)) * phases;
-  if (g_patch < 2 && tiles < 224) return -2;
+  // half a chip's worth of 256 x 128 tiles and a long reduction (the fourth encoder stage at the benchmark batch): the two class
+  // halves of the window as split-K slabs + the ordered reduce kernel (the shape rule of the LDS-DMA engine's two-K-halves launch)
+  int S = 1;
+  if (g_patch < 2 && tiles < 224) {
+    if (!wide || p.convT || !dma_split2_rule(p.M, p.N, p.Kw, 1, p.ws != nullptr, ws_bytes)) return -2;
+    S = 2;
+  }
   PatchGeo g;
   const int img = p.Hq * p.Wq;
   g.w_sh = p.wq_sh;
@@ -436,7 +459,7 @@ int launch_igemm_patch(IGemmP& p, hipStream_t st) {
     g.W1 = p.Wq;
     g.seg_rows = img;
     g.seg_sh = p.hq_sh + p.wq_sh;
-    return wide ? launch_patch_cfg<4, 2, 1>(p, g, st) : launch_patch_cfg<8, 1, 1>(p, g, st);
+    return wide ? launch_patch_cfg<4, 2, 1>(p, g, S, st) : launch_patch_cfg<8, 1, 1>(p, g, S, st);
   }
   if (!halo_ok) return -2;
   g.nseg = img >= BM ? 1 : BM / img;
@@ -444,7 +467,7 @@ int launch_igemm_patch(IGemmP& p, hipStream_t st) {
   g.W1 = p.Wq + 1;
   g.seg_rows = (g.rows + 1) * g.W1;
   g.seg_sh = __builtin_ctz((unsigned)(g.rows * p.Wq));
-  return launch_patch_cfg<4, 2, 0>(p, g, st);
+  return launch_patch_cfg<4, 2, 0>(p, g, S, st);
 }
 
 #ifdef M2H_CLOCK_DIAG

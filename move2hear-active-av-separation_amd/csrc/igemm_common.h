@@ -440,7 +440,7 @@ extern int g_big_tile;
 int launch_igemm_dma(IGemmP& p, size_t ws_bytes, hipStream_t st);
 
 // conv_patch.hip: shared-patch LDS-DMA engine (4x4/s2 convs and transposed-conv phases, N % 128 == 0); -2 when not one of its shapes
-int launch_igemm_patch(IGemmP& p, hipStream_t st);
+int launch_igemm_patch(IGemmP& p, size_t ws_bytes, hipStream_t st);   // p.S == 2 on return: the caller runs splitk_epilogue_kernel
 
 // convt_quad.hip: four-phase transposed-conv kernel (split32 operands, N <= 64); -2 when the launch is not one of its shapes
 int launch_convT_quad(IGemmP& p, hipStream_t st);

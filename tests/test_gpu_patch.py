@@ -164,3 +164,33 @@ def test_runner_with_the_patch_engine_matches_the_dma_engine_and_the_oracle(B, t
         want_m, want_mono = O.passive_pair(sd, torch.from_numpy(mixed), torch.from_numpy(tc))
     em = torch.expm1(torch.from_numpy(mixed))
     assert O.rel_l1(got[0].cpu() * em, want_m * em) < 1e-4 and O.rel_l1(got[1].cpu(), want_mono) < 1e-4
+
+
+def test_patch_engine_two_class_halves_as_split_k():
+    """Half a chip's worth of tiles and a long reduction (the fourth encoder stage at the benchmark batch; here 128 images, N = 1024):
+    the engine's own dispatch (no knob) splits the window's classes into two K-halves + the ordered reduce kernel."""
+    from m2h import ops
+    dev = _dev()
+    B, H, W, Ci, Co = 128, 4, 32, 128, 1024
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 4, 4, generator=g) * (1.0 / (16 * Ci) ** 0.5)
+    scale = torch.rand(Co, generator=g) + 0.5
+    shift = torch.randn(Co, generator=g) * 0.1
+    want = F.leaky_relu(F.conv2d(x, w, None, stride=2, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), 0.2)
+    args = (ops.split32(x.permute(0, 2, 3, 1).contiguous().to(dev)), None, ops.split32(ops.pack_conv_weight(w.to(dev))), Co, False,
+            scale.to(dev), shift.to(dev), 0.2)
+    ops.set_math_mode(ops.MATH_BF16X3)
+    try:
+        got, label = _layer(*args)
+        again, _ = _layer(*args)
+        ops.debug_set(36, -1)
+        ref, ref_label = _layer(*args)
+    finally:
+        ops.debug_set(36, 0)
+        ops.set_math_mode(ops.MATH_FP32)
+    assert label == "igemm_patch<256,128> + split-K reduce" and ref_label == "igemm_dma<256,128> + split-K reduce"
+    got, ref = got.cpu().permute(0, 3, 1, 2), ref.cpu().permute(0, 3, 1, 2)
+    assert O.rel_l1(got, want) < 1e-5 and (got - want).abs().max() < 2e-4 * want.abs().max()
+    assert O.rel_l1(got, ref) < 3e-6
+    assert torch.equal(again.cpu().permute(0, 3, 1, 2), got)
