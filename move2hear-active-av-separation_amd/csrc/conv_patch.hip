@@ -18,16 +18,21 @@
 //              stages).  A tile row spans the image's width and its rows span the image's height, so every halo pixel of P is
 //              zero padding: only the data pixels are staged -- patch row m = the input pixel under output pixel m: in(k, l) for a
 //              transposed conv, in(2k + 1 - gh, 2l + 1 - gw) for class (gh, gw) of a conv -- and a fragment row that falls off
-//              its image reads one shared 128-byte row of zeros instead (per-lane edge flags against the tap's direction).
+//              its image reads a row of zeros instead (per-lane edge flags against the tap's direction).
 //   WHOLE = 0  a tile is some rows of a larger image (down1 at 256 frames: 4 of 8 rows): the (rows + 1) x (W + 1) patch with
 //              its halo row (data of the neighbouring tile, or padding) and halo column staged as rows of their own, 297 to 340
 //              rows in a 384-row buffer (rows past the patch copy zeros).
 // Tiles: 256 x 128 (4 x 2 waves) for N % 128 == 0, 512 x 64 (8 x 1 waves) for the 64-wide decoder stage; wave tile 64 x 64.
 //
-// LDS: two patch buffers + a ring of three weight stages (+ the zero row), rows unpadded with the piece permutation of
-// conv_dma.hip (LDS piece j of row r holds split32 piece j ^ ((r >> 1) & 7)): a 16-lane group of a ds_read_b128 reads 16
-// CONSECUTIVE patch rows at any shift, the conflict-free case of that permutation (WHOLE = 0: fragments start at multiples of 16
-// output columns and W is a multiple of 16, so a fragment never crosses the end of a patch row).
+// LDS: two patch buffers + a ring of three weight stages (+ the zero row), rows unpadded.  Weight rows carry the piece permutation
+// of conv_dma.hip (LDS piece j of row r holds split32 piece j ^ ((r >> 1) & 7): conflict-free for fragments that start at
+// multiples of 16 rows).  Patch fragments start at ANY row (shifts 0, 1, W + 1, W + 2 on lines of W + 1 rows), where that map is
+// two-way conflicted (PMC: SQ_LDS_BANK_CONFLICT 28 % of SQ_LDS_IDX_ACTIVE); patch rows use a rotation instead: LDS piece
+// (p + (r & 6)) & 7 holds split32 piece p.  A 16-lane group of a ds_read_b128 is fragment rows {0-3, 12-15} at one piece and
+// {4-11} at its neighbour (p ^ 1): per row parity the row pairs r >> 1 are eight consecutive numbers, a cyclic block of four with
+// piece p and the complementary block with p ^ 1, so the rotation sends the first to the pieces of p's parity and the second to
+// the others: 16 distinct 16-byte slots at every start row (tests/test_kernel_model.py).  (WHOLE = 0: fragments start at
+// multiples of 16 output columns and W is a multiple of 16, so a fragment never crosses the end of a patch line.)
 //
 // Pipeline: as conv_dma.hip's 16x16x32 path (fragment reads half a tile ahead, one barrier in the middle of each k-tile,
 // counted vmcnt waits, straight-line steady state), unrolled over the four taps of a patch: the weights of tile t+3 are issued in
@@ -71,7 +76,7 @@ struct PatchCfg {
   static constexpr int PIPE = 2 * A_BYTES + PNSTB * B_BYTES;     // bytes of the main loop's buffers (the zero row follows)
   static constexpr int STORE = BM * (BN * 4 + 16);               // the epilogue's row image (nhwc_tile_store_T, one pass)
   static constexpr int SCRATCH = PIPE > STORE ? PIPE : STORE;
-  static constexpr int SMEM = SCRATCH + 128;
+  static constexpr int SMEM = SCRATCH + 256;                     // + the zero rows: one per row parity, so that a lane sent there keeps its bank slot
 };
 
 }  // namespace
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
     if (m < p.M) decode_row(p, m, ph, pw, q, rr, b, out, bc);
     ri_out[r] = out;
   }
-  if (WHOLE && tid < 32) reinterpret_cast<float*>(smem + ZERO_OFF)[tid] = 0.f;
+  if (WHOLE && tid < 64) reinterpret_cast<float*>(smem + ZERO_OFF)[tid] = 0.f;
 
   // ---- the patch rows this lane feeds (fixed for the whole kernel) ----
   const int b0 = m0 >> (g.w_sh + p.hq_sh);
@@ -137,8 +142,10 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
     a_hw[i] = (((q0 + ii) * sm) << 16) | (jj * sm);
     a_pix[i] = (seg < g.nseg && b < p.B) ? b * p.Hi * p.Wi : -1;
   }
-  // LDS piece (lane & 7) of row r = 8 grp + lrow holds split32 piece (lane & 7) ^ ((r >> 1) & 7); grp = wave + 8 i has wave's parity
+  // weight rows: LDS piece (lane & 7) of row r = 8 grp + lrow holds split32 piece (lane & 7) ^ ((r >> 1) & 7) (grp = wave + 8 j has
+  // wave's parity); patch rows: LDS piece j of row r holds split32 piece (j - (r & 6)) & 7, and r & 6 = lrow & 6
   const int piece_ofs = ((lane & 7) ^ (((wave & 1) << 2) | (lrow >> 1))) * 16;
+  const int piece_ofs_a = (((lane & 7) - (lrow & 6)) & 7) * 16;
   const char* zero = reinterpret_cast<const char*>(g_zero_page_patch);
   const char* ptrA[AG];
   const char* ptrB[BG];
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
       const int ih = (a_hw[i] >> 16) + dh, iw = (a_hw[i] & 0xffff) + dw;
       const bool ok = a_pix[i] >= 0 && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
       const size_t off = (size_t)(unsigned)(a_pix[i] + ih * p.Wi + iw) * (unsigned)Cs * 4u;
-      ptrA[i] = (ok ? base + off : zero) + piece_ofs;
+      ptrA[i] = (ok ? base + off : zero) + piece_ofs_a;
     }
   };
   rebuild_rows();
@@ -244,8 +251,8 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
 #pragma unroll
     for (int mi = decltype(lo)::value; mi < decltype(hi)::value; ++mi) {
       const int row = prow0[mi] + shift;
-      int ad = buf * A_BYTES + ((row << 7) | (((half ^ (row >> 1)) & 7) << 4));
-      if (WHOLE) ad = (edge[mi] & kill) ? ZERO_OFF : ad;
+      int ad = buf * A_BYTES + ((row << 7) | (((half + (row & 6)) & 7) << 4));
+      if (WHOLE) ad = (edge[mi] & kill) ? ZERO_OFF + (ad & 255) : ad;   // zeros at the bank slot of the row it replaces: the group stays conflict-free
       ah[mi] = *reinterpret_cast<const f32x4*>(smem + ad);
       al[mi] = *reinterpret_cast<const f32x4*>(smem + (ad ^ 64));
     }

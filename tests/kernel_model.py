@@ -316,3 +316,25 @@ def strip_conv1_k_order():
         kg, sb, t, c = k >> 3, (k >> 2) & 1, (k >> 1) & 1, k & 1
         order.append(c * 16 + 4 * kg + 2 * t + sb)
     return order
+
+
+# ---- shared-patch engine (csrc/conv_patch.hip): LDS patch addressing (128-byte rows, eight 16-byte pieces) ----
+def patch_row_addr(row, piece):
+    """byte offset of split32 piece `piece` (0..3 hi, 4..7 lo) of patch row `row`: LDS piece = (piece + (row & 6)) & 7."""
+    return (row << 7) | (((piece + (row & 6)) & 7) << 4)
+
+
+def patch_read_conflict_degree(row0, lo=0, xor_map=False):
+    """Worst number of distinct addresses on one 16-byte bank slot among the lanes the LDS serves together, for a ds_read_b128 of
+    the pixel fragment whose first patch row is row0 (any shift: taps move the window by one row / one patch line): lane l reads row
+    row0 + (l & 15), piece (l >> 4) + 4 lo.  xor_map: the piece ^ ((row >> 1) & 7) map of conv_dma.hip (conflict-free only at
+    row0 % 4 == 0, which is all that engine needs)."""
+    worst = 0
+    for group in DS_READ_B128_GROUPS:
+        slots = {}
+        for lane in group:
+            row, piece = row0 + (lane & 15), (lane >> 4) + 4 * lo
+            a = ((row << 7) | ((piece ^ ((row >> 1) & 7)) << 4)) if xor_map else patch_row_addr(row, piece)
+            slots.setdefault((a // 16) % 16, set()).add(a)
+        worst = max(worst, max(len(v) for v in slots.values()))
+    return worst

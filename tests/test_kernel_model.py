@@ -122,3 +122,17 @@ def test_strip_kernel_lds_map_is_conflict_free_and_the_channel_order_is_a_permut
             assert a % 16 == 0 and i * 64 <= a < (i + 1) * 64 and a not in seen
             seen.add(a)
     assert sorted(KM.strip_conv1_k_order()) == list(range(32))
+
+
+def test_patch_engine_lds_map_is_conflict_free_at_every_shift():
+    """csrc/conv_patch.hip: the pixel-fragment reads hit every 16-byte bank slot exactly once per LDS lane group whatever patch row the
+    fragment starts at (the four taps of a patch read it at row shifts 0, 1, W + 1, W + 2 and patch lines are W + 1 rows long, so
+    every alignment occurs), for the hi and the lo pieces; every row holds each piece once.  The XOR map of conv_dma.hip, kept for
+    the weight rows (always read at multiples of 16 rows), is conflict-free there and only there."""
+    for row0 in range(0, 200):
+        assert KM.patch_read_conflict_degree(row0, 0) == 1 and KM.patch_read_conflict_degree(row0, 1) == 1, row0
+    for row in range(16):
+        assert sorted((KM.patch_row_addr(row, p) - row * 128) // 16 for p in range(8)) == list(range(8))
+        assert KM.patch_row_addr(row, 5) == KM.patch_row_addr(row, 1) ^ 64     # lo piece = hi piece's address ^ 64
+    assert all(KM.patch_read_conflict_degree(r, 0, xor_map=True) == 1 for r in range(0, 64, 16))
+    assert max(KM.patch_read_conflict_degree(r, 0, xor_map=True) for r in range(1, 16)) == 2

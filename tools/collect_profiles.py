@@ -54,7 +54,7 @@ for name in fetch:
     if name.startswith("m2h::") and name in write:
         kern[name] = {"fetch_kib_per_launch_raw": fetch[name], "fetch_correction": 2.0, "write_kib_per_launch": write[name],
                       "traffic_bytes_per_launch": int((2.0 * fetch[name] + write[name]) * 1024)}
-dom = next((k for k in kern if k.startswith("m2h::igemm_dma_kernel")), None)
+dom = next((k for k in kern if k.startswith("m2h::igemm_patch_kernel<4, 2, 0")), None) or next((k for k in kern if k.startswith("m2h::igemm_dma_kernel")), None)
 src = "profiles/r03_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1 --no-other-mode --no-graph; tools/profile_round3.sh)"
 traffic = {"bf16x3": dict(kern.get(dom, {}), source=src, kernel=dom), "per_kernel": kern}
 with open(os.path.join(DST, "r03_pmc_hbm_traffic.json"), "w") as f:

@@ -18,7 +18,7 @@ done
 : > $O/pmc_sq_tcc.txt
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE" "TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   rm -rf $O/pmcx; rocprofv3 --pmc $grp -d $O/pmcx -o w --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline $HEAD --no-kernel-timing --no-graph > /dev/null 2>&1
-  python3 tools/pmc_summary.py $(ls $O/pmcx/*counter_collection.csv | head -1) 2>&1 | grep -A10 "strip_kernel\|igemm_dma_kernel\|convT_quad_kernel\|igemm_f32_kernel<128, 128" >> $O/pmc_sq_tcc.txt
+  python3 tools/pmc_summary.py $(ls $O/pmcx/*counter_collection.csv | head -1) 2>&1 | grep -A10 "strip_kernel\|igemm_patch_kernel\|igemm_dma_kernel\|convT_quad_kernel\|igemm_f32_kernel<128, 128" >> $O/pmc_sq_tcc.txt
 done
 rm -rf $O/pmcx
 python3 tools/kstats.py $O/bench/bench_kernel_stats.csv 14
