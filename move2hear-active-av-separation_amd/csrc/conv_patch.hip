@@ -81,7 +81,7 @@ struct PatchCfg {
 
 }  // namespace
 
-template <int WM, int WN, int WHOLE, int DBG>   // DBG (diagnostic builds only): 4 no MFMAs, 5 no loads
+template <int WM, int WN, int WHOLE, int DBG>   // DBG (diagnostic builds only): 4 no MFMAs, 5 no loads, 6 no loads and no k-loop barrier, 7 no k-loop barrier
 __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p, const PatchGeo g) {
   using Cfg = PatchCfg<WM, WN, WHOLE>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, A_BYTES = Cfg::A_BYTES, B_BYTES = Cfg::B_BYTES;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
     const char* sa[AG];
 #pragma unroll
     for (int i = 0; i < AG; ++i) sa[i] = ptrA[i] + cofs;
-    if constexpr (DBG != 5) {
+    if constexpr (DBG != 5 && DBG != 6) {
       glds16_run<4>(sa, dst, PNW * 1024u);
       if constexpr (AG == 6) glds16_run<2>(sa + 4, dst + 4u * PNW * 1024u, PNW * 1024u);
       if constexpr (AG == 8) glds16_run<4>(sa + 4, dst + 4u * PNW * 1024u, PNW * 1024u);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
     const char* sb[BG];
 #pragma unroll
     for (int j = 0; j < BG; ++j) sb[j] = ptrB[j] + kofs;
-    if constexpr (DBG != 5) glds16_run<BG>(sb, dst, PNW * 1024u);
+    if constexpr (DBG != 5 && DBG != 6) glds16_run<BG>(sb, dst, PNW * 1024u);
     b_stage = b_stage + 1 == PNSTB ? 0 : b_stage + 1;
     if (++b_tap == 4) {
       b_tap = 0;
@@ -289,7 +289,8 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   };
   auto wait_and_barrier = [&](auto cnt) {   // cnt: this wave's DMA instructions that may stay in flight (compile-time)
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(decltype(cnt)::value) : "memory");
+    if constexpr (DBG == 6 || DBG == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // diagnostic: no barrier in the k-loop (wrong results)
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(decltype(cnt)::value) : "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
   // tap tt = 2 a + b of class cls: row shift of its fragments and (WHOLE) the edges past which they read zeros
@@ -424,6 +425,8 @@ static int launch_patch_cfg(IGemmP& p, const PatchGeo& g, int S, hipStream_t st)
 #ifdef M2H_CLOCK_DIAG
   if (g_patch == 4) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 4>), grid, blk, 0, st, p, g);
   else if (g_patch == 5) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 5>), grid, blk, 0, st, p, g);
+  else if (g_patch == 6) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 6>), grid, blk, 0, st, p, g);
+  else if (g_patch == 7) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 7>), grid, blk, 0, st, p, g);
   else
 #endif
   hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 0>), grid, blk, 0, st, p, g);
