@@ -477,6 +477,19 @@ bool dma_split2_rule(long M, int N, int Kw, int phases, bool ws_present, size_t 
   return g_dma == 0 && g_big_tile >= 0 && g_dma_split2 >= 0 && N % 128 == 0 && t256 < 224 && t256 * 2 >= 224 && Kw / BK >= 64 && ws_present &&
          (size_t)phases * 2 * M * N * sizeof(float) <= ws_bytes;
 }
+// split-K factor of the 256 x 128 tile for layers of 16 .. 223 tiles that the two-halves rule does not take: enough K-parts for one
+// block per CU, at most 8, at least 8 k-tiles each (1 = not this engine's shape; fewer than 16 tiles: the weight-streaming tiles
+// of the register engine)
+int dma_deep_split(long M, int N, int Kw, int phases) {
+  if (g_dma != 0 || g_big_tile < 0 || g_dma_split2 < 0 || N % 128 != 0) return 1;
+  const long t256 = ((M + 255) / 256) * (N / 128) * phases;
+  if (t256 >= 224 || t256 < 16) return 1;
+  long S = (256 + t256 - 1) / t256;
+  if (S < 2) S = 2;
+  if (S > 8) S = 8;
+  while (S > 1 && Kw / BK < 8 * S) --S;
+  return (int)S;
+}
 static bool dma_split2_applies(const IGemmP& p, size_t ws_bytes) {
   return dma_split2_rule(p.M, p.N, p.Kw, p.convT ? 4 : 1, p.ws != nullptr, ws_bytes);
 }
@@ -499,6 +512,11 @@ int launch_igemm_dma(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   // K = 4096): two K-halves per tile into split-K slabs + the ordered reduce kernel
   if (dma_split2_applies(p, ws_bytes))
     return g_dma_shape == 32 ? launch_dma_cfg<256, 128, 4, 2, 3, 32>(p, 2, st) : launch_dma_cfg<256, 128, 4, 2, 3, 16>(p, 2, st);
+  // a small fraction of a chip's worth of tiles (the two deepest stages of each U-Net at the benchmark batch: 32 / 128 tiles): S K-parts
+  // per tile, one block per CU (pair_ab: down4 47.8 -> 43.0 us, up0 51.5 -> 46.9 against the register engine's 128 x 128 tiles at S = 8 / 2)
+  const int S = dma_deep_split(p.M, p.N, p.Kw, phases);
+  if (S > 1 && p.ws != nullptr && (size_t)phases * S * p.M * p.N * sizeof(float) <= ws_bytes)
+    return g_dma_shape == 32 ? launch_dma_cfg<256, 128, 4, 2, 3, 32>(p, S, st) : launch_dma_cfg<256, 128, 4, 2, 3, 16>(p, S, st);
   return -2;
 }
 

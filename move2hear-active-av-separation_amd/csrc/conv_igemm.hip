@@ -1210,7 +1210,13 @@ size_t conv_igemm_workspace_bytes(const m2h_conv_args& a) {
   if (math == 1 && (a.operand_format & both) == both && a.head_w == nullptr && a.C0 % BK == 0 && a.C1 % BK == 0 && M > 64 && g_force_splitk <= 0 &&
       g_fast_loader >= 0) {
     const size_t need = (size_t)phases * 2 * M * a.N * sizeof(float);
-    if (dma_split2_rule(M, a.N, K, phases, true, need) && need > bytes) bytes = need;
+    if (dma_split2_rule(M, a.N, K, phases, true, need)) {
+      if (need > bytes) bytes = need;
+    } else {
+      const int Sd = dma_deep_split(M, a.N, K, phases);   // ... and its S K-parts launch on the deepest stages
+      const size_t needd = (size_t)phases * Sd * M * a.N * sizeof(float);
+      if (Sd > 1 && needd > bytes) bytes = needd;
+    }
   }
   return bytes;
 }

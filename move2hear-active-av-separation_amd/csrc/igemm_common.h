@@ -447,5 +447,6 @@ int launch_convT_quad(IGemmP& p, hipStream_t st);
 
 // conv_dma.hip: shape rule of the engine's two-way split-K launch (the fourth encoder stage at the benchmark batch)
 bool dma_split2_rule(long M, int N, int Kw, int phases, bool ws_present, size_t ws_bytes);
+int dma_deep_split(long M, int N, int Kw, int phases);   // K-parts of the engine's launch on a layer of 16 .. 223 tiles (1 = none)
 
 }  // namespace m2h

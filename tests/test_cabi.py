@@ -100,3 +100,7 @@ def test_workspace_bytes_reports_the_dma_engines_two_k_halves_launch():
     a.operand_format = 1 | 2 | 4 | 8
     a.B = 1024                            # enough 256 x 128 tiles to fill the chip: no split at all on that engine
     assert lib.m2h_conv_igemm_workspace_bytes(ctypes.byref(a)) == 0
+    # the deepest encoder stage at the benchmark batch (32 tiles of 256 x 128, half of the window in the padding: walked K = 4096):
+    # eight K-parts per tile on that engine
+    a.C0, a.B, a.Hi, a.Wi, a.Hq, a.Wq, a.Ho, a.Wo = 512, 256, 2, 16, 1, 8, 1, 8
+    assert lib.m2h_conv_igemm_workspace_bytes(ctypes.byref(a)) == 8 * (256 * 8) * 512 * 4
