@@ -6,8 +6,9 @@ a HIP kernel:
                   bias = m2h_bias_grad; fused ReLU/LeakyReLU = m2h_act_bwd
 Replaces torch's Conv2d/Linear autograd in audio_separation/rl/ppo/ppo.py:159-161 (update_pol) and :228-230 (update_sep).
 """
+import contextlib
 import ctypes
-
+import threading
 import weakref
 
 import torch
@@ -537,9 +538,32 @@ class BNAct(torch.autograd.Function):
 def bn_act_train(z, bn, slope):
     """Train-mode nn.BatchNorm2d `bn` (parameter container) + activation on NHWC z."""
     y = BNAct.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum if bn.momentum is not None else 0.1, slope)
-    with torch.no_grad():
-        bn.num_batches_tracked += 1
+    sink = getattr(_bn_counters, "sink", None)
+    if sink is not None:
+        sink.append(bn.num_batches_tracked)
+    else:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
     return y
+
+
+_bn_counters = threading.local()
+
+
+@contextlib.contextmanager
+def batched_bn_counters():
+    """Inside the block, train-mode BatchNorm calls of this thread collect their ``num_batches_tracked`` counters instead of
+    incrementing them one launch each (20 per passive training step); on exit they are all incremented by ONE multi-tensor
+    launch.  Same values afterwards (nn.BatchNorm2d's own ``+= 1`` per forward, torch/nn/modules/batchnorm.py)."""
+    prev = getattr(_bn_counters, "sink", None)
+    _bn_counters.sink = sink = []
+    try:
+        yield
+    finally:
+        _bn_counters.sink = prev
+        if sink:
+            with torch.no_grad():
+                torch._foreach_add_(sink, 1)
 
 
 def _convT_phase_args(x, x2, Co, ph, pw):

@@ -106,8 +106,9 @@ class PassiveTrainer:
             with graphs.capture(g):
                 MF.refresh_pack_memos()
                 mix, gtb, gtm, tc = gs.inputs
-                masks = self.actor_critic.get_binSepMasks({"mixed_bin_audio_mag": mix, "target_class": tc})
-                mono = self.actor_critic.convert_bin2mono(masks.detach(), mixed_audio=mix)
+                with MF.batched_bn_counters():   # the 20 num_batches_tracked increments as one launch
+                    masks = self.actor_critic.get_binSepMasks({"mixed_bin_audio_mag": mix, "target_class": tc})
+                    mono = self.actor_critic.convert_bin2mono(masks.detach(), mixed_audio=mix)
                 bin_loss = MF.bin_l1_loss(masks, mix, gtb, cstep=1)
                 mono_loss = MF.l1_loss(mono, gtm, 0)
                 self.optimizer.zero_grad()
@@ -127,8 +128,9 @@ class PassiveTrainer:
                 return self._train_batch_graph(mixed_audio, gt_bin_mag, gt_mono_mag, target_class)  # (first batch: warm-up, kernel by kernel)
         obs_batch = {"mixed_bin_audio_mag": mixed_audio, "target_class": target_class}
         if split == "train":
-            pred_binSepMasks = self.actor_critic.get_binSepMasks(obs_batch)
-            pred_mono = self.actor_critic.convert_bin2mono(pred_binSepMasks.detach(), mixed_audio=mixed_audio)
+            with MF.batched_bn_counters():
+                pred_binSepMasks = self.actor_critic.get_binSepMasks(obs_batch)
+                pred_mono = self.actor_critic.convert_bin2mono(pred_binSepMasks.detach(), mixed_audio=mixed_audio)
         else:
             with torch.no_grad():
                 pred_binSepMasks = self.actor_critic.get_binSepMasks(obs_batch)
