@@ -34,9 +34,36 @@ struct WGradP {
   int S;            // splits over m (grid z)
   int chunks;       // ceil(M / 32)
   int ntiles, ktiles;  // output tiles along n and k
-  float* ws;        // [S][N][Kpad]
-  float* dw;        // [N][K]
+  float* ws;        // [S][N][Kpad]  (quad: [4 phases][S][N][Kpad])
+  float* dw;        // [N][K]        (quad: the transposed conv's torch layout [Ci][N][4][4])
+  int quad;         // 1: the four sub-pixel phases of a ConvTranspose2d(4,2,1) in one launch (grid y = phase: its taps' direction,
+                    // its dy rows, its slabs); the reduce kernel scatters into the torch layout
 };
+
+// phase (ph, pw) of a quad launch: taps step by 2 ph - 1 / 2 pw - 1 (separator_cnn.py:15-24 as four sub-pixel GEMMs)
+struct WPhase {
+  int ph, pw, mulh, mulw;
+  size_t ws_off;
+};
+__device__ __forceinline__ WPhase wgrad_phase(const WGradP& p) {
+  WPhase w{p.ph, p.pw, p.mulh, p.mulw, 0};
+  if (p.quad) {
+    const int phase = blockIdx.y;
+    w.ph = phase >> 1;
+    w.pw = phase & 1;
+    w.mulh = 2 * w.ph - 1;
+    w.mulw = 2 * w.pw - 1;
+    w.ws_off = (size_t)phase * p.S * p.N * p.Kpad;
+  }
+  return w;
+}
+// index of gradient element (n = co, k = (th, tw, ci)) of phase (ph, pw) in the torch layout dw[ci][co][kh][kw], kh = (ph ? 2 : 1) + th (ph ? -2 : 2)
+__device__ __forceinline__ size_t quad_dw_index(const WGradP& p, const WPhase& w, int n, int k) {
+  const int tap = k / p.Ctot, ci = k - tap * p.Ctot;
+  const int th = tap >> 1, tw = tap & 1;
+  const int kh = (w.ph ? 2 : 1) + th * (w.ph ? -2 : 2), kw = (w.pw ? 2 : 1) + tw * (w.pw ? -2 : 2);
+  return (((size_t)ci * p.N + n) * 4 + kh) * 4 + kw;
+}
 
 constexpr int WK = 128;  // k sub-tile (one 16-byte segment per thread of a 32-thread row group)
 constexpr int WM = 32;   // pixels per reduction chunk
@@ -62,6 +89,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave / WK_, wk = wave % WK_;
+  const WPhase wp_ = wgrad_phase(p);
   // 1-D grid, XCD-aware: the (n-tile, k-tile) blocks of one pixel split are consecutive blocks of ONE XCD (L % 8), so the
   // split's input rows and dY rows meet in that XCD's L2
   const int L = blockIdx.x;
@@ -96,8 +124,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
       ci = k - tap * p.Ctot;
     }
     const int th = (unsigned)tap / (unsigned)p.ntw, tw = tap - th * p.ntw;
-    dh[c] = th * p.mulh + p.offh;
-    dw[c] = tw * p.mulw + p.offw;
+    dh[c] = th * wp_.mulh + p.offh;
+    dw[c] = tw * wp_.mulw + p.offw;
     src[c] = p.src0;
     Cs[c] = p.C0;
     cc[c] = ci;
@@ -176,7 +204,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
       const int row = yrow0 + YSTEP * i;
       const bool ok = row < WM && w.m < p.M && ny < p.N;
       size_t pix = (size_t)w.m;
-      if (!p.direct) pix = ((size_t)w.b * p.Ho + (size_t)(w.q * p.os + p.ph)) * p.Wo + (size_t)(w.r * p.os + p.pw);
+      if (!p.direct) pix = ((size_t)w.b * p.Ho + (size_t)(w.q * p.os + wp_.ph)) * p.Wo + (size_t)(w.r * p.os + wp_.pw);
       const float* yp = p.dy + (ok ? pix * p.ldy + ny : (size_t)0);
       if (yvec) {
         ry[i] = *reinterpret_cast<const f32x4*>(yp);
@@ -253,7 +281,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradP p) {
   }
 
   // partial tile -> slab[split][n][k]
-  float* slab = p.ws + (size_t)split * p.N * p.Kpad;
+  float* slab = p.ws + wp_.ws_off + (size_t)split * p.N * p.Kpad;
   const int col = lane & 31, rhalf = (lane >> 5) * 4;
 #pragma unroll
   for (int x = 0; x < FN; ++x)
@@ -401,9 +429,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WGradP p) {
   const int k = (blockIdx.x - n * kb) * 64 + lane;
   const int z0 = (int)(((long)p.S * w) / 4), z1 = (int)(((long)p.S * (w + 1)) / 4);
   const size_t zs = (size_t)p.N * p.Kpad;
+  const WPhase wp_ = wgrad_phase(p);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (k < p.K) {
-    const float* src = p.ws + (size_t)n * p.Kpad + k;
+    const float* src = p.ws + wp_.ws_off + (size_t)n * p.Kpad + k;
     int z = z0;
     for (; z + 3 < z1; z += 4) {
       const float v0 = src[(size_t)z * zs], v1 = src[(size_t)(z + 1) * zs], v2 = src[(size_t)(z + 2) * zs], v3 = src[(size_t)(z + 3) * zs];
@@ -413,18 +442,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WGradP p) {
   }
   sh[w][lane] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (w == 0 && k < p.K) p.dw[(size_t)n * p.K + k] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+  if (w == 0 && k < p.K) p.dw[p.quad ? quad_dw_index(p, wp_, n, k) : (size_t)n * p.K + k] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
 
 // few splits: one thread per element (the block-per-64-k form above would be tens of thousands of near-empty blocks)
 __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const WGradP p) {
   const size_t total = (size_t)p.N * p.K;
+  const WPhase wp_ = wgrad_phase(p);
+  const float* ws = p.ws + wp_.ws_off;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int n = (int)(i / p.K);
     const int k = (int)(i - (size_t)n * p.K);
     float s = 0.f;
-    for (int z = 0; z < p.S; ++z) s += p.ws[((size_t)z * p.N + n) * p.Kpad + k];
-    p.dw[i] = s;
+    for (int z = 0; z < p.S; ++z) s += ws[((size_t)z * p.N + n) * p.Kpad + k];
+    p.dw[p.quad ? quad_dw_index(p, wp_, n, k) : i] = s;
   }
 }
 
@@ -461,9 +492,14 @@ size_t conv_wgrad_workspace_bytes(const m2h_conv_args& a) {
   return (size_t)wgrad_splits(M, a.N, K) * a.N * Kpad * sizeof(float);
 }
 
-int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, hipStream_t st) {
+// quad: the four phases of a ConvTranspose2d(4,2,1) in one launch (a = the geometry of one phase: taps 2x2, stride 1, os 2,
+// Ho = 2 Hi; its ph / pw / mulh / mulw are ignored), dw in the torch layout, workspace four times the single-phase size
+int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, hipStream_t st, bool quad = false) {
   M2H_REQUIRE(a.src0 != nullptr && dy != nullptr && dw != nullptr, "conv_wgrad: null pointer");
-  M2H_REQUIRE(a.conv_transpose == 0, "conv_wgrad: transposed conv not supported yet");
+  M2H_REQUIRE(a.conv_transpose == 0, "conv_wgrad: describe a transposed conv by its phase geometry (m2h_convT_wgrad_f32)");
+  M2H_REQUIRE(!quad || (a.nth == 2 && a.ntw == 2 && a.stride == 1 && a.os == 2 && a.offh == 0 && a.offw == 0 && a.Hq == a.Hi && a.Wq == a.Wi &&
+                        a.Ho == 2 * a.Hi && a.Wo == 2 * a.Wi),
+              "convT_wgrad: phase geometry of ConvTranspose2d(4,2,1) expected (taps 2x2, stride 1, os 2, Ho = 2 Hi)");
   M2H_REQUIRE(a.C0 > 0 && a.C0 % 4 == 0 && a.C1 >= 0 && a.C1 % 4 == 0, "conv_wgrad: C0/C1 must be multiples of 4");
   M2H_REQUIRE((a.C1 == 0) == (a.src1 == nullptr), "conv_wgrad: src1/C1 mismatch");
   M2H_REQUIRE(a.B > 0 && a.Hi > 0 && a.Wi > 0 && a.Hq > 0 && a.Wq > 0 && a.N > 0 && a.nth > 0 && a.ntw > 0 && a.stride > 0, "conv_wgrad: bad sizes");
@@ -475,13 +511,15 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   p.B = a.B; p.Hi = a.Hi; p.Wi = a.Wi; p.Hq = a.Hq; p.Wq = a.Wq;
   p.stride = a.stride; p.ntw = a.ntw; p.ntap = a.nth * a.ntw; p.mulh = a.mulh; p.offh = a.offh; p.mulw = a.mulw; p.offw = a.offw;
   p.Ho = a.Ho; p.Wo = a.Wo; p.os = a.os; p.ph = a.ph; p.pw = a.pw;
+  p.quad = quad ? 1 : 0;
+  const int phases = quad ? 4 : 1;
   p.direct = (a.os == 1 && a.ph == 0 && a.pw == 0 && a.Ho == a.Hq && a.Wo == a.Wq) ? 1 : 0;
   M2H_REQUIRE(a.os >= 1 && (a.Hq - 1) * a.os + a.ph < a.Ho && (a.Wq - 1) * a.os + a.pw < a.Wo, "conv_wgrad: output pixel grid exceeds Ho x Wo");
   p.dy = dy; p.ldy = ldy; p.N = a.N; p.K = p.ntap * p.Ctot; p.Kpad = (p.K + WK - 1) / WK * WK;
   p.M = (int)M; p.chunks = (int)((M + WM - 1) / WM);
   p.S = wgrad_splits(M, a.N, p.K);
-  M2H_REQUIRE(a.workspace != nullptr && a.workspace_bytes >= (size_t)p.S * p.N * p.Kpad * sizeof(float), "conv_wgrad: workspace too small (need %zu bytes)",
-              (size_t)p.S * p.N * p.Kpad * sizeof(float));
+  M2H_REQUIRE(a.workspace != nullptr && a.workspace_bytes >= (size_t)phases * p.S * p.N * p.Kpad * sizeof(float), "conv_wgrad: workspace too small (need %zu bytes)",
+              (size_t)phases * p.S * p.N * p.Kpad * sizeof(float));
   p.ws = static_cast<float*>(a.workspace);
   p.dw = dw;
   int bng, kt;
@@ -489,9 +527,9 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   p.ntiles = (a.N + bng - 1) / bng;
   const long nblk = (long)(p.S >= 8 ? (p.S + 7) / 8 * 8 : p.S) * p.ntiles * p.ktiles;
   M2H_REQUIRE(nblk < 0x7fffffffL, "conv_wgrad: grid too large");
-  const dim3 grid((unsigned)nblk), blk(256);
+  const dim3 grid((unsigned)nblk, (unsigned)phases), blk(256);
   // 3x3 / stride 1 / pad 1 over 32-channel, 32-pixel-wide images (AcousticMem): one image row per reduction chunk
-  const bool row3x3 = g_wgrad_row3x3 >= 0 && a.nth == 3 && a.ntw == 3 && a.stride == 1 && a.mulh == 1 && a.mulw == 1 && a.offh == -1 &&
+  const bool row3x3 = !quad && g_wgrad_row3x3 >= 0 && a.nth == 3 && a.ntw == 3 && a.stride == 1 && a.mulh == 1 && a.mulw == 1 && a.offh == -1 &&
                       a.offw == -1 && a.C0 == 32 && a.C1 == 0 && a.Wq == 32 && a.Wi == 32 && a.Hq == a.Hi && p.direct && a.N <= 32 &&
                       a.N % 4 == 0 && ldy % 4 == 0 && p.ntiles * p.ktiles == 1;
   if (row3x3) {
@@ -508,11 +546,11 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   if (p.S >= 16) {
     const long g = (long)p.N * ((p.K + 63) / 64);
     M2H_REQUIRE(g < 0x7fffffffL, "conv_wgrad: reduce grid too large");
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g, (unsigned)phases), dim3(256), 0, st, p);
   } else {
     size_t g = ((size_t)p.N * p.K + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)g), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)g, (unsigned)phases), dim3(256), 0, st, p);
   }
   return launch_status("conv_wgrad reduce");
 }
@@ -608,6 +646,13 @@ size_t m2h_conv_wgrad_workspace_bytes(const m2h_conv_args* args) { return args ?
 int m2h_conv_wgrad_f32(const m2h_conv_args* args, const float* dy, int ldy, float* dw, m2h_stream stream) {
   M2H_REQUIRE(args != nullptr, "conv_wgrad: null args");
   return conv_wgrad_f32(*args, dy, ldy, dw, as_stream(stream));
+}
+
+size_t m2h_convT_wgrad_workspace_bytes(const m2h_conv_args* args) { return args ? 4 * conv_wgrad_workspace_bytes(*args) : 0; }
+
+int m2h_convT_wgrad_f32(const m2h_conv_args* args, const float* dy, int ldy, float* dw, m2h_stream stream) {
+  M2H_REQUIRE(args != nullptr, "convT_wgrad: null args");
+  return conv_wgrad_f32(*args, dy, ldy, dw, as_stream(stream), true);
 }
 
 int m2h_pack_dgrad_weight(const float* w, float* wp, int Co, int Ci, int KH, int KW, int stride, int pad, m2h_stream stream) {

@@ -201,6 +201,8 @@ SIGNATURES = {
     "m2h_bn_train_fwd": [_P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "m2h_bn_train_bwd": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P],
     "m2h_unpack_convT_wgrad": [_P, _P, _I, _I, _P],
+    "m2h_convT_wgrad_f32": [ctypes.POINTER(ConvArgs), _P, _I, _P, _P],
+    "m2h_convT_wgrad_workspace_bytes": [ctypes.POINTER(ConvArgs)],
     "m2h_stft_frames": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "m2h_stft_post": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "m2h_istft_pre": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -582,7 +582,7 @@ def _convT_phase_args(x, x2, Co, ph, pw):
 class ConvTranspose2dNHWC(torch.autograd.Function):
     """z = conv_transpose2d(cat(x, x2), w, stride 2, pad 1, 4x4) on NHWC (no bias / activation): forward = 4 sub-pixel phase
     GEMMs in one launch; backward: dgrad = an ordinary 4x4/s2/p1 conv of dz with w read as a conv weight (one launch per
-    source), wgrad = the wgrad kernel per phase + scatter to torch layout."""
+    source), wgrad = the wgrad kernel over all four phases in one launch, its ordered reduce scattering to the torch layout."""
 
     @staticmethod
     def forward(ctx, x, x2, w, memo):
@@ -612,21 +612,17 @@ class ConvTranspose2dNHWC(torch.autograd.Function):
                 gx2 = ops.conv2d_nhwc(dz, wconv[C0:].contiguous(), Cin - C0, 4, 4, stride=2, pad=1, slope=1.0, name="convT.dgrad")
         if ctx.needs_input_grad[2]:
             lib = _lib.load()
-            dwp = torch.empty((4, Co, 4 * Cin), device=x.device)
             with torch.cuda.device(x.device):
-                for ph in range(2):
-                    for pw in range(2):
-                        a = _convT_phase_args(x, x2, Co, ph, pw)
-                        nbytes = lib.m2h_conv_wgrad_workspace_bytes(ctypes.byref(a))
-                        ws = torch.empty((nbytes + 3) // 4, device=x.device)
-                        a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
-                        M = B * H * W
-                        meta = {"kernel": "wgrad_f32", "M": M, "N": Co, "K": 4 * Cin, "flops": 2.0 * M * Co * 4 * Cin}
-                        ops._timed("convT_wgrad", meta, x.device,
-                                   lambda: _lib.check(lib.m2h_conv_wgrad_f32(ctypes.byref(a), ops._ptr(dz), Co, ops._ptr(dwp[ph * 2 + pw]),
-                                                                             ops._stream(x)), "m2h_conv_wgrad_f32(convT)"))
+                a = _convT_phase_args(x, x2, Co, 0, 0)   # the phase geometry; the launch walks all four phases
+                nbytes = lib.m2h_convT_wgrad_workspace_bytes(ctypes.byref(a))
+                ws = torch.empty((nbytes + 3) // 4, device=x.device)
+                a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+                M = B * H * W
                 gw = torch.empty_like(w)
-                _lib.check(lib.m2h_unpack_convT_wgrad(ops._ptr(dwp), ops._ptr(gw), Cin, Co, ops._stream(x)), "m2h_unpack_convT_wgrad")
+                meta = {"kernel": "wgrad_f32", "M": 4 * M, "N": Co, "K": 4 * Cin, "flops": 2.0 * 4 * M * Co * 4 * Cin}
+                ops._timed("convT_wgrad", meta, x.device,
+                           lambda: _lib.check(lib.m2h_convT_wgrad_f32(ctypes.byref(a), ops._ptr(dz), Co, ops._ptr(gw), ops._stream(x)),
+                                              "m2h_convT_wgrad_f32"))
         return gx, gx2, gw, None
 
 
