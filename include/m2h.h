@@ -478,11 +478,11 @@ int m2h_bn_train_bwd(const float* dy, const float* y, const float* z, const floa
                      float* dgamma, float* dbeta, float* dz, int M, int C, float* workspace, m2h_stream stream);
 
 /* Weight gradient of ConvTranspose2d(4,2,1) (separator_cnn.py:15-24; passive_trainer.py:218-286 backward) in ONE launch + one
- * reduce: args = the geometry of a sub-pixel phase (taps 2x2, stride 1, os 2, off 0, Hq = Hi, Ho = 2*Hi; ph / pw / mul are
+ * reduce + one scatter: args = the geometry of a sub-pixel phase (taps 2x2, stride 1, os 2, off 0, Hq = Hi, Ho = 2*Hi; ph / pw / mul are
  * ignored: grid y walks the four phases, each reading dy at its output pixels (2q+ph, 2r+pw) and stepping its taps by 2*ph-1 /
- * 2*pw-1); dw comes out in the torch layout [Ci][Co][4][4] (the ordered reduce over the pixel splits scatters it).  workspace:
- * m2h_convT_wgrad_workspace_bytes(args) = four times the single-phase size.  Same sums, in the same order, as the per-phase
- * calls + m2h_unpack_convT_wgrad below (9 launches per layer). */
+ * 2*pw-1); the ordered reduce over the pixel splits runs once for all phases and a transposing scatter writes dw in the torch
+ * layout [Ci][Co][4][4].  workspace: m2h_convT_wgrad_workspace_bytes(args) (four phases of slabs + the packed gradients).  Same
+ * sums, in the same order, as the per-phase calls + m2h_unpack_convT_wgrad below (3 launches per layer instead of 9). */
 size_t m2h_convT_wgrad_workspace_bytes(const m2h_conv_args* args /* host */);
 int m2h_convT_wgrad_f32(const m2h_conv_args* args /* host */, const float* dy, int ldy, float* dw, m2h_stream stream);
 

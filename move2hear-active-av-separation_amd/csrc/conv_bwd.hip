@@ -37,7 +37,8 @@ struct WGradP {
   float* ws;        // [S][N][Kpad]  (quad: [4 phases][S][N][Kpad])
   float* dw;        // [N][K]        (quad: the transposed conv's torch layout [Ci][N][4][4])
   int quad;         // 1: the four sub-pixel phases of a ConvTranspose2d(4,2,1) in one launch (grid y = phase: its taps' direction,
-                    // its dy rows, its slabs); the reduce kernel scatters into the torch layout
+                    // its dy rows, its slabs); the reduce kernels write dwp, convT_wgrad_unpack_kernel scatters it into dw
+  float* dwp;       // quad: [4 phases][N][K] packed gradients (behind the slabs in the workspace)
 };
 
 // phase (ph, pw) of a quad launch: taps step by 2 ph - 1 / 2 pw - 1 (separator_cnn.py:15-24 as four sub-pixel GEMMs)
@@ -57,14 +58,6 @@ __device__ __forceinline__ WPhase wgrad_phase(const WGradP& p) {
   }
   return w;
 }
-// index of gradient element (n = co, k = (th, tw, ci)) of phase (ph, pw) in the torch layout dw[ci][co][kh][kw], kh = (ph ? 2 : 1) + th (ph ? -2 : 2)
-__device__ __forceinline__ size_t quad_dw_index(const WGradP& p, const WPhase& w, int n, int k) {
-  const int tap = k / p.Ctot, ci = k - tap * p.Ctot;
-  const int th = tap >> 1, tw = tap & 1;
-  const int kh = (w.ph ? 2 : 1) + th * (w.ph ? -2 : 2), kw = (w.pw ? 2 : 1) + tw * (w.pw ? -2 : 2);
-  return (((size_t)ci * p.N + n) * 4 + kh) * 4 + kw;
-}
-
 constexpr int WK = 128;  // k sub-tile (one 16-byte segment per thread of a 32-thread row group)
 constexpr int WM = 32;   // pixels per reduction chunk
 
@@ -442,7 +435,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WGradP p) {
   }
   sh[w][lane] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (w == 0 && k < p.K) p.dw[p.quad ? quad_dw_index(p, wp_, n, k) : (size_t)n * p.K + k] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+  if (w == 0 && k < p.K) (p.quad ? p.dwp + (size_t)blockIdx.y * p.N * p.K : p.dw)[(size_t)n * p.K + k] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
 
 // few splits: one thread per element (the block-per-64-k form above would be tens of thousands of near-empty blocks)
@@ -455,8 +448,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const WGradP p)
     const int k = (int)(i - (size_t)n * p.K);
     float s = 0.f;
     for (int z = 0; z < p.S; ++z) s += ws[((size_t)z * p.N + n) * p.Kpad + k];
-    p.dw[p.quad ? quad_dw_index(p, wp_, n, k) : i] = s;
+    (p.quad ? p.dwp + (size_t)blockIdx.y * p.N * p.K : p.dw)[i] = s;
   }
+}
+
+// quad launches: the reduce kernels above leave the packed per-phase gradients dwp[phase][co][(th, tw, ci)] behind the slabs; this
+// kernel scatters them to the torch layout dw[ci][co][kh][kw].  A block owns (co, 16 ci): reads 16 runs of 16 consecutive ci
+// (one per (kh, kw)), transposes through LDS, writes 16 runs of 64 bytes.  (unpack_convT_wgrad_kernel's element-per-thread form
+// writes 4-byte words 64 bytes apart: 25 us per layer on average.)
+__global__ __launch_bounds__(256) void convT_wgrad_unpack_kernel(const WGradP p, const float* __restrict__ dwp) {
+  __shared__ float tile[16][17];
+  const int cb = (p.Ctot + 15) / 16;
+  const int n = blockIdx.x / cb, ci0 = (blockIdx.x - n * cb) * 16;
+  {
+    const int e = threadIdx.x >> 4, ci = ci0 + (threadIdx.x & 15);   // e = kh * 4 + kw -> phase (ph, pw), tap (th, tw): kh = (ph ? 2 : 1) + th (ph ? -2 : 2)
+    const int kh = e >> 2, kw = e & 3;
+    const int ph = (kh & 1) ^ 1, th = (kh == 0 || kh == 3) ? 1 : 0, pw = (kw & 1) ^ 1, tw = (kw == 0 || kw == 3) ? 1 : 0;
+    tile[threadIdx.x & 15][e] = ci < p.Ctot ? dwp[((size_t)(ph * 2 + pw) * p.N + n) * p.K + (size_t)(th * 2 + tw) * p.Ctot + ci] : 0.f;
+  }
+  __syncthreads();
+  const int cl = threadIdx.x >> 4, e = threadIdx.x & 15;
+  if (ci0 + cl < p.Ctot) p.dw[((size_t)(ci0 + cl) * p.N + n) * 16 + e] = tile[cl][e];
 }
 
 int g_wgrad_blocks = 0;  // tuning knob (m2h_debug_set 11): target block count of a weight-gradient launch
@@ -518,9 +530,10 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   p.dy = dy; p.ldy = ldy; p.N = a.N; p.K = p.ntap * p.Ctot; p.Kpad = (p.K + WK - 1) / WK * WK;
   p.M = (int)M; p.chunks = (int)((M + WM - 1) / WM);
   p.S = wgrad_splits(M, a.N, p.K);
-  M2H_REQUIRE(a.workspace != nullptr && a.workspace_bytes >= (size_t)phases * p.S * p.N * p.Kpad * sizeof(float), "conv_wgrad: workspace too small (need %zu bytes)",
-              (size_t)phases * p.S * p.N * p.Kpad * sizeof(float));
+  const size_t slab_floats = (size_t)phases * p.S * p.N * p.Kpad, need = (slab_floats + (quad ? (size_t)4 * p.N * p.K : 0)) * sizeof(float);
+  M2H_REQUIRE(a.workspace != nullptr && a.workspace_bytes >= need, "conv_wgrad: workspace too small (need %zu bytes)", need);
   p.ws = static_cast<float*>(a.workspace);
+  p.dwp = quad ? p.ws + slab_floats : nullptr;
   p.dw = dw;
   int bng, kt;
   wgrad_cfg(a.N, p.K, bng, kt, p.ktiles);
@@ -552,7 +565,12 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)g, (unsigned)phases), dim3(256), 0, st, p);
   }
-  return launch_status("conv_wgrad reduce");
+  rc = launch_status("conv_wgrad reduce");
+  if (rc || !quad) return rc;
+  const long gu = (long)p.N * ((p.Ctot + 15) / 16);
+  M2H_REQUIRE(gu < 0x7fffffffL, "convT_wgrad: unpack grid too large");
+  hipLaunchKernelGGL(convT_wgrad_unpack_kernel, dim3((unsigned)gu), dim3(256), 0, st, p, p.dwp);
+  return launch_status("convT_wgrad unpack");
 }
 
 // w [Co][Ci][KH][KW] -> per phase (ph,pw) of the stride: wp[phase][ci][th][tw][co] = w[co][ci][kh0(ph)+s*th][kw0(pw)+s*tw],
@@ -648,7 +666,9 @@ int m2h_conv_wgrad_f32(const m2h_conv_args* args, const float* dy, int ldy, floa
   return conv_wgrad_f32(*args, dy, ldy, dw, as_stream(stream));
 }
 
-size_t m2h_convT_wgrad_workspace_bytes(const m2h_conv_args* args) { return args ? 4 * conv_wgrad_workspace_bytes(*args) : 0; }
+size_t m2h_convT_wgrad_workspace_bytes(const m2h_conv_args* args) {   // four phases of slabs + the packed per-phase gradients
+  return args ? 4 * conv_wgrad_workspace_bytes(*args) + (size_t)4 * args->N * args->nth * args->ntw * (args->C0 + args->C1) * sizeof(float) : 0;
+}
 
 int m2h_convT_wgrad_f32(const m2h_conv_args* args, const float* dy, int ldy, float* dw, m2h_stream stream) {
   M2H_REQUIRE(args != nullptr, "convT_wgrad: null args");

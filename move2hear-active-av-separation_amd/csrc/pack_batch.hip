@@ -47,14 +47,25 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackBatchArgs a) 
   const int tiles = (n_outer_dst + PACK_TILE - 1) / PACK_TILE;
   const int m = b / tiles, o0 = (b - m * tiles) * PACK_TILE;
   const bool mid_valid = it.kind != M2H_PACK_FC_DGRAD || m < it.p[4];     // FC_DGRAD: padded input channels are zero rows
-  for (int i = threadIdx.x; i < PACK_TILE * T; i += 256) {
-    const int o = i / T, t = i - o * T;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const bool vec = T == 16;   // every 4x4 kernel (all of both U-Nets): one 16-byte load and one 16-byte store per thread
+  if (vec) {
+    const int o = threadIdx.x >> 2, c = threadIdx.x & 3;
     const int og = o0 + o;
-    tile[o][t] = (mid_valid && og < n_outer_src) ? w[(size_t)m * src_mid + (size_t)og * src_outer + t] : 0.f;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (mid_valid && og < n_outer_src) v = *reinterpret_cast<const f32x4*>(w + (size_t)m * src_mid + (size_t)og * src_outer + 4 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[o][4 * c + j] = v[j];
+  } else {
+    for (int i = threadIdx.x; i < PACK_TILE * T; i += 256) {
+      const int o = i / T, t = i - o * T;
+      const int og = o0 + o;
+      tile[o][t] = (mid_valid && og < n_outer_src) ? w[(size_t)m * src_mid + (size_t)og * src_outer + t] : 0.f;
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < PACK_TILE * T; i += 256) {
-    const int t = i / PACK_TILE, o = i - t * PACK_TILE;
+  for (int i = threadIdx.x; i < (vec ? 256 : PACK_TILE * T); i += 256) {
+    const int t = vec ? i >> 4 : i / PACK_TILE, o = vec ? (i & 15) * 4 : i - t * PACK_TILE;
     const int og = o0 + o;
     if (og >= n_outer_dst) continue;
     const int kh = t / KW, kw = t - kh * KW;
@@ -71,7 +82,15 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackBatchArgs a) 
     } else {
       base = ((size_t)t * it.p[5] + m) * it.p[0];
     }
-    wp[base + og] = tile[o][t];
+    if (vec) {   // four consecutive outer indices
+      if (og + 3 < n_outer_dst && ((base + og) & 3) == 0) {
+        *reinterpret_cast<f32x4*>(wp + base + og) = f32x4{tile[o][t], tile[o + 1][t], tile[o + 2][t], tile[o + 3][t]};
+      } else {
+        for (int j = 0; j < 4 && og + j < n_outer_dst; ++j) wp[base + og + j] = tile[o + j][t];
+      }
+    } else {
+      wp[base + og] = tile[o][t];
+    }
   }
 }
 
