@@ -186,6 +186,9 @@ class _PackMemo:
         if spec[0] == "fc_dgrad":        # full-spatial conv (a Linear): dX = dY @ Wp as one GEMM, Wp^T [KH*KW*c_in][Co]
             Co, Ci, KH, KW = w.shape
             return (KH * KW * spec[1], Co), _lib.PACK_FC_DGRAD, (Co, Ci, KH, KW, Ci, spec[1])
+        if spec[0] == "dgrad_as_convT":  # Conv2d(4,2,1) input gradient = conv_transpose2d(dy, w): w [Co][Ci][4][4] IS a ConvTranspose2d weight [in=Co][out=Ci]
+            Co, Ci = w.shape[0], w.shape[1]
+            return (4, Ci, 4 * Co), _lib.PACK_CONVT, (Co, Ci, 0, 0, 0, 0)
         if spec[0] == "convT_dgrad":     # ConvTranspose2d input gradient = a Conv2d with the weight read as [out=Cin][in=Co]
             Cin, Co = w.shape[0], w.shape[1]
             return (Cin, 16 * Co), _lib.PACK_CONV, (Cin, Co, 4, 4, Co, Co)
@@ -298,6 +301,11 @@ class Conv2dNHWC(torch.autograd.Function):
                     wp = ops.pack_conv_weight_ex(w.detach().contiguous(), Ci, c_in)      # [Co][(h,w,c)]
                     wt = pack_dgrad_weight(wp.view(Co, KH * KW * c_in, 1, 1), 1, 0).view(KH * KW * c_in, Co)
                 gx = ops.linear(dy.view(B, Co), wt, None, name="fc.dgrad").view(B, KH, KW, c_in)
+            elif (KH, KW, stride, pad) == (4, 4, 2, 1) and x.shape[1] == 2 * Ho and x.shape[2] == 2 * Wo and Ci % 4 == 0 and Ci == x.shape[3]:
+                # the U-Net's encoder convs (separator_cnn.py:5-13): dX = conv_transpose2d(dY, W) -- the four sub-pixel phases in ONE
+                # launch of the transposed-conv forward (the generic path below is one launch per phase: 4 x 10-19 us per layer)
+                wpt = ctx.memo.get_bwd(w, ("dgrad_as_convT",)) if ctx.memo is not None else ops.pack_convT_weight(w.detach().contiguous())
+                gx = ops.unet_up_fwd_raw(dy, None, wpt, Ci)
             else:
                 wpd = ctx.memo.get_bwd(w, ("dgrad", stride, pad)) if ctx.memo is not None else None
                 gx = conv_dgrad(dy, w.detach().contiguous(), (x.shape[1], x.shape[2]), stride, pad, wp=wpd)
