@@ -152,7 +152,7 @@ size_t m2h_conv_igemm_workspace_bytes(const m2h_conv_args* args /* host */);
  * gather kernel (-1 off, > 0 = pixel limit), 26 the 256 x 128 eight-wave tile of the bf16x3 arithmetic (-1 off, > 0 = minimum
  * tile count), 27 the LDS-DMA engine for split32 operands (csrc/conv_dma.hip; -1 off, 2 = below the tile-count threshold too),
  * 28 = 32: 32x32x16 instead of 16x16x32 MFMA fragments there, 30 the four-phase transposed-conv kernel (csrc/convt_quad.hip; -1
- * off, 1 = wherever its shape conditions hold), 34 = -1: no two-K-halves launch of the LDS-DMA engine, 35 = -1: the whole-network
+ * off, 1 = wherever its shape conditions hold), 34 = -1: no split-K launches of the LDS-DMA / shared-patch engines (two K-halves, K-parts of the deepest stages), 35 = -1: the whole-network
  * runner does not take the strip-walker kernels (csrc/conv_strip.hip), 36 the shared-patch LDS-DMA engine (csrc/conv_patch.hip; -1
  * off, 2 = below the tile-count threshold too, 3 = as 2 with the whole-image patch wherever it fits).  Numbers of experiments that were measured and removed
  * (5, 6, 10, 12, 13, 17, 19, 20, 29, 31, 32) are accepted and ignored. */
