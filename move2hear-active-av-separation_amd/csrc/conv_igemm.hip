@@ -1079,7 +1079,10 @@ static int walked_K(const m2h_conv_args& a) {
 }
 
 // waves per block of the skinny kernels: keep a wave's chain of 16-float steps at about 16
-static int skinny_waves(int steps) { return steps > 160 ? 16 : (steps > 80 ? 8 : 4); }
+// waves per block of the skinny kernels: they split the walked reduction, and a wave's share is a chain of dependent load rounds
+// (runs of at most Ctot / 16 steps between tap changes), so short shares win: more than 32 steps -> 16 waves, more than 16 -> 8
+// (A/B on one box, tools/train_ab.sh: rollout 74.2 -> 71.6 ms per cycle against the round-2 thresholds 160 / 80)
+static int skinny_waves(int steps) { return steps > 32 ? 16 : (steps > 16 ? 8 : 4); }
 
 // Tile choice: N picks the width; skinny M (rollout batches, GRU steps: weight-streaming bound, nothing to re-use along M)
 // gets 32- or 64-row tiles so that four times as many blocks stream the weights.

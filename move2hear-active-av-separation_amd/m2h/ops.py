@@ -53,6 +53,8 @@ def _timed(name, meta, dev, fn):
     e0.record(st)
     r = fn()
     e1.record(st)
+    if meta is not None:
+        meta = dict(meta, label=last_kernel())   # what the library's dispatch really launched (m2h_last_kernel)
     _timing.append((name, meta, e0, e1))
     return r
 
