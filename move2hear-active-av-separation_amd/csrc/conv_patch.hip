@@ -73,20 +73,21 @@ struct PatchCfg {
   static constexpr int BM = 64 * WM, BN = 64 * WN;
   static constexpr int A_ROWS = WHOLE ? BM : PHALO_ROWS;
   static constexpr int A_BYTES = A_ROWS * 128, B_BYTES = BN * 128;
-  static constexpr int PIPE = 2 * A_BYTES + PNSTB * B_BYTES;     // bytes of the main loop's buffers (the zero row follows)
+  static constexpr int A_STRIDE = A_BYTES + (WHOLE ? 256 : 0);   // WHOLE: two zero rows (one per row parity: a lane sent there keeps its bank slot) behind each patch buffer
+  static constexpr int PIPE = 2 * A_STRIDE + PNSTB * B_BYTES;    // bytes of the main loop's buffers
   static constexpr int STORE = BM * (BN * 4 + 16);               // the epilogue's row image (nhwc_tile_store_T, one pass)
   static constexpr int SCRATCH = PIPE > STORE ? PIPE : STORE;
-  static constexpr int SMEM = SCRATCH + 256;                     // + the zero rows: one per row parity, so that a lane sent there keeps its bank slot
+  static constexpr int SMEM = SCRATCH;
 };
 
 }  // namespace
 
-template <int WM, int WN, int WHOLE, int DBG>   // DBG (diagnostic builds only): 4 no MFMAs, 5 no loads, 6 no loads and no k-loop barrier, 7 no k-loop barrier
+template <int WM, int WN, int WHOLE, int CONVT, int DBG>   // CONVT: a transposed-conv phase (one class for the whole kernel); DBG (diagnostic builds only): 4 no MFMAs, 5 no loads, 6 no loads and no k-loop barrier, 7 no k-loop barrier
 __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p, const PatchGeo g) {
   using Cfg = PatchCfg<WM, WN, WHOLE>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, A_BYTES = Cfg::A_BYTES, B_BYTES = Cfg::B_BYTES;
   constexpr int FM = 4, FN = 4, AG = Cfg::A_ROWS / (8 * PNW), BG = BN / (8 * PNW);
-  constexpr int B_OFF = 2 * A_BYTES, ZERO_OFF = Cfg::SCRATCH;
+  constexpr int A_STRIDE = Cfg::A_STRIDE, B_OFF = 2 * A_STRIDE;
   static_assert(WM * WN == PNW && (WHOLE || BM == 256), "tile shape");
   static_assert(AG == 4 || AG == 6 || AG == 8, "patch DMA groups per wave");
   static_assert(BG == 1 || BG == 2, "weight DMA groups per wave");
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   const int xcd = L & 7;
   int idx = L >> 3;
   int phase = 0;
-  if (p.convT) {
+  if (CONVT) {
     phase = idx & 3;
     idx >>= 2;
   }
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
 #ifdef M2H_CLOCK_DIAG
   const unsigned long long dbg_s0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const int ph = p.convT ? phase >> 1 : 0, pw = p.convT ? phase & 1 : 0;
-  const float* wbase = p.w + (p.convT ? (size_t)phase * p.N * p.K : 0);
+  const int ph = CONVT ? phase >> 1 : 0, pw = CONVT ? phase & 1 : 0;
+  const float* wbase = p.w + (CONVT ? (size_t)phase * p.N * p.K : 0);
 
   for (int r = tid; r < BM; r += 64 * PNW) {
     const int m = m0 + r;
@@ -125,12 +126,12 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
     if (m < p.M) decode_row(p, m, ph, pw, q, rr, b, out, bc);
     ri_out[r] = out;
   }
-  if (WHOLE && tid < 64) reinterpret_cast<float*>(smem + ZERO_OFF)[tid] = 0.f;
+  if (WHOLE && tid < 128) reinterpret_cast<float*>(smem + (tid >> 6) * A_STRIDE + A_BYTES)[tid & 63] = 0.f;
 
   // ---- the patch rows this lane feeds (fixed for the whole kernel) ----
   const int b0 = m0 >> (g.w_sh + p.hq_sh);
   const int q0 = WHOLE ? 0 : (m0 >> g.w_sh) & (p.Hq - 1);   // first output row of the tile inside its image
-  const int sm = p.convT ? 1 : 2;
+  const int sm = CONVT ? 1 : 2;
   int a_hw[AG], a_pix[AG];   // (input row, column) at class offset 0, packed; image base pixel (-1: no such row)
 #pragma unroll
   for (int i = 0; i < AG; ++i) {
@@ -162,14 +163,14 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   const int nch = p.Ctot / BK;
   const int split = blockIdx.y;
   const int cls0 = p.S == 2 ? 2 * split : 0;
-  const int NS = (p.convT ? 1 : (p.S == 2 ? 2 : 4)) * nch;
+  const int NS = (CONVT ? 1 : (p.S == 2 ? 2 : 4)) * nch;
   int a_cls = cls0, a_ci = 0, a_issued = 0, a_buf = 0;
   auto rebuild_rows = [&]() {
     const bool second = a_ci >= p.C0 && p.src1 != nullptr;
     const int Cs = second ? p.C1 : p.C0;
     const char* base = reinterpret_cast<const char*>(second ? p.src1 : p.src0);
-    const int gh = p.convT ? ph : a_cls >> 1, gw = p.convT ? pw : a_cls & 1;
-    const int dh = WHOLE ? (p.convT ? 0 : 1 - gh) : gh - 1, dw = WHOLE ? (p.convT ? 0 : 1 - gw) : gw - 1;
+    const int gh = CONVT ? ph : a_cls >> 1, gw = CONVT ? pw : a_cls & 1;
+    const int dh = WHOLE ? (CONVT ? 0 : 1 - gh) : gh - 1, dw = WHOLE ? (CONVT ? 0 : 1 - gw) : gw - 1;
 #pragma unroll
     for (int i = 0; i < AG; ++i) {
       const int ih = (a_hw[i] >> 16) + dh, iw = (a_hw[i] & 0xffff) + dw;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   auto issue_patch = [&]() {
     const bool second = a_ci >= p.C0 && p.src1 != nullptr;
     const unsigned cofs = (unsigned)(second ? a_ci - p.C0 : a_ci) * 4u;
-    const unsigned dst = lds0 + (unsigned)a_buf * A_BYTES + (unsigned)wave * 1024u;
+    const unsigned dst = lds0 + (unsigned)a_buf * A_STRIDE + (unsigned)wave * 1024u;
     const char* sa[AG];
 #pragma unroll
     for (int i = 0; i < AG; ++i) sa[i] = ptrA[i] + cofs;
@@ -205,8 +206,8 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   int b_cls = cls0, b_ci = 0, b_tap = 0, b_stage = 0;
   auto issue_weights = [&]() {
     const int a = b_tap >> 1, b = b_tap & 1;
-    const int th = p.convT ? (ph ? a : 1 - a) : 2 * a + (b_cls >> 1);
-    const int tw = p.convT ? (pw ? b : 1 - b) : 2 * b + (b_cls & 1);
+    const int th = CONVT ? (ph ? a : 1 - a) : 2 * a + (b_cls >> 1);
+    const int tw = CONVT ? (pw ? b : 1 - b) : 2 * b + (b_cls & 1);
     const unsigned kofs = (unsigned)((th * p.ntw + tw) * p.Ctot + b_ci) * 4u;
     const unsigned dst = lds0 + (unsigned)B_OFF + (unsigned)b_stage * B_BYTES + (unsigned)wave * 1024u;
     const char* sb[BG];
@@ -233,26 +234,41 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   // ---- fragment addresses ----
   // pixels: patch row of output pixel (wm 64 + 16 mi + frow) at shift 0, and (WHOLE) which image edges it lies on: bit 0 top,
   // 1 bottom, 2 left, 3 right; weights: as igemm_dma_kernel's 16x16x32 path
-  int prow0[FM], edge[FM];
-#pragma unroll
-  for (int mi = 0; mi < FM; ++mi) {
-    const int ml = wm * 64 + mi * 16 + frow;
-    const int seg = ml >> g.seg_sh;
-    const int rem = ml & ((1 << g.seg_sh) - 1);
-    const int il = rem >> g.w_sh, jl = rem & ((1 << g.w_sh) - 1);
-    prow0[mi] = seg * g.seg_rows + il * g.W1 + jl;
-    edge[mi] = (il == 0 ? 1 : 0) | (il == g.rows - 1 ? 2 : 0) | (jl == 0 ? 4 : 0) | (jl == (1 << g.w_sh) - 1 ? 8 : 0);
-  }
   const int fx = (frow >> 1) & 7;
   const int offH = (half ^ fx) * 16, offL = ((4 + half) ^ fx) * 16;
   const int b_row = B_OFF + (wn * 64 + frow) * 128;
   f32x4 ah[FM], al[FM], bh[FN], bl[FN];
-  auto load_a = [&](int buf, int shift, int kill, auto lo, auto hi) {
+  // byte offsets (inside a patch buffer) of this lane's hi pieces for the four taps of the current class; lo = ^ 64.  Rebuilt only
+  // when the class changes (never, for a transposed conv): the k-loop adds the buffer base and reads.  (Computed per read, the
+  // whole-image form's edge tests were 60 VALU instructions per k-tile against 18 of the halo form.)
+  int atab[4][FM];
+  const int W1 = g.W1;
+  auto build_atab = [&](int cls) {
+    const int gh = CONVT ? ph : cls >> 1, gw = CONVT ? pw : cls & 1;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int a = tt >> 1, b = tt & 1;
+      // WHOLE: rows / columns -1, 0 (gh = 0) or 0, +1 (gh = 1) of the pixel's own, zeros past the image's edges
+      const int shift = WHOLE ? (a - 1 + gh) * W1 + (b - 1 + gw) : a * W1 + b;
+      const int kill = WHOLE ? ((a == 0 && gh == 0) ? 1 : 0) | ((a == 1 && gh == 1) ? 2 : 0) | ((b == 0 && gw == 0) ? 4 : 0) | ((b == 1 && gw == 1) ? 8 : 0) : 0;
+#pragma unroll
+      for (int mi = 0; mi < FM; ++mi) {
+        // patch row of output pixel (wm 64 + 16 mi + frow) at shift 0, and which image edges it lies on: bit 0 top, 1 bottom, 2 left, 3 right
+        const int ml = wm * 64 + mi * 16 + frow;
+        const int seg = ml >> g.seg_sh;
+        const int rem = ml & ((1 << g.seg_sh) - 1);
+        const int il = rem >> g.w_sh, jl = rem & ((1 << g.w_sh) - 1);
+        const int edge = (il == 0 ? 1 : 0) | (il == g.rows - 1 ? 2 : 0) | (jl == 0 ? 4 : 0) | (jl == (1 << g.w_sh) - 1 ? 8 : 0);
+        const int row = seg * g.seg_rows + il * g.W1 + jl + shift;
+        const int ad = (row << 7) | (((half + (row & 6)) & 7) << 4);
+        atab[tt][mi] = (edge & kill) ? A_BYTES + (ad & 255) : ad;   // zeros at the bank slot of the row they replace: the lane group stays conflict-free
+      }
+    }
+  };
+  auto load_a = [&](int buf, auto ttc, auto lo, auto hi) {
 #pragma unroll
     for (int mi = decltype(lo)::value; mi < decltype(hi)::value; ++mi) {
-      const int row = prow0[mi] + shift;
-      int ad = buf * A_BYTES + ((row << 7) | (((half + (row & 6)) & 7) << 4));
-      if (WHOLE) ad = (edge[mi] & kill) ? ZERO_OFF + (ad & 255) : ad;   // zeros at the bank slot of the row it replaces: the group stays conflict-free
+      const int ad = buf * A_STRIDE + atab[decltype(ttc)::value][mi];
       ah[mi] = *reinterpret_cast<const f32x4*>(smem + ad);
       al[mi] = *reinterpret_cast<const f32x4*>(smem + (ad ^ 64));
     }
@@ -293,20 +309,6 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(decltype(cnt)::value) : "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  // tap tt = 2 a + b of class cls: row shift of its fragments and (WHOLE) the edges past which they read zeros
-  const int W1 = g.W1;
-  auto tap_geo = [&](int cls, int tt, int& shift, int& kill) {
-    const int a = tt >> 1, b = tt & 1;
-    if (WHOLE) {
-      const int gh = p.convT ? ph : cls >> 1, gw = p.convT ? pw : cls & 1;
-      shift = (a - 1 + gh) * W1 + (b - 1 + gw);   // rows / columns -1, 0 (gh = 0) or 0, +1 (gh = 1) of the pixel's own
-      kill = ((a == 0 && gh == 0) ? 1 : 0) | ((a == 1 && gh == 1) ? 2 : 0) | ((b == 0 && gw == 0) ? 4 : 0) | ((b == 1 && gw == 1) ? 8 : 0);
-    } else {
-      shift = a * W1 + b;
-      kill = 0;
-    }
-  };
-
   // ---- pipeline ----
   issue_patch();
   issue_weights();
@@ -318,33 +320,29 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
 #ifdef M2H_CLOCK_DIAG
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  {
-    int sh, kl;
-    tap_geo(cls0, 0, sh, kl);
-    load_a(0, sh, kl, I0{}, IH{});
-  }
+  build_atab(cls0);
+  load_a(0, std::integral_constant<int, 0>{}, I0{}, IH{});
   for_ni([&](auto nic) { load_b(0, nic); });
   // tile tt of a patch: upper pixel fragments | MFMAs of the lower ones | wait + barrier | lower fragments of the next tile |
   // MFMAs of the upper ones, the next tile's weight fragments replacing this tile's one by one, the DMA issues among them
   auto body = [&](auto ttc, auto cnt, auto issue_w, auto issue_p) {
     constexpr int TT = decltype(ttc)::value;
     const int ns = cs + 1 == PNSTB ? 0 : cs + 1;
-    int sh, kl;
-    tap_geo(c_cls, TT, sh, kl);
-    load_a(ab, sh, kl, IH{}, IF{});
+    load_a(ab, ttc, IH{}, IF{});
     __builtin_amdgcn_sched_barrier(0);
     for_ni([&](auto nic) { mfma_col(I0{}, IH{}, nic); });
     wait_and_barrier(cnt);
     int nab = ab;
     if constexpr (TT == 3) {   // the next tile opens the next patch
       nab = ab ^ 1;
-      if (++c_ci == nch) {
-        c_ci = 0;
-        ++c_cls;
+      if constexpr (!CONVT) {
+        if (++c_ci == nch) {     // ... of the next class (convs: four classes per window)
+          c_ci = 0;
+          build_atab(++c_cls);
+        }
       }
     }
-    tap_geo(c_cls, (TT + 1) & 3, sh, kl);
-    load_a(nab, sh, kl, I0{}, IH{});
+    load_a(nab, std::integral_constant<int, (TT + 1) & 3>{}, I0{}, IH{});
     __builtin_amdgcn_sched_barrier(0);
     for_ni([&](auto nic) {
       mfma_col(IH{}, IF{}, nic);
@@ -375,11 +373,7 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   body(T0{}, CW{}, Y{}, N{});     // last patch: the last weight tile is issued here
   body(T1{}, CW{}, N{}, N{});
   body(T2{}, C0{}, N{}, N{});
-  {
-    int sh, kl;
-    tap_geo(c_cls, 3, sh, kl);
-    load_a(ab, sh, kl, IH{}, IF{});
-  }
+  load_a(ab, std::integral_constant<int, 3>{}, IH{}, IF{});
   for_ni([&](auto nic) { mfma_col(I0{}, IF{}, nic); });
 
 #ifdef M2H_CLOCK_DIAG
@@ -423,13 +417,15 @@ static int launch_patch_cfg(IGemmP& p, const PatchGeo& g, int S, hipStream_t st)
   if (nblk > 0x7fffffffL) return -2;
   const dim3 grid((unsigned)nblk, (unsigned)S), blk(64 * PNW);
 #ifdef M2H_CLOCK_DIAG
-  if (g_patch == 4) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 4>), grid, blk, 0, st, p, g);
-  else if (g_patch == 5) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 5>), grid, blk, 0, st, p, g);
-  else if (g_patch == 6) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 6>), grid, blk, 0, st, p, g);
-  else if (g_patch == 7) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 7>), grid, blk, 0, st, p, g);
+  if (p.convT) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 1, 0>), grid, blk, 0, st, p, g);   // (the diagnostic variants are built for convs)
+  else if (g_patch == 4) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 0, 4>), grid, blk, 0, st, p, g);
+  else if (g_patch == 5) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 0, 5>), grid, blk, 0, st, p, g);
+  else if (g_patch == 6) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 0, 6>), grid, blk, 0, st, p, g);
+  else if (g_patch == 7) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 0, 7>), grid, blk, 0, st, p, g);
   else
 #endif
-  hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 0>), grid, blk, 0, st, p, g);
+  if (p.convT) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 1, 0>), grid, blk, 0, st, p, g);
+  else hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 0, 0>), grid, blk, 0, st, p, g);
   return launch_status(BN == 64 ? "igemm_patch<512,64>" : S == 2 ? "igemm_patch<256,128> (two K-halves)" : "igemm_patch<256,128>");
 }
 
