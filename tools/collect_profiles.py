@@ -54,7 +54,29 @@ for name in fetch:
     if name.startswith("m2h::") and name in write:
         kern[name] = {"fetch_kib_per_launch_raw": fetch[name], "fetch_correction": 2.0, "write_kib_per_launch": write[name],
                       "traffic_bytes_per_launch": int((2.0 * fetch[name] + write[name]) * 1024)}
-dom = next((k for k in kern if k.startswith("m2h::igemm_patch_kernel<4, 2, 0")), None) or next((k for k in kern if k.startswith("m2h::igemm_dma_kernel")), None)
+# the bench line's dominant instantiation "igemm_patch<256,128>" (down1, down2, up1, up2 of both U-Nets) is three template
+# instantiations (halo / conv, halo / transposed, whole-image / transposed): launch-weighted mean of their traffic
+def calls(path):
+    out = {}
+    if os.path.exists(path):
+        for line in open(path):
+            m = re.match(r"^(\S.*?)\s+calls=(\d+)", line)
+            if m:
+                out[m.group(1).replace("void ", "")] = int(m.group(2))
+    return out
+
+
+ncalls = calls(os.path.join(SRC, "pmc_FETCH_SIZE.txt"))
+group = [k for k in kern if re.match(r"m2h::igemm_patch_kernel<4, 2, (0, 0|0, 1|1, 1), 0>", k)]
+dom = None
+if group:
+    tot = sum(ncalls.get(k, 0) for k in group)
+    if tot:
+        dom = "m2h::igemm_patch_kernel<4, 2, *> (launch-weighted over %s)" % ", ".join(k.split("igemm_patch_kernel")[1] for k in group)
+        kern[dom] = {"fetch_correction": 2.0,
+                     "traffic_bytes_per_launch": int(sum(kern[k]["traffic_bytes_per_launch"] * ncalls.get(k, 0) for k in group) / tot)}
+if dom is None:
+    dom = next((k for k in kern if k.startswith("m2h::igemm_dma_kernel")), None)
 src = "profiles/r03_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1 --no-other-mode --no-graph; tools/profile_round3.sh)"
 traffic = {"bf16x3": dict(kern.get(dom, {}), source=src, kernel=dom), "per_kernel": kern}
 with open(os.path.join(DST, "r03_pmc_hbm_traffic.json"), "w") as f:
