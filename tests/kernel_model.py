@@ -338,3 +338,63 @@ def patch_read_conflict_degree(row0, lo=0, xor_map=False):
             slots.setdefault((a // 16) % 16, set()).add(a)
         worst = max(worst, max(len(v) for v in slots.values()))
     return worst
+
+
+def patch_engine_layer(x, w, transposed, whole):
+    """Index arithmetic of csrc/conv_patch.hip on one image (numpy, fp64 sums): x [H, W, C] NHWC input, w the torch weight
+    (Conv2d [Co, Ci, 4, 4] / ConvTranspose2d [Ci, Co, 4, 4]), stride 2, pad 1.  For every class (gh, gw) of a conv's window / every
+    phase (ph, pw) of a transposed conv the engine stages ONE patch P of the tile's output pixels and its four taps tt = 2a + b
+    read it at a row / column shift:
+      whole = True   patch row (k, l) = in(2k + 1 - gh, 2l + 1 - gw) (conv) / in(k, l) (transposed); tap (a, b) of output pixel
+                     (q, r) reads patch (q + a - 1 + g_h, r + b - 1 + g_w), zeros where that falls off the grid (edge / kill bits)
+      whole = False  halo patch P[i][j] = in(2i + gh - 1, 2j + gw - 1) / in(i + ph - 1, j + pw - 1), i <= rows, j <= W (zeros
+                     outside the image); tap (a, b) reads P[q + a][r + b]
+    with the weight tap (kh, kw) = (2a + gh, 2b + gw) (conv) / (th, tw) = (ph ? a : 1 - a, pw ? b : 1 - b) of the phase's 2x2 window
+    (kh = (ph ? 2 : 1) + th (ph ? -2 : 2), as pack_convT_weight).  Returns the NHWC output."""
+    H, W, C = x.shape
+    if transposed:
+        Hq, Wq, Co = H, W, w.shape[1]
+        out = np.zeros((2 * H, 2 * W, Co))
+    else:
+        Hq, Wq, Co = H // 2, W // 2, w.shape[0]
+        out = np.zeros((Hq, Wq, Co))
+
+    def inp(i, j):
+        return x[i, j].astype(np.float64) if 0 <= i < H and 0 <= j < W else np.zeros(C)
+
+    for g_h in range(2):
+        for g_w in range(2):
+            if whole:
+                P = np.zeros((Hq, Wq, C))
+                for k in range(Hq):
+                    for l in range(Wq):
+                        P[k, l] = inp(k, l) if transposed else inp(2 * k + 1 - g_h, 2 * l + 1 - g_w)
+            else:
+                P = np.zeros((Hq + 1, Wq + 1, C))
+                for i in range(Hq + 1):
+                    for j in range(Wq + 1):
+                        P[i, j] = inp(i + g_h - 1, j + g_w - 1) if transposed else inp(2 * i + g_h - 1, 2 * j + g_w - 1)
+            for a in range(2):
+                for b in range(2):
+                    if transposed:
+                        th, tw = (a if g_h else 1 - a), (b if g_w else 1 - b)
+                        kh, kw = (2 if g_h else 1) + th * (-2 if g_h else 2), (2 if g_w else 1) + tw * (-2 if g_w else 2)
+                        wt = w[:, :, kh, kw].astype(np.float64)              # [Ci, Co]
+                    else:
+                        wt = w[:, :, 2 * a + g_h, 2 * b + g_w].astype(np.float64).T   # [Ci, Co]
+                    for q in range(Hq):
+                        for r in range(Wq):
+                            if whole:
+                                k, l = q + a - 1 + g_h, r + b - 1 + g_w
+                                # the kernel's edge / kill bits: top & (a == 0, g_h == 0), bottom & (a == 1, g_h == 1), likewise left / right
+                                killed = (q == 0 and a == 0 and g_h == 0) or (q == Hq - 1 and a == 1 and g_h == 1) or \
+                                         (r == 0 and b == 0 and g_w == 0) or (r == Wq - 1 and b == 1 and g_w == 1)
+                                assert killed == (not (0 <= k < Hq and 0 <= l < Wq))
+                                v = np.zeros(C) if killed else P[k, l]
+                            else:
+                                v = P[q + a, r + b]
+                            if transposed:
+                                out[2 * q + g_h, 2 * r + g_w] += v @ wt
+                            else:
+                                out[q, r] += v @ wt
+    return out

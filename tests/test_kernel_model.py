@@ -136,3 +136,25 @@ def test_patch_engine_lds_map_is_conflict_free_at_every_shift():
         assert KM.patch_row_addr(row, 5) == KM.patch_row_addr(row, 1) ^ 64     # lo piece = hi piece's address ^ 64
     assert all(KM.patch_read_conflict_degree(r, 0, xor_map=True) == 1 for r in range(0, 64, 16))
     assert max(KM.patch_read_conflict_degree(r, 0, xor_map=True) for r in range(1, 16)) == 2
+
+
+def test_patch_engine_tap_classes_match_torch():
+    """csrc/conv_patch.hip's decomposition -- one staged patch per parity class of the 4x4/s2 window / per transposed-conv phase,
+    four taps reading it at a shift, the whole-image form's zero rows selected by edge / kill bits -- equals Conv2d(4, 2, 1) and
+    ConvTranspose2d(4, 2, 1) (separator_cnn.py:5-24) on every output pixel, for both patch forms, including 1-row images."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    for (H, W, Ci, Co) in ((4, 8, 3, 5), (2, 4, 4, 2), (8, 4, 2, 3)):
+        x = torch.randn(1, Ci, H, W, generator=g)
+        w = torch.randn(Co, Ci, 4, 4, generator=g)
+        want = F.conv2d(x, w, None, stride=2, padding=1)[0].permute(1, 2, 0).numpy()
+        for whole in (True, False):
+            got = KM.patch_engine_layer(x[0].permute(1, 2, 0).numpy(), w.numpy(), False, whole)
+            assert np.abs(got - want).max() < 1e-4, (H, W, whole)
+    for (H, W, Ci, Co) in ((2, 4, 3, 4), (1, 8, 2, 3), (4, 2, 5, 2)):
+        x = torch.randn(1, Ci, H, W, generator=g)
+        w = torch.randn(Ci, Co, 4, 4, generator=g)
+        want = F.conv_transpose2d(x, w, None, stride=2, padding=1)[0].permute(1, 2, 0).numpy()
+        for whole in (True, False):
+            got = KM.patch_engine_layer(x[0].permute(1, 2, 0).numpy(), w.numpy(), True, whole)
+            assert np.abs(got - want).max() < 1e-4, (H, W, whole)
