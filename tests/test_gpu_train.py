@@ -32,6 +32,8 @@ def _rel(a, b):
     (2, 14, 14, 64, 32, 3, 1, 0, 1.0),     # VisualCNN conv2 (no activation)
     (6, 12, 12, 32, 512, 12, 1, 0, 0.0),   # VisualCNN FC as a 12x12 conv
     (9, 1, 1, 1536, 512, 1, 1, 0, 1.0),    # Linear
+    (3, 16, 8, 64, 128, 4, 2, 1, 0.2),     # U-Net encoder stage: the input gradient runs as ONE transposed-conv launch
+    (2, 2, 16, 128, 256, 4, 2, 1, 0.2),    # ... on a two-row image (one output row: half of the window in the padding)
 ])
 def test_conv2d_backward_matches_torch(B, H, W, Ci, Co, k, s, p, slope):
     from m2h import functional as MF
