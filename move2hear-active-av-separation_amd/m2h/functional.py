@@ -238,10 +238,15 @@ class _PackMemo:
         return out
 
 
+_refresh_hooks = weakref.WeakSet()   # objects with a sync() that brings derived weight tensors up to date before the packs (FusedAudioPair)
+
+
 def refresh_pack_memos():
     """Re-packs (in place) every packed operand whose source weights changed since it was packed, with one batched launch per
     48 tensors.  Called before a HIP-graph replay (the graph reads the packed buffers by address and contains no pack kernels)
     and at the top of a captured training step."""
+    for h in list(_refresh_hooks):
+        h.sync()
     items = []
     for m in list(_pack_memos):
         items += m.stale_items()

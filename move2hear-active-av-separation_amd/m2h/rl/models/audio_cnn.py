@@ -85,3 +85,70 @@ class AudioCNN(nn.Module):
             mix = observations["mixed_bin_audio_mag"]
             x = ops.slice_concat_input(mix.contiguous(), mul=pred_binSepMasks.contiguous(), op=1)  # reference :125-128
         return self.encode(x)
+
+
+class FusedAudioPair:
+    """The two audio encoders of the policy (rl/ppo/policy.py:65-66, :87-89: identical stacks over two different inputs) as ONE
+    launch chain for the no-grad rollout step: every layer runs once with the two encoders' channels side by side and a
+    block-diagonal weight (zeros off the diagonal), the first conv reading the two sliced inputs as the two sources of a
+    concatenating conv.  At 14 envs each of the 8 launches (+ 4 split-K reduces) is latency-bound, so half as many launches is
+    what counts; every output channel is its own encoder's sum plus exact zeros.  Not an nn.Module: it owns no parameters, only
+    derived tensors that sync() rebuilds in place when the encoders' weights changed (functional.refresh_pack_memos calls it
+    before a HIP-graph replay, forward() when run kernel by kernel)."""
+
+    def __init__(self, enc_a, enc_b):
+        self.a, self.b = enc_a, enc_b
+        self.w = None       # block-diagonal weights (torch layout) of conv0, conv1, conv2, fc
+        self.bias = None
+        self.key = None
+        self._memo = [MF._PackMemo() for _ in range(4)]
+        MF._refresh_hooks.add(self)
+
+    def _layers(self, enc):
+        h, w = enc._out_dims
+        fc = enc.cnn[7]
+        return [(enc.cnn[0].weight, enc.cnn[0].bias), (enc.cnn[2].weight, enc.cnn[2].bias), (enc.cnn[4].weight, enc.cnn[4].bias),
+                (fc.weight.view(fc.weight.shape[0], 32, h, w), fc.bias)]
+
+    def sync(self):
+        la, lb = self._layers(self.a), self._layers(self.b)
+        key = tuple((t.data_ptr(), t._version) for pair in la + lb for t in pair) + (MF.param_epoch(),)
+        if key == self.key:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("m2h FusedAudioPair: weights changed inside a HIP-graph capture (call functional.refresh_pack_memos() first)")
+        with torch.no_grad():
+            if self.w is None or self.w[0].device != la[0][0].device:
+                self.w, self.bias = [], []
+                for (wa, ba), (wb, bb) in zip(la, lb):
+                    Co, Ci = wa.shape[0], wa.shape[1]
+                    self.w.append(torch.zeros((2 * Co, 2 * Ci) + tuple(wa.shape[2:]), device=wa.device, dtype=torch.float32))
+                    self.bias.append(torch.zeros(2 * Co, device=wa.device, dtype=torch.float32))
+            for W, Bv, (wa, ba), (wb, bb) in zip(self.w, self.bias, la, lb):
+                Co, Ci = wa.shape[0], wa.shape[1]
+                W[:Co, :Ci].copy_(wa)
+                W[Co:, Ci:].copy_(wb)      # the off-diagonal blocks stay exact zeros
+                Bv[:Co].copy_(ba)
+                Bv[Co:].copy_(bb)
+        self.key = key
+
+    def usable(self, xa, xb):
+        return (not torch.is_grad_enabled() and self.a._out_dims == self.b._out_dims and xa.shape == xb.shape
+                and all(p.is_cuda for p in self.a.parameters()))
+
+    def encode(self, xa, xb):
+        """xa, xb: the two encoders' sliced NHWC inputs [B,32,T,32] -> (features of a [B,512], features of b [B,512])."""
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync()
+        elif self.w is None:
+            raise RuntimeError("m2h FusedAudioPair: first use inside a HIP-graph capture")
+        W, Bv, M = self.w, self.bias, self._memo
+        x = ops.conv2d_nhwc(xa, M[0].get(W[0], 64), 64, 8, 8, stride=4, pad=0, bias=Bv[0], slope=0.0, x2=xb, name="audio_pair.conv0")
+        x = ops.conv2d_nhwc(x, M[1].get(W[1], 64), 128, 4, 4, stride=2, pad=0, bias=Bv[1], slope=0.0, name="audio_pair.conv1")
+        x = ops.conv2d_nhwc(x, M[2].get(W[2], 128), 64, 2, 2, stride=1, pad=0, bias=Bv[2], slope=0.0, name="audio_pair.conv2")
+        h, w = self.a._out_dims
+        if x.shape[1] != h or x.shape[2] != w:
+            raise RuntimeError("m2h FusedAudioPair: conv output %s does not match the Linear built for %s" % (tuple(x.shape[1:3]), (h, w)))
+        n = W[3].shape[0]
+        y = ops.conv2d_nhwc(x, M[3].get(W[3], 64), n, h, w, stride=1, pad=0, bias=Bv[3], slope=0.0, name="audio_pair.fc").reshape(x.shape[0], n)
+        return y[:, :n // 2], y[:, n // 2:]

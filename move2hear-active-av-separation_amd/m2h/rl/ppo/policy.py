@@ -14,7 +14,7 @@ from ... import functional as MF
 from ... import ops
 from ...common.utils import CategoricalNet, CustomFixedCategorical
 from ...pretrain.passive.policy import PassiveSepDec, PassiveSepEnc  # identical wrappers (reference :121-156)
-from ..models.audio_cnn import AudioCNN
+from ..models.audio_cnn import AudioCNN, FusedAudioPair
 from ..models.separator_cnn import unet_forward
 from ..models.memory_nets import AcousticMem
 from ..models.rnn_state_encoder import RNNStateEncoder
@@ -66,6 +66,7 @@ class PolicyNet(Net):
         self.monoNmonoFromMem_encoder = AudioCNN(observation_space, hidden_size, encode_monoNmonoFromMem=True)
         rnn_input_size = 3 * self._hidden_size
         self.state_encoder = RNNStateEncoder(rnn_input_size, self._hidden_size)
+        self._audio_pair = FusedAudioPair(self.bin_encoder, self.monoNmonoFromMem_encoder)   # no parameters of its own (rollout fast path)
 
     @property
     def is_blind(self):
@@ -81,6 +82,14 @@ class PolicyNet(Net):
 
     def forward(self, observations, rnn_hidden_states, masks, pred_binSepMasks=None, pred_mono=None, pred_monoFromMem=None):
         from ... import graphs
+        if self._audio_pair.usable(pred_mono, pred_monoFromMem) and pred_mono.shape[0] < 64:
+            # rollout step (no gradients, 14 envs): the two audio encoders as one chain of block-diagonal layers (audio_cnn.FusedAudioPair)
+            xa = ops.slice_concat_input(observations["mixed_bin_audio_mag"].contiguous(), mul=pred_binSepMasks.contiguous(), op=1)
+            xb = ops.slice_concat_input(pred_mono.contiguous(), pred_monoFromMem.contiguous(), op=2)
+            fa, fb = self._audio_pair.encode(xa, xb)
+            x1 = torch.cat((self.visual_encoder(observations), fa, fb), dim=1)
+            x2, rnn_hidden_states_new = self.state_encoder(x1, rnn_hidden_states, masks)
+            return x2, rnn_hidden_states_new
         # The three encoders are independent kernel chains; graphs.run_parallel can put them on three HIP streams for update
         # batches (opt-in, measured slower end to end: see m2h/graphs.py), sequential otherwise.
         x = graphs.run_parallel(pred_mono.device if pred_mono.shape[0] >= 64 else None, [
