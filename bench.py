@@ -108,6 +108,7 @@ def cpu_baseline(sd, tm, seconds):
         if t > 4 * best_t:
             break  # oversubscribed: larger counts only get worse
     torch.set_num_threads(best_n)
+    _CPU_THREADS[0] = best_n
     t0 = time.perf_counter()
     n = 0
     while True:
@@ -121,13 +122,122 @@ def cpu_baseline(sd, tm, seconds):
                       % (n, bs, tm, best_n, ncpu, el)}
 
 
-def ddppo_roofline(env_steps_per_s_per_job, s_per_cycle, far_target):
+_CPU_THREADS = [None]   # thread count the U-Net probe of cpu_baseline() picked on this host; the other CPU legs re-use it
+
+
+def _cpu_threads():
+    n = _CPU_THREADS[0]
+    if n is None:
+        n = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(n)
+    return n
+
+
+def ddppo_cpu_baseline(far_target, seconds):
+    """The reference-CPU figure of the DD-PPO leg, timed in this run on this host: the oracle's restatement of the reference's
+    training loop (oracle/m2h_oracle_trainer.py: collect_rollout_step = ppo_trainer.py:253-478, update_pol / update_sep =
+    ppo.py:82-246; pinned to the reference's own PPOTrainer.train run by tests/golden/trainer_*.npz) over ONE sampled unit of
+    each phase -- 20 rollout steps at 14 envs, one update_pol (4 epochs over the 280 stored samples), one update_sep EPOCH over
+    a full 120-step buffer (1 680 samples) -- scaled by the schedule's counts per cycle (6 rollouts, 6 update_pol, 24 update_sep
+    epochs): env-steps/s = 1 680 / (6 t_rollout + 6 t_update_pol + 24 t_sep_epoch).  The env is the host-side replay env
+    (table lookups: zero-cost dynamics, like the GPU leg's).  What the reference's fps line (ppo_trainer.py:999-1001) would
+    print for this schedule on these cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import m2h_oracle as O
+    import m2h_oracle_trainer as OT
+    from m2h import synthetic
+    from m2h.envs.replay_env import ReplayHostVecEnv
+    from m2h.rl.ppo.ppo_trainer import far_target_config, near_target_config
+    ns = far_target_config() if far_target else near_target_config()
+    cfg = dict(vars(ns))
+    threads = _cpu_threads()
+    N, T, C = cfg["NUM_PROCESSES"], cfg["num_steps"], cfg["num_updates_per_cycle"]
+    sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), 1).items()}
+    for k in sd:
+        if k.startswith(OT.POL_PREFIXES + OT.MEM_PREFIXES):
+            sd[k].requires_grad_(True)
+    opt_pol = torch.optim.Adam(OT._trainable(sd, OT.POL_PREFIXES), lr=cfg["lr_pol"], eps=cfg["eps"])
+    opt_sep = torch.optim.Adam(OT._trainable(sd, OT.MEM_PREFIXES), lr=cfg["lr_sep"], eps=cfg["eps"])
+    env = ReplayHostVecEnv(N, seed=cfg["SEED"], episode_len=cfg["MAX_EPISODE_STEPS"], pool=16, env_rewards=far_target)
+    rk = OT.Rank(env, cfg)
+    torch.manual_seed(0)
+    OT.collect_rollout_step(sd, cfg, rk)          # the rollout's first step warms up (oneDNN primitive caches): not timed
+    t0 = time.perf_counter()
+    n_roll = 0
+    for _ in range(T - 1):
+        OT.collect_rollout_step(sd, cfg, rk)
+        n_roll += 1
+        if time.perf_counter() - t0 > seconds and n_roll >= 5:
+            break                                    # slow host: fewer steps, same per-step figure
+    t_step = (time.perf_counter() - t0) / n_roll
+    while rk.ro.step != 0:                           # (a short sample leaves the storage part-filled: finish the rollout untimed)
+        OT.collect_rollout_step(sd, cfg, rk)
+    t0 = time.perf_counter()
+    with torch.no_grad():                            # _update_pol (ppo_trainer.py:480-520)
+        ro = rk.ro
+        last = {kk: v[-1] for kk, v in ro.observations.items()}
+        feats, _, _ = O.policy_net(sd, last, ro.recurrent_hidden_states_pol[-1], ro.masks[-1], ro.pred_binSepMasks[-1], ro.pred_mono[-1],
+                                   ro.prev_pred_monoFromMem[-1])
+        ro.compute_returns(O.heads(sd, feats)[0], cfg["use_gae"], cfg["gamma"], cfg["tau"])
+    OT.update_pol(sd, opt_pol, [rk], cfg, cfg["clip_param"], True)
+    rk.ro.after_update()
+    t_pol = time.perf_counter() - t0
+    # the separator storage holds T of its C*T steps after one rollout: tile them over the whole buffer (timing only)
+    rs = rk.rs
+    for name in ("prev_pred_monoFromMem", "masks"):
+        buf = getattr(rs, name)
+        for c in range(1, C):
+            buf[c * T + 1:(c + 1) * T + 1].copy_(buf[1:T + 1])
+    for buf in rs.observations.values():
+        for c in range(1, C):
+            buf[c * T + 1:(c + 1) * T + 1].copy_(buf[1:T + 1])
+    one_epoch = dict(cfg, ppo_epoch=1)
+    t0 = time.perf_counter()
+    OT.update_sep(sd, opt_sep, [rk], one_epoch)
+    t_sep = time.perf_counter() - t0
+    cycle = C * T * t_step + C * t_pol + C * cfg["ppo_epoch"] * t_sep
+    return {"value": round(C * T * N / cycle, 2), "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "s_per_cycle": round(cycle, 2), "rollout_step_s": round(t_step, 4), "update_pol_s": round(t_pol, 3), "update_sep_epoch_s": round(t_sep, 3),
+            "sample": "oracle/m2h_oracle_trainer.py (PyTorch-CPU fp32 restatement of the reference's PPOTrainer loop, %d of %d host threads): "
+                      "%d rollout steps at %d envs, one update_pol (%d epochs x %d samples), one update_sep epoch (%d samples), "
+                      "scaled to the schedule's %d / %d / %d per cycle; %.1f s of CPU work"
+                      % (threads, os.cpu_count() or 1, n_roll, N, cfg["ppo_epoch"], T * N, C * T * N, C * T, C, C * cfg["ppo_epoch"],
+                         n_roll * t_step + t_pol + t_sep)}
+
+
+def passive_train_cpu_baseline(tm, seconds, batch=8):
+    """The oracle's passive training step (oracle.passive_train_step = passive_trainer.py:218-286 incl. D11: train-mode BatchNorm,
+    both L1 losses, backward, Adam) at BASELINE config 1's batch of 8 on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import m2h_oracle as O
+    from m2h import synthetic
+    threads = _cpu_threads()
+    sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in synthetic.make_state_dict(synthetic.passive_shapes(), 1).items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    buffers = {k: v for k, v in sd.items() if "running_" in k}
+    mixed, tc = synthetic.make_passive_inputs(batch, tm, 5)
+    gen = torch.Generator().manual_seed(7)
+    b = {"mixed_bin_audio_mag": torch.from_numpy(mixed), "target_class": torch.from_numpy(tc),
+         "gt_bin_mag": torch.rand(batch, 512, tm, 2, generator=gen) * 2, "gt_mono_mag": torch.rand(batch, 512, tm, 1, generator=gen) * 2}
+    _b, _m, opt = O.passive_train_step(params, buffers, b)   # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        _b, _m, opt = O.passive_train_step(params, buffers, b, opt_state=opt)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 100:
+            break
+    return {"value": round(batch * n / el, 2), "unit": "spectrograms/s", "cores": threads, "kind": "port",
+            "sample": "%d training steps of batch %d (512x%d) through oracle.passive_train_step (PyTorch-CPU fp32, %d of %d host threads), %.1f s"
+                      % (n, batch, tm, threads, os.cpu_count() or 1, el)}
+
+
+def ddppo_roofline(env_steps_per_s_per_job, s_per_cycle, far_target, phase_ms_per_cycle=None):
     """Achieved-fraction object of the DD-PPO leg (BASELINE config 3 / 5).  FLOP figures per env-step: algorithmic = SURVEY 8d's
     reference schedule (13.8 GFLOP: 24 + 2 U-Net pair passes per env-step dominate); executed = what this build runs after the two
     result-preserving re-uses of DESIGN section 5 (separator outputs cached per stored observation: one pair pass per env-step in the
-    rollout + one per stored sample per update_sep cycle, AcousticMem fwd+bwd x 24, policy fwd + 4 x fwd/bwd).  Kernel time and
-    launch counts cannot be read from inside the process: they come from the committed rocprofv3 --kernel-trace --stats summary of
-    this leg (profiles/rNN_ddppo_summary.json, tools/profile_round3.sh) when present."""
+    rollout + one per stored sample per update_sep cycle, AcousticMem fwd+bwd x 24, policy fwd + 4 x fwd/bwd)."""
     algorithmic = 13.8
     # rollout: ONE pair pass + one memory pass per env-step (the next observation's outputs serve the following step) + policy forward;
     # update_pol: 4 epochs x (forward + backward ~ 3x forward); update_sep: one pair pass per stored sample per cycle (cached) +
@@ -139,20 +249,30 @@ def ddppo_roofline(env_steps_per_s_per_job, s_per_cycle, far_target):
            "achieved": round(executed * env_steps_per_s_per_job / 1e3, 2), "peak": PEAK_F32_MFMA_TFLOPS,
            "frac": round(executed * env_steps_per_s_per_job / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
            "note": "per job (all ranks); peak = one GPU's fp32 MFMA peak x n_gpus is the fair ceiling at N > 1"}
-    for r in (3, 2):
+    # phase_time_share: the three phases' HIP-event time on the compute stream over this run's own wall time per cycle (both measured
+    # here; what is missing from 1 is host time with an idle device).  Launch counts and summed kernel time cannot be read from inside
+    # the process: the committed rocprofv3 --kernel-trace --stats summary of this same leg is quoted as its own object, with the
+    # share computed against THAT run's cycle time.
+    if phase_ms_per_cycle is not None:
+        out["phase_ms_per_cycle"] = round(phase_ms_per_cycle, 3)
+        out["phase_time_share"] = round(min(1.0, phase_ms_per_cycle / (1e3 * s_per_cycle)), 3)
+    for r in (4, 3):
         path = os.path.join(ROOT, "profiles", "r%02d_ddppo_summary.json" % r)
         if os.path.exists(path):
             with open(path) as f:
                 sj = json.load(f).get("far_target" if far_target else "near_target")
             if sj:
-                out.update(launches_per_cycle=sj.get("launches_per_cycle"), kernel_ms_per_cycle=sj.get("kernel_ms_per_cycle"),
-                           kernel_time_share=(round(sj["kernel_ms_per_cycle"] / (1e3 * s_per_cycle), 3) if sj.get("kernel_ms_per_cycle") else None),
-                           profile_source=sj.get("source"))
+                prof = {"launches_per_cycle": sj.get("launches_per_cycle"), "kernel_ms_per_cycle": sj.get("kernel_ms_per_cycle"),
+                        "s_per_cycle": sj.get("s_per_cycle"), "source": sj.get("source")}
+                if sj.get("kernel_ms_per_cycle") and sj.get("s_per_cycle"):
+                    prof["kernel_time_share"] = round(min(1.0, sj["kernel_ms_per_cycle"] / (1e3 * sj["s_per_cycle"])), 3)
+                out["profile"] = prof
+                out["launches_per_cycle"] = sj.get("launches_per_cycle")
             break
     return out
 
 
-def run_ddppo(args, dev, rank, world, dist, far_target=False):
+def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
     """Second figure of BASELINE.json's metric: DD-PPO env-steps/s on the reference schedule (nearTarget.yaml: 14 envs/rank,
     T=20, 6 policy updates + 6 separator updates per cycle, 4 epochs, 1 minibatch) with the synthetic on-device env.
     Whole-job rate = all ranks' env steps / max-over-ranks time; gradients are all-reduced over RCCL when world > 1.
@@ -260,8 +380,12 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False):
                                      "update_sep passes and by the next rollout step (result-preserving; SURVEY D13)",
            "last_pol_losses": [round(x, 5) for x in last["pol_losses"]], "last_sep_losses": [round(x, 5) for x in last["sep_losses"]],
            "phases": breakdown, "devices": idents, "distinct_devices": len({(d["uuid"], d["pci_bus_id"]) for d in idents}),
-           "roofline": ddppo_roofline(world * steps / el, el / args.ddppo_cycles, far_target),
-           "reference_cpu_env_steps_per_sec_survey_probe": 4.3}
+           "roofline": ddppo_roofline(world * steps / el, el / args.ddppo_cycles, far_target,
+                                      sum(phases.values()) / args.ddppo_cycles if phases else None)}
+    del tr
+    if with_cpu:   # rank 0 at N = 1 only: the oracle's loop on this host's cores, in this same run (bounded sample)
+        out["cpu_baseline"] = ddppo_cpu_baseline(far_target, args.cpu_seconds)
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     if far_target:
         out["math"] = "bf16x3 products (fp32 tensors and accumulation) in every forward / input-gradient GEMM; weight gradients, reductions, Adam in fp32"
         out["mixed_precision_parity"] = mixed
@@ -309,7 +433,7 @@ def run_feeder(args, dev, rank, with_cpu):
     return res
 
 
-def run_passive_train(args, dev, rank):
+def run_passive_train(args, dev, rank, with_cpu=False):
     """Secondary figure of SURVEY 8d config 2: the passive pre-training step (train-mode BN forward, U-Net backward, Adam) on
     the reference's batch (pretrain_passive.yaml: 64 clips of 512x32) with the synthetic feeder; replicas only across GPUs
     (train-mode BN), so every rank runs the same-size job and the rate is per replica."""
@@ -332,12 +456,23 @@ def run_passive_train(args, dev, rank):
     finally:
         ops.set_math_mode(ops.MATH_FP32)
     gf = (0.4226 if args.train_tm == 32 else 0.4226 * args.train_tm / 32) * 3.0   # training step ~ 3x the forward
-    return {"metric": "passive_train_spectrograms_per_sec", "value": round(args.train_batch * args.train_steps / el, 1),
-            "unit": "spectrograms/s", "ms_per_step": round(1e3 * el / args.train_steps, 3), "batch": args.train_batch,
-            "time_frames": args.train_tm, "steps": args.train_steps, "math": args.train_math,
-            "algorithmic_tflops": round(gf * args.train_batch * args.train_steps / el / 1e3, 2),
-            "last_losses": [round(float(x), 5) for x in losses],
-            "what": "PassiveTrainer.train_batch: both U-Nets forward in train-mode BN, L1 losses, full backward, FlatAdam step"}
+    ach = gf * args.train_batch * args.train_steps / el / 1e3
+    peak = PEAK_F32_MFMA_TFLOPS if args.train_math == "fp32" else 2500.0 / 3.0
+    out = {"metric": "passive_train_spectrograms_per_sec", "value": round(args.train_batch * args.train_steps / el, 1),
+           "unit": "spectrograms/s", "ms_per_step": round(1e3 * el / args.train_steps, 3), "batch": args.train_batch,
+           "time_frames": args.train_tm, "steps": args.train_steps, "math": args.train_math,
+           "algorithmic_tflops": round(ach, 2),
+           "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "algorithmic_gflop_per_step": round(gf * args.train_batch, 2),
+                        "what": "algorithmic FLOP of the step (SURVEY 8d: 3 x the pair forward, 1.27 GFLOP per 512x32 clip) over the whole step's wall "
+                                "time (forward, BatchNorm statistics, backward, Adam), against the dense MFMA peak of the step's GEMM arithmetic"},
+           "last_losses": [round(float(x), 5) for x in losses],
+           "what": "PassiveTrainer.train_batch: both U-Nets forward in train-mode BN, L1 losses, full backward, FlatAdam step"}
+    del tr
+    if with_cpu:
+        out["cpu_baseline"] = passive_train_cpu_baseline(args.train_tm, min(args.cpu_seconds, 8.0))
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    return out
 
 
 def spawn_ranks(n):
@@ -614,19 +749,18 @@ def main():
         del m_a, m_b, mono_a, mono_b, em
     ops.set_math_mode(ops.MATH_FP32)
 
-    ddppo = run_ddppo(args, dev, rank, world, dist) if args.ddppo_cycles > 0 else None
+    # the host-core baselines are single-GPU-run figures (rank 0, N = 1); the pair's comes first: its probe picks the thread count
+    with_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    cpu = cpu_baseline(sd, args.tm, args.cpu_seconds) if with_cpu else None
+    ddppo = run_ddppo(args, dev, rank, world, dist, with_cpu=with_cpu) if args.ddppo_cycles > 0 else None
     ddppo_far = run_ddppo(args, dev, rank, world, dist, far_target=True) if (args.ddppo_cycles > 0 and not args.no_far_target) else None
-    ptrain = run_passive_train(args, dev, rank) if args.train_steps > 0 else None
-    feeder = run_feeder(args, dev, rank, with_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline)) if args.feeder_steps > 0 else None
+    ptrain = run_passive_train(args, dev, rank, with_cpu=with_cpu) if args.train_steps > 0 else None
+    feeder = run_feeder(args, dev, rank, with_cpu=with_cpu) if args.feeder_steps > 0 else None
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-
-    cpu = None
-    if not args.no_cpu_baseline and world == 1:   # the host-core baseline is a single-GPU-run figure (rank 0, N = 1)
-        cpu = cpu_baseline(sd, args.tm, args.cpu_seconds)
 
     value = world * args.batch * args.steps / elapsed
     line = {

@@ -157,6 +157,11 @@ class _PackMemo:
         self.src = None                 # (Parameter, view shape or None): how to find the weight again at refresh time
         _pack_memos.add(self)
 
+    def __deepcopy__(self, memo):
+        """A copied module gets an empty memo of its own, registered like any other (copy.deepcopy would clone the packed buffers
+        and skip __init__, so refresh_pack_memos would never see the copy and a replayed graph would read stale packs)."""
+        return _PackMemo()
+
     # compatibility with callers that look at the forward pack directly
     @property
     def key(self):
@@ -241,12 +246,16 @@ class _PackMemo:
 _refresh_hooks = weakref.WeakSet()   # objects with a sync() that brings derived weight tensors up to date before the packs (FusedAudioPair)
 
 
-def refresh_pack_memos():
+def refresh_pack_memos(hooks=True):
     """Re-packs (in place) every packed operand whose source weights changed since it was packed, with one batched launch per
     48 tensors.  Called before a HIP-graph replay (the graph reads the packed buffers by address and contains no pack kernels)
-    and at the top of a captured training step."""
-    for h in list(_refresh_hooks):
-        h.sync()
+    and at the top of a captured training step.
+    hooks: also bring derived weight tensors (FusedAudioPair's block-diagonal copies) up to date first.  Skipped inside a
+    HIP-graph capture (a capture of some OTHER model must not trip over them: they are rebuilt outside captures, and their user
+    checks freshness itself) and by callers whose graph does not read them (the update_pol epoch)."""
+    if hooks and not torch.cuda.is_current_stream_capturing():
+        for h in list(_refresh_hooks):
+            h.sync()
     items = []
     for m in list(_pack_memos):
         items += m.stale_items()

@@ -104,19 +104,28 @@ class FusedAudioPair:
         self._memo = [MF._PackMemo() for _ in range(4)]
         MF._refresh_hooks.add(self)
 
+    def __deepcopy__(self, memo):
+        import copy
+        return FusedAudioPair(copy.deepcopy(self.a, memo), copy.deepcopy(self.b, memo))  # registered, rebuilt on first use
+
     def _layers(self, enc):
         h, w = enc._out_dims
         fc = enc.cnn[7]
         return [(enc.cnn[0].weight, enc.cnn[0].bias), (enc.cnn[2].weight, enc.cnn[2].bias), (enc.cnn[4].weight, enc.cnn[4].bias),
                 (fc.weight.view(fc.weight.shape[0], 32, h, w), fc.bias)]
 
+    def _key(self, la, lb):
+        return tuple((t.data_ptr(), t._version) for pair in la + lb for t in pair) + (MF.param_epoch(),)
+
     def sync(self):
+        """Rebuild the block-diagonal tensors if the encoders' weights changed.  Never raises: inside a HIP-graph capture, or with
+        the encoders on the host, it leaves them as they are -- encode() is what refuses to run on stale ones."""
         la, lb = self._layers(self.a), self._layers(self.b)
-        key = tuple((t.data_ptr(), t._version) for pair in la + lb for t in pair) + (MF.param_epoch(),)
+        if not la[0][0].is_cuda or torch.cuda.is_current_stream_capturing():
+            return
+        key = self._key(la, lb)
         if key == self.key:
             return
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("m2h FusedAudioPair: weights changed inside a HIP-graph capture (call functional.refresh_pack_memos() first)")
         with torch.no_grad():
             if self.w is None or self.w[0].device != la[0][0].device:
                 self.w, self.bias = [], []
@@ -140,8 +149,9 @@ class FusedAudioPair:
         """xa, xb: the two encoders' sliced NHWC inputs [B,32,T,32] -> (features of a [B,512], features of b [B,512])."""
         if not torch.cuda.is_current_stream_capturing():
             self.sync()
-        elif self.w is None:
-            raise RuntimeError("m2h FusedAudioPair: first use inside a HIP-graph capture")
+        elif self.w is None or self.key != self._key(self._layers(self.a), self._layers(self.b)):
+            raise RuntimeError("m2h FusedAudioPair: used inside a HIP-graph capture with stale block-diagonal weights "
+                               "(call functional.refresh_pack_memos() before the capture)")
         W, Bv, M = self.w, self.bias, self._memo
         x = ops.conv2d_nhwc(xa, M[0].get(W[0], 64), 64, 8, 8, stride=4, pad=0, bias=Bv[0], slope=0.0, x2=xb, name="audio_pair.conv0")
         x = ops.conv2d_nhwc(x, M[1].get(W[1], 64), 128, 4, 4, stride=2, pad=0, bias=Bv[1], slope=0.0, name="audio_pair.conv1")

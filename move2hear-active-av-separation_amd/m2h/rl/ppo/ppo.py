@@ -169,7 +169,7 @@ class PPO(nn.Module):
         num_envs = rollouts_pol.rewards.size(1)
         for _e in range(self.ppo_epoch):
             self._reducers["pol"].fence()   # the graph holds no fence: order it after a pending optimizer step here
-            MF.refresh_pack_memos()         # conv weights re-packed in place after the previous step
+            MF.refresh_pack_memos(hooks=False)  # conv weights re-packed in place after the previous step (the rollout's fused audio pair is rebuilt lazily, by its next user)
             if gs.graph is None:
                 cpu_rng = torch.get_rng_state()  # capture executes the python once without running kernels: no RNG side effect
                 g = torch.cuda.CUDAGraph()
