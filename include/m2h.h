@@ -260,6 +260,13 @@ int m2h_pack_conv_weight_ex(const float* w, float* wp, int Co, int Ci, int KH, i
 int m2h_slice_concat_input(const float* a, int Ca, const float* b, int Cb, const float* mul, const float* bscale, int op,
                            float* out, int B, int F, int T, m2h_stream stream);
 
+/* AcousticMem forward (memory_nets.py:40-69, the DD-PPO variant without BatchNorm) for small batches in ONE launch: both inputs
+ * sliced 16-way and concatenated, the previous memory scaled by not_done[b] (ppo_trainer.py:310-314; NULL = 1), Conv2d(32, 32, 3, 1, 1)
+ * + ReLU, Conv2d(32, 16, 3, 1, 1), de-slice.  pred_mono, prev_mem, out: BHWC [B][512][32][1]; w0p [32][9*32], w1p [16][9*32]: the
+ * two conv weights packed by m2h_pack_conv_weight.  fp32 MFMA; the rollout step's call (14 environments). */
+int m2h_acoustic_mem_small_fwd(const float* pred_mono, const float* prev_mem, const float* not_done, const float* w0p, const float* w1p,
+                               float* out, int B, int F, int T, m2h_stream stream);
+
 /* VisualCNN input (visual_cnn.py:135-150): rgb [B][H][W][3] in 0..255 -> out [B][H][W][4] = (rgb/255, depth or 0). */
 int m2h_visual_input(const float* rgb, const float* depth, float* out, int B, int H, int W, m2h_stream stream);
 
@@ -283,6 +290,12 @@ int m2h_policy_heads(const float* feats, const float* Wa, const float* ba, const
                      const long long* actions, float* value, float* logp_all, float* probs, float* entropy, float* logp_act,
                      int M, int H, int A, m2h_stream stream);
 int m2h_gather_logp(const float* logp_all, const long long* actions, float* out, int M, int A, m2h_stream stream);
+/* Policy.act's tail in ONE launch (rl/ppo/policy.py:217-225): m2h_policy_heads, then the action -- noise != NULL: the single draw of
+ * torch.multinomial(probs, 1, True) == argmax(probs / noise) with caller-supplied Exp(1) noise [M][A] (as m2h_sample_actions);
+ * noise == NULL: CustomFixedCategorical.mode() == argmax(probs) -- and logp_act[row] = logp_all[row][action]. */
+int m2h_policy_heads_act(const float* feats, const float* Wa, const float* ba, const float* Wc, const float* bc, const float* noise,
+                         float* value, float* logp_all, float* probs, float* entropy, long long* actions, float* logp_act, int M, int H,
+                         int A, m2h_stream stream);
 
 /* CustomFixedCategorical.sample (common/utils.py:16-24) with the noise supplied by the caller: the single-draw path of
  * torch.multinomial(probs, 1, True) is argmax(probs / q), q ~ Exp(1) drawn from the tensor's generator -- on the reference's

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restri
                                                            const float* __restrict__ bc, const long long* __restrict__ actions,
                                                            float* __restrict__ value, float* __restrict__ logp_all,
                                                            float* __restrict__ probs, float* __restrict__ entropy,
-                                                           float* __restrict__ logp_act, int M, int H, int A) {
+                                                           float* __restrict__ logp_act, int M, int H, int A,
+                                                           const float* __restrict__ noise = nullptr, long long* __restrict__ act_out = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -222,6 +223,20 @@ __global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restri
     value[row] = acc[8] + bc[0];
     entropy[row] = ent;
     if (actions != nullptr && logp_act != nullptr) logp_act[row] = logp_all[row * A + (int)actions[row]];
+    if (act_out != nullptr) {
+      // Policy.act in the same launch (rl/ppo/policy.py:217-225): the action -- with noise the single draw of torch.multinomial,
+      // argmax(probs / Exp(1) noise), exactly as sample_actions_kernel takes it (correctly rounded division, NaN is the maximum,
+      // ties keep the lowest index); without noise the mode, argmax(probs) -- and its log-probability
+      int arg = 0;
+      float best = noise != nullptr ? expf(acc[0] - lse) / noise[row * A] : expf(acc[0] - lse);
+      for (int a = 1; a < A; ++a) {
+        const float p = expf(acc[a] - lse);
+        const float q = noise != nullptr ? p / noise[row * A + a] : p;
+        if (!(best != best) && (q > best || q != q)) { best = q; arg = a; }
+      }
+      act_out[row] = arg;
+      if (logp_act != nullptr) logp_act[row] = acc[arg] - lse;
+    }
   }
 }
 
@@ -854,6 +869,16 @@ int m2h_policy_heads(const float* feats, const float* Wa, const float* ba, const
   hipLaunchKernelGGL(policy_heads_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), feats, Wa, ba, Wc, bc, actions, value,
                      logp_all, probs, entropy, logp_act, M, H, A);
   return launch_status("policy_heads");
+}
+
+int m2h_policy_heads_act(const float* feats, const float* Wa, const float* ba, const float* Wc, const float* bc, const float* noise,
+                         float* value, float* logp_all, float* probs, float* entropy, long long* actions, float* logp_act, int M, int H,
+                         int A, m2h_stream stream) {
+  M2H_REQUIRE(feats && Wa && ba && Wc && bc && value && logp_all && probs && entropy && actions && logp_act, "policy_heads_act: null pointer");
+  M2H_REQUIRE(M > 0 && H > 0 && H % 64 == 0 && A > 0 && A <= 8, "policy_heads_act: bad sizes (H %% 64, A <= 8)");
+  hipLaunchKernelGGL(policy_heads_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), feats, Wa, ba, Wc, bc,
+                     static_cast<const long long*>(nullptr), value, logp_all, probs, entropy, logp_act, M, H, A, noise, actions);
+  return launch_status("policy_heads_act");
 }
 
 int m2h_sample_actions(const float* probs, const float* noise, long long* actions, int M, int A, m2h_stream stream) {

@@ -16,7 +16,7 @@ CSRC = os.path.join(_PKG_ROOT, "csrc")
 INCLUDE = os.path.join(_REPO_ROOT, "include")
 # M2H_LIB: kernel-tuning override -- load an experimental build of the same C-ABI (tools/build_variant.sh) instead of the in-tree one
 LIB_PATH = os.environ.get("M2H_LIB") or os.path.join(_HERE, "libm2h.so")
-SOURCES = ["conv_igemm.hip", "conv_dma.hip", "conv_patch.hip", "convt_quad.hip", "conv_strip.hip", "conv_small.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "rollout_fused.hip", "pack_batch.hip", "fftconv.hip", "api.hip"]
+SOURCES = ["conv_igemm.hip", "conv_dma.hip", "conv_patch.hip", "convt_quad.hip", "conv_strip.hip", "conv_small.hip", "acoustic_mem.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "rollout_fused.hip", "pack_batch.hip", "fftconv.hip", "api.hip"]
 
 _lock = threading.Lock()
 _lib = None
@@ -195,6 +195,7 @@ SIGNATURES = {
     "m2h_gru_gates": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_policy_heads": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "m2h_gather_logp": [_P, _P, _P, _I, _I, _P],
+    "m2h_policy_heads_act": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "m2h_sample_actions": [_P, _P, _P, _I, _I, _P],
     "m2h_gae_returns": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P],
     "m2h_advantages": [_P, _P, _P, _P, _I, _I, _F, _P],
@@ -255,6 +256,7 @@ SIGNATURES = {
     "m2h_synth_env_observe": [_P, _I, _P, _P, _P, _I, _P],
     "m2h_stft_l2": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
     "m2h_conv_small_fwd": [ctypes.POINTER(SmallConvArgs), _P],
+    "m2h_acoustic_mem_small_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "m2h_unet_small_tiling": [_I, _I, _I, _I, _I, _I],
 }
 

@@ -126,28 +126,69 @@ class RolloutStorageSep:
         self.step = 0
         self.generation = 0  # bumped whenever stored observations change (keys PPO's separator-output cache)
         self.row0_only_since = None  # generation before the last bump that changed nothing but row 0 (after_update)
+        # Optional: the frozen, eval-mode separators' outputs for every stored observation, written by the trainer's rollout step
+        # (which computes them anyway, for the reward and for the next step) so that update_sep need not run the U-Nets over the
+        # buffer again (the reference re-runs them 24 x per cycle under no_grad: ppo.py:184-195).  Rows are valid once
+        # written since enable / invalidate; PPO.update_sep falls back to computing them when any needed row is not.
+        self.pred_binSepMasks = None
+        self.pred_mono = None
+        self._pred_rows_valid = None
 
     def to(self, device):
         for sensor in self.observations:
             self.observations[sensor] = self.observations[sensor].to(device)
         self.prev_pred_monoFromMem = self.prev_pred_monoFromMem.to(device)
         self.masks = self.masks.to(device)
+        if self.pred_mono is not None:
+            self.pred_binSepMasks, self.pred_mono = self.pred_binSepMasks.to(device), self.pred_mono.to(device)
         self.generation += 1
 
-    def _rows(self, observations, masks, pred_monoFromMem=None):
-        return [(self.observations[sensor], observations[sensor]) for sensor in observations] + \
+    def enable_separator_outputs(self):
+        """Allocate the per-row separator outputs (see __init__); every row starts invalid."""
+        ref = self.prev_pred_monoFromMem
+        self.pred_binSepMasks = torch.zeros(tuple(ref.shape[:-1]) + (2,), device=ref.device)
+        self.pred_mono = torch.zeros_like(ref)
+        self._pred_rows_valid = [False] * (self.num_steps + 1)
+
+    def invalidate_separator_outputs(self):
+        """The separators' weights changed (checkpoint load): stored outputs no longer belong to them."""
+        if self._pred_rows_valid is not None:
+            self._pred_rows_valid = [False] * (self.num_steps + 1)
+
+    def store_separator_outputs(self, row, pred_binSepMasks, pred_mono):
+        """Outputs of the observation stored in `row`, computed outside an insert (the first step after a reset of the chain)."""
+        if self.pred_mono is not None:
+            self.pred_binSepMasks[row].copy_(pred_binSepMasks)
+            self.pred_mono[row].copy_(pred_mono)
+            self._pred_rows_valid[row] = True
+
+    def stored_separator_outputs(self):
+        """(pred_binSepMasks, pred_mono) of rows 0 .. T-1 -- what update_sep's batch is made of -- or None when any is missing."""
+        if self._pred_rows_valid is None or not all(self._pred_rows_valid[:-1]):
+            return None
+        return self.pred_binSepMasks[:-1], self.pred_mono[:-1]
+
+    def _rows(self, observations, masks, pred_monoFromMem=None, pred_binSepMasks=None, pred_mono=None):
+        rows = [(self.observations[sensor], observations[sensor]) for sensor in observations] + \
             [(self.prev_pred_monoFromMem, pred_monoFromMem), (self.masks, masks)]
+        if self.pred_mono is not None and pred_mono is not None:   # separator outputs OF THE INSERTED observation
+            rows += [(self.pred_binSepMasks, pred_binSepMasks), (self.pred_mono, pred_mono)]
+        return rows
 
-    def insert(self, observations, masks, pred_monoFromMem=None):
-        for dst, v in self._rows(observations, masks, pred_monoFromMem):
+    def insert(self, observations, masks, pred_monoFromMem=None, pred_binSepMasks=None, pred_mono=None):
+        for dst, v in self._rows(observations, masks, pred_monoFromMem, pred_binSepMasks, pred_mono):
             dst[self.step + 1].copy_(v)
-        self.advance()
+        self.advance(with_preds=pred_mono is not None)
 
-    def insert_items(self, slot, observations, masks, pred_monoFromMem=None):
+    def insert_items(self, slot, observations, masks, pred_monoFromMem=None, pred_binSepMasks=None, pred_mono=None):
         """See RolloutStoragePol.insert_items; slot = position of `step + 1` in the index tensor."""
-        return [(v.contiguous().view(dst.shape[1:]), dst, -1, slot) for dst, v in self._rows(observations, masks, pred_monoFromMem)]
+        return [(v.contiguous().view(dst.shape[1:]), dst, -1, slot)
+                for dst, v in self._rows(observations, masks, pred_monoFromMem, pred_binSepMasks, pred_mono)]
 
-    def advance(self):
+    def advance(self, with_preds=False):
+        """with_preds: the insert this advance belongs to carried the inserted observation's separator outputs."""
+        if self._pred_rows_valid is not None:
+            self._pred_rows_valid[self.step + 1] = bool(with_preds)
         self.generation += 1
         self.step = (self.step + 1) % self.num_steps
 
@@ -160,6 +201,10 @@ class RolloutStorageSep:
             self.observations[sensor][0].copy_(self.observations[sensor][-1])
         self.prev_pred_monoFromMem[0].copy_(self.prev_pred_monoFromMem[-1])
         self.masks[0].copy_(self.masks[-1])
+        if self.pred_mono is not None:
+            self.pred_binSepMasks[0].copy_(self.pred_binSepMasks[-1])
+            self.pred_mono[0].copy_(self.pred_mono[-1])
+            self._pred_rows_valid[0] = self._pred_rows_valid[-1]
         if changed:
             # only row 0 of the stored observations changed: a cache built for generation g - 1 needs row 0 refreshed, not rebuilt
             self.row0_only_since = self.generation

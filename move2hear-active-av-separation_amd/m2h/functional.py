@@ -504,7 +504,24 @@ class L1Loss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
+        u = _unit_grads.get(g.device)
+        if u is not None and g.data_ptr() == u.data_ptr():
+            return grad, None, None     # d(loss)/d(loss) = the library's own 1.0 (unit_grad): the product is the factor itself, bit for bit
         return grad * g, None, None
+
+
+_unit_grads = {}
+
+
+def unit_grad(device):
+    """A cached scalar 1.0 on `device` to pass as the root gradient (``loss.backward(unit_grad(dev))``): L1Loss.backward recognises
+    it by address and hands its saved gradient on without the elementwise multiply by one (a 110 MB read-modify-write per
+    update_sep epoch); any other root gradient takes the general path."""
+    device = torch.device(device)
+    t = _unit_grads.get(device)
+    if t is None:
+        t = _unit_grads[device] = torch.ones((), device=device)
+    return t
 
 
 def l1_loss(pred, gt_comps, off=0):

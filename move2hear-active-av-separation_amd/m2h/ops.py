@@ -496,6 +496,29 @@ def policy_heads(feats, Wa, ba, Wc, bc, actions=None):
     return value, logp_all, probs, ent, logp_act
 
 
+def policy_heads_act(feats, Wa, ba, Wc, bc, noise=None):
+    """Heads + action + its log-probability in one launch (m2h_policy_heads_act): noise [M,A] Exp(1) -> the multinomial draw
+    argmax(probs / noise); None -> the mode.  -> value [M,1], logp_all [M,A], probs [M,A], entropy [M], action [M,1] int64, logp_act [M,1]."""
+    for t in (feats, Wa, ba, Wc, bc, noise):
+        _chk(t, "policy_heads_act")
+    M, H = feats.shape
+    A = Wa.shape[0]
+    dev = feats.device
+    if noise is not None and tuple(noise.shape) != (M, A):
+        raise RuntimeError("m2h.policy_heads_act: noise must be [%d, %d]" % (M, A))
+    value = torch.empty((M, 1), device=dev)
+    logp_all = torch.empty((M, A), device=dev)
+    probs = torch.empty((M, A), device=dev)
+    ent = torch.empty((M,), device=dev)
+    action = torch.empty((M, 1), device=dev, dtype=torch.int64)
+    logp_act = torch.empty((M, 1), device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().m2h_policy_heads_act(_ptr(feats), _ptr(Wa), _ptr(ba), _ptr(Wc), _ptr(bc), _ptr(noise), _ptr(value),
+                                                    _ptr(logp_all), _ptr(probs), _ptr(ent), _ptr(action), _ptr(logp_act), M, H, A,
+                                                    _stream(feats)), "m2h_policy_heads_act")
+    return value, logp_all, probs, ent, action, logp_act
+
+
 def gather_logp(logp_all, actions):
     _chk(logp_all, "gather_logp")
     _chk(actions, "gather_logp(actions)", torch.int64)
@@ -958,3 +981,20 @@ def unet_small_tiling(stage, tiling=None):
     """Tuning hook (thread-local): the small-batch runner's tiling of stage 0-9, None = the built-in one (m2h_unet_small_tiling)."""
     t = tuple(tiling) if tiling is not None else (0, 0, 0, 0, 0)
     _lib.check(_lib.load().m2h_unet_small_tiling(int(stage), *[int(v) for v in t]), "m2h_unet_small_tiling")
+
+
+def acoustic_mem_small(pred_mono, prev_mem, not_done, w0p, w1p):
+    """AcousticMem's forward for a small batch in one launch (m2h_acoustic_mem_small_fwd): BHWC [B,512,32,1] x 2 (+ not-done flags [B])
+    -> [B,512,32,1]; w0p / w1p: the packed conv weights [32, 288] / [16, 288]."""
+    for t in (pred_mono, prev_mem, not_done, w0p, w1p):
+        _chk(t, "acoustic_mem_small")
+    B, F, T, C = pred_mono.shape
+    if C != 1 or prev_mem.shape != pred_mono.shape or w0p.numel() != 32 * 288 or w1p.numel() != 16 * 288:
+        raise RuntimeError("m2h.acoustic_mem_small: expected [B,512,32,1] inputs and [32,288] / [16,288] packed weights")
+    if not_done is not None and not_done.numel() != B:
+        raise RuntimeError("m2h.acoustic_mem_small: one not-done flag per batch row")
+    out = torch.empty_like(pred_mono)
+    with torch.cuda.device(pred_mono.device):
+        _lib.check(_lib.load().m2h_acoustic_mem_small_fwd(_ptr(pred_mono), _ptr(prev_mem), _ptr(not_done), _ptr(w0p), _ptr(w1p), _ptr(out),
+                                                          B, F, T, _stream(pred_mono)), "m2h_acoustic_mem_small_fwd")
+    return out

@@ -47,12 +47,27 @@ class AcousticMem(nn.Module):
                     layer.weight.data.fill_(1)
                     layer.bias.data.zero_()
 
-    def forward_masked(self, pred_mono, prev_pred_monoFromMem, masks=None):
+    SMALL_BATCH = 64   # up to here the no-grad forward is the one-launch kernel (above it the image-row kernels of the update batch)
+
+    def slice_inputs(self, pred_mono, prev_pred_monoFromMem, masks=None):
+        """The convs' input: both tensors sliced 16-way and concatenated (memory_nets.py:40-61), the previous memory scaled by the
+        not-done masks; NHWC [B, 32, T, 32].  A function of the inputs alone: update_sep builds it once for its four epochs."""
+        bscale = masks.reshape(-1).contiguous() if masks is not None else None
+        return ops.slice_concat_input(pred_mono.contiguous(), prev_pred_monoFromMem.contiguous(), bscale=bscale, op=0)
+
+    def forward_masked(self, pred_mono, prev_pred_monoFromMem, masks=None, sliced=None):
+        """sliced: ``slice_inputs`` of the same three arguments, when the caller already holds it."""
         if torch.is_grad_enabled() and (pred_mono.requires_grad or prev_pred_monoFromMem.requires_grad):
             raise NotImplementedError("m2h AcousticMem: gradients w.r.t. the inputs are not built (the separators are frozen in RL, "
                                       "ppo.py:184-195); detach the inputs")
-        bscale = masks.reshape(-1).contiguous() if masks is not None else None
-        x = ops.slice_concat_input(pred_mono.contiguous(), prev_pred_monoFromMem.contiguous(), bscale=bscale, op=0)
+        if (self._use_ddppo and sliced is None and not torch.is_grad_enabled() and pred_mono.shape[0] <= self.SMALL_BATCH
+                and tuple(pred_mono.shape[1:]) == (512, 32, 1) and ops.math_mode() == ops.MATH_FP32 and not ops.timing_enabled()):
+            # the rollout step's call (14 envs, no autograd): slice, both convs and the de-slice in ONE launch (csrc/acoustic_mem.hip)
+            c0, c1 = self.cnn[0], self.cnn[-1]
+            return ops.acoustic_mem_small(pred_mono.contiguous(), prev_pred_monoFromMem.contiguous(),
+                                          masks.reshape(-1).contiguous() if masks is not None else None,
+                                          self._memo[0].get(c0.weight, 32), self._memo[1].get(c1.weight, 32))
+        x = sliced if sliced is not None else self.slice_inputs(pred_mono, prev_pred_monoFromMem, masks)
         c0, c1 = self.cnn[0], self.cnn[-1]
         if self._use_ddppo:
             x = MF.conv2d(x, c0.weight, None, 1, 1, slope=0.0, memo=self._memo[0], name="acoustic_mem.conv0")

@@ -153,10 +153,11 @@ class Policy(nn.Module):
         self._fence("mem")
         return self.acoustic_mem(pred_mono, prev_pred_monoFromMem_masked)
 
-    def get_monoFromMem_masked(self, pred_mono, prev_pred_monoFromMem, masks):
-        """get_monoFromMem with the not-done masking of the previous memory fused (ppo_trainer.py:310-319)."""
+    def get_monoFromMem_masked(self, pred_mono, prev_pred_monoFromMem, masks, sliced=None):
+        """get_monoFromMem with the not-done masking of the previous memory fused (ppo_trainer.py:310-319).
+        sliced: AcousticMem.slice_inputs of the same arguments, when the caller holds it (update_sep's epochs share one)."""
         self._fence("mem")
-        return self.acoustic_mem.forward_masked(pred_mono, prev_pred_monoFromMem, masks)
+        return self.acoustic_mem.forward_masked(pred_mono, prev_pred_monoFromMem, masks, sliced=sliced)
 
     # action sampling (common/utils.py): None = noise from the device generator; a HostNoise = noise from the CPU default generator
     _host_noise = None
@@ -197,6 +198,21 @@ class Policy(nn.Module):
         feats_pol, rnn_hidden_states_pol = self.pol_net(
             observations, rnn_hidden_states_pol, masks, pred_binSepMasks=pred_binSepMasks.detach(),
             pred_mono=pred_mono.detach(), pred_monoFromMem=pred_monoFromMem.detach())
+        if not torch.is_grad_enabled():
+            # rollout / evaluation (no autograd): heads, the draw (or the mode) and its log-probability in ONE launch.  The noise is
+            # the draw torch.multinomial makes -- Exp(1) from the device generator, or from the CPU default generator through the
+            # pinned ring (set_action_sampling); same generator state in, same noise, same actions out as the per-op path below.
+            a, c = self.action_dist.linear, self.critic.fc
+            noise = None
+            if not deterministic:
+                M, A = feats_pol.shape[0], self.dim_actions
+                if self._host_noise is not None:
+                    noise = self._host_noise.buffer(M, A) if torch.cuda.is_current_stream_capturing() else self._host_noise.stage(M, A)
+                else:
+                    noise = torch.empty((M, A), device=feats_pol.device).exponential_(1)
+            value, _lpa, probs, _ent, action, action_log_probs = ops.policy_heads_act(
+                feats_pol.contiguous(), a.weight.detach(), a.bias.detach(), c.weight.detach(), c.bias.detach(), noise)
+            return value, action, action_log_probs, rnn_hidden_states_pol, probs
         value, dist, _ = self._heads(feats_pol)
         action = dist.mode() if deterministic else dist.sample()
         action_log_probs = dist.log_probs(action)

@@ -189,6 +189,12 @@ class PPO(nn.Module):
         key = (id(rollouts_sep), getattr(rollouts_sep, "generation", None), rollouts_sep.observations["mixed_bin_audio_mag"].data_ptr())
         if self.cache_separator_outputs and self._sep_cache is not None and self._sep_cache[0] == key and key[1] is not None:
             return self._sep_cache[1]
+        stored = getattr(rollouts_sep, "stored_separator_outputs", None)
+        stored = stored() if (stored is not None and self.cache_separator_outputs) else None
+        if stored is not None:
+            # the trainer's rollout steps left every stored observation's outputs beside it (ppo_trainer.py): nothing to compute
+            self._sep_cache = (key, stored)
+            return stored
         mix = rollouts_sep.observations["mixed_bin_audio_mag"][:-1]
         T, N = mix.shape[0], mix.shape[1]
         tcl = rollouts_sep.observations["target_class"][:-1]
@@ -228,6 +234,7 @@ class PPO(nn.Module):
         # still runs them under no_grad, in whatever mode the modules are in, and back-propagates only the memory's loss (:184-195,
         # :226); every pass of the reference is then made (no cached outputs: train-mode BatchNorm would move its statistics)
         cached = self._separator_outputs(rollouts_sep) if (self.cache_separator_outputs and sep_frozen) else None
+        sliced = None   # the memory's sliced + concatenated + masked input: the same tensor in every epoch of a full-batch update
         for _e in range(self.ppo_epoch):
             needed = ("mixed_bin_audio_mag", "gt_mono_comps", "gt_bin_comps", "target_class")  # what this update reads
             gen = rollouts_sep.recurrent_generator(self.num_mini_batch, with_perm=True, sensors=needed)
@@ -241,7 +248,13 @@ class PPO(nn.Module):
                         pred_binSepMasks = self.actor_critic.get_binSepMasks(obs_batch)
                         pred_mono = self.actor_critic.convert_bin2mono(pred_binSepMasks.detach(),
                                                                        mixed_audio=obs_batch["mixed_bin_audio_mag"])
-                pred_monoFromMem = self.actor_critic.get_monoFromMem_masked(pred_mono, prev_mem_batch, masks_batch)
+                if cached is not None and idx is None:
+                    if sliced is None:
+                        with torch.no_grad():
+                            sliced = self.actor_critic.acoustic_mem.slice_inputs(pred_mono, prev_mem_batch, masks_batch)
+                    pred_monoFromMem = self.actor_critic.get_monoFromMem_masked(pred_mono, prev_mem_batch, masks_batch, sliced=sliced)
+                else:
+                    pred_monoFromMem = self.actor_critic.get_monoFromMem_masked(pred_mono, prev_mem_batch, masks_batch)
                 gt_mono = obs_batch["gt_mono_comps"]
                 monoFromMem_loss = MF.l1_loss(pred_monoFromMem, gt_mono, 0)          # gt_mono_comps[..., 0::2][..., :1]
                 if cached is not None and idx is None and len(cached) > 2:
@@ -255,7 +268,7 @@ class PPO(nn.Module):
                         # separator outputs alone: computed once per buffer generation like those outputs
                         cached = self._sep_cache_add_losses(bin_loss, mono_loss)
                 self.optimizer_sep.zero_grad()
-                monoFromMem_loss.backward()                                          # total_loss = monoFromMem_loss (:226)
+                monoFromMem_loss.backward(MF.unit_grad(monoFromMem_loss.device))     # total_loss = monoFromMem_loss (:226)
                 self._reduce_and_step("mem", self.optimizer_sep, last=_e == self.ppo_epoch - 1 and _mb == self.num_mini_batch - 1)
                 acc += torch.stack((bin_loss, mono_loss, monoFromMem_loss.detach()))
         num_updates = self.ppo_epoch * self.num_mini_batch

@@ -12,6 +12,8 @@ tests/test_gpu_trainer_golden.py).  Changed in mechanism only:
   * the separator outputs for the *next* observation, which the reference computes for the reward (:358-373), are re-used as
     the *current* outputs of the following step (same frozen networks, same observation): half the U-Net passes, identical
     values; invalidated whenever acoustic_mem changes (after update_sep);
+  * the same outputs are stored beside the observation in the separator storage, where update_sep reads them instead of
+    re-running the frozen U-Nets over the whole buffer (the reference does that 24 x per cycle under no_grad, ppo.py:184-195);
   * checkpoints keep the reference format {"state_dict", "config"} (:223-238).
 Out of scope: Habitat env construction, TensorBoard, the eval loop (:1015-1551).
 """
@@ -115,6 +117,10 @@ class PPOTrainer:
         self.rollouts_sep.full_batch_views = True
         self.rollouts_pol.to(self.device)
         self.rollouts_sep.to(self.device)
+        # the frozen separators' outputs of every stored observation are kept beside it (the rollout step computes them anyway), so
+        # update_sep reads them instead of re-running the U-Nets over its 1 680-sample buffer (result-preserving: same networks, same
+        # observations; module docstring)
+        self.rollouts_sep.enable_separator_outputs()
         batch = self.envs.reset()
         for sensor in self.rollouts_pol.observations:
             self.rollouts_pol.observations[sensor][0].copy_(batch[sensor])
@@ -158,7 +164,7 @@ class PPOTrainer:
         if on_device and self._graphs_enabled() and self._next_cache is not None:
             self._graph_step(extra, done)
             self.rollouts_pol.advance()  # the replayed inserts address their rows on the device
-            self.rollouts_sep.advance()
+            self.rollouts_sep.advance(with_preds=True)
         else:
             with torch.no_grad():
                 self._next_cache = self._rollout_step_device(self._next_cache, None, extra, done)
@@ -195,6 +201,7 @@ class PPOTrainer:
         else:
             pred_binSepMasks, pred_mono = self._separate(step_observation)
             pred_monoFromMem = ac.get_monoFromMem_masked(pred_mono, row(ro.prev_pred_monoFromMem), step_masks)
+            rs.store_separator_outputs(rs.step, pred_binSepMasks, pred_mono)   # (the same observation sits in row rs.step of that storage)
         values, actions, actions_log_probs, recurrent_hidden_states_pol, distribution_probs = ac.act(
             step_observation, step_h, step_masks, pred_binSepMasks=pred_binSepMasks,
             pred_mono=pred_mono, pred_monoFromMem=pred_monoFromMem)
@@ -219,9 +226,11 @@ class PPOTrainer:
         pol_kw = dict(pred_binSepMasks=pred_binSepMasks, pred_mono=pred_mono, pred_monoFromMem=pred_monoFromMem)
         if at is None:
             ro.insert(*pol_args, **pol_kw)
-            rs.insert(batch, masks, pred_monoFromMem=pred_monoFromMem)
+            rs.insert(batch, masks, pred_monoFromMem=pred_monoFromMem, pred_binSepMasks=next_pred_binSepMasks, pred_mono=next_pred_mono)
         else:
-            ops.rows_copy(ro.insert_items((0, 1), *pol_args, **pol_kw) + rs.insert_items(2, batch, masks, pred_monoFromMem=pred_monoFromMem), at)
+            ops.rows_copy(ro.insert_items((0, 1), *pol_args, **pol_kw) +
+                          rs.insert_items(2, batch, masks, pred_monoFromMem=pred_monoFromMem, pred_binSepMasks=next_pred_binSepMasks,
+                                          pred_mono=next_pred_mono), at)
             # hand the next-observation separator outputs over to the following step's static buffers: one batched copy, AFTER the
             # inserts above have read those buffers (they hold this step's outputs)
             nxt = (next_pred_binSepMasks, next_pred_mono, next_pred_monoFromMem)
@@ -424,6 +433,7 @@ class PPOTrainer:
         from ... import functional as MF
         MF.bump_param_epoch()  # packed-weight memos key on the optimizer epoch
         self._next_cache = None
+        self.rollouts_sep.invalidate_separator_outputs()
         self._drop_graphs()    # the frozen separators' packed weights / folded-BN buffers are rebuilt at new addresses
         return out
 
