@@ -283,6 +283,12 @@ int m2h_gru_gates(const float* gi, const float* gh_raw, const float* bhh, const 
 int m2h_gru_step(const float* gi, const float* whh, const float* bhh, const float* hprev, const float* mask, float* gh_raw, float* hout,
                  int M, int H, m2h_stream stream);
 
+/* The whole cell of a NO-GRAD single step for M <= 16 rows in one launch (the rollout step, ppo_trainer.py:322-335): the input
+ * projection gi = x W_ih^T + b_ih, the recurrent product and the gates of m2h_gru_gates; only hout is written.  x [M][I],
+ * wih [3H][I], whh [3H][H] (torch weight_ih_l0 / weight_hh_l0), hprev [M][H], mask [M] or NULL.  I % 16 == 0, H % 16 == 0. */
+int m2h_gru_cell(const float* x, const float* wih, const float* bih, const float* whh, const float* bhh, const float* hprev,
+                 const float* mask, float* hout, int M, int I, int H, m2h_stream stream);
+
 /* CategoricalNet + CriticHead (common/utils.py:16-50, rl/ppo/policy.py:15-23): logits = feats Wa^T + ba (A <= 8),
  * value = feats Wc^T + bc, logp_all = log_softmax, probs = softmax, entropy = -sum p*logp per row; when actions != NULL
  * also logp_act[row] = logp_all[row][actions[row]] (CustomFixedCategorical.log_probs).  actions: int64. */
@@ -474,6 +480,12 @@ int m2h_stft_l2(const float* mix, const float* pred, int Cp, const float* gt_com
  * order: bit-reproducible). */
 size_t m2h_conv_wgrad_workspace_bytes(const m2h_conv_args* args /* host */);
 int m2h_conv_wgrad_f32(const m2h_conv_args* args /* host */, const float* dy, int ldy, float* dw, m2h_stream stream);
+/* The same with the backward of the layer's fused activation folded into the load of dy: dy is taken as dy * (y > 0 ? 1 : slope),
+ * y = the layer's forward output (same layout as dy) -- m2h_act_bwd followed by m2h_conv_wgrad_f32 without the 3-tensor pass in
+ * between.  Built into the image-row kernel only (3x3 / stride 1 / pad 1 over 32-channel, 32-pixel-wide images: AcousticMem's first
+ * conv, memory_nets.py:11-16, at update_sep's 1.7 M pixels); other shapes are refused (rc < 0). */
+int m2h_conv_wgrad_gated_f32(const m2h_conv_args* args /* host */, const float* dy, int ldy, const float* y, float slope, float* dw,
+                             m2h_stream stream);
 
 /* Input gradient = forward engine on re-laid-out weights: for a Conv2d(k, stride s, pad p) weight w [Co][Ci][KH][KW]
  * (KH, KW multiples of s) writes s*s phase matrices wp[ph*s+pw][ci][th][tw][co] = w[co][ci][(ph+p)%s + s*th][(pw+p)%s + s*tw].

@@ -39,6 +39,8 @@ struct WGradP {
   int quad;         // 1: the four sub-pixel phases of a ConvTranspose2d(4,2,1) in one launch (grid y = phase: its taps' direction,
                     // its dy rows, its slabs); the reduce kernels write dwp, convT_wgrad_unpack_kernel scatters it into dw
   float* dwp;       // quad: [4 phases][N][K] packed gradients (behind the slabs in the workspace)
+  const float* gate;  // optional (image-row 3x3 kernel): the forward output y of the layer, same layout as dy: dy is read as
+  float gate_slope;   // dy * (y > 0 ? 1 : gate_slope) -- the backward of the layer's fused ReLU / LeakyReLU without a pass of its own
 };
 
 // phase (ph, pw) of a quad launch: taps step by 2 ph - 1 / 2 pw - 1 (separator_cnn.py:15-24 as four sub-pixel GEMMs)
@@ -334,6 +336,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_row_kernel(const WGradP p) {
     }
     const bool yok = yrow < W && yseg * 4 < p.N;
     ry = *reinterpret_cast<const f32x4*>(p.dy + (yok ? ((size_t)c * W + yrow) * p.ldy + yseg * 4 : (size_t)0));
+    if (p.gate != nullptr) {   // m2h_act_bwd folded into the load: same values, no 3-tensor pass of its own
+      const f32x4 gy = *reinterpret_cast<const f32x4*>(p.gate + (yok ? ((size_t)c * W + yrow) * p.ldy + yseg * 4 : (size_t)0));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ry[e] = gy[e] > 0.f ? ry[e] : ry[e] * p.gate_slope;
+    }
     okm |= yok ? (1u << 8) : 0u;
   };
   auto store_chunk = [&](int buf) {
@@ -506,7 +513,8 @@ size_t conv_wgrad_workspace_bytes(const m2h_conv_args& a) {
 
 // quad: the four phases of a ConvTranspose2d(4,2,1) in one launch (a = the geometry of one phase: taps 2x2, stride 1, os 2,
 // Ho = 2 Hi; its ph / pw / mulh / mulw are ignored), dw in the torch layout, workspace four times the single-phase size
-int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, hipStream_t st, bool quad = false) {
+int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, hipStream_t st, bool quad = false, const float* gate = nullptr,
+                   float gate_slope = 1.f) {
   M2H_REQUIRE(a.src0 != nullptr && dy != nullptr && dw != nullptr, "conv_wgrad: null pointer");
   M2H_REQUIRE(a.conv_transpose == 0, "conv_wgrad: describe a transposed conv by its phase geometry (m2h_convT_wgrad_f32)");
   M2H_REQUIRE(!quad || (a.nth == 2 && a.ntw == 2 && a.stride == 1 && a.os == 2 && a.offh == 0 && a.offw == 0 && a.Hq == a.Hi && a.Wq == a.Wi &&
@@ -535,6 +543,7 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   p.ws = static_cast<float*>(a.workspace);
   p.dwp = quad ? p.ws + slab_floats : nullptr;
   p.dw = dw;
+  p.gate = gate; p.gate_slope = gate_slope;
   int bng, kt;
   wgrad_cfg(a.N, p.K, bng, kt, p.ktiles);
   p.ntiles = (a.N + bng - 1) / bng;
@@ -545,6 +554,7 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   const bool row3x3 = !quad && g_wgrad_row3x3 >= 0 && a.nth == 3 && a.ntw == 3 && a.stride == 1 && a.mulh == 1 && a.mulw == 1 && a.offh == -1 &&
                       a.offw == -1 && a.C0 == 32 && a.C1 == 0 && a.Wq == 32 && a.Wi == 32 && a.Hq == a.Hi && p.direct && a.N <= 32 &&
                       a.N % 4 == 0 && ldy % 4 == 0 && p.ntiles * p.ktiles == 1;
+  M2H_REQUIRE(gate == nullptr || row3x3, "conv_wgrad: the activation gate is built into the image-row 3x3 kernel only (3x3 / stride 1 / pad 1, 32 channels, 32-pixel rows)");
   if (row3x3) {
     p.chunks = a.B * a.Hq;   // image rows
     if (p.S > p.chunks) p.S = p.chunks;
@@ -664,6 +674,11 @@ size_t m2h_conv_wgrad_workspace_bytes(const m2h_conv_args* args) { return args ?
 int m2h_conv_wgrad_f32(const m2h_conv_args* args, const float* dy, int ldy, float* dw, m2h_stream stream) {
   M2H_REQUIRE(args != nullptr, "conv_wgrad: null args");
   return conv_wgrad_f32(*args, dy, ldy, dw, as_stream(stream));
+}
+
+int m2h_conv_wgrad_gated_f32(const m2h_conv_args* args, const float* dy, int ldy, const float* y, float slope, float* dw, m2h_stream stream) {
+  M2H_REQUIRE(args != nullptr && y != nullptr, "conv_wgrad_gated: null pointer");
+  return conv_wgrad_f32(*args, dy, ldy, dw, as_stream(stream), false, y, slope);
 }
 
 size_t m2h_convT_wgrad_workspace_bytes(const m2h_conv_args* args) {   // four phases of slabs + the packed per-phase gradients

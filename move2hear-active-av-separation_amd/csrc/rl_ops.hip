@@ -178,6 +178,47 @@ __global__ __launch_bounds__(256) void gru_step_kernel(const float* __restrict__
   }
 }
 
+// The whole GRU cell of a no-grad single step (rnn_state_encoder.py:74-84 at the rollout width, M <= 16 rows) in ONE launch: the input
+// projection gi = x W_ih^T + b_ih is the same kind of weight stream as the recurrent product (3H x I floats, 9.4 MB at I = 1536),
+// so the block that owns GRU_U hidden units runs the dot products of its 3*GRU_U rows of BOTH matrices through skinny_dot16 and
+// applies the gates; nothing but the new state is written (no backward pass follows a no-grad step).  Replaces the projection GEMM +
+// gru_step_kernel of the rollout step.
+__global__ __launch_bounds__(256) void gru_cell_kernel(const float* __restrict__ x, const float* __restrict__ wih, const float* __restrict__ bih,
+                                                       const float* __restrict__ whh, const float* __restrict__ bhh,
+                                                       const float* __restrict__ hprev, const float* __restrict__ mask,
+                                                       float* __restrict__ hout, int M, int I, int H) {
+  __shared__ float R[2][4][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int j0 = blockIdx.x * GRU_U;
+  const int r = min(i, 3 * GRU_U - 1);                         // weight row of this lane: gate r / GRU_U, unit r % GRU_U
+  const size_t wr = (size_t)(r / GRU_U) * H + j0 + (r % GRU_U);
+  const int row = min(i, M - 1);
+  const int gu = (tid >> 4) & (GRU_U - 1), ge = min(tid & 15, M - 1), gj = j0 + gu;
+  const float gmask = mask != nullptr ? mask[ge] : 1.f;
+  const float bi_r = bih[gj], bi_z = bih[H + gj], bi_n = bih[2 * H + gj];
+  const float b_r = bhh[gj], b_z = bhh[H + gj], b_n = bhh[2 * H + gj];
+  const float hp_raw = hprev[(size_t)ge * H + gj];
+  const f32x4_r ai = skinny_dot16(x + (size_t)row * I + 4 * kq, wih + wr * I + 4 * kq, I >> 4, wave);
+  const f32x4_r ah = skinny_dot16(hprev + (size_t)row * H + 4 * kq, whh + wr * H + 4 * kq, H >> 4, wave);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    R[0][wave][kq * 4 + e][i] = ai[e];   // [m][weight row]
+    R[1][wave][kq * 4 + e][i] = ah[e];
+  }
+  __syncthreads();
+  if (tid < GRU_U * GRU_E && (tid & 15) < M) {
+    const int u = tid >> 4, m = tid & 15;
+    auto tot = [&](int w, int rr) { return (R[w][0][m][rr] + R[w][1][m][rr]) + (R[w][2][m][rr] + R[w][3][m][rr]); };
+    const float gi_r = tot(0, u) + bi_r, gi_z = tot(0, GRU_U + u) + bi_z, gi_n = tot(0, 2 * GRU_U + u) + bi_n;
+    const float gr = tot(1, u), gz = tot(1, GRU_U + u), gn = tot(1, 2 * GRU_U + u);
+    const float rg = sigmoidf_(gi_r + (gmask * gr + b_r));
+    const float z = sigmoidf_(gi_z + (gmask * gz + b_z));
+    const float n = tanhf(gi_n + rg * (gmask * gn + b_n));
+    hout[(size_t)m * H + j0 + u] = (1.f - z) * n + z * (gmask * hp_raw);
+  }
+}
+
 // One wave per row: logits = feats Wa^T + ba (A <= 8 actions), value = feats Wc^T + bc; log-softmax, softmax, entropy,
 // optional log-prob of a given action.  H multiple of 64.
 __global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restrict__ feats, const float* __restrict__ Wa,
@@ -859,6 +900,15 @@ int m2h_gru_step(const float* gi, const float* whh, const float* bhh, const floa
               GRU_E, M, H);
   hipLaunchKernelGGL(gru_step_kernel, dim3(H / GRU_U), dim3(256), 0, as_stream(stream), gi, whh, bhh, hprev, mask, gh_raw, hout, M, H);
   return launch_status("gru_step");
+}
+
+int m2h_gru_cell(const float* x, const float* wih, const float* bih, const float* whh, const float* bhh, const float* hprev,
+                 const float* mask, float* hout, int M, int I, int H, m2h_stream stream) {
+  M2H_REQUIRE(x && wih && bih && whh && bhh && hprev && hout, "gru_cell: null pointer");
+  M2H_REQUIRE(M > 0 && M <= GRU_E && H > 0 && H % 16 == 0 && I > 0 && I % 16 == 0,
+              "gru_cell: needs 1 <= M <= %d rows, H %% 16 == 0 and I %% 16 == 0 (got M=%d, I=%d, H=%d)", GRU_E, M, I, H);
+  hipLaunchKernelGGL(gru_cell_kernel, dim3(H / GRU_U), dim3(256), 0, as_stream(stream), x, wih, bih, whh, bhh, hprev, mask, hout, M, I, H);
+  return launch_status("gru_cell");
 }
 
 int m2h_policy_heads(const float* feats, const float* Wa, const float* ba, const float* Wc, const float* bc,

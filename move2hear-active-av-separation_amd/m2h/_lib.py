@@ -214,6 +214,7 @@ SIGNATURES = {
     "m2h_rewards_from_stats": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "m2h_conv_wgrad_workspace_bytes": [ctypes.POINTER(ConvArgs)],
     "m2h_conv_wgrad_f32": [ctypes.POINTER(ConvArgs), _P, _I, _P, _P],
+    "m2h_conv_wgrad_gated_f32": [ctypes.POINTER(ConvArgs), _P, _I, _P, _F, _P, _P],
     "m2h_pack_dgrad_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "m2h_act_bwd": [_P, _P, _F, _P, _Z, _P],
     "m2h_bias_grad_workspace_bytes": [_I, _I],
@@ -245,6 +246,7 @@ SIGNATURES = {
     "m2h_strip_last_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "m2h_gather_envs": [_P, _P, _P, _I, _I, _I, _Z, _P],
     "m2h_gru_step": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "m2h_gru_cell": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "m2h_episode_stats_update": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_step_stats_workspace_bytes": [_I],
     "m2h_rollout_step_stats": [ctypes.POINTER(StepStatsArgs), _P],

@@ -44,8 +44,9 @@ def _conv_args(x, x2, n_out, kh, kw, stride, pad, Ho, Wo):
     return a
 
 
-def conv_wgrad(x, x2, dy, n_out, kh, kw, stride, pad):
-    """Packed weight gradient [n_out, kh*kw*(C0+C1)] of a conv whose NHWC inputs were x (+x2) and NHWC output grad is dy."""
+def conv_wgrad(x, x2, dy, n_out, kh, kw, stride, pad, gate=None, gate_slope=1.0):
+    """Packed weight gradient [n_out, kh*kw*(C0+C1)] of a conv whose NHWC inputs were x (+x2) and NHWC output grad is dy.
+    gate: the layer's forward output y; dy is then read as dy * (y > 0 ? 1 : gate_slope) (m2h_conv_wgrad_gated_f32: image-row shapes only)."""
     B, Ho, Wo, N = dy.shape
     a = _conv_args(x, x2, n_out, kh, kw, stride, pad, Ho, Wo)
     lib = _lib.load()
@@ -57,8 +58,13 @@ def conv_wgrad(x, x2, dy, n_out, kh, kw, stride, pad):
         a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
         M = B * Ho * Wo
         meta = {"kernel": "wgrad_f32", "M": M, "N": n_out, "K": K, "flops": 2.0 * M * n_out * K, "bytes": 4.0 * (x.numel() + dy.numel() + dw.numel())}
-        ops._timed("conv_wgrad", meta, x.device,
-                   lambda: _lib.check(lib.m2h_conv_wgrad_f32(ctypes.byref(a), ops._ptr(dy), N, ops._ptr(dw), ops._stream(x)), "m2h_conv_wgrad_f32"))
+        if gate is not None:
+            ops._timed("conv_wgrad", meta, x.device,
+                       lambda: _lib.check(lib.m2h_conv_wgrad_gated_f32(ctypes.byref(a), ops._ptr(dy), N, ops._ptr(gate), float(gate_slope), ops._ptr(dw),
+                                                                       ops._stream(x)), "m2h_conv_wgrad_gated_f32"))
+        else:
+            ops._timed("conv_wgrad", meta, x.device,
+                       lambda: _lib.check(lib.m2h_conv_wgrad_f32(ctypes.byref(a), ops._ptr(dy), N, ops._ptr(dw), ops._stream(x)), "m2h_conv_wgrad_f32"))
     return dw
 
 
@@ -292,13 +298,26 @@ class Conv2dNHWC(torch.autograd.Function):
             dy = ops.slice_concat_input(dy, op=0)
             if slope != 1.0:
                 raise NotImplementedError("m2h Conv2dNHWC: activation + de-sliced output has no backward")
-        if slope != 1.0:
+        need_x = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
+        # AcousticMem's first conv over the update batch (3x3 / 1 / 1, 32 channels, 32-pixel rows, no bias, no input gradient): the
+        # weight gradient is the only reader of dy, and its image-row kernel applies the activation's derivative as it loads dy
+        gated = (slope != 1.0 and ctx.needs_input_grad[2] and not need_x and not ctx.needs_input_grad[3] and x2 is None and
+                 (KH, KW, stride, pad) == (3, 3, 1, 1) and x.shape[3] == 32 and x.shape[2] == 32 and Co <= 32 and Co % 4 == 0 and
+                 x.shape[0] * x.shape[1] >= 512 and ops.math_mode() == ops.MATH_FP32 and not ops.timing_enabled())
+        if slope != 1.0 and not gated:
             dy = act_bwd(dy, y, slope)
         B, Ho, Wo, _ = dy.shape
         gx = gx2 = gw = gb = None
         if ctx.needs_input_grad[2]:
             c_in = x.shape[3] + (x2.shape[3] if x2 is not None else 0)
-            dwp = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad)  # [Co, KH*KW*c_in]
+            dwp = None
+            if gated:
+                try:
+                    dwp = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, gate=y, gate_slope=slope)
+                except RuntimeError:        # the library refused (image-row kernel switched off: m2h_debug_set(21, -1)): two passes
+                    dy = act_bwd(dy, y, slope)
+            if dwp is None:
+                dwp = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad)  # [Co, KH*KW*c_in]
             gw = dwp.view(Co, KH, KW, c_in)[..., :Ci].permute(0, 3, 1, 2).contiguous()
         if ctx.needs_input_grad[3]:
             gb = bias_grad(dy.view(B * Ho * Wo, Co))

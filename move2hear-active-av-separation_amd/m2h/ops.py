@@ -357,7 +357,14 @@ def conv2d_nhwc(x, wp, n_out, kh, kw, stride=1, pad=0, bias=None, scale=None, sl
     Wo = (W + 2 * pad - kw) // stride + 1
     if wp.numel() != n_out * kh * kw * (C0 + C1):
         raise RuntimeError("m2h.%s: packed weight has %d elements, expected %d" % (name, wp.numel(), n_out * kh * kw * (C0 + C1)))
-    if out is not None:
+    ldc = n_out
+    if out is not None and out.dim() == 2 and not out.is_contiguous():
+        # a column block of a wider row-major matrix (the policy's concatenated features, rl/ppo/policy.py:103): rows ldc floats apart
+        if not (out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (B, n_out) and out.stride(1) == 1 and Ho * Wo == 1
+                and not deslice and out.stride(0) >= n_out and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0):
+            raise RuntimeError("m2h.%s: a strided out must be a [B, n_out] column block of a row-major fp32 matrix" % name)
+        ldc = out.stride(0)
+    elif out is not None:
         _chk(out, name + "(out)")
         if out.numel() != B * Ho * Wo * n_out:
             raise RuntimeError("m2h.%s: out has %d elements, expected %d" % (name, out.numel(), B * Ho * Wo * n_out))
@@ -374,7 +381,7 @@ def conv2d_nhwc(x, wp, n_out, kh, kw, stride=1, pad=0, bias=None, scale=None, sl
     a.shift = bias.data_ptr() if bias is not None else None
     a.slope = float(slope)
     a.cls_table, a.cls_val = None, None
-    a.dst, a.Ho, a.Wo, a.os, a.ph, a.pw, a.ldc = out.data_ptr(), Ho, Wo, 1, 0, 0, n_out
+    a.dst, a.Ho, a.Wo, a.os, a.ph, a.pw, a.ldc = out.data_ptr(), Ho, Wo, 1, 0, 0, ldc
     a.out_mode = OUT_DESLICE if deslice else OUT_NHWC
     a.operand_format = int(operand_format)   # FMT_* bits: split32 operands / output (bf16x3 math only)
     lib = _lib.load()
@@ -474,6 +481,22 @@ def gru_step(gi, whh, bhh, hprev, mask=None, gh_out=None, out=None):
                lambda: _lib.check(_lib.load().m2h_gru_step(_ptr(gi), _ptr(whh), _ptr(bhh), _ptr(hprev), _ptr(mask), _ptr(gh), _ptr(hout), M, H,
                                                            _stream(gi)), "m2h_gru_step"))
     return hout, gh
+
+
+def gru_cell(x, wih, bih, whh, bhh, hprev, mask=None):
+    """The whole GRU cell of a no-grad single step for M <= 16 rows in one launch (m2h_gru_cell) -> hout [M,H]."""
+    for t in (x, wih, bih, whh, bhh, hprev, mask):
+        _chk(t, "gru_cell")
+    M, H = hprev.shape
+    I = x.shape[1]
+    if x.shape[0] != M or wih.shape != (3 * H, I) or whh.shape != (3 * H, H) or bih.numel() != 3 * H or bhh.numel() != 3 * H or \
+            (mask is not None and mask.numel() != M):
+        raise RuntimeError("m2h.gru_cell: shape mismatch")
+    hout = torch.empty_like(hprev)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().m2h_gru_cell(_ptr(x), _ptr(wih), _ptr(bih), _ptr(whh), _ptr(bhh), _ptr(hprev), _ptr(mask), _ptr(hout), M, I, H,
+                                            _stream(x)), "m2h_gru_cell")
+    return hout
 
 
 def policy_heads(feats, Wa, ba, Wc, bc, actions=None):
@@ -722,8 +745,15 @@ def pack_batch(items):
 _step_stats_scratch = {}
 
 
+def step_stats_scratch(N, dev):
+    """Scratch of m2h_rollout_step_stats for N envs: (partial sums, zeroed tickets).  The kernel leaves the tickets at zero, so one
+    allocation serves every later launch of its owner; a trainer makes its own at setup (outside any HIP-graph capture: the zeroing
+    is then not a node of the captured step) and passes it in."""
+    return (torch.empty(_lib.load().m2h_step_stats_workspace_bytes(N) // 4, device=dev), torch.zeros(N, dtype=torch.int32, device=dev))
+
+
 def rollout_step_stats(stats, next_mem, next_gt_mono_comps, mem, gt_mono_comps, masks, mix, gt_bin_comps, mono, not_done, probs,
-                       env_rewards=None, ndgs=None, dgs=None, override=True, extra=False, extra_mult=10.0):
+                       env_rewards=None, ndgs=None, dgs=None, override=True, extra=False, extra_mult=10.0, scratch=None):
     """The per-env bookkeeping of one rollout step in ONE launch (m2h_rollout_step_stats): reward, the three STFT-L2 distances and
     the per-episode statistics update (ppo_trainer.py:375-455).  Returns (rewards [N,1], losses [3,N]: bin / mono / mono-from-memory);
     `stats` (the object of episode_stats_update) is updated in place.  Scratch (partial sums, tickets) is cached per (device, stream, N)."""
@@ -751,11 +781,11 @@ def rollout_step_stats(stats, next_mem, next_gt_mono_comps, mem, gt_mono_comps, 
     # the last-arriver protocol of the kernel assumes exclusive use of its tickets and partial slabs while a launch is in flight:
     # launches on ONE stream are ordered, so the scratch is per (device, stream, N) -- two trainers, or a graph replay beside an
     # eager step on another stream, never share it (a captured graph holds the addresses of the scratch of its capture stream)
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, N)
-    scratch = _step_stats_scratch.get(key)
-    if scratch is None:
-        scratch = _step_stats_scratch[key] = (torch.empty(_lib.load().m2h_step_stats_workspace_bytes(N) // 4, device=dev),
-                                              torch.zeros(N, dtype=torch.int32, device=dev))
+    if scratch is None:     # callers without a scratch of their own
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, N)
+        scratch = _step_stats_scratch.get(key)
+        if scratch is None:
+            scratch = _step_stats_scratch[key] = step_stats_scratch(N, dev)
     rewards = torch.empty((N, 1), device=dev)
     losses = torch.empty((3, N), device=dev)
     a.rewards, a.losses, a.partial, a.tickets = rewards.data_ptr(), losses.data_ptr(), scratch[0].data_ptr(), scratch[1].data_ptr()

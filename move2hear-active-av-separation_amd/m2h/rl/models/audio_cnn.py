@@ -145,8 +145,9 @@ class FusedAudioPair:
         return (not torch.is_grad_enabled() and self.a._out_dims == self.b._out_dims and xa.shape == xb.shape
                 and all(p.is_cuda for p in self.a.parameters()))
 
-    def encode(self, xa, xb):
-        """xa, xb: the two encoders' sliced NHWC inputs [B,32,T,32] -> (features of a [B,512], features of b [B,512])."""
+    def encode(self, xa, xb, out=None):
+        """xa, xb: the two encoders' sliced NHWC inputs [B,32,T,32] -> (features of a [B,512], features of b [B,512]).
+        out: optional [B, 1024] destination (a column block of the policy's concatenated feature matrix)."""
         if not torch.cuda.is_current_stream_capturing():
             self.sync()
         elif self.w is None or self.key != self._key(self._layers(self.a), self._layers(self.b)):
@@ -160,5 +161,6 @@ class FusedAudioPair:
         if x.shape[1] != h or x.shape[2] != w:
             raise RuntimeError("m2h FusedAudioPair: conv output %s does not match the Linear built for %s" % (tuple(x.shape[1:3]), (h, w)))
         n = W[3].shape[0]
-        y = ops.conv2d_nhwc(x, M[3].get(W[3], 64), n, h, w, stride=1, pad=0, bias=Bv[3], slope=0.0, name="audio_pair.fc").reshape(x.shape[0], n)
+        y = ops.conv2d_nhwc(x, M[3].get(W[3], 64), n, h, w, stride=1, pad=0, bias=Bv[3], slope=0.0, name="audio_pair.fc", out=out)
+        y = y.reshape(x.shape[0], n) if out is None else out
         return y[:, :n // 2], y[:, n // 2:]

@@ -6,9 +6,11 @@ the MFMA engine (torch's [3H][K] weight layout is already the packed [N][K] form
 stretch; masking h with masks[t] before every step is the same function, needs no device->host sync (the reference's
 ``.nonzero().cpu()`` at :105) and is what is done here; the input GEMM is batched over all T*N rows.
 """
+import torch
 import torch.nn as nn
 
 from ... import functional as MF
+from ... import ops
 
 
 class RNNStateEncoder(nn.Module):
@@ -36,5 +38,11 @@ class RNNStateEncoder(nn.Module):
         n = hidden_states.size(1)
         t = x.size(0) // n  # 1: single_forward (:74-84); > 1: seq_forward (:86-137)
         r = self.rnn
+        if (t == 1 and not torch.is_grad_enabled() and n <= ops.GRU_STEP_MAX_ROWS and r.hidden_size % 16 == 0 and x.size(1) % 16 == 0
+                and ops.math_mode() == ops.MATH_FP32 and not ops.timing_enabled()):
+            # the rollout step (no autograd, 14 rows): input projection, recurrent product and gates in ONE launch (m2h_gru_cell)
+            h = ops.gru_cell(x.contiguous(), r.weight_ih_l0.detach(), r.bias_ih_l0.detach(), r.weight_hh_l0.detach(), r.bias_hh_l0.detach(),
+                             hidden_states[0].contiguous(), masks.reshape(n).contiguous())
+            return h, h.unsqueeze(0)
         out, h = MF.GRUSequence.apply(x, hidden_states[0], masks, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0, t)
         return out, h.unsqueeze(0)

@@ -4,6 +4,7 @@ Same constructor / forward / state_dict keys (``cnn.{0,2,4}.{weight,bias}``, ``c
 written once as a 4-channel NHWC tensor (the observation already is BHWC == NHWC); the 3- or 4-channel first conv is packed
 to 4 input channels; conv8x8s4+ReLU, conv4x4s2+ReLU, conv3x3s1 and the Linear+ReLU run on the MFMA implicit-GEMM engine.
 """
+import torch
 import torch.nn as nn
 
 from ... import functional as MF
@@ -59,7 +60,9 @@ class VisualCNN(nn.Module):
     def is_blind(self):
         return self._n_input_rgb + self._n_input_depth == 0
 
-    def forward(self, observations):
+    def forward(self, observations, out=None):
+        """out: optional [B, output_size] destination (a column block of the policy's concatenated feature matrix) for the no-grad
+        rollout path: the last layer then writes there instead of into a tensor of its own."""
         if self.is_blind:
             raise NotImplementedError("m2h VisualCNN: blind configuration has no encoder")
         if self._n_input_rgb != 3 or self._n_input_depth not in (0, 1):
@@ -72,5 +75,9 @@ class VisualCNN(nn.Module):
         x = MF.conv2d(x, c1.weight, c1.bias, 2, 0, slope=0.0, memo=self._memo[1], name="visual_cnn.conv1")
         x = MF.conv2d(x, c2.weight, c2.bias, 1, 0, slope=1.0, memo=self._memo[2], name="visual_cnn.conv2")  # no ReLU (:81-88)
         h, w = self._out_dims
-        y = MF.conv2d(x, fc.weight.view(fc.weight.shape[0], 32, h, w), fc.bias, 1, 0, slope=0.0, memo=self._memo[3], name="visual_cnn.fc")
+        fcw = fc.weight.view(fc.weight.shape[0], 32, h, w)
+        if out is not None and not torch.is_grad_enabled():
+            ops.conv2d_nhwc(x, self._memo[3].get(fcw, 32), fcw.shape[0], h, w, bias=fc.bias.detach(), slope=0.0, out=out, name="visual_cnn.fc")
+            return out
+        y = MF.conv2d(x, fcw, fc.bias, 1, 0, slope=0.0, memo=self._memo[3], name="visual_cnn.fc")
         return y.reshape(y.shape[0], -1)

@@ -86,8 +86,11 @@ class PolicyNet(Net):
             # rollout step (no gradients, 14 envs): the two audio encoders as one chain of block-diagonal layers (audio_cnn.FusedAudioPair)
             xa = ops.slice_concat_input(observations["mixed_bin_audio_mag"].contiguous(), mul=pred_binSepMasks.contiguous(), op=1)
             xb = ops.slice_concat_input(pred_mono.contiguous(), pred_monoFromMem.contiguous(), op=2)
-            fa, fb = self._audio_pair.encode(xa, xb)
-            x1 = torch.cat((self.visual_encoder(observations), fa, fb), dim=1)
+            # the three encoders write their features side by side into one matrix (the cat of :103 is never a copy)
+            hs = self._hidden_size
+            x1 = torch.empty((pred_mono.shape[0], 3 * hs), device=pred_mono.device)
+            self._audio_pair.encode(xa, xb, out=x1[:, hs:])
+            self.visual_encoder(observations, out=x1[:, :hs])
             x2, rnn_hidden_states_new = self.state_encoder(x1, rnn_hidden_states, masks)
             return x2, rnn_hidden_states_new
         # The three encoders are independent kernel chains; graphs.run_parallel can put them on three HIP streams for update

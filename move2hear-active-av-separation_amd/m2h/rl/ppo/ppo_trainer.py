@@ -133,6 +133,7 @@ class PPOTrainer:
             episode_dgs=z(N, 1), current_episode_reward=z(N, 1), current_episode_step=z(N, 1), current_episode_dist_probs=z(N, 3),
             current_episode_bin_losses=z(N, 1), current_episode_mono_losses=z(N, 1), current_episode_monoFromMem_losses=z(N, 1))
         self._episode_step_host = 0
+        self._stats_scratch = ops.step_stats_scratch(N, self.device) if self.device.type == "cuda" else None   # (one launch at a time per trainer)
         # the reference steps the LR schedulers at the START of each sub-update (:733-735, :981-982); torch warns about that order
         warnings.filterwarnings("ignore", message="Detected call of `lr_scheduler.step\\(\\)` before `optimizer.step\\(\\)`")
         self.lr_scheduler_pol = LambdaLR(self.agent.optimizer_pol, lr_lambda=lambda x: linear_decay(x, cfg.NUM_UPDATES))
@@ -221,7 +222,7 @@ class PPOTrainer:
             step_observation["mixed_bin_audio_mag"], step_observation["gt_bin_comps"], pred_mono, masks, distribution_probs,
             env_rewards=rewards, ndgs=infos.get("normalized_geo_distance_to_target_audio_source"),
             dgs=infos.get("geo_distance_to_target_audio_source"), override=override, extra=extra,
-            extra_mult=2.0 * cfg.extra_reward_multiplier)
+            extra_mult=2.0 * cfg.extra_reward_multiplier, scratch=self._stats_scratch)
         pol_args = (batch, recurrent_hidden_states_pol, actions, actions_log_probs, values, rewards, masks)
         pol_kw = dict(pred_binSepMasks=pred_binSepMasks, pred_mono=pred_mono, pred_monoFromMem=pred_monoFromMem)
         if at is None:
