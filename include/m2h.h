@@ -142,22 +142,6 @@ int m2h_get_math_mode(void);
  * (bit-reproducible) and applies the fused epilogue. */
 size_t m2h_conv_igemm_workspace_bytes(const m2h_conv_args* args /* host */);
 
-/* Tuning / test knobs -- NOT part of the contract, not for production use: they only choose between kernels that compute the
- * same values (0 = automatic everywhere), process-wide, set before the launches they are to affect.  tests/ use them to pit one
- * engine against another; tools/ for A/B timing.  0 force split-K factor (-1 never), 1 / 2 LDS stages of the narrow / wide tiles,
- * 3 skinny-M tiles (-1 off), 4 16-wide MFMA tile (-1 off), 7 extra dynamic LDS, 8 phase-major transposed-conv order (-1 off),
- * 9 scalar-decode loader (-1 off), 11 weight-gradient block target, 14 = m2h_set_math_mode (kept for older callers; thread-local
- * like it), 15 / 16 tap-sharing transposed-conv kernel (-1 off, 2 = only for N <= 32 / tile: 128, 256, 512), 18 tap window (-1
- * off), 21 / 22 image-row 3x3 weight-gradient / conv kernels (-1 off), 23 skinny rows kernel for M <= 16 (-1 off), 24 skinny
- * gather kernel (-1 off, > 0 = pixel limit), 26 the 256 x 128 eight-wave tile of the bf16x3 arithmetic (-1 off, > 0 = minimum
- * tile count), 27 the LDS-DMA engine for split32 operands (csrc/conv_dma.hip; -1 off, 2 = below the tile-count threshold too),
- * 28 = 32: 32x32x16 instead of 16x16x32 MFMA fragments there, 30 the four-phase transposed-conv kernel (csrc/convt_quad.hip; -1
- * off, 1 = wherever its shape conditions hold), 34 = -1: no split-K launches of the LDS-DMA / shared-patch engines (two K-halves, K-parts of the deepest stages), 35 = -1: the whole-network
- * runner does not take the strip-walker kernels (csrc/conv_strip.hip), 36 the shared-patch LDS-DMA engine (csrc/conv_patch.hip; -1
- * off, 2 = below the tile-count threshold too, 3 = as 2 with the whole-image patch wherever it fits), 37 = 1: the whole-network
- * runner takes the small-batch engine (csrc/conv_small.hip) for rollout-size batches (off by default: measured at parity).  Numbers of experiments that were measured and removed
- * (5, 6, 10, 12, 13, 17, 19, 20, 29, 31, 32) are accepted and ignored. */
-int m2h_debug_set(int knob, int value);
 
 /*
  * Named fused ops of the separator U-Nets; thin argument adapters over m2h_conv_igemm_f32.
@@ -648,7 +632,7 @@ int m2h_unet_fwd(const m2h_unet_weights* w /* host */, const float* mix, const f
 int m2h_unet_fwd_events(const m2h_unet_weights* w /* host */, const float* mix, const float* masks, const float* cls_val, float* out,
                         int B, int F, int T, void* workspace, size_t workspace_bytes, void* const* events, int n_events,
                         m2h_stream stream);
-/* With m2h_debug_set(37, 1), batches of at most 32 reference-native clips (T == 32) in fp32 arithmetic -- the rollout step's 14
+/* With tuning knob 37 set (include/m2h_tuning.h), batches of at most 32 reference-native clips (T == 32) in fp32 arithmetic -- the rollout step's 14
  * environments (ppo_trainer.py:295-373) -- run on the small-batch engine (m2h_conv_small_fwd): ten launches, the slice fused into the
  * first stage, the head into the last, no reduce launches; interval 0 of m2h_unet_fwd_events is then empty, 1-10 are the ten stages.
  * m2h_unet_small_tiling overrides, for the CALLING THREAD, the tiling of stage 0-9 (0 = the built-in value): a tuning hook

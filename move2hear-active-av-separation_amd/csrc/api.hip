@@ -10,9 +10,10 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st);
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a);
 int conv_small_fwd(const m2h_small_conv_args& a, hipStream_t st);
 thread_local int tl_small_tiling[10][5] = {};   // per-thread tiling override of the small-batch runner (m2h_unet_small_tiling): 0 = the table's
-extern int g_force_splitk, g_force_stages, g_wide_stages, g_skinny, g_narrow16, g_extra_lds, g_phase_major, g_fast_loader, g_wgrad_blocks, g_tapshare, g_tap_bm, g_tap_window, g_wgrad_row3x3, g_row3x3, g_skinny_linear, g_skinny_gather, g_big_tile, g_dma, g_dma_shape, g_quad, g_dma_split2, g_strip, g_patch;
-int g_small = -1;  // 1: the whole-network runner takes the small-batch engine (csrc/conv_small.hip) for rollout-size batches.  OFF by default:
-                   // measured at parity with the tiled engines (274 vs 282 us per separator pair at 14 envs), kept for the tests and further tuning
+thread_local Tuning tl_tuning = {};   // every knob 0 = automatic (m2h_internal.h)
+// knob 37 (g_small) = 1: the whole-network runner takes the small-batch engine (csrc/conv_small.hip) for rollout-size batches.  Off by
+// default: measured at parity with the tiled engines (274 vs 282 us per separator pair at 14 envs), kept for the tests and
+// further tuning
 extern thread_local int tl_math_mode;
 }  // namespace m2h
 
@@ -45,34 +46,22 @@ int m2h_set_math_mode(int mode) {
 
 int m2h_get_math_mode(void) { return tl_math_mode; }
 
-int m2h_debug_set(int knob, int value) {
-  if (knob == 0) g_force_splitk = value;
-  else if (knob == 1) g_force_stages = value;
-  else if (knob == 2) g_wide_stages = value;
-  else if (knob == 3) g_skinny = value;
-  else if (knob == 4) g_narrow16 = value;
-  else if (knob == 5 || knob == 6 || knob == 10 || knob == 12 || knob == 13 || knob == 17 || knob == 19 || knob == 20 || knob == 29 || knob == 31 || knob == 32) {}  // retired experiments (block stagger, ping-pong wave groups, 256-row narrow tiles, direct-operand narrow kernel, prefetch distance 4 on skinny tiles, 128x256 / 256x128 one-block-per-CU tiles in bf16x3 math, no split-K under a k-tile count, in-launch split-K reduction by the last-arriving block, the LDS-DMA engine's 256x64 tile and L2-friendly k-tile orders, the weights-in-registers first stage that the strip-walker kernel replaced): measured no gain, code removed
-  else if (knob == 7) g_extra_lds = value;
-  else if (knob == 8) g_phase_major = value;
-  else if (knob == 9) g_fast_loader = value;
-  else if (knob == 11) g_wgrad_blocks = value;
-  else if (knob == 14) return m2h_set_math_mode(value);
-  else if (knob == 15) g_tapshare = value;
-  else if (knob == 16) g_tap_bm = value;
-  else if (knob == 18) g_tap_window = value;
-  else if (knob == 21) g_wgrad_row3x3 = value;
-  else if (knob == 22) g_row3x3 = value;
-  else if (knob == 23) g_skinny_linear = value;
-  else if (knob == 24) g_skinny_gather = value;
-  else if (knob == 26) g_big_tile = value;
-  else if (knob == 27) g_dma = value;
-  else if (knob == 28) g_dma_shape = value;
-  else if (knob == 30) g_quad = value;
-  else if (knob == 34) g_dma_split2 = value;
-  else if (knob == 35) g_strip = value;
-  else if (knob == 36) g_patch = value;
-  else if (knob == 37) g_small = value;
-  else return fail(-1, "debug_set: unknown knob %d", knob);
+int m2h_tuning_set(int knob, int value) {
+  if (knob == 14) return m2h_set_math_mode(value);   // (kept for older callers; thread-local like the rest)
+  M2H_REQUIRE(knob >= 0 && knob < M2H_TUNING_KNOBS, "tuning_set: unknown knob %d", knob);
+  tl_tuning.v[knob] = value;   // numbers of experiments that were measured and removed are accepted and read by nothing
+  return 0;
+}
+
+int m2h_tuning_snapshot(int* out, int n) {
+  M2H_REQUIRE(out != nullptr && n == M2H_TUNING_KNOBS, "tuning_snapshot: need room for %d knobs", M2H_TUNING_KNOBS);
+  for (int i = 0; i < M2H_TUNING_KNOBS; ++i) out[i] = tl_tuning.v[i];
+  return 0;
+}
+
+int m2h_tuning_restore(const int* in, int n) {
+  M2H_REQUIRE(in != nullptr && n == M2H_TUNING_KNOBS, "tuning_restore: need %d knobs", M2H_TUNING_KNOBS);
+  for (int i = 0; i < M2H_TUNING_KNOBS; ++i) tl_tuning.v[i] = in[i];
   return 0;
 }
 

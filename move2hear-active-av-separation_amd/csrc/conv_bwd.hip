@@ -478,8 +478,8 @@ __global__ __launch_bounds__(256) void convT_wgrad_unpack_kernel(const WGradP p,
   if (ci0 + cl < p.Ctot) p.dw[((size_t)(ci0 + cl) * p.N + n) * 16 + e] = tile[cl][e];
 }
 
-int g_wgrad_blocks = 0;  // tuning knob (m2h_debug_set 11): target block count of a weight-gradient launch
-int g_wgrad_row3x3 = 0;  // -1: never use the image-row 3x3 kernel (m2h_debug_set 21)
+// (tuning knob g_wgrad_blocks: thread-local, m2h_internal.h) tuning knob (m2h_tuning_set 11): target block count of a weight-gradient launch
+// (tuning knob g_wgrad_row3x3: thread-local, m2h_internal.h) -1: never use the image-row 3x3 kernel (m2h_tuning_set 21)
 
 // block shape for (N, K): n extent, k sub-tiles per block, blocks along k
 static void wgrad_cfg(int N, int K, int& bng, int& kt, int& ktiles) {

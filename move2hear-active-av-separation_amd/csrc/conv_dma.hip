@@ -26,9 +26,9 @@
 
 namespace m2h {
 
-int g_dma_split2 = 0;   // m2h_debug_set 34: -1 = no two-way split-K on the 256 x 128 tile
-int g_dma_shape = 0;   // m2h_debug_set 28: 32 = v_mfma_f32_32x32x16_bf16 fragments instead of 16x16x32
-int g_dma = 0;   // m2h_debug_set 27: -1 never use this engine; 2 = also below its tile-count threshold (tests)
+// (tuning knob g_dma_split2: thread-local, m2h_internal.h) m2h_tuning_set 34: -1 = no two-way split-K on the 256 x 128 tile
+// (tuning knob g_dma_shape: thread-local, m2h_internal.h) m2h_tuning_set 28: 32 = v_mfma_f32_32x32x16_bf16 fragments instead of 16x16x32
+// (tuning knob g_dma: thread-local, m2h_internal.h) m2h_tuning_set 27: -1 never use this engine; 2 = also below its tile-count threshold (tests)
 
 __device__ __attribute__((aligned(128))) float g_zero_page[2048 + 32];   // 8 KiB + one row: source of padding rows at any channel offset
 

@@ -1013,23 +1013,23 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IGemmP p) {
   }
 }
 
-// Debug/tuning knobs (m2h_debug_set): 0 = automatic.
-int g_force_splitk = 0;   // >0: force this split-K factor (when workspace allows), -1: never split
-int g_force_stages = 0;   // 1 | 2: force the LDS stage count of the narrow-N configs
-int g_wide_stages = 0;    // 1 | 2: LDS stage count of the 128x128 config (0 = 2)
-int g_skinny = 0;         // -1: never use the 32/64-row tiles
-int g_extra_lds = 0;      // tuning experiment: dynamic LDS bytes added to every launch (lowers blocks/CU)
-int g_phase_major = 0;    // -1: transposed-conv phases as grid z (four passes over the input) instead of interleaved
+// Debug/tuning knobs (m2h_tuning_set): 0 = automatic.
+// (tuning knob g_force_splitk: thread-local, m2h_internal.h) >0: force this split-K factor (when workspace allows), -1: never split
+// (tuning knob g_force_stages: thread-local, m2h_internal.h) 1 | 2: force the LDS stage count of the narrow-N configs
+// (tuning knob g_wide_stages: thread-local, m2h_internal.h) 1 | 2: LDS stage count of the 128x128 config (0 = 2)
+// (tuning knob g_skinny: thread-local, m2h_internal.h) -1: never use the 32/64-row tiles
+// (tuning knob g_extra_lds: thread-local, m2h_internal.h) tuning experiment: dynamic LDS bytes added to every launch (lowers blocks/CU)
+// (tuning knob g_phase_major: thread-local, m2h_internal.h) -1: transposed-conv phases as grid z (four passes over the input) instead of interleaved
 static constexpr int M2H_FMT_LAYOUT_BITS = M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT | M2H_FMT_DST_SPLIT;   // operand_format minus the M2H_FMT_MATH_* bits
 thread_local int tl_math_mode = 0;   // m2h_set_math_mode: the calling thread's arithmetic (0 fp32 MFMA, 1 bf16x3 split products)
-int g_tapshare = 0;       // -1: never use the tap-sharing transposed-conv kernel
-int g_tap_bm = 0;         // 128: 128-output tiles only in the tap-sharing kernel
-int g_fast_loader = 0;    // -1: always use the generic (per-lane k decode) loader
-int g_narrow16 = 0;       // -1: never use the 16-wide (v_mfma_f32_16x16x4_f32) tile for N <= 16
-int g_skinny_linear = 0;   // -1: never use the skinny dense kernel for M <= 16
-int g_skinny_gather = 0;   // -1: never use the skinny gather kernel for 16 < M <= 256
-int g_row3x3 = 0;         // -1: never use the image-row 3x3 kernel
-int g_tap_window = 0;     // -1: walk every tap even where a whole kernel row / column lies in the zero padding
+// (tuning knob g_tapshare: thread-local, m2h_internal.h) -1: never use the tap-sharing transposed-conv kernel
+// (tuning knob g_tap_bm: thread-local, m2h_internal.h) 128: 128-output tiles only in the tap-sharing kernel
+// (tuning knob g_fast_loader: thread-local, m2h_internal.h) -1: always use the generic (per-lane k decode) loader
+// (tuning knob g_narrow16: thread-local, m2h_internal.h) -1: never use the 16-wide (v_mfma_f32_16x16x4_f32) tile for N <= 16
+// (tuning knob g_skinny_linear: thread-local, m2h_internal.h) -1: never use the skinny dense kernel for M <= 16
+// (tuning knob g_skinny_gather: thread-local, m2h_internal.h) -1: never use the skinny gather kernel for 16 < M <= 256
+// (tuning knob g_row3x3: thread-local, m2h_internal.h) -1: never use the image-row 3x3 kernel
+// (tuning knob g_tap_window: thread-local, m2h_internal.h) -1: walk every tap even where a whole kernel row / column lies in the zero padding
 
 // Tap window (see IGemmP): the contiguous range of kernel rows / columns that reach inside the image for at least one output
 // pixel.  conv: ih = q*stride + off + t*mul, q in [0, Q); transposed conv: both sub-pixel phases (mul = -1, +1, off = 0) must agree.
@@ -1124,7 +1124,7 @@ int choose_splitk(const IGemmP& p, int BM, int BN, size_t ws_bytes) {
   return S < 1 ? 1 : S;
 }
 
-int g_big_tile = 0;   // -1: never use the 256 x 128 eight-wave tile; > 0: minimum tile count for it (m2h_debug_set 26)
+// (tuning knob g_big_tile: thread-local, m2h_internal.h) -1: never use the 256 x 128 eight-wave tile; > 0: minimum tile count for it (m2h_tuning_set 26)
 
 // 256 x BN tile, 8 waves, two LDS stages, bf16x3 math on scalar-loader shapes only (no split-K: chosen when the tiles fill the chip)
 template <int BN>
@@ -1313,7 +1313,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
       a.Hq % (128 / a.Wq) == 0 && g_force_splitk <= 0 && g_phase_major >= 0 && M >= 128L * 256) {
     // 256-output tiles when the image geometry and the block count allow (bytes per output: see the kernel)
     // eight-wave blocks (one per CU): 256-output tiles for N = 64 by default (pair_ab, headline pair: 3.392 -> 3.364 ms); the
-    // 512-output tiles for N <= 32 measured no gain (3.388 / 3.388) and stay behind m2h_debug_set 16 = 512 (128 / 256 = the
+    // 512-output tiles for N <= 32 measured no gain (3.388 / 3.388) and stay behind m2h_tuning_set 16 = 512 (128 / 256 = the
     // four-wave tiles only)
     const int bm8 = p.N <= 32 ? 512 : 256;
     const bool wave8 = (g_tap_bm == 512 || (g_tap_bm == 0 && p.N > 32)) && bm8 / a.Wq >= 1 && a.Hq % (bm8 / a.Wq) == 0 && M >= (long)bm8 * 512;

@@ -44,7 +44,7 @@
 
 namespace m2h {
 
-int g_patch = 0;   // m2h_debug_set 36: -1 never use this engine; 2 = also below its tile-count threshold (tests); 3 = as 2, and the whole-image patch wherever it fits
+// (tuning knob g_patch: thread-local, m2h_internal.h) m2h_tuning_set 36: -1 never use this engine; 2 = also below its tile-count threshold (tests); 3 = as 2, and the whole-image patch wherever it fits
 
 __device__ __attribute__((aligned(128))) float g_zero_page_patch[2048 + 32];   // 8 KiB + one row: source of padding rows at any channel offset
 

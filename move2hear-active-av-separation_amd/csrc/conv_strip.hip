@@ -33,7 +33,7 @@
 
 namespace m2h {
 
-int g_strip = 0;   // m2h_debug_set 35: -1 = the runner never takes the strip-walker kernels (A/B against the tiled engines)
+// (tuning knob g_strip: thread-local, m2h_internal.h) m2h_tuning_set 35: -1 = the runner never takes the strip-walker kernels (A/B against the tiled engines)
 
 #ifndef M2H_STRIP_DEPTH
 #define M2H_STRIP_DEPTH 2   // fragment groups read ahead of their MFMAs

@@ -24,7 +24,7 @@
 
 namespace m2h {
 
-int g_quad = 0;   // m2h_debug_set 30: -1 never use this kernel; 1 = wherever its shape conditions hold (also N <= 16 and few output blocks)
+// (tuning knob g_quad: thread-local, m2h_internal.h) m2h_tuning_set 30: -1 never use this kernel; 1 = wherever its shape conditions hold (also N <= 16 and few output blocks)
 
 extern __device__ float g_zero_page_quad[];
 __device__ __attribute__((aligned(128))) float g_zero_page_quad[2048 + 32];

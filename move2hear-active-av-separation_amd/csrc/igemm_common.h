@@ -434,7 +434,6 @@ __device__ __forceinline__ void fused_epilogue(const IGemmP& p, AccT (&acc)[BM /
 
 // conv_igemm.hip: split-K factor of a launch on BM x BN tiles (the one rule of both engines: equal factors keep their results bit-identical)
 int choose_splitk(const IGemmP& p, int BM, int BN, size_t ws_bytes);
-extern int g_big_tile;
 
 // conv_dma.hip: LDS-DMA engine; returns -2 when the launch is not one of its shapes (the caller falls through), 0 / error otherwise
 int launch_igemm_dma(IGemmP& p, size_t ws_bytes, hipStream_t st);

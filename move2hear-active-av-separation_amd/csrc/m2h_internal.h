@@ -5,6 +5,7 @@
 #include <cstdio>
 
 #include "m2h.h"
+#include "m2h_tuning.h"
 
 namespace m2h {
 
@@ -17,6 +18,40 @@ inline int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+
+
+// Tuning / test knobs of the dispatch code: which of several kernels that compute the same values a launch takes (engine-vs-engine
+// tests, A/B timing).  THREAD-LOCAL like the arithmetic mode -- the library holds no process-global mutable state: every
+// launch reads the knobs of the host thread that makes it; m2h_tuning_set / _snapshot / _restore (include/m2h_tuning.h) are the only
+// writers, and m2h.functional carries a forward pass's knobs into the autograd thread that runs its backward.  Index = knob number.
+struct Tuning {
+  int v[M2H_TUNING_KNOBS];
+};
+extern thread_local Tuning tl_tuning;
+#define g_force_splitk (::m2h::tl_tuning.v[0])
+#define g_force_stages (::m2h::tl_tuning.v[1])
+#define g_wide_stages (::m2h::tl_tuning.v[2])
+#define g_skinny (::m2h::tl_tuning.v[3])
+#define g_narrow16 (::m2h::tl_tuning.v[4])
+#define g_extra_lds (::m2h::tl_tuning.v[7])
+#define g_phase_major (::m2h::tl_tuning.v[8])
+#define g_fast_loader (::m2h::tl_tuning.v[9])
+#define g_wgrad_blocks (::m2h::tl_tuning.v[11])
+#define g_tapshare (::m2h::tl_tuning.v[15])
+#define g_tap_bm (::m2h::tl_tuning.v[16])
+#define g_tap_window (::m2h::tl_tuning.v[18])
+#define g_wgrad_row3x3 (::m2h::tl_tuning.v[21])
+#define g_row3x3 (::m2h::tl_tuning.v[22])
+#define g_skinny_linear (::m2h::tl_tuning.v[23])
+#define g_skinny_gather (::m2h::tl_tuning.v[24])
+#define g_big_tile (::m2h::tl_tuning.v[26])
+#define g_dma (::m2h::tl_tuning.v[27])
+#define g_dma_shape (::m2h::tl_tuning.v[28])
+#define g_quad (::m2h::tl_tuning.v[30])
+#define g_dma_split2 (::m2h::tl_tuning.v[34])
+#define g_strip (::m2h::tl_tuning.v[35])
+#define g_patch (::m2h::tl_tuning.v[36])
+#define g_small (::m2h::tl_tuning.v[37])
 
 // Label of the calling thread's most recent kernel launch (the `what` of launch_status: every launch site names its kernel family):
 // read back by m2h_last_kernel / m2h_unet_fwd_stage_kernel, so that benchmark tables name the kernel that really ran.

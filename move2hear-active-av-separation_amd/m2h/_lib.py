@@ -26,7 +26,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "m2h_internal.h"), os.path.join(CSRC, "igemm_common.h"), os.path.join(CSRC, "lds_dma.h"), os.path.join(INCLUDE, "m2h.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "m2h_internal.h"), os.path.join(CSRC, "igemm_common.h"), os.path.join(CSRC, "lds_dma.h"), os.path.join(INCLUDE, "m2h.h"), os.path.join(INCLUDE, "m2h_tuning.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -156,6 +156,7 @@ class PackItem(ctypes.Structure):
 PACK_BATCH_MAX = 48
 PACK_CONV, PACK_CONVT, PACK_DGRAD, PACK_FC_DGRAD = 0, 1, 2, 3
 STEP_STATS_CHUNKS = 16
+TUNING_KNOBS = 40   # include/m2h_tuning.h
 ROWS_COPY_MAX = 32
 
 
@@ -180,7 +181,9 @@ SIGNATURES = {
     "m2h_fold_bn": [_P, _P, _P, _P, _F, _P, _P, _I, _P],
     "m2h_conv_igemm_f32": [ctypes.POINTER(ConvArgs), _P],
     "m2h_conv_igemm_workspace_bytes": [ctypes.POINTER(ConvArgs)],
-    "m2h_debug_set": [_I, _I],
+    "m2h_tuning_set": [_I, _I],
+    "m2h_tuning_snapshot": [_P, _I],
+    "m2h_tuning_restore": [_P, _I],
     "m2h_set_math_mode": [_I],
     "m2h_get_math_mode": [],
     "m2h_unet_down_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P],

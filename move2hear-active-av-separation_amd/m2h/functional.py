@@ -16,6 +16,15 @@ import torch
 from . import _lib, ops
 
 
+_carry_tuning = [False]   # set by carry_tuning(): tests / tools that A/B engines through a backward pass
+
+
+def carry_tuning(on=True):
+    """Make the autograd Functions below carry the forward thread's TUNING KNOBS (ops.debug_set) into their backward, as they always
+    carry its arithmetic mode.  Off by default: production code sets no knobs, and the snapshot is a library call per Function."""
+    _carry_tuning[0] = bool(on)
+
+
 def carries_math_mode(cls):
     """Class decorator for the autograd Functions whose backward launches igemm-engine kernels: the forward records the calling
     thread's arithmetic (ops.math_mode(), thread-local) and the backward -- which autograd runs on ITS thread -- computes in it."""
@@ -23,10 +32,14 @@ def carries_math_mode(cls):
 
     def forward(ctx, *args):
         ctx._m2h_math = ops.math_mode()
+        ctx._m2h_tuning = ops.tuning_snapshot() if _carry_tuning[0] else None
         return fwd(ctx, *args)
 
     def backward(ctx, *grads):
         with ops.math_scope(ctx._m2h_math):
+            if ctx._m2h_tuning is not None:     # the forward thread's tuning knobs (thread-local in the library, include/m2h_tuning.h)
+                with ops.tuning_scope(ctx._m2h_tuning):
+                    return bwd(ctx, *grads)
             return bwd(ctx, *grads)
 
     cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
@@ -314,7 +327,7 @@ class Conv2dNHWC(torch.autograd.Function):
             if gated:
                 try:
                     dwp = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, gate=y, gate_slope=slope)
-                except RuntimeError:        # the library refused (image-row kernel switched off: m2h_debug_set(21, -1)): two passes
+                except RuntimeError:        # the library refused (image-row kernel switched off: m2h_tuning_set(21, -1)): two passes
                     dy = act_bwd(dy, y, slope)
             if dwp is None:
                 dwp = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad)  # [Co, KH*KW*c_in]

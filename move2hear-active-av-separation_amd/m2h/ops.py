@@ -68,7 +68,36 @@ def _workspace(nbytes, dev):
 
 
 def debug_set(knob, value):
-    _lib.check(_lib.load().m2h_debug_set(int(knob), int(value)), "m2h_debug_set")
+    """Tuning / test knob of the CALLING THREAD (m2h_tuning_set, include/m2h_tuning.h): which of several kernels computing the same values
+    the library's dispatch takes.  Thread-local like the arithmetic mode; autograd Functions carry a forward's knobs into their backward
+    (functional.carries_math_mode)."""
+    _lib.check(_lib.load().m2h_tuning_set(int(knob), int(value)), "m2h_tuning_set")
+
+
+def tuning_snapshot():
+    """The calling thread's tuning knobs as a ctypes int array (m2h_tuning_snapshot)."""
+    arr = (ctypes.c_int * _lib.TUNING_KNOBS)()
+    _lib.check(_lib.load().m2h_tuning_snapshot(arr, _lib.TUNING_KNOBS), "m2h_tuning_snapshot")
+    return arr
+
+
+def tuning_restore(arr):
+    _lib.check(_lib.load().m2h_tuning_restore(arr, _lib.TUNING_KNOBS), "m2h_tuning_restore")
+
+
+class tuning_scope:
+    """``with ops.tuning_scope(snapshot):`` -- the calling thread dispatches with the given knobs inside the block, with its own after."""
+
+    def __init__(self, arr):
+        self.arr = arr
+
+    def __enter__(self):
+        self.prev = tuning_snapshot()
+        tuning_restore(self.arr)
+
+    def __exit__(self, *exc):
+        tuning_restore(self.prev)
+        return False
 
 
 MATH_FP32, MATH_BF16X3 = 0, 1

@@ -18,3 +18,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _carry_tuning_knobs_into_backward_passes():
+    """Tests A/B the library's engines through thread-local tuning knobs (ops.debug_set); autograd runs backward passes on its own
+    thread, so the autograd Functions are told to carry the forward thread's knobs along (m2h.functional.carry_tuning)."""
+    from m2h import functional as MF
+    MF.carry_tuning(True)
+    yield
+    MF.carry_tuning(False)

@@ -9,8 +9,8 @@ from m2h import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "m2h.h")).read()
+def _declared_symbols(header="m2h.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(m2h_[a-z0-9_A-Z]+)\s*\(", txt)))
 
@@ -23,9 +23,39 @@ def test_library_builds_and_exports_header_symbols():
     assert "m2h_conv_igemm_f32" in syms and "m2h_unet_down_fwd" in syms
     for s in syms:
         assert hasattr(lib, s), "libm2h.so does not export %s" % s
+    # the diagnostic surface (thread-local tuning knobs) lives in its own header, outside the product contract
+    diag = _declared_symbols("m2h_tuning.h")
+    assert diag == ["m2h_tuning_restore", "m2h_tuning_set", "m2h_tuning_snapshot"] and not set(diag) & set(syms)
+    assert "m2h_debug_set" not in syms and not hasattr(lib, "m2h_debug_set")
+    for s in diag:
+        assert hasattr(lib, s), "libm2h.so does not export %s" % s
     # the ctypes binding covers every declared function
     bound = set(_lib.SIGNATURES) | {"m2h_last_error"}
-    assert set(syms) == bound, (set(syms) ^ bound)
+    assert set(syms) | set(diag) == bound, ((set(syms) | set(diag)) ^ bound)
+
+
+def test_tuning_knobs_are_thread_local():
+    """no process-global mutable state -- a knob set by one host thread is not seen by another (runs without a GPU)."""
+    import threading
+    lib = _lib.load()
+    n = _lib.TUNING_KNOBS
+    assert lib.m2h_tuning_set(24, 7) == 0
+    seen = {}
+
+    def other():
+        arr = (ctypes.c_int * n)()
+        assert lib.m2h_tuning_snapshot(arr, n) == 0
+        seen["other"] = list(arr)
+        assert lib.m2h_tuning_set(24, -1) == 0
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    mine = (ctypes.c_int * n)()
+    assert lib.m2h_tuning_snapshot(mine, n) == 0
+    assert seen["other"] == [0] * n and mine[24] == 7
+    zero = (ctypes.c_int * n)()
+    assert lib.m2h_tuning_restore(zero, n) == 0 and lib.m2h_tuning_set(n, 1) < 0
 
 
 def test_version_and_error_string_without_gpu():

@@ -1,6 +1,6 @@
 """GPU: the strip-walker kernels (csrc/conv_strip.hip) -- slice + first encoder stage in one launch, last decoder stage + head
 in one launch -- against the CPU oracle's layers (separator_cnn.py:73-105, :128-135, :153-168) and against the tiled engines the
-runner used before (m2h_debug_set 35 = -1), through the C-ABI.  bf16x3 arithmetic: held to 1e-5 rel-L1 like the other
+runner used before (m2h_tuning_set 35 = -1), through the C-ABI.  bf16x3 arithmetic: held to 1e-5 rel-L1 like the other
 engine-vs-engine tests (contract 1e-3)."""
 import numpy as np
 import pytest
@@ -92,7 +92,7 @@ def test_strip_last_stage_matches_the_oracle_layer(B, W, Co):
 @pytest.mark.parametrize("B,tm", [(3, 64), (1, 256), (2, 128)])
 def test_runner_with_strip_kernels_matches_the_tiled_engines(B, tm):
     """The whole separator pair through m2h_unet_fwd with the strip kernels (default) against the same call with them switched
-    off (m2h_debug_set 35 = -1: slice kernel + tiled first stage, tiled last stage), and against the oracle."""
+    off (m2h_tuning_set 35 = -1: slice kernel + tiled first stage, tiled last stage), and against the oracle."""
     from m2h import ops
     dev = _dev()
     pol, sd = _policy(3, dev)

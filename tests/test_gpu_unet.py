@@ -266,7 +266,7 @@ def test_whole_network_runner_is_bitwise_the_module_chain(mode):
 def test_dma_engine_matches_register_engine(B, tm):
     """The LDS-DMA engine (csrc/conv_dma.hip: split32 operands DMA'd into an LDS ring, fragments read through a row permutation)
     against the register-staged engine on the whole runner pair -- plain and transposed convs, the skip concat's second source,
-    zero-padded borders, rows past M, the class plane, split32 output.  Forced on every wide layer (m2h_debug_set 27 = 2: its
+    zero-padded borders, rows past M, the class plane, split32 output.  Forced on every wide layer (m2h_tuning_set 27 = 2: its
     256 x 128 tile also below the tile-count threshold) since the test batches are too small for the automatic choice.  With
     32x32x16 fragments (knob 28 = 32) the two engines run the same products in the same order: bit-identical; with the default
     16x16x32 fragments the fp32 sums associate differently: equal to summation order.  Then the four-phase transposed-conv kernel
@@ -305,7 +305,7 @@ def test_dma_engine_matches_register_engine(B, tm):
         assert not torch.equal(got[0], ref[0])     # the engine really ran (another summation order)
         again = run(2, 0, -1)
         assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1])
-        # the four-phase transposed-conv kernel on every decoder stage it takes (m2h_debug_set 30 = 1: also below its block-count
+        # the four-phase transposed-conv kernel on every decoder stage it takes (m2h_tuning_set 30 = 1: also below its block-count
         # threshold), the other layers on the register engine: its sums run (chunk, half, tap) instead of (chunk, tap, half)
         ref = run(-1, 0)
         quad = run(-1, 0, 0, 1)

@@ -19,6 +19,23 @@ def show(title, a, b):
         print("  %-72s %7.1f us  gap %5.1f  grid %s/%s" % (names[i], (en[i] - st[i]) / 1e3, (st[i] - en[i - 1]) / 1e3, grid[i][0], grid[i][1]))
 idx = [i for i, n in enumerate(names) if n.startswith("step_index_advance")]
 show("one replayed rollout step", idx[len(idx) // 2], idx[len(idx) // 2 + 1])
+# gaps inside replayed steps, over all of them: how much of a step is the device waiting between two kernels of the chain?
+import collections
+walls, gaps, where = [], [], collections.Counter()
+for a, b in zip(idx[:-1], idx[1:]):
+    if b - a > 80 or b - a < 30:
+        continue   # an update phase lies in between / not a whole step
+    g = [(st[i] - en[i - 1]) / 1e3 for i in range(a + 2, b + 1)]   # (the first gap of a step is the graph launch itself)
+    walls.append((en[b] - en[a]) / 1e3)
+    gaps.append(sum(x for x in g if x > 1.0))
+    for k, x in enumerate(g):
+        if x > 5.0:
+            where[names[a + 2 + k][:40]] += 1
+if walls:
+    import statistics as S
+    print("all %d replayed steps: wall median %.1f mean %.1f p90 %.1f us; in-chain gaps > 1 us per step: median %.1f mean %.1f p90 %.1f us" % (
+        len(walls), S.median(walls), S.mean(walls), sorted(walls)[int(0.9 * len(walls))], S.median(gaps), S.mean(gaps), sorted(gaps)[int(0.9 * len(gaps))]))
+    print("kernels most often preceded by a gap > 5 us:", where.most_common(8))
 idx = [i for i, n in enumerate(names) if n.startswith("ppo_loss")]
 show("one update_pol epoch (between two ppo_loss launches)", idx[-3], idx[-2])
 idx = [i for i, n in enumerate(names) if n.startswith("l1_loss")]

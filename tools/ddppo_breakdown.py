@@ -16,7 +16,7 @@ from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config  # noqa: E402
 
 def main():
     dev = torch.device("cuda", 0)
-    for kv in os.environ.get("M2H_KNOBS", "").split(","):   # e.g. M2H_KNOBS=24=4096 (m2h_debug_set knob=value)
+    for kv in os.environ.get("M2H_KNOBS", "").split(","):   # e.g. M2H_KNOBS=24=4096 (m2h_tuning_set knob=value)
         if kv:
             k, v = kv.split("=")
             ops.debug_set(int(k), int(v))

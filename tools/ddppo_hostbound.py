@@ -17,7 +17,7 @@ from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config  # noqa: E402
 def main():
     from m2h import ops
     for a in sys.argv[1:]:
-        if a.startswith("--knob="):   # --knob=19:16 -> m2h_debug_set(19, 16)
+        if a.startswith("--knob="):   # --knob=19:16 -> m2h_tuning_set(19, 16)
             k, v = a[7:].split(":")
             ops.debug_set(int(k), int(v))
     if "--bf16x3" in sys.argv:

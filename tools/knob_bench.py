@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py under one m2h_debug_set knob (tuning tool): python tools/knob_bench.py KNOB VALUE [bench.py arguments ...]
+"""bench.py under one m2h_tuning_set knob (tuning tool): python tools/knob_bench.py KNOB VALUE [bench.py arguments ...]
 e.g. tools/knob_bench.py 24 4096 --ddppo-cycles 2 --no-far-target --train-steps 0   (measured: the skinny gather kernel's pixel limit
 1024 / 4096 / 16384 leaves the DD-PPO cycle at 9.5-9.7 K env-steps/s)."""
 import sys, os

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Interleaved A/B timing of the headline separator pair under different m2h_debug_set knob settings (tuning tool, not a test).
+"""Interleaved A/B timing of the headline separator pair under different m2h_tuning_set knob settings (tuning tool, not a test).
 
 Two bench.py runs land on different boxes and clock states (+-5 %); here every variant's HIP graph is captured once and the
 variants are replayed round-robin, so a difference of a per cent or two between them is visible.
