@@ -326,7 +326,9 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
   int rc = mark();
   if (rc) return rc;
   // slice + first encoder stage as one strip-walker launch (csrc/conv_strip.hip) where its shape conditions hold
-  const bool strip0 = sp && wts->down0_strip != nullptr && T % 64 == 0 && g_strip >= 0;
+  // (the strip walkers index pixels with 32 bits: batches beyond that fall back to the tiled engines instead of failing)
+  const bool strip_fits = (size_t)B * 512 * T * 2 < (1ull << 31);
+  const bool strip0 = sp && wts->down0_strip != nullptr && T % 64 == 0 && g_strip >= 0 && strip_fits;
   if (!strip0) {
     rc = m2h_sep_slice_input_fmt(mix, masks, x0, B, F, T, 2, sp, stream);
     if (rc) return rc;
@@ -365,7 +367,7 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
     h *= 2; w *= 2;
   }
   // last stage + 1x1 head + de-slice in one kernel: the strip walker where its shape conditions hold
-  if (sp && T % 64 == 0 && g_strip >= 0 && wts->down0_strip != nullptr) {
+  if (sp && T % 64 == 0 && g_strip >= 0 && wts->down0_strip != nullptr && strip_fits && (long)B * h * w * 64 < (1L << 31)) {
     M2H_REQUIRE(wts->head_w != nullptr && wts->head_b != nullptr, "unet_fwd: null head");
     if ((rc = m2h_strip_last_fwd(cur, e[0], wts->up_w[4], wts->up_scale[4], wts->up_shift[4], wts->head_w, wts->head_b, out, B, h, w, dco[4], stream)))
       return rc;

@@ -48,7 +48,10 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackBatchArgs a) 
   const int m = b / tiles, o0 = (b - m * tiles) * PACK_TILE;
   const bool mid_valid = it.kind != M2H_PACK_FC_DGRAD || m < it.p[4];     // FC_DGRAD: padded input channels are zero rows
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  const bool vec = T == 16;   // every 4x4 kernel (all of both U-Nets): one 16-byte load and one 16-byte store per thread
+  // every 4x4 kernel (all of both U-Nets): one 16-byte load and one 16-byte store per thread -- where the source weight is 16-byte
+  // aligned (parameters sit back to back in FlatAdam's flat buffer: a 4x4 weight behind a 1- or 3-element bias is only 4-byte aligned;
+  // block-uniform, so no divergence)
+  const bool vec = T == 16 && (reinterpret_cast<size_t>(w) & 15) == 0;
   if (vec) {
     const int o = threadIdx.x >> 2, c = threadIdx.x & 3;
     const int og = o0 + o;

@@ -255,7 +255,7 @@ class PPOTrainer:
         if gs is None:
             dev = self.device
             gs = self._graph_state = SimpleNamespace(
-                graphs={}, pool=None, where=None, idx=torch.zeros(3, dtype=torch.int64, device=dev), expect=None, epoch=None,
+                graphs={}, pool=None, where=None, idx=torch.zeros(3, dtype=torch.int64, device=dev), expect=None, epoch=None, noise_rows=None,
                 cache=tuple(torch.empty_like(t) for t in self._next_cache))
         if self._next_cache[0] is not gs.cache[0]:  # the previous step ran outside the graphs: hand its outputs over
             for dst, src in zip(gs.cache, self._next_cache):
@@ -286,7 +286,12 @@ class PPOTrainer:
             if gs.pool is None:
                 gs.pool = g.pool()
             gs.graphs[key] = g
-        self.actor_critic.stage_action_noise(self.envs.num_envs)  # cpu_generator sampling: this step's noise, drawn on the host
+            gs.noise_rows = self.envs.num_envs     # the captured act() reads the static [rows, actions] noise buffer of THIS row count
+        if gs.noise_rows != self.envs.num_envs:
+            raise RuntimeError("m2h PPOTrainer: the rollout graph was captured for %d envs, the env now has %d" % (gs.noise_rows, self.envs.num_envs))
+        # cpu_generator sampling: a graph that contains sample() must be replayed through here -- the noise of THIS step is drawn on
+        # the host and staged into the buffer the graph reads before every replay (a bare g.replay() would re-use the last step's)
+        self.actor_critic.stage_action_noise(self.envs.num_envs)
         g.replay()
         gs.expect = ((ro.step + 1) % ro.num_steps, (rs.step + 1) % rs.num_steps)
 
