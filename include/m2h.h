@@ -497,6 +497,13 @@ int m2h_gru_bwd_combine(const float* a, const float* b, const float* c, const fl
  * whh_t: W_hh^T as [H][3H] (m2h_pack_dgrad_weight of weight_hh_l0); a may be NULL.  H % 16 == 0. */
 int m2h_gru_bwd_rec(const float* dpre, const float* whh_t, const float* a, const float* dhp, const float* mask, float* out, int M, int H,
                     m2h_stream stream);
+/* m2h_gru_bwd_rec of time step t followed, in the same launch, by m2h_gru_gates_bwd of step t-1 with dh = the out just produced
+ * (the gate backward is elementwise in (row, hidden unit): each thread continues with the element it wrote): one launch per BPTT
+ * step.  *_prev: step t-1's gi, gh_raw, its previous hidden state and mask (inputs), dgi, dpre, hpm (outputs); dhp is read
+ * (step t's) and rewritten (step t-1's) in place.  dpre_prev must not alias dpre. */
+int m2h_gru_bwd_step(const float* dpre, const float* whh_t, const float* a, float* dhp, const float* mask, float* out, const float* gi_prev,
+                     const float* gh_prev, const float* bhh, const float* hprev_prev, const float* mask_prev, float* dgi_prev, float* dpre_prev,
+                     float* hpm_prev, int M, int H, m2h_stream stream);
 
 /* Backward of m2h_policy_heads: g_value[M], g_logp[M], g_ent[M] = dL/d(value | logp_act | entropy row) (each may be NULL); dz [M][ZS] receives
  * (dL/dlogits[0..A), dL/dvalue, 0...) with ZS = A+1 rounded up to a multiple of 4; dfeats [M][H]. */

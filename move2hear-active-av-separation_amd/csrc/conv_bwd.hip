@@ -660,6 +660,7 @@ static int bias_grad_splits(int M, int N) {
   int splits = (1024 + colblocks - 1) / colblocks;  // ~4 blocks per CU
   if (splits > (M + 63) / 64) splits = (M + 63) / 64;  // at least 64 rows per split
   if (splits < 1) splits = 1;
+  if (M <= 1024) splits = 1;   // a few hundred rows (the update batch's Linear / GRU layers): one stage, straight into db -- no second launch
   return splits;
 }
 
@@ -725,6 +726,10 @@ int m2h_bias_grad(const float* dy, float* db, int M, int N, float* workspace, m2
   M2H_REQUIRE(dy && db && workspace && M > 0 && N > 0, "bias_grad: bad arguments");
   const int splits = bias_grad_splits(M, N);
   const int rps = (M + splits - 1) / splits;
+  if (splits == 1) {   // the one split's "partial" IS the column sum
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, as_stream(stream), dy, db, M, N, rps);
+    return launch_status("bias_grad");
+  }
   hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, as_stream(stream), dy, workspace, M, N, rps);
   hipLaunchKernelGGL(bias_grad_final_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), workspace, db, N, splits);
   return launch_status("bias_grad");

@@ -682,9 +682,17 @@ __global__ void gru_bwd_combine_kernel(const float* __restrict__ a, const float*
 // of W_hh^T and runs their 3H-long dot products with the 16 rows of dpre through skinny_dot16 (the 16-wide tile's other columns
 // repeat the last row); the four waves' partial tiles meet through LDS in wave order.
 constexpr int GB_U = 4, GB_E = 16;
+// With the *_p arguments (gi_p != nullptr) the gate backward of the PREVIOUS time step (gru_gates_bwd_kernel over this block's
+// columns: it is elementwise in (row, hidden unit), and its dh is exactly the out element the thread has just produced) runs as this
+// kernel's epilogue: one launch per BPTT step instead of two.  dhp is read (this step's) and rewritten (the previous step's) by the
+// same thread at the same element.
 __global__ __launch_bounds__(256) void gru_bwd_rec_kernel(const float* __restrict__ dpre, const float* __restrict__ whh_t,
-                                                          const float* __restrict__ a, const float* __restrict__ dhp,
-                                                          const float* __restrict__ mask, float* __restrict__ out, int M, int H) {
+                                                          const float* __restrict__ a, float* __restrict__ dhp,
+                                                          const float* __restrict__ mask, float* __restrict__ out, int M, int H,
+                                                          const float* __restrict__ gi_p = nullptr, const float* __restrict__ gh_p = nullptr,
+                                                          const float* __restrict__ bhh = nullptr, const float* __restrict__ hprev_p = nullptr,
+                                                          const float* __restrict__ mask_p = nullptr, float* __restrict__ dgi_p = nullptr,
+                                                          float* __restrict__ dpre_p = nullptr, float* __restrict__ hpm_p = nullptr) {
   __shared__ float R[4][16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
@@ -700,7 +708,32 @@ __global__ __launch_bounds__(256) void gru_bwd_rec_kernel(const float* __restric
     const float rec = (R[0][m][u] + R[1][m][u]) + (R[2][m][u] + R[3][m][u]);
     const size_t o = (size_t)m * H + j0 + u;
     const float mk = mask != nullptr ? mask[m] : 1.f;
-    out[o] = (a != nullptr ? a[o] : 0.f) + mk * (rec + dhp[o]);
+    const float g = (a != nullptr ? a[o] : 0.f) + mk * (rec + dhp[o]);
+    out[o] = g;
+    if (gi_p != nullptr) {                 // gru_gates_bwd_kernel of the previous step at (row m, unit j), dh = g
+      const int j = j0 + u;
+      const float mp = mask_p != nullptr ? mask_p[m] : 1.f;
+      const size_t o3 = (size_t)m * 3 * H;
+      const float r = sigmoidf_(gi_p[o3 + j] + (mp * gh_p[o3 + j] + bhh[j]));
+      const float z = sigmoidf_(gi_p[o3 + H + j] + (mp * gh_p[o3 + H + j] + bhh[H + j]));
+      const float hn = mp * gh_p[o3 + 2 * H + j] + bhh[2 * H + j];
+      const float n = tanhf(gi_p[o3 + 2 * H + j] + r * hn);
+      const float hp = mp * hprev_p[o];
+      const float dn = g * (1.f - z);
+      const float dz = g * (hp - n);
+      const float dan = dn * (1.f - n * n);
+      const float dr = dan * hn;
+      const float daz = dz * z * (1.f - z);
+      const float dar = dr * r * (1.f - r);
+      dgi_p[o3 + j] = dar;
+      dgi_p[o3 + H + j] = daz;
+      dgi_p[o3 + 2 * H + j] = dan;
+      dpre_p[o3 + j] = dar;
+      dpre_p[o3 + H + j] = daz;
+      dpre_p[o3 + 2 * H + j] = dan * r;
+      dhp[o] = g * z;
+      hpm_p[o] = hp;
+    }
   }
 }
 
@@ -998,8 +1031,23 @@ int m2h_gru_bwd_rec(const float* dpre, const float* whh_t, const float* a, const
   M2H_REQUIRE(dpre && whh_t && dhp && out, "gru_bwd_rec: null pointer");
   M2H_REQUIRE(M > 0 && M <= GB_E && H > 0 && H % 16 == 0, "gru_bwd_rec: needs 1 <= M <= %d rows and H %% 16 == 0 (got M=%d, H=%d)",
               GB_E, M, H);
-  hipLaunchKernelGGL(gru_bwd_rec_kernel, dim3(H / GB_U), dim3(256), 0, as_stream(stream), dpre, whh_t, a, dhp, mask, out, M, H);
+  hipLaunchKernelGGL(gru_bwd_rec_kernel, dim3(H / GB_U), dim3(256), 0, as_stream(stream), dpre, whh_t, a, const_cast<float*>(dhp), mask, out, M, H,
+                     static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), static_cast<const float*>(nullptr),
+                     static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), static_cast<float*>(nullptr),
+                     static_cast<float*>(nullptr), static_cast<float*>(nullptr));
   return launch_status("gru_bwd_rec");
+}
+
+int m2h_gru_bwd_step(const float* dpre, const float* whh_t, const float* a, float* dhp, const float* mask, float* out, const float* gi_prev,
+                     const float* gh_prev, const float* bhh, const float* hprev_prev, const float* mask_prev, float* dgi_prev, float* dpre_prev,
+                     float* hpm_prev, int M, int H, m2h_stream stream) {
+  M2H_REQUIRE(dpre && whh_t && dhp && out && gi_prev && gh_prev && bhh && hprev_prev && dgi_prev && dpre_prev && hpm_prev, "gru_bwd_step: null pointer");
+  M2H_REQUIRE(M > 0 && M <= GB_E && H > 0 && H % 16 == 0, "gru_bwd_step: needs 1 <= M <= %d rows and H %% 16 == 0 (got M=%d, H=%d)",
+              GB_E, M, H);
+  M2H_REQUIRE(dpre_prev != dpre, "gru_bwd_step: the previous step's dpre must not alias this step's (every block reads all of it)");
+  hipLaunchKernelGGL(gru_bwd_rec_kernel, dim3(H / GB_U), dim3(256), 0, as_stream(stream), dpre, whh_t, a, dhp, mask, out, M, H, gi_prev, gh_prev, bhh,
+                     hprev_prev, mask_prev, dgi_prev, dpre_prev, hpm_prev);
+  return launch_status("gru_bwd_step");
 }
 
 int m2h_policy_heads_bwd(const float* logp_all, const float* probs, const long long* actions, const float* g_value, const float* g_logp,

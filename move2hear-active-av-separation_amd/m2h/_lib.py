@@ -208,6 +208,7 @@ SIGNATURES = {
     "m2h_gru_gates_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_gru_bwd_combine": [_P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_gru_bwd_rec": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "m2h_gru_bwd_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_policy_heads_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "m2h_l1_loss": [_P, _P, _I, _I, _P, _P, _P, _Z, _P],
     "m2h_bin_l1_loss": [_P, _P, _P, _I, _I, _P, _P, _P, _Z, _P],

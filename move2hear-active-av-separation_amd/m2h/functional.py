@@ -425,15 +425,25 @@ class GRUSequence(torch.autograd.Function):
             dh = dh + g_hT  # tiny [N,H] add; hT is rarely used downstream
         dh = dh.contiguous()
         with torch.cuda.device(dev):
+            h0c = h0.contiguous()
             for t in range(T - 1, -1, -1):
                 sl = slice(t * N, (t + 1) * N)
-                hprev = out[(t - 1) * N:t * N] if t > 0 else h0
-                _lib.check(lib.m2h_gru_gates_bwd(ops._ptr(gi[sl]), ops._ptr(gh[sl]), ops._ptr(b_hh), ops._ptr(hprev.contiguous()),
-                                                 ops._ptr(masks[sl]), ops._ptr(dh), ops._ptr(dgi[sl]), ops._ptr(dpre[sl]), ops._ptr(dhp),
-                                                 ops._ptr(hpm[sl]), N, H, ops._stream(x)), "m2h_gru_gates_bwd")
+                hprev = out[(t - 1) * N:t * N] if t > 0 else h0c
+                if not fused or t == T - 1:   # (at the rollout width every later step's gate backward rides on the step after it)
+                    _lib.check(lib.m2h_gru_gates_bwd(ops._ptr(gi[sl]), ops._ptr(gh[sl]), ops._ptr(b_hh), ops._ptr(hprev),
+                                                     ops._ptr(masks[sl]), ops._ptr(dh), ops._ptr(dgi[sl]), ops._ptr(dpre[sl]), ops._ptr(dhp),
+                                                     ops._ptr(hpm[sl]), N, H, ops._stream(x)), "m2h_gru_gates_bwd")
                 nxt = torch.empty((N, H), device=dev)
                 a = g_out[(t - 1) * N:t * N] if t > 0 else None
-                if fused:  # rollout width: recurrent product + combine in one launch
+                if fused and t > 0:
+                    # recurrent product + combine of step t, then the gate backward of step t - 1 on the dh just produced: ONE launch
+                    sp = slice((t - 1) * N, t * N)
+                    hpp = out[(t - 2) * N:(t - 1) * N] if t > 1 else h0c
+                    _lib.check(lib.m2h_gru_bwd_step(ops._ptr(dpre[sl]), ops._ptr(whh_t), ops._ptr(a), ops._ptr(dhp), ops._ptr(masks[sl]),
+                                                    ops._ptr(nxt), ops._ptr(gi[sp]), ops._ptr(gh[sp]), ops._ptr(b_hh), ops._ptr(hpp),
+                                                    ops._ptr(masks[sp]), ops._ptr(dgi[sp]), ops._ptr(dpre[sp]), ops._ptr(hpm[sp]), N, H,
+                                                    ops._stream(x)), "m2h_gru_bwd_step")
+                elif fused:  # rollout width: recurrent product + combine in one launch
                     _lib.check(lib.m2h_gru_bwd_rec(ops._ptr(dpre[sl]), ops._ptr(whh_t), ops._ptr(a), ops._ptr(dhp), ops._ptr(masks[sl]),
                                                    ops._ptr(nxt), N, H, ops._stream(x)), "m2h_gru_bwd_rec")
                 else:
