@@ -35,6 +35,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
         self.coef = torch.ones(2, device=dev, dtype=torch.float32)
+        self._coef_dirty = False
         self._scratch = torch.empty(1024, device=dev, dtype=torch.float32)
         off = 0
         with torch.no_grad():
@@ -119,15 +120,25 @@ class FlatAdam(torch.optim.Optimizer):
             st = ops._stream(self.flat_p)
             if grad_scale != 1.0:
                 self.flat_g.mul_(grad_scale)
-            mg = float(max_grad_norm) if max_grad_norm is not None else 0.0
-            _lib.check(lib.m2h_grad_clip_coef(ops._ptr(self.flat_g), self.n, mg, ops._ptr(self.coef), ops._ptr(self._scratch), st),
-                       "m2h_grad_clip_coef")
+            if max_grad_norm is None and not self.measure_grad_norm:
+                # no clipping asked for (passive pre-training: the reference's clip_grad_norm_ acts on zeroed gradients)
+                # and nobody reads the norm: the two reduction launches over the whole gradient are skipped, the factor stays 1
+                if self._coef_dirty:
+                    self.coef.fill_(1.0)
+                    self._coef_dirty = False
+            else:
+                mg = float(max_grad_norm) if max_grad_norm is not None else 0.0
+                _lib.check(lib.m2h_grad_clip_coef(ops._ptr(self.flat_g), self.n, mg, ops._ptr(self.coef), ops._ptr(self._scratch), st),
+                           "m2h_grad_clip_coef")
+                self._coef_dirty = True
             _lib.check(lib.m2h_adam_step(ops._ptr(self.flat_p), ops._ptr(self.flat_g), ops._ptr(self.exp_avg), ops._ptr(self.exp_avg_sq),
                                          self.n, float(lr), float(b1), float(b2), float(eps), self.t, ops._ptr(self.coef), 1.0, st),
                        "m2h_adam_step")
         from . import functional
         functional.bump_param_epoch()
 
+    measure_grad_norm = False   # True: step(max_grad_norm=None) still measures ||g||_2 (grad_norm()); off: those two launches are skipped
+
     def grad_norm(self):
-        """||g||_2 measured by the last step (device tensor)."""
+        """||g||_2 measured by the last step that clipped or had ``measure_grad_norm`` set (device tensor)."""
         return self.coef[1]
