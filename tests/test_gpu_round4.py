@@ -1,0 +1,164 @@
+"""GPU: the one-launch kernels of round 4, each directly against the CPU oracle and against the separate kernels it replaces --
+AcousticMem's rollout forward (memory_nets.py:40-69), the no-grad GRU cell (rnn_state_encoder.py:74-84), Policy.act's heads + draw +
+log-probability (rl/ppo/policy.py:217-225), the BPTT step with the previous step's gate backward (nn.GRU autograd), the activation
+backward folded into the image-row weight gradient (ppo.py:228-230), and update_sep on the separator outputs the rollout stored
+(ppo.py:184-195 without the recompute)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import m2h_oracle as O
+from m2h import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+def _rel(a, b):
+    return O.rel_l1(torch.as_tensor(a).cpu(), torch.as_tensor(b).cpu())
+
+
+def _policy(seed, dev):
+    from m2h.common.spaces import Discrete, move2hear_observation_space
+    from m2h.rl.ppo.policy import Move2HearPolicy
+    pol = Move2HearPolicy(move2hear_observation_space(), Discrete(3), "spectrogram", 512, False, True, use_ddppo=True)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), seed).items()}
+    pol.load_state_dict(sd, strict=True)
+    return pol.to(dev), sd
+
+
+@pytest.mark.parametrize("B", [1, 3, 14, 33])
+def test_acoustic_mem_one_launch_matches_the_oracle_and_the_tiled_path(B):
+    from m2h import ops
+    dev = _dev()
+    pol, sd = _policy(6, dev)
+    g = torch.Generator().manual_seed(B)
+    mono, prev = torch.rand(B, 512, 32, 1, generator=g) * 2, torch.rand(B, 512, 32, 1, generator=g) * 2
+    nd = (torch.rand(B, 1, generator=g) > 0.3).float()
+    want = O.acoustic_mem(sd, mono, O.mask_prev_mem(prev, nd))
+    with torch.no_grad():
+        got = pol.get_monoFromMem_masked(mono.to(dev), prev.to(dev), nd.to(dev))
+        assert ops.last_kernel() == "acoustic_mem_small"
+        sliced = pol.acoustic_mem.slice_inputs(mono.to(dev), prev.to(dev), nd.to(dev))
+        tiled = pol.get_monoFromMem_masked(mono.to(dev), prev.to(dev), nd.to(dev), sliced=sliced)   # the update batch's route
+        assert ops.last_kernel() != "acoustic_mem_small"
+        unmasked = pol.get_monoFromMem(mono.to(dev), (prev * nd.view(-1, 1, 1, 1)).to(dev))
+    assert got.shape == (B, 512, 32, 1)
+    assert _rel(got, want) < 2e-6 and _rel(got, tiled) < 2e-6 and _rel(unmasked, want) < 2e-6
+
+
+@pytest.mark.parametrize("N", [1, 7, 14, 16])
+def test_gru_cell_one_launch_matches_the_oracle_and_the_two_kernel_path(N):
+    from m2h import functional as MF
+    from m2h import ops
+    dev = _dev()
+    pol, sd = _policy(2, dev)
+    enc = pol.pol_net.state_encoder
+    g = torch.Generator().manual_seed(N)
+    x, h = torch.randn(N, 1536, generator=g), torch.randn(1, N, 512, generator=g)
+    m = (torch.rand(N, 1, generator=g) > 0.4).float()
+    want = O.gru_cell(sd, x, h[0] * m)
+    with torch.no_grad():
+        out, hn = enc(x.to(dev), h.to(dev), m.to(dev))
+        assert ops.last_kernel() == "gru_cell"
+        r = enc.rnn
+        two, _ = MF.GRUSequence.apply(x.to(dev), h[0].to(dev), m.to(dev), r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0, 1)
+    assert out.shape == (N, 512) and hn.shape == (1, N, 512) and torch.equal(out, hn[0])
+    assert _rel(out, want) < 2e-6 and _rel(out, two) < 2e-6
+
+
+def test_heads_act_one_launch_is_the_separate_ops_bit_for_bit():
+    """values, probabilities, the multinomial draw for given noise, the mode, and the log-probability of the action taken."""
+    from m2h import ops
+    dev = _dev()
+    pol, sd = _policy(5, dev)
+    g = torch.Generator().manual_seed(1)
+    feats = torch.randn(14, 512, generator=g).to(dev) * 4
+    a, c = pol.action_dist.linear, pol.critic.fc
+    noise = torch.empty(14, 3).exponential_(1, generator=g).to(dev)
+    with torch.no_grad():
+        v0, lpa0, p0, e0, _ = ops.policy_heads(feats, a.weight, a.bias, c.weight, c.bias)
+        act0 = ops.sample_actions(p0, noise)
+        lp0 = ops.gather_logp(lpa0, act0)
+        v1, lpa1, p1, e1, act1, lp1 = ops.policy_heads_act(feats, a.weight, a.bias, c.weight, c.bias, noise)
+        assert all(torch.equal(x, y) for x, y in ((v0, v1), (lpa0, lpa1), (p0, p1), (e0, e1), (act0, act1), (lp0, lp1)))
+        assert torch.equal(act1, torch.argmax(p1 / noise, dim=-1, keepdim=True)) and act1.dtype == torch.int64
+        _, _, p2, _, act2, lp2 = ops.policy_heads_act(feats, a.weight, a.bias, c.weight, c.bias, None)      # the mode
+        assert torch.equal(act2, p2.argmax(dim=-1, keepdim=True)) and torch.equal(lp2, ops.gather_logp(lpa1, act2))
+    wv, wl, wp = O.heads(sd, feats.cpu())
+    assert _rel(v1, wv) < 2e-6 and _rel(p1, wp) < 2e-6
+    assert len(set(act1.reshape(-1).tolist())) > 1   # (the noise does move the draw)
+
+
+def test_bptt_step_with_fused_gate_backward_is_the_two_kernels_bit_for_bit():
+    from m2h import _lib, ops
+    dev = _dev()
+    N, H = 14, 512
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    gi, gh, bhh, hp2, dpre_t, whh_t, a_prev, dhp, nxt_dh = r(N, 3 * H), r(N, 3 * H), r(3 * H), r(N, H), r(N, 3 * H) * 0.1, r(H, 3 * H) * 0.05, r(N, H), r(N, H), None
+    mask_t, mask_p = (torch.rand(N, generator=g) > 0.3).float().to(dev), (torch.rand(N, generator=g) > 0.3).float().to(dev)
+    lib = _lib.load()
+    p, st = ops._ptr, ops._stream(gi)
+    # separate: recurrent backward of step t, then the gate backward of step t-1 on its output
+    out0, dhp0 = torch.empty(N, H, device=dev), dhp.clone()
+    _lib.check(lib.m2h_gru_bwd_rec(p(dpre_t), p(whh_t), p(a_prev), p(dhp0), p(mask_t), p(out0), N, H, st), "rec")
+    dgi0, dpre0, hpm0, dhp_n0 = (torch.empty(N, 3 * H, device=dev), torch.empty(N, 3 * H, device=dev), torch.empty(N, H, device=dev), torch.empty(N, H, device=dev))
+    _lib.check(lib.m2h_gru_gates_bwd(p(gi), p(gh), p(bhh), p(hp2), p(mask_p), p(out0), p(dgi0), p(dpre0), p(dhp_n0), p(hpm0), N, H, st), "gates")
+    # fused
+    out1, dhp1 = torch.empty(N, H, device=dev), dhp.clone()
+    dgi1, dpre1, hpm1 = torch.empty(N, 3 * H, device=dev), torch.empty(N, 3 * H, device=dev), torch.empty(N, H, device=dev)
+    _lib.check(lib.m2h_gru_bwd_step(p(dpre_t), p(whh_t), p(a_prev), p(dhp1), p(mask_t), p(out1), p(gi), p(gh), p(bhh), p(hp2), p(mask_p), p(dgi1),
+                                    p(dpre1), p(hpm1), N, H, st), "step")
+    for x, y in ((out0, out1), (dgi0, dgi1), (dpre0, dpre1), (hpm0, hpm1), (dhp_n0, dhp1)):
+        assert torch.equal(x, y)
+    with pytest.raises(RuntimeError, match="must not alias"):
+        _lib.check(lib.m2h_gru_bwd_step(p(dpre_t), p(whh_t), p(a_prev), p(dhp1), p(mask_t), p(out1), p(gi), p(gh), p(bhh), p(hp2), p(mask_p), p(dgi1),
+                                        p(dpre_t), p(hpm1), N, H, st), "step")
+
+
+@pytest.mark.parametrize("N,slope", [(32, 0.0), (16, 0.2)])
+def test_gated_weight_gradient_is_act_bwd_then_wgrad_bit_for_bit(N, slope):
+    from m2h import functional as MF
+    dev = _dev()
+    g = torch.Generator().manual_seed(N)
+    B, Hh = 20, 32
+    x, dy, y = torch.randn(B, Hh, 32, 32, generator=g).to(dev), torch.randn(B, Hh, 32, N, generator=g).to(dev), torch.randn(B, Hh, 32, N, generator=g).to(dev)
+    two = MF.conv_wgrad(x, None, MF.act_bwd(dy, y, slope), N, 3, 3, 1, 1)
+    one = MF.conv_wgrad(x, None, dy, N, 3, 3, 1, 1, gate=y, gate_slope=slope)
+    assert torch.equal(one, two)
+    ref = F.conv2d(x.cpu().permute(0, 3, 1, 2), torch.zeros(N, 32, 3, 3, requires_grad=True), None, 1, 1)   # shape check of the layout only
+    assert one.shape == (N, 9 * 32) and ref.shape == (B, N, Hh, 32)
+    with pytest.raises(RuntimeError, match="image-row 3x3 kernel only"):     # other shapes are refused, not silently ungated
+        MF.conv_wgrad(torch.randn(4, 8, 8, 64, device=dev), None, torch.randn(4, 8, 8, 32, device=dev), 32, 3, 3, 1, 1,
+                      gate=torch.randn(4, 8, 8, 32, device=dev), gate_slope=0.0)
+
+
+def test_update_sep_on_stored_separator_outputs_equals_the_recompute():
+    """The trainer's rollout leaves every stored observation's separator outputs beside it; update_sep on them gives the losses and the
+    post-update memory weights of update_sep recomputing them over the buffer (same networks, same observations: fp32 association only)."""
+    from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config
+    dev = _dev()
+    out = {}
+    for stored in (True, False):
+        cfg = near_target_config(num_updates_per_cycle=1, num_steps=6, NUM_PROCESSES=5, use_hip_graphs=True, action_sampling="cpu_generator")
+        tr = PPOTrainer(cfg, dev)
+        tr.setup()
+        tr.actor_critic.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), 1).items()})
+        if not stored:
+            tr.rollouts_sep.pred_mono = tr.rollouts_sep.pred_binSepMasks = tr.rollouts_sep._pred_rows_valid = None   # a storage without them
+        torch.manual_seed(0)
+        for _ in range(cfg.num_steps):
+            tr._collect_rollout_step()
+        assert (tr.rollouts_sep.stored_separator_outputs() is not None) == stored
+        losses = tr._update_sep()
+        out[stored] = (losses, {k: v.detach().clone() for k, v in tr.actor_critic.acoustic_mem.state_dict().items()})
+    for a, b in zip(out[True][0], out[False][0]):
+        assert abs(a - b) < 2e-6 * max(1.0, abs(b))
+    for k in out[True][1]:
+        assert (out[True][1][k] - out[False][1][k]).abs().max().item() < 2e-6, k
