@@ -282,7 +282,7 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
     from m2h import ops
     from m2h.rl.ppo.ppo_trainer import PPOTrainer, far_target_config, near_target_config
     syn = __import__("m2h.synthetic", fromlist=["x"])
-    cfg = far_target_config() if far_target else near_target_config()
+    cfg = far_target_config(rollout_math="fp32") if far_target else near_target_config()
     ops.set_math_mode(ops.MATH_BF16X3 if far_target else ops.MATH_FP32)
     try:
         tr = PPOTrainer(cfg, dev, world_rank=rank, world_size=world)
@@ -387,7 +387,9 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
         out["cpu_baseline"] = ddppo_cpu_baseline(far_target, args.cpu_seconds)
         out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     if far_target:
-        out["math"] = "bf16x3 products (fp32 tensors and accumulation) in every forward / input-gradient GEMM; weight gradients, reductions, Adam in fp32"
+        out["math"] = ("mixed: bf16x3 products (fp32 tensors and accumulation) in the forward / input-gradient GEMMs of update_pol and update_sep; fp32 in the "
+                       "14-env rollout steps (launch- and latency-bound: nothing matrix-bound to save there, and that batch's one-launch kernels are fp32), "
+                       "weight gradients, reductions, Adam")
         out["mixed_precision_parity"] = mixed
     return out
 

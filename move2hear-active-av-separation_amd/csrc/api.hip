@@ -204,16 +204,16 @@ size_t m2h_unet_fwd_workspace_bytes(int B, int F, int T) {
 // ---- the same network on the small-batch engine: ten launches, no slice / reduce / epilogue launches (csrc/conv_small.hip) ----
 // tilings (images per tile, rows per tile, channels per block, columns per block, K waves) per stage, for batches of <= 16 images;
 // larger batches scale the images per tile down to keep a tile within 64 GEMM rows
-static const int kSmallTiling[10][5] = {   // tools/small_tune.py at 14 images (coordinate descent on the pair's graph replay time)
+static const int kSmallTiling[10][5] = {   // tools/small_tune.py at 14 images (coordinate descent on the pair's graph replay time: 271 us)
     {1, 2, 32, 32, 8},     // down0: 32 x 32 x 32 (sliced input) -> 16 x 16 x 64, finishes itself (class plane)
-    {1, 4, 32, 32, 8},     // down1: 16 x 16 x 64 -> 8 x 8 x 128
-    {2, 4, 32, 32, 8},     // down2: 8 x 8 x 128 -> 4 x 4 x 256
-    {8, 2, 32, 32, 8},     // down3: 4 x 4 x 256 -> 2 x 2 x 512
-    {64, 1, 128, 32, 8},   // down4: 2 x 2 x 512 -> 1 x 1 x 512
-    {32, 1, 64, 16, 4},    // up0:   1 x 1 x 512 -> 2 x 2 x 512
+    {1, 4, 64, 16, 16},    // down1: 16 x 16 x 64 -> 8 x 8 x 128 (one channel group: finishes itself)
+    {2, 4, 64, 16, 16},    // down2: 8 x 8 x 128 -> 4 x 4 x 256
+    {8, 2, 64, 16, 16},    // down3: 4 x 4 x 256 -> 2 x 2 x 512
+    {32, 1, 128, 16, 16},  // down4: 2 x 2 x 512 -> 1 x 1 x 512
+    {16, 1, 128, 16, 4},   // up0:   1 x 1 x 512 -> 2 x 2 x 512
     {4, 2, 128, 32, 2},    // up1:   2 x 2 x 1024 -> 4 x 4 x 256
-    {2, 4, 128, 16, 4},    // up2:   4 x 4 x 512 -> 8 x 8 x 128
-    {1, 4, 128, 16, 4},    // up3:   8 x 8 x 256 -> 16 x 16 x 64
+    {1, 4, 128, 32, 2},    // up2:   4 x 4 x 512 -> 8 x 8 x 128
+    {1, 8, 64, 16, 4},     // up3:   8 x 8 x 256 -> 16 x 16 x 64
     {1, 1, 128, 0, 2},     // up4 + head: 16 x 16 x 128 -> 32 x 32 x n_out (columns per block = n_out)
 };
 
@@ -269,8 +269,15 @@ static int unet_fwd_small(const m2h_unet_weights* wts, const float* mix, const f
         prod[0] = {a.dst, nullptr, nullptr, 1.f, cout[0], 1, a.dst_slab};
       } else {
         M2H_REQUIRE(cin[i] / t[2] <= cin[i] / 32, "unet_fwd: small-batch tiling of stage %d: fewer than 32 channels per block", i);
-        prod[i] = {a.dst, up ? wts->up_scale[i - 5] : wts->down_scale[i], up ? wts->up_shift[i - 5] : wts->down_shift[i], up ? 0.f : 0.2f,
-                   cout[i], cin[i] / t[2], a.dst_slab};
+        const float* sc = up ? wts->up_scale[i - 5] : wts->down_scale[i];
+        const float* sf = up ? wts->up_shift[i - 5] : wts->down_shift[i];
+        const float sl = up ? 0.f : 0.2f;
+        if (t[2] == cin[i]) {   // one channel group: the stage applies its own folded BatchNorm + activation, its output is a plain tensor
+          a.finish = 1; a.scale = sc; a.shift = sf; a.slope = sl;
+          prod[i] = {a.dst, nullptr, nullptr, 1.f, cout[i], 1, a.dst_slab};
+        } else {
+          prod[i] = {a.dst, sc, sf, sl, cout[i], cin[i] / t[2], a.dst_slab};
+        }
       }
     }
     if ((rc = conv_small_fwd(a, st))) return rc;

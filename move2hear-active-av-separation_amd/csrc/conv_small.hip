@@ -57,8 +57,9 @@ struct SmallP {
   const float* w;
   int N, K;
   int IB, QR, CG, ccsh, ncg, nnt, row_tiles, rows_total;
-  int ih_mul, ih_off, iw_off;   // patch origin: ih0 = q0 * ih_mul + ih_off, iw0 = iw_off
-  int PR, PC, pitch, Wt;        // patch rows / cols per image, floats per patch pixel, pixels per tile row
+  int ih_mul, ih_off;           // first input row of a tile's window: ih0 = q0 * ih_mul + ih_off (may lie above the image)
+  int PRwin, pad;               // rows of the window; padding of the conv
+  int PR, PC, pitch, Wt;        // patch rows (window clipped to the image) / cols (= Wi) per image, floats per patch pixel, pixels per tile row
   unsigned pc_magic, pr_magic, ncg_magic, nnt_magic, rt_magic, wt_magic, qr_magic, twn_magic;   // ceil(2^32 / d) of PC, PR, ncg, nnt, row_tiles, Wt, QR, twn
   int c0sh, c1sh;               // log2(C / 4) of the two sources (a finishing layer's one channel group covers both)
   float* dst;
@@ -128,7 +129,12 @@ __global__ __launch_bounds__(64 * PH * NWN * NWK) void conv_small_kernel(const S
   // U items (16-byte pieces) per thread and pass, all their loads issued before the first use; addresses of pieces outside
   // the image are clamped to the tensor's first element and the value replaced by zero (no divergent branches around loads).
   // A block's channel group lies in one source, or (a finishing layer over two sources) covers both: one pass per source.
+  // The patch holds IN-IMAGE pixels only: input rows [ih_lo, ih_lo + prs) of the tile's window (clipped to the image) x all Wi
+  // columns; what a tap reaches outside the image is masked per lane in the reduction (no zero halo: a whole-image tile of a deep
+  // stage would spend half its LDS on padding).
   const int ih0 = q0 * p.ih_mul + p.ih_off;
+  const int ih_lo = max(ih0, 0);
+  const int prs = min(ih0 + p.PRwin, p.Hi) - ih_lo;      // rows this tile stores (<= p.PR)
   const int npix = p.IB * p.PR * p.PC;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto stage = [&](const SmallSrcP& s, int cl0, int lds_c0, int n4sh) {
@@ -147,8 +153,8 @@ __global__ __launch_bounds__(64 * PH * NWN * NWK) void conv_small_kernel(const S
         const int px = item >> n4sh, piece = item & (n4 - 1);
         const int row = fdiv(px, p.pc_magic), pc = px - row * p.PC;
         const int ib = fdiv(row, p.pr_magic), pr = row - ib * p.PR;
-        const int b = img0 + ib, ih = ih0 + pr, iw = p.iw_off + pc;
-        ok[u] = b < p.B && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+        const int b = img0 + ib, ih = ih_lo + pr, iw = pc;
+        ok[u] = b < p.B && pr < prs;
         dofs[u] = px * p.pitch + lds_c0 + piece * 4;
         cl[u] = cl0 + piece * 4;
         if (p.mix != nullptr) {
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(64 * PH * NWN * NWK) void conv_small_kernel(const S
 
   M2H_STAMP(2);
   // ---- 3. this lane's GEMM rows: pixel (ib, r, x) of the tile -> patch pixel index at tap (0, 0)
-  int pix[MT];
+  int pixb[MT], row0[MT], col0[MT];       // patch pixel index of image pixel (0, 0) of the row's image; input position at tap offset (0, 0)
   bool okm[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -247,7 +253,9 @@ __global__ __launch_bounds__(64 * PH * NWN * NWK) void conv_small_kernel(const S
     const int t = fdiv(m, p.wt_magic), x = m - t * p.Wt;
     const int ib = fdiv(t, p.qr_magic), r = t - ib * p.QR;
     okm[mt] = ib < p.IB && img0 + ib < p.B && q0 + r < p.rows_total;
-    pix[mt] = okm[mt] ? (p.convT ? (ib * p.PR + r + 1) * p.PC + x + 1 : (ib * p.PR + r * p.stride) * p.PC + x * p.stride) : (p.convT ? p.PC + 1 : 0);
+    row0[mt] = p.convT ? q0 + r : (q0 + r) * p.stride - p.pad;
+    col0[mt] = p.convT ? x : x * p.stride - p.pad;
+    pixb[mt] = (ib * p.PR - ih_lo) * p.PC;
   }
   const int sh = p.convT ? (2 * ph - 1) : 1, sw = p.convT ? (2 * pw - 1) : 1;
   f32x4 acc[MT];
@@ -260,23 +268,31 @@ __global__ __launch_bounds__(64 * PH * NWN * NWK) void conv_small_kernel(const S
   auto compute = [&](f32x4 (&buf)[G], int base) {
     // straight-line code over the buffer's G chunks (no branch per chunk: the LDS reads of all of them can be issued ahead of
     // the MFMAs); chunks past this wave's range multiply zero weights against the last chunk's pixels
-    int toff[G];
+    int dr[G], dc[G], coff[G];
 #pragma unroll
     for (int j = 0; j < G; ++j) {
       const int ch = min(base + j, c1 - 1);
       const int tapi = ch >> p.ccsh, cc = ch & (CC - 1);
       const int thi = fdiv(tapi, p.twn_magic), twi = tapi - thi * p.twn;
-      toff[j] = (thi * sh * p.PC + twi * sw) * p.pitch + cc * 16 + 4 * kq;
+      dr[j] = p.convT ? thi * sh : p.th0 + thi;
+      dc[j] = p.convT ? twi * sw : p.tw0 + twi;
+      coff[j] = cc * 16 + 4 * kq;
     }
 #pragma unroll
     for (int j = 0; j < G; ++j) {
       const f32x4 bw = base + j < c1 ? buf[j] : zero4;
       f32x4 a[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(lds + pix[mt] * p.pitch + toff[j]);
+      bool oka[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const f32x4 av = okm[mt] ? a[mt] : zero4;
+        const int rr = row0[mt] + dr[j], cl = col0[mt] + dc[j];
+        oka[mt] = okm[mt] && (unsigned)rr < (unsigned)p.Hi && (unsigned)cl < (unsigned)p.Wi;
+        const int ad = oka[mt] ? (pixb[mt] + rr * p.PC + cl) * p.pitch + coff[j] : coff[j];   // outside the image: any valid address, value dropped
+        a[mt] = *reinterpret_cast<const f32x4*>(lds + ad);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 av = oka[mt] ? a[mt] : zero4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[e], acc[mt], 0, 0, 0);
       }
@@ -419,8 +435,8 @@ int conv_small_fwd(const m2h_small_conv_args& a, hipStream_t st) {
     p.K = 4 * p.Ctot;
     rows = a.Hi;
     p.Wt = a.Wi;
-    p.ih_mul = 1; p.ih_off = -1; p.iw_off = -1;
-    p.PR = QR + 2; p.PC = a.Wi + 2;
+    p.ih_mul = 1; p.ih_off = -1; p.pad = 0;
+    p.PRwin = QR + 2; p.PC = a.Wi;
   } else {
     M2H_REQUIRE(a.KH > 0 && a.KW > 0 && a.stride > 0 && a.pad >= 0, "conv_small: bad kernel geometry");
     p.Ho = (a.Hi + 2 * a.pad - a.KH) / a.stride + 1;
@@ -437,9 +453,10 @@ int conv_small_fwd(const m2h_small_conv_args& a, hipStream_t st) {
     p.K = a.KH * a.KW * p.Ctot;
     rows = p.Ho;
     p.Wt = p.Wo;
-    p.ih_mul = a.stride; p.ih_off = -a.pad + p.th0; p.iw_off = -a.pad + p.tw0;
-    p.PR = (QR - 1) * a.stride + p.thn; p.PC = (p.Wo - 1) * a.stride + p.twn;
+    p.ih_mul = a.stride; p.ih_off = -a.pad + p.th0; p.pad = a.pad;
+    p.PRwin = (QR - 1) * a.stride + p.thn; p.PC = a.Wi;
   }
+  p.PR = p.PRwin < a.Hi ? p.PRwin : a.Hi;
   p.rows_total = rows;
   p.w = a.wp; p.N = a.N;
   p.IB = IB; p.QR = QR; p.CG = CG; p.ncg = p.Ctot / CG;

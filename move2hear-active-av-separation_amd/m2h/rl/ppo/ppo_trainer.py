@@ -48,6 +48,9 @@ def near_target_config(**over):
              use_hip_graphs=True,       # build-side key: replay the rollout step and the update_pol epoch from HIP graphs (same kernels, same results)
              overlap_grad_reduce=None,  # build-side key: None = overlap the last all-reduce + step of an update when distributed
              pretrained_passive_separators_ckpt="", train_passive_separators=False,   # nearTarget.yaml:23-24 (accepted; see setup())
+             rollout_math=None,         # build-side key: arithmetic of the rollout steps' conv / GEMM launches: None = the calling thread's mode (ops.set_math_mode);
+             #                            "fp32" pins them to fp32 MFMA whatever the update phases compute in (the mixed-precision far-target leg: at 14
+             #                            environments nothing is matrix-bound, and the one-launch / skinny kernels of that batch are fp32 kernels)
              action_sampling="device")  # build-side key: "device" = multinomial noise from the device generator; "cpu_generator" = from
     #                                     the CPU default generator: the reference PyTorch-CPU run's actions from the seed alone
     c.update(over)
@@ -157,6 +160,10 @@ class PPOTrainer:
         graph whenever the previous step left its next-observation separator outputs behind (every step but the first after
         update_sep); otherwise it is enqueued kernel by kernel."""
         cfg = self.config
+        rm = getattr(cfg, "rollout_math", None)
+        if rm is not None and ops.math_mode() != {"fp32": ops.MATH_FP32, "bf16x3": ops.MATH_BF16X3}[rm]:
+            with ops.math_scope({"fp32": ops.MATH_FP32, "bf16x3": ops.MATH_BF16X3}[rm]):   # (graphs are keyed on the mode they were captured in)
+                return self._collect_rollout_step()
         override = cfg.sep_reward_weight == 1.0 and cfg.nav_reward_weight == 0.0
         # :395 reads env 0's step count (current_episode_step[0].item(): a host sync); it is known on the host here
         extra = override and self._episode_step_host == cfg.MAX_EPISODE_STEPS - 2

@@ -26,8 +26,8 @@ obs = {"mixed_bin_audio_mag": torch.from_numpy(mixed).to(dev), "target_class": t
 # stage geometry: (rows the tiles walk, pixels per tile row, Ctot, C0, N, transposed)
 GEO = [(16, 16, 32, 32, 64, 0), (8, 8, 64, 64, 128, 0), (4, 4, 128, 128, 256, 0), (2, 2, 256, 256, 512, 0), (1, 1, 512, 512, 512, 0),
        (1, 1, 512, 512, 512, 1), (2, 2, 1024, 512, 256, 1), (4, 4, 512, 256, 128, 1), (8, 8, 256, 128, 64, 1), (16, 16, 128, 64, 0, 1)]
-BASE = [(1, 2, 32, 32, 8), (1, 4, 32, 32, 8), (2, 4, 32, 32, 8), (8, 2, 32, 32, 8), (64, 1, 128, 32, 8), (32, 1, 64, 16, 4), (4, 2, 128, 32, 2),
-        (2, 4, 128, 16, 4), (1, 4, 128, 16, 4), (1, 1, 128, 0, 2)]
+BASE = [(1, 2, 32, 32, 8), (1, 4, 64, 16, 16), (2, 4, 64, 16, 16), (8, 2, 64, 16, 16), (32, 1, 128, 16, 16), (16, 1, 128, 16, 4), (4, 2, 128, 32, 2),
+        (1, 4, 128, 32, 2), (1, 8, 64, 16, 4), (1, 1, 128, 0, 2)]
 
 
 def candidates(i):
@@ -41,7 +41,7 @@ def candidates(i):
             tiles.add((1, min(qr, rows)))
         else:
             tiles.add((min(64, max(1, target // px)), rows))
-    cgs = [ctot] if i in (0, 9) else [c for c in (32, 64, 128, 256) if c <= c0]
+    cgs = [ctot] if i in (0, 9) else sorted(set([c for c in (32, 64, 128, 256) if c <= c0] + [ctot]))
     colss = [0] if i == 9 else [c for c in (16, 32, 64) if c <= n]
     out = []
     for (ib, qr), cg, cols, kw in itertools.product(sorted(tiles), cgs, colss, (1, 2, 4, 8, 16)):
