@@ -6,7 +6,8 @@ import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "move2hear-active-av-separation_amd"))
 knob, val = int(sys.argv[1]), int(sys.argv[2])
 sys.argv = [sys.argv[0]] + sys.argv[3:]
-from m2h import ops
+from m2h import functional as MF, ops
+MF.carry_tuning(True)   # the knobs are thread-local: backward passes run on autograd's thread
 ops.debug_set(knob, val)
 import bench
 bench.main()
