@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+for v in 0 1 0 1; do
+  python tools/knob_bench.py 37 $v --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-mode --ddppo-cycles 2 --no-far-target --train-steps 0 --feeder-steps 0 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read())['ddppo']; print('knob37=$v', d['value'], d['phases']['rollout_ms'], d['phases']['update_pol_ms'], d['phases']['update_sep_ms'])"
+done
