@@ -19,7 +19,7 @@
  * runner does not take the strip-walker kernels (csrc/conv_strip.hip), 36 the shared-patch LDS-DMA engine (csrc/conv_patch.hip; -1
  * off, 2 = below the tile-count threshold too, 3 = as 2 with the whole-image patch wherever it fits), 37 = 1: the whole-network
  * runner takes the small-batch engine (csrc/conv_small.hip) for rollout-size batches (off by default: measured at parity).  Numbers of experiments that were measured and removed
- * (5, 6, 10, 12, 13, 17, 19, 20, 29, 31, 32) are accepted and ignored. */
+ * (5, 6, 10, 12, 13, 17, 19, 20, 29, 31, 32, 38) are accepted and ignored. */
 #ifndef M2H_TUNING_H
 #define M2H_TUNING_H
 #ifdef __cplusplus
