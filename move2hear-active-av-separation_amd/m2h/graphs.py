@@ -22,15 +22,25 @@ def capture(graph, pool=None):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# Fork / join of independent kernel chains onto side HIP streams (captured into a HIP graph they become parallel branches).
-# Same kernels, same values.  OFF by default (M2H_PARALLEL_BRANCHES=1 switches it on): measured on the policy's three encoders,
-# whose kernels each occupy a few of the chip's 256 CUs for 5-15 us -- with a device sync between the phases of a DD-PPO cycle the
-# update_pol epochs gained 5 % (60 -> 57 ms per cycle), but in the free-running cycle (bench.py, no syncs) the multi-stream
-# graph replays cost 9 % of the whole cycle (9 420 -> 8 600 env-steps/s), and at the rollout width (14 rows) the cross-stream
-# edges alone cost more than the overlap returns (rollout 75 -> 88 ms per cycle).
+# Fork / join of independent kernel chains onto side HIP streams WHILE A HIP GRAPH IS BEING CAPTURED: they become parallel
+# branches of the graph.  Same kernels, same values.  Used for the policy's three encoders at update batches (forward and,
+# through autograd's stream bookkeeping, backward): their kernels each occupy a few of the chip's 256 CUs for 5-35 us.
+#
+# What was measured on this stack (ROCm 7.2, tools/graph_fork.py, tools/graph_fork_after.py, profiles/r04_graph_fork*.txt):
+#   * a fork / join inside a replayed graph costs ~22 us (a 7-node side chain of 45 us beside a 10-node main chain returns 23 us;
+#     a 1-node side chain costs 25 us) and launching a multi-branch graph is HOST-bound (83-128 us for 25 nodes on 2-4 branches);
+#   * a multi-branch graph enqueued BEHIND other work parks one barrier packet per side queue until its turn comes, and while such
+#     packets wait every kernel boundary of the running queue is dearer: a 53-node chain replays in 345 us alone, in 413 / 533 /
+#     611 us while a 2 / 3 / 4-branch graph waits behind it; in the free-running DD-PPO cycle that turned -6 ms of update_pol into
+#     +19 ms of rollout (GPU_MAX_HW_QUEUES=8: +110 ms).  Hence the rule in ppo.py: a graph with parallel branches is launched
+#     onto a DRAINED stream (one host synchronize per epoch: 24 per cycle), never queued behind the rollout's replays;
+#   * at the rollout width (14 rows) the fork / join costs more than the 55 us side chain returns, and every step's graph would
+#     need the drained stream: the rollout step stays one chain.
+# With the rule: update_pol 54.6 -> 46.5 ms per cycle, rollout unchanged, 10 800 -> 11 450 env-steps/s.
+# M2H_PARALLEL_BRANCHES=0 switches the fork off (A/B runs).
 # ------------------------------------------------------------------------------------------------------------------
 _side_streams = {}
-parallel_branches = os.environ.get("M2H_PARALLEL_BRANCHES", "0") == "1"     # module switch (tests / A-B measurements)
+parallel_branches = os.environ.get("M2H_PARALLEL_BRANCHES", "1") != "0"     # module switch (tests / A-B measurements)
 
 
 def _tensors(x):
@@ -44,8 +54,9 @@ def _tensors(x):
 def run_parallel(device, fns):
     """Runs fns[0] on the current stream and fns[1:] on side streams that start after the work enqueued so far; the current
     stream waits for all of them before this returns.  Tensors produced on a side stream are handed to the current stream
-    (allocator bookkeeping: ``record_stream``).  device None: plain sequential calls."""
-    if device is None or not parallel_branches or len(fns) == 1 or ops.timing_enabled():
+    (allocator bookkeeping: ``record_stream``).  device None, or no graph capture in progress (eager launches are host-bound: a
+    second stream buys nothing there): plain sequential calls."""
+    if device is None or not parallel_branches or len(fns) == 1 or ops.timing_enabled() or not torch.cuda.is_current_stream_capturing():
         return [f() for f in fns]
     main = torch.cuda.current_stream(device)
     key = (device.index, len(fns) - 1)

@@ -93,8 +93,9 @@ class PolicyNet(Net):
             self.visual_encoder(observations, out=x1[:, :hs])
             x2, rnn_hidden_states_new = self.state_encoder(x1, rnn_hidden_states, masks)
             return x2, rnn_hidden_states_new
-        # The three encoders are independent kernel chains; graphs.run_parallel can put them on three HIP streams for update
-        # batches (opt-in, measured slower end to end: see m2h/graphs.py), sequential otherwise.
+        # The three encoders are independent kernel chains: at update batches, while a HIP graph is being captured (update_pol's
+        # epoch, ppo.py), graphs.run_parallel puts them on three streams = three branches of the graph (forward and backward);
+        # sequential otherwise (m2h/graphs.py has the measurements and the launch rule that goes with it).
         x = graphs.run_parallel(pred_mono.device if pred_mono.shape[0] >= 64 else None, [
             lambda: self.visual_encoder(observations),
             lambda: self.bin_encoder(observations, pred_binSepMasks=pred_binSepMasks),

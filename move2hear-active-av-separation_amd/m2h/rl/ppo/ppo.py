@@ -161,7 +161,7 @@ class PPO(nn.Module):
                tuple(p.data_ptr() for p in self.optimizer_pol.param_groups[0]["params"]))
         if gs is None or gs.sig != sig:
             from types import SimpleNamespace
-            gs = self._pol_graph = SimpleNamespace(sig=sig, graph=None, adv=torch.empty_like(advantages),
+            gs = self._pol_graph = SimpleNamespace(sig=sig, graph=None, forked=False, adv=torch.empty_like(advantages),
                                                    clip=torch.zeros(1, device=self.device), acc=torch.zeros(4, device=self.device))
         gs.adv.copy_(advantages)
         gs.clip.fill_(float(self.clip_param))
@@ -176,8 +176,12 @@ class PPO(nn.Module):
                 with graphs.capture(g):
                     self._pol_epoch(next(iter(rollouts_pol.recurrent_generator(gs.adv, 1))), gs.clip, gs.acc)
                 torch.set_rng_state(cpu_rng)
-                gs.graph = g
+                gs.graph, gs.forked = g, graphs.parallel_branches
             torch.randperm(num_envs)        # recurrent_generator's draw (:197); the batch itself is the storage in place
+            if gs.forked:
+                # the epoch's graph has parallel branches (the three encoders, m2h/graphs.py): it is launched onto a drained stream --
+                # queued behind the rollout's replays its side queues' parked barrier packets slow every kernel boundary ahead of it
+                torch.cuda.current_stream().synchronize()
             gs.graph.replay()
             self._reduce_and_step("pol", self.optimizer_pol, last=_e == self.ppo_epoch - 1)
         v, a, h, _ = (gs.acc / self.ppo_epoch).tolist()
