@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-far-target", action="store_true", help="skip the far-target / mixed-precision DD-PPO leg")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the pair kernel by kernel instead of replaying a HIP graph")
     ap.add_argument("--ddppo-cycles", type=int, default=2, help="timed DD-PPO cycles (0 = skip); one untimed warm-up cycle precedes them")
+    ap.add_argument("--sep-update-math", choices=["fp32", "bf16x3"], default="bf16x3",
+                    help="near-target DD-PPO leg: arithmetic of update_sep's launches (its convs over the 1680 stored samples are the cycle's one "
+                         "matrix-bound phase); rollout and update_pol compute in fp32 either way")
     ap.add_argument("--math", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="arithmetic of the conv engine in the timed U-Net pair: fp32 MFMA (exact products) or bf16x3 split products")
     ap.add_argument("--no-other-mode", action="store_true",
@@ -282,7 +285,7 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
     from m2h import ops
     from m2h.rl.ppo.ppo_trainer import PPOTrainer, far_target_config, near_target_config
     syn = __import__("m2h.synthetic", fromlist=["x"])
-    cfg = far_target_config(rollout_math="fp32") if far_target else near_target_config()
+    cfg = far_target_config(rollout_math="fp32") if far_target else near_target_config(sep_update_math=args.sep_update_math)
     ops.set_math_mode(ops.MATH_BF16X3 if far_target else ops.MATH_FP32)
     try:
         tr = PPOTrainer(cfg, dev, world_rank=rank, world_size=world)
@@ -391,6 +394,11 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
                        "14-env rollout steps (launch- and latency-bound: nothing matrix-bound to save there, and that batch's one-launch kernels are fp32), "
                        "weight gradients, reductions, Adam")
         out["mixed_precision_parity"] = mixed
+    else:
+        out["math"] = ("fp32 MFMA / fp32 everywhere" if args.sep_update_math == "fp32" else
+                       "fp32 (MFMA and vector) in the rollout steps and update_pol; update_sep's AcousticMem convolutions, input gradient and weight gradients "
+                       "over the 1680 stored samples in bf16x3 (split bf16 products, fp32 tensors and accumulation: ~6e-6 rel-L1 from the fp32 kernels, "
+                       "tests/test_gpu_round4.py); --sep-update-math fp32 runs them on the fp32 matrix pipe")
     return out
 
 

@@ -16,8 +16,12 @@
 
 namespace m2h {
 
+extern thread_local int tl_math_mode;   // conv_igemm.hip: the calling thread's arithmetic
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct WGradP {
   const float* src0;
@@ -418,6 +422,150 @@ __global__ __launch_bounds__(256) void wgrad3x3_row_kernel(const WGradP p) {
   }
 }
 
+// The same weight gradient in bf16x3 arithmetic (M2H_MATH_BF16X3: lo*hi + hi*lo + hi*hi on the bf16 matrix pipe, fp32 accumulate).
+// The reduction runs over PIXELS, so both operands of v_mfma_f32_16x16x32_bf16 (a lane holds eight consecutive k of its row) are
+// needed pixel-contiguous: an image row of x is staged TRANSPOSED and split, XT[channel][32 pixels] as [hi | lo] bf16 (one MFMA
+// contracts the whole 32-pixel row), and so is the row of dY, YT[n][32 pixels].  A tap's column shift is applied to dY instead of
+// x -- dW[n][ty][tx][c] = sum_px' dY[px' - tx + 1][n] x[row + ty - 1][px'][c] -- and made in registers (a 16-byte fragment + the
+// neighbouring dword, v_alignbit), so x rows are staged once, unshifted, in a ring of four (step c reads rows c - 1, c, c + 1 and
+// row c + 2 arrives), and rows outside the image are skipped rather than staged as zeros.  Wave (nh, ch) owns the 16 x 16 tiles
+// (n half, channel half) of all nine taps (N <= 16: channel half x taps 0-4 / 5-8): no cross-wave reduction.  One barrier per row.
+// The fp32-MFMA kernel above is matrix-bound at 1.7 M pixels (324 us for the 32 x 288 gradient, 62 % of the fp32 peak); this one
+// leaves the layer to its HBM stream (x + dY + gate: 660 MB).
+constexpr int WRB_RS = 144;                         // row stride of the transposed stages, bytes: [hi 64 | lo 64 | 16]: 9 x 16 (odd)
+template <int FR>
+__global__ __launch_bounds__(256, 3) void wgrad3x3_row_bf16x3_kernel(const WGradP p) {
+  constexpr int W = 32, C = 32;
+  __shared__ __attribute__((aligned(16))) char XT[4][C * WRB_RS];      // ring over image rows (slot = row & 3)
+  __shared__ __attribute__((aligned(16))) char YT[2][FR * WRB_RS];     // dY rows (slot = row & 1)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x;
+  const int c0 = (int)(((long)p.chunks * split) / p.S), c1 = (int)(((long)p.chunks * (split + 1)) / p.S);
+  const int rows_total = p.B * p.Hq;
+  const int fi = lane & 15, kq = lane >> 4;
+  const int nh = FR == 32 ? (wave >> 1) : 0, ch = wave & 1;
+  const int t_lo = FR == 32 ? 0 : ((wave >> 1) ? 5 : 0), t_hi = FR == 32 ? 9 : ((wave >> 1) ? 9 : 5);
+
+  // staging: thread (pixel = tid / 8, quad = tid % 8) moves 16 bytes = 4 channels of one pixel
+  const int spx = tid >> 3, sq = tid & 7;
+  f32x4 rx, ry;
+  bool okx = false, oky = false;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto load_x = [&](int r) {                         // image row r (global row index b * Hq + ih)
+    okx = r >= 0 && r < rows_total;
+    rx = *reinterpret_cast<const f32x4*>(p.src0 + (okx ? ((size_t)r * W + spx) * C + sq * 4 : (size_t)0));
+  };
+  auto load_y = [&](int r) {
+    oky = r < rows_total && sq * 4 < p.N;
+    const size_t off = oky ? ((size_t)r * W + spx) * p.ldy + sq * 4 : (size_t)0;
+    ry = *reinterpret_cast<const f32x4*>(p.dy + off);
+    if (p.gate != nullptr) {   // m2h_act_bwd folded into the load
+      const f32x4 gy = *reinterpret_cast<const f32x4*>(p.gate + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ry[e] = gy[e] > 0.f ? ry[e] : ry[e] * p.gate_slope;
+    }
+  };
+  auto store_t = [&](char* base, f32x4 v) {          // rows 4 sq .. 4 sq + 3 of a transposed stage, column spx
+    const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+    const f32x4 hf = __builtin_convertvector(hi, f32x4);
+    const bf16x4 lo = __builtin_convertvector(v - hf, bf16x4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      char* d = base + (sq * 4 + e) * WRB_RS + spx * 2;
+      *reinterpret_cast<__bf16*>(d) = hi[e];
+      *reinterpret_cast<__bf16*>(d + 64) = lo[e];
+    }
+  };
+  auto store_x = [&](int r) { if (okx) store_t(XT[r & 3], rx); };
+  auto store_y = [&](int r) { if (sq * 4 < FR) store_t(YT[r & 1], oky ? ry : zero4); };
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = zero4;
+  auto mma = [&](const f32x4& a, const f32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  };
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  auto compute = [&](int c) {
+    const int q = c % p.Hq;
+    // dY fragments of the three column shifts (hi / lo): the unshifted 16 bytes + the dword before / after
+    f32x4 ya[3][2];
+    const char* yb = YT[c & 1] + (nh * 16 + fi) * WRB_RS + kq * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const char* yp = yb + h * 64;
+      const u32x4 d = *reinterpret_cast<const u32x4*>(yp);
+      const unsigned before = kq > 0 ? *reinterpret_cast<const unsigned*>(yp - 4) : 0u;
+      const unsigned after = kq < 3 ? *reinterpret_cast<const unsigned*>(yp + 16) : 0u;
+      u32x4 l, r;                                    // l: element k takes dY[k + 1] (tap column 0); r: dY[k - 1] (tap column 2)
+      l[0] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
+      l[1] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+      l[2] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
+      l[3] = __builtin_amdgcn_alignbit(after, d[3], 16);
+      r[0] = __builtin_amdgcn_alignbit(d[0], before, 16);
+      r[1] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
+      r[2] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+      r[3] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
+      ya[0][h] = __builtin_bit_cast(f32x4, l);
+      ya[1][h] = __builtin_bit_cast(f32x4, d);
+      ya[2][h] = __builtin_bit_cast(f32x4, r);
+    }
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      if (3 * ty + 3 <= t_lo || 3 * ty >= t_hi) continue;            // (wave-uniform: none of this wave's taps)
+      const int ih = q + ty - 1;
+      if ((unsigned)ih >= (unsigned)p.Hq) continue;                  // the row above / below the image: zeros
+      const char* xb = XT[(c + ty - 1) & 3] + (ch * 16 + fi) * WRB_RS + kq * 16;
+      const f32x4 bh = *reinterpret_cast<const f32x4*>(xb), bl = *reinterpret_cast<const f32x4*>(xb + 64);
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        const int t = ty * 3 + tx;
+        if (t < t_lo || t >= t_hi) continue;
+        mma(ya[tx][1], bh, acc[t]);
+        mma(ya[tx][0], bl, acc[t]);
+        mma(ya[tx][0], bh, acc[t]);
+      }
+    }
+  };
+
+  if (c0 < c1) {
+    // prologue: rows c0 - 1, c0, c0 + 1 of x and row c0 of dY staged; rows c0 + 2 / c0 + 1 in registers
+#pragma unroll 1
+    for (int r = c0 - 1; r <= c0 + 1; ++r) {
+      load_x(r);
+      store_x(r);
+    }
+    load_y(c0);
+    store_y(c0);
+    load_x(c0 + 2);
+    load_y(c0 + 1);
+    __syncthreads();
+#pragma unroll 1
+    for (int c = c0; c < c1; ++c) {
+      store_x(c + 2);                  // slot (c + 2) & 3 held row c - 2: last read in step c - 1, before that step's barrier
+      store_y(c + 1);
+      if (c + 1 < c1) {
+        load_x(c + 3);
+        load_y(c + 2);
+      }
+      compute(c);
+      __syncthreads();
+    }
+  }
+
+  // each wave owns its tiles: slab[split][n][t * 32 + ch * 16 + col]
+  float* slab = p.ws + (size_t)split * p.N * p.Kpad;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if (t < t_lo || t >= t_hi) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = nh * 16 + kq * 4 + e;
+      if (n < p.N) slab[(size_t)n * p.Kpad + t * C + ch * 16 + fi] = acc[t][e];
+    }
+  }
+}
+
 // dw[n][k] = sum over splits, fixed order.  A block owns 64 consecutive k of one row n; its four waves each sum a quarter of
 // the splits (four loads in flight per lane), then the quarters are combined in wave order.  (One thread per element walking
 // all splits serially took 39 us for a 32 x 384 gradient with 512 splits: 36 blocks, one dependent load at a time.)
@@ -558,7 +706,10 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   if (row3x3) {
     p.chunks = a.B * a.Hq;   // image rows
     if (p.S > p.chunks) p.S = p.chunks;
-    if (a.N <= 16) hipLaunchKernelGGL((wgrad3x3_row_kernel<16>), dim3((unsigned)p.S), blk, 0, st, p);
+    if (tl_math_mode == 1) {           // the calling thread computes in bf16x3 (update_sep with sep_update_math, the far-target leg)
+      if (a.N <= 16) hipLaunchKernelGGL((wgrad3x3_row_bf16x3_kernel<16>), dim3((unsigned)p.S), blk, 0, st, p);
+      else hipLaunchKernelGGL((wgrad3x3_row_bf16x3_kernel<32>), dim3((unsigned)p.S), blk, 0, st, p);
+    } else if (a.N <= 16) hipLaunchKernelGGL((wgrad3x3_row_kernel<16>), dim3((unsigned)p.S), blk, 0, st, p);
     else hipLaunchKernelGGL((wgrad3x3_row_kernel<32>), dim3((unsigned)p.S), blk, 0, st, p);
   } else if (bng == 128) hipLaunchKernelGGL((wgrad_kernel<128, 1, 2>), grid, blk, 0, st, p);
   else if (kt == 1) hipLaunchKernelGGL((wgrad_kernel<32, 1, 2>), grid, blk, 0, st, p);

@@ -786,6 +786,150 @@ __global__ __launch_bounds__(256, 2) void conv3x3_row_kernel(const IGemmP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The image-row 3x3 convolution in bf16x3 arithmetic (three bf16 MFMAs per fp32 product: lo*hi + hi*lo + hi*hi, fp32 accumulate --
+// the engine's split-product mode, M2H_MATH_BF16X3).  Same walk as conv3x3_row_kernel: a block keeps the weight matrix in LDS and
+// stages four image rows + halo as a zero-padded 6 x 34-pixel patch; here both are SPLIT on the way into LDS -- a pixel's (a
+// weight row's) k-values as [hi bf16 x K | lo bf16 x K] -- so a 16-byte fragment read is eight consecutive channels of one pixel:
+// one operand of v_mfma_f32_32x32x16_bf16 (N <= 32) / v_mfma_f32_16x16x32_bf16 (N <= 16).  At the 1.7 M pixels of an update_sep
+// epoch the fp32-MFMA kernel is matrix-bound (31.7 GFLOP of 16-pass fp32 MFMAs: 285 us at 71 % of the 157 TFLOP/s peak); the
+// three bf16 MFMAs cost 3/16 of that, which leaves the layer to its HBM stream (220 MB in + 220 MB out).
+// De-sliced store with N = 16: a lane's four accumulator values are four consecutive time frames of one band: one 16-byte store.
+template <int FR, int C>
+__global__ __launch_bounds__(256, 2) void conv3x3_row_bf16x3_kernel(const IGemmP p) {
+  constexpr int W = 32, PW = W + 2, ROWS = 4, PR = ROWS + 2;
+  constexpr int K = 9 * C;
+  constexpr int PS = 4 * C + 16;                    // patch pixel stride, bytes ([hi C | lo C] + 16: an odd count of 16-byte units)
+  constexpr int WS = 4 * K + 16;                    // weight row stride, bytes
+  constexpr int KI = FR == 32 ? 16 : 32;            // k per MFMA
+  constexpr int NG = C / KI;                        // MFMAs (x3) per tap
+  constexpr int FM = 32 / FR;                       // pixel fragments per wave (one image row)
+  constexpr int NE = FR == 32 ? 16 : 4;
+  constexpr int SEG = C / 4;                        // 16-byte fp32 segments per pixel
+  constexpr int NPL = (PR * PW * SEG + 255) / 256;  // patch loads per thread
+  using AccT = typename std::conditional<FR == 32, f32x16, f32x4>::type;
+  static_assert(NG >= 1 && C % KI == 0 && (PS / 16) % 2 == 1 && (WS / 16) % 2 == 1, "tile shape");
+  __shared__ __attribute__((aligned(16))) char Wl[FR * WS];
+  __shared__ __attribute__((aligned(16))) char Pl[PR * PW * PS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & (FR - 1), kq = lane / FR;
+  const int chunks = p.B * (p.Hq / ROWS);
+
+  auto split_store = [&](char* dst_hi, int lo_off, f32x4 v) {
+    const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+    const f32x4 hf = __builtin_convertvector(hi, f32x4);
+    const bf16x4 lo = __builtin_convertvector(v - hf, bf16x4);
+    *reinterpret_cast<bf16x4*>(dst_hi) = hi;
+    *reinterpret_cast<bf16x4*>(dst_hi + lo_off) = lo;
+  };
+  // weights [N][K] fp32 -> split LDS rows (rows past N: zeros), once per block
+  for (int i = tid; i < FR * (K / 4); i += 256) {
+    const int n = i / (K / 4), s4 = i - n * (K / 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.N) v = *reinterpret_cast<const f32x4*>(p.w + (size_t)n * K + s4 * 4);
+    split_store(Wl + n * WS + s4 * 8, 2 * K, v);
+  }
+  int shift[9];                                     // patch offset of tap t relative to the output pixel's own patch position
+#pragma unroll
+  for (int t = 0; t < 9; ++t) shift[t] = (p.offh + (t / 3) * p.mulh) * PW + (p.offw + (t % 3) * p.mulw);
+
+  f32x4 rp[NPL];
+  unsigned okm = 0;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto load_chunk = [&](int c) {
+    const int b = c / (p.Hq / ROWS), q0 = (c - b * (p.Hq / ROWS)) * ROWS;
+    okm = 0;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int i = tid + 256 * j;
+      const int l = i / SEG, seg = i - l * SEG;
+      const int pr = l / PW, pc = l - pr * PW;
+      const int ih = q0 + pr - 1, iw = pc - 1;
+      const bool ok = i < PR * PW * SEG && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)W;
+      const size_t off = ok ? ((size_t)(b * p.Hi + ih) * W + iw) * C + seg * 4 : (size_t)0;
+      rp[j] = *reinterpret_cast<const f32x4*>(p.src0 + off);
+      okm |= ok ? (1u << j) : 0u;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int i = tid + 256 * j;
+      if (i < PR * PW * SEG) split_store(Pl + (i / SEG) * PS + (i % SEG) * 8, 2 * C, (okm & (1u << j)) ? rp[j] : zero4);
+    }
+  };
+  auto mma = [&](const f32x4& a, const f32x4& b, AccT& c) {
+    if constexpr (FR == 32)
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  };
+  const size_t plane = (size_t)p.Ho * p.Wo;
+  const int Cc = p.N >> 4;
+  for (int c = blockIdx.x; c < chunks; c += gridDim.x) {
+    if (c == (int)blockIdx.x) load_chunk(c);
+    __syncthreads();              // the previous chunk's fragment reads (and the weight stores) are done
+    store_chunk();
+    __syncthreads();
+    if (c + (int)gridDim.x < chunks) load_chunk(c + gridDim.x);   // next chunk's loads fly under this chunk's MFMAs
+    AccT acc[FM];
+#pragma unroll
+    for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+      for (int e = 0; e < NE; ++e) acc[mi][e] = 0.f;
+    const int prow0 = (wave + 1) * PW + 1;          // this wave's image row inside the patch, column 0
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const char* wp = Wl + frow * WS + (t * C + g * KI) * 2 + kq * 16;
+        const f32x4 bh = *reinterpret_cast<const f32x4*>(wp), bl = *reinterpret_cast<const f32x4*>(wp + 2 * K);
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) {
+          const char* ap = Pl + (prow0 + mi * FR + frow + shift[t]) * PS + g * KI * 2 + kq * 16;
+          const f32x4 ah = *reinterpret_cast<const f32x4*>(ap), al = *reinterpret_cast<const f32x4*>(ap + 2 * C);
+          mma(al, bh, acc[mi]);
+          mma(ah, bl, acc[mi]);
+          mma(ah, bh, acc[mi]);
+        }
+      }
+    }
+    // epilogue: rows = pixels of image row (q0 + wave), columns = output channels
+    const int b = c / (p.Hq / ROWS), q = (c - b * (p.Hq / ROWS)) * ROWS + wave;
+    const int n = lane & (FR - 1);
+    const float sh = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
+    if (n < p.N) {
+#pragma unroll
+      for (int mi = 0; mi < FM; ++mi) {
+        if constexpr (FR == 16) {
+          if (p.out_mode != M2H_OUT_NHWC && Cc == 1) {   // four consecutive frames of band n
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = acc[mi][e] + sh;
+              v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+            }
+            *reinterpret_cast<f32x4*>(p.dst + (size_t)b * 16 * plane + (size_t)n * plane + (size_t)q * p.Wo + mi * FR + (lane >> 4) * 4) = v;
+            continue;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int x = mi * FR + (FR == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : (lane >> 4) * 4 + e);
+          float v = acc[mi][e] + sh;
+          v = v > 0.f ? v : v * p.slope;
+          if (p.out_mode == M2H_OUT_NHWC) {
+            p.dst[((size_t)(b * p.Ho + q) * p.Wo + x) * p.ldc + n] = v;
+          } else {
+            const size_t out = (size_t)b * 16 * plane + (size_t)q * p.Wo + x;
+            p.dst[(out + (size_t)(n & 15) * plane) * Cc + (n >> 4)] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // Skinny dense GEMM, M <= 16 rows (fp32 MFMA): D[m][n] = act(scale[n] * sum_k X[m][k] W[n][k] + shift[n]) where every GEMM row is
 // one contiguous run of floats -- nn.Linear at the rollout width (the GRU's input projection, 1536 x 1536), the full-spatial
 // "conv as Linear" of VisualCNN / AudioCNN (visual_cnn.py:140-141: 4608 -> 512), and the two U-Net stages around the 1 x 1
@@ -1399,6 +1543,19 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
     else if (a.C0 == 32) hipLaunchKernelGGL((conv3x3_row_kernel<32, 32>), grid, blk, 0, st, p);
     else hipLaunchKernelGGL((conv3x3_row_kernel<32, 16>), grid, blk, 0, st, p);
     return launch_status("conv_igemm_f32 (image-row 3x3)");
+  }
+  // the same image-row shapes in bf16x3 math (update_sep with sep_update_math / the far-target leg): split operands in LDS, bf16 MFMAs
+  if (p.math == 1 && !p.presplit && !p.dst_split && g_row3x3 >= 0 && !p.convT && a.nth == 3 && a.ntw == 3 && a.stride == 1 && a.os == 1 && a.ph == 0 &&
+      a.pw == 0 && (a.mulh == 1 || a.mulh == -1) && a.offh == -a.mulh && a.mulw == a.mulh && a.offw == a.offh && a.C1 == 0 &&
+      ((a.C0 == 32 && a.N <= 32) || (a.C0 == 16 && a.N > 16 && a.N <= 32)) && a.Wq == 32 && a.Wi == 32 && a.Hq == a.Hi && a.Ho == a.Hq && a.Wo == a.Wq &&
+      a.Hq % 4 == 0 && a.N % 4 == 0 && a.scale == nullptr && a.cls_table == nullptr && a.head_w == nullptr &&
+      (a.operand_format & M2H_FMT_LAYOUT_BITS) == 0 && (long)a.B * (a.Hq / 4) >= 512 && (a.out_mode == M2H_OUT_NHWC || a.N % 16 == 0)) {
+    const long chunks = (long)a.B * (a.Hq / 4);
+    const dim3 grid((unsigned)(chunks < 512 ? chunks : 512)), blk(256);
+    if (a.N <= 16) hipLaunchKernelGGL((conv3x3_row_bf16x3_kernel<16, 32>), grid, blk, 0, st, p);
+    else if (a.C0 == 32) hipLaunchKernelGGL((conv3x3_row_bf16x3_kernel<32, 32>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((conv3x3_row_bf16x3_kernel<32, 16>), grid, blk, 0, st, p);
+    return launch_status("conv_igemm_bf16x3 (image-row 3x3)");
   }
   // bf16x3 math, wide N, enough work for one 256 x 128 tile per CU: eight waves (4 x 2 wave tiles of 64 x 64) share one staged
   // pair of operand tiles.  The 128 x 128 kernel at two blocks per CU is bound by the chip's aggregate L2 -> LDS operand stream

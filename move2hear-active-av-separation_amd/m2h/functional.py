@@ -316,7 +316,7 @@ class Conv2dNHWC(torch.autograd.Function):
         # weight gradient is the only reader of dy, and its image-row kernel applies the activation's derivative as it loads dy
         gated = (slope != 1.0 and ctx.needs_input_grad[2] and not need_x and not ctx.needs_input_grad[3] and x2 is None and
                  (KH, KW, stride, pad) == (3, 3, 1, 1) and x.shape[3] == 32 and x.shape[2] == 32 and Co <= 32 and Co % 4 == 0 and
-                 x.shape[0] * x.shape[1] >= 512 and ops.math_mode() == ops.MATH_FP32 and not ops.timing_enabled())
+                 x.shape[0] * x.shape[1] >= 512 and not ops.timing_enabled())
         if slope != 1.0 and not gated:
             dy = act_bwd(dy, y, slope)
         B, Ho, Wo, _ = dy.shape

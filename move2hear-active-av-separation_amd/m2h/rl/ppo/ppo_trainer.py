@@ -51,6 +51,9 @@ def near_target_config(**over):
              rollout_math=None,         # build-side key: arithmetic of the rollout steps' conv / GEMM launches: None = the calling thread's mode (ops.set_math_mode);
              #                            "fp32" pins them to fp32 MFMA whatever the update phases compute in (the mixed-precision far-target leg: at 14
              #                            environments nothing is matrix-bound, and the one-launch / skinny kernels of that batch are fp32 kernels)
+             sep_update_math=None,      # build-side key: arithmetic of update_sep's launches (AcousticMem over the 1680 stored samples: the one matrix-bound
+             #                            phase of the cycle): None = the calling thread's mode; "bf16x3" = split bf16 products, fp32 accumulate (the
+             #                            image-row kernels of csrc/conv_igemm.hip / conv_bwd.hip: ~6e-6 from the fp32 result, 1.36 -> 0.75 ms per epoch)
              action_sampling="device")  # build-side key: "device" = multinomial noise from the device generator; "cpu_generator" = from
     #                                     the CPU default generator: the reference PyTorch-CPU run's actions from the seed alone
     c.update(over)
@@ -315,7 +318,13 @@ class PPOTrainer:
         ro.after_update()
         return out
 
+    _MATH = {"fp32": ops.MATH_FP32, "bf16x3": ops.MATH_BF16X3}
+
     def _update_sep(self):
+        sm = getattr(self.config, "sep_update_math", None)
+        if sm is not None and ops.math_mode() != self._MATH[sm]:
+            with ops.math_scope(self._MATH[sm]):    # (autograd Functions carry the forward's mode into their backward)
+                return self._update_sep()
         out = self.agent.update_sep(self.rollouts_sep)
         self.rollouts_sep.after_update()
         self._next_cache = None  # acoustic_mem changed: the cached next-step memory output is stale

@@ -2,7 +2,7 @@
 AcousticMem's rollout forward (memory_nets.py:40-69), the no-grad GRU cell (rnn_state_encoder.py:74-84), Policy.act's heads + draw +
 log-probability (rl/ppo/policy.py:217-225), the BPTT step with the previous step's gate backward (nn.GRU autograd), the activation
 backward folded into the image-row weight gradient (ppo.py:228-230), and update_sep on the separator outputs the rollout stored
-(ppo.py:184-195 without the recompute)."""
+(ppo.py:184-195 without the recompute), and the image-row 3x3 kernels of update_sep in bf16x3 arithmetic against the fp32 ones and torch."""
 import numpy as np
 import pytest
 import torch
@@ -162,3 +162,93 @@ def test_update_sep_on_stored_separator_outputs_equals_the_recompute():
         assert abs(a - b) < 2e-6 * max(1.0, abs(b))
     for k in out[True][1]:
         assert (out[True][1][k] - out[False][1][k]).abs().max().item() < 2e-6, k
+
+
+# ---------------------------------------------------------------------------------------------------------------- bf16x3 image-row kernels
+def _amem_case(B, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 32, 32, 32, generator=g) * 2            # the sliced, concatenated input (non-negative magnitudes)
+    w0 = torch.randn(32, 32, 3, 3, generator=g) * 0.08
+    w1 = torch.randn(16, 32, 3, 3, generator=g) * 0.08
+    return x.to(dev), w0.to(dev), w1.to(dev)
+
+
+@pytest.mark.parametrize("B", [64, 97])
+def test_image_row_convs_in_bf16x3_match_fp32_and_torch(B):
+    """memory_nets.py:11-16 over an update batch: conv3x3 + ReLU (32 -> 32, NHWC), conv3x3 (32 -> 16, de-sliced store) and the second
+    conv's input gradient (16 -> 32, taps mirrored), each by the fp32-MFMA image-row kernel and by its bf16x3 twin."""
+    from m2h import functional as MF
+    from m2h import ops
+    dev = _dev()
+    x, w0, w1 = _amem_case(B, B, dev)
+    dy = (torch.sign(torch.randn(B, 512, 32, 1, generator=torch.Generator().manual_seed(B))) / (B * 16384)).to(dev)   # an L1 loss's gradient
+    res = {}
+    for mode in (ops.MATH_FP32, ops.MATH_BF16X3):
+        with ops.math_scope(mode), torch.no_grad():
+            h = MF.conv2d(x, w0, None, 1, 1, slope=0.0)
+            k0 = ops.last_kernel()
+            y = MF.conv2d(h, w1, None, 1, 1, slope=1.0, deslice=True)
+            k1 = ops.last_kernel()
+            dh = MF.conv_dgrad(ops.slice_concat_input(dy, op=0), w1, (32, 32), 1, 1)
+            k2 = ops.last_kernel()
+        want = "conv_igemm_bf16x3 (image-row 3x3)" if mode == ops.MATH_BF16X3 else "conv_igemm_f32 (image-row 3x3)"
+        assert (k0, k1, k2) == (want, want, want), (k0, k1, k2)
+        res[mode] = (h, y, dh)
+    for a, b in zip(res[ops.MATH_BF16X3], res[ops.MATH_FP32]):
+        assert a.shape == b.shape and _rel(a, b) < 2e-5
+    xc = x.cpu().double().permute(0, 3, 1, 2)
+    hr = F.relu(F.conv2d(xc, w0.cpu().double(), None, 1, 1))
+    yr = F.conv2d(hr, w1.cpu().double(), None, 1, 1)
+    h16, y16, _ = res[ops.MATH_BF16X3]
+    assert _rel(h16.cpu().double().permute(0, 3, 1, 2), hr) < 2e-5
+    assert _rel(y16.cpu().double(), yr.reshape(B, 512, 32, 1)) < 2e-5
+
+
+@pytest.mark.parametrize("B,N", [(64, 16), (64, 32), (131, 32), (19, 16)])
+def test_image_row_weight_gradient_in_bf16x3_matches_fp32_and_torch(B, N):
+    """nn.Conv2d's weight gradient over an update batch (ppo.py:228-230), plain and with the layer's ReLU derivative folded in (the
+    SAME gate tensor in both modes: a gate that flips with the arithmetic is a different sub-gradient, not an error of the kernel)."""
+    from m2h import functional as MF
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + N)
+    x = (torch.rand(B, 32, 32, 32, generator=g) * 2).to(dev)
+    dy = torch.randn(B, 32, 32, N, generator=g).to(dev)
+    gate = torch.randn(B, 32, 32, N, generator=g).to(dev)
+    out = {}
+    for mode in (ops.MATH_FP32, ops.MATH_BF16X3):
+        with ops.math_scope(mode):
+            out[mode] = (MF.conv_wgrad(x, None, dy, N, 3, 3, 1, 1), MF.conv_wgrad(x, None, dy, N, 3, 3, 1, 1, gate=gate, gate_slope=0.0))
+    for a, b in zip(out[ops.MATH_BF16X3], out[ops.MATH_FP32]):
+        assert a.shape == (N, 288) and _rel(a, b) < 2e-5
+    w = torch.zeros(N, 32, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.cpu().double().permute(0, 3, 1, 2), w, None, 1, 1).backward((dy * (gate > 0)).cpu().double().permute(0, 3, 1, 2))
+    want = w.grad.permute(0, 2, 3, 1).reshape(N, 288)              # packed [n][(kh, kw, c)]
+    assert _rel(out[ops.MATH_BF16X3][1].cpu().double(), want) < 2e-5 and _rel(out[ops.MATH_FP32][1].cpu().double(), want) < 2e-6
+
+
+def test_update_sep_in_bf16x3_follows_the_fp32_update():
+    """sep_update_math="bf16x3" (build-side config key): the same update_sep -- losses and post-update memory weights -- as in fp32,
+    to the arithmetic's 1e-5; the rollout (which produced the storage) is untouched by the key."""
+    from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config
+    from m2h import ops
+    dev = _dev()
+    out = {}
+    for sm in (None, "bf16x3"):
+        cfg = near_target_config(num_updates_per_cycle=1, num_steps=8, NUM_PROCESSES=8, use_hip_graphs=True, action_sampling="cpu_generator", sep_update_math=sm)
+        tr = PPOTrainer(cfg, dev)
+        tr.setup()
+        tr.actor_critic.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), 1).items()})
+        torch.manual_seed(0)
+        for _ in range(cfg.num_steps):
+            tr._collect_rollout_step()
+        losses = tr._update_sep()
+        assert ops.math_mode() == ops.MATH_FP32        # the scope ends with the update
+        out[sm] = (losses, {k: v.detach().clone() for k, v in tr.actor_critic.acoustic_mem.state_dict().items()})
+    for a, b in zip(out["bf16x3"][0], out[None][0]):
+        assert abs(a - b) < 1e-5 * max(1.0, abs(b))
+    moved = 0.0
+    for k in out[None][1]:
+        assert (out["bf16x3"][1][k] - out[None][1][k]).abs().max().item() < 2e-5, k
+        moved = max(moved, (out[None][1][k] - torch.from_numpy(np.asarray(synthetic.make_state_dict(synthetic.policy_shapes(), 1)["acoustic_mem." + k])).to(dev)).abs().max().item())
+    assert moved > 1e-4                                 # (the update did move the weights)
