@@ -43,6 +43,14 @@ _side_streams = {}
 parallel_branches = os.environ.get("M2H_PARALLEL_BRANCHES", "1") != "0"     # module switch (tests / A-B measurements)
 
 
+def side_stream(device, index=0):
+    """A side HIP stream of `device` for a hand-made fork inside a graph capture (kept per device: graphs captured later re-use it)."""
+    key = (torch.device(device).index, "side", index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device)
+    return _side_streams[key]
+
+
 def _tensors(x):
     if torch.is_tensor(x):
         yield x

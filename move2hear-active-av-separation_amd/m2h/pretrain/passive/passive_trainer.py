@@ -97,24 +97,47 @@ class PassiveTrainer:
                tuple(p.data_ptr() for p in self.actor_critic.parameters()))
         if gs is None or gs.sig != sig:
             gs = self._train_graph = SimpleNamespace(sig=sig, graph=None, inputs=tuple(torch.empty_like(t) for t in (
-                mixed_audio, gt_bin_mag, gt_mono_mag, target_class)), losses=None)
+                mixed_audio, gt_bin_mag, gt_mono_mag, target_class)), losses=None, forked=False)
         for dst, src in zip(gs.inputs, (mixed_audio, gt_bin_mag, gt_mono_mag, target_class)):
             dst.copy_(src)
         if gs.graph is None:
             MF.bump_param_epoch()  # every packed-weight memo is stale at the capture: the ONE batched pack launch below becomes
             g = torch.cuda.CUDAGraph()  # the graph's first node (the warm-up step has told every memo which packs it needs)
+            gs.forked = graphs.parallel_branches
             with graphs.capture(g):
                 MF.refresh_pack_memos()
                 mix, gtb, gtm, tc = gs.inputs
-                with MF.batched_bn_counters():   # the 20 num_batches_tracked increments as one launch
-                    masks = self.actor_critic.get_binSepMasks({"mixed_bin_audio_mag": mix, "target_class": tc})
-                    mono = self.actor_critic.convert_bin2mono(masks.detach(), mixed_audio=mix)
-                bin_loss = MF.bin_l1_loss(masks, mix, gtb, cstep=1)
-                mono_loss = MF.l1_loss(mono, gtm, 0)
                 self.optimizer.zero_grad()
-                (bin_loss + mono_loss).backward()
+                if gs.forked:
+                    # The mono separator reads the binaural one's masks DETACHED (:218-249): the two networks' backward passes are
+                    # independent, and so is the second network's forward from the first one's backward.  Two branches of the graph:
+                    #   this stream:  forward A -> bin loss -> backward A
+                    #   side stream:  (after forward A) forward B -> mono loss -> backward B
+                    # (two backward() calls instead of one on the sum: the same gradients, each network's from its own loss).
+                    main = torch.cuda.current_stream()
+                    side = graphs.side_stream(self.device)
+                    with MF.batched_bn_counters():   # the 20 num_batches_tracked increments as one launch
+                        masks = self.actor_critic.get_binSepMasks({"mixed_bin_audio_mag": mix, "target_class": tc})
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            mono = self.actor_critic.convert_bin2mono(masks.detach(), mixed_audio=mix)
+                    with torch.cuda.stream(side):
+                        mono_loss = MF.l1_loss(mono, gtm, 0)
+                        mono_loss.backward()
+                    bin_loss = MF.bin_l1_loss(masks, mix, gtb, cstep=1)
+                    bin_loss.backward()
+                    main.wait_stream(side)
+                else:
+                    with MF.batched_bn_counters():
+                        masks = self.actor_critic.get_binSepMasks({"mixed_bin_audio_mag": mix, "target_class": tc})
+                        mono = self.actor_critic.convert_bin2mono(masks.detach(), mixed_audio=mix)
+                    bin_loss = MF.bin_l1_loss(masks, mix, gtb, cstep=1)
+                    mono_loss = MF.l1_loss(mono, gtm, 0)
+                    (bin_loss + mono_loss).backward()
                 gs.losses = (bin_loss.detach(), mono_loss.detach())
             gs.graph = g
+        if gs.forked:
+            torch.cuda.current_stream().synchronize()   # a graph with parallel branches goes onto a drained stream (m2h/graphs.py)
         gs.graph.replay()
         self.optimizer.step(max_grad_norm=None)
         return gs.losses
