@@ -531,6 +531,14 @@ int m2h_grad_clip_coef(const float* g, size_t n, float max_norm, float* coef, fl
 int m2h_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,
                   const float* coef, float gscale, m2h_stream stream);
 
+/* The same step with its step-dependent scalars read from device memory -- hyper[0] = lr, hyper[1] = 1 - beta1^t, hyper[2] =
+ * sqrt(1 - beta2^t) -- so that the launch can sit inside a captured HIP graph (the host refreshes `hyper` before each replay:
+ * m2h_adam_hyper writes the three values for step t, computed with m2h_adam_step's own host arithmetic, by a one-thread launch).  Same
+ * arithmetic as m2h_adam_step; p / g / m / v may be a sub-range of the flat buffers (one network's parameters). */
+int m2h_adam_hyper(float lr, float beta1, float beta2, int step, float* hyper /* 3 floats, DEVICE memory */, m2h_stream stream);
+int m2h_adam_step_dev(float* p, float* g, float* m, float* v, size_t n, const float* hyper, float beta1, float beta2, float eps,
+                      const float* coef, float gscale, m2h_stream stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Passive pre-training (pretrain/passive/passive_trainer.py:218-286): train-mode BatchNorm and transposed-conv gradients.
  * ------------------------------------------------------------------------------------------------------------------ */

@@ -795,6 +795,32 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __r
   if (w == 0 && n < N) part[(size_t)blockIdx.y * N + n] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
+// The same partial sums for NARROW gradients (N in {1, 2, 4, 8, 16, 32}: the U-Net heads' 2 channels over a million pixels, the encoders'
+// 32-channel convs): with lanes walking columns only N of 64 lanes work and a wave's load is an N-float run (the head's bias gradient
+// took 82 us for 8 MB).  Here a wave reads 64 consecutive floats = 64 / N whole rows per step (lane l: row l / N, column l % N), four
+// steps in flight, and the lanes of one column meet in a fixed xor butterfly; then the waves in order.
+__global__ __launch_bounds__(256) void bias_grad_partial_narrow_kernel(const float* __restrict__ dy, float* __restrict__ part, int M, int N,
+                                                                       int rows_per_split) {
+  __shared__ float sh[4][32];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int RW = 64 / N;                                   // rows per wave step
+  const int m0 = blockIdx.y * rows_per_split;
+  const int m1 = min(M, m0 + rows_per_split);
+  const size_t end = (size_t)m1 * N;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  size_t i = ((size_t)m0 + (size_t)w * RW) * N + lane;      // this lane's element; a block step is 4 waves x 64 floats
+  for (; i + 3 * 256 < end; i += 4 * 256) {
+    const float a = dy[i], b = dy[i + 256], c = dy[i + 512], d = dy[i + 768];
+    s0 += a; s1 += b; s2 += c; s3 += d;
+  }
+  for (; i < end; i += 256) s0 += dy[i];
+  float s = (s0 + s1) + (s2 + s3);
+  for (int o = 32; o >= N; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane < N) sh[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && lane < N) part[(size_t)blockIdx.y * N + lane] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+
 // one wave per column: lanes sum the splits strided by 64, then a fixed butterfly (deterministic)
 __global__ __launch_bounds__(256) void bias_grad_final_kernel(const float* __restrict__ part, float* __restrict__ db, int N, int splits) {
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -881,7 +907,11 @@ int m2h_bias_grad(const float* dy, float* db, int M, int N, float* workspace, m2
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, as_stream(stream), dy, db, M, N, rps);
     return launch_status("bias_grad");
   }
-  hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, as_stream(stream), dy, workspace, M, N, rps);
+  if (N <= 32 && 64 % N == 0) {   // narrow: splits of whole wave steps (64 / N rows); trailing splits may be empty (their partial is 0)
+    const int rw = 64 / N, rps_n = (rps + rw - 1) / rw * rw;
+    hipLaunchKernelGGL(bias_grad_partial_narrow_kernel, dim3(1, splits), dim3(256), 0, as_stream(stream), dy, workspace, M, N, rps_n);
+  } else
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, as_stream(stream), dy, workspace, M, N, rps);
   hipLaunchKernelGGL(bias_grad_final_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), workspace, db, N, splits);
   return launch_status("bias_grad");
 }

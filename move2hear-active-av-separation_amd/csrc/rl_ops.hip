@@ -845,8 +845,13 @@ __global__ void clip_coef_kernel(const float* __restrict__ part, int nparts, flo
 // (1/world_size after a sum all-reduce) and written back scaled (as clip_grad_norm_ does in place).
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    size_t n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
-                                                   const float* __restrict__ coef, float gscale) {
+                                                   const float* __restrict__ coef, float gscale, const float* __restrict__ hyper) {
   const float c = (coef != nullptr ? coef[0] : 1.f) * gscale;
+  if (hyper != nullptr) {   // m2h_adam_step_dev: the step-dependent scalars come from device memory (a replayed HIP graph holds no host scalars)
+    lr = hyper[0];
+    bc1 = hyper[1];
+    bc2_sqrt = hyper[2];
+  }
   const float step = lr / bc1;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * c;
@@ -858,6 +863,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] -= step * (mi / denom);
   }
+}
+
+__global__ void set3_kernel(float* __restrict__ dst, float a, float b, float c) {
+  dst[0] = a;
+  dst[1] = b;
+  dst[2] = c;
 }
 
 // Minibatch gather of the recurrent generators (common/rollout_storage.py:182-298,392-457):
@@ -1093,8 +1104,25 @@ int m2h_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, fl
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps, bc1,
-                     sqrtf(bc2), coef, gscale);
+                     sqrtf(bc2), coef, gscale, (const float*)nullptr);
   return launch_status("adam_step");
+}
+
+int m2h_adam_hyper(float lr, float beta1, float beta2, int step, float* hyper, m2h_stream stream) {
+  M2H_REQUIRE(hyper && step >= 1, "adam_hyper: bad arguments");
+  // host arithmetic of m2h_adam_step (both entries take the same step); the values travel as kernel arguments: stream-ordered, no
+  // host buffer to keep alive, no blocking copy
+  hipLaunchKernelGGL(set3_kernel, dim3(1), dim3(1), 0, as_stream(stream), hyper, lr, 1.f - powf(beta1, (float)step),
+                     sqrtf(1.f - powf(beta2, (float)step)));
+  return launch_status("adam_hyper");
+}
+
+int m2h_adam_step_dev(float* p, float* g, float* m, float* v, size_t n, const float* hyper, float beta1, float beta2, float eps,
+                      const float* coef, float gscale, m2h_stream stream) {
+  M2H_REQUIRE(p && g && m && v && hyper && n > 0, "adam_step_dev: bad arguments");
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, as_stream(stream), p, g, m, v, n, 0.f, beta1, beta2, eps, 1.f, 1.f, coef,
+                     gscale, hyper);
+  return launch_status("adam_step_dev");
 }
 
 int m2h_sq_stats(const float* pred, const float* gt_comps, int gt_stride, int gt_off, float* stats, int N, int L, m2h_stream stream) {

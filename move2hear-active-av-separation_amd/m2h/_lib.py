@@ -214,6 +214,8 @@ SIGNATURES = {
     "m2h_bin_l1_loss": [_P, _P, _P, _I, _I, _P, _P, _P, _Z, _P],
     "m2h_grad_clip_coef": [_P, _Z, _F, _P, _P, _P],
     "m2h_adam_step": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _P, _F, _P],
+    "m2h_adam_hyper": [_F, _F, _F, _I, _P, _P],
+    "m2h_adam_step_dev": [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _P, _F, _P],
     "m2h_sq_stats": [_P, _P, _I, _I, _P, _I, _I, _P],
     "m2h_rewards_from_stats": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "m2h_conv_wgrad_workspace_bytes": [ctypes.POINTER(ConvArgs)],

@@ -265,18 +265,32 @@ class _PackMemo:
 _refresh_hooks = weakref.WeakSet()   # objects with a sync() that brings derived weight tensors up to date before the packs (FusedAudioPair)
 
 
-def refresh_pack_memos(hooks=True):
+def memos_of(*modules):
+    """The packed-weight memos held by `modules` and their sub-modules (attributes that are a _PackMemo or a list / tuple of them)."""
+    out = []
+    for root in modules:
+        for mod in root.modules():
+            for v in vars(mod).values():
+                for m in (v if isinstance(v, (list, tuple)) else (v,)):
+                    if isinstance(m, _PackMemo):
+                        out.append(m)
+    return out
+
+
+def refresh_pack_memos(hooks=True, only=None):
     """Re-packs (in place) every packed operand whose source weights changed since it was packed, with one batched launch per
     48 tensors.  Called before a HIP-graph replay (the graph reads the packed buffers by address and contains no pack kernels)
     and at the top of a captured training step.
     hooks: also bring derived weight tensors (FusedAudioPair's block-diagonal copies) up to date first.  Skipped inside a
     HIP-graph capture (a capture of some OTHER model must not trip over them: they are rebuilt outside captures, and their user
-    checks freshness itself) and by callers whose graph does not read them (the update_pol epoch)."""
+    checks freshness itself) and by callers whose graph does not read them (the update_pol epoch).
+    only: restrict the refresh to these memos (``memos_of(network)``): a step that packs each network's weights on that network's own
+    stream (the passive training step's two graph branches)."""
     if hooks and not torch.cuda.is_current_stream_capturing():
         for h in list(_refresh_hooks):
             h.sync()
     items = []
-    for m in list(_pack_memos):
+    for m in (list(_pack_memos) if only is None else only):   # only: the memos of one network (memos_of), the others are the caller's business
         items += m.stale_items()
     if items:
         ops.pack_batch(items)

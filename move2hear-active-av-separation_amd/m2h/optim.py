@@ -36,6 +36,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
         self.coef = torch.ones(2, device=dev, dtype=torch.float32)
         self._coef_dirty = False
+        self._hyper = torch.zeros(4, device=dev, dtype=torch.float32)    # lr, 1 - beta1^t, sqrt(1 - beta2^t) of captured_step launches
         self._scratch = torch.empty(1024, device=dev, dtype=torch.float32)
         off = 0
         with torch.no_grad():
@@ -135,6 +136,57 @@ class FlatAdam(torch.optim.Optimizer):
                                          self.n, float(lr), float(b1), float(b2), float(eps), self.t, ops._ptr(self.coef), 1.0, st),
                        "m2h_adam_step")
         from . import functional
+        functional.bump_param_epoch()
+
+    # ------------------------------------------------------------------ the step inside a captured HIP graph
+    def param_range(self, params):
+        """[begin, end) of `params` in the flat buffers; they must be a contiguous run of this optimizer's parameters."""
+        if not self._built:
+            self._build()
+        ids = {id(p) for p in params if p.requires_grad}
+        idx = [i for i, p in enumerate(self._ps) if id(p) in ids]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)) or len(idx) != len(ids):
+            raise ValueError("FlatAdam.param_range: the parameters are not a contiguous run of this optimizer's")
+        return self._offsets[idx[0]], self._offsets[idx[-1]] + self._ps[idx[-1]].numel(), idx
+
+    @torch.no_grad()
+    def captured_step(self, params=None):
+        """Adam on the current gradients of `params` (default: all), to be CAPTURED into a HIP graph right behind the backward that
+        produced them (no clipping: passive pre-training).  The step count and the learning rate reach the kernel through
+        a device buffer: call ``begin_replayed_step()`` on the host before every replay (once per step, however many ranges the graph
+        updates), ``end_replayed_step()`` after it."""
+        b0, b1_, idx = self.param_range(params if params is not None else self._ps)
+        items = []
+        for i in idx:
+            p, off = self._ps[i], self._offsets[i]
+            if p.grad is None:
+                raise RuntimeError("FlatAdam.captured_step: a parameter of the range has no gradient")
+            dst = self.flat_g[off:off + p.numel()]
+            if p.grad.data_ptr() != dst.data_ptr():
+                items.append((p.grad.contiguous().view(-1), dst, -1, -1))
+        if items:
+            ops.rows_copy(items, self._no_idx)
+        g = self.param_groups[0]
+        eps, (b1, b2) = g["eps"], g["betas"]
+        lib = _lib.load()
+        sl = slice(b0, b1_)
+        with torch.cuda.device(self.flat_p.device):
+            _lib.check(lib.m2h_adam_step_dev(ops._ptr(self.flat_p[sl]), ops._ptr(self.flat_g[sl]), ops._ptr(self.exp_avg[sl]),
+                                             ops._ptr(self.exp_avg_sq[sl]), b1_ - b0, ops._ptr(self._hyper), float(b1), float(b2), float(eps),
+                                             None, 1.0, ops._stream(self.flat_p)), "m2h_adam_step_dev")
+
+    def begin_replayed_step(self):
+        """Host side of a replayed step whose graph holds ``captured_step`` launches: count the step, upload lr and the bias corrections."""
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        self.t += 1
+        with torch.cuda.device(self.flat_p.device):
+            _lib.check(_lib.load().m2h_adam_hyper(float(g["lr"]), float(b1), float(b2), self.t, ops._ptr(self._hyper), ops._stream(self._hyper)),
+                       "m2h_adam_hyper")
+
+    def end_replayed_step(self):
+        from . import functional
+        self._gathered = False
         functional.bump_param_epoch()
 
     measure_grad_norm = False   # True: step(max_grad_norm=None) still measures ||g||_2 (grad_norm()); off: those two launches are skipped

@@ -87,8 +87,8 @@ class PassiveTrainer:
         """A training batch with forward (train-mode BN, running statistics included), both losses and the whole backward
         replayed from one HIP graph: at the reference batch (64 x 512x32) the step is ~700 small launches behind Python and
         autograd dispatch.  The batch is copied into four static tensors; weight (re)packing is part of the graph (the packed
-        copies are made from the current weights at every replay); the optimizer step -- its step count enters Adam's bias
-        correction as a host scalar -- stays outside.  Returns the two loss scalars of THIS replay (static tensors,
+        copies are made from the current weights at every replay) and so is the optimizer step (its step count and learning
+        rate reach the kernel through a device buffer: FlatAdam.captured_step).  Returns the two loss scalars of THIS replay (static tensors,
         overwritten by the next one)."""
         from ... import graphs
         gs = self._train_graph
@@ -105,9 +105,20 @@ class PassiveTrainer:
             g = torch.cuda.CUDAGraph()  # the graph's first node (the warm-up step has told every memo which packs it needs)
             gs.forked = graphs.parallel_branches
             with graphs.capture(g):
-                MF.refresh_pack_memos()
                 mix, gtb, gtm, tc = gs.inputs
                 self.optimizer.zero_grad()
+                ac = self.actor_critic
+                memos_b = MF.memos_of(ac.bin2mono_enc, ac.bin2mono_dec) if gs.forked else []
+                if gs.forked and memos_b:
+                    # the second network's weights are packed on ITS branch, under the first network's forward
+                    ids_b = {id(m) for m in memos_b}
+                    MF.refresh_pack_memos(only=[m for m in list(MF._pack_memos) if id(m) not in ids_b])
+                    side = graphs.side_stream(self.device)
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        MF.refresh_pack_memos(hooks=False, only=memos_b)
+                else:
+                    MF.refresh_pack_memos()
                 if gs.forked:
                     # The mono separator reads the binaural one's masks DETACHED (:218-249): the two networks' backward passes are
                     # independent, and so is the second network's forward from the first one's backward.  Two branches of the graph:
@@ -124,8 +135,12 @@ class PassiveTrainer:
                     with torch.cuda.stream(side):
                         mono_loss = MF.l1_loss(mono, gtm, 0)
                         mono_loss.backward()
+                        self.optimizer.captured_step(list(ac.bin2mono_enc.parameters()) + list(ac.bin2mono_dec.parameters()))
                     bin_loss = MF.bin_l1_loss(masks, mix, gtb, cstep=1)
                     bin_loss.backward()
+                    # each network's Adam step right behind its own backward, on its own branch (FlatAdam.captured_step: lr and the
+                    # bias corrections come from a device buffer the host refreshes before each replay)
+                    self.optimizer.captured_step(list(ac.binSep_enc.parameters()) + list(ac.binSep_dec.parameters()))
                     main.wait_stream(side)
                 else:
                     with MF.batched_bn_counters():
@@ -134,12 +149,14 @@ class PassiveTrainer:
                     bin_loss = MF.bin_l1_loss(masks, mix, gtb, cstep=1)
                     mono_loss = MF.l1_loss(mono, gtm, 0)
                     (bin_loss + mono_loss).backward()
+                    self.optimizer.captured_step()
                 gs.losses = (bin_loss.detach(), mono_loss.detach())
             gs.graph = g
+        self.optimizer.begin_replayed_step()
         if gs.forked:
             torch.cuda.current_stream().synchronize()   # a graph with parallel branches goes onto a drained stream (m2h/graphs.py)
         gs.graph.replay()
-        self.optimizer.step(max_grad_norm=None)
+        self.optimizer.end_replayed_step()
         return gs.losses
 
     def train_batch(self, mixed_audio, gt_bin_mag, gt_mono_mag, target_class, split="train"):

@@ -252,3 +252,18 @@ def test_update_sep_in_bf16x3_follows_the_fp32_update():
         assert (out["bf16x3"][1][k] - out[None][1][k]).abs().max().item() < 2e-5, k
         moved = max(moved, (out[None][1][k] - torch.from_numpy(np.asarray(synthetic.make_state_dict(synthetic.policy_shapes(), 1)["acoustic_mem." + k])).to(dev)).abs().max().item())
     assert moved > 1e-4                                 # (the update did move the weights)
+
+
+@pytest.mark.parametrize("M,N", [(1 << 20, 2), (65536, 32), (269080, 32), (1000, 1), (4099, 4), (70000, 16), (5000, 8), (3000, 48), (2049, 64), (700, 2)])
+def test_bias_gradient_column_sums_narrow_and_wide(M, N):
+    """nn.Conv2d's bias gradient = column sums of dY (ppo.py:228-230 through autograd): the narrow kernel (N dividing 64: a wave reads
+    whole rows, 64 floats a step -- the U-Net heads' 2 channels over a million pixels) and the column-walking one, against float64."""
+    from m2h import functional as MF
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N)
+    dy = torch.randn(M, N, generator=g)
+    got = MF.bias_grad(dy.to(dev))
+    want = dy.double().sum(0)
+    assert got.shape == (N,)
+    assert (got.cpu().double() - want).abs().max().item() < 2e-6 * max(1.0, dy.abs().double().sum(0).max().item())
+    assert torch.equal(got, MF.bias_grad(dy.to(dev)))          # (ordered reduction: the same bits every time)
