@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-far-target", action="store_true", help="skip the far-target / mixed-precision DD-PPO leg")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the pair kernel by kernel instead of replaying a HIP graph")
     ap.add_argument("--ddppo-cycles", type=int, default=2, help="timed DD-PPO cycles (0 = skip); one untimed warm-up cycle precedes them")
+    ap.add_argument("--tail-overlap", action="store_true",
+                    help="DD-PPO legs: enqueue the cycle's six update_sep on a second stream beside the last update_pol (overlap_update_tail; measured +0.5 %%: off)")
     ap.add_argument("--sep-update-math", choices=["fp32", "bf16x3"], default="bf16x3",
                     help="near-target DD-PPO leg: arithmetic of update_sep's launches (its convs over the 1680 stored samples are the cycle's one "
                          "matrix-bound phase); rollout and update_pol compute in fp32 either way")
@@ -285,7 +287,9 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
     from m2h import ops
     from m2h.rl.ppo.ppo_trainer import PPOTrainer, far_target_config, near_target_config
     syn = __import__("m2h.synthetic", fromlist=["x"])
-    cfg = far_target_config(rollout_math="fp32") if far_target else near_target_config(sep_update_math=args.sep_update_math)
+    tail = bool(args.tail_overlap)
+    cfg = (far_target_config(rollout_math="fp32", overlap_update_tail=tail) if far_target
+           else near_target_config(sep_update_math=args.sep_update_math, overlap_update_tail=tail))
     ops.set_math_mode(ops.MATH_BF16X3 if far_target else ops.MATH_FP32)
     try:
         tr = PPOTrainer(cfg, dev, world_rank=rank, world_size=world)
@@ -339,6 +343,9 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
             standalone_us = 1e3 * e0.elapsed_time(e1) / 5
             del buf
         breakdown["allreduce_23MB_us"] = round(standalone_us, 1)
+        if tail:
+            breakdown["overlap"] = ("the cycle's six update_sep run on a second HIP stream beside the sixth update_pol (same results, tests/test_gpu_round4.py): "
+                                    "update_sep_ms is measured on that stream and overlaps the last sixth of update_pol_ms, so the three phases sum to more than the cycle")
         breakdown["what"] = ("HIP-event time per cycle of the three phases on the compute stream (6 x rollout of 20 steps, 6 x update_pol, 6 x update_sep) and of the "
                              "flat-gradient all-reduces on the stream each ran on (the last one of every update on the side stream, under the next phase); "
                              "allreduce_23MB_us = a stand-alone all-reduce of the policy gradient's size; all zero-collective at one rank")

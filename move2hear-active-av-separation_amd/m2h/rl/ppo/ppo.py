@@ -169,7 +169,11 @@ class PPO(nn.Module):
         num_envs = rollouts_pol.rewards.size(1)
         for _e in range(self.ppo_epoch):
             self._reducers["pol"].fence()   # the graph holds no fence: order it after a pending optimizer step here
-            MF.refresh_pack_memos(hooks=False)  # conv weights re-packed in place after the previous step (the rollout's fused audio pair is rebuilt lazily, by its next user)
+            # conv weights re-packed in place after the previous step (the rollout's fused audio pair is rebuilt lazily, by its next user).
+            # AcousticMem's packs are not this update's business -- and not its right: the trainer may be running update_sep on a second
+            # stream at this moment (ppo_trainer.py, the cycle's tail), where that module re-packs its own weights in its own order.
+            mem_ids = {id(m) for m in MF.memos_of(self.actor_critic.acoustic_mem)}
+            MF.refresh_pack_memos(hooks=False, only=[m for m in list(MF._pack_memos) if id(m) not in mem_ids])
             if gs.graph is None:
                 cpu_rng = torch.get_rng_state()  # capture executes the python once without running kernels: no RNG side effect
                 g = torch.cuda.CUDAGraph()
@@ -229,7 +233,9 @@ class PPO(nn.Module):
         self._sep_cache = (key, val)
         return val
 
-    def update_sep(self, rollouts_sep):
+    def update_sep(self, rollouts_sep, as_tensor=False):
+        """as_tensor: return the three mean losses as a device tensor instead of python floats (no host synchronisation: the
+        trainer enqueues the cycle's separator updates on a second stream and reads the losses after the join)."""
         acc = torch.zeros(3, device=self.device)
         sep_frozen = not any(p.requires_grad for m in (self.actor_critic.binSep_enc, self.actor_critic.binSep_dec,
                                                         self.actor_critic.bin2mono_enc, self.actor_critic.bin2mono_dec)
@@ -276,6 +282,8 @@ class PPO(nn.Module):
                 self._reduce_and_step("mem", self.optimizer_sep, last=_e == self.ppo_epoch - 1 and _mb == self.num_mini_batch - 1)
                 acc += torch.stack((bin_loss, mono_loss, monoFromMem_loss.detach()))
         num_updates = self.ppo_epoch * self.num_mini_batch
+        if as_tensor:
+            return acc / num_updates
         b, m, mm = (acc / num_updates).tolist()
         return b, m, mm
 

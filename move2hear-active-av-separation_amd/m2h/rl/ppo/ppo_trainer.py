@@ -51,6 +51,10 @@ def near_target_config(**over):
              rollout_math=None,         # build-side key: arithmetic of the rollout steps' conv / GEMM launches: None = the calling thread's mode (ops.set_math_mode);
              #                            "fp32" pins them to fp32 MFMA whatever the update phases compute in (the mixed-precision far-target leg: at 14
              #                            environments nothing is matrix-bound, and the one-launch / skinny kernels of that batch are fp32 kernels)
+             overlap_update_tail=False,  # build-side key: the cycle's six update_sep on a second HIP stream beside the last update_pol (same bits,
+             #                            tests/test_gpu_round4.py).  Off: measured +0.5 % only (profiles/r04_ddppo_tail_overlap_ab.txt) -- update_sep's
+             #                            image-row kernels keep every CU's LDS occupied for their whole run, so the policy update's small
+             #                            kernels wait for the gaps between them instead of running beside them
              sep_update_math=None,      # build-side key: arithmetic of update_sep's launches (AcousticMem over the 1680 stored samples: the one matrix-bound
              #                            phase of the cycle): None = the calling thread's mode; "bf16x3" = split bf16 products, fp32 accumulate (the
              #                            image-row kernels of csrc/conv_igemm.hip / conv_bwd.hip: ~6e-6 from the fp32 result, 1.36 -> 0.75 ms per epoch)
@@ -320,12 +324,12 @@ class PPOTrainer:
 
     _MATH = {"fp32": ops.MATH_FP32, "bf16x3": ops.MATH_BF16X3}
 
-    def _update_sep(self):
+    def _update_sep(self, as_tensor=False):
         sm = getattr(self.config, "sep_update_math", None)
         if sm is not None and ops.math_mode() != self._MATH[sm]:
             with ops.math_scope(self._MATH[sm]):    # (autograd Functions carry the forward's mode into their backward)
-                return self._update_sep()
-        out = self.agent.update_sep(self.rollouts_sep)
+                return self._update_sep(as_tensor)
+        out = self.agent.update_sep(self.rollouts_sep, as_tensor=as_tensor)
         self.rollouts_sep.after_update()
         self._next_cache = None  # acoustic_mem changed: the cached next-step memory output is stale
         return out
@@ -341,7 +345,7 @@ class PPOTrainer:
         cfg = self.config
         t0 = time.perf_counter()
         steps = 0
-        pol_losses, sep_losses = None, None
+        pol_losses, sep_losses, tail, sep_pending = None, None, False, None
         for _sub in range(cfg.num_updates_per_cycle):
             if cfg.use_linear_lr_decay:
                 self.lr_scheduler_pol.step()
@@ -353,13 +357,19 @@ class PPOTrainer:
                 sub_steps += self._collect_rollout_step()
             steps += sub_steps
             e1 = self._mark(phase_events)
+            tail = _sub == cfg.num_updates_per_cycle - 1 and self._tail_overlap(checkpoint)
+            if tail:
+                sep_pending = self._enqueue_separator_updates(phase_events)
             pol_losses = self._update_pol()
             if phase_events is not None:
                 phase_events += [("rollout", e0, e1), ("update_pol", e1, self._mark(phase_events))]
             self.num_updates_done += 1
             if log_stats:
                 self._log_window_stats(pol_losses, sub_steps)
-        for _sub in range(cfg.num_updates_per_cycle):
+        if tail:
+            torch.cuda.current_stream(self.device).wait_stream(self._tail_stream)
+            sep_losses = tuple(sep_pending[-1].tolist())
+        for _sub in range(0 if tail else cfg.num_updates_per_cycle):
             if cfg.use_linear_lr_decay:
                 self.lr_scheduler_sep.step()
             e0 = self._mark(phase_events)
@@ -373,6 +383,43 @@ class PPOTrainer:
         if not log_stats:
             self.count_steps += steps
         return {"env_steps": steps, "seconds": time.perf_counter() - t0, "pol_losses": pol_losses, "sep_losses": sep_losses}
+
+    # ------------------------------------------------------------------ the cycle's tail: update_pol #6 beside the six update_sep
+    # After the last rollout of a cycle nothing links the last policy update (policy network + heads, policy storage, "pol" optimizer)
+    # to the separator updates (AcousticMem, separator storage, "mem" optimizer): the reference runs them one after the other
+    # (:730-1011), here the six update_sep are enqueued on a second HIP stream -- no host synchronisation inside: their losses stay on
+    # the device until the join -- and the policy update runs beside them on the compute stream.  Same kernels on the same data in the
+    # same per-stream order: the same bits (tests/test_gpu_round4.py).  Opt-in (overlap_update_tail): measured, the policy update's small
+    # launches find no room beside update_sep's image-row kernels (2 x 67 KB of LDS per CU for a launch's whole run) and the cycle gains
+    # 0.5 % (12 560-12 670 -> 12 630-12 720 env-steps/s).  The CPU generator's randperm draws of the two phases swap places;
+    # with full-batch views (one mini-batch) their values are never used and each advances the generator by the same amount.
+    def _tail_overlap(self, checkpoint):
+        cfg = self.config
+        return (bool(getattr(cfg, "overlap_update_tail", False)) and self.device.type == "cuda" and not checkpoint and cfg.num_mini_batch == 1
+                and getattr(self.rollouts_sep, "full_batch_views", False) and getattr(self.rollouts_pol, "full_batch_views", False)
+                and not ops.timing_enabled())
+
+    _tail_stream = None
+
+    def _enqueue_separator_updates(self, phase_events):
+        cfg = self.config
+        main = torch.cuda.current_stream(self.device)
+        if self._tail_stream is None:
+            self._tail_stream = torch.cuda.Stream(self.device)
+        # the second stream starts where the compute stream stands; the host waits for that point first, so that the stream's first
+        # packet is not parked behind the rollout's replays (a parked cross-queue wait slows the running queue: m2h/graphs.py)
+        main.synchronize()
+        out = []
+        with torch.cuda.stream(self._tail_stream):
+            for _sub in range(cfg.num_updates_per_cycle):
+                if cfg.use_linear_lr_decay:
+                    self.lr_scheduler_sep.step()
+                e0 = self._mark(phase_events)
+                out.append(self._update_sep(as_tensor=True))
+                if phase_events is not None:
+                    phase_events.append(("update_sep", e0, self._mark(phase_events)))
+                self.num_sep_updates_done += 1
+        return out
 
     def _mark(self, sink):
         if sink is None:

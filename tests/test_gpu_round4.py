@@ -267,3 +267,31 @@ def test_bias_gradient_column_sums_narrow_and_wide(M, N):
     assert got.shape == (N,)
     assert (got.cpu().double() - want).abs().max().item() < 2e-6 * max(1.0, dy.abs().double().sum(0).max().item())
     assert torch.equal(got, MF.bias_grad(dy.to(dev)))          # (ordered reduction: the same bits every time)
+
+
+def test_cycle_tail_overlap_leaves_the_same_bits():
+    """overlap_update_tail (build-side config key): the cycle's six update_sep on a second stream beside the last update_pol.  Same kernels
+    on the same data in the same per-stream order: losses, every weight, both storages and the CPU generator's state equal the
+    one-stream cycle's bit for bit, over three cycles (a race between the two streams would show as a difference here)."""
+    from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config
+    dev = _dev()
+    out = {}
+    for overlap in (False, True):
+        cfg = near_target_config(num_updates_per_cycle=3, num_steps=6, NUM_PROCESSES=6, MAX_EPISODE_STEPS=6, use_hip_graphs=True, action_sampling="cpu_generator",
+                                 overlap_update_tail=overlap, sep_update_math="bf16x3")
+        tr = PPOTrainer(cfg, dev)
+        tr.setup()
+        tr.actor_critic.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), 3).items()})
+        torch.manual_seed(7)
+        res = [tr.train_cycle() for _ in range(3)]
+        assert (tr._tail_stream is not None) == overlap
+        tr.agent.synchronize_updates()
+        torch.cuda.synchronize()
+        out[overlap] = ([(r["pol_losses"], r["sep_losses"]) for r in res], {k: v.detach().clone() for k, v in tr.actor_critic.state_dict().items()},
+                        tr.rollouts_sep.prev_pred_monoFromMem.clone(), tr.rollouts_pol.rewards.clone(), torch.get_rng_state().clone(),
+                        tr.num_sep_updates_done, tr.num_updates_done)
+    a, b = out[False], out[True]
+    assert a[0] == b[0], (a[0], b[0])
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and a[5:] == b[5:]
