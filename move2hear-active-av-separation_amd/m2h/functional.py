@@ -534,9 +534,19 @@ class PPOLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_stats):
         gv, gl = ctx.saved_tensors
-        # g_total is 1 for total_loss.backward(); scaling by it is a scalar multiply on [n,1] tensors
-        ge = torch.full((ctx.n,), -ctx.ecoef / ctx.n, device=gv.device) * g_total
-        return gv * g_total, gl * g_total, ge, None, None, None, None, None, None, None, None
+        key = (gv.device, ctx.n, float(ctx.ecoef))
+        ge = _entropy_grads.get(key)               # d total / d entropy[i] = -entropy_coef / n: a constant tensor, made once
+        if ge is None:
+            ge = torch.full((ctx.n,), -ctx.ecoef / ctx.n, device=gv.device)
+            if not torch.cuda.is_current_stream_capturing():      # (a tensor born inside a capture holds nothing until a replay: not cached)
+                if len(_entropy_grads) > 16:
+                    _entropy_grads.clear()
+                _entropy_grads[key] = ge
+        u = _unit_grads.get(g_total.device)
+        if u is not None and g_total.data_ptr() == u.data_ptr():
+            return gv, gl, ge, None, None, None, None, None, None, None, None     # root gradient = unit_grad: no multiplies by one (4 launches per epoch)
+        # any other root gradient: a scalar multiply on [n,1] tensors
+        return gv * g_total, gl * g_total, ge * g_total, None, None, None, None, None, None, None, None
 
 
 class L1Loss(torch.autograd.Function):
@@ -567,6 +577,7 @@ class L1Loss(torch.autograd.Function):
 
 
 _unit_grads = {}
+_entropy_grads = {}
 
 
 def unit_grad(device):

@@ -127,7 +127,7 @@ class PPO(nn.Module):
         total_loss, stats = MF.PPOLoss.apply(values, logp, ent_rows, value_preds_batch, return_batch, adv_targ, old_logp_batch,
                                              clip, float(self.value_loss_coef), float(self.entropy_coef),
                                              bool(self.use_clipped_value_loss))
-        total_loss.backward()
+        total_loss.backward(MF.unit_grad(total_loss.device))
         acc += stats
 
     def update_pol(self, rollouts_pol):
