@@ -470,6 +470,11 @@ int m2h_conv_wgrad_f32(const m2h_conv_args* args /* host */, const float* dy, in
  * conv, memory_nets.py:11-16, at update_sep's 1.7 M pixels); other shapes are refused (rc < 0). */
 int m2h_conv_wgrad_gated_f32(const m2h_conv_args* args /* host */, const float* dy, int ldy, const float* y, float slope, float* dw,
                              m2h_stream stream);
+/* The same gradient delivered in nn.Conv2d's own layout dw[N][Ci][KH][KW] (Ci <= C0 + C1: packed channels from Ci on are input
+ * padding and are dropped) -- the split sum and the re-layout are one launch, where m2h_conv_wgrad_f32 + a permute copy were two
+ * (one launch less per conv layer of every backward pass; same bits).  y: optional gate as in m2h_conv_wgrad_gated_f32 (NULL: none). */
+int m2h_conv_wgrad_torch_f32(const m2h_conv_args* args /* host */, const float* dy, int ldy, const float* y, float slope, float* dw, int Ci,
+                             m2h_stream stream);
 
 /* Input gradient = forward engine on re-laid-out weights: for a Conv2d(k, stride s, pad p) weight w [Co][Ci][KH][KW]
  * (KH, KW multiples of s) writes s*s phase matrices wp[ph*s+pw][ci][th][tw][co] = w[co][ci][(ph+p)%s + s*th][(pw+p)%s + s*tw].

@@ -45,6 +45,7 @@ struct WGradP {
   float* dwp;       // quad: [4 phases][N][K] packed gradients (behind the slabs in the workspace)
   const float* gate;  // optional (image-row 3x3 kernel): the forward output y of the layer, same layout as dy: dy is read as
   float gate_slope;   // dy * (y > 0 ? 1 : gate_slope) -- the backward of the layer's fused ReLU / LeakyReLU without a pass of its own
+  int torch_ci;       // > 0: dw is nn.Conv2d's own layout [N][torch_ci][KH][KW] (channels torch_ci .. Ctot-1 of the packed k axis are input padding: dropped)
 };
 
 // phase (ph, pw) of a quad launch: taps step by 2 ph - 1 / 2 pw - 1 (separator_cnn.py:15-24 as four sub-pixel GEMMs)
@@ -607,23 +608,90 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const WGradP p)
   }
 }
 
-// quad launches: the reduce kernels above leave the packed per-phase gradients dwp[phase][co][(th, tw, ci)] behind the slabs; this
-// kernel scatters them to the torch layout dw[ci][co][kh][kw].  A block owns (co, 16 ci): reads 16 runs of 16 consecutive ci
-// (one per (kh, kw)), transposes through LDS, writes 16 runs of 64 bytes.  (unpack_convT_wgrad_kernel's element-per-thread form
-// writes 4-byte words 64 bytes apart: 25 us per layer on average.)
-__global__ __launch_bounds__(256) void convT_wgrad_unpack_kernel(const WGradP p, const float* __restrict__ dwp) {
+// Sum of one slab element over the splits [z0, z1) as the reduce kernels above do it: four running sums, combined pairwise.
+__device__ __forceinline__ float wgrad_quarter_sum(const float* __restrict__ src, int z0, int z1, size_t zs) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int z = z0;
+  for (; z + 3 < z1; z += 4) {
+    const float v0 = src[(size_t)z * zs], v1 = src[(size_t)(z + 1) * zs], v2 = src[(size_t)(z + 2) * zs], v3 = src[(size_t)(z + 3) * zs];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; z < z1; ++z) a0 += src[(size_t)z * zs];
+  return (a0 + a1) + (a2 + a3);
+}
+
+// The split sum of a 16 x 16 tile of gradient elements, in the order (and so with the bits) of the reduce kernel the launch would
+// otherwise take: S < 16 -> 256 threads, one running sum per element (wgrad_reduce_small_kernel); S >= 16 -> 1024 threads, thread
+// (quarter, element) sums its quarter of the splits, the quarters meet in LDS as (q0 + q1) + (q2 + q3) (wgrad_reduce_kernel).
+// src = this thread's element in split 0 (nullptr: outside the tensor).  Returns the sum in the threads of quarter 0.
+template <bool Q4>
+__device__ __forceinline__ float wgrad_tile_sum(const float* __restrict__ src, int S, size_t zs, float (*qs)[256]) {
+  const int el = threadIdx.x & 255, w = threadIdx.x >> 8;
+  if constexpr (!Q4) {
+    float s = 0.f;
+    if (src != nullptr)
+      for (int z = 0; z < S; ++z) s += src[(size_t)z * zs];
+    return s;
+  } else {
+    qs[w][el] = src != nullptr ? wgrad_quarter_sum(src, (int)(((long)S * w) / 4), (int)(((long)S * (w + 1)) / 4), zs) : 0.f;
+    __syncthreads();
+    return w == 0 ? (qs[0][el] + qs[1][el]) + (qs[2][el] + qs[3][el]) : 0.f;
+  }
+}
+
+// Transposed-conv weight gradient: split sum AND the scatter to the torch layout dw[ci][co][kh][kw] in one launch (round 4: one node
+// less per decoder layer on the training step's chain).  A block owns (co, 16 ci): element (e = kh * 4 + kw, ci) of phase (ph, pw),
+// tap (th, tw) is summed over the splits straight from the slabs (16 consecutive ci = 64-byte runs), the tile is transposed through
+// LDS and leaves as 16 runs of 64 bytes.
+template <bool Q4>
+__global__ __launch_bounds__(Q4 ? 1024 : 256) void convT_wgrad_reduce_unpack_kernel(const WGradP p) {
   __shared__ float tile[16][17];
+  __shared__ float qs[Q4 ? 4 : 1][256];
   const int cb = (p.Ctot + 15) / 16;
   const int n = blockIdx.x / cb, ci0 = (blockIdx.x - n * cb) * 16;
+  const int el = threadIdx.x & 255;
   {
-    const int e = threadIdx.x >> 4, ci = ci0 + (threadIdx.x & 15);   // e = kh * 4 + kw -> phase (ph, pw), tap (th, tw): kh = (ph ? 2 : 1) + th (ph ? -2 : 2)
+    const int e = el >> 4, ci = ci0 + (el & 15);
     const int kh = e >> 2, kw = e & 3;
     const int ph = (kh & 1) ^ 1, th = (kh == 0 || kh == 3) ? 1 : 0, pw = (kw & 1) ^ 1, tw = (kw == 0 || kw == 3) ? 1 : 0;
-    tile[threadIdx.x & 15][e] = ci < p.Ctot ? dwp[((size_t)(ph * 2 + pw) * p.N + n) * p.K + (size_t)(th * 2 + tw) * p.Ctot + ci] : 0.f;
+    const size_t zs = (size_t)p.N * p.Kpad;
+    const float* src = ci < p.Ctot ? p.ws + (size_t)(ph * 2 + pw) * p.S * zs + (size_t)n * p.Kpad + (size_t)(th * 2 + tw) * p.Ctot + ci : nullptr;
+    const float v = wgrad_tile_sum<Q4>(src, p.S, zs, qs);
+    if (threadIdx.x < 256) tile[el & 15][e] = v;
   }
   __syncthreads();
-  const int cl = threadIdx.x >> 4, e = threadIdx.x & 15;
-  if (ci0 + cl < p.Ctot) p.dw[((size_t)(ci0 + cl) * p.N + n) * 16 + e] = tile[cl][e];
+  if (threadIdx.x < 256) {
+    const int cl = el >> 4, e = el & 15;
+    if (ci0 + cl < p.Ctot) p.dw[((size_t)(ci0 + cl) * p.N + n) * 16 + e] = tile[cl][e];
+  }
+}
+
+// Conv2d weight gradient: split sum AND the re-layout packed [n][(tap, c)] -> torch [n][c][tap] in one launch (m2h_conv_wgrad_torch_f32: the
+// permute(0, 3, 1, 2).contiguous() copy of the packed gradient was a launch per conv layer of every backward pass).  A block owns
+// (n, 16 channels): its output is ONE run of 16 x ntap floats; taps go through the LDS tile sixteen at a time.
+template <bool Q4>
+__global__ __launch_bounds__(Q4 ? 1024 : 256) void conv_wgrad_reduce_torch_kernel(const WGradP p) {
+  __shared__ float tile[16][17];
+  __shared__ float qs[Q4 ? 4 : 1][256];
+  const int Ci = p.torch_ci;
+  const int cb = (Ci + 15) / 16;
+  const int n = blockIdx.x / cb, ci0 = (blockIdx.x - n * cb) * 16;
+  const size_t zs = (size_t)p.N * p.Kpad;
+  const int el = threadIdx.x & 255;
+  for (int t0 = 0; t0 < p.ntap; t0 += 16) {
+    {
+      const int t = t0 + (el >> 4), ci = ci0 + (el & 15);
+      const float* src = (t < p.ntap && ci < Ci) ? p.ws + (size_t)n * p.Kpad + (size_t)t * p.Ctot + ci : nullptr;
+      const float v = wgrad_tile_sum<Q4>(src, p.S, zs, qs);
+      if (threadIdx.x < 256) tile[el & 15][el >> 4] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const int cl = el >> 4, t = t0 + (el & 15);
+      if (ci0 + cl < Ci && t < p.ntap) p.dw[((size_t)n * Ci + ci0 + cl) * p.ntap + t] = tile[cl][el & 15];
+    }
+    __syncthreads();
+  }
 }
 
 // (tuning knob g_wgrad_blocks: thread-local, m2h_internal.h) tuning knob (m2h_tuning_set 11): target block count of a weight-gradient launch
@@ -662,7 +730,8 @@ size_t conv_wgrad_workspace_bytes(const m2h_conv_args& a) {
 // quad: the four phases of a ConvTranspose2d(4,2,1) in one launch (a = the geometry of one phase: taps 2x2, stride 1, os 2,
 // Ho = 2 Hi; its ph / pw / mulh / mulw are ignored), dw in the torch layout, workspace four times the single-phase size
 int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, hipStream_t st, bool quad = false, const float* gate = nullptr,
-                   float gate_slope = 1.f) {
+                   float gate_slope = 1.f, int torch_ci = 0) {
+  M2H_REQUIRE(torch_ci >= 0 && torch_ci <= a.C0 + a.C1 && (!quad || torch_ci == 0), "conv_wgrad: torch_ci (%d) must lie in 1 .. C0 + C1", torch_ci);
   M2H_REQUIRE(a.src0 != nullptr && dy != nullptr && dw != nullptr, "conv_wgrad: null pointer");
   M2H_REQUIRE(a.conv_transpose == 0, "conv_wgrad: describe a transposed conv by its phase geometry (m2h_convT_wgrad_f32)");
   M2H_REQUIRE(!quad || (a.nth == 2 && a.ntw == 2 && a.stride == 1 && a.os == 2 && a.offh == 0 && a.offw == 0 && a.Hq == a.Hi && a.Wq == a.Wi &&
@@ -691,7 +760,7 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   p.ws = static_cast<float*>(a.workspace);
   p.dwp = quad ? p.ws + slab_floats : nullptr;
   p.dw = dw;
-  p.gate = gate; p.gate_slope = gate_slope;
+  p.gate = gate; p.gate_slope = gate_slope; p.torch_ci = torch_ci;
   int bng, kt;
   wgrad_cfg(a.N, p.K, bng, kt, p.ktiles);
   p.ntiles = (a.N + bng - 1) / bng;
@@ -717,6 +786,20 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   else hipLaunchKernelGGL((wgrad_kernel<32, 3, 1>), grid, blk, 0, st, p);
   int rc = launch_status("conv_wgrad");
   if (rc) return rc;
+  if (quad) {   // split sum + scatter to the torch layout in one launch
+    const long gu = (long)p.N * ((p.Ctot + 15) / 16);
+    M2H_REQUIRE(gu < 0x7fffffffL, "convT_wgrad: unpack grid too large");
+    if (p.S >= 16) hipLaunchKernelGGL(convT_wgrad_reduce_unpack_kernel<true>, dim3((unsigned)gu), dim3(1024), 0, st, p);
+    else hipLaunchKernelGGL(convT_wgrad_reduce_unpack_kernel<false>, dim3((unsigned)gu), dim3(256), 0, st, p);
+    return launch_status("convT_wgrad reduce + unpack");
+  }
+  if (torch_ci > 0) {   // split sum + re-layout to [N][Ci][KH][KW] in one launch
+    const long gt = (long)p.N * ((torch_ci + 15) / 16);
+    M2H_REQUIRE(gt < 0x7fffffffL, "conv_wgrad: reduce grid too large");
+    if (p.S >= 16) hipLaunchKernelGGL(conv_wgrad_reduce_torch_kernel<true>, dim3((unsigned)gt), dim3(1024), 0, st, p);
+    else hipLaunchKernelGGL(conv_wgrad_reduce_torch_kernel<false>, dim3((unsigned)gt), dim3(256), 0, st, p);
+    return launch_status("conv_wgrad reduce (torch layout)");
+  }
   if (p.S >= 16) {
     const long g = (long)p.N * ((p.K + 63) / 64);
     M2H_REQUIRE(g < 0x7fffffffL, "conv_wgrad: reduce grid too large");
@@ -726,12 +809,7 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)g, (unsigned)phases), dim3(256), 0, st, p);
   }
-  rc = launch_status("conv_wgrad reduce");
-  if (rc || !quad) return rc;
-  const long gu = (long)p.N * ((p.Ctot + 15) / 16);
-  M2H_REQUIRE(gu < 0x7fffffffL, "convT_wgrad: unpack grid too large");
-  hipLaunchKernelGGL(convT_wgrad_unpack_kernel, dim3((unsigned)gu), dim3(256), 0, st, p, p.dwp);
-  return launch_status("convT_wgrad unpack");
+  return launch_status("conv_wgrad reduce");
 }
 
 // w [Co][Ci][KH][KW] -> per phase (ph,pw) of the stride: wp[phase][ci][th][tw][co] = w[co][ci][kh0(ph)+s*th][kw0(pw)+s*tw],
@@ -857,6 +935,11 @@ int m2h_conv_wgrad_f32(const m2h_conv_args* args, const float* dy, int ldy, floa
 int m2h_conv_wgrad_gated_f32(const m2h_conv_args* args, const float* dy, int ldy, const float* y, float slope, float* dw, m2h_stream stream) {
   M2H_REQUIRE(args != nullptr && y != nullptr, "conv_wgrad_gated: null pointer");
   return conv_wgrad_f32(*args, dy, ldy, dw, as_stream(stream), false, y, slope);
+}
+
+int m2h_conv_wgrad_torch_f32(const m2h_conv_args* args, const float* dy, int ldy, const float* y, float slope, float* dw, int Ci, m2h_stream stream) {
+  M2H_REQUIRE(args != nullptr && Ci > 0, "conv_wgrad_torch: null args / Ci <= 0");
+  return conv_wgrad_f32(*args, dy, ldy, dw, as_stream(stream), false, y, slope, Ci);
 }
 
 size_t m2h_convT_wgrad_workspace_bytes(const m2h_conv_args* args) {   // four phases of slabs + the packed per-phase gradients

@@ -57,21 +57,26 @@ def _conv_args(x, x2, n_out, kh, kw, stride, pad, Ho, Wo):
     return a
 
 
-def conv_wgrad(x, x2, dy, n_out, kh, kw, stride, pad, gate=None, gate_slope=1.0):
+def conv_wgrad(x, x2, dy, n_out, kh, kw, stride, pad, gate=None, gate_slope=1.0, torch_ci=None):
     """Packed weight gradient [n_out, kh*kw*(C0+C1)] of a conv whose NHWC inputs were x (+x2) and NHWC output grad is dy.
-    gate: the layer's forward output y; dy is then read as dy * (y > 0 ? 1 : gate_slope) (m2h_conv_wgrad_gated_f32: image-row shapes only)."""
+    gate: the layer's forward output y; dy is then read as dy * (y > 0 ? 1 : gate_slope) (m2h_conv_wgrad_gated_f32: image-row shapes only).
+    torch_ci: return nn.Conv2d's own layout [n_out, torch_ci, kh, kw] instead (m2h_conv_wgrad_torch_f32: no permute copy afterwards)."""
     B, Ho, Wo, N = dy.shape
     a = _conv_args(x, x2, n_out, kh, kw, stride, pad, Ho, Wo)
     lib = _lib.load()
     K = kh * kw * (x.shape[3] + (x2.shape[3] if x2 is not None else 0))
-    dw = torch.empty((n_out, K), device=x.device, dtype=torch.float32)
+    dw = torch.empty((n_out, K) if torch_ci is None else (n_out, int(torch_ci), kh, kw), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
         nbytes = lib.m2h_conv_wgrad_workspace_bytes(ctypes.byref(a))
         ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
         a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
         M = B * Ho * Wo
         meta = {"kernel": "wgrad_f32", "M": M, "N": n_out, "K": K, "flops": 2.0 * M * n_out * K, "bytes": 4.0 * (x.numel() + dy.numel() + dw.numel())}
-        if gate is not None:
+        if torch_ci is not None:
+            ops._timed("conv_wgrad", meta, x.device,
+                       lambda: _lib.check(lib.m2h_conv_wgrad_torch_f32(ctypes.byref(a), ops._ptr(dy), N, ops._ptr(gate) if gate is not None else None,
+                                                                       float(gate_slope), ops._ptr(dw), int(torch_ci), ops._stream(x)), "m2h_conv_wgrad_torch_f32"))
+        elif gate is not None:
             ops._timed("conv_wgrad", meta, x.device,
                        lambda: _lib.check(lib.m2h_conv_wgrad_gated_f32(ctypes.byref(a), ops._ptr(dy), N, ops._ptr(gate), float(gate_slope), ops._ptr(dw),
                                                                        ops._stream(x)), "m2h_conv_wgrad_gated_f32"))
@@ -336,16 +341,14 @@ class Conv2dNHWC(torch.autograd.Function):
         B, Ho, Wo, _ = dy.shape
         gx = gx2 = gw = gb = None
         if ctx.needs_input_grad[2]:
-            c_in = x.shape[3] + (x2.shape[3] if x2 is not None else 0)
-            dwp = None
+            # the gradient arrives in the weight's own layout [Co, Ci, KH, KW] (split sum + re-layout in one launch)
             if gated:
                 try:
-                    dwp = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, gate=y, gate_slope=slope)
+                    gw = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, gate=y, gate_slope=slope, torch_ci=Ci)
                 except RuntimeError:        # the library refused (image-row kernel switched off: m2h_tuning_set(21, -1)): two passes
                     dy = act_bwd(dy, y, slope)
-            if dwp is None:
-                dwp = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad)  # [Co, KH*KW*c_in]
-            gw = dwp.view(Co, KH, KW, c_in)[..., :Ci].permute(0, 3, 1, 2).contiguous()
+            if gw is None:
+                gw = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, torch_ci=Ci)
         if ctx.needs_input_grad[3]:
             gb = bias_grad(dy.view(B * Ho * Wo, Co))
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):

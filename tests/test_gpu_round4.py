@@ -295,3 +295,26 @@ def test_cycle_tail_overlap_leaves_the_same_bits():
     for k in a[1]:
         assert torch.equal(a[1][k], b[1][k]), k
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and a[5:] == b[5:]
+
+
+@pytest.mark.parametrize("B,H,W,c_in,Ci,Co,k,st,pad", [(280, 31, 31, 32, 32, 64, 4, 2, 0), (14, 128, 128, 4, 3, 32, 8, 4, 0), (64, 32, 32, 32, 32, 32, 3, 1, 1),
+                                                      (3, 16, 16, 64, 64, 128, 4, 2, 1), (280, 14, 14, 64, 64, 32, 3, 1, 0), (2, 8, 8, 16, 16, 16, 3, 1, 1)])
+def test_weight_gradient_in_the_torch_layout_is_the_packed_gradient_permuted(B, H, W, c_in, Ci, Co, k, st, pad):
+    """m2h_conv_wgrad_torch_f32: split sum + re-layout in one launch == m2h_conv_wgrad_f32 followed by view / permute / contiguous, bit for
+    bit (few and many splits, 9 / 16 / 64 taps, a channel-padded input whose padding channels carry no gradient), and == torch."""
+    from m2h import functional as MF
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + Co)
+    x = torch.randn(B, H, W, c_in, generator=g)
+    if Ci < c_in:
+        x[..., Ci:] = 0
+    Ho, Wo = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+    dy = torch.randn(B, Ho, Wo, Co, generator=g) / (B * Ho * Wo) ** 0.5
+    xd, dyd = x.to(dev), dy.to(dev)
+    packed = MF.conv_wgrad(xd, None, dyd, Co, k, k, st, pad)
+    two = packed.view(Co, k, k, c_in)[..., :Ci].permute(0, 3, 1, 2).contiguous()
+    one = MF.conv_wgrad(xd, None, dyd, Co, k, k, st, pad, torch_ci=Ci)
+    assert one.shape == (Co, Ci, k, k) and torch.equal(one, two)
+    w = torch.zeros(Co, Ci, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x[..., :Ci].double().permute(0, 3, 1, 2), w, None, st, pad).backward(dy.double().permute(0, 3, 1, 2))
+    assert _rel(one.cpu().double(), w.grad) < 2e-6
