@@ -253,9 +253,16 @@ class _PackMemo:
     def get_bwd(self, w, spec):
         return self._get(self.bwd, w, spec)
 
-    def stale_items(self):
+    def mark_fresh(self):
+        """Host bookkeeping only: the packed buffers ARE up to date with the current weights (a replayed HIP graph packed them)."""
+        self.stale_items()
+
+    def stale_items(self, force=False):
         if self.src is None:
             return []
+        if force:
+            for slot in (self.fwd, self.bwd):
+                slot[0] = None
         base, shape = self.src
         w = base if shape is None else base.view(shape)
         out = []
@@ -282,7 +289,7 @@ def memos_of(*modules):
     return out
 
 
-def refresh_pack_memos(hooks=True, only=None):
+def refresh_pack_memos(hooks=True, only=None, force=False):
     """Re-packs (in place) every packed operand whose source weights changed since it was packed, with one batched launch per
     48 tensors.  Called before a HIP-graph replay (the graph reads the packed buffers by address and contains no pack kernels)
     and at the top of a captured training step.
@@ -290,13 +297,14 @@ def refresh_pack_memos(hooks=True, only=None):
     HIP-graph capture (a capture of some OTHER model must not trip over them: they are rebuilt outside captures, and their user
     checks freshness itself) and by callers whose graph does not read them (the update_pol epoch).
     only: restrict the refresh to these memos (``memos_of(network)``): a step that packs each network's weights on that network's own
-    stream (the passive training step's two graph branches)."""
+    stream (the passive training step's two graph branches).
+    force: re-pack every slot of the memos whatever their keys say (a graph capture that must contain the pack launches)."""
     if hooks and not torch.cuda.is_current_stream_capturing():
         for h in list(_refresh_hooks):
             h.sync()
     items = []
     for m in (list(_pack_memos) if only is None else only):   # only: the memos of one network (memos_of), the others are the caller's business
-        items += m.stale_items()
+        items += m.stale_items(force)
     if items:
         ops.pack_batch(items)
 

@@ -97,28 +97,31 @@ class PassiveTrainer:
                tuple(p.data_ptr() for p in self.actor_critic.parameters()))
         if gs is None or gs.sig != sig:
             gs = self._train_graph = SimpleNamespace(sig=sig, graph=None, inputs=tuple(torch.empty_like(t) for t in (
-                mixed_audio, gt_bin_mag, gt_mono_mag, target_class)), losses=None, forked=False)
+                mixed_audio, gt_bin_mag, gt_mono_mag, target_class)), losses=None, forked=False, memos_a=[], memos_b=[])
         for dst, src in zip(gs.inputs, (mixed_audio, gt_bin_mag, gt_mono_mag, target_class)):
             dst.copy_(src)
+        ac = self.actor_critic
         if gs.graph is None:
-            MF.bump_param_epoch()  # every packed-weight memo is stale at the capture: the ONE batched pack launch below becomes
-            g = torch.cuda.CUDAGraph()  # the graph's first node (the warm-up step has told every memo which packs it needs)
+            g = torch.cuda.CUDAGraph()
             gs.forked = graphs.parallel_branches
+            # which packed-weight memos the step reads (the warm-up step has told every memo which packs it needs)
+            gs.memos_a = MF.memos_of(ac.binSep_enc, ac.binSep_dec)
+            gs.memos_b = MF.memos_of(ac.bin2mono_enc, ac.bin2mono_dec)
+            if gs.forked:
+                MF.refresh_pack_memos()    # the first replay finds the first network's packs made (later ones: packed at the end of the step before)
             with graphs.capture(g):
                 mix, gtb, gtm, tc = gs.inputs
                 self.optimizer.zero_grad()
-                ac = self.actor_critic
-                memos_b = MF.memos_of(ac.bin2mono_enc, ac.bin2mono_dec) if gs.forked else []
-                if gs.forked and memos_b:
-                    # the second network's weights are packed on ITS branch, under the first network's forward
-                    ids_b = {id(m) for m in memos_b}
-                    MF.refresh_pack_memos(only=[m for m in list(MF._pack_memos) if id(m) not in ids_b])
+                if gs.forked:
+                    # Weight packs (the packed copies are made from the current weights inside the graph): the second network's at the top of
+                    # ITS branch, under the first network's forward; the first network's at the END of its branch, behind its Adam step, for
+                    # the next replay -- that branch is idle there while the other one still runs its backward.
                     side = graphs.side_stream(self.device)
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
-                        MF.refresh_pack_memos(hooks=False, only=memos_b)
+                        MF.refresh_pack_memos(hooks=False, only=gs.memos_b, force=True)
                 else:
-                    MF.refresh_pack_memos()
+                    MF.refresh_pack_memos(hooks=False, only=gs.memos_a + gs.memos_b, force=True)
                 if gs.forked:
                     # The mono separator reads the binaural one's masks DETACHED (:218-249): the two networks' backward passes are
                     # independent, and so is the second network's forward from the first one's backward.  Two branches of the graph:
@@ -141,6 +144,7 @@ class PassiveTrainer:
                     # each network's Adam step right behind its own backward, on its own branch (FlatAdam.captured_step: lr and the
                     # bias corrections come from a device buffer the host refreshes before each replay)
                     self.optimizer.captured_step(list(ac.binSep_enc.parameters()) + list(ac.binSep_dec.parameters()))
+                    MF.refresh_pack_memos(hooks=False, only=gs.memos_a, force=True)
                     main.wait_stream(side)
                 else:
                     with MF.batched_bn_counters():
@@ -152,11 +156,16 @@ class PassiveTrainer:
                     self.optimizer.captured_step()
                 gs.losses = (bin_loss.detach(), mono_loss.detach())
             gs.graph = g
+        if gs.forked:
+            MF.refresh_pack_memos(hooks=False, only=gs.memos_a)   # nothing, unless somebody else changed the weights since the last replay (load_state_dict)
         self.optimizer.begin_replayed_step()
         if gs.forked:
             torch.cuda.current_stream().synchronize()   # a graph with parallel branches goes onto a drained stream (m2h/graphs.py)
         gs.graph.replay()
         self.optimizer.end_replayed_step()
+        if gs.forked:
+            for m in gs.memos_a:
+                m.mark_fresh()            # (the replay packed them from the weights it left)
         return gs.losses
 
     def train_batch(self, mixed_audio, gt_bin_mag, gt_mono_mag, target_class, split="train"):
