@@ -57,15 +57,43 @@ def _conv_args(x, x2, n_out, kh, kw, stride, pad, Ho, Wo):
     return a
 
 
-def conv_wgrad(x, x2, dy, n_out, kh, kw, stride, pad, gate=None, gate_slope=1.0, torch_ci=None):
+_flat_optimizers = weakref.WeakSet()   # FlatAdam instances (m2h/optim.py): their flat gradient buffers offer each weight's gradient a home
+
+
+def grad_slot(w):
+    """Where the gradient of weight `w` will be wanted: if w lives in a FlatAdam's flat parameter buffer, the matching slice of that
+    optimizer's flat GRADIENT buffer, shaped like w -- a weight-gradient kernel that writes there spares the optimizer's gather copy
+    (FlatAdam._gather skips gradients that already are views of their slice).  Handed out once per zero_grad() and weight (a second
+    backward pass before the next zero_grad gets None and its gradient is accumulated by autograd as usual); None for any other tensor."""
+    if not w.is_cuda or not w.is_contiguous():
+        return None
+    ptr = w.data_ptr()
+    for opt in list(_flat_optimizers):
+        if not getattr(opt, "_built", False) or opt.flat_p.device != w.device:
+            continue
+        base = opt.flat_p.data_ptr()
+        if base <= ptr < base + 4 * opt.n:
+            off = (ptr - base) // 4
+            if off + w.numel() > opt.n or off in opt._slots_used:
+                return None
+            opt._slots_used.add(off)
+            return opt.flat_g[off:off + w.numel()].view(w.shape)
+    return None
+
+
+def conv_wgrad(x, x2, dy, n_out, kh, kw, stride, pad, gate=None, gate_slope=1.0, torch_ci=None, out=None):
     """Packed weight gradient [n_out, kh*kw*(C0+C1)] of a conv whose NHWC inputs were x (+x2) and NHWC output grad is dy.
     gate: the layer's forward output y; dy is then read as dy * (y > 0 ? 1 : gate_slope) (m2h_conv_wgrad_gated_f32: image-row shapes only).
-    torch_ci: return nn.Conv2d's own layout [n_out, torch_ci, kh, kw] instead (m2h_conv_wgrad_torch_f32: no permute copy afterwards)."""
+    torch_ci: return nn.Conv2d's own layout [n_out, torch_ci, kh, kw] instead (m2h_conv_wgrad_torch_f32: no permute copy afterwards).
+    out: write the gradient there (grad_slot(w): the weight's place in its optimizer's flat gradient buffer)."""
     B, Ho, Wo, N = dy.shape
     a = _conv_args(x, x2, n_out, kh, kw, stride, pad, Ho, Wo)
     lib = _lib.load()
     K = kh * kw * (x.shape[3] + (x2.shape[3] if x2 is not None else 0))
-    dw = torch.empty((n_out, K) if torch_ci is None else (n_out, int(torch_ci), kh, kw), device=x.device, dtype=torch.float32)
+    shape = (n_out, K) if torch_ci is None else (n_out, int(torch_ci), kh, kw)
+    if out is not None and (tuple(out.shape) != shape or not out.is_contiguous() or out.dtype != torch.float32):
+        raise RuntimeError("m2h.conv_wgrad: out must be a contiguous fp32 tensor of shape %s" % (shape,))
+    dw = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
         nbytes = lib.m2h_conv_wgrad_workspace_bytes(ctypes.byref(a))
         ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
@@ -350,13 +378,14 @@ class Conv2dNHWC(torch.autograd.Function):
         gx = gx2 = gw = gb = None
         if ctx.needs_input_grad[2]:
             # the gradient arrives in the weight's own layout [Co, Ci, KH, KW] (split sum + re-layout in one launch)
+            slot = grad_slot(w)             # (None unless a FlatAdam owns w: then the kernel writes where the optimizer reads)
             if gated:
                 try:
-                    gw = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, gate=y, gate_slope=slope, torch_ci=Ci)
+                    gw = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, gate=y, gate_slope=slope, torch_ci=Ci, out=slot)
                 except RuntimeError:        # the library refused (image-row kernel switched off: m2h_tuning_set(21, -1)): two passes
                     dy = act_bwd(dy, y, slope)
             if gw is None:
-                gw = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, torch_ci=Ci)
+                gw = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, torch_ci=Ci, out=slot)
         if ctx.needs_input_grad[3]:
             gb = bias_grad(dy.view(B * Ho * Wo, Co))
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
@@ -735,7 +764,9 @@ class ConvTranspose2dNHWC(torch.autograd.Function):
                 ws = torch.empty((nbytes + 3) // 4, device=x.device)
                 a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
                 M = B * H * W
-                gw = torch.empty_like(w)
+                gw = grad_slot(w)
+                if gw is None:
+                    gw = torch.empty_like(w)
                 meta = {"kernel": "wgrad_f32", "M": 4 * M, "N": Co, "K": 4 * Cin, "flops": 2.0 * 4 * M * Co * 4 * Cin}
                 ops._timed("convT_wgrad", meta, x.device,
                            lambda: _lib.check(lib.m2h_convT_wgrad_f32(ctypes.byref(a), ops._ptr(dz), Co, ops._ptr(gw), ops._stream(x)),

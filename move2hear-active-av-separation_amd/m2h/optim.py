@@ -53,7 +53,10 @@ class FlatAdam(torch.optim.Optimizer):
             off += p.numel()
         self._no_idx = torch.zeros(1, device=dev, dtype=torch.int64)      # rows_copy's index argument (no item uses an index)
         self._gathered = True                                             # flat_g (zeros) is consistent with "no gradients yet"
+        self._slots_used = set()                                          # offsets handed out by functional.grad_slot since the last zero_grad
         self._built = True
+        from . import functional
+        functional._flat_optimizers.add(self)
 
     def build(self):
         """Moves the trainable parameters into the flat buffer now (otherwise done by the first zero_grad).  Anything that
@@ -72,6 +75,8 @@ class FlatAdam(torch.optim.Optimizer):
                     p.grad = None
                 else:
                     p.grad.zero_()
+        if set_to_none:
+            self._slots_used = set()     # every gradient of the coming backward may be written straight into its slice (functional.grad_slot)
         self._gathered = False
 
     @torch.no_grad()
@@ -79,20 +84,24 @@ class FlatAdam(torch.optim.Optimizer):
         """p.grad of every parameter -> its slice of the flat gradient buffer (one batched copy; None counts as zeros)."""
         if self._gathered:
             return
-        items, missing = [], False
+        items, missing, resident = [], [], False
         for p, off in zip(self._ps, self._offsets):
             g = p.grad
             if g is None:
-                missing = True
+                missing.append((off, p.numel()))
                 continue
             if g.dtype != torch.float32 or g.device != self.flat_g.device:
                 raise RuntimeError("FlatAdam: gradients must be fp32 tensors on the parameters' GPU")
             dst = self.flat_g[off:off + p.numel()]
             if g.data_ptr() == dst.data_ptr():
-                continue                                   # already a view of its slice
+                resident = True
+                continue                                   # already a view of its slice (functional.grad_slot)
             items.append((g.contiguous().view(-1), dst, -1, -1))
-        if missing:
+        if missing and not resident:
             self.flat_g.zero_()
+        else:
+            for off, k in missing:                         # (gradients that live in the buffer must survive: zero the absent ones' slices only)
+                self.flat_g[off:off + k].zero_()
         if items:
             ops.rows_copy(items, self._no_idx)
         self._gathered = True

@@ -318,3 +318,50 @@ def test_weight_gradient_in_the_torch_layout_is_the_packed_gradient_permuted(B, 
     w = torch.zeros(Co, Ci, k, k, dtype=torch.float64, requires_grad=True)
     F.conv2d(x[..., :Ci].double().permute(0, 3, 1, 2), w, None, st, pad).backward(dy.double().permute(0, 3, 1, 2))
     assert _rel(one.cpu().double(), w.grad) < 2e-6
+
+
+def test_weight_gradients_are_born_in_the_optimizers_flat_buffer():
+    """functional.grad_slot: a conv / transposed-conv weight owned by a FlatAdam gets its gradient written straight into its slice of the
+    flat gradient buffer (no gather copy); a second backward before zero_grad() accumulates the usual way; parameters without a
+    gradient are zeroed slice by slice without touching the resident ones; the step equals torch.optim.Adam's."""
+    from m2h import functional as MF
+    from m2h.optim import FlatAdam
+    dev = _dev()
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(8, 16, 4, 2, 1, bias=False).to(dev)
+    convT = torch.nn.ConvTranspose2d(16, 8, 4, 2, 1, bias=False).to(dev)
+    unused = torch.nn.Parameter(torch.randn(5, device=dev))
+    ref = [p.detach().clone().requires_grad_(True) for p in (conv.weight, convT.weight, unused)]
+    opt = FlatAdam([conv.weight, convT.weight, unused], lr=1e-2, eps=1e-5)
+    ropt = torch.optim.Adam(ref, lr=1e-2, eps=1e-5)
+    x = torch.randn(3, 16, 16, 8, device=dev)
+
+    def loss_m2h():
+        h = MF.conv2d(x, conv.weight, None, 2, 1, slope=0.0)
+        return MF.conv_transpose2d(h, convT.weight).square().mean()
+
+    def loss_ref():
+        h = F.relu(F.conv2d(x.permute(0, 3, 1, 2), ref[0], None, 2, 1))
+        return F.conv_transpose2d(h, ref[1], None, 2, 1).square().mean()
+
+    for step in range(3):
+        opt.zero_grad()
+        loss_m2h().backward()
+        for p, off in zip(opt._ps[:2], opt._offsets[:2]):
+            assert p.grad.data_ptr() == opt.flat_g[off:off + p.numel()].data_ptr(), "gradient not resident in the flat buffer"
+        if step == 1:                              # a second backward pass: accumulated by autograd, not overwritten
+            g0 = [p.grad.clone() for p in opt._ps[:2]]
+            loss_m2h().backward()
+            for p, g in zip(opt._ps[:2], g0):
+                assert _rel(p.grad, 2 * g) < 1e-6
+            ropt.zero_grad()
+            (2 * loss_ref()).backward()
+        else:
+            ropt.zero_grad()
+            loss_ref().backward()
+        assert unused.grad is None
+        opt.step(max_grad_norm=0.5)
+        torch.nn.utils.clip_grad_norm_(ref[:2], 0.5)
+        ropt.step()
+        for p, r in zip(opt._ps, ref):
+            assert _rel(p.detach(), r.detach()) < 2e-5, step
