@@ -521,6 +521,13 @@ int m2h_policy_heads_bwd(const float* logp_all, const float* probs, const long l
 int m2h_l1_loss(const float* pred, const float* gt, int gt_stride, int gt_off, float* loss, float* grad, float* scratch, size_t n,
                 m2h_stream stream);
 
+/* m2h_l1_loss for a prediction still in its convolution's NHWC layout y[B][32][T][16] (AcousticMem's last conv before the de-slice of
+ * memory_nets.py:62-67: pred[b][band * 32 + row][t] = y[b][row][t][band]) against gt [B][512][T][gt_stride]; dy (NULL to skip) =
+ * d loss / d y in the same NHWC layout, i.e. what m2h_conv_wgrad_* / the input-gradient launch of that conv read.  One pass instead
+ * of de-sliced store + m2h_l1_loss + re-slice of the gradient.  scratch: >= min(32 * B, 2048) floats. */
+int m2h_l1_loss_nhwc16(const float* y, const float* gt, int gt_stride, int gt_off, float* loss, float* dy, float* scratch, int B, int T,
+                       m2h_stream stream);
+
 /* Binaural separation L1 (ppo.py:219-221; passive_trainer.py:270-272): loss[0] = mean |(exp(mix)-1)*masks - gt[..., cstep*c]|, c < 2,
  * over [npix][2]; gt: [npix][Cg] (cstep 2 reads the magnitudes of interleaved (mag, phase) components, cstep 1 a plain
  * 2-channel tensor); grad_masks (NULL to skip) = d loss / d masks.  mix, masks: [npix][2]. */

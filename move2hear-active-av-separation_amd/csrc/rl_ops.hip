@@ -791,6 +791,52 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
+// The same loss for a prediction that is still in the convolution's NHWC layout [B][32 rows][T][16 bands] (AcousticMem's last conv before its
+// de-slice, memory_nets.py:62-67): pred_BHWC[b][band * 32 + row][t] = y[b][row][t][band].  One block per (b, row): the 16 band rows of the
+// ground truth (T x gt_stride floats each, contiguous) and the T x 16 tile of y are read coalesced, |y - g| is summed and the gradient
+// sign(y - g) / n leaves in the SAME NHWC layout -- the layout the conv's weight / input gradient kernels read.  Replaces the conv's
+// de-sliced store + m2h_l1_loss + the gradient's re-slice (m2h_slice_concat_input): one pass over y instead of three tensors' round trips.
+__global__ __launch_bounds__(256) void l1_nhwc16_kernel(const float* __restrict__ y, const float* __restrict__ gt, int gt_stride, int gt_off, int T,
+                                                        float* __restrict__ part, float* __restrict__ dy, float inv, int nrows) {
+  extern __shared__ float gts[];                       // [16 bands][T] (+1 pad per band row)
+  __shared__ float sh[4];
+  const int TP = T + 1;
+  float s = 0.f;
+  for (int br = blockIdx.x; br < nrows; br += gridDim.x) {   // (b, row) pairs of this block: at most 2048 partial sums whatever B
+    const int b = br >> 5, row = br & 31;
+    __syncthreads();                                   // (the previous pair's tile is consumed)
+    for (int i = threadIdx.x; i < 16 * T; i += 256) {  // band-major, coalesced over t
+      const int band = i / T, t = i - band * T;
+      gts[band * TP + t] = gt[(((size_t)b * 512 + band * 32 + row) * T + t) * gt_stride + gt_off];
+    }
+    __syncthreads();
+    const size_t base = ((size_t)b * 32 + row) * T * 16;
+    for (int i = threadIdx.x; i < 16 * T; i += 256) {  // NHWC order: band fastest
+      const int t = i >> 4, band = i & 15;
+      const float d = y[base + i] - gts[band * TP + t];
+      s += fabsf(d);
+      if (dy != nullptr) dy[base + i] = d > 0.f ? inv : (d < 0.f ? -inv : 0.f);
+    }
+  }
+  const float tot = block_sum(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// partial sums of a long list (one block per 1024 entries is overkill here: a few tens of thousands of floats) -> out[0] = scale * sum, fixed order
+__global__ __launch_bounds__(1024) void sum_partials_wide_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ out) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    out[0] = t * scale;
+  }
+}
+
 // bin loss for logging (ppo.py:219-221; passive_trainer.py:270-272): mean | (exp(mix)-1)*mask - gt_bin_comps[..., 2c] | over [.., c<2]
 __global__ __launch_bounds__(256) void bin_l1_kernel(const float* __restrict__ mix, const float* __restrict__ masks, const float* __restrict__ gt,
                                                      int Cg, int cstep, float* __restrict__ part, float* __restrict__ grad_masks, size_t npix) {
@@ -1079,6 +1125,17 @@ int m2h_l1_loss(const float* pred, const float* gt, int gt_stride, int gt_off, f
   hipLaunchKernelGGL(l1_loss_kernel, dim3(g), dim3(256), 0, as_stream(stream), pred, gt, gt_stride, gt_off, scratch, grad, n);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch, (int)g, 1.f / (float)n, loss);
   return launch_status("l1_loss");
+}
+
+int m2h_l1_loss_nhwc16(const float* y, const float* gt, int gt_stride, int gt_off, float* loss, float* dy, float* scratch, int B, int T,
+                       m2h_stream stream) {
+  M2H_REQUIRE(y && gt && loss && scratch && B > 0 && T > 0 && T <= 256 && gt_stride > 0 && gt_off >= 0 && gt_off < gt_stride, "l1_loss_nhwc16: bad arguments");
+  const size_t n = (size_t)B * 512 * T;
+  const int nrows = B * 32, blocks = nrows < 2048 ? nrows : 2048;
+  hipLaunchKernelGGL(l1_nhwc16_kernel, dim3((unsigned)blocks), dim3(256), 16 * (T + 1) * sizeof(float), as_stream(stream), y, gt, gt_stride, gt_off, T,
+                     scratch, dy, 1.f / (float)n, nrows);
+  hipLaunchKernelGGL(sum_partials_wide_kernel, dim3(1), dim3(1024), 0, as_stream(stream), scratch, blocks, 1.f / (float)n, loss);
+  return launch_status("l1_loss_nhwc16");
 }
 
 int m2h_bin_l1_loss(const float* mix, const float* masks, const float* gt_bin_comps, int Cg, int cstep, float* loss, float* grad_masks,

@@ -211,6 +211,7 @@ SIGNATURES = {
     "m2h_gru_bwd_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_policy_heads_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "m2h_l1_loss": [_P, _P, _I, _I, _P, _P, _P, _Z, _P],
+    "m2h_l1_loss_nhwc16": [_P, _P, _I, _I, _P, _P, _P, _I, _I, _P],
     "m2h_bin_l1_loss": [_P, _P, _P, _I, _I, _P, _P, _P, _Z, _P],
     "m2h_grad_clip_coef": [_P, _Z, _F, _P, _P, _P],
     "m2h_adam_step": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _P, _F, _P],

@@ -616,6 +616,47 @@ class L1Loss(torch.autograd.Function):
         return grad * g, None, None
 
 
+@carries_math_mode
+class ConvL1NHWC16(torch.autograd.Function):
+    """loss = F.l1_loss(deslice(conv3x3(h, w)), gt_comps[..., off]) -- AcousticMem's last conv, its de-slice and update_sep's loss
+    (memory_nets.py:16, :62-67; ppo.py:206-216) -- without the de-sliced tensor: the conv stores NHWC, m2h_l1_loss_nhwc16 reads that once and
+    leaves d loss / d y in NHWC, where the conv's weight- and input-gradient launches read it (no de-sliced store, no re-slice of the
+    gradient: 160 of an update_sep epoch's 840 us were those two round trips)."""
+
+    @staticmethod
+    def forward(ctx, h, w, gt_comps, off, memo):
+        Co, Ci, KH, KW = w.shape
+        if (Co, KH, KW) != (16, 3, 3) or h.shape[1] != 32:
+            raise RuntimeError("m2h.conv_l1_nhwc16: a 3x3 conv to 16 bands over 32-row images expected")
+        wp = memo.get(w, h.shape[3]) if memo is not None else ops.pack_conv_weight_ex(w.detach().contiguous(), Ci, h.shape[3])
+        y = ops.conv2d_nhwc(h, wp, Co, 3, 3, stride=1, pad=1, slope=1.0, name="acoustic_mem.conv1")
+        loss, dy = ops.l1_loss_nhwc16(y, gt_comps, off, want_grad=True)
+        ctx.save_for_backward(h, w, dy)
+        ctx.memo = memo
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w, dy = ctx.saved_tensors
+        u = _unit_grads.get(g.device)
+        if u is None or g.data_ptr() != u.data_ptr():
+            dy = dy * g
+        gh = gw = None
+        Co, Ci, _, _ = w.shape
+        if ctx.needs_input_grad[1]:
+            gw = conv_wgrad(h, None, dy, Co, 3, 3, 1, 1, torch_ci=Ci, out=grad_slot(w))
+        if ctx.needs_input_grad[0]:
+            wpd = ctx.memo.get_bwd(w, ("dgrad", 1, 1)) if ctx.memo is not None else None
+            gh = conv_dgrad(dy, w.detach().contiguous(), (h.shape[1], h.shape[2]), 1, 1, wp=wpd)
+            if gh.shape[3] != h.shape[3]:
+                gh = torch.nn.functional.pad(gh, (0, h.shape[3] - gh.shape[3]))
+        return gh, gw, None, None, None
+
+
+def conv_l1_nhwc16(h, w, gt_comps, off=0, memo=None):
+    return ConvL1NHWC16.apply(h, w, gt_comps.contiguous(), off, memo)
+
+
 _unit_grads = {}
 _entropy_grads = {}
 

@@ -913,6 +913,24 @@ def bin_l1_loss(mix, masks, gt, cstep=2, want_grad=False):
     return (loss[0], grad) if want_grad else loss[0]
 
 
+def l1_loss_nhwc16(y, gt_comps, off=0, want_grad=True):
+    """F.l1_loss(deslice(y), gt_comps[..., off:off+1]) for y still in its conv's NHWC layout [B, 32, T, 16] (m2h_l1_loss_nhwc16) ->
+    (0-dim loss, d loss / d y in the same layout or None)."""
+    _chk(y, "l1_loss_nhwc16")
+    _chk(gt_comps, "l1_loss_nhwc16")
+    B, H, T, C = y.shape
+    if H != 32 or C != 16 or tuple(gt_comps.shape[:3]) != (B, 512, T):
+        raise RuntimeError("m2h.l1_loss_nhwc16: y %s must be [B, 32, T, 16] and gt_comps %s [B, 512, T, *]" % (tuple(y.shape), tuple(gt_comps.shape)))
+    loss = torch.empty(1, device=y.device)
+    dy = torch.empty_like(y) if want_grad else None
+    scratch = torch.empty(32 * B, device=y.device)
+    lib = _lib.load()
+    with torch.cuda.device(y.device):
+        _lib.check(lib.m2h_l1_loss_nhwc16(_ptr(y), _ptr(gt_comps), gt_comps.shape[-1], int(off), _ptr(loss), _ptr(dy), _ptr(scratch), B, T, _stream(y)),
+                   "m2h_l1_loss_nhwc16")
+    return loss[0], dy
+
+
 def sep_slice_input_plane(mix, cls_val, ldo=36):
     """binSep stage-0 training input: slice + (target_class+1) plane as channel 32, zero padded to ldo channels."""
     _chk(mix, "sep_slice_input_plane")

@@ -85,5 +85,17 @@ class AcousticMem(nn.Module):
             x = ops.conv2d_nhwc(x, wp, c0.weight.shape[0], 3, 3, stride=1, pad=1, bias=shift, scale=scale, slope=0.0, name="acoustic_mem.conv0")
         return MF.conv2d(x, c1.weight, None, 1, 1, slope=1.0, deslice=True, memo=self._memo[1], name="acoustic_mem.conv1")
 
+    def l1_loss_masked(self, pred_mono, prev_pred_monoFromMem, masks, gt_comps, off=0, sliced=None):
+        """F.l1_loss(forward_masked(...), gt_comps[..., off:off+1]) (ppo.py:206-216) without materialising the memory's output: the last
+        conv stays in NHWC and the loss kernel reads it there (functional.ConvL1NHWC16).  DD-PPO variant, [B, 512, T, 1] inputs."""
+        if not self._use_ddppo or pred_mono.shape[1] != 512:
+            return MF.l1_loss(self.forward_masked(pred_mono, prev_pred_monoFromMem, masks, sliced=sliced), gt_comps, off)
+        if torch.is_grad_enabled() and (pred_mono.requires_grad or prev_pred_monoFromMem.requires_grad):
+            raise NotImplementedError("m2h AcousticMem: gradients w.r.t. the inputs are not built; detach the inputs")
+        x = sliced if sliced is not None else self.slice_inputs(pred_mono, prev_pred_monoFromMem, masks)
+        c0, c1 = self.cnn[0], self.cnn[-1]
+        x = MF.conv2d(x, c0.weight, None, 1, 1, slope=0.0, memo=self._memo[0], name="acoustic_mem.conv0")
+        return MF.conv_l1_nhwc16(x, c1.weight, gt_comps, off, memo=self._memo[1])
+
     def forward(self, pred_mono, prev_pred_monoFromMem_masked):
         return self.forward_masked(pred_mono, prev_pred_monoFromMem_masked, None)

@@ -163,6 +163,12 @@ class Policy(nn.Module):
         self._fence("mem")
         return self.acoustic_mem.forward_masked(pred_mono, prev_pred_monoFromMem, masks, sliced=sliced)
 
+    def monoFromMem_l1_masked(self, pred_mono, prev_pred_monoFromMem, masks, gt_comps, off=0, sliced=None):
+        """update_sep's loss (ppo.py:206-216): l1_loss(get_monoFromMem_masked(...), gt_comps[..., off]) with the memory's output left in
+        its conv's layout (AcousticMem.l1_loss_masked)."""
+        self._fence("mem")
+        return self.acoustic_mem.l1_loss_masked(pred_mono, prev_pred_monoFromMem, masks, gt_comps, off, sliced=sliced)
+
     # action sampling (common/utils.py): None = noise from the device generator; a HostNoise = noise from the CPU default generator
     _host_noise = None
 

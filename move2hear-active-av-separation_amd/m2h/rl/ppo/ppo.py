@@ -258,15 +258,16 @@ class PPO(nn.Module):
                         pred_binSepMasks = self.actor_critic.get_binSepMasks(obs_batch)
                         pred_mono = self.actor_critic.convert_bin2mono(pred_binSepMasks.detach(),
                                                                        mixed_audio=obs_batch["mixed_bin_audio_mag"])
+                gt_mono = obs_batch["gt_mono_comps"]
                 if cached is not None and idx is None:
                     if sliced is None:
                         with torch.no_grad():
                             sliced = self.actor_critic.acoustic_mem.slice_inputs(pred_mono, prev_mem_batch, masks_batch)
-                    pred_monoFromMem = self.actor_critic.get_monoFromMem_masked(pred_mono, prev_mem_batch, masks_batch, sliced=sliced)
+                    # the memory's output is only this loss's operand here: it stays in its conv's layout (no de-slice / re-slice round trips)
+                    monoFromMem_loss = self.actor_critic.monoFromMem_l1_masked(pred_mono, prev_mem_batch, masks_batch, gt_mono, 0, sliced=sliced)
                 else:
                     pred_monoFromMem = self.actor_critic.get_monoFromMem_masked(pred_mono, prev_mem_batch, masks_batch)
-                gt_mono = obs_batch["gt_mono_comps"]
-                monoFromMem_loss = MF.l1_loss(pred_monoFromMem, gt_mono, 0)          # gt_mono_comps[..., 0::2][..., :1]
+                    monoFromMem_loss = MF.l1_loss(pred_monoFromMem, gt_mono, 0)      # gt_mono_comps[..., 0::2][..., :1]
                 if cached is not None and idx is None and len(cached) > 2:
                     bin_loss, mono_loss = cached[2]  # logging losses of the frozen separators: same buffer, same numbers
                 else:

@@ -365,3 +365,55 @@ def test_weight_gradients_are_born_in_the_optimizers_flat_buffer():
         ropt.step()
         for p, r in zip(opt._ps, ref):
             assert _rel(p.detach(), r.detach()) < 2e-5, step
+
+
+@pytest.mark.parametrize("B,T", [(3, 32), (5, 20)])
+def test_l1_loss_in_the_convs_layout_matches_torch(B, T):
+    """m2h_l1_loss_nhwc16: F.l1_loss(deslice(y), gt[..., off]) and its gradient for y in NHWC [B, 32, T, 16] (memory_nets.py:62-67, ppo.py:212-216)."""
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * T)
+    y = torch.randn(B, 32, T, 16, generator=g)
+    gt = torch.randn(B, 512, T, 2, generator=g)
+    y[0, 0, 0, 0] = gt[0, 0, 0, 1]                                           # an exact tie: sign(0) = 0 like torch
+    yr = y.clone().double().requires_grad_(True)
+    pred = yr.permute(0, 3, 1, 2).reshape(B, 512, T, 1)                      # band-major frequency axis: f = band * 32 + row
+    want = F.l1_loss(pred, gt[..., 1:2].double())
+    want.backward()
+    loss, dy = ops.l1_loss_nhwc16(y.to(dev), gt.to(dev), 1)
+    assert abs(loss.item() - want.item()) < 1e-6 * max(1.0, abs(want.item()))
+    assert torch.equal(dy.cpu(), yr.grad.float()) and dy[0, 0, 0, 0].item() == 0.0
+    loss2, none = ops.l1_loss_nhwc16(y.to(dev), gt.to(dev), 1, want_grad=False)
+    assert none is None and loss2.item() == loss.item()
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_memory_loss_without_the_desliced_output_equals_the_two_step_form(mode):
+    """AcousticMem.l1_loss_masked (ConvL1NHWC16) == F.l1_loss(forward_masked(...), gt[..., 0:1]): the loss to summation order, both weight
+    gradients bit for bit (the same conv values, the same gradient signs, the same weight-gradient kernels)."""
+    from m2h import functional as MF
+    from m2h import ops
+    dev = _dev()
+    pol, sd = _policy(8, dev)
+    mem = pol.acoustic_mem
+    B = 70
+    g = torch.Generator().manual_seed(2)
+    mono, prev = (torch.rand(B, 512, 32, 1, generator=g) * 2).to(dev), (torch.rand(B, 512, 32, 1, generator=g) * 2).to(dev)
+    nd = (torch.rand(B, 1, generator=g) > 0.3).float().to(dev)
+    gt = torch.rand(B, 512, 32, 2, generator=g).to(dev)
+    out = {}
+    with ops.math_scope(ops.MATH_BF16X3 if mode == "bf16x3" else ops.MATH_FP32):
+        for fused in (False, True):
+            for p in mem.parameters():
+                p.grad = None
+            if fused:
+                loss = pol.monoFromMem_l1_masked(mono, prev, nd, gt, 0)
+            else:
+                loss = MF.l1_loss(pol.get_monoFromMem_masked(mono, prev, nd), gt, 0)
+            loss.backward(MF.unit_grad(dev))
+            out[fused] = (loss.item(), [p.grad.clone() for p in mem.parameters()])
+    assert abs(out[True][0] - out[False][0]) < 1e-6 * max(1.0, abs(out[False][0]))
+    for a, b in zip(out[True][1], out[False][1]):
+        assert torch.equal(a, b)
+    want = O.acoustic_mem(sd, mono.cpu(), O.mask_prev_mem(prev.cpu(), nd.cpu()))
+    assert abs(out[True][0] - F.l1_loss(want, gt.cpu()[..., 0:1]).item()) < (2e-5 if mode == "bf16x3" else 2e-6)

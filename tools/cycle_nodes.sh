@@ -38,7 +38,7 @@ if walls:
     print("kernels most often preceded by a gap > 5 us:", where.most_common(8))
 idx = [i for i, n in enumerate(names) if n.startswith("ppo_loss")]
 show("one update_pol epoch (between two ppo_loss launches)", idx[-3], idx[-2])
-idx = [i for i, n in enumerate(names) if n.startswith("l1_loss")]
+idx = [i for i, n in enumerate(names) if (n.startswith("l1_nhwc16") or n.startswith("l1_loss_kernel"))]
 show("one update_sep epoch (between two l1_loss launches)", idx[-3], idx[-2])
 P
 rm -rf gpurun_out/prof_nodes

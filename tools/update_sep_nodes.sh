@@ -10,7 +10,7 @@ names = [r["Kernel_Name"].split("(")[0].replace("void m2h::", "").replace("m2h::
 st = [int(r["Start_Timestamp"]) for r in rows]
 en = [int(r["End_Timestamp"]) for r in rows]
 # one update_sep epoch = the kernels between two consecutive l1_loss launches near the end of the run (the last update_sep)
-idx = [i for i, n in enumerate(names) if n.startswith("l1_loss")]
+idx = [i for i, n in enumerate(names) if (n.startswith("l1_nhwc16") or n.startswith("l1_loss_kernel"))]
 a, b = idx[-3], idx[-2]
 print("kernels between two l1_loss launches (one update_sep epoch): %d, wall %.1f us, kernel time %.1f us" % (b - a, (en[b] - en[a]) / 1e3, sum(en[i] - st[i] for i in range(a + 1, b + 1)) / 1e3))
 for i in range(a + 1, b + 1):
