@@ -7,10 +7,11 @@ import csv, glob
 f = glob.glob("gpurun_out/prof_nodes/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-names = [r["Kernel_Name"].split("(")[0].replace("void m2h::", "").replace("m2h::", "").replace("void at::native::", "at::")[:50] for r in rows]
+names = [r["Kernel_Name"].split("(")[0].replace("void m2h::", "").replace("m2h::", "").replace("void at::native::", "at::")[:110] for r in rows]
 st = [int(r["Start_Timestamp"]) for r in rows]
 en = [int(r["End_Timestamp"]) for r in rows]
 q = [r.get("Queue_Id", "?") for r in rows]
+gsz = [r.get("Grid_Size_X", "?") for r in rows]
 idx = [i for i, n in enumerate(names) if n.startswith("bin_l1")]
 a, b = idx[-3], idx[-2]
 t0 = st[a]
@@ -27,7 +28,7 @@ for i in range(a, b):
     per_q[q[i]][1] += en[i] - st[i]
 print("time with at least one kernel running: %.1f us; per queue (kernels, us): %s" % (busy / 1e3, {k: (v[0], round(v[1] / 1e3, 1)) for k, v in per_q.items()}))
 for i in range(a, b):
-    print("  +%8.1f  %7.1f us  q%-3s %s" % ((st[i] - t0) / 1e3, (en[i] - st[i]) / 1e3, q[i], names[i]))
+    print("  +%8.1f  %7.1f us  q%-3s grid %-9s %s" % ((st[i] - t0) / 1e3, (en[i] - st[i]) / 1e3, q[i], gsz[i], names[i]))
 P
 rm -rf gpurun_out/prof_nodes
 head -3 gpurun_out/ptrain_timeline.txt
