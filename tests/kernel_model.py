@@ -285,6 +285,78 @@ def wgrad3x3_row(x, dy):
     return dw
 
 
+def wgrad3x3_row_bf16x3(x, dy, splits):
+    """Mirror of wgrad3x3_row_bf16x3_kernel's indexing (csrc/conv_bwd.hip, round 4), in bf16x3 arithmetic: a split walks its image rows
+    c0 .. c1-1 of the flattened (b, row) list; x rows live TRANSPOSED ([channel][32 pixels]) in a ring of four slots (slot = row & 3: step c
+    reads slots of rows c-1, c, c+1 while row c+2 arrives), rows outside the image are skipped; the tap's column shift is applied to
+    dY -- dW[n][ty][tx][c] += sum_px' dY[px' - tx + 1][n] * x[row + ty - 1][px'][c], zeros shifted in at the row ends -- and one product is
+    lo*hi + hi*lo + hi*hi of the bf16 splits.  Returns the per-split slabs [splits][N][9*C]."""
+    B, H, W, C = x.shape
+    N = dy.shape[3]
+    assert W == 32
+    rows_total = B * H
+    xr, yr = x.reshape(rows_total, W, C), dy.reshape(rows_total, W, N)
+    slabs = np.zeros((splits, N, 9 * C), np.float64)
+    for s in range(splits):
+        c0, c1 = (rows_total * s) // splits, (rows_total * (s + 1)) // splits
+        ring = [None] * 4
+        for r in (c0 - 1, c0, c0 + 1):                       # prologue
+            if 0 <= r < rows_total:
+                ring[r & 3] = (r, split_hi_lo(xr[r].T))       # [C][32] hi / lo
+        for c in range(c0, c1):
+            if 0 <= c + 2 < rows_total:
+                ring[(c + 2) & 3] = (c + 2, split_hi_lo(xr[c + 2].T))
+            q = c % H
+            yh, yl = split_hi_lo(yr[c].T)                     # [N][32]
+            for ty in range(3):
+                if not 0 <= q + ty - 1 < H:
+                    continue
+                tag, (xh, xl) = ring[(c + ty - 1) & 3]
+                assert tag == c + ty - 1, "ring slot overwritten before use"
+                for tx in range(3):
+                    sh = 1 - tx                               # element k takes dY[k + sh]
+                    ah, al = np.zeros_like(yh), np.zeros_like(yl)
+                    if sh == 1:
+                        ah[:, :-1], al[:, :-1] = yh[:, 1:], yl[:, 1:]
+                    elif sh == -1:
+                        ah[:, 1:], al[:, 1:] = yh[:, :-1], yl[:, :-1]
+                    else:
+                        ah, al = yh, yl
+                    t = ty * 3 + tx
+                    slabs[s, :, t * C:(t + 1) * C] += (al.astype(np.float64) @ xh.astype(np.float64).T + ah.astype(np.float64) @ xl.astype(np.float64).T
+                                                       + ah.astype(np.float64) @ xh.astype(np.float64).T)
+    return slabs
+
+
+def wgrad_reduce_torch(slabs, Ci, KH, KW):
+    """Mirror of conv_wgrad_reduce_torch_kernel (csrc/conv_bwd.hip): the split sum in the reduce kernels' order (S < 16: one running sum;
+    else four quarters of four interleaved running sums, pairwise) and the re-layout packed [n][(tap, c)] -> torch [n][c][kh][kw], channels
+    from Ci on dropped."""
+    S, N, K = slabs.shape
+    Ctot = K // (KH * KW)
+    sl = slabs.astype(np.float32)
+    if S < 16:
+        tot = np.zeros((N, K), np.float32)
+        for z in range(S):
+            tot = tot + sl[z]
+    else:
+        qs = []
+        for w in range(4):
+            z0, z1 = (S * w) // 4, (S * (w + 1)) // 4
+            a = [np.zeros((N, K), np.float32) for _ in range(4)]
+            z = z0
+            while z + 3 < z1:
+                for j in range(4):
+                    a[j] = a[j] + sl[z + j]
+                z += 4
+            while z < z1:
+                a[0] = a[0] + sl[z]
+                z += 1
+            qs.append((a[0] + a[1]) + (a[2] + a[3]))
+        tot = (qs[0] + qs[1]) + (qs[2] + qs[3])
+    return np.ascontiguousarray(tot.reshape(N, KH, KW, Ctot)[..., :Ci].transpose(0, 3, 1, 2))
+
+
 # ---- strip-walker kernels (csrc/conv_strip.hip): LDS patch addressing and the first stage's channel order ----
 DS_READ_B128_GROUPS = ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31],
                        [32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59], [36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63])

@@ -158,3 +158,27 @@ def test_patch_engine_tap_classes_match_torch():
         for whole in (True, False):
             got = KM.patch_engine_layer(x[0].permute(1, 2, 0).numpy(), w.numpy(), True, whole)
             assert np.abs(got - want).max() < 1e-4, (H, W, whole)
+
+
+def test_bf16x3_weight_gradient_row_ring_and_column_shift_match_torch():
+    """CPU: the index arithmetic of wgrad3x3_row_bf16x3_kernel (ring of transposed rows, column shift on dY, rows outside the image
+    skipped, splits that start and end mid-image) and of conv_wgrad_reduce_torch_kernel (split-sum order, re-layout, dropped padding
+    channels), restated in numpy, against torch's weight gradient; the split products' error stays at the bf16x3 level."""
+    import torch
+    import torch.nn.functional as F
+    g = np.random.default_rng(7)
+    B, H, C, N = 3, 5, 32, 16
+    x = g.standard_normal((B, H, 32, C)).astype(np.float32)
+    x[..., 30:] = 0                                           # two padding channels: no gradient, dropped by the re-layout
+    dy = g.standard_normal((B, H, 32, N)).astype(np.float32)
+    w = torch.zeros(N, 30, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(torch.from_numpy(x[..., :30]).double().permute(0, 3, 1, 2), w, None, 1, 1).backward(torch.from_numpy(dy).double().permute(0, 3, 1, 2))
+    want = w.grad.numpy()
+    for splits in (1, 4, 7, 15, 16, 23):                      # 15 rows in all: splits of one row and of none; both split-sum orders
+        slabs = KM.wgrad3x3_row_bf16x3(x, dy, splits)
+        got = KM.wgrad_reduce_torch(slabs, 30, 3, 3)
+        assert got.shape == (N, 30, 3, 3)
+        err = np.abs(got - want).sum() / np.abs(want).sum()
+        assert err < 2e-5, (splits, err)
+    exact = KM.wgrad3x3_row(x, dy)                            # the fp32 kernel's model: the same gradient
+    assert np.abs(KM.wgrad3x3_row_bf16x3(x, dy, 3).sum(0) - exact).max() < 2e-3
