@@ -831,6 +831,9 @@ class BinL1Loss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
+        u = _unit_grads.get(g.device)
+        if u is not None and g.data_ptr() == u.data_ptr():
+            return grad, None, None, None   # root gradient = unit_grad: the saved gradient itself, no multiply by one
         return grad * g, None, None, None
 
 

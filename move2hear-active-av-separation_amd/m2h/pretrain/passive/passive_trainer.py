@@ -90,7 +90,7 @@ class PassiveTrainer:
         copies are made from the current weights at every replay) and so is the optimizer step (its step count and learning
         rate reach the kernel through a device buffer: FlatAdam.captured_step).  Returns the two loss scalars of THIS replay (static tensors,
         overwritten by the next one)."""
-        from ... import graphs
+        from ... import graphs, ops
         gs = self._train_graph
         self.optimizer.build()
         sig = (tuple(mixed_audio.shape), tuple(gt_bin_mag.shape), tuple(gt_mono_mag.shape), tuple(target_class.shape), target_class.dtype,
@@ -98,8 +98,14 @@ class PassiveTrainer:
         if gs is None or gs.sig != sig:
             gs = self._train_graph = SimpleNamespace(sig=sig, graph=None, inputs=tuple(torch.empty_like(t) for t in (
                 mixed_audio, gt_bin_mag, gt_mono_mag, target_class)), losses=None, forked=False, memos_a=[], memos_b=[])
-        for dst, src in zip(gs.inputs, (mixed_audio, gt_bin_mag, gt_mono_mag, target_class)):
-            dst.copy_(src)
+        srcs = (mixed_audio, gt_bin_mag, gt_mono_mag, target_class)
+        if all(s.is_cuda and s.is_contiguous() and s.dtype == d.dtype for s, d in zip(srcs, gs.inputs)):
+            if getattr(gs, "no_idx", None) is None:
+                gs.no_idx = torch.zeros(1, dtype=torch.int64, device=self.device)
+            ops.rows_copy([(s, d, -1, -1) for s, d in zip(srcs, gs.inputs)], gs.no_idx)     # the four batch tensors in ONE launch
+        else:
+            for dst, src in zip(gs.inputs, srcs):
+                dst.copy_(src)
         ac = self.actor_critic
         if gs.graph is None:
             g = torch.cuda.CUDAGraph()
@@ -137,10 +143,10 @@ class PassiveTrainer:
                             mono = self.actor_critic.convert_bin2mono(masks.detach(), mixed_audio=mix)
                     with torch.cuda.stream(side):
                         mono_loss = MF.l1_loss(mono, gtm, 0)
-                        mono_loss.backward()
+                        mono_loss.backward(MF.unit_grad(self.device))
                         self.optimizer.captured_step(list(ac.bin2mono_enc.parameters()) + list(ac.bin2mono_dec.parameters()))
                     bin_loss = MF.bin_l1_loss(masks, mix, gtb, cstep=1)
-                    bin_loss.backward()
+                    bin_loss.backward(MF.unit_grad(self.device))
                     # each network's Adam step right behind its own backward, on its own branch (FlatAdam.captured_step: lr and the
                     # bias corrections come from a device buffer the host refreshes before each replay)
                     self.optimizer.captured_step(list(ac.binSep_enc.parameters()) + list(ac.binSep_dec.parameters()))
