@@ -381,9 +381,9 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
            "schedule": ("farTarget.yaml: episodes of 80 steps, navigation reward (no override), " if far_target else "nearTarget.yaml: ") +
                        "T=20, 6x(rollout+update_pol) + 6x update_sep per cycle, ppo_epoch 4, 1 minibatch, hidden 512",
            "env": "synthetic on-device env (cached 128x128 RGB-D frames + spectrogram pool), zero-cost dynamics",
-           "launch": ("HIP graphs: the rollout step (one graph per (extra-reward, episode-end) flag pair) and the update_pol epoch "
-                      "(forward + losses + backward) are captured once and replayed; optimizer steps, collectives and update_sep "
-                      "are enqueued kernel by kernel" if cfg.use_hip_graphs else "kernel by kernel"),
+           "launch": ("HIP graphs: the rollout step (one graph per (extra-reward, episode-end) flag pair, one chain) and the update_pol epoch "
+                      "(forward + losses + backward; the three encoders as parallel branches, launched onto a drained stream: DESIGN 3.2h) are "
+                      "captured once and replayed; optimizer steps, collectives and update_sep are enqueued kernel by kernel" if cfg.use_hip_graphs else "kernel by kernel"),
            "grad_reduce": ("flat-buffer sum all-reduce per backward (RCCL); the last all-reduce + clip + Adam of every update runs on a "
                            "side stream, fenced at the next reader of those parameters" if world > 1 else "single rank: no collective"),
            "separator_output_reuse": "frozen eval-mode U-Net outputs computed once per stored observation and re-used by the 24 "
@@ -484,7 +484,9 @@ def run_passive_train(args, dev, rank, with_cpu=False):
                         "what": "algorithmic FLOP of the step (SURVEY 8d: 3 x the pair forward, 1.27 GFLOP per 512x32 clip) over the whole step's wall "
                                 "time (forward, BatchNorm statistics, backward, Adam), against the dense MFMA peak of the step's GEMM arithmetic"},
            "last_losses": [round(float(x), 5) for x in losses],
-           "what": "PassiveTrainer.train_batch: both U-Nets forward in train-mode BN, L1 losses, full backward, FlatAdam step"}
+           "what": "PassiveTrainer.train_batch: both U-Nets forward in train-mode BN, L1 losses, full backward, FlatAdam step",
+           "launch": "one HIP graph per step: weight packs, forward, losses, backward and Adam of the two networks as two branches (the mono separator reads the "
+                     "binaural masks detached), launched onto a drained stream (DESIGN 3.2h); M2H_PARALLEL_BRANCHES=0 = one chain"}
     del tr
     if with_cpu:
         out["cpu_baseline"] = passive_train_cpu_baseline(args.train_tm, min(args.cpu_seconds, 8.0))
