@@ -700,8 +700,8 @@ __global__ __launch_bounds__(Q4 ? 1024 : 256) void conv_wgrad_reduce_torch_kerne
 // block shape for (N, K): n extent, k sub-tiles per block, blocks along k
 static void wgrad_cfg(int N, int K, int& bng, int& kt, int& ktiles) {
   const int kt128 = (K + WK - 1) / WK;
-  bng = N > 32 ? 128 : 32;
-  kt = bng == 32 ? (kt128 >= 3 ? 3 : kt128) : 1;  // narrow layers: up to three k sub-tiles per block share the dY operand
+  bng = N > 64 ? 128 : (N > 32 ? 64 : 32);        // (64: round 4 -- a 64-channel layer on the 128-wide block spent half its MFMAs on padding)
+  kt = bng == 32 ? (kt128 >= 3 ? 3 : kt128) : (bng == 64 ? (kt128 >= 2 ? 2 : 1) : 1);  // narrow layers: up to three k sub-tiles per block share the dY operand
   ktiles = (kt128 + kt - 1) / kt;
 }
 
@@ -781,6 +781,8 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
     } else if (a.N <= 16) hipLaunchKernelGGL((wgrad3x3_row_kernel<16>), dim3((unsigned)p.S), blk, 0, st, p);
     else hipLaunchKernelGGL((wgrad3x3_row_kernel<32>), dim3((unsigned)p.S), blk, 0, st, p);
   } else if (bng == 128) hipLaunchKernelGGL((wgrad_kernel<128, 1, 2>), grid, blk, 0, st, p);
+  else if (bng == 64 && kt == 2) hipLaunchKernelGGL((wgrad_kernel<64, 2, 1>), grid, blk, 0, st, p);
+  else if (bng == 64) hipLaunchKernelGGL((wgrad_kernel<64, 1, 2>), grid, blk, 0, st, p);
   else if (kt == 1) hipLaunchKernelGGL((wgrad_kernel<32, 1, 2>), grid, blk, 0, st, p);
   else if (kt == 2) hipLaunchKernelGGL((wgrad_kernel<32, 2, 1>), grid, blk, 0, st, p);
   else hipLaunchKernelGGL((wgrad_kernel<32, 3, 1>), grid, blk, 0, st, p);
