@@ -1245,7 +1245,11 @@ static int splitk_for(long M, int N, int K, int phases, int BM, int BN) {
   const long mt = (M + BM - 1) / BM, ntl = (N + BN - 1) / BN;
   const long blocks = mt * ntl * phases;  // working blocks (padding blocks of the XCD map exit at once)
   long S = 1;
-  if (blocks < 512) S = (512 + blocks - 1) / blocks;  // aim at two resident blocks per CU
+  // Fewer blocks than CUs: split K, aiming at two resident blocks per CU.  From one block per CU up the launch is left whole (round 4): at
+  // 256-511 tiles a two-way split bought occupancy the layer did not need and paid a slab round trip plus a reduce launch for it
+  // (the policy encoders at the 280-sample update batch, tools/enc_fwd_bench.py: conv 4x4/2 32 -> 64 forward 66 -> 50 us, the 3x3
+  // conv's input gradient 49 -> 34 us).
+  if (blocks < 256) S = (512 + blocks - 1) / blocks;
   // ... but keep enough k-tiles per split to amortise a block's fixed cost (row decode, cold first loads, slab write): measured
   // optimum at the rollout shapes (layer_bench --batch 14 --tm 32) is ~4 tiles for the MFMA-paced 128-row tile and ~16 for the
   // weight-streaming 32/64-row tiles (deeper splits made the 14-env U-Net pass 25 % slower)
