@@ -118,10 +118,12 @@ typedef float f32x4_r __attribute__((ext_vector_type(4)));
 
 // Skinny dot products on the matrix pipe: D[m][r] = sum_k X[m][k] * Wr[k] for 16 rows m of X and 16 weight rows r, both operands
 // straight from global memory into v_mfma_f32_16x16x4_f32 registers (lane (row i, k-quarter kq) loads 16 bytes of its row = four
-// consecutive MFMAs' worth; no LDS staging, no barrier in the k-loop).  The block's four waves split the K/16 steps; the caller
-// sums their partial tiles through LDS.  Returns acc[e] = D[m = kq*4 + e][r = i] over this wave's steps.
+// consecutive MFMAs' worth; no LDS staging, no barrier in the k-loop).  The block's NW waves split the K/16 steps (a block's latency is
+// its longest wave's chain of dependent loads: 16 waves quarter it against 4 for the long-K products); the caller
+// sums their partial tiles through LDS in a fixed order (wave_tile_sum).  Returns acc[e] = D[m = kq*4 + e][r = i] over this wave's steps.
+template <int NW = 4>
 __device__ __forceinline__ f32x4_r skinny_dot16(const float* __restrict__ xrow, const float* __restrict__ wrow, int steps, int wave) {
-  const int s0 = (steps * wave) >> 2, s1 = (steps * (wave + 1)) >> 2;
+  const int s0 = (steps * wave) / NW, s1 = (steps * (wave + 1)) / NW;   // the block's NW waves split the K / 16 steps
   f32x4_r acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
   for (int s = s0; s < s1; ++s) {
@@ -131,6 +133,19 @@ __device__ __forceinline__ f32x4_r skinny_dot16(const float* __restrict__ xrow, 
     for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
   }
   return acc;
+}
+
+// sum over the NW waves' partial tiles, pairwise in a fixed tree (bit-reproducible)
+template <int NW>
+__device__ __forceinline__ float wave_tile_sum(const float (*R)[16][17], int m, int r) {
+  float t[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) t[w] = R[w][m][r];
+#pragma unroll
+  for (int n = NW; n > 1; n >>= 1)
+#pragma unroll
+    for (int w = 0; w < n / 2; ++w) t[w] = t[2 * w] + t[2 * w + 1];
+  return t[0];
 }
 
 // One GRU time step for a handful of rows (M <= 16: the rollout's 14 envs, one step of the update's sequence pass) in ONE
@@ -183,11 +198,12 @@ __global__ __launch_bounds__(256) void gru_step_kernel(const float* __restrict__
 // so the block that owns GRU_U hidden units runs the dot products of its 3*GRU_U rows of BOTH matrices through skinny_dot16 and
 // applies the gates; nothing but the new state is written (no backward pass follows a no-grad step).  Replaces the projection GEMM +
 // gru_step_kernel of the rollout step.
-__global__ __launch_bounds__(256) void gru_cell_kernel(const float* __restrict__ x, const float* __restrict__ wih, const float* __restrict__ bih,
+constexpr int GC_NW = 16;    // waves per block of gru_cell_kernel: the 96 + 32 steps of the two products are 8 per wave
+__global__ __launch_bounds__(64 * GC_NW) void gru_cell_kernel(const float* __restrict__ x, const float* __restrict__ wih, const float* __restrict__ bih,
                                                        const float* __restrict__ whh, const float* __restrict__ bhh,
                                                        const float* __restrict__ hprev, const float* __restrict__ mask,
                                                        float* __restrict__ hout, int M, int I, int H) {
-  __shared__ float R[2][4][16][17];
+  __shared__ float R[2][GC_NW][16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int j0 = blockIdx.x * GRU_U;
@@ -199,8 +215,8 @@ __global__ __launch_bounds__(256) void gru_cell_kernel(const float* __restrict__
   const float bi_r = bih[gj], bi_z = bih[H + gj], bi_n = bih[2 * H + gj];
   const float b_r = bhh[gj], b_z = bhh[H + gj], b_n = bhh[2 * H + gj];
   const float hp_raw = hprev[(size_t)ge * H + gj];
-  const f32x4_r ai = skinny_dot16(x + (size_t)row * I + 4 * kq, wih + wr * I + 4 * kq, I >> 4, wave);
-  const f32x4_r ah = skinny_dot16(hprev + (size_t)row * H + 4 * kq, whh + wr * H + 4 * kq, H >> 4, wave);
+  const f32x4_r ai = skinny_dot16<GC_NW>(x + (size_t)row * I + 4 * kq, wih + wr * I + 4 * kq, I >> 4, wave);
+  const f32x4_r ah = skinny_dot16<GC_NW>(hprev + (size_t)row * H + 4 * kq, whh + wr * H + 4 * kq, H >> 4, wave);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     R[0][wave][kq * 4 + e][i] = ai[e];   // [m][weight row]
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(256) void gru_cell_kernel(const float* __restrict__
   __syncthreads();
   if (tid < GRU_U * GRU_E && (tid & 15) < M) {
     const int u = tid >> 4, m = tid & 15;
-    auto tot = [&](int w, int rr) { return (R[w][0][m][rr] + R[w][1][m][rr]) + (R[w][2][m][rr] + R[w][3][m][rr]); };
+    auto tot = [&](int w, int rr) { return wave_tile_sum<GC_NW>(R[w], m, rr); };
     const float gi_r = tot(0, u) + bi_r, gi_z = tot(0, GRU_U + u) + bi_z, gi_n = tot(0, 2 * GRU_U + u) + bi_n;
     const float gr = tot(1, u), gz = tot(1, GRU_U + u), gn = tot(1, 2 * GRU_U + u);
     const float rg = sigmoidf_(gi_r + (gmask * gr + b_r));
@@ -686,26 +702,27 @@ constexpr int GB_U = 4, GB_E = 16;
 // columns: it is elementwise in (row, hidden unit), and its dh is exactly the out element the thread has just produced) runs as this
 // kernel's epilogue: one launch per BPTT step instead of two.  dhp is read (this step's) and rewritten (the previous step's) by the
 // same thread at the same element.
-__global__ __launch_bounds__(256) void gru_bwd_rec_kernel(const float* __restrict__ dpre, const float* __restrict__ whh_t,
+constexpr int GB_NW = 16;    // waves per block: the 96 steps of the 3H-long products are 6 per wave (four waves: 24 -- 9.7 us per BPTT step)
+__global__ __launch_bounds__(64 * GB_NW) void gru_bwd_rec_kernel(const float* __restrict__ dpre, const float* __restrict__ whh_t,
                                                           const float* __restrict__ a, float* __restrict__ dhp,
                                                           const float* __restrict__ mask, float* __restrict__ out, int M, int H,
                                                           const float* __restrict__ gi_p = nullptr, const float* __restrict__ gh_p = nullptr,
                                                           const float* __restrict__ bhh = nullptr, const float* __restrict__ hprev_p = nullptr,
                                                           const float* __restrict__ mask_p = nullptr, float* __restrict__ dgi_p = nullptr,
                                                           float* __restrict__ dpre_p = nullptr, float* __restrict__ hpm_p = nullptr) {
-  __shared__ float R[4][16][17];
+  __shared__ float R[GB_NW][16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int j0 = blockIdx.x * GB_U, K = 3 * H;
   const float* wrow = whh_t + (size_t)(j0 + min(i, GB_U - 1)) * K + 4 * kq;
   const float* xrow = dpre + (size_t)min(i, M - 1) * K + 4 * kq;
-  const f32x4_r acc = skinny_dot16(xrow, wrow, K >> 4, wave);
+  const f32x4_r acc = skinny_dot16<GB_NW>(xrow, wrow, K >> 4, wave);
 #pragma unroll
   for (int e = 0; e < 4; ++e) R[wave][kq * 4 + e][i] = acc[e];
   __syncthreads();
   if (tid < GB_U * GB_E && (tid & 15) < M) {
     const int u = tid >> 4, m = tid & 15;
-    const float rec = (R[0][m][u] + R[1][m][u]) + (R[2][m][u] + R[3][m][u]);
+    const float rec = wave_tile_sum<GB_NW>(R, m, u);
     const size_t o = (size_t)m * H + j0 + u;
     const float mk = mask != nullptr ? mask[m] : 1.f;
     const float g = (a != nullptr ? a[o] : 0.f) + mk * (rec + dhp[o]);
@@ -997,7 +1014,7 @@ int m2h_gru_cell(const float* x, const float* wih, const float* bih, const float
   M2H_REQUIRE(x && wih && bih && whh && bhh && hprev && hout, "gru_cell: null pointer");
   M2H_REQUIRE(M > 0 && M <= GRU_E && H > 0 && H % 16 == 0 && I > 0 && I % 16 == 0,
               "gru_cell: needs 1 <= M <= %d rows, H %% 16 == 0 and I %% 16 == 0 (got M=%d, I=%d, H=%d)", GRU_E, M, I, H);
-  hipLaunchKernelGGL(gru_cell_kernel, dim3(H / GRU_U), dim3(256), 0, as_stream(stream), x, wih, bih, whh, bhh, hprev, mask, hout, M, I, H);
+  hipLaunchKernelGGL(gru_cell_kernel, dim3(H / GRU_U), dim3(64 * GC_NW), 0, as_stream(stream), x, wih, bih, whh, bhh, hprev, mask, hout, M, I, H);
   return launch_status("gru_cell");
 }
 
@@ -1088,7 +1105,7 @@ int m2h_gru_bwd_rec(const float* dpre, const float* whh_t, const float* a, const
   M2H_REQUIRE(dpre && whh_t && dhp && out, "gru_bwd_rec: null pointer");
   M2H_REQUIRE(M > 0 && M <= GB_E && H > 0 && H % 16 == 0, "gru_bwd_rec: needs 1 <= M <= %d rows and H %% 16 == 0 (got M=%d, H=%d)",
               GB_E, M, H);
-  hipLaunchKernelGGL(gru_bwd_rec_kernel, dim3(H / GB_U), dim3(256), 0, as_stream(stream), dpre, whh_t, a, const_cast<float*>(dhp), mask, out, M, H,
+  hipLaunchKernelGGL(gru_bwd_rec_kernel, dim3(H / GB_U), dim3(64 * GB_NW), 0, as_stream(stream), dpre, whh_t, a, const_cast<float*>(dhp), mask, out, M, H,
                      static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), static_cast<const float*>(nullptr),
                      static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), static_cast<float*>(nullptr),
                      static_cast<float*>(nullptr), static_cast<float*>(nullptr));
@@ -1102,7 +1119,7 @@ int m2h_gru_bwd_step(const float* dpre, const float* whh_t, const float* a, floa
   M2H_REQUIRE(M > 0 && M <= GB_E && H > 0 && H % 16 == 0, "gru_bwd_step: needs 1 <= M <= %d rows and H %% 16 == 0 (got M=%d, H=%d)",
               GB_E, M, H);
   M2H_REQUIRE(dpre_prev != dpre, "gru_bwd_step: the previous step's dpre must not alias this step's (every block reads all of it)");
-  hipLaunchKernelGGL(gru_bwd_rec_kernel, dim3(H / GB_U), dim3(256), 0, as_stream(stream), dpre, whh_t, a, dhp, mask, out, M, H, gi_prev, gh_prev, bhh,
+  hipLaunchKernelGGL(gru_bwd_rec_kernel, dim3(H / GB_U), dim3(64 * GB_NW), 0, as_stream(stream), dpre, whh_t, a, dhp, mask, out, M, H, gi_prev, gh_prev, bhh,
                      hprev_prev, mask_prev, dgi_prev, dpre_prev, hpm_prev);
   return launch_status("gru_bwd_step");
 }
