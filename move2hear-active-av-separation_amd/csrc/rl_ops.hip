@@ -157,11 +157,12 @@ __device__ __forceinline__ float wave_tile_sum(const float (*R)[16][17], int m, 
 // product with broadcast LDS reads -- 12 us, bound by LDS bandwidth.)
 constexpr int GRU_U = 4;     // hidden units per block
 constexpr int GRU_E = 16;    // env slots per block (M <= 16)
-__global__ __launch_bounds__(256) void gru_step_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
+constexpr int GS_NW = 8;     // waves per block: the 32 steps of the H-long products are 4 per wave
+__global__ __launch_bounds__(64 * GS_NW) void gru_step_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
                                                        const float* __restrict__ bhh, const float* __restrict__ hprev,
                                                        const float* __restrict__ mask, float* __restrict__ gh_raw,
                                                        float* __restrict__ hout, int M, int H) {
-  __shared__ float R[4][16][17];
+  __shared__ float R[GS_NW][16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int j0 = blockIdx.x * GRU_U;
@@ -174,17 +175,17 @@ __global__ __launch_bounds__(256) void gru_step_kernel(const float* __restrict__
   const float gi_r = gi[(size_t)ge * 3 * H + gj], gi_z = gi[(size_t)ge * 3 * H + H + gj], gi_n = gi[(size_t)ge * 3 * H + 2 * H + gj];
   const float b_r = bhh[gj], b_z = bhh[H + gj], b_n = bhh[2 * H + gj];
   const float hp_raw = hprev[(size_t)ge * H + gj];
-  const f32x4_r acc = skinny_dot16(xrow, wrow, H >> 4, wave);
+  const f32x4_r acc = skinny_dot16<GS_NW>(xrow, wrow, H >> 4, wave);
 #pragma unroll
   for (int e = 0; e < 4; ++e) R[wave][kq * 4 + e][i] = acc[e];   // [m][weight row]
   __syncthreads();
   if (tid < 3 * GRU_U * GRU_E) {                                  // gh_raw: thread (weight row rr, env m)
     const int rr = tid >> 4, m = tid & 15;
-    if (m < M) gh_raw[(size_t)m * 3 * H + (size_t)(rr / GRU_U) * H + j0 + (rr % GRU_U)] = (R[0][m][rr] + R[1][m][rr]) + (R[2][m][rr] + R[3][m][rr]);
+    if (m < M) gh_raw[(size_t)m * 3 * H + (size_t)(rr / GRU_U) * H + j0 + (rr % GRU_U)] = wave_tile_sum<GS_NW>(R, m, rr);
   }
   if (tid < GRU_U * GRU_E && (tid & 15) < M) {
     const int u = tid >> 4, m = tid & 15;
-    auto tot = [&](int rr) { return (R[0][m][rr] + R[1][m][rr]) + (R[2][m][rr] + R[3][m][rr]); };
+    auto tot = [&](int rr) { return wave_tile_sum<GS_NW>(R, m, rr); };
     const float gr = tot(u), gz = tot(GRU_U + u), gn = tot(2 * GRU_U + u);
     const float rg = sigmoidf_(gi_r + (gmask * gr + b_r));
     const float z = sigmoidf_(gi_z + (gmask * gz + b_z));
@@ -1005,7 +1006,7 @@ int m2h_gru_step(const float* gi, const float* whh, const float* bhh, const floa
   M2H_REQUIRE(gi && whh && bhh && hprev && gh_raw && hout, "gru_step: null pointer");
   M2H_REQUIRE(M > 0 && M <= GRU_E && H > 0 && H % 16 == 0, "gru_step: needs 1 <= M <= %d rows and H %% 16 == 0 (got M=%d, H=%d)",
               GRU_E, M, H);
-  hipLaunchKernelGGL(gru_step_kernel, dim3(H / GRU_U), dim3(256), 0, as_stream(stream), gi, whh, bhh, hprev, mask, gh_raw, hout, M, H);
+  hipLaunchKernelGGL(gru_step_kernel, dim3(H / GRU_U), dim3(64 * GS_NW), 0, as_stream(stream), gi, whh, bhh, hprev, mask, gh_raw, hout, M, H);
   return launch_status("gru_step");
 }
 
