@@ -252,12 +252,29 @@ __global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restri
 #pragma unroll
   for (int a = 0; a < 9; ++a) acc[a] = 0.f;
   const float* f = feats + (size_t)row * H;
-  for (int k = lane; k < H; k += 64) {
-    const float x = f[k];
+  if ((H & 255) == 0) {
+    // 16 bytes per lane and load, every load of a pass issued before the first use (the scalar loop below is a chain of H / 64 dependent
+    // load rounds: 10 us of a 14-row launch)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int k = lane * 4; k < H; k += 256) {
+      const f4 x = *reinterpret_cast<const f4*>(f + k);
+      const f4 wc = *reinterpret_cast<const f4*>(Wc + k);
+      f4 w[8];
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
-      if (a < A) acc[a] += x * Wa[a * H + k];
-    acc[8] += x * Wc[k];
+      for (int a = 0; a < 8; ++a) w[a] = *reinterpret_cast<const f4*>(Wa + (size_t)(a < A ? a : 0) * H + k);
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+        if (a < A) acc[a] += (x[0] * w[a][0] + x[1] * w[a][1]) + (x[2] * w[a][2] + x[3] * w[a][3]);
+      acc[8] += (x[0] * wc[0] + x[1] * wc[1]) + (x[2] * wc[2] + x[3] * wc[3]);
+    }
+  } else {
+    for (int k = lane; k < H; k += 64) {
+      const float x = f[k];
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+        if (a < A) acc[a] += x * Wa[a * H + k];
+      acc[8] += x * Wc[k];
+    }
   }
 #pragma unroll
   for (int a = 0; a < 9; ++a) acc[a] = wave_sum(acc[a]);
