@@ -705,14 +705,20 @@ static void wgrad_cfg(int N, int K, int& bng, int& kt, int& ktiles) {
   ktiles = (kt128 + kt - 1) / kt;
 }
 
-static int wgrad_splits(long M, int N, int K) {
+// the shapes the image-row 3x3 kernels take (geometry only: the launch adds its conditions on ldy and the knob)
+static bool wgrad_row3x3_shape(const m2h_conv_args& a) {
+  return a.nth == 3 && a.ntw == 3 && a.stride == 1 && a.mulh == 1 && a.mulw == 1 && a.offh == -1 && a.offw == -1 && a.C0 == 32 && a.C1 == 0 &&
+         a.Wq == 32 && a.Wi == 32 && a.Hq == a.Hi && a.os == 1 && a.ph == 0 && a.pw == 0 && a.Ho == a.Hq && a.Wo == a.Wq && a.N <= 32 && a.N % 4 == 0;
+}
+
+static int wgrad_splits(long M, int N, int K, bool row3x3 = false) {
   int bng, kt, ktiles;
   wgrad_cfg(N, K, bng, kt, ktiles);
   const long tiles = ((N + bng - 1) / bng) * (long)ktiles;
   const long chunks = (M + WM - 1) / WM;
   // one wave front, no tail round: 3 resident blocks per CU for the one-sub-tile kernels (40 / 64 KB LDS, <= 176 VGPRs), 2 for
-  // the wide-k ones (196-240 VGPRs)
-  const long target = g_wgrad_blocks > 0 ? g_wgrad_blocks : (kt >= 2 ? 512 : 768);
+  // the wide-k ones (196-240 VGPRs); the image-row kernels (one block per split, 46 KB LDS) fill 3 per CU as well
+  const long target = g_wgrad_blocks > 0 ? g_wgrad_blocks : (row3x3 ? 768 : (kt >= 2 ? 512 : 768));
   long S = (target + tiles - 1) / tiles;
   if (S > chunks / 4) S = chunks / 4;   // at least 4 chunks per split
   if (S > 1024) S = 1024;
@@ -724,7 +730,7 @@ size_t conv_wgrad_workspace_bytes(const m2h_conv_args& a) {
   const long M = (long)a.B * a.Hq * a.Wq;
   const int K = a.nth * a.ntw * (a.C0 + a.C1);
   const int Kpad = (K + WK - 1) / WK * WK;
-  return (size_t)wgrad_splits(M, a.N, K) * a.N * Kpad * sizeof(float);
+  return (size_t)wgrad_splits(M, a.N, K, wgrad_row3x3_shape(a)) * a.N * Kpad * sizeof(float);
 }
 
 // quad: the four phases of a ConvTranspose2d(4,2,1) in one launch (a = the geometry of one phase: taps 2x2, stride 1, os 2,
@@ -754,7 +760,7 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   M2H_REQUIRE(a.os >= 1 && (a.Hq - 1) * a.os + a.ph < a.Ho && (a.Wq - 1) * a.os + a.pw < a.Wo, "conv_wgrad: output pixel grid exceeds Ho x Wo");
   p.dy = dy; p.ldy = ldy; p.N = a.N; p.K = p.ntap * p.Ctot; p.Kpad = (p.K + WK - 1) / WK * WK;
   p.M = (int)M; p.chunks = (int)((M + WM - 1) / WM);
-  p.S = wgrad_splits(M, a.N, p.K);
+  p.S = wgrad_splits(M, a.N, p.K, !quad && wgrad_row3x3_shape(a));
   const size_t slab_floats = (size_t)phases * p.S * p.N * p.Kpad, need = (slab_floats + (quad ? (size_t)4 * p.N * p.K : 0)) * sizeof(float);
   M2H_REQUIRE(a.workspace != nullptr && a.workspace_bytes >= need, "conv_wgrad: workspace too small (need %zu bytes)", need);
   p.ws = static_cast<float*>(a.workspace);
