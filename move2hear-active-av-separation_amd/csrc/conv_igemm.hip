@@ -794,8 +794,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_row_kernel(const IGemmP p) {
 // epoch the fp32-MFMA kernel is matrix-bound (31.7 GFLOP of 16-pass fp32 MFMAs: 285 us at 71 % of the 157 TFLOP/s peak); the
 // three bf16 MFMAs cost 3/16 of that, which leaves the layer to its HBM stream (220 MB in + 220 MB out).
 // De-sliced store with N = 16: a lane's four accumulator values are four consecutive time frames of one band: one 16-byte store.
+// blocks per CU by LDS: 32 -> 32 channels 66.8 KB (2), 32 -> 16 48.1 KB (3), 16 -> 32 35.3 KB (4, held at 3: the register budget of three)
 template <int FR, int C>
-__global__ __launch_bounds__(256, 2) void conv3x3_row_bf16x3_kernel(const IGemmP p) {
+__global__ __launch_bounds__(256, (FR == 32 && C == 32) ? 2 : 3) void conv3x3_row_bf16x3_kernel(const IGemmP p) {
   constexpr int W = 32, PW = W + 2, ROWS = 4, PR = ROWS + 2;
   constexpr int K = 9 * C;
   constexpr int PS = 4 * C + 16;                    // patch pixel stride, bytes ([hi C | lo C] + 16: an odd count of 16-byte units)
@@ -1555,7 +1556,8 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
       a.Hq % 4 == 0 && a.N % 4 == 0 && a.scale == nullptr && a.cls_table == nullptr && a.head_w == nullptr &&
       (a.operand_format & M2H_FMT_LAYOUT_BITS) == 0 && (long)a.B * (a.Hq / 4) >= 512 && (a.out_mode == M2H_OUT_NHWC || a.N % 16 == 0)) {
     const long chunks = (long)a.B * (a.Hq / 4);
-    const dim3 grid((unsigned)(chunks < 512 ? chunks : 512)), blk(256);
+    const long cap = (a.N > 16 && a.C0 == 32) ? 512 : 768;      // resident blocks: two / three per CU (LDS)
+    const dim3 grid((unsigned)(chunks < cap ? chunks : cap)), blk(256);
     if (a.N <= 16) hipLaunchKernelGGL((conv3x3_row_bf16x3_kernel<16, 32>), grid, blk, 0, st, p);
     else if (a.C0 == 32) hipLaunchKernelGGL((conv3x3_row_bf16x3_kernel<32, 32>), grid, blk, 0, st, p);
     else hipLaunchKernelGGL((conv3x3_row_bf16x3_kernel<32, 16>), grid, blk, 0, st, p);
