@@ -383,7 +383,7 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
            "env": "synthetic on-device env (cached 128x128 RGB-D frames + spectrogram pool), zero-cost dynamics",
            "launch": ("HIP graphs: the rollout step (one graph per (extra-reward, episode-end) flag pair, one chain) and the update_pol epoch "
                       "(forward + losses + backward; the three encoders as parallel branches, launched onto a drained stream: DESIGN 3.2h) are "
-                      "captured once and replayed; optimizer steps, collectives and update_sep are enqueued kernel by kernel" if cfg.use_hip_graphs else "kernel by kernel"),
+                      "captured once and replayed, and so is the update_sep epoch (one chain); optimizer steps and collectives are enqueued kernel by kernel" if cfg.use_hip_graphs else "kernel by kernel"),
            "grad_reduce": ("flat-buffer sum all-reduce per backward (RCCL); the last all-reduce + clip + Adam of every update runs on a "
                            "side stream, fenced at the next reader of those parameters" if world > 1 else "single rank: no collective"),
            "separator_output_reuse": "frozen eval-mode U-Net outputs computed once per stored observation and re-used by the 24 "

@@ -444,8 +444,8 @@ def pack_conv_weight_ex(w4d, ci_used, ci_out, out=None):
     return wp
 
 
-def slice_concat_input(a, b=None, mul=None, bscale=None, op=0):
-    """AcousticMem / AudioCNN input glue (m2h_slice_concat_input).  a [B,F,T,Ca], b [B,F,T,Cb] -> NHWC [B,F/16,T,16*(Ca+Cb)]."""
+def slice_concat_input(a, b=None, mul=None, bscale=None, op=0, out=None):
+    """AcousticMem / AudioCNN input glue (m2h_slice_concat_input).  a [B,F,T,Ca], b [B,F,T,Cb] -> NHWC [B,F/16,T,16*(Ca+Cb)] (into `out` if given)."""
     for t in (a, b, mul, bscale):
         _chk(t, "slice_concat_input")
     B, F, T, Ca = a.shape
@@ -456,7 +456,11 @@ def slice_concat_input(a, b=None, mul=None, bscale=None, op=0):
         raise RuntimeError("m2h.slice_concat_input: mul shape")
     if bscale is not None and bscale.numel() != B:
         raise RuntimeError("m2h.slice_concat_input: bscale size")
-    out = torch.empty((B, F // 16, T, 16 * (Ca + Cb)), device=a.device, dtype=torch.float32)
+    shape = (B, F // 16, T, 16 * (Ca + Cb))
+    if out is None:
+        out = torch.empty(shape, device=a.device, dtype=torch.float32)
+    elif tuple(out.shape) != shape or not out.is_contiguous() or out.dtype != torch.float32 or out.device != a.device:
+        raise RuntimeError("m2h.slice_concat_input: out must be a contiguous fp32 tensor of shape %s on the inputs' device" % (shape,))
     lib = _lib.load()
     with torch.cuda.device(a.device):
         _timed("slice_concat_input", {"bytes": 4.0 * (2 * out.numel())}, a.device,

@@ -49,11 +49,11 @@ class AcousticMem(nn.Module):
 
     SMALL_BATCH = 64   # up to here the no-grad forward is the one-launch kernel (above it the image-row kernels of the update batch)
 
-    def slice_inputs(self, pred_mono, prev_pred_monoFromMem, masks=None):
+    def slice_inputs(self, pred_mono, prev_pred_monoFromMem, masks=None, out=None):
         """The convs' input: both tensors sliced 16-way and concatenated (memory_nets.py:40-61), the previous memory scaled by the
         not-done masks; NHWC [B, 32, T, 32].  A function of the inputs alone: update_sep builds it once for its four epochs."""
         bscale = masks.reshape(-1).contiguous() if masks is not None else None
-        return ops.slice_concat_input(pred_mono.contiguous(), prev_pred_monoFromMem.contiguous(), bscale=bscale, op=0)
+        return ops.slice_concat_input(pred_mono.contiguous(), prev_pred_monoFromMem.contiguous(), bscale=bscale, op=0, out=out)
 
     def forward_masked(self, pred_mono, prev_pred_monoFromMem, masks=None, sliced=None):
         """sliced: ``slice_inputs`` of the same three arguments, when the caller already holds it."""

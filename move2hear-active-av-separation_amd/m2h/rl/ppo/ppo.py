@@ -233,9 +233,42 @@ class PPO(nn.Module):
         self._sep_cache = (key, val)
         return val
 
+    _sep_graph = None
+    _sep_updates = 0
+
+    def _sep_graph_state(self, pred_mono, prev_mem, masks, gt_mono):
+        """Static state of the update_sep epoch's graph: the memory's sliced input lives in a buffer of its own (written once per update),
+        everything else the epoch reads is a view of the separator storage or lives in the optimizer's flat buffers."""
+        self.optimizer_sep.build()
+        sig = (pred_mono.data_ptr(), prev_mem.data_ptr(), masks.data_ptr(), gt_mono.data_ptr(), tuple(pred_mono.shape), ops.math_mode(),
+               tuple(p.data_ptr() for p in self.optimizer_sep.param_groups[0]["params"]))
+        gs = self._sep_graph
+        if gs is None or gs.sig != sig:
+            from types import SimpleNamespace
+            B, Fq, T, _ = pred_mono.shape
+            gs = self._sep_graph = SimpleNamespace(sig=sig, graph=None, loss=None,
+                                                   sliced=torch.empty((B, Fq // 16, T, 32), device=pred_mono.device, dtype=torch.float32),
+                                                   memos=MF.memos_of(self.actor_critic.acoustic_mem))
+        return gs
+
+    def _sep_epoch_graph(self, gs, pred_mono, prev_mem, masks, gt_mono):
+        self._reducers["mem"].fence()       # the graph holds no fence: order it after a pending optimizer step here
+        MF.refresh_pack_memos(hooks=False, only=gs.memos)   # the memory's conv weights re-packed in place after the previous step
+        if gs.graph is None:
+            g = torch.cuda.CUDAGraph()
+            with graphs.capture(g):
+                self.optimizer_sep.zero_grad()
+                loss = self.actor_critic.monoFromMem_l1_masked(pred_mono, prev_mem, masks, gt_mono, 0, sliced=gs.sliced)
+                loss.backward(MF.unit_grad(loss.device))
+                gs.loss = loss.detach()
+            gs.graph = g
+        gs.graph.replay()
+        return gs.loss
+
     def update_sep(self, rollouts_sep, as_tensor=False):
         """as_tensor: return the three mean losses as a device tensor instead of python floats (no host synchronisation: the
         trainer enqueues the cycle's separator updates on a second stream and reads the losses after the join)."""
+        self._sep_updates += 1
         acc = torch.zeros(3, device=self.device)
         sep_frozen = not any(p.requires_grad for m in (self.actor_critic.binSep_enc, self.actor_critic.binSep_dec,
                                                         self.actor_critic.bin2mono_enc, self.actor_critic.bin2mono_dec)
@@ -259,7 +292,17 @@ class PPO(nn.Module):
                         pred_mono = self.actor_critic.convert_bin2mono(pred_binSepMasks.detach(),
                                                                        mixed_audio=obs_batch["mixed_bin_audio_mag"])
                 gt_mono = obs_batch["gt_mono_comps"]
-                if cached is not None and idx is None:
+                graphed = (cached is not None and idx is None and self.use_hip_graphs and self._sep_updates > 1 and not ops.timing_enabled()
+                           and getattr(rollouts_sep, "full_batch_views", False) and pred_mono.shape[1] == 512)
+                if graphed:
+                    # forward + loss + backward of the epoch replayed from a HIP graph (one chain; same kernels, same values): the 20 launches
+                    # of an epoch no longer wait for the host one by one
+                    gs = self._sep_graph_state(pred_mono, prev_mem_batch, masks_batch, gt_mono)
+                    if sliced is None:
+                        with torch.no_grad():
+                            sliced = self.actor_critic.acoustic_mem.slice_inputs(pred_mono, prev_mem_batch, masks_batch, out=gs.sliced)
+                    monoFromMem_loss = self._sep_epoch_graph(gs, pred_mono, prev_mem_batch, masks_batch, gt_mono)
+                elif cached is not None and idx is None:
                     if sliced is None:
                         with torch.no_grad():
                             sliced = self.actor_critic.acoustic_mem.slice_inputs(pred_mono, prev_mem_batch, masks_batch)
@@ -278,8 +321,9 @@ class PPO(nn.Module):
                         # the two losses that are only logged (:219-224) are functions of the stored observations and the cached
                         # separator outputs alone: computed once per buffer generation like those outputs
                         cached = self._sep_cache_add_losses(bin_loss, mono_loss)
-                self.optimizer_sep.zero_grad()
-                monoFromMem_loss.backward(MF.unit_grad(monoFromMem_loss.device))     # total_loss = monoFromMem_loss (:226)
+                if not graphed:
+                    self.optimizer_sep.zero_grad()
+                    monoFromMem_loss.backward(MF.unit_grad(monoFromMem_loss.device))     # total_loss = monoFromMem_loss (:226)
                 self._reduce_and_step("mem", self.optimizer_sep, last=_e == self.ppo_epoch - 1 and _mb == self.num_mini_batch - 1)
                 acc += torch.stack((bin_loss, mono_loss, monoFromMem_loss.detach()))
         num_updates = self.ppo_epoch * self.num_mini_batch
