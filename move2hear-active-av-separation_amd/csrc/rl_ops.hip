@@ -252,7 +252,11 @@ __global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restri
 #pragma unroll
   for (int a = 0; a < 9; ++a) acc[a] = 0.f;
   const float* f = feats + (size_t)row * H;
-  if ((H & 255) == 0 && (((size_t)feats | (size_t)Wa | (size_t)Wc) & 15) == 0) {   // (parameters live back to back in FlatAdam's buffer: 16-byte alignment is checked, not assumed)
+  if ((H & 255) == 0) {
+    // (The heads' weights live back to back in FlatAdam's buffer -- the critic's row starts 12 bytes past a 16-byte boundary behind the
+    // 3-float action bias: the 16-byte loads below are then dword-aligned only, which global loads accept on gfx950, as the GRU / skinny
+    // kernels' loads of flat-buffer rows rely on too.  ONE path whatever the alignment: a second one would round differently, and the
+    // same weights before and after they move into the flat buffer would give losses that differ in the last bit.)
     // 16 bytes per lane and load, every load of a pass issued before the first use (the scalar loop below is a chain of H / 64 dependent
     // load rounds: 10 us of a 14-row launch)
     typedef float f4 __attribute__((ext_vector_type(4)));
