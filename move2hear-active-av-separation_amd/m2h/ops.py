@@ -469,13 +469,16 @@ def slice_concat_input(a, b=None, mul=None, bscale=None, op=0, out=None):
     return out
 
 
-def visual_input(rgb, depth=None):
+def visual_input(rgb, depth=None, out=None):
     _chk(rgb, "visual_input(rgb)")
     _chk(depth, "visual_input(depth)")
     B, H, W, C = rgb.shape
     if C != 3:
         raise RuntimeError("m2h.visual_input: rgb must have 3 channels")
-    out = torch.empty((B, H, W, 4), device=rgb.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((B, H, W, 4), device=rgb.device, dtype=torch.float32)
+    elif tuple(out.shape) != (B, H, W, 4) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != rgb.device:
+        raise RuntimeError("m2h.visual_input: out must be a contiguous fp32 [B, H, W, 4] tensor on the inputs' device")
     lib = _lib.load()
     with torch.cuda.device(rgb.device):
         _lib.check(lib.m2h_visual_input(_ptr(rgb), _ptr(depth), _ptr(out), B, H, W, _stream(rgb)), "m2h_visual_input")

@@ -60,16 +60,22 @@ class VisualCNN(nn.Module):
     def is_blind(self):
         return self._n_input_rgb + self._n_input_depth == 0
 
-    def forward(self, observations, out=None):
+    def prepare(self, observations, out=None):
+        """The conv stack's input: rgb (+ depth) / 255 as one NHWC [B, H, W, 4] tensor (visual_cnn.py:135-140).  A function of the observations
+        alone: update_pol makes it once for its four epochs (``forward(..., x=)``)."""
+        rgb = observations["rgb"]
+        depth = observations["depth"] if self._n_input_depth > 0 else None
+        return ops.visual_input(rgb.contiguous(), depth.contiguous() if depth is not None else None, out=out)
+
+    def forward(self, observations, out=None, x=None):
         """out: optional [B, output_size] destination (a column block of the policy's concatenated feature matrix) for the no-grad
-        rollout path: the last layer then writes there instead of into a tensor of its own."""
+        rollout path: the last layer then writes there instead of into a tensor of its own.  x: ``prepare(observations)`` when the caller holds it."""
         if self.is_blind:
             raise NotImplementedError("m2h VisualCNN: blind configuration has no encoder")
         if self._n_input_rgb != 3 or self._n_input_depth not in (0, 1):
             raise NotImplementedError("m2h VisualCNN: built for rgb (3 ch) with optional depth (1 ch)")
-        rgb = observations["rgb"]
-        depth = observations["depth"] if self._n_input_depth > 0 else None
-        x = ops.visual_input(rgb.contiguous(), depth.contiguous() if depth is not None else None)
+        if x is None:
+            x = self.prepare(observations)
         c0, c1, c2, fc = self.cnn[0], self.cnn[2], self.cnn[4], self.cnn[6]
         x = MF.conv2d(x, c0.weight, c0.bias, 4, 0, slope=0.0, memo=self._memo[0], name="visual_cnn.conv0")  # Ci 3 packed to 4
         x = MF.conv2d(x, c1.weight, c1.bias, 2, 0, slope=0.0, memo=self._memo[1], name="visual_cnn.conv1")

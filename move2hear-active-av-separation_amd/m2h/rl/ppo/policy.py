@@ -80,7 +80,17 @@ class PolicyNet(Net):
     def num_recurrent_layers(self):
         return self.state_encoder.num_recurrent_layers
 
-    def forward(self, observations, rnn_hidden_states, masks, pred_binSepMasks=None, pred_mono=None, pred_monoFromMem=None):
+    def prepare_inputs(self, observations, pred_binSepMasks, pred_mono, pred_monoFromMem, out=None):
+        """The three encoders' NHWC inputs (visual: rgb-d / 255; binaural: log1p(clamp0(mix * masks)) sliced; mono: mono | memory sliced;
+        :98-103 with visual_cnn.py:135-140, audio_cnn.py:118-128): functions of the stored batch alone, so update_pol makes them once per
+        update instead of once per epoch.  out: a previous result to overwrite in place (the epoch's HIP graph reads these by address)."""
+        o = out if out is not None else (None, None, None)
+        xv = self.visual_encoder.prepare(observations, out=o[0])
+        xa = ops.slice_concat_input(observations["mixed_bin_audio_mag"].contiguous(), mul=pred_binSepMasks.contiguous(), op=1, out=o[1])
+        xb = ops.slice_concat_input(pred_mono.contiguous(), pred_monoFromMem.contiguous(), op=2, out=o[2])
+        return xv, xa, xb
+
+    def forward(self, observations, rnn_hidden_states, masks, pred_binSepMasks=None, pred_mono=None, pred_monoFromMem=None, prepared=None):
         from ... import graphs
         if self._audio_pair.usable(pred_mono, pred_monoFromMem) and pred_mono.shape[0] < 64:
             # rollout step (no gradients, 14 envs): the two audio encoders as one chain of block-diagonal layers (audio_cnn.FusedAudioPair)
@@ -96,11 +106,15 @@ class PolicyNet(Net):
         # The three encoders are independent kernel chains: at update batches, while a HIP graph is being captured (update_pol's
         # epoch, ppo.py), graphs.run_parallel puts them on three streams = three branches of the graph (forward and backward);
         # sequential otherwise (m2h/graphs.py has the measurements and the launch rule that goes with it).
-        x = graphs.run_parallel(pred_mono.device if pred_mono.shape[0] >= 64 else None, [
-            lambda: self.visual_encoder(observations),
-            lambda: self.bin_encoder(observations, pred_binSepMasks=pred_binSepMasks),
-            lambda: self.monoNmonoFromMem_encoder.forward_pair(pred_mono, pred_monoFromMem),  # cat(dim=3) read in place
-        ])
+        if prepared is not None:      # update_pol's epochs: the inputs' glue was made once for the update (prepare_inputs)
+            xv, xa, xb = prepared
+            fns = [lambda: self.visual_encoder(observations, x=xv), lambda: self.bin_encoder.encode(xa),
+                   lambda: self.monoNmonoFromMem_encoder.encode(xb)]
+        else:
+            fns = [lambda: self.visual_encoder(observations),
+                   lambda: self.bin_encoder(observations, pred_binSepMasks=pred_binSepMasks),
+                   lambda: self.monoNmonoFromMem_encoder.forward_pair(pred_mono, pred_monoFromMem)]  # cat(dim=3) read in place
+        x = graphs.run_parallel(pred_mono.device if pred_mono.shape[0] >= 64 else None, fns)
         x1 = torch.cat(x, dim=1)
         x2, rnn_hidden_states_new = self.state_encoder(x1, rnn_hidden_states, masks)
         # the reference asserts "not isnan(x2).any().item()" here (:116): a host sync per call; dropped.
@@ -193,12 +207,13 @@ class Policy(nn.Module):
         return value, CustomFixedCategorical(logp_all, probs, ent, self._host_noise), (logp_act if actions is not None else None)
 
     def evaluate_rows(self, observations, rnn_hidden_states_pol, masks, action, pred_binSepMasks=None, pred_mono=None,
-                      pred_monoFromMem=None):
-        """evaluate_actions with the per-row entropies (what the fused PPO-loss kernel consumes)."""
+                      pred_monoFromMem=None, prepared=None):
+        """evaluate_actions with the per-row entropies (what the fused PPO-loss kernel consumes).
+        prepared: ``pol_net.prepare_inputs`` of the same batch, when the caller holds it (update_pol's epochs share one)."""
         self._fence("pol")
         feats_pol, rnn_hidden_states_pol = self.pol_net(
             observations, rnn_hidden_states_pol, masks, pred_binSepMasks=pred_binSepMasks, pred_mono=pred_mono,
-            pred_monoFromMem=pred_monoFromMem)
+            pred_monoFromMem=pred_monoFromMem, prepared=prepared)
         value, dist, action_log_probs = self._heads(feats_pol, action)
         return value, action_log_probs, dist.entropy(), rnn_hidden_states_pol
 

@@ -14,6 +14,8 @@ get_advantages, load_pretrained_passive_separators, init_distributed).  Mechanis
     (24x fewer U-Net passes, identical numbers); ``cache_separator_outputs=False`` restores the reference schedule.
   * loss scalars are accumulated on the device and read back once per update instead of 3 ``.item()`` per minibatch.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -116,13 +118,13 @@ class PPO(nn.Module):
             r.fence()
 
     # ------------------------------------------------------------------ policy update (reference :82-177)
-    def _pol_epoch(self, sample, clip, acc):
+    def _pol_epoch(self, sample, clip, acc, prepared=None):
         """Forward, losses and backward of one mini-batch (reference :94-163); the optimizer step follows in the caller."""
         (obs_batch, h_batch, pm_batch, mono_batch, mem_batch, value_preds_batch, return_batch, adv_targ, actions_batch,
          old_logp_batch, masks_batch) = sample
         values, logp, ent_rows, _ = self.actor_critic.evaluate_rows(
             obs_batch, h_batch, masks_batch, actions_batch, pred_binSepMasks=pm_batch, pred_mono=mono_batch,
-            pred_monoFromMem=mem_batch)
+            pred_monoFromMem=mem_batch, prepared=prepared)
         self.optimizer_pol.zero_grad()
         total_loss, stats = MF.PPOLoss.apply(values, logp, ent_rows, value_preds_batch, return_batch, adv_targ, old_logp_batch,
                                              clip, float(self.value_loss_coef), float(self.entropy_coef),
@@ -161,12 +163,19 @@ class PPO(nn.Module):
                tuple(p.data_ptr() for p in self.optimizer_pol.param_groups[0]["params"]))
         if gs is None or gs.sig != sig:
             from types import SimpleNamespace
-            gs = self._pol_graph = SimpleNamespace(sig=sig, graph=None, forked=False, adv=torch.empty_like(advantages),
+            gs = self._pol_graph = SimpleNamespace(sig=sig, graph=None, forked=False, prepared=None, adv=torch.empty_like(advantages),
                                                    clip=torch.zeros(1, device=self.device), acc=torch.zeros(4, device=self.device))
         gs.adv.copy_(advantages)
         gs.clip.fill_(float(self.clip_param))
         gs.acc.zero_()
         num_envs = rollouts_pol.rewards.size(1)
+        # the encoders' input glue (rgb-d scaling, the two audio inputs' slicing) depends on the stored batch alone: once per update, into
+        # the buffers the epoch's graph reads (it was the first kernel of each of the graph's three branches, four times per update)
+        cpu_rng = torch.get_rng_state()
+        s0 = next(iter(rollouts_pol.recurrent_generator(gs.adv, 1)))     # (the batch is the storage in place: views; its randperm draw is undone)
+        torch.set_rng_state(cpu_rng)
+        with torch.no_grad():
+            gs.prepared = self.actor_critic.pol_net.prepare_inputs(s0[0], s0[2], s0[3], s0[4], out=gs.prepared)
         for _e in range(self.ppo_epoch):
             self._reducers["pol"].fence()   # the graph holds no fence: order it after a pending optimizer step here
             # conv weights re-packed in place after the previous step (the rollout's fused audio pair is rebuilt lazily, by its next user).
@@ -178,7 +187,7 @@ class PPO(nn.Module):
                 cpu_rng = torch.get_rng_state()  # capture executes the python once without running kernels: no RNG side effect
                 g = torch.cuda.CUDAGraph()
                 with graphs.capture(g):
-                    self._pol_epoch(next(iter(rollouts_pol.recurrent_generator(gs.adv, 1))), gs.clip, gs.acc)
+                    self._pol_epoch(next(iter(rollouts_pol.recurrent_generator(gs.adv, 1))), gs.clip, gs.acc, prepared=gs.prepared)
                 torch.set_rng_state(cpu_rng)
                 gs.graph, gs.forked = g, graphs.parallel_branches
             torch.randperm(num_envs)        # recurrent_generator's draw (:197); the batch itself is the storage in place
