@@ -439,7 +439,11 @@ class GRUSequence(torch.autograd.Function):
     per step one fused gate-gradient kernel + one recurrent GEMM; the four weight/bias gradients and dx are batched GEMMs."""
 
     @staticmethod
-    def forward(ctx, x, h0, masks, w_ih, w_hh, b_ih, b_hh, T):
+    def forward(ctx, x, h0, masks, w_ih, w_hh, b_ih, b_hh, T, memos=None):
+        """memos: optional (_PackMemo of W_ih, _PackMemo of W_hh): the transposed copies the backward's two input-gradient products read are
+        then kept by the memos and refreshed with every other pack (functional.refresh_pack_memos: one batched launch ahead of an update
+        epoch) instead of being made inside the backward, on its serial chain."""
+        ctx.memos = memos
         N, H = h0.shape
         gi = _lin_nograd(x.contiguous(), w_ih.detach(), b_ih.detach(), "gru.ih")  # [T*N, 3H]
         masks = masks.reshape(T * N).contiguous()
@@ -472,7 +476,10 @@ class GRUSequence(torch.autograd.Function):
         hpm = torch.empty_like(out)
         dhp = torch.empty((N, H), device=dev)
         # W_hh^T as an [H][3H] "Linear" weight for the recurrent dgrad GEMM
-        whh_t = pack_dgrad_weight(w_hh.detach().reshape(3 * H, H, 1, 1).contiguous(), 1, 0).view(H, 3 * H)
+        if ctx.memos is not None:
+            whh_t = ctx.memos[1].get_bwd(w_hh.view(3 * H, H, 1, 1), ("dgrad", 1, 0)).view(H, 3 * H)
+        else:
+            whh_t = pack_dgrad_weight(w_hh.detach().reshape(3 * H, H, 1, 1).contiguous(), 1, 0).view(H, 3 * H)
         fused = N <= ops.GRU_STEP_MAX_ROWS and H % 16 == 0
         dh = g_out[(T - 1) * N:T * N].clone()
         if g_hT is not None:
@@ -509,15 +516,19 @@ class GRUSequence(torch.autograd.Function):
         # batched parameter / input gradients
         M = T * N
         I = x.shape[1]
-        g_wih = conv_wgrad(x.reshape(M, 1, 1, I), None, dgi.view(M, 1, 1, 3 * H), 3 * H, 1, 1, 1, 0) if ctx.needs_input_grad[3] else None
-        g_whh = conv_wgrad(hpm.view(M, 1, 1, H), None, dpre.view(M, 1, 1, 3 * H), 3 * H, 1, 1, 1, 0) if ctx.needs_input_grad[4] else None
+        # (a 1x1 "conv": the packed gradient [3H][K] IS the weight's layout -- written straight into the optimizer's flat gradient buffer)
+        g_wih = conv_wgrad(x.reshape(M, 1, 1, I), None, dgi.view(M, 1, 1, 3 * H), 3 * H, 1, 1, 1, 0, out=grad_slot(w_ih)) if ctx.needs_input_grad[3] else None
+        g_whh = conv_wgrad(hpm.view(M, 1, 1, H), None, dpre.view(M, 1, 1, 3 * H), 3 * H, 1, 1, 1, 0, out=grad_slot(w_hh)) if ctx.needs_input_grad[4] else None
         g_bih = bias_grad(dgi) if ctx.needs_input_grad[5] else None
         g_bhh = bias_grad(dpre) if ctx.needs_input_grad[6] else None
         g_x = None
         if ctx.needs_input_grad[0]:
-            wih_t = pack_dgrad_weight(w_ih.detach().reshape(3 * H, I, 1, 1).contiguous(), 1, 0).view(I, 3 * H)
+            if ctx.memos is not None:
+                wih_t = ctx.memos[0].get_bwd(w_ih.view(3 * H, I, 1, 1), ("dgrad", 1, 0)).view(I, 3 * H)
+            else:
+                wih_t = pack_dgrad_weight(w_ih.detach().reshape(3 * H, I, 1, 1).contiguous(), 1, 0).view(I, 3 * H)
             g_x = _lin_nograd(dgi, wih_t, None, "gru.ih.dgrad")
-        return g_x, g_h0, None, g_wih, g_whh, g_bih, g_bhh, None
+        return g_x, g_h0, None, g_wih, g_whh, g_bih, g_bhh, None, None
 
 
 class PolicyHeads(torch.autograd.Function):

@@ -44,5 +44,7 @@ class RNNStateEncoder(nn.Module):
             h = ops.gru_cell(x.contiguous(), r.weight_ih_l0.detach(), r.bias_ih_l0.detach(), r.weight_hh_l0.detach(), r.bias_hh_l0.detach(),
                              hidden_states[0].contiguous(), masks.reshape(n).contiguous())
             return h, h.unsqueeze(0)
-        out, h = MF.GRUSequence.apply(x, hidden_states[0], masks, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0, t)
+        if getattr(self, "_memo", None) is None:
+            self._memo = [MF._PackMemo(), MF._PackMemo()]      # the transposed weights of the backward's input-gradient products
+        out, h = MF.GRUSequence.apply(x, hidden_states[0], masks, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0, t, self._memo)
         return out, h.unsqueeze(0)
