@@ -14,8 +14,6 @@ get_advantages, load_pretrained_passive_separators, init_distributed).  Mechanis
     (24x fewer U-Net passes, identical numbers); ``cache_separator_outputs=False`` restores the reference schedule.
   * loss scalars are accumulated on the device and read back once per update instead of 3 ``.item()`` per minibatch.
 """
-import os
-
 import torch
 import torch.nn as nn
 
