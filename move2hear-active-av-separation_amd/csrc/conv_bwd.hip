@@ -567,8 +567,24 @@ __global__ __launch_bounds__(256, 3) void wgrad3x3_row_bf16x3_kernel(const WGrad
   }
 }
 
+// Sum of one slab element over the splits [z0, z1): eight running sums (eight loads in flight per lane), combined pairwise -- the ONE
+// order of every many-split reduce below (wgrad_reduce_kernel and the fused re-layout kernels give the same bits).
+__device__ __forceinline__ float wgrad_quarter_sum(const float* __restrict__ src, int z0, int z1, size_t zs) {
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int z = z0;
+  for (; z + 7 < z1; z += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(z + j) * zs];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += v[j];
+  }
+  for (; z < z1; ++z) a[0] += src[(size_t)z * zs];
+  return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
 // dw[n][k] = sum over splits, fixed order.  A block owns 64 consecutive k of one row n; its four waves each sum a quarter of
-// the splits (four loads in flight per lane), then the quarters are combined in wave order.  (One thread per element walking
+// the splits (eight loads in flight per lane: wgrad_quarter_sum), then the quarters are combined in wave order.  (One thread per element walking
 // all splits serially took 39 us for a 32 x 384 gradient with 512 splits: 36 blocks, one dependent load at a time.)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WGradP p) {
   __shared__ float sh[4][64];
@@ -579,17 +595,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WGradP p) {
   const int z0 = (int)(((long)p.S * w) / 4), z1 = (int)(((long)p.S * (w + 1)) / 4);
   const size_t zs = (size_t)p.N * p.Kpad;
   const WPhase wp_ = wgrad_phase(p);
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (k < p.K) {
-    const float* src = p.ws + wp_.ws_off + (size_t)n * p.Kpad + k;
-    int z = z0;
-    for (; z + 3 < z1; z += 4) {
-      const float v0 = src[(size_t)z * zs], v1 = src[(size_t)(z + 1) * zs], v2 = src[(size_t)(z + 2) * zs], v3 = src[(size_t)(z + 3) * zs];
-      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
-    }
-    for (; z < z1; ++z) a0 += src[(size_t)z * zs];
-  }
-  sh[w][lane] = (a0 + a1) + (a2 + a3);
+  float q = 0.f;
+  if (k < p.K) q = wgrad_quarter_sum(p.ws + wp_.ws_off + (size_t)n * p.Kpad + k, z0, z1, zs);
+  sh[w][lane] = q;
   __syncthreads();
   if (w == 0 && k < p.K) (p.quad ? p.dwp + (size_t)blockIdx.y * p.N * p.K : p.dw)[(size_t)n * p.K + k] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
@@ -606,18 +614,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const WGradP p)
     for (int z = 0; z < p.S; ++z) s += ws[((size_t)z * p.N + n) * p.Kpad + k];
     (p.quad ? p.dwp + (size_t)blockIdx.y * p.N * p.K : p.dw)[i] = s;
   }
-}
-
-// Sum of one slab element over the splits [z0, z1) as the reduce kernels above do it: four running sums, combined pairwise.
-__device__ __forceinline__ float wgrad_quarter_sum(const float* __restrict__ src, int z0, int z1, size_t zs) {
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int z = z0;
-  for (; z + 3 < z1; z += 4) {
-    const float v0 = src[(size_t)z * zs], v1 = src[(size_t)(z + 1) * zs], v2 = src[(size_t)(z + 2) * zs], v3 = src[(size_t)(z + 3) * zs];
-    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
-  }
-  for (; z < z1; ++z) a0 += src[(size_t)z * zs];
-  return (a0 + a1) + (a2 + a3);
 }
 
 // The split sum of a 16 x 16 tile of gradient elements, in the order (and so with the bits) of the reduce kernel the launch would

@@ -330,7 +330,7 @@ def wgrad3x3_row_bf16x3(x, dy, splits):
 
 def wgrad_reduce_torch(slabs, Ci, KH, KW):
     """Mirror of conv_wgrad_reduce_torch_kernel (csrc/conv_bwd.hip): the split sum in the reduce kernels' order (S < 16: one running sum;
-    else four quarters of four interleaved running sums, pairwise) and the re-layout packed [n][(tap, c)] -> torch [n][c][kh][kw], channels
+    else four quarters of eight interleaved running sums, pairwise) and the re-layout packed [n][(tap, c)] -> torch [n][c][kh][kw], channels
     from Ci on dropped."""
     S, N, K = slabs.shape
     Ctot = K // (KH * KW)
@@ -343,16 +343,16 @@ def wgrad_reduce_torch(slabs, Ci, KH, KW):
         qs = []
         for w in range(4):
             z0, z1 = (S * w) // 4, (S * (w + 1)) // 4
-            a = [np.zeros((N, K), np.float32) for _ in range(4)]
+            a = [np.zeros((N, K), np.float32) for _ in range(8)]
             z = z0
-            while z + 3 < z1:
-                for j in range(4):
+            while z + 7 < z1:
+                for j in range(8):
                     a[j] = a[j] + sl[z + j]
-                z += 4
+                z += 8
             while z < z1:
                 a[0] = a[0] + sl[z]
                 z += 1
-            qs.append((a[0] + a[1]) + (a[2] + a[3]))
+            qs.append(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])))
         tot = (qs[0] + qs[1]) + (qs[2] + qs[3])
     return np.ascontiguousarray(tot.reshape(N, KH, KW, Ctot)[..., :Ci].transpose(0, 3, 1, 2))
 
