@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--feeder-batch", type=int, default=64)
     ap.add_argument("--no-far-target", action="store_true", help="skip the far-target / mixed-precision DD-PPO leg")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the pair kernel by kernel instead of replaying a HIP graph")
-    ap.add_argument("--ddppo-cycles", type=int, default=2, help="timed DD-PPO cycles (0 = skip); one untimed warm-up cycle precedes them")
+    ap.add_argument("--ddppo-cycles", type=int, default=4, help="timed DD-PPO cycles (0 = skip); two untimed warm-up cycles precede them")
     ap.add_argument("--tail-overlap", action="store_true",
                     help="DD-PPO legs: enqueue the cycle's six update_sep on a second stream beside the last update_pol (overlap_update_tail; measured +0.5 %%: off)")
     ap.add_argument("--sep-update-math", choices=["fp32", "bf16x3"], default="bf16x3",
@@ -297,6 +297,7 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
         tr.actor_critic.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_state_dict(syn.policy_shapes(), 1).items()})
         from m2h.rl.ppo import ddppo_utils
         tr.train_cycle()  # warm-up (allocator, pack caches, lazy optimizer buffers, graph capture)
+        tr.train_cycle()  # ... and a second one: the leg starts after ~15 s of host-only work (the CPU baseline) with the device idle
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

@@ -88,10 +88,10 @@ if os.path.exists(stats):
     rows = list(csv.DictReader(open(stats)))
     launches = sum(int(r["Calls"]) for r in rows)
     ms = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
-    cycles = 3.0   # one warm-up + two timed cycles (bench.py --ddppo-cycles 2); set-up launches are a few hundred of the total
+    cycles = 4.0   # two warm-up + two timed cycles (bench.py --ddppo-cycles 2); set-up launches are a few hundred of the total
     top = [(r["Name"].split("(")[0].replace("void ", ""), int(r["Calls"]), round(float(r["Percentage"]), 2)) for r in rows[:10]]
     summ = {"near_target": {"launches_per_cycle": int(launches / cycles), "kernel_ms_per_cycle": round(ms / cycles, 2), "top10": top,
-                            "source": "profiles/%s_ddppo_kernel_stats.csv (rocprofv3 --kernel-trace --stats, bench.py --ddppo-cycles 2 --no-far-target: three cycles incl. warm-up)" % TAG}}
+                            "source": "profiles/%s_ddppo_kernel_stats.csv (rocprofv3 --kernel-trace --stats, bench.py --ddppo-cycles 2 --no-far-target: four cycles incl. two of warm-up)" % TAG}}
     line = os.path.join(SRC, "ddppo_line.json")   # the cycle time of THAT run: the kernel-time share is computed against it, not against a later run's
     if os.path.exists(line):
         try:
