@@ -489,6 +489,10 @@ int m2h_act_bwd(const float* dy, const float* y, float slope, float* out, size_t
  * workspace: m2h_bias_grad_workspace_bytes(M, N) bytes of device scratch. */
 size_t m2h_bias_grad_workspace_bytes(int M, int N);
 int m2h_bias_grad(const float* dy, float* db, int M, int N, float* workspace, m2h_stream stream);
+/* m2h_act_bwd followed by m2h_bias_grad in one pass over dy: out[m][n] = y[m][n] > 0 ? dy[m][n] : dy[m][n] * slope, db[n] = sum_m out[m][n]
+ * (the same partition and summation order as m2h_bias_grad: the same bits).  The backward of a conv / Linear layer with bias and a fused
+ * ReLU / LeakyReLU (ppo.py:159-161).  workspace: m2h_bias_grad_workspace_bytes(M, N). */
+int m2h_act_bwd_bias(const float* dy, const float* y, float slope, float* out, float* db, int M, int N, float* workspace, m2h_stream stream);
 
 /* GRU backward, one time step (torch.nn.GRU semantics, rnn_state_encoder.py:86-137 under autograd): inputs of
  * m2h_gru_gates plus dh = dL/dh_out; outputs dgi = dL/d(gi), dpre = dL/d(mask*gh_raw + b_hh) (so dL/dgh_raw = mask*dpre,

@@ -863,7 +863,11 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 
 // db[n] = sum_m dy[m][n].  Two ordered stages (deterministic): grid (column blocks of 64, row splits) -> part[split][n],
 // then one thread per column sums the splits.  Lanes walk columns (coalesced 256-byte rows), the 4 waves stride the rows.
-__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dy, float* __restrict__ part, int M, int N, int rows_per_split) {
+// GATE: m2h_act_bwd_bias -- the element is first passed through the activation's backward (y > 0 ? dy : dy * slope) and written to `out`: the
+// same partition and summation order, so db has the bits of m2h_act_bwd followed by m2h_bias_grad, from one pass over dy instead of two.
+template <bool GATE>
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dy, float* __restrict__ part, int M, int N, int rows_per_split,
+                                                                const float* __restrict__ y = nullptr, float slope = 1.f, float* __restrict__ out = nullptr) {
   __shared__ float sh[4][64];
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   const int w = threadIdx.x >> 6;
@@ -871,7 +875,14 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __r
   const int m1 = min(M, m0 + rows_per_split);
   float s = 0.f;
   if (n < N)
-    for (int m = m0 + w; m < m1; m += 4) s += dy[(size_t)m * N + n];
+    for (int m = m0 + w; m < m1; m += 4) {
+      float v = dy[(size_t)m * N + n];
+      if constexpr (GATE) {
+        v = y[(size_t)m * N + n] > 0.f ? v : v * slope;
+        out[(size_t)m * N + n] = v;
+      }
+      s += v;
+    }
   sh[w][threadIdx.x & 63] = s;
   __syncthreads();
   if (w == 0 && n < N) part[(size_t)blockIdx.y * N + n] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
@@ -881,8 +892,10 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __r
 // 32-channel convs): with lanes walking columns only N of 64 lanes work and a wave's load is an N-float run (the head's bias gradient
 // took 82 us for 8 MB).  Here a wave reads 64 consecutive floats = 64 / N whole rows per step (lane l: row l / N, column l % N), four
 // steps in flight, and the lanes of one column meet in a fixed xor butterfly; then the waves in order.
+template <bool GATE>
 __global__ __launch_bounds__(256) void bias_grad_partial_narrow_kernel(const float* __restrict__ dy, float* __restrict__ part, int M, int N,
-                                                                       int rows_per_split) {
+                                                                       int rows_per_split, const float* __restrict__ y = nullptr, float slope = 1.f,
+                                                                       float* __restrict__ out = nullptr) {
   __shared__ float sh[4][32];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int RW = 64 / N;                                   // rows per wave step
@@ -891,11 +904,19 @@ __global__ __launch_bounds__(256) void bias_grad_partial_narrow_kernel(const flo
   const size_t end = (size_t)m1 * N;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   size_t i = ((size_t)m0 + (size_t)w * RW) * N + lane;      // this lane's element; a block step is 4 waves x 64 floats
+  auto gated = [&](size_t j, float v) {
+    if constexpr (GATE) {
+      v = y[j] > 0.f ? v : v * slope;
+      out[j] = v;
+    }
+    return v;
+  };
   for (; i + 3 * 256 < end; i += 4 * 256) {
-    const float a = dy[i], b = dy[i + 256], c = dy[i + 512], d = dy[i + 768];
+    float a = dy[i], b = dy[i + 256], c = dy[i + 512], d = dy[i + 768];
+    a = gated(i, a); b = gated(i + 256, b); c = gated(i + 512, c); d = gated(i + 768, d);
     s0 += a; s1 += b; s2 += c; s3 += d;
   }
-  for (; i < end; i += 256) s0 += dy[i];
+  for (; i < end; i += 256) s0 += gated(i, dy[i]);
   float s = (s0 + s1) + (s2 + s3);
   for (int o = 32; o >= N; o >>= 1) s += __shfl_xor(s, o, 64);
   if (lane < N) sh[w][lane] = s;
@@ -921,6 +942,23 @@ static int bias_grad_splits(int M, int N) {
   if (splits < 1) splits = 1;
   if (M <= 1024) splits = 1;   // a few hundred rows (the update batch's Linear / GRU layers): one stage, straight into db -- no second launch
   return splits;
+}
+
+template <bool GATE>
+static int bias_grad_launch(const float* dy, const float* y, float slope, float* out, float* db, int M, int N, float* workspace, hipStream_t st) {
+  const int splits = bias_grad_splits(M, N);
+  const int rps = (M + splits - 1) / splits;
+  if (splits == 1) {   // the one split's "partial" IS the column sum
+    hipLaunchKernelGGL(bias_grad_partial_kernel<GATE>, dim3((N + 63) / 64, 1), dim3(256), 0, st, dy, db, M, N, rps, y, slope, out);
+    return launch_status(GATE ? "act_bwd_bias" : "bias_grad");
+  }
+  if (N <= 32 && 64 % N == 0) {   // narrow: splits of whole wave steps (64 / N rows); trailing splits may be empty (their partial is 0)
+    const int rw = 64 / N, rps_n = (rps + rw - 1) / rw * rw;
+    hipLaunchKernelGGL(bias_grad_partial_narrow_kernel<GATE>, dim3(1, splits), dim3(256), 0, st, dy, workspace, M, N, rps_n, y, slope, out);
+  } else
+    hipLaunchKernelGGL(bias_grad_partial_kernel<GATE>, dim3((N + 63) / 64, splits), dim3(256), 0, st, dy, workspace, M, N, rps, y, slope, out);
+  hipLaunchKernelGGL(bias_grad_final_kernel, dim3((N + 3) / 4), dim3(256), 0, st, workspace, db, N, splits);
+  return launch_status(GATE ? "act_bwd_bias" : "bias_grad");
 }
 
 }  // namespace m2h
@@ -988,19 +1026,13 @@ size_t m2h_bias_grad_workspace_bytes(int M, int N) {
 
 int m2h_bias_grad(const float* dy, float* db, int M, int N, float* workspace, m2h_stream stream) {
   M2H_REQUIRE(dy && db && workspace && M > 0 && N > 0, "bias_grad: bad arguments");
-  const int splits = bias_grad_splits(M, N);
-  const int rps = (M + splits - 1) / splits;
-  if (splits == 1) {   // the one split's "partial" IS the column sum
-    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, as_stream(stream), dy, db, M, N, rps);
-    return launch_status("bias_grad");
-  }
-  if (N <= 32 && 64 % N == 0) {   // narrow: splits of whole wave steps (64 / N rows); trailing splits may be empty (their partial is 0)
-    const int rw = 64 / N, rps_n = (rps + rw - 1) / rw * rw;
-    hipLaunchKernelGGL(bias_grad_partial_narrow_kernel, dim3(1, splits), dim3(256), 0, as_stream(stream), dy, workspace, M, N, rps_n);
-  } else
-    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, as_stream(stream), dy, workspace, M, N, rps);
-  hipLaunchKernelGGL(bias_grad_final_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), workspace, db, N, splits);
-  return launch_status("bias_grad");
+  return bias_grad_launch<false>(dy, nullptr, 1.f, nullptr, db, M, N, workspace, as_stream(stream));
+}
+
+int m2h_act_bwd_bias(const float* dy, const float* y, float slope, float* out, float* db, int M, int N, float* workspace, m2h_stream stream) {
+  M2H_REQUIRE(dy && y && out && db && workspace && M > 0 && N > 0, "act_bwd_bias: bad arguments");
+  M2H_REQUIRE((size_t)M * N < ((size_t)1 << 40), "act_bwd_bias: tensor too large");
+  return bias_grad_launch<true>(dy, y, slope, out, db, M, N, workspace, as_stream(stream));
 }
 
 }  // extern "C"

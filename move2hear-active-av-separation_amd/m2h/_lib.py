@@ -227,6 +227,7 @@ SIGNATURES = {
     "m2h_act_bwd": [_P, _P, _F, _P, _Z, _P],
     "m2h_bias_grad_workspace_bytes": [_I, _I],
     "m2h_bias_grad": [_P, _P, _I, _I, _P, _P],
+    "m2h_act_bwd_bias": [_P, _P, _F, _P, _P, _I, _I, _P, _P],
     "m2h_sep_slice_input_plane": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "m2h_bn_workspace_bytes": [_I, _I],
     "m2h_bn_train_fwd": [_P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _I, _I, _P, _P],

@@ -168,6 +168,20 @@ def act_bwd(dy, y, slope):
     return out
 
 
+def act_bwd_bias(dy, y, slope):
+    """(act_bwd(dy, y, slope), bias_grad of it) from one pass over dy (m2h_act_bwd_bias); dy, y: [..., N] contiguous."""
+    N = dy.shape[-1]
+    M = dy.numel() // N
+    out = torch.empty_like(dy)
+    db = torch.empty(N, device=dy.device, dtype=torch.float32)
+    lib = _lib.load()
+    with torch.cuda.device(dy.device):
+        ws = torch.empty((lib.m2h_bias_grad_workspace_bytes(M, N) + 3) // 4, device=dy.device, dtype=torch.float32)
+        _lib.check(lib.m2h_act_bwd_bias(ops._ptr(dy), ops._ptr(y), float(slope), ops._ptr(out), ops._ptr(db), M, N, ops._ptr(ws), ops._stream(dy)),
+                   "m2h_act_bwd_bias")
+    return out, db
+
+
 def bias_grad(dy2d):
     M, N = dy2d.shape
     db = torch.empty(N, device=dy2d.device, dtype=torch.float32)
@@ -372,10 +386,14 @@ class Conv2dNHWC(torch.autograd.Function):
         gated = (slope != 1.0 and ctx.needs_input_grad[2] and not need_x and not ctx.needs_input_grad[3] and x2 is None and
                  (KH, KW, stride, pad) == (3, 3, 1, 1) and x.shape[3] == 32 and x.shape[2] == 32 and Co <= 32 and Co % 4 == 0 and
                  x.shape[0] * x.shape[1] >= 512 and not ops.timing_enabled())
+        gb = None
         if slope != 1.0 and not gated:
-            dy = act_bwd(dy, y, slope)
+            if ctx.needs_input_grad[3] and dy.is_contiguous() and y.is_contiguous():
+                dy, gb = act_bwd_bias(dy, y, slope)      # the activation's backward and the bias gradient from one pass over dy
+            else:
+                dy = act_bwd(dy, y, slope)
         B, Ho, Wo, _ = dy.shape
-        gx = gx2 = gw = gb = None
+        gx = gx2 = gw = None
         if ctx.needs_input_grad[2]:
             # the gradient arrives in the weight's own layout [Co, Ci, KH, KW] (split sum + re-layout in one launch)
             slot = grad_slot(w)             # (None unless a FlatAdam owns w: then the kernel writes where the optimizer reads)
@@ -386,7 +404,7 @@ class Conv2dNHWC(torch.autograd.Function):
                     dy = act_bwd(dy, y, slope)
             if gw is None:
                 gw = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, torch_ci=Ci, out=slot)
-        if ctx.needs_input_grad[3]:
+        if ctx.needs_input_grad[3] and gb is None:
             gb = bias_grad(dy.view(B * Ho * Wo, Co))
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             if x2 is not None:

@@ -417,3 +417,19 @@ def test_memory_loss_without_the_desliced_output_equals_the_two_step_form(mode):
         assert torch.equal(a, b)
     want = O.acoustic_mem(sd, mono.cpu(), O.mask_prev_mem(prev.cpu(), nd.cpu()))
     assert abs(out[True][0] - F.l1_loss(want, gt.cpu()[..., 0:1]).item()) < (2e-5 if mode == "bf16x3" else 2e-6)
+
+
+@pytest.mark.parametrize("M,N,slope", [(269080, 32, 0.0), (54880, 64, 0.0), (280, 512, 0.0), (70001, 16, 0.2), (3000, 48, 0.0), (1 << 18, 2, 0.2), (5, 8, 0.0)])
+def test_activation_backward_and_bias_gradient_in_one_pass(M, N, slope):
+    """m2h_act_bwd_bias == m2h_act_bwd followed by m2h_bias_grad, bit for bit (same partition, same summation order), for the column-walking,
+    the narrow and the single-split forms; and == torch."""
+    from m2h import functional as MF
+    dev = _dev()
+    g = torch.Generator().manual_seed(M % 1000 + N)
+    dy, y = torch.randn(M, N, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
+    two = MF.act_bwd(dy, y, slope)
+    db2 = MF.bias_grad(two)
+    one, db1 = MF.act_bwd_bias(dy, y, slope)
+    assert torch.equal(one, two) and torch.equal(db1, db2)
+    want = torch.where(y > 0, dy, dy * slope).double().sum(0)
+    assert (db1.double() - want).abs().max().item() < 2e-6 * max(1.0, torch.where(y > 0, dy, dy * slope).abs().double().sum(0).max().item())
