@@ -714,7 +714,9 @@ static int wgrad_splits(long M, int N, int K, bool row3x3 = false) {
   const long chunks = (M + WM - 1) / WM;
   // one wave front, no tail round: 3 resident blocks per CU for the one-sub-tile kernels (40 / 64 KB LDS, <= 176 VGPRs), 2 for
   // the wide-k ones (196-240 VGPRs); the image-row kernels (one block per split, 46 KB LDS) fill 3 per CU as well
-  const long target = g_wgrad_blocks > 0 ? g_wgrad_blocks : (row3x3 ? 768 : (kt >= 2 ? 512 : 768));
+  // (round 4: 512 for every tiled shape -- at 768 the one-sub-tile kernels' extra splits cost more in slabs and reduce than the third
+  // resident block returned: the pre-training step 2.44 -> 2.41 ms)
+  const long target = g_wgrad_blocks > 0 ? g_wgrad_blocks : (row3x3 ? 768 : 512);
   long S = (target + tiles - 1) / tiles;
   if (S > chunks / 4) S = chunks / 4;   // at least 4 chunks per split
   if (S > 1024) S = 1024;
