@@ -386,11 +386,17 @@ namespace {
 template <int PH, int NWN, int NWK, int MT>
 int launch_small(const SmallP& p, unsigned blocks, size_t lds_bytes, hipStream_t st) {
   auto k = conv_small_kernel<PH, NWN, NWK, MT>;
-  static thread_local size_t granted = 0;    // per instantiation and thread: dynamic LDS above 64 KB needs the attribute once
-  if (lds_bytes > 65536 && lds_bytes > granted) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return fail((int)e, "conv_small: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    granted = 160 * 1024;
+  // dynamic LDS above 64 KB needs the attribute once per instantiation AND DEVICE (hipFuncSetAttribute acts on the current device's
+  // copy of the function); the flags are process-wide and only ever go 0 -> 1 (a racing second set is harmless)
+  static bool granted[64] = {};
+  if (lds_bytes > 65536) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev < 0 || !granted[dev]) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return fail((int)e, "conv_small: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      if (dev >= 0) granted[dev] = true;
+    }
   }
   hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * PH * NWN * NWK), lds_bytes, st, p);
   return launch_status("conv_small");

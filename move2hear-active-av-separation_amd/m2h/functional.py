@@ -397,11 +397,11 @@ class Conv2dNHWC(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             # the gradient arrives in the weight's own layout [Co, Ci, KH, KW] (split sum + re-layout in one launch)
             slot = grad_slot(w)             # (None unless a FlatAdam owns w: then the kernel writes where the optimizer reads)
-            if gated:
-                try:
-                    gw = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, gate=y, gate_slope=slope, torch_ci=Ci, out=slot)
-                except RuntimeError:        # the library refused (image-row kernel switched off: m2h_tuning_set(21, -1)): two passes
-                    dy = act_bwd(dy, y, slope)
+            if gated and ops.tuning_snapshot()[21] < 0:   # the image-row weight-gradient kernel is switched off (m2h_tuning_set(21, -1)): two passes
+                dy = act_bwd(dy, y, slope)
+                gated = False
+            if gated:                       # (any failure of the gated launch is a real error: it is not swallowed)
+                gw = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, gate=y, gate_slope=slope, torch_ci=Ci, out=slot)
             if gw is None:
                 gw = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, torch_ci=Ci, out=slot)
         if ctx.needs_input_grad[3] and gb is None:
@@ -697,6 +697,10 @@ def unit_grad(device):
     device = torch.device(device)
     t = _unit_grads.get(device)
     if t is None:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # a tensor born inside a capture lives in the graph's pool and holds nothing until a replay (and its fill is a graph
+            # node): every capture of this package goes through graphs.capture, which creates it first
+            raise RuntimeError("m2h.unit_grad: first use inside a graph capture; call functional.unit_grad(device) before capturing")
         t = _unit_grads[device] = torch.ones((), device=device)
     return t
 

@@ -18,6 +18,8 @@ def capture(graph, pool=None):
     """torch.cuda.graph with capture_error_mode="thread_local": other threads of the process (RCCL's watchdog polling its
     events, a data feeder) may keep calling into HIP while this thread captures; work the autograd engine's thread enqueues
     on the capturing stream is recorded all the same."""
+    from . import functional
+    functional.unit_grad(torch.device("cuda", torch.cuda.current_device()))   # the cached root gradient must not be born inside a capture
     return torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local")
 
 

@@ -164,6 +164,8 @@ class FlatAdam(torch.optim.Optimizer):
         produced them (no clipping: passive pre-training).  The step count and the learning rate reach the kernel through
         a device buffer: call ``begin_replayed_step()`` on the host before every replay (once per step, however many ranges the graph
         updates), ``end_replayed_step()`` after it."""
+        if len(self.param_groups) != 1:
+            raise RuntimeError("FlatAdam.captured_step: one parameter group only (the captured step reads param_groups[0]'s lr / betas / eps)")
         b0, b1_, idx = self.param_range(params if params is not None else self._ps)
         items = []
         for i in idx:

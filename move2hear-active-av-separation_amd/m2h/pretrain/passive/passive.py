@@ -1,5 +1,5 @@
-"""Agent wrapper of passive pre-training: drop-in for audio_separation/pretrain/passive/passive.py (state_dict root
-``actor_critic.`` of the saved checkpoints)."""
+"""Agent wrapper of passive pre-training: the state_dict root ``actor_critic.`` of the checkpoints that
+audio_separation/pretrain/passive/passive.py saves; the training step itself is PassiveTrainer.train_batch."""
 import torch.nn as nn
 
 
@@ -7,21 +7,3 @@ class Passive(nn.Module):
     def __init__(self, actor_critic):
         super().__init__()
         self.actor_critic = actor_critic
-
-    def forward(self, *x):
-        raise NotImplementedError
-
-    def update(self, rollouts):
-        raise NotImplementedError
-
-    def before_backward(self, loss):
-        pass
-
-    def after_backward(self, loss):
-        pass
-
-    def before_step(self):
-        pass
-
-    def after_step(self):
-        pass

@@ -329,6 +329,7 @@ class PPO(nn.Module):
                         # separator outputs alone: computed once per buffer generation like those outputs
                         cached = self._sep_cache_add_losses(bin_loss, mono_loss)
                 if not graphed:
+                    self._sep_graph = None  # an eager epoch re-binds p.grad: a graph captured earlier would gather stale gradients (as update_pol)
                     self.optimizer_sep.zero_grad()
                     monoFromMem_loss.backward(MF.unit_grad(monoFromMem_loss.device))     # total_loss = monoFromMem_loss (:226)
                 self._reduce_and_step("mem", self.optimizer_sep, last=_e == self.ppo_epoch - 1 and _mb == self.num_mini_batch - 1)

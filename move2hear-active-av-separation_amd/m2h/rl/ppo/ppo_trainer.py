@@ -507,11 +507,12 @@ class PPOTrainer:
         return out
 
     def _drop_graphs(self):
-        """Forget every captured HIP graph (rollout step, update_pol epoch): they hold device addresses of packed weights and
+        """Forget every captured HIP graph (rollout step, update_pol epoch, update_sep epoch): they hold device addresses of packed weights and
         of the arithmetic-mode-specific operand copies, which a weight load or ``ops.set_math_mode`` replaces."""
         self._graph_state = None
         if self.agent is not None:
             self.agent._pol_graph = None
+            self.agent._sep_graph = None
 
     @staticmethod
     def save_switch_checkpoint(path, nav_checkpoint, qual_improv_checkpoint):
