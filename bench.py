@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16X3_TFLOPS = 2500.0 / 3  # dense bf16 MFMA peak over the three products of a bf16x3 product
 PEAK_HBM_GBS = 8000.0
 
 
@@ -238,6 +239,39 @@ def passive_train_cpu_baseline(tm, seconds, batch=8):
                       % (n, batch, tm, threads, os.cpu_count() or 1, el)}
 
 
+def ddppo_phase_rooflines(phase_ms, phase_launches, env_steps_per_cycle, sep_bf16x3, pol_bf16x3):
+    """One roofline object per phase of the cycle, each against what bounds THAT phase, from this run's HIP events and launch counts only.
+    rollout    : T x N env-steps of one frozen U-Net pair + AcousticMem + policy forward at 14 rows: nothing matrix-bound; the floor is
+                 (kernel launches x 2 us, the price of a dependent kernel boundary, MI355X_MICROARCH.md) + (the step's weight set, 157.2 MB
+                 of fp32 -- 33.47 M separator + 5.83 M policy parameters -- streamed once per step at the 6.3 TB/s a copy achieves);
+    update_pol : ppo_epoch x (forward + backward ~ 3 x forward) of the policy over the 280 stored samples, fp32 (or bf16x3) MFMA;
+    update_sep : ppo_epoch x AcousticMem forward + backward over the 1 680 stored samples (separator outputs cached), bf16x3 (or fp32)."""
+    out = {}
+    steps = env_steps_per_cycle
+    if "rollout" in phase_ms:
+        n = phase_launches.get("rollout")
+        stream_ms = steps / 14.0 * 157.2e6 / 6.3e12 * 1e3           # one weight pass per rollout step (14 envs per step)
+        floor = (n * 2e-3 if n else 0.0) + stream_ms
+        out["rollout"] = {"bound": "kernel boundaries + weight stream", "ms_per_cycle": round(phase_ms["rollout"], 3), "m2h_kernel_launches_per_cycle": n,
+                          "weight_stream_ms": round(stream_ms, 3), "launch_floor_ms": round(n * 2e-3, 3) if n else None,
+                          "floor_ms": round(floor, 3), "frac": round(floor / phase_ms["rollout"], 4),
+                          "achieved_weight_GBps": round(steps / 14.0 * 157.2e6 / (phase_ms["rollout"] * 1e-3) / 1e9, 1), "peak_GBps": 6300.0}
+    if "update_pol" in phase_ms:
+        gf = 6 * 4 * 3 * 0.0545 * 280
+        peak = PEAK_BF16X3_TFLOPS if pol_bf16x3 else PEAK_F32_MFMA_TFLOPS
+        ach = gf / phase_ms["update_pol"]
+        out["update_pol"] = {"bound": "mfma", "ms_per_cycle": round(phase_ms["update_pol"], 3), "m2h_kernel_launches_per_cycle": phase_launches.get("update_pol"),
+                             "gflop_per_cycle": round(gf, 1), "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                             "note": "24 epochs of ~170 launches over 280 rows: launch- and latency-bound far below the matrix peak (DESIGN 3.2c)"}
+    if "update_sep" in phase_ms:
+        gf = 24 * 3 * 0.0283 * steps
+        peak = PEAK_BF16X3_TFLOPS if sep_bf16x3 else PEAK_F32_MFMA_TFLOPS
+        ach = gf / phase_ms["update_sep"]
+        out["update_sep"] = {"bound": "mfma", "ms_per_cycle": round(phase_ms["update_sep"], 3), "m2h_kernel_launches_per_cycle": phase_launches.get("update_sep"),
+                             "gflop_per_cycle": round(gf, 1), "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
+    return out
+
+
 def ddppo_roofline(env_steps_per_s_per_job, s_per_cycle, far_target, phase_ms_per_cycle=None):
     """Achieved-fraction object of the DD-PPO leg (BASELINE config 3 / 5).  FLOP figures per env-step: algorithmic = SURVEY 8d's
     reference schedule (13.8 GFLOP: 24 + 2 U-Net pair passes per env-step dominate); executed = what this build runs after the two
@@ -255,25 +289,11 @@ def ddppo_roofline(env_steps_per_s_per_job, s_per_cycle, far_target, phase_ms_pe
            "frac": round(executed * env_steps_per_s_per_job / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
            "note": "per job (all ranks); peak = one GPU's fp32 MFMA peak x n_gpus is the fair ceiling at N > 1"}
     # phase_time_share: the three phases' HIP-event time on the compute stream over this run's own wall time per cycle (both measured
-    # here; what is missing from 1 is host time with an idle device).  Launch counts and summed kernel time cannot be read from inside
-    # the process: the committed rocprofv3 --kernel-trace --stats summary of this same leg is quoted as its own object, with the
-    # share computed against THAT run's cycle time.
+    # here; what is missing from 1 is host time with an idle device).  The per-phase objects (`phases`, ddppo_phase_rooflines) carry
+    # this run's own launch counts and bound every phase by what bounds it; nothing here is read from a committed profile.
     if phase_ms_per_cycle is not None:
         out["phase_ms_per_cycle"] = round(phase_ms_per_cycle, 3)
         out["phase_time_share"] = round(min(1.0, phase_ms_per_cycle / (1e3 * s_per_cycle)), 3)
-    for r in (4, 3):
-        path = os.path.join(ROOT, "profiles", "r%02d_ddppo_summary.json" % r)
-        if os.path.exists(path):
-            with open(path) as f:
-                sj = json.load(f).get("far_target" if far_target else "near_target")
-            if sj:
-                prof = {"launches_per_cycle": sj.get("launches_per_cycle"), "kernel_ms_per_cycle": sj.get("kernel_ms_per_cycle"),
-                        "s_per_cycle": sj.get("s_per_cycle"), "source": sj.get("source")}
-                if sj.get("kernel_ms_per_cycle") and sj.get("s_per_cycle"):
-                    prof["kernel_time_share"] = round(min(1.0, sj["kernel_ms_per_cycle"] / (1e3 * sj["s_per_cycle"])), 3)
-                out["profile"] = prof
-                out["launches_per_cycle"] = sj.get("launches_per_cycle")
-            break
     return out
 
 
@@ -319,13 +339,21 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         # per-cycle phase times on the compute stream and the gradient all-reduces wherever they ran (compute or side stream)
-        phases = {}
+        phases, launches = {}, {}
         for name, e0, e1 in phase_events:
             phases[name] = phases.get(name, 0.0) + e0.elapsed_time(e1)
+            launches[name] = launches.get(name, 0) + (e1.m2h_kernels - e0.m2h_kernels)
+        launches = {k: int(round(v / args.ddppo_cycles)) for k, v in launches.items()}
+        if tail and "update_pol" in launches and "update_sep" in launches:
+            launches["update_pol"] -= launches["update_sep"]   # (the tail's separator updates are enqueued inside the last update_pol's bracket)
         breakdown = {k + "_ms": round(v / args.ddppo_cycles, 3) for k, v in phases.items()}
-        breakdown["grad_allreduce_ms"] = round(sum(e0.elapsed_time(e1) for e0, e1, _b in coll) / args.ddppo_cycles, 3)
+        breakdown["grad_allreduce_ms"] = round(sum(e0.elapsed_time(e1) for e0, e1, _b, _x in coll) / args.ddppo_cycles, 3)
+        # exposed: the all-reduces enqueued on the compute stream (it waits for them before clip + Adam); the others run on the side stream
+        # under the encoders' backward (first bucket of every policy epoch) or under the next phase (the last step of every update)
+        breakdown["grad_allreduce_exposed_ms"] = round(sum(e0.elapsed_time(e1) for e0, e1, _b, x in coll if x) / args.ddppo_cycles, 3)
+        breakdown["grad_allreduce_exposed_count"] = sum(1 for _e0, _e1, _b, x in coll if x) // max(1, args.ddppo_cycles)
         breakdown["grad_allreduce_count"] = len(coll) // max(1, args.ddppo_cycles)
-        breakdown["grad_allreduce_payload_bytes"] = sorted({b for _e0, _e1, b in coll}, reverse=True)
+        breakdown["grad_allreduce_payload_bytes"] = sorted({b for _e0, _e1, b, _x in coll}, reverse=True)
         pol_bytes = tr.agent.optimizer_pol.flat_g.numel() * 4
         breakdown["policy_grad_bytes"] = pol_bytes
         # one stand-alone all-reduce of the policy's flat gradient size, timed alone (RCCL over xGMI when world > 1)
@@ -385,14 +413,18 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
            "launch": ("HIP graphs: the rollout step (one graph per (extra-reward, episode-end) flag pair, one chain) and the update_pol epoch "
                       "(forward + losses + backward; the three encoders as parallel branches, launched onto a drained stream: DESIGN 3.2h) are "
                       "captured once and replayed, and so is the update_sep epoch (one chain); optimizer steps and collectives are enqueued kernel by kernel" if cfg.use_hip_graphs else "kernel by kernel"),
-           "grad_reduce": ("flat-buffer sum all-reduce per backward (RCCL); the last all-reduce + clip + Adam of every update runs on a "
-                           "side stream, fenced at the next reader of those parameters" if world > 1 else "single rank: no collective"),
+           "grad_reduce": ("sum all-reduce (RCCL) of the policy's flat gradient in two buckets per backward: recurrent encoder + heads on a side stream "
+                           "under the encoders' backward, then the encoders' bucket; one flat all-reduce for the acoustic memory; the last all-reduce + "
+                           "clip + Adam of every update runs on the side stream, fenced at the next reader of those parameters" if world > 1 else "single rank: no collective"),
            "separator_output_reuse": "frozen eval-mode U-Net outputs computed once per stored observation and re-used by the 24 "
                                      "update_sep passes and by the next rollout step (result-preserving; SURVEY D13)",
            "last_pol_losses": [round(x, 5) for x in last["pol_losses"]], "last_sep_losses": [round(x, 5) for x in last["sep_losses"]],
            "phases": breakdown, "devices": idents, "distinct_devices": len({(d["uuid"], d["pci_bus_id"]) for d in idents}),
            "roofline": ddppo_roofline(world * steps / el, el / args.ddppo_cycles, far_target,
                                       sum(phases.values()) / args.ddppo_cycles if phases else None)}
+    out["roofline"]["m2h_kernel_launches_per_cycle"] = sum(launches.values()) if launches else None
+    out["roofline"]["phases"] = ddppo_phase_rooflines({k: v / args.ddppo_cycles for k, v in phases.items()}, launches, steps / args.ddppo_cycles,
+                                                      sep_bf16x3=far_target or args.sep_update_math == "bf16x3", pol_bf16x3=far_target)
     del tr
     if with_cpu:   # rank 0 at N = 1 only: the oracle's loop on this host's cores, in this same run (bounded sample)
         out["cpu_baseline"] = ddppo_cpu_baseline(far_target, args.cpu_seconds)
@@ -640,8 +672,8 @@ def main():
 
     def timed_run(mode, steps, warmup, with_events):
         """W untimed + K timed steps of the pair in the given math mode -> (elapsed s, HIP-event sink or None)."""
-        ops.set_math_mode(ops.MATH_BF16X3 if mode == "bf16x3" else ops.MATH_FP32)
-        current_mode[0] = mode
+        ops.set_math_mode({"bf16x3": ops.MATH_BF16X3, "bf16": ops.MATH_BF16}.get(mode, ops.MATH_FP32))
+        current_mode[0] = mode if mode != "bf16" else "bf16x3"   # (the hi-halves-only mode runs the bf16x3 mode's engines)
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
@@ -744,7 +776,7 @@ def main():
         roofline, layers = account(sink, args.steps, args.math)
         evented_ms = round(1e3 * ev_elapsed / args.steps, 3)
         roofline["evented_pass_ms_per_step"] = evented_ms
-    other_mode, parity = None, None
+    other_mode, parity, bf16_mode = None, None, None
     if not args.no_other_mode:
         o_steps = max(2, args.steps // 3)
         o_elapsed, _ = timed_run(other, o_steps, 1, False)
@@ -766,7 +798,25 @@ def main():
         }
         parity = {"what": "rel-L1 of the bf16x3 result against the fp32-MFMA result on the benchmark batch (contract: 1e-3 vs the reference)",
                   "pred_bin": rel(m_b * em, m_a * em), "pred_mono": rel(mono_b, mono_a)}
-        del m_a, m_b, mono_a, mono_b, em
+        # BASELINE config 2's literal dtype, a REPORTED mode (never `value`): one bf16 product per product (the hi halves of the same
+        # split32 tensors: include/m2h.h M2H_MATH_BF16), with its distance from the fp32 result and whether that holds the contract
+        b_elapsed, _ = timed_run("bf16", o_steps, 1, False)
+        ops.set_math_mode(ops.MATH_BF16)
+        m_c, mono_c = (t.clone() for t in step())
+        ops.set_math_mode(ops.MATH_FP32)
+        e_bin, e_mono = rel(m_c * em, m_a * em), rel(mono_c, mono_a)
+        gflop = 0.4226 * (args.tm / 32.0) * args.batch * world
+        bf16_mode = {
+            "math": "bf16 (single product: hi*hi of the bf16 hi halves, fp32 accumulate; tensors stay split32, so this engine still moves both halves)",
+            "value": round(world * args.batch * o_steps / b_elapsed, 1), "unit": "spectrograms/s", "steps": o_steps,
+            "ms_per_step": round(1e3 * b_elapsed / o_steps, 3),
+            "rel_l1_vs_fp32": {"pred_bin": e_bin, "pred_mono": e_mono}, "contract": 1e-3,
+            "within_contract": bool(e_bin <= 1e-3 and e_mono <= 1e-3),
+            "roofline": {"bound": "mfma", "achieved": round(gflop * o_steps / b_elapsed / 1e3, 2), "peak": PEAK_BF16, "unit": "TFLOP/s",
+                         "frac": round(gflop * o_steps / b_elapsed / 1e3 / PEAK_BF16, 4)},
+            "note": "reported mode only: the headline `value` is the bf16x3 arithmetic, which holds the fp32 contract by two orders of magnitude",
+        }
+        del m_a, m_b, mono_a, mono_b, m_c, mono_c, em
     ops.set_math_mode(ops.MATH_FP32)
 
     # the host-core baselines are single-GPU-run figures (rank 0, N = 1); the pair's comes first: its probe picks the thread count
@@ -800,6 +850,7 @@ def main():
                               "HIP graph: the step's kernels (20 convs -- the first of each U-Net with the input slice fused in --, the split-K reduces of the deep stages) captured once per arithmetic mode, replayed every step (m2h.graphs)")},
         "roofline": roofline,
         "other_math_mode": other_mode,
+        "other_math_modes": [m for m in (other_mode, bf16_mode) if m is not None],
         "math_mode_parity": parity,
         "ddppo": ddppo,
         "ddppo_far_target": ddppo_far,

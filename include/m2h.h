@@ -133,7 +133,14 @@ int m2h_conv_igemm_f32(const m2h_conv_args* args /* host */, m2h_stream stream);
  * may pin their arithmetic there (M2H_FMT_MATH_*, m2h_unet_weights.math_mode) and then ignore this. */
 #define M2H_MATH_FP32 0
 #define M2H_MATH_BF16X3 1
+#define M2H_MATH_BF16 2 /* BASELINE config 2's literal dtype, a REPORTED mode (bench.py other_math_modes), never the default: every dispatch
+                          decision as M2H_MATH_BF16X3, but the split32 engines of the benchmark batch (csrc/conv_patch.hip, conv_dma.hip,
+                          conv_strip.hip) multiply the bf16 hi halves only -- one MFMA product per product instead of three; operands,
+                          accumulation and outputs unchanged (fp32 sums, split32 tensors).  Other engines compute bf16x3. */
 int m2h_set_math_mode(int mode);
+/* Diagnostic: kernels this process has enqueued (or captured into a HIP graph) through libm2h so far.  bench.py's per-phase launch
+ * counts (a replayed graph counts its captured kernels once per replay, on the host side: m2h/graphs.py). */
+long long m2h_launch_count(void);
 int m2h_get_math_mode(void);
 
 /* Bytes of split-K scratch the launch described by args would use (0 = the grid already fills the chip).

@@ -120,7 +120,7 @@ extern "C" int m2h_acoustic_mem_small_fwd(const float* pred_mono, const float* p
                                           const float* w1p, float* out, int B, int F, int T, m2h_stream stream) {
   M2H_REQUIRE(pred_mono && prev_mem && w0p && w1p && out, "acoustic_mem_small: null pointer");
   M2H_REQUIRE(B > 0 && F == 512 && T == 32, "acoustic_mem_small: built for [B, 512, 32, 1] spectrograms (got %d x %d)", F, T);
-  hipLaunchKernelGGL(m2h::acoustic_mem_small_kernel, dim3(B * (32 / m2h::MEM_R)), dim3(256), 0, m2h::as_stream(stream), pred_mono, prev_mem,
+  M2H_LAUNCH(m2h::acoustic_mem_small_kernel, dim3(B * (32 / m2h::MEM_R)), dim3(256), 0, m2h::as_stream(stream), pred_mono, prev_mem,
                      not_done, w0p, w1p, out, B);
   return m2h::launch_status("acoustic_mem_small");
 }

@@ -15,6 +15,7 @@ thread_local Tuning tl_tuning = {};   // every knob 0 = automatic (m2h_internal.
 // default: measured at parity with the tiled engines (274 vs 282 us per separator pair at 14 envs), kept for the tests and
 // further tuning
 extern thread_local int tl_math_mode;
+extern thread_local int tl_hi_only;
 }  // namespace m2h
 
 using namespace m2h;
@@ -39,12 +40,15 @@ const char* m2h_last_kernel(void) { return tl_last_launch; }
 const char* m2h_unet_fwd_stage_kernel(int stage) { return (stage >= 0 && stage < 11) ? tl_unet_stage[stage] : ""; }
 
 int m2h_set_math_mode(int mode) {
-  M2H_REQUIRE(mode == M2H_MATH_FP32 || mode == M2H_MATH_BF16X3, "set_math_mode: mode must be M2H_MATH_FP32 or M2H_MATH_BF16X3");
-  tl_math_mode = mode;
+  M2H_REQUIRE(mode == M2H_MATH_FP32 || mode == M2H_MATH_BF16X3 || mode == M2H_MATH_BF16, "set_math_mode: mode must be M2H_MATH_FP32, M2H_MATH_BF16X3 or M2H_MATH_BF16");
+  tl_math_mode = mode == M2H_MATH_FP32 ? 0 : 1;
+  tl_hi_only = mode == M2H_MATH_BF16 ? 1 : 0;
   return 0;
 }
 
-int m2h_get_math_mode(void) { return tl_math_mode; }
+long long m2h_launch_count(void) { return m2h::g_launch_count.load(std::memory_order_relaxed); }
+
+int m2h_get_math_mode(void) { return tl_hi_only ? M2H_MATH_BF16 : tl_math_mode; }
 
 int m2h_tuning_set(int knob, int value) {
   if (knob == 14) return m2h_set_math_mode(value);   // (kept for older callers; thread-local like the rest)

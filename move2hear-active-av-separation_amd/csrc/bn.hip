@@ -210,11 +210,11 @@ int m2h_bn_train_fwd(const float* z, const float* gamma, const float* beta, floa
   const int splits = bn_splits(M, C);
   const int rps = (M + splits - 1) / splits;
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, z, workspace, M, C, rps);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, splits, C, eps, momentum, mean, invstd,
+  M2H_LAUNCH(bn_stats_partial_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, z, workspace, M, C, rps);
+  M2H_LAUNCH(bn_stats_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, splits, C, eps, momentum, mean, invstd,
                      running_mean, running_var);
   const size_t n4 = (size_t)M * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, z, mean, invstd, gamma, beta, slope, y, n4, C / 4);
+  M2H_LAUNCH(bn_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, z, mean, invstd, gamma, beta, slope, y, n4, C / 4);
   return launch_status("bn_train_fwd");
 }
 
@@ -225,10 +225,10 @@ int m2h_bn_train_bwd(const float* dy, const float* y, const float* z, const floa
   const int splits = bn_splits(M, C);
   const int rps = (M + splits - 1) / splits;
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, y, z, mean, invstd, slope, workspace, M, C, rps);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, splits, C, dgamma, dbeta);
+  M2H_LAUNCH(bn_bwd_partial_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, y, z, mean, invstd, slope, workspace, M, C, rps);
+  M2H_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, splits, C, dgamma, dbeta);
   const size_t n4 = (size_t)M * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, dgamma, dbeta, slope,
+  M2H_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, y, z, mean, invstd, gamma, dgamma, dbeta, slope,
                      1.f / (float)M, dz, n4, C / 4);
   return launch_status("bn_train_bwd");
 }

@@ -780,40 +780,40 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
     p.chunks = a.B * a.Hq;   // image rows
     if (p.S > p.chunks) p.S = p.chunks;
     if (tl_math_mode == 1) {           // the calling thread computes in bf16x3 (update_sep with sep_update_math, the far-target leg)
-      if (a.N <= 16) hipLaunchKernelGGL((wgrad3x3_row_bf16x3_kernel<16>), dim3((unsigned)p.S), blk, 0, st, p);
-      else hipLaunchKernelGGL((wgrad3x3_row_bf16x3_kernel<32>), dim3((unsigned)p.S), blk, 0, st, p);
-    } else if (a.N <= 16) hipLaunchKernelGGL((wgrad3x3_row_kernel<16>), dim3((unsigned)p.S), blk, 0, st, p);
-    else hipLaunchKernelGGL((wgrad3x3_row_kernel<32>), dim3((unsigned)p.S), blk, 0, st, p);
-  } else if (bng == 128) hipLaunchKernelGGL((wgrad_kernel<128, 1, 2>), grid, blk, 0, st, p);
-  else if (bng == 64 && kt == 2) hipLaunchKernelGGL((wgrad_kernel<64, 2, 1>), grid, blk, 0, st, p);
-  else if (bng == 64) hipLaunchKernelGGL((wgrad_kernel<64, 1, 2>), grid, blk, 0, st, p);
-  else if (kt == 1) hipLaunchKernelGGL((wgrad_kernel<32, 1, 2>), grid, blk, 0, st, p);
-  else if (kt == 2) hipLaunchKernelGGL((wgrad_kernel<32, 2, 1>), grid, blk, 0, st, p);
-  else hipLaunchKernelGGL((wgrad_kernel<32, 3, 1>), grid, blk, 0, st, p);
+      if (a.N <= 16) M2H_LAUNCH((wgrad3x3_row_bf16x3_kernel<16>), dim3((unsigned)p.S), blk, 0, st, p);
+      else M2H_LAUNCH((wgrad3x3_row_bf16x3_kernel<32>), dim3((unsigned)p.S), blk, 0, st, p);
+    } else if (a.N <= 16) M2H_LAUNCH((wgrad3x3_row_kernel<16>), dim3((unsigned)p.S), blk, 0, st, p);
+    else M2H_LAUNCH((wgrad3x3_row_kernel<32>), dim3((unsigned)p.S), blk, 0, st, p);
+  } else if (bng == 128) M2H_LAUNCH((wgrad_kernel<128, 1, 2>), grid, blk, 0, st, p);
+  else if (bng == 64 && kt == 2) M2H_LAUNCH((wgrad_kernel<64, 2, 1>), grid, blk, 0, st, p);
+  else if (bng == 64) M2H_LAUNCH((wgrad_kernel<64, 1, 2>), grid, blk, 0, st, p);
+  else if (kt == 1) M2H_LAUNCH((wgrad_kernel<32, 1, 2>), grid, blk, 0, st, p);
+  else if (kt == 2) M2H_LAUNCH((wgrad_kernel<32, 2, 1>), grid, blk, 0, st, p);
+  else M2H_LAUNCH((wgrad_kernel<32, 3, 1>), grid, blk, 0, st, p);
   int rc = launch_status("conv_wgrad");
   if (rc) return rc;
   if (quad) {   // split sum + scatter to the torch layout in one launch
     const long gu = (long)p.N * ((p.Ctot + 15) / 16);
     M2H_REQUIRE(gu < 0x7fffffffL, "convT_wgrad: unpack grid too large");
-    if (p.S >= 16) hipLaunchKernelGGL(convT_wgrad_reduce_unpack_kernel<true>, dim3((unsigned)gu), dim3(1024), 0, st, p);
-    else hipLaunchKernelGGL(convT_wgrad_reduce_unpack_kernel<false>, dim3((unsigned)gu), dim3(256), 0, st, p);
+    if (p.S >= 16) M2H_LAUNCH(convT_wgrad_reduce_unpack_kernel<true>, dim3((unsigned)gu), dim3(1024), 0, st, p);
+    else M2H_LAUNCH(convT_wgrad_reduce_unpack_kernel<false>, dim3((unsigned)gu), dim3(256), 0, st, p);
     return launch_status("convT_wgrad reduce + unpack");
   }
   if (torch_ci > 0) {   // split sum + re-layout to [N][Ci][KH][KW] in one launch
     const long gt = (long)p.N * ((torch_ci + 15) / 16);
     M2H_REQUIRE(gt < 0x7fffffffL, "conv_wgrad: reduce grid too large");
-    if (p.S >= 16) hipLaunchKernelGGL(conv_wgrad_reduce_torch_kernel<true>, dim3((unsigned)gt), dim3(1024), 0, st, p);
-    else hipLaunchKernelGGL(conv_wgrad_reduce_torch_kernel<false>, dim3((unsigned)gt), dim3(256), 0, st, p);
+    if (p.S >= 16) M2H_LAUNCH(conv_wgrad_reduce_torch_kernel<true>, dim3((unsigned)gt), dim3(1024), 0, st, p);
+    else M2H_LAUNCH(conv_wgrad_reduce_torch_kernel<false>, dim3((unsigned)gt), dim3(256), 0, st, p);
     return launch_status("conv_wgrad reduce (torch layout)");
   }
   if (p.S >= 16) {
     const long g = (long)p.N * ((p.K + 63) / 64);
     M2H_REQUIRE(g < 0x7fffffffL, "conv_wgrad: reduce grid too large");
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g, (unsigned)phases), dim3(256), 0, st, p);
+    M2H_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)g, (unsigned)phases), dim3(256), 0, st, p);
   } else {
     size_t g = ((size_t)p.N * p.K + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)g, (unsigned)phases), dim3(256), 0, st, p);
+    M2H_LAUNCH(wgrad_reduce_small_kernel, dim3((unsigned)g, (unsigned)phases), dim3(256), 0, st, p);
   }
   return launch_status("conv_wgrad reduce");
 }
@@ -951,15 +951,15 @@ static int bias_grad_launch(const float* dy, const float* y, float slope, float*
   const int splits = bias_grad_splits(M, N);
   const int rps = (M + splits - 1) / splits;
   if (splits == 1) {   // the one split's "partial" IS the column sum
-    hipLaunchKernelGGL(bias_grad_partial_kernel<GATE>, dim3((N + 63) / 64, 1), dim3(256), 0, st, dy, db, M, N, rps, y, slope, out);
+    M2H_LAUNCH(bias_grad_partial_kernel<GATE>, dim3((N + 63) / 64, 1), dim3(256), 0, st, dy, db, M, N, rps, y, slope, out);
     return launch_status(GATE ? "act_bwd_bias" : "bias_grad");
   }
   if (N <= 32 && 64 % N == 0) {   // narrow: splits of whole wave steps (64 / N rows); trailing splits may be empty (their partial is 0)
     const int rw = 64 / N, rps_n = (rps + rw - 1) / rw * rw;
-    hipLaunchKernelGGL(bias_grad_partial_narrow_kernel<GATE>, dim3(1, splits), dim3(256), 0, st, dy, workspace, M, N, rps_n, y, slope, out);
+    M2H_LAUNCH(bias_grad_partial_narrow_kernel<GATE>, dim3(1, splits), dim3(256), 0, st, dy, workspace, M, N, rps_n, y, slope, out);
   } else
-    hipLaunchKernelGGL(bias_grad_partial_kernel<GATE>, dim3((N + 63) / 64, splits), dim3(256), 0, st, dy, workspace, M, N, rps, y, slope, out);
-  hipLaunchKernelGGL(bias_grad_final_kernel, dim3((N + 3) / 4), dim3(256), 0, st, workspace, db, N, splits);
+    M2H_LAUNCH(bias_grad_partial_kernel<GATE>, dim3((N + 63) / 64, splits), dim3(256), 0, st, dy, workspace, M, N, rps, y, slope, out);
+  M2H_LAUNCH(bias_grad_final_kernel, dim3((N + 3) / 4), dim3(256), 0, st, workspace, db, N, splits);
   return launch_status(GATE ? "act_bwd_bias" : "bias_grad");
 }
 
@@ -1001,7 +1001,7 @@ int m2h_pack_dgrad_weight(const float* w, float* wp, int Co, int Ci, int KH, int
   const size_t total = (size_t)Co * Ci * KH * KW;
   size_t g = (total + 255) / 256;
   if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), w, wp, Co, Ci, KH, KW, stride, pad);
+  M2H_LAUNCH(pack_dgrad_weight_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), w, wp, Co, Ci, KH, KW, stride, pad);
   return launch_status("pack_dgrad_weight");
 }
 
@@ -1009,7 +1009,7 @@ int m2h_unpack_convT_wgrad(const float* dwp, float* dw, int Ci, int Co, m2h_stre
   M2H_REQUIRE(dwp && dw && Ci > 0 && Co > 0, "unpack_convT_wgrad: bad arguments");
   size_t g = ((size_t)16 * Co * Ci + 255) / 256;
   if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(unpack_convT_wgrad_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), dwp, dw, Ci, Co);
+  M2H_LAUNCH(unpack_convT_wgrad_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), dwp, dw, Ci, Co);
   return launch_status("unpack_convT_wgrad");
 }
 
@@ -1017,7 +1017,7 @@ int m2h_act_bwd(const float* dy, const float* y, float slope, float* out, size_t
   M2H_REQUIRE(dy && y && out && n > 0, "act_bwd: bad arguments");
   size_t g = (n + 255) / 256;
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), dy, y, slope, out, n);
+  M2H_LAUNCH(act_bwd_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), dy, y, slope, out, n);
   return launch_status("act_bwd");
 }
 

@@ -274,8 +274,10 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
       for (int mi = mi0; mi < mi1; ++mi)
 #pragma unroll
         for (int ni = 0; ni < FN; ++ni) {
-          mfma(f.al[mi], f.bh[ni], acc[mi][ni]);
-          mfma(f.ah[mi], f.bl[ni], acc[mi][ni]);
+          if constexpr (DBG != 9) {
+            mfma(f.al[mi], f.bh[ni], acc[mi][ni]);
+            mfma(f.ah[mi], f.bl[ni], acc[mi][ni]);
+          }
           mfma(f.ah[mi], f.bh[ni], acc[mi][ni]);
         }
     };
@@ -339,8 +341,10 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_dma_kernel(const IGemmP
       for (int mi = decltype(lo)::value; mi < decltype(hi)::value; ++mi) {
         // the weights as the A operand (rows = channels), the pixels as B (columns): a lane ends up with four consecutive
         // channels of one pixel (igemm_common.h nhwc_tile_store_T); same products, same k order, same sums
-        mfma(bh[ni], al[mi], acc[mi][ni]);
-        mfma(bl[ni], ah[mi], acc[mi][ni]);
+        if constexpr (DBG != 9) {
+          mfma(bh[ni], al[mi], acc[mi][ni]);
+          mfma(bl[ni], ah[mi], acc[mi][ni]);
+        }
         mfma(bh[ni], ah[mi], acc[mi][ni]);
       }
     };
@@ -459,15 +463,16 @@ static int launch_dma_cfg(IGemmP& p, int S, hipStream_t st) {
   p.pmaj = p.convT ? 1 : 0;
   const dim3 grid((unsigned)(nblk * phases), (unsigned)S, 1);
 #ifdef M2H_CLOCK_DIAG
-  if (g_dma == 3) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 3>), grid, dim3(64 * WM * WN), 0, st, p);
-  else if (g_dma == 4) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 4>), grid, dim3(64 * WM * WN), 0, st, p);
-  else if (g_dma == 5) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 5>), grid, dim3(64 * WM * WN), 0, st, p);
-  else if (g_dma == 6) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 6>), grid, dim3(64 * WM * WN), 0, st, p);
-  else if (g_dma == 7) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 7>), grid, dim3(64 * WM * WN), 0, st, p);
-  else if (g_dma == 8) hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 8>), grid, dim3(64 * WM * WN), 0, st, p);
+  if (g_dma == 3) M2H_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 3>), grid, dim3(64 * WM * WN), 0, st, p);
+  else if (g_dma == 4) M2H_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 4>), grid, dim3(64 * WM * WN), 0, st, p);
+  else if (g_dma == 5) M2H_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 5>), grid, dim3(64 * WM * WN), 0, st, p);
+  else if (g_dma == 6) M2H_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 6>), grid, dim3(64 * WM * WN), 0, st, p);
+  else if (g_dma == 7) M2H_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 7>), grid, dim3(64 * WM * WN), 0, st, p);
+  else if (g_dma == 8) M2H_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 8>), grid, dim3(64 * WM * WN), 0, st, p);
   else
 #endif
-  hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, NST, FR>), grid, dim3(64 * WM * WN), 0, st, p);
+  if (p.hi_only) M2H_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, NST, FR, 9>), grid, dim3(64 * WM * WN), 0, st, p);   // M2H_MATH_BF16: hi x hi only
+  else M2H_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, NST, FR>), grid, dim3(64 * WM * WN), 0, st, p);
   return launch_status(BM == 256 && BN == 128 ? "igemm_dma<256,128>" : "igemm_dma");
 }
 

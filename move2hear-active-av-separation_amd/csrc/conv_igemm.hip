@@ -1167,6 +1167,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const IGemmP p) {
 // (tuning knob g_phase_major: thread-local, m2h_internal.h) -1: transposed-conv phases as grid z (four passes over the input) instead of interleaved
 static constexpr int M2H_FMT_LAYOUT_BITS = M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT | M2H_FMT_DST_SPLIT;   // operand_format minus the M2H_FMT_MATH_* bits
 thread_local int tl_math_mode = 0;   // m2h_set_math_mode: the calling thread's arithmetic (0 fp32 MFMA, 1 bf16x3 split products)
+std::atomic<long long> g_launch_count{0};   // M2H_LAUNCH (m2h_internal.h)
+thread_local int tl_hi_only = 0;     // m2h_set_math_mode(M2H_MATH_BF16): tl_math_mode = 1 for every dispatch decision, and the engines listed in m2h.h drop the two cross products
 // (tuning knob g_tapshare: thread-local, m2h_internal.h) -1: never use the tap-sharing transposed-conv kernel
 // (tuning knob g_tap_bm: thread-local, m2h_internal.h) 128: 128-output tiles only in the tap-sharing kernel
 // (tuning knob g_fast_loader: thread-local, m2h_internal.h) -1: always use the generic (per-lane k decode) loader
@@ -1290,9 +1292,9 @@ static int launch_big(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   p.pmaj = (p.convT && g_phase_major >= 0) ? 1 : 0;
   dim3 grid((unsigned)(p.pmaj ? nblk * 4 : nblk), 1, p.pmaj ? 1 : phases);
   if (p.presplit)
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, 4, 2, 2, 32, 1, 2>), grid, dim3(512), 0, st, p);
+    M2H_LAUNCH((igemm_f32_kernel<BM, BN, 4, 2, 2, 32, 1, 2>), grid, dim3(512), 0, st, p);
   else
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, 4, 2, 2, 32, 1, 1>), grid, dim3(512), 0, st, p);
+    M2H_LAUNCH((igemm_f32_kernel<BM, BN, 4, 2, 2, 32, 1, 1>), grid, dim3(512), 0, st, p);
   return launch_status("igemm_f32<256,128> (eight waves)");
 }
 
@@ -1310,20 +1312,20 @@ static int launch_cfg(IGemmP& p, size_t ws_bytes, hipStream_t st) {
   dim3 grid((unsigned)(p.pmaj ? nblk * 4 : nblk), (unsigned)p.S, p.pmaj ? 1 : phases);
   const dim3 blk(64 * WM * WN);
   if (fast && p.math == 1 && p.presplit)
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1, 2>), grid, blk, (size_t)g_extra_lds, st, p);
+    M2H_LAUNCH((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1, 2>), grid, blk, (size_t)g_extra_lds, st, p);
   else if (fast && p.math == 1)
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1, 1>), grid, blk, (size_t)g_extra_lds, st, p);
+    M2H_LAUNCH((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1, 1>), grid, blk, (size_t)g_extra_lds, st, p);
   else if (fast)
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1>), grid, blk, (size_t)g_extra_lds, st, p);
+    M2H_LAUNCH((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 1>), grid, blk, (size_t)g_extra_lds, st, p);
   else
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 0>), grid, blk, (size_t)g_extra_lds, st, p);
+    M2H_LAUNCH((igemm_f32_kernel<BM, BN, WM, WN, NSTAGE, FR, 0>), grid, blk, (size_t)g_extra_lds, st, p);
   static const std::string label = "igemm_f32<" + std::to_string(BM) + "," + std::to_string(BN) + ">";   // one per instantiation
   int rc = launch_status(label.c_str());
   if (rc != 0 || p.S == 1) return rc;
   const long total = (long)p.M * (p.N >> 2);
   long g = (total + 255) / 256;
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g, phases), dim3(256), 0, st, p);
+  M2H_LAUNCH(splitk_epilogue_kernel, dim3((unsigned)g, phases), dim3(256), 0, st, p);
   static const std::string label_sk = label + " + split-K reduce";
   rc = launch_status("conv_igemm_f32 split-K epilogue");
   tl_last_launch = label_sk.c_str();
@@ -1341,7 +1343,7 @@ static int launch_splitk_reduce(const IGemmP& p, hipStream_t st) {
   const long total = (long)p.M * (p.N >> 2);
   long g = (total + 255) / 256;
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g, p.convT ? 4 : 1), dim3(256), 0, st, p);
+  M2H_LAUNCH(splitk_epilogue_kernel, dim3((unsigned)g, p.convT ? 4 : 1), dim3(256), 0, st, p);
   return launch_status("conv_igemm_f32 split-K epilogue");
 }
 
@@ -1414,6 +1416,7 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
     M2H_REQUIRE((fmt & (M2H_FMT_MATH_BF16X3 | M2H_FMT_MATH_FP32)) != (M2H_FMT_MATH_BF16X3 | M2H_FMT_MATH_FP32),
                 "conv_igemm: operand_format names both arithmetic modes");
     p.math = (fmt & M2H_FMT_MATH_BF16X3) ? 1 : (fmt & M2H_FMT_MATH_FP32) ? 0 : tl_math_mode;
+    p.hi_only = (p.math == 1 && tl_hi_only) ? 1 : 0;
     M2H_REQUIRE((fmt & (M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT | M2H_FMT_DST_SPLIT)) == 0 || p.math == 1,
                 "conv_igemm: split32 operands need the bf16x3 math mode");
     const int both = M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT;
@@ -1479,9 +1482,9 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
       const dim3 grid((unsigned)nblk), blk(wave8 ? 512 : 256);
 #define M2H_TAP_P(BN_, FR_, PRE_)                                                                                  \
   do {                                                                                                             \
-    if (wave8) hipLaunchKernelGGL((convT_tap_kernel<BN_, FR_, PRE_, (BN_ <= 32 ? 512 : 256), 8>), grid, blk, 0, st, p); \
-    else if (big) hipLaunchKernelGGL((convT_tap_kernel<BN_, FR_, PRE_, 256>), grid, blk, 0, st, p);               \
-    else hipLaunchKernelGGL((convT_tap_kernel<BN_, FR_, PRE_, 128>), grid, blk, 0, st, p);                        \
+    if (wave8) M2H_LAUNCH((convT_tap_kernel<BN_, FR_, PRE_, (BN_ <= 32 ? 512 : 256), 8>), grid, blk, 0, st, p); \
+    else if (big) M2H_LAUNCH((convT_tap_kernel<BN_, FR_, PRE_, 256>), grid, blk, 0, st, p);               \
+    else M2H_LAUNCH((convT_tap_kernel<BN_, FR_, PRE_, 128>), grid, blk, 0, st, p);                        \
   } while (0)
 #define M2H_TAP(BN_, FR_)                       \
   do {                                          \
@@ -1512,8 +1515,8 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
       const dim3 grid((unsigned)(phases * (wide ? (a.N + 15) / 16 : (a.N + 3) / 4))), blk(64 * nw);
 #define M2H_SKINNY_ROWS(NW_)                                                                       \
   do {                                                                                             \
-    if (wide) hipLaunchKernelGGL((skinny_rows_kernel<16, NW_>), grid, blk, 0, st, p);              \
-    else hipLaunchKernelGGL((skinny_rows_kernel<4, NW_>), grid, blk, 0, st, p);                    \
+    if (wide) M2H_LAUNCH((skinny_rows_kernel<16, NW_>), grid, blk, 0, st, p);              \
+    else M2H_LAUNCH((skinny_rows_kernel<4, NW_>), grid, blk, 0, st, p);                    \
   } while (0)
       if (nw == 4) M2H_SKINNY_ROWS(4);
       else if (nw == 8) M2H_SKINNY_ROWS(8);
@@ -1530,9 +1533,9 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
     p.MT = (int)((M + 15) / 16);
     const long blocks = (long)phases * (a.N / 16) * ((p.MT + 1) / 2);
     const int nw = skinny_waves(p.Kw / 16);
-    if (nw == 4) hipLaunchKernelGGL((skinny_gather_kernel<2, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-    else if (nw == 8) hipLaunchKernelGGL((skinny_gather_kernel<2, 8>), dim3((unsigned)blocks), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((skinny_gather_kernel<2, 16>), dim3((unsigned)blocks), dim3(1024), 0, st, p);
+    if (nw == 4) M2H_LAUNCH((skinny_gather_kernel<2, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else if (nw == 8) M2H_LAUNCH((skinny_gather_kernel<2, 8>), dim3((unsigned)blocks), dim3(512), 0, st, p);
+    else M2H_LAUNCH((skinny_gather_kernel<2, 16>), dim3((unsigned)blocks), dim3(1024), 0, st, p);
     return launch_status("conv_igemm_f32 (skinny gather)");
   }
   // 3x3 / stride 1 / pad 1 over 16- or 32-channel, 32-pixel-wide images in fp32 math, many rows (AcousticMem in update_sep)
@@ -1543,10 +1546,10 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
       (a.out_mode == M2H_OUT_NHWC || a.N % 16 == 0)) {
     const long chunks = (long)a.B * (a.Hq / 4);
     const dim3 grid((unsigned)(chunks < 512 ? chunks : 512)), blk(256);
-    if (a.N <= 16 && a.C0 == 32) hipLaunchKernelGGL((conv3x3_row_kernel<16, 32>), grid, blk, 0, st, p);
-    else if (a.N <= 16) hipLaunchKernelGGL((conv3x3_row_kernel<16, 16>), grid, blk, 0, st, p);
-    else if (a.C0 == 32) hipLaunchKernelGGL((conv3x3_row_kernel<32, 32>), grid, blk, 0, st, p);
-    else hipLaunchKernelGGL((conv3x3_row_kernel<32, 16>), grid, blk, 0, st, p);
+    if (a.N <= 16 && a.C0 == 32) M2H_LAUNCH((conv3x3_row_kernel<16, 32>), grid, blk, 0, st, p);
+    else if (a.N <= 16) M2H_LAUNCH((conv3x3_row_kernel<16, 16>), grid, blk, 0, st, p);
+    else if (a.C0 == 32) M2H_LAUNCH((conv3x3_row_kernel<32, 32>), grid, blk, 0, st, p);
+    else M2H_LAUNCH((conv3x3_row_kernel<32, 16>), grid, blk, 0, st, p);
     return launch_status("conv_igemm_f32 (image-row 3x3)");
   }
   // the same image-row shapes in bf16x3 math (update_sep with sep_update_math / the far-target leg): split operands in LDS, bf16 MFMAs
@@ -1558,9 +1561,9 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
     const long chunks = (long)a.B * (a.Hq / 4);
     const long cap = (a.N > 16 && a.C0 == 32) ? 512 : 768;      // resident blocks: two / three per CU (LDS)
     const dim3 grid((unsigned)(chunks < cap ? chunks : cap)), blk(256);
-    if (a.N <= 16) hipLaunchKernelGGL((conv3x3_row_bf16x3_kernel<16, 32>), grid, blk, 0, st, p);
-    else if (a.C0 == 32) hipLaunchKernelGGL((conv3x3_row_bf16x3_kernel<32, 32>), grid, blk, 0, st, p);
-    else hipLaunchKernelGGL((conv3x3_row_bf16x3_kernel<32, 16>), grid, blk, 0, st, p);
+    if (a.N <= 16) M2H_LAUNCH((conv3x3_row_bf16x3_kernel<16, 32>), grid, blk, 0, st, p);
+    else if (a.C0 == 32) M2H_LAUNCH((conv3x3_row_bf16x3_kernel<32, 32>), grid, blk, 0, st, p);
+    else M2H_LAUNCH((conv3x3_row_bf16x3_kernel<32, 16>), grid, blk, 0, st, p);
     return launch_status("conv_igemm_bf16x3 (image-row 3x3)");
   }
   // bf16x3 math, wide N, enough work for one 256 x 128 tile per CU: eight waves (4 x 2 wave tiles of 64 x 64) share one staged

@@ -89,7 +89,7 @@ struct PatchCfg {
 // are the MFMA's A operand, so a lane holds four consecutive channels of one pixel; v_permlane16_swap pairs two fragments into
 // 16-byte pieces of the split32 row).  Stores count in vmcnt in issue order with the DMAs: the two waits that follow an epilogue
 // are for DMAs OLDER than its stores and leave the stores in flight too (+ PST); the third wait is for a DMA issued after them.
-template <int WM, int WN, int WHOLE, int CONVT, int DBG>   // CONVT: a transposed-conv phase (one class per tile); DBG (diagnostic builds only): 4 no MFMAs, 5 no loads, 6 no loads and no k-loop barrier, 7 no k-loop barrier
+template <int WM, int WN, int WHOLE, int CONVT, int DBG>   // CONVT: a transposed-conv phase (one class per tile); DBG: 9 = the bf16 hi halves only (M2H_MATH_BF16); diagnostic builds only: 4 no MFMAs, 5 no loads, 6 no loads and no k-loop barrier, 7 no k-loop barrier
 __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p, const PatchGeo g, const int ntiles) {
   using Cfg = PatchCfg<WM, WN, WHOLE>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, A_BYTES = Cfg::A_BYTES, B_BYTES = Cfg::B_BYTES;
@@ -345,8 +345,10 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
     constexpr int ni = decltype(nic)::value;
 #pragma unroll
     for (int mi = decltype(lo)::value; mi < decltype(hi)::value; ++mi) {
-      mfma(bh[ni], al[mi], acc[mi][ni]);
-      mfma(bl[ni], ah[mi], acc[mi][ni]);
+      if constexpr (DBG != 9) {   // (9: M2H_MATH_BF16, the hi halves only)
+        mfma(bh[ni], al[mi], acc[mi][ni]);
+        mfma(bl[ni], ah[mi], acc[mi][ni]);
+      }
       mfma(bh[ni], ah[mi], acc[mi][ni]);
     }
   };
@@ -626,15 +628,17 @@ static int launch_patch_cfg(IGemmP& p, const PatchGeo& g, int S, hipStream_t st)
   const dim3 grid((unsigned)gx, (unsigned)S), blk(64 * PNW);
   const int ntiles = (int)nblk;
 #ifdef M2H_CLOCK_DIAG
-  if (p.convT) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 1, 0>), grid, blk, 0, st, p, g, ntiles);   // (the diagnostic variants are built for convs)
-  else if (g_patch == 4) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 0, 4>), grid, blk, 0, st, p, g, ntiles);
-  else if (g_patch == 5) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 0, 5>), grid, blk, 0, st, p, g, ntiles);
-  else if (g_patch == 6) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 0, 6>), grid, blk, 0, st, p, g, ntiles);
-  else if (g_patch == 7) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 0, 7>), grid, blk, 0, st, p, g, ntiles);
+  if (p.convT) M2H_LAUNCH((igemm_patch_kernel<WM, WN, WHOLE, 1, 0>), grid, blk, 0, st, p, g, ntiles);   // (the diagnostic variants are built for convs)
+  else if (g_patch == 4) M2H_LAUNCH((igemm_patch_kernel<WM, WN, WHOLE, 0, 4>), grid, blk, 0, st, p, g, ntiles);
+  else if (g_patch == 5) M2H_LAUNCH((igemm_patch_kernel<WM, WN, WHOLE, 0, 5>), grid, blk, 0, st, p, g, ntiles);
+  else if (g_patch == 6) M2H_LAUNCH((igemm_patch_kernel<WM, WN, WHOLE, 0, 6>), grid, blk, 0, st, p, g, ntiles);
+  else if (g_patch == 7) M2H_LAUNCH((igemm_patch_kernel<WM, WN, WHOLE, 0, 7>), grid, blk, 0, st, p, g, ntiles);
   else
 #endif
-  if (p.convT) hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 1, 0>), grid, blk, 0, st, p, g, ntiles);
-  else hipLaunchKernelGGL((igemm_patch_kernel<WM, WN, WHOLE, 0, 0>), grid, blk, 0, st, p, g, ntiles);
+  if (p.hi_only && p.convT) M2H_LAUNCH((igemm_patch_kernel<WM, WN, WHOLE, 1, 9>), grid, blk, 0, st, p, g, ntiles);
+  else if (p.hi_only) M2H_LAUNCH((igemm_patch_kernel<WM, WN, WHOLE, 0, 9>), grid, blk, 0, st, p, g, ntiles);
+  else if (p.convT) M2H_LAUNCH((igemm_patch_kernel<WM, WN, WHOLE, 1, 0>), grid, blk, 0, st, p, g, ntiles);
+  else M2H_LAUNCH((igemm_patch_kernel<WM, WN, WHOLE, 0, 0>), grid, blk, 0, st, p, g, ntiles);
   return launch_status(BN == 64 ? "igemm_patch<512,64>" : S == 2 ? "igemm_patch<256,128> (two K-halves)" : "igemm_patch<256,128>");
 }
 

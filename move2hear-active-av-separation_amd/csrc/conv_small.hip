@@ -398,7 +398,7 @@ int launch_small(const SmallP& p, unsigned blocks, size_t lds_bytes, hipStream_t
       if (dev >= 0) granted[dev] = true;
     }
   }
-  hipLaunchKernelGGL(k, dim3(blocks), dim3(64 * PH * NWN * NWK), lds_bytes, st, p);
+  M2H_LAUNCH(k, dim3(blocks), dim3(64 * PH * NWN * NWK), lds_bytes, st, p);
   return launch_status("conv_small");
 }
 }  // namespace

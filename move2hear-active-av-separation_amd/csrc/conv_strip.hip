@@ -33,6 +33,8 @@
 
 namespace m2h {
 
+extern thread_local int tl_hi_only;   // conv_igemm.hip: M2H_MATH_BF16
+
 // (tuning knob g_strip: thread-local, m2h_internal.h) m2h_tuning_set 35: -1 = the runner never takes the strip-walker kernels (A/B against the tiled engines)
 
 #ifndef M2H_STRIP_DEPTH
@@ -114,7 +116,7 @@ struct StripConv1P {
   float slope;
 };
 
-template <bool MASKED>
+template <bool MASKED, bool HI = false>   // HI: the bf16 hi halves only (M2H_MATH_BF16)
 __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p) {
   constexpr int ROW = 2 * PLANE;   // a row slot: even-column plane, odd-column plane
   __shared__ __attribute__((aligned(1024))) char s_ring[4 * ROW];
@@ -281,8 +283,10 @@ __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p
             if constexpr (M2H_STRIP_DBG == 1) {
               acc[mt] += a.l + a.h + Bh[tap] + Bl[tap];
             } else {
-              acc[mt] = mfma16(Bh[tap], a.l, acc[mt]);   // rows = this wave's channels, columns = the fragment's pixels
-              acc[mt] = mfma16(Bl[tap], a.h, acc[mt]);
+              if constexpr (!HI) {
+                acc[mt] = mfma16(Bh[tap], a.l, acc[mt]);   // rows = this wave's channels, columns = the fragment's pixels
+                acc[mt] = mfma16(Bl[tap], a.h, acc[mt]);
+              }
               acc[mt] = mfma16(Bh[tap], a.h, acc[mt]);
             }
           }
@@ -362,8 +366,10 @@ int launch_strip_conv1(const float* mix, const float* masks, const void* wreg, c
   p.B = B; p.T = T; p.Wq = T / 2; p.strips = p.Wq / SW; p.jobs = B * p.strips; p.slope = slope;
   p.jobs_padded = (B + 7) / 8 * 8 * p.strips;
   const int grid = p.jobs_padded < 512 ? p.jobs_padded : 512;   // a multiple of 8 (strip_job)
-  if (masks != nullptr) hipLaunchKernelGGL((conv1_strip_kernel<true>), dim3(grid), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((conv1_strip_kernel<false>), dim3(grid), dim3(256), 0, st, p);
+  if (tl_hi_only && masks != nullptr) M2H_LAUNCH((conv1_strip_kernel<true, true>), dim3(grid), dim3(256), 0, st, p);
+  else if (tl_hi_only) M2H_LAUNCH((conv1_strip_kernel<false, true>), dim3(grid), dim3(256), 0, st, p);
+  else if (masks != nullptr) M2H_LAUNCH((conv1_strip_kernel<true>), dim3(grid), dim3(256), 0, st, p);
+  else M2H_LAUNCH((conv1_strip_kernel<false>), dim3(grid), dim3(256), 0, st, p);
   return launch_status(masks != nullptr ? "strip_conv1<masked>" : "strip_conv1");
 }
 
@@ -394,7 +400,7 @@ struct StripLastP {
   float slope;
 };
 
-template <int N>
+template <int N, bool HI = false>   // HI: the bf16 hi halves only (M2H_MATH_BF16), head included
 __global__ __launch_bounds__(N * 16, 2) void convT_last_strip_kernel(const StripLastP p) {
   constexpr int NT = N / 16, NW = 4 * NT, NTH = 64 * NW;
   constexpr int Cc = N / 16;                 // output channels after the de-slice
@@ -534,8 +540,10 @@ __global__ __launch_bounds__(N * 16, 2) void convT_last_strip_kernel(const Strip
             const int c = g - DEPTH;
             const int t = c >> 1, mt = c & 1;
             const Frag& a = f[c % (DEPTH + 1)];
-            acc[mt] = mfma16(Bh[t], a.l, acc[mt]);   // rows = this wave's channels, columns = the fragment's positions
-            acc[mt] = mfma16(Bl[t], a.h, acc[mt]);
+            if constexpr (!HI) {
+              acc[mt] = mfma16(Bh[t], a.l, acc[mt]);   // rows = this wave's channels, columns = the fragment's positions
+              acc[mt] = mfma16(Bl[t], a.h, acc[mt]);
+            }
             acc[mt] = mfma16(Bh[t], a.h, acc[mt]);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -570,8 +578,10 @@ __global__ __launch_bounds__(N * 16, 2) void convT_last_strip_kernel(const Strip
         for (int hn = 0; hn < NT; ++hn) {
           const f32x4 bh = s_wh[(hn * 2 + 0) * 64 + lane], bl = s_wh[(hn * 2 + 1) * 64 + lane];
           z[hn] = *reinterpret_cast<const f32x4*>(s_cst + 2 * N + hn * 16 + 4 * kg);   // head bias of rows c * 16 + s, s = 4 kg + j
-          z[hn] = mfma16(bh, al, z[hn]);   // rows = head outputs c * 16 + s (c = hn), columns = positions
-          z[hn] = mfma16(bl, ah, z[hn]);
+          if constexpr (!HI) {
+            z[hn] = mfma16(bh, al, z[hn]);   // rows = head outputs c * 16 + s (c = hn), columns = positions
+            z[hn] = mfma16(bl, ah, z[hn]);
+          }
           z[hn] = mfma16(bh, ah, z[hn]);
         }
         // lane: position 16 mt + m -> output column 2 position + pw; rows s = 4 kg + j of run (s, ph)
@@ -633,8 +643,10 @@ __global__ __launch_bounds__(N * 16, 2) void convT_last_strip_kernel(const Strip
 }
 
 int launch_strip_last(const StripLastP& p, int N, hipStream_t st) {
-  if (N == 32) hipLaunchKernelGGL((convT_last_strip_kernel<32>), dim3(p.jobs_padded < 256 ? p.jobs_padded : 256), dim3(512), 0, st, p);
-  else hipLaunchKernelGGL((convT_last_strip_kernel<16>), dim3(p.jobs_padded < 512 ? p.jobs_padded : 512), dim3(256), 0, st, p);
+  if (tl_hi_only && N == 32) M2H_LAUNCH((convT_last_strip_kernel<32, true>), dim3(p.jobs_padded < 256 ? p.jobs_padded : 256), dim3(512), 0, st, p);
+  else if (tl_hi_only) M2H_LAUNCH((convT_last_strip_kernel<16, true>), dim3(p.jobs_padded < 512 ? p.jobs_padded : 512), dim3(256), 0, st, p);
+  else if (N == 32) M2H_LAUNCH((convT_last_strip_kernel<32>), dim3(p.jobs_padded < 256 ? p.jobs_padded : 256), dim3(512), 0, st, p);
+  else M2H_LAUNCH((convT_last_strip_kernel<16>), dim3(p.jobs_padded < 512 ? p.jobs_padded : 512), dim3(256), 0, st, p);
   return launch_status(N == 32 ? "strip_convT_last<32>" : "strip_convT_last<16>");
 }
 
@@ -654,7 +666,7 @@ size_t m2h_strip_conv1_weight_bytes(void) { return (size_t)4 * 16 * 2 * 64 * 16;
 
 int m2h_pack_strip_conv1(const float* w, int Ci, void* out, m2h_stream stream) {
   M2H_REQUIRE(w && out && Ci >= 32, "pack_strip_conv1: bad arguments");
-  hipLaunchKernelGGL(pack_strip_conv1_kernel, dim3(32), dim3(256), 0, as_stream(stream), w, Ci, static_cast<f32x4*>(out));
+  M2H_LAUNCH(pack_strip_conv1_kernel, dim3(32), dim3(256), 0, as_stream(stream), w, Ci, static_cast<f32x4*>(out));
   return launch_status("pack_strip_conv1");
 }
 

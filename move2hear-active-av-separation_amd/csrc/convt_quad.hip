@@ -381,8 +381,8 @@ int launch_convT_quad(IGemmP& p, hipStream_t st) {
   const dim3 grid((unsigned)(per * 8 * p.NT)), blk(512);
   // without a head the tile leaves through nhwc_tile_store_T: whole NHWC rows, 16-byte pieces
   const bool plain = p.head_w == nullptr && p.out_mode == M2H_OUT_NHWC && p.N % 4 == 0 && p.ldc % 4 == 0 && (reinterpret_cast<size_t>(p.dst) & 15) == 0;
-  if (plain) hipLaunchKernelGGL((convT_quad_kernel<32, false>), grid, blk, 0, st, p);
-  else hipLaunchKernelGGL((convT_quad_kernel<32, true>), grid, blk, 0, st, p);
+  if (plain) M2H_LAUNCH((convT_quad_kernel<32, false>), grid, blk, 0, st, p);
+  else M2H_LAUNCH((convT_quad_kernel<32, true>), grid, blk, 0, st, p);
   return launch_status(p.N > 32 ? "igemm_convT_quad<64>" : "igemm_convT_quad<32>");
 }
 

@@ -133,7 +133,7 @@ static int launch_fftconv(const float* mono, const float* rirs, const float* tw,
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail((int)e, "fftconv_same: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(kern, dim3(CS, 2), dim3(1024), lds, st, mono, rirs, reinterpret_cast<const cf*>(tw), reinterpret_cast<cf*>(xspec), full, L, Lr);
+  M2H_LAUNCH(kern, dim3(CS, 2), dim3(1024), lds, st, mono, rirs, reinterpret_cast<const cf*>(tw), reinterpret_cast<cf*>(xspec), full, L, Lr);
   return launch_status("fftconv_same");
 }
 

@@ -34,6 +34,7 @@ struct IGemmP {
   const float* head_b;
   int fast_ok; // scalar-decode loader applicable (host check)
   int math;      // arithmetic of this launch: 0 fp32 MFMA, 1 bf16x3 split products (args' M2H_FMT_MATH_* or the calling thread's mode)
+  int hi_only;   // M2H_MATH_BF16 (the calling thread's mode): the split32 engines of the benchmark batch multiply the bf16 hi halves only (one product of the three)
   int presplit;  // both operands arrive in the split32 layout
   int dst_split; // epilogue writes dst in the split32 layout (bf16x3 math, NHWC, N % 32 == 0)
   int wq_sh, hq_sh;   // log2 of Wq / Hq when they are powers of two, else -1 (decode_row)

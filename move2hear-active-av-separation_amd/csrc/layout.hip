@@ -222,7 +222,7 @@ extern "C" {
 
 int m2h_split32(const float* src, float* dst, size_t count, m2h_stream stream) {
   M2H_REQUIRE(src != nullptr && dst != nullptr && src != dst && count > 0 && count % 32 == 0, "split32: bad arguments (count %% 32, out of place)");
-  hipLaunchKernelGGL(split32_kernel, dim3(grid_for(count / 4, 256, 256 * 16)), dim3(256), 0, as_stream(stream), src, dst, count / 4);
+  M2H_LAUNCH(split32_kernel, dim3(grid_for(count / 4, 256, 256 * 16)), dim3(256), 0, as_stream(stream), src, dst, count / 4);
   return launch_status("split32");
 }
 
@@ -233,12 +233,12 @@ int m2h_sep_slice_input_fmt(const float* mix, const float* masks, float* out, in
   M2H_REQUIRE((16 * C) % 4 == 0, "sep_slice_input: 16*C must be a multiple of 4");
   const long nblk = (long)B * (F / 16) * ((T + 63) / 64);
   if (C == 2 && T % 2 == 0 && nblk <= 0x7fffffffL) {
-    hipLaunchKernelGGL(sep_slice_input_c2_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), mix, masks, out, B, F, T, split_out);
+    M2H_LAUNCH(sep_slice_input_c2_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), mix, masks, out, B, F, T, split_out);
     return launch_status("sep_slice_input");
   }
   M2H_REQUIRE(!split_out, "sep_slice_input: split32 output needs C == 2 and an even T");
   const size_t total = (size_t)B * (F / 16) * T * (16 * C / 4);
-  hipLaunchKernelGGL(sep_slice_input_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, as_stream(stream), mix, masks, out, B, F, T, C);
+  M2H_LAUNCH(sep_slice_input_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, as_stream(stream), mix, masks, out, B, F, T, C);
   return launch_status("sep_slice_input");
 }
 
@@ -250,7 +250,7 @@ int m2h_sep_slice_input_plane(const float* mix, const float* cls_val, float* out
   M2H_REQUIRE(mix && cls_val && out && B > 0 && F > 0 && T > 0 && C > 0 && F % 16 == 0, "sep_slice_input_plane: bad arguments");
   M2H_REQUIRE(ldo >= 16 * C + 1 && ldo % 4 == 0, "sep_slice_input_plane: ldo must be a multiple of 4 and > 16*C");
   const size_t total = (size_t)B * (F / 16) * T * (ldo / 4);
-  hipLaunchKernelGGL(sep_slice_input_plane_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, as_stream(stream), mix, cls_val, out, B, F, T, C, ldo);
+  M2H_LAUNCH(sep_slice_input_plane_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, as_stream(stream), mix, cls_val, out, B, F, T, C, ldo);
   return launch_status("sep_slice_input_plane");
 }
 
@@ -258,7 +258,7 @@ int m2h_pack_conv_weight_ex(const float* w, float* wp, int Co, int Ci, int KH, i
   M2H_REQUIRE(w != nullptr && wp != nullptr, "pack_conv_weight: null pointer");
   M2H_REQUIRE(Co > 0 && Ci > 0 && KH > 0 && KW > 0 && ci_used > 0 && ci_used <= Ci && ci_out >= ci_used, "pack_conv_weight: bad sizes");
   const size_t total = (size_t)Co * KH * KW * ci_out;
-  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w, wp, Co, Ci, KH, KW, ci_used, ci_out);
+  M2H_LAUNCH(pack_conv_weight_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w, wp, Co, Ci, KH, KW, ci_used, ci_out);
   return launch_status("pack_conv_weight");
 }
 
@@ -270,14 +270,14 @@ int m2h_pack_convT_weight(const float* w, float* wp, int Ci, int Co, m2h_stream 
   M2H_REQUIRE(w != nullptr && wp != nullptr, "pack_convT_weight: null pointer");
   M2H_REQUIRE(Co > 0 && Ci > 0, "pack_convT_weight: bad sizes");
   const size_t total = (size_t)16 * Co * Ci;
-  hipLaunchKernelGGL(pack_convT_weight_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w, wp, Ci, Co);
+  M2H_LAUNCH(pack_convT_weight_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w, wp, Ci, Co);
   return launch_status("pack_convT_weight");
 }
 
 int m2h_unet_class_table(const float* w, float* table, int Co, int Ci, int plane, m2h_stream stream) {
   M2H_REQUIRE(w != nullptr && table != nullptr, "unet_class_table: null pointer");
   M2H_REQUIRE(Co > 0 && Ci > 0 && plane >= 0 && plane < Ci, "unet_class_table: bad sizes");
-  hipLaunchKernelGGL(unet_class_table_kernel, dim3((9 * Co + 255) / 256), dim3(256), 0, as_stream(stream), w, table, Co, Ci, plane);
+  M2H_LAUNCH(unet_class_table_kernel, dim3((9 * Co + 255) / 256), dim3(256), 0, as_stream(stream), w, table, Co, Ci, plane);
   return launch_status("unet_class_table");
 }
 
@@ -285,7 +285,7 @@ int m2h_fold_bn(const float* gamma, const float* beta, const float* mean, const 
                 float* shift, int C, m2h_stream stream) {
   M2H_REQUIRE(gamma && beta && mean && var && scale && shift, "fold_bn: null pointer");
   M2H_REQUIRE(C > 0, "fold_bn: bad size");
-  hipLaunchKernelGGL(fold_bn_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), gamma, beta, mean, var, eps, scale, shift, C);
+  M2H_LAUNCH(fold_bn_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), gamma, beta, mean, var, eps, scale, shift, C);
   return launch_status("fold_bn");
 }
 

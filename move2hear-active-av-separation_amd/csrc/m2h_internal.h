@@ -1,6 +1,7 @@
 // Internal helpers shared by the libm2h translation units (not part of the C-ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 
@@ -56,6 +57,15 @@ extern thread_local Tuning tl_tuning;
 // Label of the calling thread's most recent kernel launch (the `what` of launch_status: every launch site names its kernel family):
 // read back by m2h_last_kernel / m2h_unet_fwd_stage_kernel, so that benchmark tables name the kernel that really ran.
 extern thread_local const char* tl_last_launch;
+
+// Every kernel launch of the library goes through M2H_LAUNCH: it counts (m2h_launch_count: the kernels this process enqueued or
+// captured through libm2h -- a diagnostic for bench.py's per-phase launch figures, never read by the product path).
+extern std::atomic<long long> g_launch_count;
+#define M2H_LAUNCH(...)                                                      \
+  do {                                                                       \
+    ::m2h::g_launch_count.fetch_add(1, std::memory_order_relaxed);           \
+    hipLaunchKernelGGL(__VA_ARGS__);                                         \
+  } while (0)
 
 // Launch errors: sticky error is consumed so that a later call does not inherit it.
 inline int launch_status(const char* what) {

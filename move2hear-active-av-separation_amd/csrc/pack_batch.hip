@@ -133,6 +133,6 @@ extern "C" int m2h_pack_batch(const m2h_pack_item* items, int n_items, m2h_strea
     blocks += (unsigned)n_mid * (unsigned)((n_outer + PACK_TILE - 1) / PACK_TILE);
   }
   a.first_block[n_items] = blocks;
-  hipLaunchKernelGGL(pack_batch_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a);
+  M2H_LAUNCH(pack_batch_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a);
   return launch_status("pack_batch");
 }

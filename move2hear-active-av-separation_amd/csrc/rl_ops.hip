@@ -1004,21 +1004,21 @@ int m2h_slice_concat_input(const float* a, int Ca, const float* b, int Cb, const
   M2H_REQUIRE(op >= 0 && op <= 2 && (op != 1 || mul != nullptr), "slice_concat_input: bad op");
   M2H_REQUIRE(B > 0 && F > 0 && T > 0 && F % 16 == 0, "slice_concat_input: bad sizes (F %% 16)");
   const size_t total = (size_t)B * (F / 16) * T * (16 * (Ca + Cb) / 4);
-  hipLaunchKernelGGL(slice_concat_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), a, Ca, b, Cb, mul, bscale, op, out, B, F, T);
+  M2H_LAUNCH(slice_concat_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), a, Ca, b, Cb, mul, bscale, op, out, B, F, T);
   return launch_status("slice_concat_input");
 }
 
 int m2h_visual_input(const float* rgb, const float* depth, float* out, int B, int H, int W, m2h_stream stream) {
   M2H_REQUIRE(rgb != nullptr && out != nullptr && B > 0 && H > 0 && W > 0, "visual_input: bad arguments");
   const size_t npix = (size_t)B * H * W;
-  hipLaunchKernelGGL(visual_input_kernel, dim3(grid_for(npix)), dim3(256), 0, as_stream(stream), rgb, depth, out, npix);
+  M2H_LAUNCH(visual_input_kernel, dim3(grid_for(npix)), dim3(256), 0, as_stream(stream), rgb, depth, out, npix);
   return launch_status("visual_input");
 }
 
 int m2h_gru_gates(const float* gi, const float* gh_raw, const float* bhh, const float* hprev, const float* mask, float* hout,
                   int M, int H, m2h_stream stream) {
   M2H_REQUIRE(gi && gh_raw && bhh && hprev && hout && M > 0 && H > 0, "gru_gates: bad arguments");
-  hipLaunchKernelGGL(gru_gates_kernel, dim3(grid_for((size_t)M * H)), dim3(256), 0, as_stream(stream), gi, gh_raw, bhh, hprev, mask, hout, M, H);
+  M2H_LAUNCH(gru_gates_kernel, dim3(grid_for((size_t)M * H)), dim3(256), 0, as_stream(stream), gi, gh_raw, bhh, hprev, mask, hout, M, H);
   return launch_status("gru_gates");
 }
 
@@ -1027,7 +1027,7 @@ int m2h_gru_step(const float* gi, const float* whh, const float* bhh, const floa
   M2H_REQUIRE(gi && whh && bhh && hprev && gh_raw && hout, "gru_step: null pointer");
   M2H_REQUIRE(M > 0 && M <= GRU_E && H > 0 && H % 16 == 0, "gru_step: needs 1 <= M <= %d rows and H %% 16 == 0 (got M=%d, H=%d)",
               GRU_E, M, H);
-  hipLaunchKernelGGL(gru_step_kernel, dim3(H / GRU_U), dim3(64 * GS_NW), 0, as_stream(stream), gi, whh, bhh, hprev, mask, gh_raw, hout, M, H);
+  M2H_LAUNCH(gru_step_kernel, dim3(H / GRU_U), dim3(64 * GS_NW), 0, as_stream(stream), gi, whh, bhh, hprev, mask, gh_raw, hout, M, H);
   return launch_status("gru_step");
 }
 
@@ -1036,7 +1036,7 @@ int m2h_gru_cell(const float* x, const float* wih, const float* bih, const float
   M2H_REQUIRE(x && wih && bih && whh && bhh && hprev && hout, "gru_cell: null pointer");
   M2H_REQUIRE(M > 0 && M <= GRU_E && H > 0 && H % 16 == 0 && I > 0 && I % 16 == 0,
               "gru_cell: needs 1 <= M <= %d rows, H %% 16 == 0 and I %% 16 == 0 (got M=%d, I=%d, H=%d)", GRU_E, M, I, H);
-  hipLaunchKernelGGL(gru_cell_kernel, dim3(H / GRU_U), dim3(64 * GC_NW), 0, as_stream(stream), x, wih, bih, whh, bhh, hprev, mask, hout, M, I, H);
+  M2H_LAUNCH(gru_cell_kernel, dim3(H / GRU_U), dim3(64 * GC_NW), 0, as_stream(stream), x, wih, bih, whh, bhh, hprev, mask, hout, M, I, H);
   return launch_status("gru_cell");
 }
 
@@ -1045,7 +1045,7 @@ int m2h_policy_heads(const float* feats, const float* Wa, const float* ba, const
                      int M, int H, int A, m2h_stream stream) {
   M2H_REQUIRE(feats && Wa && ba && Wc && bc && value && logp_all && probs && entropy, "policy_heads: null pointer");
   M2H_REQUIRE(M > 0 && H > 0 && H % 64 == 0 && A > 0 && A <= 8, "policy_heads: bad sizes (H %% 64, A <= 8)");
-  hipLaunchKernelGGL(policy_heads_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), feats, Wa, ba, Wc, bc, actions, value,
+  M2H_LAUNCH(policy_heads_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), feats, Wa, ba, Wc, bc, actions, value,
                      logp_all, probs, entropy, logp_act, M, H, A);
   return launch_status("policy_heads");
 }
@@ -1055,27 +1055,27 @@ int m2h_policy_heads_act(const float* feats, const float* Wa, const float* ba, c
                          int A, m2h_stream stream) {
   M2H_REQUIRE(feats && Wa && ba && Wc && bc && value && logp_all && probs && entropy && actions && logp_act, "policy_heads_act: null pointer");
   M2H_REQUIRE(M > 0 && H > 0 && H % 64 == 0 && A > 0 && A <= 8, "policy_heads_act: bad sizes (H %% 64, A <= 8)");
-  hipLaunchKernelGGL(policy_heads_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), feats, Wa, ba, Wc, bc,
+  M2H_LAUNCH(policy_heads_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), feats, Wa, ba, Wc, bc,
                      static_cast<const long long*>(nullptr), value, logp_all, probs, entropy, logp_act, M, H, A, noise, actions);
   return launch_status("policy_heads_act");
 }
 
 int m2h_sample_actions(const float* probs, const float* noise, long long* actions, int M, int A, m2h_stream stream) {
   M2H_REQUIRE(probs && noise && actions && M > 0 && A > 0 && A <= 64, "sample_actions: bad arguments");
-  hipLaunchKernelGGL(sample_actions_kernel, dim3((M + 255) / 256), dim3(256), 0, as_stream(stream), probs, noise, actions, M, A);
+  M2H_LAUNCH(sample_actions_kernel, dim3((M + 255) / 256), dim3(256), 0, as_stream(stream), probs, noise, actions, M, A);
   return launch_status("sample_actions");
 }
 
 int m2h_gather_logp(const float* logp_all, const long long* actions, float* out, int M, int A, m2h_stream stream) {
   M2H_REQUIRE(logp_all && actions && out && M > 0 && A > 0, "gather_logp: bad arguments");
-  hipLaunchKernelGGL(gather_logp_kernel, dim3((M + 255) / 256), dim3(256), 0, as_stream(stream), logp_all, actions, out, M, A);
+  M2H_LAUNCH(gather_logp_kernel, dim3((M + 255) / 256), dim3(256), 0, as_stream(stream), logp_all, actions, out, M, A);
   return launch_status("gather_logp");
 }
 
 int m2h_gae_returns(const float* rewards, float* value_preds, const float* masks, const float* next_value, float* returns, int T,
                     int N, int use_gae, float gamma, float tau, m2h_stream stream) {
   M2H_REQUIRE(rewards && value_preds && masks && next_value && returns && T > 0 && N > 0, "gae_returns: bad arguments");
-  hipLaunchKernelGGL(gae_returns_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), rewards, value_preds, masks, next_value,
+  M2H_LAUNCH(gae_returns_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), rewards, value_preds, masks, next_value,
                      returns, T, N, use_gae, gamma, tau);
   return launch_status("gae_returns");
 }
@@ -1083,19 +1083,19 @@ int m2h_gae_returns(const float* rewards, float* value_preds, const float* masks
 int m2h_advantages(const float* returns, const float* value_preds, float* adv, float* stats, int n, int mode, float eps,
                    m2h_stream stream) {
   M2H_REQUIRE(returns && value_preds && adv && n > 1 && mode >= 0 && mode <= 2, "advantages: bad arguments");
-  hipLaunchKernelGGL(advantages_kernel, dim3(1), dim3(256), 0, as_stream(stream), returns, value_preds, adv, stats, n, mode, eps);
+  M2H_LAUNCH(advantages_kernel, dim3(1), dim3(256), 0, as_stream(stream), returns, value_preds, adv, stats, n, mode, eps);
   return launch_status("advantages");
 }
 
 int m2h_adv_sqdiff(const float* adv, const float* gmean, float* out, int n, m2h_stream stream) {
   M2H_REQUIRE(adv && gmean && out && n > 0, "adv_sqdiff: bad arguments");
-  hipLaunchKernelGGL(adv_sqdiff_kernel, dim3(1), dim3(256), 0, as_stream(stream), adv, gmean, out, n);
+  M2H_LAUNCH(adv_sqdiff_kernel, dim3(1), dim3(256), 0, as_stream(stream), adv, gmean, out, n);
   return launch_status("adv_sqdiff");
 }
 
 int m2h_adv_apply(float* adv, const float* gmean, const float* gvar, int n, float eps, m2h_stream stream) {
   M2H_REQUIRE(adv && gmean && gvar && n > 0, "adv_apply: bad arguments");
-  hipLaunchKernelGGL(adv_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), adv, gmean, gvar, n, eps);
+  M2H_LAUNCH(adv_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), adv, gmean, gvar, n, eps);
   return launch_status("adv_apply");
 }
 
@@ -1103,7 +1103,7 @@ int m2h_ppo_loss(const float* values, const float* logp, const float* old_values
                  const float* old_logp, const float* entropy, float clip, const float* clip_dev, int use_clipped_value_loss,
                  float value_loss_coef, float entropy_coef, float* out, float* g_values, float* g_logp, int n, m2h_stream stream) {
   M2H_REQUIRE(values && logp && old_values && returns && adv && old_logp && out && n > 0, "ppo_loss: bad arguments");
-  hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), values, logp, old_values, returns, adv, old_logp, clip,
+  M2H_LAUNCH(ppo_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), values, logp, old_values, returns, adv, old_logp, clip,
                      clip_dev, use_clipped_value_loss, out, g_values, g_logp, value_loss_coef, entropy, entropy_coef, n);
   return launch_status("ppo_loss");
 }
@@ -1111,14 +1111,14 @@ int m2h_ppo_loss(const float* values, const float* logp, const float* old_values
 int m2h_gru_gates_bwd(const float* gi, const float* gh_raw, const float* bhh, const float* hprev, const float* mask, const float* dh,
                       float* dgi, float* dpre, float* dhp, float* hpm, int M, int H, m2h_stream stream) {
   M2H_REQUIRE(gi && gh_raw && bhh && hprev && dh && dgi && dpre && dhp && hpm && M > 0 && H > 0, "gru_gates_bwd: bad arguments");
-  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(grid_for((size_t)M * H)), dim3(256), 0, as_stream(stream), gi, gh_raw, bhh, hprev, mask, dh,
+  M2H_LAUNCH(gru_gates_bwd_kernel, dim3(grid_for((size_t)M * H)), dim3(256), 0, as_stream(stream), gi, gh_raw, bhh, hprev, mask, dh,
                      dgi, dpre, dhp, hpm, M, H);
   return launch_status("gru_gates_bwd");
 }
 
 int m2h_gru_bwd_combine(const float* a, const float* b, const float* c, const float* mask, float* out, int M, int H, m2h_stream stream) {
   M2H_REQUIRE(b && c && out && M > 0 && H > 0, "gru_bwd_combine: bad arguments");
-  hipLaunchKernelGGL(gru_bwd_combine_kernel, dim3(grid_for((size_t)M * H)), dim3(256), 0, as_stream(stream), a, b, c, mask, out, M, H);
+  M2H_LAUNCH(gru_bwd_combine_kernel, dim3(grid_for((size_t)M * H)), dim3(256), 0, as_stream(stream), a, b, c, mask, out, M, H);
   return launch_status("gru_bwd_combine");
 }
 
@@ -1127,7 +1127,7 @@ int m2h_gru_bwd_rec(const float* dpre, const float* whh_t, const float* a, const
   M2H_REQUIRE(dpre && whh_t && dhp && out, "gru_bwd_rec: null pointer");
   M2H_REQUIRE(M > 0 && M <= GB_E && H > 0 && H % 16 == 0, "gru_bwd_rec: needs 1 <= M <= %d rows and H %% 16 == 0 (got M=%d, H=%d)",
               GB_E, M, H);
-  hipLaunchKernelGGL(gru_bwd_rec_kernel, dim3(H / GB_U), dim3(64 * GB_NW), 0, as_stream(stream), dpre, whh_t, a, const_cast<float*>(dhp), mask, out, M, H,
+  M2H_LAUNCH(gru_bwd_rec_kernel, dim3(H / GB_U), dim3(64 * GB_NW), 0, as_stream(stream), dpre, whh_t, a, const_cast<float*>(dhp), mask, out, M, H,
                      static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), static_cast<const float*>(nullptr),
                      static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), static_cast<float*>(nullptr),
                      static_cast<float*>(nullptr), static_cast<float*>(nullptr));
@@ -1141,7 +1141,7 @@ int m2h_gru_bwd_step(const float* dpre, const float* whh_t, const float* a, floa
   M2H_REQUIRE(M > 0 && M <= GB_E && H > 0 && H % 16 == 0, "gru_bwd_step: needs 1 <= M <= %d rows and H %% 16 == 0 (got M=%d, H=%d)",
               GB_E, M, H);
   M2H_REQUIRE(dpre_prev != dpre, "gru_bwd_step: the previous step's dpre must not alias this step's (every block reads all of it)");
-  hipLaunchKernelGGL(gru_bwd_rec_kernel, dim3(H / GB_U), dim3(64 * GB_NW), 0, as_stream(stream), dpre, whh_t, a, dhp, mask, out, M, H, gi_prev, gh_prev, bhh,
+  M2H_LAUNCH(gru_bwd_rec_kernel, dim3(H / GB_U), dim3(64 * GB_NW), 0, as_stream(stream), dpre, whh_t, a, dhp, mask, out, M, H, gi_prev, gh_prev, bhh,
                      hprev_prev, mask_prev, dgi_prev, dpre_prev, hpm_prev);
   return launch_status("gru_bwd_step");
 }
@@ -1151,7 +1151,7 @@ int m2h_policy_heads_bwd(const float* logp_all, const float* probs, const long l
                          m2h_stream stream) {
   M2H_REQUIRE(logp_all && probs && Wa && Wc && dz && dfeats && M > 0 && H > 0 && A > 0 && A <= 8 && ZS >= A + 1 && ZS % 4 == 0,
               "policy_heads_bwd: bad arguments");
-  hipLaunchKernelGGL(policy_heads_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), logp_all, probs, actions, g_value, g_logp,
+  M2H_LAUNCH(policy_heads_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), logp_all, probs, actions, g_value, g_logp,
                      g_ent, Wa, Wc, dz, dfeats, M, H, A, ZS);
   return launch_status("policy_heads_bwd");
 }
@@ -1161,8 +1161,8 @@ int m2h_l1_loss(const float* pred, const float* gt, int gt_stride, int gt_off, f
                 m2h_stream stream) {
   M2H_REQUIRE(pred && gt && loss && scratch && n > 0 && gt_stride > 0 && gt_off >= 0 && gt_off < gt_stride, "l1_loss: bad arguments");
   const unsigned g = grid_for(n, M2H_PARTS);
-  hipLaunchKernelGGL(l1_loss_kernel, dim3(g), dim3(256), 0, as_stream(stream), pred, gt, gt_stride, gt_off, scratch, grad, n);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch, (int)g, 1.f / (float)n, loss);
+  M2H_LAUNCH(l1_loss_kernel, dim3(g), dim3(256), 0, as_stream(stream), pred, gt, gt_stride, gt_off, scratch, grad, n);
+  M2H_LAUNCH(sum_partials_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch, (int)g, 1.f / (float)n, loss);
   return launch_status("l1_loss");
 }
 
@@ -1171,9 +1171,9 @@ int m2h_l1_loss_nhwc16(const float* y, const float* gt, int gt_stride, int gt_of
   M2H_REQUIRE(y && gt && loss && scratch && B > 0 && T > 0 && T <= 256 && gt_stride > 0 && gt_off >= 0 && gt_off < gt_stride, "l1_loss_nhwc16: bad arguments");
   const size_t n = (size_t)B * 512 * T;
   const int nrows = B * 32, blocks = nrows < 2048 ? nrows : 2048;
-  hipLaunchKernelGGL(l1_nhwc16_kernel, dim3((unsigned)blocks), dim3(256), 16 * (T + 1) * sizeof(float), as_stream(stream), y, gt, gt_stride, gt_off, T,
+  M2H_LAUNCH(l1_nhwc16_kernel, dim3((unsigned)blocks), dim3(256), 16 * (T + 1) * sizeof(float), as_stream(stream), y, gt, gt_stride, gt_off, T,
                      scratch, dy, 1.f / (float)n, nrows);
-  hipLaunchKernelGGL(sum_partials_wide_kernel, dim3(1), dim3(1024), 0, as_stream(stream), scratch, blocks, 1.f / (float)n, loss);
+  M2H_LAUNCH(sum_partials_wide_kernel, dim3(1), dim3(1024), 0, as_stream(stream), scratch, blocks, 1.f / (float)n, loss);
   return launch_status("l1_loss_nhwc16");
 }
 
@@ -1181,16 +1181,16 @@ int m2h_bin_l1_loss(const float* mix, const float* masks, const float* gt_bin_co
                     float* scratch, size_t npix, m2h_stream stream) {
   M2H_REQUIRE(mix && masks && gt_bin_comps && loss && scratch && npix > 0 && cstep >= 1 && Cg >= cstep + 1, "bin_l1_loss: bad arguments");
   const unsigned g = grid_for(2 * npix, M2H_PARTS);
-  hipLaunchKernelGGL(bin_l1_kernel, dim3(g), dim3(256), 0, as_stream(stream), mix, masks, gt_bin_comps, Cg, cstep, scratch, grad_masks, npix);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch, (int)g, 1.f / (float)(2 * npix), loss);
+  M2H_LAUNCH(bin_l1_kernel, dim3(g), dim3(256), 0, as_stream(stream), mix, masks, gt_bin_comps, Cg, cstep, scratch, grad_masks, npix);
+  M2H_LAUNCH(sum_partials_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch, (int)g, 1.f / (float)(2 * npix), loss);
   return launch_status("bin_l1_loss");
 }
 
 int m2h_grad_clip_coef(const float* g, size_t n, float max_norm, float* coef, float* scratch, m2h_stream stream) {
   M2H_REQUIRE(g && coef && scratch && n > 0, "grad_clip_coef: bad arguments");
   const unsigned gr = grid_for(n, M2H_PARTS);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(gr), dim3(256), 0, as_stream(stream), g, n, scratch);
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch, (int)gr, max_norm, coef);
+  M2H_LAUNCH(sumsq_kernel, dim3(gr), dim3(256), 0, as_stream(stream), g, n, scratch);
+  M2H_LAUNCH(clip_coef_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch, (int)gr, max_norm, coef);
   return launch_status("grad_clip_coef");
 }
 
@@ -1199,7 +1199,7 @@ int m2h_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, fl
   M2H_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps, bc1,
+  M2H_LAUNCH(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps, bc1,
                      sqrtf(bc2), coef, gscale, (const float*)nullptr);
   return launch_status("adam_step");
 }
@@ -1208,7 +1208,7 @@ int m2h_adam_hyper(float lr, float beta1, float beta2, int step, float* hyper, m
   M2H_REQUIRE(hyper && step >= 1, "adam_hyper: bad arguments");
   // host arithmetic of m2h_adam_step (both entries take the same step); the values travel as kernel arguments: stream-ordered, no
   // host buffer to keep alive, no blocking copy
-  hipLaunchKernelGGL(set3_kernel, dim3(1), dim3(1), 0, as_stream(stream), hyper, lr, 1.f - powf(beta1, (float)step),
+  M2H_LAUNCH(set3_kernel, dim3(1), dim3(1), 0, as_stream(stream), hyper, lr, 1.f - powf(beta1, (float)step),
                      sqrtf(1.f - powf(beta2, (float)step)));
   return launch_status("adam_hyper");
 }
@@ -1216,21 +1216,21 @@ int m2h_adam_hyper(float lr, float beta1, float beta2, int step, float* hyper, m
 int m2h_adam_step_dev(float* p, float* g, float* m, float* v, size_t n, const float* hyper, float beta1, float beta2, float eps,
                       const float* coef, float gscale, m2h_stream stream) {
   M2H_REQUIRE(p && g && m && v && hyper && n > 0, "adam_step_dev: bad arguments");
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, as_stream(stream), p, g, m, v, n, 0.f, beta1, beta2, eps, 1.f, 1.f, coef,
+  M2H_LAUNCH(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, as_stream(stream), p, g, m, v, n, 0.f, beta1, beta2, eps, 1.f, 1.f, coef,
                      gscale, hyper);
   return launch_status("adam_step_dev");
 }
 
 int m2h_sq_stats(const float* pred, const float* gt_comps, int gt_stride, int gt_off, float* stats, int N, int L, m2h_stream stream) {
   M2H_REQUIRE(pred && gt_comps && stats && N > 0 && L > 0 && gt_stride > 0 && gt_off >= 0 && gt_off < gt_stride, "sq_stats: bad arguments");
-  hipLaunchKernelGGL(sq_stats_kernel, dim3(N), dim3(1024), 0, as_stream(stream), pred, gt_comps, gt_stride, gt_off, stats, L);
+  M2H_LAUNCH(sq_stats_kernel, dim3(N), dim3(1024), 0, as_stream(stream), pred, gt_comps, gt_stride, gt_off, stats, L);
   return launch_status("sq_stats");
 }
 
 int m2h_rewards_from_stats(const float* next_stats, const float* cur_stats, const float* not_done, float* rewards, int N, int L,
                            int quality_improvement, float mult, m2h_stream stream) {
   M2H_REQUIRE(next_stats && not_done && rewards && N > 0 && L > 0 && (!quality_improvement || cur_stats), "rewards_from_stats: bad arguments");
-  hipLaunchKernelGGL(rewards_from_stats_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), next_stats, cur_stats, not_done,
+  M2H_LAUNCH(rewards_from_stats_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), next_stats, cur_stats, not_done,
                      rewards, N, L, quality_improvement, mult);
   return launch_status("rewards_from_stats");
 }
@@ -1238,7 +1238,7 @@ int m2h_rewards_from_stats(const float* next_stats, const float* cur_stats, cons
 int m2h_gather_envs(const void* src, const long long* perm, void* dst, int T, int N, int Nsel, size_t row_bytes, m2h_stream stream) {
   M2H_REQUIRE(src && perm && dst && T > 0 && N > 0 && Nsel > 0 && row_bytes > 0 && row_bytes % 4 == 0, "gather_envs: bad arguments (row_bytes %% 4)");
   const size_t Lw = row_bytes / 4;
-  hipLaunchKernelGGL(gather_envs_kernel, dim3(grid_for((size_t)T * Nsel * ((Lw & 3) ? Lw : Lw / 4), 8192)), dim3(256), 0, as_stream(stream),
+  M2H_LAUNCH(gather_envs_kernel, dim3(grid_for((size_t)T * Nsel * ((Lw & 3) ? Lw : Lw / 4), 8192)), dim3(256), 0, as_stream(stream),
                      static_cast<const uint32_t*>(src), perm, static_cast<uint32_t*>(dst), T, N, Nsel, Lw);
   return launch_status("gather_envs");
 }
@@ -1246,7 +1246,7 @@ int m2h_gather_envs(const void* src, const long long* perm, void* dst, int T, in
 int m2h_stft_l2(const float* mix, const float* pred, int Cp, const float* gt_comps, int Cg, int nch, int use_mix, float* out, int N,
                 int L, m2h_stream stream) {
   M2H_REQUIRE(pred && gt_comps && out && N > 0 && L > 0 && nch > 0 && Cp >= nch && Cg >= 2 * nch && (!use_mix || mix), "stft_l2: bad arguments");
-  hipLaunchKernelGGL(stft_l2_kernel, dim3(N), dim3(1024), 0, as_stream(stream), mix, pred, Cp, gt_comps, Cg, nch, use_mix, out, L);
+  M2H_LAUNCH(stft_l2_kernel, dim3(N), dim3(1024), 0, as_stream(stream), mix, pred, Cp, gt_comps, Cg, nch, use_mix, out, L);
   return launch_status("stft_l2");
 }
 
@@ -1257,7 +1257,7 @@ int m2h_episode_stats_update(const m2h_episode_stats* st, const float* rewards, 
               "episode_stats_update: bad arguments");
   const float* const* fields = reinterpret_cast<const float* const*>(st);
   for (size_t i = 0; i < sizeof(m2h_episode_stats) / sizeof(float*); ++i) M2H_REQUIRE(fields[i], "episode_stats_update: null statistics tensor");
-  hipLaunchKernelGGL(episode_stats_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), *st, rewards, dist_probs, bin_losses,
+  M2H_LAUNCH(episode_stats_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), *st, rewards, dist_probs, bin_losses,
                      mono_losses, monoFromMem_losses, not_done, ndgs, dgs, N, A);
   return launch_status("episode_stats_update");
 }
@@ -1274,19 +1274,19 @@ int m2h_rows_copy(const m2h_row_copy* items, int n_items, const long long* idx, 
     big = it.bytes > big ? it.bytes : big;
   }
   const int gx = (int)((big / 16 + 255) / 256 > 256 ? 256 : ((big / 16 + 255) / 256 < 1 ? 1 : (big / 16 + 255) / 256));
-  hipLaunchKernelGGL(rows_copy_kernel, dim3(gx, n_items), dim3(256), 0, as_stream(stream), a, idx);
+  M2H_LAUNCH(rows_copy_kernel, dim3(gx, n_items), dim3(256), 0, as_stream(stream), a, idx);
   return launch_status("rows_copy");
 }
 
 int m2h_step_index_advance(long long* idx, int T_pol, int T_sep, m2h_stream stream) {
   M2H_REQUIRE(idx && T_pol > 0 && T_sep > 0, "step_index_advance: bad arguments");
-  hipLaunchKernelGGL(step_index_advance_kernel, dim3(1), dim3(64), 0, as_stream(stream), idx, T_pol, T_sep);
+  M2H_LAUNCH(step_index_advance_kernel, dim3(1), dim3(64), 0, as_stream(stream), idx, T_pol, T_sep);
   return launch_status("step_index_advance");
 }
 
 int m2h_synth_env_step(const long long* actions, long long* node, long long* angle, int n_nodes, int N, m2h_stream stream) {
   M2H_REQUIRE(actions && node && angle && n_nodes > 0 && N > 0, "synth_env_step: bad arguments");
-  hipLaunchKernelGGL(synth_env_step_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), actions, node, angle, n_nodes, N);
+  M2H_LAUNCH(synth_env_step_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), actions, node, angle, n_nodes, N);
   return launch_status("synth_env_step");
 }
 
@@ -1303,7 +1303,7 @@ int m2h_synth_env_observe(const m2h_row_copy* items, int n_items, const long lon
   }
   size_t gx = (big / 16 + 255) / 256;
   gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
-  hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)gx, (unsigned)N, (unsigned)n_items), dim3(256), 0, as_stream(stream), a, node, angle, audio_idx);
+  M2H_LAUNCH(rows_gather_kernel, dim3((unsigned)gx, (unsigned)N, (unsigned)n_items), dim3(256), 0, as_stream(stream), a, node, angle, audio_idx);
   return launch_status("synth_env_observe");
 }
 

@@ -156,7 +156,7 @@ int m2h_rollout_step_stats(const m2h_step_stats_args* args, m2h_stream stream) {
   M2H_REQUIRE(a.override_rewards || a.env_rewards, "rollout_step_stats: env rewards missing");
   const float* const* fields = reinterpret_cast<const float* const*>(&a.stats);
   for (size_t i = 0; i < sizeof(m2h_episode_stats) / sizeof(float*); ++i) M2H_REQUIRE(fields[i], "rollout_step_stats: null statistics tensor");
-  hipLaunchKernelGGL((rollout_step_stats_kernel<M2H_STEP_STATS_CHUNKS>), dim3(M2H_STEP_STATS_CHUNKS, a.N), dim3(256), 0, as_stream(stream), a);
+  M2H_LAUNCH((rollout_step_stats_kernel<M2H_STEP_STATS_CHUNKS>), dim3(M2H_STEP_STATS_CHUNKS, a.N), dim3(256), 0, as_stream(stream), a);
   return launch_status("rollout_step_stats");
 }
 

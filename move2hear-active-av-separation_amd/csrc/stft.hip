@@ -257,45 +257,45 @@ extern "C" {
 int m2h_stft_frames(const float* y, const float* window, float* frames, int S, int L, int T, int n_fft, int hop, int ldf, m2h_stream stream) {
   M2H_REQUIRE(y && window && frames && S > 0 && L > n_fft / 2 && T > 0 && n_fft > 1 && hop > 0 && ldf >= n_fft, "stft_frames: bad arguments");
   M2H_REQUIRE((T - 1) * hop + n_fft - n_fft / 2 <= L + n_fft / 2, "stft_frames: frames exceed the padded signal");
-  hipLaunchKernelGGL(stft_frames_kernel, dim3(sgrid((size_t)S * T * ldf)), dim3(256), 0, as_stream(stream), y, window, frames, S, L, T, n_fft, hop, ldf);
+  M2H_LAUNCH(stft_frames_kernel, dim3(sgrid((size_t)S * T * ldf)), dim3(256), 0, as_stream(stream), y, window, frames, S, L, T, n_fft, hop, ldf);
   return launch_status("stft_frames");
 }
 
 int m2h_stft_post(const float* spec, float* mag_out, float* phase_out, int B, int C, int T, int nb, int lds, int mode, m2h_stream stream) {
   M2H_REQUIRE(spec && (mag_out || phase_out) && B > 0 && C > 0 && T > 0 && nb > 0 && lds >= 2 * nb && mode >= 0 && mode <= 2, "stft_post: bad arguments");
-  hipLaunchKernelGGL(stft_post_kernel, dim3(sgrid((size_t)B * nb * T * C)), dim3(256), 0, as_stream(stream), spec, mag_out, phase_out, B, C, T, nb, lds, mode);
+  M2H_LAUNCH(stft_post_kernel, dim3(sgrid((size_t)B * nb * T * C)), dim3(256), 0, as_stream(stream), spec, mag_out, phase_out, B, C, T, nb, lds, mode);
   return launch_status("stft_post");
 }
 
 int m2h_istft_pre(const float* mag, const float* phase, float* rows, int B, int C, int c, int T, int nb, int ldr, m2h_stream stream) {
   M2H_REQUIRE(mag && phase && rows && B > 0 && C > 0 && c >= 0 && c < C && T > 0 && nb > 0 && ldr >= 2 * nb, "istft_pre: bad arguments");
-  hipLaunchKernelGGL(istft_pre_kernel, dim3(sgrid((size_t)B * T * nb)), dim3(256), 0, as_stream(stream), mag, phase, rows, B, C, c, T, nb, ldr);
+  M2H_LAUNCH(istft_pre_kernel, dim3(sgrid((size_t)B * T * nb)), dim3(256), 0, as_stream(stream), mag, phase, rows, B, C, c, T, nb, ldr);
   return launch_status("istft_pre");
 }
 
 int m2h_istft_ola(const float* frames, const float* window, float* y, int S, int T, int n_fft, int hop, int ldf, int length, m2h_stream stream) {
   M2H_REQUIRE(frames && window && y && S > 0 && T > 0 && n_fft > 1 && hop > 0 && ldf >= n_fft && length > 0, "istft_ola: bad arguments");
-  hipLaunchKernelGGL(istft_ola_kernel, dim3(sgrid((size_t)S * length)), dim3(256), 0, as_stream(stream), frames, window, y, S, T, n_fft, hop, ldf, length);
+  M2H_LAUNCH(istft_ola_kernel, dim3(sgrid((size_t)S * length)), dim3(256), 0, as_stream(stream), frames, window, y, S, T, n_fft, hop, ldf, length);
   return launch_status("istft_ola");
 }
 
 int m2h_feeder_round_mix(const float* full, int ldfull, int start, float* conv_out, float* mix, int S, int L, int first, float mix_scale,
                           m2h_stream stream) {
   M2H_REQUIRE(full && mix && S > 0 && L > 0 && start >= 0 && start + L <= ldfull, "feeder_round_mix: bad arguments");
-  hipLaunchKernelGGL(feeder_round_mix_kernel, dim3(sgrid((size_t)S * L)), dim3(256), 0, as_stream(stream), full, ldfull, start, conv_out, mix, S, L,
+  M2H_LAUNCH(feeder_round_mix_kernel, dim3(sgrid((size_t)S * L)), dim3(256), 0, as_stream(stream), full, ldfull, start, conv_out, mix, S, L,
                      first, mix_scale);
   return launch_status("feeder_round_mix");
 }
 
 int m2h_rms_normalize(float* mag, int S, int n, float norm, m2h_stream stream) {
   M2H_REQUIRE(mag && S > 0 && n > 0, "rms_normalize: bad arguments");
-  hipLaunchKernelGGL(rms_normalize_kernel, dim3(S), dim3(1024), 0, as_stream(stream), mag, n, norm);
+  M2H_LAUNCH(rms_normalize_kernel, dim3(S), dim3(1024), 0, as_stream(stream), mag, n, norm);
   return launch_status("rms_normalize");
 }
 
 int m2h_bss_metrics(const float* ref, const float* est, const float* mix_l, const float* mix_r, float* out, int S, int L, m2h_stream stream) {
   M2H_REQUIRE(ref && est && mix_l && out && S > 0 && L > 1, "bss_metrics: bad arguments");
-  hipLaunchKernelGGL(bss_metrics_kernel, dim3(S), dim3(1024), 0, as_stream(stream), ref, est, mix_l, mix_r, out, L);
+  M2H_LAUNCH(bss_metrics_kernel, dim3(S), dim3(1024), 0, as_stream(stream), ref, est, mix_l, mix_r, out, L);
   return launch_status("bss_metrics");
 }
 

@@ -186,6 +186,7 @@ SIGNATURES = {
     "m2h_tuning_restore": [_P, _I],
     "m2h_set_math_mode": [_I],
     "m2h_get_math_mode": [],
+    "m2h_launch_count": [],
     "m2h_unet_down_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P],
     "m2h_unet_up_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P],
     "m2h_unet_down_workspace_bytes": [_I, _I, _I, _I, _I],
@@ -294,7 +295,7 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_size_t if name.endswith("_bytes") else (ctypes.c_char_p if name in ("m2h_last_kernel", "m2h_unet_fwd_stage_kernel") else ctypes.c_int)
+            fn.restype = ctypes.c_longlong if name == "m2h_launch_count" else ctypes.c_size_t if name.endswith("_bytes") else (ctypes.c_char_p if name in ("m2h_last_kernel", "m2h_unet_fwd_stage_kernel") else ctypes.c_int)
         lib.m2h_last_error.argtypes = []
         lib.m2h_last_error.restype = ctypes.c_char_p
         _lib = lib

@@ -11,16 +11,45 @@ import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
-def capture(graph, pool=None):
+class capture:
     """torch.cuda.graph with capture_error_mode="thread_local": other threads of the process (RCCL's watchdog polling its
     events, a data feeder) may keep calling into HIP while this thread captures; work the autograd engine's thread enqueues
-    on the capturing stream is recorded all the same."""
-    from . import functional
-    functional.unit_grad(torch.device("cuda", torch.cuda.current_device()))   # the cached root gradient must not be born inside a capture
-    return torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local")
+    on the capturing stream is recorded all the same.  The graph remembers how many libm2h kernels it holds (``replay`` below)."""
+
+    def __init__(self, graph, pool=None):
+        from . import functional
+        functional.unit_grad(torch.device("cuda", torch.cuda.current_device()))   # the cached root gradient must not be born inside a capture
+        self.graph = graph
+        self.ctx = torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local")
+
+    def __enter__(self):
+        self.n0 = _lib.load().m2h_launch_count()
+        return self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        out = self.ctx.__exit__(*exc)
+        n = _lib.load().m2h_launch_count() - self.n0
+        self.graph._m2h_kernels = n
+        _counts["captured"] += n
+        return out
+
+
+_counts = {"captured": 0, "replayed": 0}
+
+
+def replay(graph):
+    """graph.replay(), counted: the graph's libm2h kernels run once more (launch_total)."""
+    graph.replay()
+    _counts["replayed"] += getattr(graph, "_m2h_kernels", 0)
+
+
+def launch_total():
+    """libm2h kernels executed by this process so far: enqueued one by one + replayed from graphs (captures execute nothing).
+    A diagnostic for bench.py's per-phase launch counts; torch's own kernels are not in it."""
+    return _lib.load().m2h_launch_count() - _counts["captured"] + _counts["replayed"]
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -125,5 +154,5 @@ class GraphedSeparatorPair:
     def __call__(self):
         if self.stale():
             self.capture()
-        self._graph.replay()
+        replay(self._graph)
         return self.masks, self.mono

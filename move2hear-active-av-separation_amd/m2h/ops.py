@@ -100,7 +100,7 @@ class tuning_scope:
         return False
 
 
-MATH_FP32, MATH_BF16X3 = 0, 1
+MATH_FP32, MATH_BF16X3, MATH_BF16 = 0, 1, 2   # include/m2h.h M2H_MATH_*
 _tls = threading.local()   # the calling thread's arithmetic (mirrors libm2h's thread-local m2h_set_math_mode)
 FMT_SRC_SPLIT, FMT_W_SPLIT, FMT_DST_SPLIT, FMT_MATH_BF16X3, FMT_MATH_FP32 = 1, 2, 4, 8, 16   # include/m2h.h M2H_FMT_*
 
@@ -164,8 +164,8 @@ def set_math_mode(mode):
     MATH_FP32 (default): fp32 matrix instructions, exact fp32 products.  MATH_BF16X3: fp32 operands split into bf16 hi + lo
     inside the kernel, products hi*hi + hi*lo + lo*hi on the bf16 matrix pipe with fp32 accumulation (~16 mantissa bits per
     product; tensors in HBM stay fp32).  Applies to shapes the scalar loader takes (channel counts multiples of 32)."""
-    if mode not in (MATH_FP32, MATH_BF16X3):
-        raise ValueError("math mode must be ops.MATH_FP32 or ops.MATH_BF16X3")
+    if mode not in (MATH_FP32, MATH_BF16X3, MATH_BF16):
+        raise ValueError("math mode must be ops.MATH_FP32, ops.MATH_BF16X3 or ops.MATH_BF16")
     _lib.check(_lib.load().m2h_set_math_mode(int(mode)), "m2h_set_math_mode")
     _tls.math_mode = mode
 

@@ -53,6 +53,7 @@ class FlatAdam(torch.optim.Optimizer):
             off += p.numel()
         self._no_idx = torch.zeros(1, device=dev, dtype=torch.int64)      # rows_copy's index argument (no item uses an index)
         self._gathered = True                                             # flat_g (zeros) is consistent with "no gradients yet"
+        self._gathered_idx = set()                                        # parameters gathered since the last step (partial gathers: grad_bucket)
         self._slots_used = set()                                          # offsets handed out by functional.grad_slot since the last zero_grad
         self._built = True
         from . import functional
@@ -75,17 +76,23 @@ class FlatAdam(torch.optim.Optimizer):
                     p.grad = None
                 else:
                     p.grad.zero_()
+        self._gathered_idx = set()
         if set_to_none:
             self._slots_used = set()     # every gradient of the coming backward may be written straight into its slice (functional.grad_slot)
         self._gathered = False
 
     @torch.no_grad()
-    def _gather(self):
-        """p.grad of every parameter -> its slice of the flat gradient buffer (one batched copy; None counts as zeros)."""
+    def _gather(self, idx=None):
+        """p.grad of every parameter (idx: of those parameters only) -> its slice of the flat gradient buffer (one batched copy; None
+        counts as zeros).  A parameter gathered once is not gathered again before the next step / zero_grad: its slice may hold an
+        all-reduced sum by then (bucketed reduction, ddppo_utils.GradReduceStep.early)."""
         if self._gathered:
             return
-        items, missing, resident = [], [], False
-        for p, off in zip(self._ps, self._offsets):
+        done = self._gathered_idx
+        todo = [i for i in (range(len(self._ps)) if idx is None else idx) if i not in done]
+        items, missing = [], []
+        for i in todo:
+            p, off = self._ps[i], self._offsets[i]
             g = p.grad
             if g is None:
                 missing.append((off, p.numel()))
@@ -94,17 +101,19 @@ class FlatAdam(torch.optim.Optimizer):
                 raise RuntimeError("FlatAdam: gradients must be fp32 tensors on the parameters' GPU")
             dst = self.flat_g[off:off + p.numel()]
             if g.data_ptr() == dst.data_ptr():
-                resident = True
                 continue                                   # already a view of its slice (functional.grad_slot)
             items.append((g.contiguous().view(-1), dst, -1, -1))
-        if missing and not resident:
+        if missing and len(missing) == len(self._ps):
             self.flat_g.zero_()
         else:
             for off, k in missing:                         # (gradients that live in the buffer must survive: zero the absent ones' slices only)
                 self.flat_g[off:off + k].zero_()
         if items:
             ops.rows_copy(items, self._no_idx)
-        self._gathered = True
+        done.update(todo)
+        if len(done) == len(self._ps):
+            self._gathered = True
+            self._gathered_idx = set()
 
     def grad_buffer(self):
         """The flat gradient (all-reduce payload), gathered from the parameters' .grad."""
@@ -112,6 +121,13 @@ class FlatAdam(torch.optim.Optimizer):
             self._build()
         self._gather()
         return self.flat_g
+
+    def grad_bucket(self, params):
+        """The slice of the flat gradient that belongs to `params` (a contiguous run of this optimizer's parameters), gathered from
+        their .grad now -- a bucket whose backward is complete while the rest of the backward is still being enqueued."""
+        b0, b1, idx = self.param_range(params)
+        self._gather(idx)
+        return self.flat_g[b0:b1]
 
     @torch.no_grad()
     def step(self, max_grad_norm=None, grad_scale=1.0):
@@ -121,6 +137,7 @@ class FlatAdam(torch.optim.Optimizer):
             raise RuntimeError("FlatAdam.step before zero_grad()/backward")
         self._gather()
         self._gathered = False   # the next step gathers afresh (gradients may be replaced without zero_grad: HIP-graph replays)
+        self._gathered_idx = set()
         g = self.param_groups[0]
         lr, eps, (b1, b2) = g["lr"], g["eps"], g["betas"]
         self.t += 1

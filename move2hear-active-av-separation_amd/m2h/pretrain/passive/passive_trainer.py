@@ -167,7 +167,7 @@ class PassiveTrainer:
         self.optimizer.begin_replayed_step()
         if gs.forked:
             torch.cuda.current_stream().synchronize()   # a graph with parallel branches goes onto a drained stream (m2h/graphs.py)
-        gs.graph.replay()
+        graphs.replay(gs.graph)
         self.optimizer.end_replayed_step()
         if gs.forked:
             for m in gs.memos_a:

@@ -284,7 +284,7 @@ def unet_forward(enc, dec, mix, masks=None, target_class=None, events=None):
     B, F, T, C = mix.shape
     if C != 2 or F != 512 or T % 32 != 0:
         raise RuntimeError("m2h.unet_forward: expected mix [B,512,T,2] with T %% 32 == 0, got %s" % (tuple(mix.shape),))
-    split = ops.math_mode() == ops.MATH_BF16X3
+    split = ops.math_mode() in (ops.MATH_BF16X3, ops.MATH_BF16)   # (MATH_BF16: the reported hi-halves-only mode, same tensors and engines)
     wsel = _split32_of if split else (lambda t: t)
     w = _lib.UnetWeights()
     for i, (wp, scale, shift, table, _co) in enumerate(downs):

@@ -7,7 +7,13 @@ same code runs over gloo on CPU for the world_size-2 tests.  The data path of th
                          ppo.py:313-319); the division by world size happens inside the optimizer step
   advantage statistics   two scalar all-reduces per update_pol (ddppo_utils.py:168-190)
 
-Overlap: ``GradReduceStep`` runs the all-reduce + clip + Adam of the LAST mini-batch of an update on a side HIP
+Overlap with the backward (the reference's DDP reducer, ppo.py:286-319): the policy's gradient is cut into two buckets in
+reverse-backward order -- recurrent encoder + heads, whose gradients are complete when the backward reaches the encoders'
+features, and the three encoders.  ``GradReduceStep.early`` enqueues the first bucket's all-reduce on the side stream as soon
+as its last weight gradient has been issued, under the encoders' backward; only the second bucket's all-reduce is exposed
+before clip + Adam (bench.py: phases.grad_allreduce_exposed_ms).  Sums are element-wise, so the buckets give the flat buffer's values.
+
+Overlap with the next phase: ``GradReduceStep`` runs the all-reduce + clip + Adam of the LAST mini-batch of an update on a side HIP
 stream and hands back a fence; whoever next reads those parameters (Policy.act / get_value / evaluate_* for the policy,
 Policy.get_monoFromMem* for the acoustic memory) makes its stream wait on the fence first.  The collective and the optimizer
 step of update_pol's last epoch therefore run under the following update_sep passes / the bookkeeping of the next rollout,
@@ -57,15 +63,16 @@ _COLLECTIVE_LOG = None
 
 def collective_log(enable=True):
     """Diagnostics (bench.py): while enabled every gradient all-reduce on a GPU tensor is bracketed by two timing events on the
-    stream it is enqueued on (the compute stream, or GradReduceStep's side stream) and logged as (start, end, payload bytes).
+    stream it is enqueued on (the compute stream, or GradReduceStep's side stream) and logged as (start, end, payload bytes, on the compute stream?).
     Returns the list being filled (None when disabled); the caller reads the events after a device synchronize."""
     global _COLLECTIVE_LOG
     _COLLECTIVE_LOG = [] if enable else None
     return _COLLECTIVE_LOG
 
 
-def reduce_gradients(flat_grad):
-    """Sum all-reduce of the flat gradient buffer; returns the scale (1/world) the optimizer applies before clipping."""
+def reduce_gradients(flat_grad, exposed=True):
+    """Sum all-reduce of the flat gradient buffer (or a bucket of it); returns the scale (1/world) the optimizer applies before clipping.
+    exposed: the collective is enqueued on the compute stream (it waits for it), not on the side stream (logged for bench.py)."""
     w = world_size()
     if w == 1:
         return 1.0
@@ -75,7 +82,7 @@ def reduce_gradients(flat_grad):
         e0.record()
         dist.all_reduce(flat_grad)
         e1.record()
-        log.append((e0, e1, flat_grad.numel() * flat_grad.element_size()))
+        log.append((e0, e1, flat_grad.numel() * flat_grad.element_size(), bool(exposed)))
     else:
         dist.all_reduce(flat_grad)
     return 1.0 / w
@@ -97,7 +104,33 @@ class GradReduceStep:
         self._dev = None
         self._event = None
         self._lazy = None
+        self._early_event = None
         self.deferred_steps = 0
+        self.early_buckets = 0
+
+    def _side_stream(self, dev):
+        self._dev = dev
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
+
+    def early(self, flat_bucket):
+        """Sum all-reduce of a bucket whose gradients are complete while the rest of the backward is still to be enqueued: on the
+        side stream, behind what the caller's stream holds so far; the caller's stream does not wait (submit() orders the
+        optimizer step after it).  CPU tensors (gloo tests): reduced at once."""
+        self.early_buckets += 1
+        if not flat_bucket.is_cuda:
+            reduce_gradients(flat_bucket)
+            return
+        dev = flat_bucket.device
+        side = self._side_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            reduce_gradients(flat_bucket, exposed=False)
+            self._early_event = torch.cuda.Event()
+            self._early_event.record(side)
 
     def pending(self):
         return self._event is not None or self._lazy is not None
@@ -105,20 +138,24 @@ class GradReduceStep:
     def submit(self, flat_grad, step_fn, defer=False):
         self.fence()  # at most one step in flight per parameter group; its buffers are about to be reused
         if not defer:
-            step_fn(reduce_gradients(flat_grad))
+            scale = reduce_gradients(flat_grad)
+            if self._early_event is not None:     # the early bucket's all-reduce (side stream) before the step reads the whole buffer
+                ev, self._early_event = self._early_event, None
+                torch.cuda.current_stream(self._dev).wait_event(ev)
+            step_fn(scale)
             return
         self.deferred_steps += 1
         if not flat_grad.is_cuda:
             self._lazy = lambda: step_fn(reduce_gradients(flat_grad))
             return
-        dev = self._dev = flat_grad.device
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
+        dev = flat_grad.device
+        self._side_stream(dev)
+        self._early_event = None   # (an early bucket ran on this same side stream: already ordered before what follows)
         backward_done = torch.cuda.Event()
         backward_done.record(torch.cuda.current_stream(dev))
         self._side.wait_event(backward_done)
         with torch.cuda.stream(self._side):
-            step_fn(reduce_gradients(flat_grad))
+            step_fn(reduce_gradients(flat_grad, exposed=False))
             self._event = torch.cuda.Event()
             self._event.record(self._side)
 

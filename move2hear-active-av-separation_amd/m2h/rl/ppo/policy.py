@@ -67,6 +67,8 @@ class PolicyNet(Net):
         rnn_input_size = 3 * self._hidden_size
         self.state_encoder = RNNStateEncoder(rnn_input_size, self._hidden_size)
         self._audio_pair = FusedAudioPair(self.bin_encoder, self.monoNmonoFromMem_encoder)   # no parameters of its own (rollout fast path)
+        self.encoder_features = None
+        self.keep_encoder_features = False
 
     @property
     def is_blind(self):
@@ -116,6 +118,8 @@ class PolicyNet(Net):
                    lambda: self.monoNmonoFromMem_encoder.forward_pair(pred_mono, pred_monoFromMem)]  # cat(dim=3) read in place
         x = graphs.run_parallel(pred_mono.device if pred_mono.shape[0] >= 64 else None, fns)
         x1 = torch.cat(x, dim=1)
+        if self.keep_encoder_features:     # where a split backward stops (ppo.py, the bucketed gradient reduction): handed over once
+            self.encoder_features = x1
         x2, rnn_hidden_states_new = self.state_encoder(x1, rnn_hidden_states, masks)
         # the reference asserts "not isnan(x2).any().item()" here (:116): a host sync per call; dropped.
         return x2, rnn_hidden_states_new

@@ -30,7 +30,7 @@ class PPO(nn.Module):
     def __init__(self, actor_critic, clip_param, ppo_epoch, num_mini_batch, value_loss_coef, bin_separation_loss_coef,
                  mono_conversion_loss_coef, entropy_coef, lr_pol=None, lr_sep=None, eps=None, max_grad_norm=None,
                  freeze_passive_separators=False, use_clipped_value_loss=True, use_normalized_advantage=True,
-                 cache_separator_outputs=True, overlap_grad_reduce=None, use_hip_graphs=False):
+                 cache_separator_outputs=True, overlap_grad_reduce=None, use_hip_graphs=False, bucketed_grad_reduce=None):
         super().__init__()
         self.actor_critic = actor_critic
         self.clip_param = clip_param
@@ -60,6 +60,10 @@ class PPO(nn.Module):
         # overlap_grad_reduce: None = on when distributed (init_distributed), True = also at world size 1 (the side-stream
         # schedule without the collective; tests), False = the synchronous order of the reference
         self.overlap_grad_reduce = overlap_grad_reduce
+        # bucketed_grad_reduce: the policy gradient's all-reduce in two buckets, the first (recurrent encoder + heads) under the encoders'
+        # backward (ddppo_utils.GradReduceStep.early).  None = on when distributed, True = also at world size 1 (the schedule without the
+        # collective; tests), False = one flat all-reduce behind the whole backward
+        self.bucketed_grad_reduce = bucketed_grad_reduce
         # use_hip_graphs: replay one epoch of update_pol (forward, losses, backward) from a HIP graph (same kernels and values;
         # the epoch is ~400 small launches behind ~5 ms of Python and autograd dispatch)
         self.use_hip_graphs = use_hip_graphs
@@ -102,6 +106,16 @@ class PPO(nn.Module):
     def _overlap(self):
         return self._world > 1 if self.overlap_grad_reduce is None else bool(self.overlap_grad_reduce)
 
+    def _bucketed(self):
+        return self._world > 1 if self.bucketed_grad_reduce is None else bool(self.bucketed_grad_reduce)
+
+    def _tail_bucket_params(self):
+        """The parameters whose gradients are complete when the backward reaches the encoders' features: the recurrent state encoder
+        and the two heads -- the tail of the policy optimizer's flat buffer (the encoders come first in pol_net.parameters())."""
+        ac = self.actor_critic
+        return [q for q in list(ac.pol_net.state_encoder.parameters()) + list(ac.action_dist.parameters()) + list(ac.critic.parameters())
+                if q.requires_grad]
+
     def _reduce_and_step(self, group, opt, last):
         """One flat sum all-reduce (RCCL) + clip + Adam.  The last mini-batch of an update is deferred onto the side stream
         when overlap is on: nothing in the rest of the update reads these parameters (ddppo_utils.GradReduceStep)."""
@@ -116,19 +130,37 @@ class PPO(nn.Module):
             r.fence()
 
     # ------------------------------------------------------------------ policy update (reference :82-177)
-    def _pol_epoch(self, sample, clip, acc, prepared=None):
-        """Forward, losses and backward of one mini-batch (reference :94-163); the optimizer step follows in the caller."""
+    def _pol_epoch(self, sample, clip, acc, prepared=None, split=False):
+        """Forward, losses and backward of one mini-batch (reference :94-163); the optimizer step follows in the caller.
+        split: the backward stops at the encoders' features (gradients of the recurrent encoder and the heads complete) and returns
+        them; ``_pol_epoch_rest`` runs the encoders' backward (the bucketed gradient reduction goes in between)."""
         (obs_batch, h_batch, pm_batch, mono_batch, mem_batch, value_preds_batch, return_batch, adv_targ, actions_batch,
          old_logp_batch, masks_batch) = sample
-        values, logp, ent_rows, _ = self.actor_critic.evaluate_rows(
-            obs_batch, h_batch, masks_batch, actions_batch, pred_binSepMasks=pm_batch, pred_mono=mono_batch,
-            pred_monoFromMem=mem_batch, prepared=prepared)
+        net = self.actor_critic.pol_net
+        net.keep_encoder_features = bool(split)
+        try:
+            values, logp, ent_rows, _ = self.actor_critic.evaluate_rows(
+                obs_batch, h_batch, masks_batch, actions_batch, pred_binSepMasks=pm_batch, pred_mono=mono_batch,
+                pred_monoFromMem=mem_batch, prepared=prepared)
+        finally:
+            net.keep_encoder_features = False
+        feats, net.encoder_features = net.encoder_features, None   # (the concatenated encoder outputs of THIS forward, non-leaf; nothing is kept on the module)
         self.optimizer_pol.zero_grad()
         total_loss, stats = MF.PPOLoss.apply(values, logp, ent_rows, value_preds_batch, return_batch, adv_targ, old_logp_batch,
                                              clip, float(self.value_loss_coef), float(self.entropy_coef),
                                              bool(self.use_clipped_value_loss))
-        total_loss.backward(MF.unit_grad(total_loss.device))
+        if split:
+            torch.autograd.backward(total_loss, MF.unit_grad(total_loss.device), inputs=[feats] + self._tail_bucket_params())
+        else:
+            total_loss.backward(MF.unit_grad(total_loss.device))
         acc += stats
+        return feats
+
+    def _pol_epoch_rest(self, feats):
+        """The encoders' backward from the features' gradient (second half of a split ``_pol_epoch``)."""
+        g = feats.grad
+        feats.grad = None
+        torch.autograd.backward(feats, g)
 
     def update_pol(self, rollouts_pol):
         advantages = self.get_advantages(rollouts_pol)
@@ -140,7 +172,12 @@ class PPO(nn.Module):
         acc = torch.zeros(4, device=self.device)
         for _e in range(self.ppo_epoch):
             for _mb, sample in enumerate(rollouts_pol.recurrent_generator(advantages, self.num_mini_batch)):
-                self._pol_epoch(sample, float(self.clip_param), acc)
+                if self._bucketed():
+                    feats = self._pol_epoch(sample, float(self.clip_param), acc, split=True)
+                    self._reducers["pol"].early(self.optimizer_pol.grad_bucket(self._tail_bucket_params()))
+                    self._pol_epoch_rest(feats)
+                else:
+                    self._pol_epoch(sample, float(self.clip_param), acc)
                 self._reduce_and_step("pol", self.optimizer_pol,  # before_step_pol + step
                                       last=_e == self.ppo_epoch - 1 and _mb == self.num_mini_batch - 1)
         num_updates = self.ppo_epoch * self.num_mini_batch
@@ -157,11 +194,12 @@ class PPO(nn.Module):
         gs = self._pol_graph
         self.optimizer_pol.build()
         sig = (id(rollouts_pol), rollouts_pol.rewards.data_ptr(), tuple(advantages.shape), float(self.value_loss_coef),
-               float(self.entropy_coef), bool(self.use_clipped_value_loss), ops.math_mode(),
+               float(self.entropy_coef), bool(self.use_clipped_value_loss), ops.math_mode(), self._bucketed(),
                tuple(p.data_ptr() for p in self.optimizer_pol.param_groups[0]["params"]))
         if gs is None or gs.sig != sig:
             from types import SimpleNamespace
-            gs = self._pol_graph = SimpleNamespace(sig=sig, graph=None, forked=False, prepared=None, adv=torch.empty_like(advantages),
+            gs = self._pol_graph = SimpleNamespace(sig=sig, graph=None, graph_rest=None, feats=None, bucketed=self._bucketed(), forked=False,
+                                                   prepared=None, adv=torch.empty_like(advantages),
                                                    clip=torch.zeros(1, device=self.device), acc=torch.zeros(4, device=self.device))
         gs.adv.copy_(advantages)
         gs.clip.fill_(float(self.clip_param))
@@ -184,8 +222,19 @@ class PPO(nn.Module):
             if gs.graph is None:
                 cpu_rng = torch.get_rng_state()  # capture executes the python once without running kernels: no RNG side effect
                 g = torch.cuda.CUDAGraph()
-                with graphs.capture(g):
-                    self._pol_epoch(next(iter(rollouts_pol.recurrent_generator(gs.adv, 1))), gs.clip, gs.acc, prepared=gs.prepared)
+                if gs.bucketed:
+                    # two graphs: forward + losses + the backward down to the encoders' features | the encoders' backward.  Between their
+                    # replays the first bucket (recurrent encoder + heads) goes to the side stream for its all-reduce.
+                    with graphs.capture(g):
+                        gs.feats = self._pol_epoch(next(iter(rollouts_pol.recurrent_generator(gs.adv, 1))), gs.clip, gs.acc, prepared=gs.prepared,
+                                                   split=True)
+                    g2 = torch.cuda.CUDAGraph()
+                    with graphs.capture(g2, pool=g.pool()):
+                        self._pol_epoch_rest(gs.feats)
+                    gs.graph_rest = g2
+                else:
+                    with graphs.capture(g):
+                        self._pol_epoch(next(iter(rollouts_pol.recurrent_generator(gs.adv, 1))), gs.clip, gs.acc, prepared=gs.prepared)
                 torch.set_rng_state(cpu_rng)
                 gs.graph, gs.forked = g, graphs.parallel_branches
             torch.randperm(num_envs)        # recurrent_generator's draw (:197); the batch itself is the storage in place
@@ -193,7 +242,10 @@ class PPO(nn.Module):
                 # the epoch's graph has parallel branches (the three encoders, m2h/graphs.py): it is launched onto a drained stream --
                 # queued behind the rollout's replays its side queues' parked barrier packets slow every kernel boundary ahead of it
                 torch.cuda.current_stream().synchronize()
-            gs.graph.replay()
+            graphs.replay(gs.graph)
+            if gs.bucketed:
+                self._reducers["pol"].early(self.optimizer_pol.grad_bucket(self._tail_bucket_params()))
+                graphs.replay(gs.graph_rest)
             self._reduce_and_step("pol", self.optimizer_pol, last=_e == self.ppo_epoch - 1)
         v, a, h, _ = (gs.acc / self.ppo_epoch).tolist()
         return v, a, h
@@ -269,7 +321,7 @@ class PPO(nn.Module):
                 loss.backward(MF.unit_grad(loss.device))
                 gs.loss = loss.detach()
             gs.graph = g
-        gs.graph.replay()
+        graphs.replay(gs.graph)
         return gs.loss
 
     def update_sep(self, rollouts_sep, as_tensor=False):

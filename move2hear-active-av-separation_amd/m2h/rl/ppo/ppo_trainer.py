@@ -46,6 +46,7 @@ def near_target_config(**over):
              ddppo_distrib_backend="NCCL", master_port=8738, master_addr="127.0.0.1",       # config/default.py:94-97
              short_rollout_threshold=1.0, sync_frac=0.6,  # nearTarget.yaml:58-59: at 1.0 the preemption of :775-781 never triggers; not built
              use_hip_graphs=True,       # build-side key: replay the rollout step and the update_pol epoch from HIP graphs (same kernels, same results)
+             bucketed_grad_reduce=None,  # build-side key: None = when distributed, the policy gradient's all-reduce in two buckets, the first under the encoders' backward
              overlap_grad_reduce=None,  # build-side key: None = overlap the last all-reduce + step of an update when distributed
              pretrained_passive_separators_ckpt="", train_passive_separators=False,   # nearTarget.yaml:23-24 (accepted; see setup())
              rollout_math=None,         # build-side key: arithmetic of the rollout steps' conv / GEMM launches: None = the calling thread's mode (ops.set_math_mode);
@@ -104,6 +105,7 @@ class PPOTrainer:
                          max_grad_norm=cfg.max_grad_norm,
                          freeze_passive_separators=not bool(getattr(cfg, "train_passive_separators", False)),   # :72-73 (stored, read nowhere)
                          overlap_grad_reduce=getattr(cfg, "overlap_grad_reduce", None),
+                         bucketed_grad_reduce=getattr(cfg, "bucketed_grad_reduce", None),
                          use_hip_graphs=bool(getattr(cfg, "use_hip_graphs", False)))
         self.actor_critic.train()
         if passive_state_dict is not None:
@@ -306,7 +308,7 @@ class PPOTrainer:
         # cpu_generator sampling: a graph that contains sample() must be replayed through here -- the noise of THIS step is drawn on
         # the host and staged into the buffer the graph reads before every replay (a bare g.replay() would re-use the last step's)
         self.actor_critic.stage_action_noise(self.envs.num_envs)
-        g.replay()
+        graphs.replay(g)
         gs.expect = ((ro.step + 1) % ro.num_steps, (rs.step + 1) % rs.num_steps)
 
     # ------------------------------------------------------------------ updates (reference :480-541)
@@ -426,6 +428,7 @@ class PPOTrainer:
             return None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
+        ev.m2h_kernels = graphs.launch_total()   # (host-side count at this point of the enqueue order: bench.py's launches per phase)
         return ev
 
     _WINDOW_KEYS = (("count", "episode_counts"), ("reward", "episode_rewards"), ("step", "episode_steps"), ("dist_probs", "episode_dist_probs"),

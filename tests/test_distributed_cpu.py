@@ -73,7 +73,29 @@ def _worker(rank, world, port, q):
     p_sync, seen_sync, _, n_sync = run(False)
     p_def, seen_def, late, n_def = run(True)
     ok_d = torch.equal(p_sync, p_def) and all(torch.equal(a, b) for a, b in zip(seen_sync, seen_def)) and late and (n_sync, n_def) == (0, 3)
-    q.put((rank, ok_b, ok_g, ok_a, ok_s, ok_d))
+    # 6. bucketed reduction (GradReduceStep.early): the tail bucket of the flat gradient is all-reduced first, the head bucket by
+    #    submit() -- element-wise sums, so the step sees the values of the one flat all-reduce, synchronous or deferred
+    def run_buckets(bucketed, defer):
+        p = torch.linspace(-1, 1, 64).clone()
+        red = D.GradReduceStep()
+        for upd in range(3):
+            red.fence()
+            grad = torch.cos(p * (upd + 2)) * (rank + 1)
+
+            def step(scale, grad=grad):
+                p.sub_(0.05 * grad * scale)
+            if bucketed:
+                red.early(grad[40:])          # (the step function reads the whole buffer: both buckets must be summed by then)
+                red.submit(grad[:40], step, defer=defer)
+            else:
+                red.submit(grad, step, defer=defer)
+        red.fence()
+        return p, red.early_buckets
+    p_flat, n0 = run_buckets(False, False)
+    p_b, n1 = run_buckets(True, False)
+    p_bd, n2 = run_buckets(True, True)
+    ok_e = torch.equal(p_flat, p_b) and torch.equal(p_flat, p_bd) and (n0, n1, n2) == (0, 3, 3)
+    q.put((rank, ok_b, ok_g, ok_a, ok_s, ok_d, ok_e))
     torch.distributed.destroy_process_group()
 
 

@@ -24,7 +24,7 @@ torch.cuda.set_device(dev)
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(%(port)d), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 calls = [0]
-def reduce_gradients(flat):   # world size 1 would skip the collective: issue it anyway (sum over one rank = identity)
+def reduce_gradients(flat, exposed=True):   # world size 1 would skip the collective: issue it anyway (sum over one rank = identity)
     calls[0] += 1
     dist.all_reduce(flat)
     return 1.0
@@ -32,7 +32,7 @@ D.reduce_gradients = reduce_gradients
 out = []
 for graphs, overlap in ((False, False), (True, True)):
     cfg = near_target_config(NUM_PROCESSES=3, num_steps=4, num_updates_per_cycle=2, ppo_epoch=2, MAX_EPISODE_STEPS=4,
-                             use_hip_graphs=graphs, overlap_grad_reduce=overlap)
+                             use_hip_graphs=graphs, overlap_grad_reduce=overlap, bucketed_grad_reduce=overlap)
     tr = PPOTrainer(cfg, dev)
     tr.setup()
     tr.actor_critic.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.policy_shapes(), 5).items()})
@@ -43,12 +43,12 @@ for graphs, overlap in ((False, False), (True, True)):
     out.append(({k: v.detach().cpu().clone() for k, v in tr.actor_critic.state_dict().items()}, res["pol_losses"], res["sep_losses"]))
     if graphs:
         assert tr._graph_state is not None and len(tr._graph_state.graphs) >= 2 and tr.agent._pol_graph.graph is not None
-        assert tr.agent._reducers["pol"].deferred_steps == 6
+        assert tr.agent._reducers["pol"].deferred_steps == 6 and tr.agent._reducers["pol"].early_buckets == 3 * 2 * 2
 (wa, pa, sa), (wb, pb, sb) = out
 assert pa == pb and sa == sb, (pa, pb, sa, sb)
 for k in wa:
     assert torch.equal(wa[k], wb[k]), k
-assert calls[0] == 2 * 3 * 2 * 2 * 2   # 2 runs x 3 cycles x (2 update_pol + 2 update_sep) x 2 epochs
+assert calls[0] == 3 * 2 * 2 * 2 + 3 * (2 * 2 + 2) * 2   # 3 cycles x (2 update_pol + 2 update_sep) x 2 epochs; the second run: two buckets per policy epoch
 dist.destroy_process_group()
 print("OK", calls[0])
 '''
@@ -100,6 +100,7 @@ seeds = [torch.zeros_like(obs_seed) for _ in range(2)]
 dist.all_gather(seeds, obs_seed)
 assert not torch.equal(seeds[0], seeds[1])                                   # each rank rolled out its own environments (seed + 3*rank)
 assert tr.agent._reducers["pol"].deferred_steps == 6 and tr._graph_state is not None and tr.agent._pol_graph.graph is not None
+assert tr.agent._bucketed() and tr.agent._pol_graph.graph_rest is not None and tr.agent._reducers["pol"].early_buckets == 3 * 2 * 2
 assert float(stats[1]) == 2 * 3 * 3 * 2                                      # finished episodes summed over both ranks (3 cycles x 2 x 3 envs x 2 ranks)
 dist.barrier()
 dist.destroy_process_group()

@@ -61,6 +61,33 @@ def test_overlapped_grad_reduce_schedule_gives_the_synchronous_weights():
     assert torch.equal(va, vb) and torch.equal(ma, mb)
 
 
+@pytest.mark.parametrize("graphs", [False, True])
+def test_bucketed_grad_reduce_schedule_gives_the_flat_schedule_weights(graphs):
+    """The policy gradient's all-reduce in two buckets (ppo.py:286-319 is DDP's bucketed reducer): the backward stops at the encoders'
+    features, the recurrent encoder's and the heads' slice of the flat gradient goes to the side stream, the encoders' backward follows
+    -- as two HIP graphs per epoch when graphs are on.  Forced on at world size 1 (no collective: the schedule, the split backward and
+    the partial gathers are what is tested): bit-identical weights, losses and storages to the one-backward / one-buffer schedule."""
+    runs = []
+    for bucketed in (False, True):
+        tr, _ = _trainer(bucketed_grad_reduce=bucketed, overlap_grad_reduce=True, use_hip_graphs=graphs)
+        losses = []
+        for c in range(3):
+            torch.manual_seed(700 + c)
+            res = tr.train_cycle()
+            losses.append((res["pol_losses"], res["sep_losses"]))
+        red = tr.agent._reducers["pol"]
+        assert red.early_buckets == (3 * 2 * 2 if bucketed else 0)     # cycles x updates x epochs
+        if graphs and bucketed:
+            assert tr.agent._pol_graph.graph is not None and tr.agent._pol_graph.graph_rest is not None
+        sd = {k: v.detach().cpu().clone() for k, v in tr.actor_critic.state_dict().items()}
+        runs.append((losses, sd, tr.rollouts_pol.value_preds.cpu().clone()))
+    (la, sa, va), (lb, sb, vb) = runs
+    assert la == lb
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert torch.equal(va, vb)
+
+
 def test_hip_graph_rollout_equals_the_kernel_by_kernel_rollout():
     """The rollout step replayed from a HIP graph (device-indexed storage rows, static separator-output buffers, in-place
     packed weights) must leave bit-identical storages, statistics, sampled actions and -- after the updates -- weights."""
