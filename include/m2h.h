@@ -180,61 +180,6 @@ int m2h_unet_head_fwd(const float* x, const float* wp, const float* bias, float*
                       int B, int H, int W, int Ci, int Co, m2h_stream stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Small-batch convolution engine (csrc/conv_small.hip, fp32 MFMA): the layers of the separator U-Nets (separator_cnn.py:46-52,
- * :128-135) and of the policy's audio encoders (audio_cnn.py:50-75) at the ROLLOUT batch (ppo_trainer.py:295-373: 14 envs).
- * One launch per layer and no reduce launches: K is split over workgroups by input-channel group; the partial sums of the
- * groups go to Ctot / channels_per_block slabs, and the CONSUMER's input stager sums a source's slabs in slab order and
- * applies the producer's epilogue (folded BatchNorm scale / shift, leaky slope) -- so a source here is "S slabs + epilogue".
- *   src[k]: NHWC [S][B][Hi][Wi][C] partial sums (S == 1, scale == NULL, slope == 1: a plain tensor); the two sources are
- *           concatenated along channels (the skip concat of separator_cnn.py:160-161 is never materialised).
- *   mix / masks: the first stage's input instead of src[0]: BHWC [B][16*Hi][Wi][2], sliced 16-way on the fly into 32
- *           channels c*16 + band (separator_cnn.py:85-90) with, for bin2mono, log1p(max(0, masks*(exp(mix)-1))) (:73-79).
- *   conv_transpose 0: Conv2d(KH x KW, stride, pad), wp from m2h_pack_conv_weight(_ex): [N][KH][KW][Ctot];
- *                  1: ConvTranspose2d(4, 2, 1), wp from m2h_pack_convT_weight: [4][N][2][2][Ctot] (the four sub-pixel phases
- *                     are four wave groups of one workgroup).
- *   tiling: a workgroup computes images_per_tile images x rows_per_tile rows (output rows; input rows for a transposed
- *           conv) x all columns -- at most 64 GEMM rows (per phase) -- for cols_per_block (multiple of 16) output channels
- *           from channels_per_block (power of two >= 16, dividing C of both sources) input channels and every tap, with
- *           k_waves waves splitting that reduction; waves = (4 if transposed) * cols_per_block/16 * k_waves <= 16.
- *   finish 0: dst = raw partial sums [Ctot/channels_per_block][B][Ho][Wo][N], slabs dst_slab floats apart;
- *          1: (channels_per_block == Ctot) dst = act((sum + cls_val[b]*cls_table[border class][n]) * scale[n] + shift[n]), NHWC;
- *          2: as 1, then the 1x1 head (head_w [N][N], head_b [N]; cols_per_block == N) and the de-sliced BHWC store
- *             dst[b][band*Ho + oh][ow][c] for channel n = c*16 + band (separator_cnn.py:134, :163-168).
- * ------------------------------------------------------------------------------------------------------------------ */
-typedef struct m2h_small_src {
-  const float* p;
-  const float* scale; /* [C] or NULL (= 1); comes with shift */
-  const float* shift; /* [C] or NULL (= 0) */
-  float slope;        /* y = v > 0 ? v : v*slope after scale/shift (1 = identity) */
-  int C, S;
-  size_t slab;        /* floats between slabs */
-} m2h_small_src;
-
-typedef struct m2h_small_conv_args {
-  m2h_small_src src[2]; /* src[1].C == 0: one source */
-  const float* mix;     /* first-stage input, or NULL */
-  const float* masks;   /* with mix: bin2mono pre-op, or NULL */
-  int B, Hi, Wi;
-  int conv_transpose;
-  int KH, KW, stride, pad; /* conv_transpose == 0 */
-  const float* wp;
-  int N;
-  int images_per_tile, rows_per_tile, channels_per_block, cols_per_block, k_waves;
-  float* dst;
-  size_t dst_slab;
-  int finish;
-  const float* scale;
-  const float* shift;
-  float slope;
-  const float* cls_table; /* [9][N] or NULL: the (target_class + 1) plane of the first binSep stage (m2h_unet_class_table) */
-  const float* cls_val;   /* [B] */
-  const float* head_w;
-  const float* head_b;
-} m2h_small_conv_args;
-
-int m2h_conv_small_fwd(const m2h_small_conv_args* args /* host */, m2h_stream stream);
-
-/* ------------------------------------------------------------------------------------------------------------------
  * RL path (forward): layout glue, GRU cell, heads, scans and reductions.  All fp32, all HBM-bound or tiny.
  * ------------------------------------------------------------------------------------------------------------------ */
 
@@ -670,13 +615,6 @@ int m2h_unet_fwd(const m2h_unet_weights* w /* host */, const float* mix, const f
 int m2h_unet_fwd_events(const m2h_unet_weights* w /* host */, const float* mix, const float* masks, const float* cls_val, float* out,
                         int B, int F, int T, void* workspace, size_t workspace_bytes, void* const* events, int n_events,
                         m2h_stream stream);
-/* With tuning knob 37 set (include/m2h_tuning.h), batches of at most 32 reference-native clips (T == 32) in fp32 arithmetic -- the rollout step's 14
- * environments (ppo_trainer.py:295-373) -- run on the small-batch engine (m2h_conv_small_fwd): ten launches, the slice fused into the
- * first stage, the head into the last, no reduce launches; interval 0 of m2h_unet_fwd_events is then empty, 1-10 are the ten stages.
- * m2h_unet_small_tiling overrides, for the CALLING THREAD, the tiling of stage 0-9 (0 = the built-in value): a tuning hook
- * (tools/small_tune.py), thread-local like the arithmetic mode; results do not depend on it beyond fp32 association. */
-int m2h_unet_small_tiling(int stage, int images_per_tile, int rows_per_tile, int channels_per_block, int cols_per_block, int k_waves);
-
 /* Which kernel ran: the label of the calling thread's most recent launch through this library (thread-local, like the error
  * string), and the labels of the 11 stages of its most recent m2h_unet_fwd / m2h_unet_fwd_events call (stage numbering as the
  * event intervals above).  For benchmark tables and profiles -- the dispatch rules live in the library, not in its callers. */

@@ -8,12 +8,7 @@ thread_local const char* tl_last_launch = "";
 thread_local const char* tl_unet_stage[11] = {"", "", "", "", "", "", "", "", "", "", ""};
 int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st);
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a);
-int conv_small_fwd(const m2h_small_conv_args& a, hipStream_t st);
-thread_local int tl_small_tiling[10][5] = {};   // per-thread tiling override of the small-batch runner (m2h_unet_small_tiling): 0 = the table's
 thread_local Tuning tl_tuning = {};   // every knob 0 = automatic (m2h_internal.h)
-// knob 37 (g_small) = 1: the whole-network runner takes the small-batch engine (csrc/conv_small.hip) for rollout-size batches.  Off by
-// default: measured at parity with the tiled engines (274 vs 282 us per separator pair at 14 envs), kept for the tests and
-// further tuning
 extern thread_local int tl_math_mode;
 extern thread_local int tl_hi_only;
 }  // namespace m2h
@@ -148,11 +143,8 @@ static const int kEnc[6] = {32, 64, 128, 256, 512, 512};
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 struct UnetLayout {
-  size_t x0, e[5], d[5], splitk, slabs[10], total;
+  size_t x0, e[5], d[5], splitk, total;
 };
-
-// The small-batch runner (csrc/conv_small.hip) takes rollout-size batches of reference-native clips in fp32 arithmetic
-static bool unet_small_shape(int B, int F, int T) { return F == 512 && T == 32 && B <= 32; }
 
 static UnetLayout unet_layout(int B, int F, int T, int n_out) {
   UnetLayout L;
@@ -184,18 +176,6 @@ static UnetLayout unet_layout(int B, int F, int T, int n_out) {
     h *= 2; w *= 2;
   }
   L.splitk = off; off += align256(sk);
-  // partial-sum slabs of the small-batch runner: stage i's output as up to Ctot_next / 32 ... its own Ctot / 32 channel-group slabs
-  for (int i = 0; i < 10; ++i) L.slabs[i] = 0;
-  if (unet_small_shape(B, F, T)) {
-    const int cin[10] = {32, 64, 128, 256, 512, 512, 1024, 512, 256, 128};
-    const int cout[10] = {64, 128, 256, 512, 512, 512, 256, 128, 64, n_out};
-    int hh = H, ww = T;
-    for (int i = 0; i < 9; ++i) {          // (the last stage writes the network's output)
-      if (i < 5) { hh /= 2; ww /= 2; } else { hh *= 2; ww *= 2; }
-      L.slabs[i] = off;
-      off += align256((size_t)(cin[i] / 32) * B * hh * ww * cout[i] * 4);
-    }
-  }
   L.total = off;
   return L;
 }
@@ -203,93 +183,6 @@ static UnetLayout unet_layout(int B, int F, int T, int n_out) {
 size_t m2h_unet_fwd_workspace_bytes(int B, int F, int T) {
   if (B <= 0 || F <= 0 || T <= 0) return 0;
   return unet_layout(B, F, T, 32).total;
-}
-
-// ---- the same network on the small-batch engine: ten launches, no slice / reduce / epilogue launches (csrc/conv_small.hip) ----
-// tilings (images per tile, rows per tile, channels per block, columns per block, K waves) per stage, for batches of <= 16 images;
-// larger batches scale the images per tile down to keep a tile within 64 GEMM rows
-static const int kSmallTiling[10][5] = {   // tools/small_tune.py at 14 images (coordinate descent on the pair's graph replay time: 271 us)
-    {1, 2, 32, 32, 8},     // down0: 32 x 32 x 32 (sliced input) -> 16 x 16 x 64, finishes itself (class plane)
-    {1, 4, 64, 16, 16},    // down1: 16 x 16 x 64 -> 8 x 8 x 128 (one channel group: finishes itself)
-    {2, 4, 64, 16, 16},    // down2: 8 x 8 x 128 -> 4 x 4 x 256
-    {8, 2, 64, 16, 16},    // down3: 4 x 4 x 256 -> 2 x 2 x 512
-    {32, 1, 128, 16, 16},  // down4: 2 x 2 x 512 -> 1 x 1 x 512
-    {16, 1, 128, 16, 4},   // up0:   1 x 1 x 512 -> 2 x 2 x 512
-    {4, 2, 128, 32, 2},    // up1:   2 x 2 x 1024 -> 4 x 4 x 256
-    {1, 4, 128, 32, 2},    // up2:   4 x 4 x 512 -> 8 x 8 x 128
-    {1, 8, 64, 16, 4},     // up3:   8 x 8 x 256 -> 16 x 16 x 64
-    {1, 1, 128, 0, 2},     // up4 + head: 16 x 16 x 128 -> 32 x 32 x n_out (columns per block = n_out)
-};
-
-static int unet_fwd_small(const m2h_unet_weights* wts, const float* mix, const float* masks, const float* cls_val, float* out, int B,
-                          const UnetLayout& L, char* ws, void* const* events, int& ev, int& stage_no, hipStream_t st) {
-  auto mark = [&]() -> int {
-    if (stage_no > 0 && stage_no <= 11) tl_unet_stage[stage_no - 1] = tl_last_launch;
-    ++stage_no;
-    tl_last_launch = "(no launch: fused into the next stage)";
-    if (events == nullptr) return 0;
-    const hipError_t err = hipEventRecord(static_cast<hipEvent_t>(events[ev++]), st);
-    return err == hipSuccess ? 0 : fail((int)err, "unet_fwd: hipEventRecord failed: %s", hipGetErrorString(err));
-  };
-  int rc = mark();
-  if (rc) return rc;
-  if ((rc = mark())) return rc;   // (interval 0, the slice launch of the tiled path, is empty: the slice is part of the first stage)
-  const int cin[10] = {32, 64, 128, 256, 512, 512, 1024, 512, 256, 128};
-  const int cout[10] = {64, 128, 256, 512, 512, 512, 256, 128, 64, wts->n_out};
-  m2h_small_src prod[10];   // stage i's output as the next stages' source
-  int h = 32, w = 32;
-  for (int i = 0; i < 10; ++i) {
-    int t[5];
-    for (int k = 0; k < 5; ++k) t[k] = tl_small_tiling[i][k] ? tl_small_tiling[i][k] : kSmallTiling[i][k];
-    if (i == 9 && t[3] == 0) t[3] = wts->n_out;
-    m2h_small_conv_args a = {};
-    a.B = B; a.Hi = h; a.Wi = w;
-    const bool up = i >= 5;
-    a.conv_transpose = up ? 1 : 0;
-    a.KH = 4; a.KW = 4; a.stride = 2; a.pad = 1;
-    a.wp = up ? wts->up_w[i - 5] : wts->down_w[i];
-    a.N = cout[i];
-    if (i == 0) {
-      a.mix = mix; a.masks = masks;
-    } else {
-      a.src[0] = prod[i - 1];
-      if (i >= 6) a.src[1] = prod[9 - i];       // skip: up1 <- down3, up2 <- down2, up3 <- down1, up4 <- down0
-    }
-    const int rows = up ? h : h / 2, wt = up ? w : w / 2;     // rows the tiles walk, pixels per tile row
-    int ib = t[0], qr = t[1] < rows ? t[1] : rows;
-    while (ib > 1 && (ib > B || ib * qr * wt > 64)) --ib;
-    while (qr > 1 && ib * qr * wt > 64) --qr;
-    a.images_per_tile = ib; a.rows_per_tile = qr; a.channels_per_block = t[2]; a.cols_per_block = t[3]; a.k_waves = t[4];
-    const int ho = up ? 2 * h : h / 2, wo = up ? 2 * w : w / 2;
-    if (i == 9) {
-      a.dst = out; a.finish = 2;
-      a.scale = wts->up_scale[4]; a.shift = wts->up_shift[4]; a.slope = 0.f; a.head_w = wts->head_w; a.head_b = wts->head_b;
-      M2H_REQUIRE(a.head_w != nullptr && a.head_b != nullptr, "unet_fwd: null head");
-    } else {
-      a.dst = reinterpret_cast<float*>(ws + L.slabs[i]);
-      a.dst_slab = (size_t)B * ho * wo * cout[i];
-      if (i == 0) {
-        a.finish = 1; a.scale = wts->down_scale[0]; a.shift = wts->down_shift[0]; a.slope = 0.2f; a.cls_table = wts->cls_table; a.cls_val = cls_val;
-        prod[0] = {a.dst, nullptr, nullptr, 1.f, cout[0], 1, a.dst_slab};
-      } else {
-        M2H_REQUIRE(cin[i] / t[2] <= cin[i] / 32, "unet_fwd: small-batch tiling of stage %d: fewer than 32 channels per block", i);
-        const float* sc = up ? wts->up_scale[i - 5] : wts->down_scale[i];
-        const float* sf = up ? wts->up_shift[i - 5] : wts->down_shift[i];
-        const float sl = up ? 0.f : 0.2f;
-        if (t[2] == cin[i]) {   // one channel group: the stage applies its own folded BatchNorm + activation, its output is a plain tensor
-          a.finish = 1; a.scale = sc; a.shift = sf; a.slope = sl;
-          prod[i] = {a.dst, nullptr, nullptr, 1.f, cout[i], 1, a.dst_slab};
-        } else {
-          prod[i] = {a.dst, sc, sf, sl, cout[i], cin[i] / t[2], a.dst_slab};
-        }
-      }
-    }
-    if ((rc = conv_small_fwd(a, st))) return rc;
-    tl_last_launch = i == 0 ? "conv_small (slice + stage)" : (i == 9 ? "conv_small (stage + head)" : "conv_small");
-    if ((rc = mark())) return rc;
-    h = ho; w = wo;
-  }
-  return 0;
 }
 
 static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const float* masks, const float* cls_val, float* out, int B, int F,
@@ -312,7 +205,7 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
     d[i] = reinterpret_cast<float*>(ws + L.d[i]);
   }
   void* sk = ws + L.splitk;
-  const size_t skb = (L.slabs[0] ? L.slabs[0] : L.total) - L.splitk;
+  const size_t skb = L.total - L.splitk;
   hipStream_t st = as_stream(stream);
   int ev = 0, stage_no = 0;
   auto mark = [&]() -> int {
@@ -328,12 +221,6 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
   const int fmt_math = math == 1 ? M2H_FMT_MATH_BF16X3 : M2H_FMT_MATH_FP32;   // every launch of this call pinned to its arithmetic
   const int fmt_mid = fmt_math | (sp ? (M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT | M2H_FMT_DST_SPLIT) : 0);
   const int fmt_last = fmt_math | (sp ? (M2H_FMT_SRC_SPLIT | M2H_FMT_W_SPLIT) : 0);
-  if (math == 0 && !sp && unet_small_shape(B, F, T) && g_small > 0) {
-    // rollout-size batches (ppo_trainer.py:295-373) in fp32 arithmetic: the small-batch engine, ten launches
-    int rcs = unet_fwd_small(wts, mix, masks, cls_val, out, B, L, ws, events, ev, stage_no, st);
-    if (rcs) return rcs;
-    return 0;
-  }
   int rc = mark();
   if (rc) return rc;
   // slice + first encoder stage as one strip-walker launch (csrc/conv_strip.hip) where its shape conditions hold
@@ -392,13 +279,6 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
   M2H_REQUIRE(a.head_w != nullptr && a.head_b != nullptr, "unet_fwd: null head");
   if ((rc = conv_igemm_f32(a, st))) return rc;
   return mark();
-}
-
-int m2h_unet_small_tiling(int stage, int images_per_tile, int rows_per_tile, int channels_per_block, int cols_per_block, int k_waves) {
-  M2H_REQUIRE(stage >= 0 && stage < 10, "unet_small_tiling: stage %d", stage);
-  const int v[5] = {images_per_tile, rows_per_tile, channels_per_block, cols_per_block, k_waves};
-  for (int k = 0; k < 5; ++k) tl_small_tiling[stage][k] = v[k];
-  return 0;
 }
 
 int m2h_unet_fwd(const m2h_unet_weights* wts, const float* mix, const float* masks, const float* cls_val, float* out, int B, int F,

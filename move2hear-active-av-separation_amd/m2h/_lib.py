@@ -16,7 +16,7 @@ CSRC = os.path.join(_PKG_ROOT, "csrc")
 INCLUDE = os.path.join(_REPO_ROOT, "include")
 # M2H_LIB: kernel-tuning override -- load an experimental build of the same C-ABI (tools/build_variant.sh) instead of the in-tree one
 LIB_PATH = os.environ.get("M2H_LIB") or os.path.join(_HERE, "libm2h.so")
-SOURCES = ["conv_igemm.hip", "conv_dma.hip", "conv_patch.hip", "convt_quad.hip", "conv_strip.hip", "conv_small.hip", "acoustic_mem.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "rollout_fused.hip", "pack_batch.hip", "fftconv.hip", "api.hip"]
+SOURCES = ["conv_igemm.hip", "conv_dma.hip", "conv_patch.hip", "convt_quad.hip", "conv_strip.hip", "acoustic_mem.hip", "conv_bwd.hip", "bn.hip", "stft.hip", "layout.hip", "rl_ops.hip", "rollout_fused.hip", "pack_batch.hip", "fftconv.hip", "api.hip"]
 
 _lock = threading.Lock()
 _lib = None
@@ -90,27 +90,6 @@ class ConvArgs(ctypes.Structure):
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
         ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p),
         ("operand_format", ctypes.c_int),
-    ]
-
-
-class SmallSrc(ctypes.Structure):
-    """Mirror of ``struct m2h_small_src`` (include/m2h.h)."""
-    _fields_ = [("p", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("slope", ctypes.c_float),
-                ("C", ctypes.c_int), ("S", ctypes.c_int), ("slab", ctypes.c_size_t)]
-
-
-class SmallConvArgs(ctypes.Structure):
-    """Mirror of ``struct m2h_small_conv_args`` (include/m2h.h)."""
-    _fields_ = [
-        ("src", SmallSrc * 2), ("mix", ctypes.c_void_p), ("masks", ctypes.c_void_p),
-        ("B", ctypes.c_int), ("Hi", ctypes.c_int), ("Wi", ctypes.c_int), ("conv_transpose", ctypes.c_int),
-        ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int),
-        ("wp", ctypes.c_void_p), ("N", ctypes.c_int),
-        ("images_per_tile", ctypes.c_int), ("rows_per_tile", ctypes.c_int), ("channels_per_block", ctypes.c_int),
-        ("cols_per_block", ctypes.c_int), ("k_waves", ctypes.c_int),
-        ("dst", ctypes.c_void_p), ("dst_slab", ctypes.c_size_t), ("finish", ctypes.c_int),
-        ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("slope", ctypes.c_float),
-        ("cls_table", ctypes.c_void_p), ("cls_val", ctypes.c_void_p), ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p),
     ]
 
 
@@ -267,9 +246,7 @@ SIGNATURES = {
     "m2h_synth_env_step": [_P, _P, _P, _I, _I, _P],
     "m2h_synth_env_observe": [_P, _I, _P, _P, _P, _I, _P],
     "m2h_stft_l2": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
-    "m2h_conv_small_fwd": [ctypes.POINTER(SmallConvArgs), _P],
     "m2h_acoustic_mem_small_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "m2h_unet_small_tiling": [_I, _I, _I, _I, _I, _I],
 }
 
 

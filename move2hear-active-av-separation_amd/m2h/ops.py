@@ -997,76 +997,6 @@ def unet_up_head_fwd(x, skip, wp, scale, shift, head_w, head_b, Co):
     return out
 
 
-def conv_small(srcs, wp, N, B, Hi, Wi, conv_transpose=False, KH=4, KW=4, stride=2, pad=1, tiling=None, finish=0, scale=None,
-               shift=None, slope=1.0, cls_table=None, cls_val=None, head_w=None, head_b=None, mix=None, masks=None, out=None):
-    """One layer on the small-batch conv engine (m2h_conv_small_fwd; csrc/conv_small.hip).
-    srcs: list of 1-2 sources ``(tensor, scale, shift, slope)``; tensor [S,B,Hi,Wi,C] (S partial-sum slabs) or [B,Hi,Wi,C];
-    with ``mix`` (BHWC [B,16*Hi,Wi,2], optional ``masks``) the first stage's sliced input replaces them.
-    tiling: (images_per_tile, rows_per_tile, channels_per_block, cols_per_block, k_waves).
-    finish 0 -> raw partial sums [Ctot/channels_per_block, B, Ho, Wo, N]; 1 -> NHWC [B,Ho,Wo,N]; 2 -> de-sliced BHWC [B,16*Ho,Wo,N/16]."""
-    lib = _lib.load()
-    a = _lib.SmallConvArgs()
-    keep = []
-    ctot = 0
-    if mix is not None:
-        _chk(mix, "conv_small")
-        a.mix = _ptr(mix)
-        if masks is not None:
-            _chk(masks, "conv_small")
-            a.masks = _ptr(masks)
-        ctot = 32
-        dev = mix.device
-    else:
-        for k, (t, sc, sh, sl) in enumerate(srcs):
-            _chk(t, "conv_small")
-            t5 = t if t.dim() == 5 else t.unsqueeze(0)
-            if tuple(t5.shape[1:4]) != (B, Hi, Wi):
-                raise RuntimeError("m2h.conv_small: source %d is %s, expected [S, %d, %d, %d, C]" % (k, tuple(t5.shape), B, Hi, Wi))
-            s = a.src[k]
-            s.p, s.C, s.S, s.slab, s.slope = _ptr(t5), t5.shape[4], t5.shape[0], t5[0].numel(), float(sl)
-            if sc is not None:
-                _chk(sc, "conv_small")
-                _chk(sh, "conv_small")
-                s.scale, s.shift = _ptr(sc), _ptr(sh)
-                keep += [sc, sh]
-            ctot += t5.shape[4]
-        dev = srcs[0][0].device
-    _chk(wp, "conv_small")
-    a.B, a.Hi, a.Wi, a.conv_transpose = B, Hi, Wi, 1 if conv_transpose else 0
-    a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
-    a.wp, a.N = _ptr(wp), N
-    ib, qr, cg, cols, kwv = tiling
-    a.images_per_tile, a.rows_per_tile, a.channels_per_block, a.cols_per_block, a.k_waves = ib, qr, cg, cols, kwv
-    if conv_transpose:
-        Ho, Wo = 2 * Hi, 2 * Wi
-    else:
-        Ho, Wo = (Hi + 2 * pad - KH) // stride + 1, (Wi + 2 * pad - KW) // stride + 1
-    if finish == 0:
-        shape = (ctot // cg, B, Ho, Wo, N)
-    elif finish == 1:
-        shape = (B, Ho, Wo, N)
-    else:
-        shape = (B, 16 * Ho, Wo, N // 16)
-    if out is None:
-        out = torch.empty(shape, device=dev, dtype=torch.float32)
-    elif tuple(out.shape) != shape or not out.is_contiguous():
-        raise RuntimeError("m2h.conv_small: out must be a contiguous %s tensor" % (shape,))
-    a.dst, a.dst_slab, a.finish, a.slope = _ptr(out), (out[0].numel() if finish == 0 else 0), finish, float(slope)
-    for name, t in (("scale", scale), ("shift", shift), ("cls_table", cls_table), ("cls_val", cls_val), ("head_w", head_w), ("head_b", head_b)):
-        if t is not None:
-            _chk(t, "conv_small")
-            setattr(a, name, _ptr(t))
-    with torch.cuda.device(dev):
-        _lib.check(lib.m2h_conv_small_fwd(ctypes.byref(a), _stream(out)), "m2h_conv_small_fwd")
-    return out
-
-
-def unet_small_tiling(stage, tiling=None):
-    """Tuning hook (thread-local): the small-batch runner's tiling of stage 0-9, None = the built-in one (m2h_unet_small_tiling)."""
-    t = tuple(tiling) if tiling is not None else (0, 0, 0, 0, 0)
-    _lib.check(_lib.load().m2h_unet_small_tiling(int(stage), *[int(v) for v in t]), "m2h_unet_small_tiling")
-
-
 def acoustic_mem_small(pred_mono, prev_mem, not_done, w0p, w1p):
     """AcousticMem's forward for a small batch in one launch (m2h_acoustic_mem_small_fwd): BHWC [B,512,32,1] x 2 (+ not-done flags [B])
     -> [B,512,32,1]; w0p / w1p: the packed conv weights [32, 288] / [16, 288]."""

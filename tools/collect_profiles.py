@@ -2,7 +2,7 @@
 """Copies the summaries of tools/profile_round3.sh (gpurun_out/r03) into profiles/ (tracked) and derives the two JSON files bench.py
 reads back: r03_pmc_hbm_traffic.json (HBM bytes per launch of every headline kernel: 2 x FETCH_SIZE + WRITE_SIZE, the guide's
 gfx950 correction for wide coalesced reads) and r03_ddppo_summary.json (launches and kernel time per DD-PPO cycle).
-usage: python tools/collect_profiles.py [gpurun_out/r04] [r04]"""
+usage: python tools/collect_profiles.py [gpurun_out/r05] [r05]"""
 import csv
 import json
 import os
@@ -78,7 +78,7 @@ if group:
                      "traffic_bytes_per_launch": int(sum(kern[k]["traffic_bytes_per_launch"] * ncalls.get(k, 0) for k in group) / tot)}
 if dom is None:
     dom = next((k for k in kern if k.startswith("m2h::igemm_dma_kernel")), None)
-src = "profiles/%s_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1 --no-other-mode --no-graph; tools/profile_round4.sh)" % TAG
+src = "profiles/%s_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1 --no-other-mode --no-graph; tools/profile_round%s.sh)" % (TAG, TAG[-1])
 traffic = {"bf16x3": dict(kern.get(dom, {}), source=src, kernel=dom), "per_kernel": kern}
 with open(os.path.join(DST, TAG + "_pmc_hbm_traffic.json"), "w") as f:
     json.dump(traffic, f, indent=1)
