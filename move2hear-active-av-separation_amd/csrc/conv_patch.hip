@@ -42,6 +42,16 @@
 #include "igemm_common.h"
 #include "lds_dma.h"
 
+#ifndef M2H_PATCH_W_AT
+#define M2H_PATCH_W_AT 0   // weight-fragment step of a k-tile's second half behind which the weight DMAs are issued (A/B builds)
+#endif
+#ifndef M2H_PATCH_P_AT
+#define M2H_PATCH_P_AT 1   // ... the patch DMAs
+#endif
+#ifndef M2H_PATCH_PRIO
+#define M2H_PATCH_PRIO 0   // 1: s_setprio 1 for waves 4-7 (the younger wave of every SIMD) for the whole kernel (A/B builds)
+#endif
+
 namespace m2h {
 
 // (tuning knob g_patch: thread-local, m2h_internal.h) m2h_tuning_set 36: -1 never use this engine; 2 = also below its tile-count threshold (tests); 3 = as 2, and the whole-image patch wherever it fits
@@ -441,6 +451,7 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   };
 
   // ---- pipeline ----
+  if (M2H_PATCH_PRIO && wave >= PNW / 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int k = 0; k < SCN; ++k) {
     const int n = tid + 64 * PNW * k;
@@ -505,10 +516,10 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
       mfma_col(IH{}, IF{}, nic);
       __builtin_amdgcn_sched_barrier(0);
       load_b(ns, nic);
-      if constexpr (decltype(nic)::value == 0 && decltype(issue_w)::value) issue_weights();
-      if constexpr (decltype(nic)::value == 1 && decltype(issue_p)::value == 1) issue_patch(std::integral_constant<int, 1>{});
-      if constexpr (decltype(nic)::value == 1 && decltype(issue_p)::value == 2) issue_patch(std::integral_constant<int, 2>{});
-      if constexpr (decltype(nic)::value == 1 && decltype(issue_p)::value == 3) {
+      if constexpr (decltype(nic)::value == M2H_PATCH_W_AT && decltype(issue_w)::value) issue_weights();
+      if constexpr (decltype(nic)::value == M2H_PATCH_P_AT && decltype(issue_p)::value == 1) issue_patch(std::integral_constant<int, 1>{});
+      if constexpr (decltype(nic)::value == M2H_PATCH_P_AT && decltype(issue_p)::value == 2) issue_patch(std::integral_constant<int, 2>{});
+      if constexpr (decltype(nic)::value == M2H_PATCH_P_AT && decltype(issue_p)::value == 3) {
         if (more_patches) issue_patch(I0{});
       }
       __builtin_amdgcn_sched_barrier(0);

@@ -116,11 +116,19 @@ class PPO(nn.Module):
         return [q for q in list(ac.pol_net.state_encoder.parameters()) + list(ac.action_dist.parameters()) + list(ac.critic.parameters())
                 if q.requires_grad]
 
-    def _reduce_and_step(self, group, opt, last):
+    def _reduce_and_step(self, group, opt, last, reduced_tail=None):
         """One flat sum all-reduce (RCCL) + clip + Adam.  The last mini-batch of an update is deferred onto the side stream
-        when overlap is on: nothing in the rest of the update reads these parameters (ddppo_utils.GradReduceStep)."""
+        when overlap is on: nothing in the rest of the update reads these parameters (ddppo_utils.GradReduceStep).
+        reduced_tail: parameters whose bucket ``GradReduceStep.early`` has already all-reduced (the tail of the flat buffer): the
+        collective here covers the rest of the buffer only."""
+        flat = opt.grad_buffer()
+        if reduced_tail is not None:
+            b0, b1, _idx = opt.param_range(reduced_tail)
+            if b1 != flat.numel():
+                raise RuntimeError("bucketed gradient reduction: the early bucket must be the tail of the flat buffer")
+            flat = flat[:b0]
         self._reducers[group].submit(
-            opt.grad_buffer(), lambda gscale: opt.step(max_grad_norm=self.max_grad_norm, grad_scale=gscale),
+            flat, lambda gscale: opt.step(max_grad_norm=self.max_grad_norm, grad_scale=gscale),
             defer=last and self._overlap())
 
     def synchronize_updates(self):
@@ -172,14 +180,16 @@ class PPO(nn.Module):
         acc = torch.zeros(4, device=self.device)
         for _e in range(self.ppo_epoch):
             for _mb, sample in enumerate(rollouts_pol.recurrent_generator(advantages, self.num_mini_batch)):
+                tail = None
                 if self._bucketed():
+                    tail = self._tail_bucket_params()
                     feats = self._pol_epoch(sample, float(self.clip_param), acc, split=True)
-                    self._reducers["pol"].early(self.optimizer_pol.grad_bucket(self._tail_bucket_params()))
+                    self._reducers["pol"].early(self.optimizer_pol.grad_bucket(tail))
                     self._pol_epoch_rest(feats)
                 else:
                     self._pol_epoch(sample, float(self.clip_param), acc)
                 self._reduce_and_step("pol", self.optimizer_pol,  # before_step_pol + step
-                                      last=_e == self.ppo_epoch - 1 and _mb == self.num_mini_batch - 1)
+                                      last=_e == self.ppo_epoch - 1 and _mb == self.num_mini_batch - 1, reduced_tail=tail)
         num_updates = self.ppo_epoch * self.num_mini_batch
         v, a, h, _ = (acc / num_updates).tolist()  # the only host read of the update
         return v, a, h
@@ -243,10 +253,12 @@ class PPO(nn.Module):
                 # queued behind the rollout's replays its side queues' parked barrier packets slow every kernel boundary ahead of it
                 torch.cuda.current_stream().synchronize()
             graphs.replay(gs.graph)
+            tail = None
             if gs.bucketed:
-                self._reducers["pol"].early(self.optimizer_pol.grad_bucket(self._tail_bucket_params()))
+                tail = self._tail_bucket_params()
+                self._reducers["pol"].early(self.optimizer_pol.grad_bucket(tail))
                 graphs.replay(gs.graph_rest)
-            self._reduce_and_step("pol", self.optimizer_pol, last=_e == self.ppo_epoch - 1)
+            self._reduce_and_step("pol", self.optimizer_pol, last=_e == self.ppo_epoch - 1, reduced_tail=tail)
         v, a, h, _ = (gs.acc / self.ppo_epoch).tolist()
         return v, a, h
 

@@ -28,8 +28,13 @@ def test_bench_gpus_2_spawns_two_ranks_and_reports_them():
     # the stream they ran on), a stand-alone all-reduce of the policy gradient's size, and who ran where
     ph = line["ddppo"]["phases"]
     assert ph["rollout_ms"] > 0 and ph["update_pol_ms"] > 0 and ph["update_sep_ms"] > 0
-    assert ph["grad_allreduce_count"] == 48 and ph["grad_allreduce_ms"] > 0 and ph["allreduce_23MB_us"] > 0   # 6 x 4 policy + 6 x 4 memory steps per cycle
-    assert ph["policy_grad_bytes"] in ph["grad_allreduce_payload_bytes"] and ph["policy_grad_bytes"] > 20e6
+    # 6 x 4 policy backward passes in two buckets each (recurrent encoder + heads under the encoders' backward, then the encoders) + 6 x 4 memory steps
+    assert ph["grad_allreduce_count"] == 72 and ph["grad_allreduce_ms"] > 0 and ph["allreduce_23MB_us"] > 0
+    # exposed (enqueued on the compute stream): the encoders' bucket of 3 of every 4 policy epochs, 3 of every 4 memory steps; the rest run on the side stream
+    assert ph["grad_allreduce_exposed_count"] == 18 + 18 and 0 < ph["grad_allreduce_exposed_ms"] <= ph["grad_allreduce_ms"]
+    pay = ph["grad_allreduce_payload_bytes"]
+    assert len(pay) == 3 and pay[0] + pay[1] == ph["policy_grad_bytes"] > 20e6 and pay[2] < 100e3   # two policy buckets, the acoustic memory
+    assert line["ddppo"]["roofline"]["phases"]["rollout"]["m2h_kernel_launches_per_cycle"] > 1000
     devs = line["ddppo"]["devices"]
     assert [d["rank"] for d in devs] == [0, 1] and all(d["name"] for d in devs) and line["ddppo"]["distinct_devices"] == 1   # (both ranks share the box's card here)
     rf = line["ddppo"]["roofline"]
