@@ -215,8 +215,6 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
       ptrA[i] = (ok ? base + off : zero) + piece_ofs_a;
     }
   };
-  open_a_tile();
-  rebuild_rows();
   // the patch leaves in three parts, in the last k-tile of the patch two before it and the first two k-tiles of the patch before it
   // (all AG instructions in one k-tile made that k-tile ~1 100-1 400 cycles longer than the other three; in two halves still ~300:
   // in-kernel stamps, tools/clock_diag_dma.py patch).  Part 0 goes into the buffer the k-tile's first half has just finished with.
@@ -264,7 +262,6 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
       ptrB[j] = reinterpret_cast<const char*>(wbase) + ((size_t)min(n0 + r, p.N - 1) * p.K) * 4 + piece_ofs;   // rows past N re-read row N-1 (never stored)
     }
   };
-  open_b_tile();
   auto issue_weights = [&]() {
     const int a = b_tap >> 1, b = b_tap & 1;
     const int bph = b_phase >> 1, bpw = b_phase & 1;
@@ -451,7 +448,21 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   };
 
   // ---- pipeline ----
+  // the first three weight tiles leave before anything else (their addresses need the tile's n-tile and phase only), under the
+  // patch-row pointer set-up; then patch 0 and, when there is one, the first part of patch 1 (the steady loop's first wait counts it)
   if (M2H_PATCH_PRIO && wave >= PNW / 2) __builtin_amdgcn_s_setprio(1);
+  open_b_tile();
+  issue_weights();
+  issue_weights();
+  issue_weights();
+  open_a_tile();
+  rebuild_rows();
+  issue_patch(I0{});
+  issue_patch(std::integral_constant<int, 1>{});
+  issue_patch(std::integral_constant<int, 2>{});
+  constexpr int PA = AG == 8 ? 3 : 2, PB = AG == 4 ? 1 : PA;   // instructions of a patch's first / second part
+  if (my_tiles * NS > 1) issue_patch(I0{});
+  // (the scale / shift table last: the compiler waits for its global loads with vmcnt(0), i.e. for every DMA issued so far as well)
 #pragma unroll
   for (int k = 0; k < SCN; ++k) {
     const int n = tid + 64 * PNW * k;
@@ -460,18 +471,11 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
       reinterpret_cast<float*>(smem + Cfg::SC_OFF)[Cfg::MAX_N + n] = sh_r[k];
     }
   }
-  issue_patch(I0{});
-  issue_patch(std::integral_constant<int, 1>{});
-  issue_patch(std::integral_constant<int, 2>{});
-  issue_weights();
-  issue_weights();
-  issue_weights();
-  constexpr int PA = AG == 8 ? 3 : 2, PB = AG == 4 ? 1 : PA;   // instructions of a patch's first / second part
-  if (my_tiles * NS > 1) {   // the second patch's first part (the steady loop's first wait counts it)
-    issue_patch(I0{});
-    wait_and_barrier(std::integral_constant<int, 2 * BG + PA>{}, false);
+  build_atab(CONVT ? c_phase >> 1 : cls0 >> 1, CONVT ? c_phase & 1 : cls0 & 1);   // (under the DMAs' latency)
+  if (my_tiles * NS > 1) {
+    wait_and_barrier(std::integral_constant<int, PA>{}, false);   // patch 0 and (older) the three weight tiles have landed; also orders the scale / shift table, the zero rows
   } else {
-    wait_and_barrier(std::integral_constant<int, 2 * BG>{}, false);   // patch 0 and the weights of tile 0 have landed (also orders the scale / shift table, the zero rows)
+    wait_and_barrier(std::integral_constant<int, 0>{}, false);
   }
   int cs = 0, ab = 0;        // weight stage / patch buffer of the current tile
   int c_cls = cls0, c_ci = 0;   // class / chunk of the current patch
@@ -481,7 +485,6 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
 #ifdef M2H_CLOCK_DIAG
   const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  build_atab(CONVT ? c_phase >> 1 : cls0 >> 1, CONVT ? c_phase & 1 : cls0 & 1);
   load_a(0, std::integral_constant<int, 0>{}, I0{}, IH{});
   for_ni([&](auto nic) { load_b(0, nic); });
   // tile tt of a patch: upper pixel fragments | MFMAs of the lower ones | wait + barrier | lower fragments of the next tile |

@@ -111,6 +111,44 @@ def test_gru_sequence_backward_matches_torch(N):
     assert _rel(xd.grad, x.grad) < 1e-4
 
 
+@pytest.mark.parametrize("T", [1, 4])
+def test_two_layer_gru_state_encoder_matches_torch(T):
+    """RNNStateEncoder(num_layers=2) (rnn_state_encoder.py:10-32,63-137): nn.GRU's stacked layers, every layer's hidden state masked at
+    the reset steps -- forward (single step and sequence) and backward against torch's nn.GRU stepped on the CPU."""
+    from m2h.rl.models.rnn_state_encoder import RNNStateEncoder
+    dev = _dev()
+    torch.manual_seed(5)
+    N, I, H = 14, 96, 64
+    enc = RNNStateEncoder(I, H, num_layers=2)
+    ref = torch.nn.GRU(I, H, num_layers=2)
+    ref.load_state_dict(enc.rnn.state_dict())
+    assert enc.num_recurrent_layers == 2
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(T * N, I, generator=g)
+    h0 = torch.randn(2, N, H, generator=g) * 0.5
+    masks = (torch.rand(T * N, 1, generator=g) > 0.3).float()
+    # reference: one step at a time, the hidden state of BOTH layers multiplied by the step's mask first (_mask_hidden)
+    xr = x.clone().requires_grad_(True)
+    h, outs = h0.clone(), []
+    for t in range(T):
+        o, h = ref(xr[t * N:(t + 1) * N].unsqueeze(0), h * masks[t * N:(t + 1) * N].view(1, N, 1))
+        outs.append(o[0])
+    want = torch.cat(outs, 0)
+    gout = torch.randn(want.shape, generator=g)
+    ((want * gout).sum() + h.sum()).backward()
+    enc = enc.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    got, hT = enc(xd, h0.to(dev), masks.to(dev))
+    assert hT.shape == (2, N, H) and _rel(got, want) < TOL and _rel(hT, h) < TOL
+    ((got * gout.to(dev)).sum() + hT.sum()).backward()
+    assert _rel(xd.grad, xr.grad) < 1e-4
+    for (k, p_), (_k2, q) in zip(enc.rnn.named_parameters(), ref.named_parameters()):
+        assert _rel(p_.grad, q.grad) < 1e-4, k
+    with torch.no_grad():                       # the no-grad path of a rollout step takes the same stacked route
+        got2, hT2 = enc(x.to(dev), h0.to(dev), masks.to(dev))
+    assert _rel(got2, want) < TOL and _rel(hT2, h) < TOL
+
+
 def test_policy_heads_and_ppo_loss_backward_match_torch():
     from m2h import functional as MF
     dev = _dev()
