@@ -1,4 +1,5 @@
-"""GRU state encoder on MI355X: drop-in for audio_separation/rl/models/rnn_state_encoder.py (RNNStateEncoder, :5-143), any number of layers.
+"""Recurrent state encoder on MI355X: drop-in for audio_separation/rl/models/rnn_state_encoder.py (RNNStateEncoder, :5-143): GRU (what
+policy.py:63 constructs: fused kernels) with any number of layers, and the class's LSTM variant (library GEMMs + torch gate math).
 
 ``nn.GRU`` is the parameter container (keys ``rnn.weight_ih_l0`` ...; orthogonal init, :36-41).  The two GEMMs of a step run on
 the MFMA engine (torch's [3H][K] weight layout is already the packed [N][K] form); the gate math and the hidden-state reset
@@ -16,12 +17,11 @@ from ... import ops
 class RNNStateEncoder(nn.Module):
     def __init__(self, input_size: int, hidden_size: int, num_layers: int = 1, rnn_type: str = "GRU"):
         super().__init__()
-        if rnn_type != "GRU":
-            # (the reference's class also takes "LSTM" (:10-34); policy.py:63 never passes it and no config key reaches it)
-            raise NotImplementedError("m2h RNNStateEncoder: GRU only (what policy.py:63 constructs); LSTM cells are not built")
+        if rnn_type not in ("GRU", "LSTM"):
+            raise ValueError("m2h RNNStateEncoder: rnn_type must be GRU or LSTM (rnn_state_encoder.py:22)")
         self._num_recurrent_layers = num_layers
         self._rnn_type = rnn_type
-        self.rnn = nn.GRU(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers)
+        self.rnn = getattr(nn, rnn_type)(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers)
         self.layer_init()
 
     def layer_init(self):
@@ -33,13 +33,40 @@ class RNNStateEncoder(nn.Module):
 
     @property
     def num_recurrent_layers(self):
-        return self._num_recurrent_layers
+        return self._num_recurrent_layers * (2 if "LSTM" in self._rnn_type else 1)   # (:43-47: h and c packed along dim 0)
+
+    def _lstm_forward(self, x, hidden_states, masks, n, t):
+        """The "LSTM" variant (:10-34, 49-61; policy.py:63 never selects it and no config key reaches it).  hidden_states packs
+        (h, c) along dim 0 ([2 L, N, H], :49-61); both are multiplied by the step's reset mask (:63-69).  The four GEMMs of a step
+        run on the library's engine (the input projection batched over all T N rows); the gate math is torch's pointwise kernels with
+        torch's autograd -- no fused LSTM cell kernel is built for a variant nothing instantiates."""
+        r, L, H = self.rnn, self._num_recurrent_layers, self.rnn.hidden_size
+        hs, cs = hidden_states[:L], hidden_states[L:]
+        m = masks.reshape(t, n, 1)
+        out, h_out, c_out = x, [], []
+        for l in range(L):
+            w_ih, w_hh, b_ih, b_hh = (getattr(r, "%s_l%d" % (name, l)) for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+            gi = MF.linear(out.contiguous(), w_ih, b_ih, name="lstm.ih").reshape(t, n, 4 * H)
+            h, c, steps = hs[l], cs[l], []
+            for k in range(t):
+                h, c = h * m[k], c * m[k]
+                g = gi[k] + MF.linear(h.contiguous(), w_hh, b_hh, name="lstm.hh")
+                i_, f_, g_, o_ = g.split(H, dim=1)                   # nn.LSTM's gate order: input, forget, cell, output
+                c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(g_)
+                h = torch.sigmoid(o_) * torch.tanh(c)
+                steps.append(h)
+            out = torch.cat(steps, 0)
+            h_out.append(h)
+            c_out.append(c)
+        return out, torch.stack(h_out + c_out, 0)
 
     def forward(self, x, hidden_states, masks):
         n = hidden_states.size(1)
         t = x.size(0) // n  # 1: single_forward (:74-84); > 1: seq_forward (:86-137)
         r = self.rnn
         L = self._num_recurrent_layers
+        if self._rnn_type == "LSTM":
+            return self._lstm_forward(x, hidden_states, masks, n, t)
         if (L == 1 and t == 1 and not torch.is_grad_enabled() and n <= ops.GRU_STEP_MAX_ROWS and r.hidden_size % 16 == 0 and x.size(1) % 16 == 0
                 and ops.math_mode() == ops.MATH_FP32 and not ops.timing_enabled()):
             # the rollout step (no autograd, 14 rows): input projection, recurrent product and gates in ONE launch (m2h_gru_cell)

@@ -71,6 +71,7 @@ class VisualCNN(nn.Module):
         """out: optional [B, output_size] destination (a column block of the policy's concatenated feature matrix) for the no-grad
         rollout path: the last layer then writes there instead of into a tensor of its own.  x: ``prepare(observations)`` when the caller holds it."""
         if self.is_blind:
+            # (the reference fails here too: its forward concatenates an empty list, visual_cnn.py:147-150, and policy.py:98 always calls it)
             raise NotImplementedError("m2h VisualCNN: blind configuration has no encoder")
         if self._n_input_rgb != 3 or self._n_input_depth not in (0, 1):
             raise NotImplementedError("m2h VisualCNN: built for rgb (3 ch) with optional depth (1 ch)")

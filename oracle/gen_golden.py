@@ -423,7 +423,40 @@ def gen_eval_metrics(ref):
     print("eval_metrics: si_sdr", out["scores_f32_L16000"][:, 0])
 
 
-GENS = {"eval_metrics": gen_eval_metrics, "unet_tm32": gen_unet_tm32, "unet_tm256": gen_unet_tm256, "init": gen_init,
+def gen_rnn_variants(ref):
+    """RNNStateEncoder's other configurations (rnn_state_encoder.py:10-61: num_layers > 1, rnn_type "LSTM") through the reference
+    class itself: single_forward (T = 1) and seq_forward (T = 4, with resets) outputs, final hidden states and the gradients of
+    sum(out * g) + sum(h) with respect to the input and every parameter."""
+    RSE = ref["rnn_state_encoder"].RNNStateEncoder
+    N, I, H = 14, 96, 64
+    out = {}
+    for tag, kw in (("gru2", dict(num_layers=2, rnn_type="GRU")), ("lstm1", dict(num_layers=1, rnn_type="LSTM")),
+                    ("lstm2", dict(num_layers=2, rnn_type="LSTM"))):
+        torch.manual_seed(31)
+        enc = RSE(I, H, **kw)
+        for k, v in enc.state_dict().items():
+            out["%s.w.%s" % (tag, k)] = v.numpy().copy()
+        for T in (1, 4):
+            g = torch.Generator().manual_seed(17 + T)
+            x = torch.randn(T * N, I, generator=g).requires_grad_(True)
+            h0 = torch.randn(enc.num_recurrent_layers, N, H, generator=g) * 0.5
+            masks = (torch.rand(T * N, 1, generator=g) > 0.3).float()
+            if T > 1:
+                masks[:N] = 1.0       # (the reference's seq_forward assumes nothing about step 0; keep it un-reset like a mid-rollout batch)
+            gout = torch.randn(T * N, H, generator=g)
+            enc.zero_grad()
+            y, hT = enc(x, h0, masks)
+            ((y * gout).sum() + hT.sum()).backward()
+            pre = "%s.T%d." % (tag, T)
+            out.update({pre + "x": x.detach().numpy(), pre + "h0": h0.numpy(), pre + "masks": masks.numpy(), pre + "gout": gout.numpy(),
+                        pre + "y": y.detach().numpy(), pre + "hT": hT.detach().numpy(), pre + "dx": x.grad.numpy().copy()})
+            for k, v in enc.named_parameters():
+                out[pre + "d." + k] = v.grad.numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "rnn_variants.npz"), **out)
+    print("rnn_variants.npz: %d arrays" % len(out))
+
+
+GENS = {"rnn_variants": gen_rnn_variants, "eval_metrics": gen_eval_metrics, "unet_tm32": gen_unet_tm32, "unet_tm256": gen_unet_tm256, "init": gen_init,
         "rl_forward": gen_rl_forward, "rl_scalars": gen_rl_scalars, "rl_updates": gen_rl_updates, "passive_train": gen_passive_train}
 
 

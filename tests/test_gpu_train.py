@@ -149,6 +149,35 @@ def test_two_layer_gru_state_encoder_matches_torch(T):
     assert _rel(got2, want) < TOL and _rel(hT2, h) < TOL
 
 
+@pytest.mark.parametrize("tag,kw", [("gru2", dict(num_layers=2, rnn_type="GRU")), ("lstm1", dict(num_layers=1, rnn_type="LSTM")),
+                                    ("lstm2", dict(num_layers=2, rnn_type="LSTM"))])
+def test_rnn_state_encoder_variants_match_the_reference_fixture(tag, kw):
+    """RNNStateEncoder's configurations that policy.py never selects (rnn_state_encoder.py:10-61): outputs, final hidden states (h and c
+    packed for the LSTM) and gradients of the reference class itself (tests/golden/rnn_variants.npz, oracle/gen_golden.py --only rnn_variants)."""
+    from m2h.rl.models.rnn_state_encoder import RNNStateEncoder
+    dev = _dev()
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "rnn_variants.npz"))
+    N, I, H = 14, 96, 64
+    enc = RNNStateEncoder(I, H, **kw)
+    enc.load_state_dict({k[len(tag) + 3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith(tag + ".w.")})
+    enc = enc.to(dev)
+    assert enc.num_recurrent_layers == kw["num_layers"] * (2 if kw["rnn_type"] == "LSTM" else 1)
+    for T in (1, 4):
+        pre = "%s.T%d." % (tag, T)
+        t = lambda k: torch.from_numpy(gold[pre + k]).to(dev)  # noqa: E731
+        x = t("x").requires_grad_(True)
+        enc.zero_grad()
+        y, hT = enc(x, t("h0"), t("masks"))
+        assert _rel(y, gold[pre + "y"]) < TOL and _rel(hT, gold[pre + "hT"]) < TOL
+        ((y * t("gout")).sum() + hT.sum()).backward()
+        assert _rel(x.grad, gold[pre + "dx"]) < 1e-4
+        for k, p_ in enc.named_parameters():
+            assert _rel(p_.grad, gold[pre + "d." + k]) < 1e-4, (T, k)
+        with torch.no_grad():
+            y2, hT2 = enc(t("x"), t("h0"), t("masks"))
+        assert _rel(y2, gold[pre + "y"]) < TOL and _rel(hT2, gold[pre + "hT"]) < TOL
+
+
 def test_policy_heads_and_ppo_loss_backward_match_torch():
     from m2h import functional as MF
     dev = _dev()
