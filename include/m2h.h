@@ -238,6 +238,12 @@ int m2h_gather_logp(const float* logp_all, const long long* actions, float* out,
 int m2h_policy_heads_act(const float* feats, const float* Wa, const float* ba, const float* Wc, const float* bc, const float* noise,
                          float* value, float* logp_all, float* probs, float* entropy, long long* actions, float* logp_act, int M, int H,
                          int A, m2h_stream stream);
+/* Same with the draw's Exp(1) noise made INSIDE the kernel ("fused" sampling: no generator launch in the rollout step): element (row, a)
+ * takes -log(u), u from Philox4x32-10 keyed by rng_state[0] (seed) at counter rng_state[1] + row A + a; rng_state: two uint64 on the
+ * device, the counter is advanced by the caller (m2h_step_index_advance_rng inside a replayed step). */
+int m2h_policy_heads_act_rng(const float* feats, const float* Wa, const float* ba, const float* Wc, const float* bc,
+                             const unsigned long long* rng_state, float* value, float* logp_all, float* probs, float* entropy,
+                             long long* actions, float* logp_act, int M, int H, int A, m2h_stream stream);
 
 /* CustomFixedCategorical.sample (common/utils.py:16-24) with the noise supplied by the caller: the single-draw path of
  * torch.multinomial(probs, 1, True) is argmax(probs / q), q ~ Exp(1) drawn from the tensor's generator -- on the reference's
@@ -389,6 +395,8 @@ int m2h_rows_copy(const m2h_row_copy* items, int n_items, const long long* idx, 
 /* idx = (pol_step, pol_step + 1, sep_step + 1), the device-resident step counters m2h_rows_copy addresses rows with, advanced as
  * RolloutStoragePol/Sep.insert advance theirs: step = (step + 1) % num_steps (common/rollout_storage.py:96,390). */
 int m2h_step_index_advance(long long* idx, int T_pol, int T_sep, m2h_stream stream);
+/* Same, and the fused sampler's counter (rng_state[1], m2h_policy_heads_act_rng) moves past the step's rng_inc draws. */
+int m2h_step_index_advance_rng(long long* idx, int T_pol, int T_sep, unsigned long long* rng_state, unsigned long long rng_inc, m2h_stream stream);
 
 /* Synthetic on-device vector env (m2h/envs/synthetic_env.py; stands where the simulator's pose update and sensor suite stand,
  * habitat_audio/simulator_train.py:216-227,386-486).  m2h_synth_env_step: per env, action 0 moves to node + 1, 1 / 2 turn by

@@ -236,6 +236,23 @@ __global__ __launch_bounds__(64 * GC_NW) void gru_cell_kernel(const float* __res
   }
 }
 
+// Philox4x32-10 (Salmon et al., SC'11: the counter-based generator torch's device generator is built on), one 32-bit word of the
+// block at `counter` under `seed`, as Exp(1) noise: -log(u), u = (24 random bits + 0.5) / 2^24 in (0, 1).
+__device__ __forceinline__ float philox_exp1(unsigned long long seed, unsigned long long counter) {
+  unsigned c0 = (unsigned)counter, c1 = (unsigned)(counter >> 32), c2 = 0x6d32685fu, c3 = 0u;   // (c2: a stream tag)
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const float u = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  return -logf(u);
+}
+
 // One wave per row: logits = feats Wa^T + ba (A <= 8 actions), value = feats Wc^T + bc; log-softmax, softmax, entropy,
 // optional log-prob of a given action.  H multiple of 64.
 __global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restrict__ feats, const float* __restrict__ Wa,
@@ -244,7 +261,8 @@ __global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restri
                                                            float* __restrict__ value, float* __restrict__ logp_all,
                                                            float* __restrict__ probs, float* __restrict__ entropy,
                                                            float* __restrict__ logp_act, int M, int H, int A,
-                                                           const float* __restrict__ noise = nullptr, long long* __restrict__ act_out = nullptr) {
+                                                           const float* __restrict__ noise = nullptr, long long* __restrict__ act_out = nullptr,
+                                                           const unsigned long long* __restrict__ rng = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -306,11 +324,15 @@ __global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restri
       // Policy.act in the same launch (rl/ppo/policy.py:217-225): the action -- with noise the single draw of torch.multinomial,
       // argmax(probs / Exp(1) noise), exactly as sample_actions_kernel takes it (correctly rounded division, NaN is the maximum,
       // ties keep the lowest index); without noise the mode, argmax(probs) -- and its log-probability
+      // rng = {seed, counter} on the device ("fused" sampling): the Exp(1) noise of element (row, a) is -log(u), u from Philox4x32-10
+      // keyed by the seed at counter + row A + a -- no generator launch in the step; the counter is advanced by step_index_advance
+      const bool draw = noise != nullptr || rng != nullptr;
+      auto nz = [&](int a) { return rng != nullptr ? philox_exp1(rng[0], rng[1] + (unsigned long long)(row * A + a)) : noise[row * A + a]; };
       int arg = 0;
-      float best = noise != nullptr ? expf(acc[0] - lse) / noise[row * A] : expf(acc[0] - lse);
+      float best = draw ? expf(acc[0] - lse) / nz(0) : expf(acc[0] - lse);
       for (int a = 1; a < A; ++a) {
         const float p = expf(acc[a] - lse);
-        const float q = noise != nullptr ? p / noise[row * A + a] : p;
+        const float q = draw ? p / nz(a) : p;
         if (!(best != best) && (q > best || q != q)) { best = q; arg = a; }
       }
       act_out[row] = arg;
@@ -618,8 +640,10 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(RowsCopyArgs a, const lo
 
 // Device-resident step counters of the two rollout storages, idx = (pol_step, pol_step + 1, sep_step + 1), advanced at the end
 // of a replayed rollout step (RolloutStoragePol/Sep.insert: step = (step + 1) % num_steps, common/rollout_storage.py:96,390).
-__global__ void step_index_advance_kernel(long long* __restrict__ idx, int T_pol, int T_sep) {
+__global__ void step_index_advance_kernel(long long* __restrict__ idx, int T_pol, int T_sep, unsigned long long* __restrict__ rng = nullptr,
+                                          unsigned long long rng_inc = 0) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (rng != nullptr) rng[1] += rng_inc;   // the fused sampler's counter: past the step's draws
     const long long p = (idx[0] + 1) % T_pol;
     const long long s = idx[2] % T_sep;   // idx[2] holds sep_step + 1
     idx[0] = p;
@@ -1060,6 +1084,16 @@ int m2h_policy_heads_act(const float* feats, const float* Wa, const float* ba, c
   return launch_status("policy_heads_act");
 }
 
+int m2h_policy_heads_act_rng(const float* feats, const float* Wa, const float* ba, const float* Wc, const float* bc, const unsigned long long* rng_state,
+                             float* value, float* logp_all, float* probs, float* entropy, long long* actions, float* logp_act, int M, int H,
+                             int A, m2h_stream stream) {
+  M2H_REQUIRE(feats && Wa && ba && Wc && bc && rng_state && value && logp_all && probs && entropy && actions && logp_act, "policy_heads_act_rng: null pointer");
+  M2H_REQUIRE(M > 0 && H > 0 && H % 64 == 0 && A > 0 && A <= 8, "policy_heads_act_rng: bad sizes (H %% 64, A <= 8)");
+  M2H_LAUNCH(policy_heads_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), feats, Wa, ba, Wc, bc,
+             static_cast<const long long*>(nullptr), value, logp_all, probs, entropy, logp_act, M, H, A, static_cast<const float*>(nullptr), actions, rng_state);
+  return launch_status("policy_heads_act (fused draw)");
+}
+
 int m2h_sample_actions(const float* probs, const float* noise, long long* actions, int M, int A, m2h_stream stream) {
   M2H_REQUIRE(probs && noise && actions && M > 0 && A > 0 && A <= 64, "sample_actions: bad arguments");
   M2H_LAUNCH(sample_actions_kernel, dim3((M + 255) / 256), dim3(256), 0, as_stream(stream), probs, noise, actions, M, A);
@@ -1281,6 +1315,12 @@ int m2h_rows_copy(const m2h_row_copy* items, int n_items, const long long* idx, 
 int m2h_step_index_advance(long long* idx, int T_pol, int T_sep, m2h_stream stream) {
   M2H_REQUIRE(idx && T_pol > 0 && T_sep > 0, "step_index_advance: bad arguments");
   M2H_LAUNCH(step_index_advance_kernel, dim3(1), dim3(64), 0, as_stream(stream), idx, T_pol, T_sep);
+  return launch_status("step_index_advance");
+}
+
+int m2h_step_index_advance_rng(long long* idx, int T_pol, int T_sep, unsigned long long* rng_state, unsigned long long rng_inc, m2h_stream stream) {
+  M2H_REQUIRE(idx && T_pol > 0 && T_sep > 0 && rng_state, "step_index_advance_rng: bad arguments");
+  M2H_LAUNCH(step_index_advance_kernel, dim3(1), dim3(64), 0, as_stream(stream), idx, T_pol, T_sep, rng_state, rng_inc);
   return launch_status("step_index_advance");
 }
 

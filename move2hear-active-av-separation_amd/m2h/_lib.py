@@ -179,6 +179,7 @@ SIGNATURES = {
     "m2h_policy_heads": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "m2h_gather_logp": [_P, _P, _P, _I, _I, _P],
     "m2h_policy_heads_act": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "m2h_policy_heads_act_rng": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "m2h_sample_actions": [_P, _P, _P, _I, _I, _P],
     "m2h_gae_returns": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P],
     "m2h_advantages": [_P, _P, _P, _P, _I, _I, _F, _P],
@@ -243,6 +244,7 @@ SIGNATURES = {
     "m2h_fftconv_full": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "m2h_rows_copy": [_P, _I, _P, _P],
     "m2h_step_index_advance": [_P, _I, _I, _P],
+    "m2h_step_index_advance_rng": [_P, _I, _I, _P, ctypes.c_ulonglong, _P],
     "m2h_synth_env_step": [_P, _P, _P, _I, _I, _P],
     "m2h_synth_env_observe": [_P, _I, _P, _P, _P, _I, _P],
     "m2h_stft_l2": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],

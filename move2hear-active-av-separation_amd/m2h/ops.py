@@ -555,9 +555,10 @@ def policy_heads(feats, Wa, ba, Wc, bc, actions=None):
     return value, logp_all, probs, ent, logp_act
 
 
-def policy_heads_act(feats, Wa, ba, Wc, bc, noise=None):
+def policy_heads_act(feats, Wa, ba, Wc, bc, noise=None, rng=None):
     """Heads + action + its log-probability in one launch (m2h_policy_heads_act): noise [M,A] Exp(1) -> the multinomial draw
-    argmax(probs / noise); None -> the mode.  -> value [M,1], logp_all [M,A], probs [M,A], entropy [M], action [M,1] int64, logp_act [M,1]."""
+    argmax(probs / noise); None -> the mode; rng = int64 device tensor [seed, counter] -> the noise is drawn inside the kernel
+    (m2h_policy_heads_act_rng; the caller advances the counter).  -> value [M,1], logp_all [M,A], probs [M,A], entropy [M], action [M,1] int64, logp_act [M,1]."""
     for t in (feats, Wa, ba, Wc, bc, noise):
         _chk(t, "policy_heads_act")
     M, H = feats.shape
@@ -571,6 +572,14 @@ def policy_heads_act(feats, Wa, ba, Wc, bc, noise=None):
     ent = torch.empty((M,), device=dev)
     action = torch.empty((M, 1), device=dev, dtype=torch.int64)
     logp_act = torch.empty((M, 1), device=dev)
+    if rng is not None:
+        if noise is not None or rng.dtype != torch.int64 or rng.numel() != 2 or not rng.is_cuda or not rng.is_contiguous():
+            raise RuntimeError("m2h.policy_heads_act: rng must be a contiguous int64 device tensor [seed, counter] (and noise None)")
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().m2h_policy_heads_act_rng(_ptr(feats), _ptr(Wa), _ptr(ba), _ptr(Wc), _ptr(bc), _ptr(rng), _ptr(value),
+                                                            _ptr(logp_all), _ptr(probs), _ptr(ent), _ptr(action), _ptr(logp_act), M, H, A,
+                                                            _stream(feats)), "m2h_policy_heads_act_rng")
+        return value, logp_all, probs, ent, action, logp_act
     with torch.cuda.device(dev):
         _lib.check(_lib.load().m2h_policy_heads_act(_ptr(feats), _ptr(Wa), _ptr(ba), _ptr(Wc), _ptr(bc), _ptr(noise), _ptr(value),
                                                     _ptr(logp_all), _ptr(probs), _ptr(ent), _ptr(action), _ptr(logp_act), M, H, A,
@@ -858,11 +867,15 @@ def rows_copy(items, idx):
             _lib.check(lib.m2h_rows_copy((_lib.RowCopy * len(chunk))(*chunk), len(chunk), _ptr(idx), _stream(idx)), "m2h_rows_copy")
 
 
-def step_index_advance(idx, t_pol, t_sep):
-    """(pol_step, pol_step + 1, sep_step + 1) -> the next step's, on the device (m2h_step_index_advance)."""
+def step_index_advance(idx, t_pol, t_sep, rng=None, rng_inc=0):
+    """(pol_step, pol_step + 1, sep_step + 1) -> the next step's, on the device (m2h_step_index_advance); rng: the fused sampler's
+    [seed, counter] state, whose counter moves on by rng_inc in the same launch."""
     if idx.dtype != torch.int64 or not idx.is_cuda or idx.numel() != 3 or not idx.is_contiguous():
         raise RuntimeError("m2h.step_index_advance: idx must be a contiguous int64 device tensor of 3 elements")
     with torch.cuda.device(idx.device):
+        if rng is not None:
+            _lib.check(_lib.load().m2h_step_index_advance_rng(_ptr(idx), int(t_pol), int(t_sep), _ptr(rng), int(rng_inc), _stream(idx)), "m2h_step_index_advance_rng")
+            return
         _lib.check(_lib.load().m2h_step_index_advance(_ptr(idx), int(t_pol), int(t_sep), _stream(idx)), "m2h_step_index_advance")
 
 

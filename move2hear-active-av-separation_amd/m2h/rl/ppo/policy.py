@@ -187,17 +187,23 @@ class Policy(nn.Module):
         self._fence("mem")
         return self.acoustic_mem.l1_loss_masked(pred_mono, prev_pred_monoFromMem, masks, gt_comps, off, sliced=sliced)
 
-    # action sampling (common/utils.py): None = noise from the device generator; a HostNoise = noise from the CPU default generator
+    # action sampling (common/utils.py): None = noise from the device generator; a HostNoise = noise from the CPU default generator;
+    # _rng_state = [seed, counter] on the device = noise drawn inside the heads kernel ("fused")
     _host_noise = None
+    _rng_state = None
 
-    def set_action_sampling(self, mode):
-        """"device": torch.multinomial's draw on the device generator (throughput default).  "cpu_generator": the same draw with
-        its Exp(1) noise taken from the CPU default generator, i.e. the actions of the reference PyTorch-CPU path for the same
-        seed (common/utils.py:16-24 on a CPU policy)."""
+    def set_action_sampling(self, mode, seed=0):
+        """"fused" (throughput default of the trainers): torch.multinomial's single draw, argmax(probs / Exp(1) noise), with the noise made
+        inside the heads kernel by a counter-based generator (Philox4x32-10 keyed by `seed`, counter on the device): no generator launch
+        in the rollout step.  "device": the same draw with torch's device generator supplying the noise (three more launches per step inside
+        a HIP graph).  "cpu_generator": the noise taken from the CPU default generator, i.e. the actions of the reference PyTorch-CPU path
+        for the same seed (common/utils.py:16-24 on a CPU policy)."""
         from ...common.utils import HostNoise
-        if mode not in ("device", "cpu_generator"):
-            raise ValueError("action_sampling must be 'device' or 'cpu_generator', got %r" % (mode,))
-        self._host_noise = HostNoise(next(self.parameters()).device) if mode == "cpu_generator" else None
+        if mode not in ("fused", "device", "cpu_generator"):
+            raise ValueError("action_sampling must be 'fused', 'device' or 'cpu_generator', got %r" % (mode,))
+        dev = next(self.parameters()).device
+        self._host_noise = HostNoise(dev) if mode == "cpu_generator" else None
+        self._rng_state = torch.tensor([int(seed) & 0x7fffffffffffffff, 0], dtype=torch.int64, device=dev) if mode == "fused" else None
 
     def stage_action_noise(self, rows):
         """cpu_generator mode: draw the next step's noise and enqueue its upload (called ahead of a graph replay that samples)."""
@@ -232,15 +238,19 @@ class Policy(nn.Module):
             # the draw torch.multinomial makes -- Exp(1) from the device generator, or from the CPU default generator through the
             # pinned ring (set_action_sampling); same generator state in, same noise, same actions out as the per-op path below.
             a, c = self.action_dist.linear, self.critic.fc
-            noise = None
+            noise, rng = None, None
+            M, A = feats_pol.shape[0], self.dim_actions
             if not deterministic:
-                M, A = feats_pol.shape[0], self.dim_actions
                 if self._host_noise is not None:
                     noise = self._host_noise.buffer(M, A) if torch.cuda.is_current_stream_capturing() else self._host_noise.stage(M, A)
+                elif self._rng_state is not None and feats_pol.is_cuda:
+                    rng = self._rng_state
                 else:
                     noise = torch.empty((M, A), device=feats_pol.device).exponential_(1)
             value, _lpa, probs, _ent, action, action_log_probs = ops.policy_heads_act(
-                feats_pol.contiguous(), a.weight.detach(), a.bias.detach(), c.weight.detach(), c.bias.detach(), noise)
+                feats_pol.contiguous(), a.weight.detach(), a.bias.detach(), c.weight.detach(), c.bias.detach(), noise, rng=rng)
+            if rng is not None and not torch.cuda.is_current_stream_capturing():
+                rng[1:2] += M * A     # kernel-by-kernel steps: the counter moves on here; a captured step advances it in its last launch (ppo_trainer.py)
             return value, action, action_log_probs, rnn_hidden_states_pol, probs
         value, dist, _ = self._heads(feats_pol)
         action = dist.mode() if deterministic else dist.sample()

@@ -59,8 +59,10 @@ def near_target_config(**over):
              sep_update_math=None,      # build-side key: arithmetic of update_sep's launches (AcousticMem over the 1680 stored samples: the one matrix-bound
              #                            phase of the cycle): None = the calling thread's mode; "bf16x3" = split bf16 products, fp32 accumulate (the
              #                            image-row kernels of csrc/conv_igemm.hip / conv_bwd.hip: ~6e-6 from the fp32 result, 1.36 -> 0.75 ms per epoch)
-             action_sampling="device")  # build-side key: "device" = multinomial noise from the device generator; "cpu_generator" = from
-    #                                     the CPU default generator: the reference PyTorch-CPU run's actions from the seed alone
+             action_sampling="fused")  # build-side key: "fused" = torch.multinomial's single draw with its Exp(1) noise made inside the heads kernel
+    #                                     (Philox4x32-10, seed = SEED + rank offset, counter on the device: no generator launch in the step);
+    #                                     "device" = the noise from torch's device generator; "cpu_generator" = from the CPU default generator:
+    #                                     the reference PyTorch-CPU run's actions from the seed alone
     c.update(over)
     return SimpleNamespace(**c)
 
@@ -96,7 +98,7 @@ class PPOTrainer:
             hidden_size=cfg.hidden_size, extra_rgb=cfg.EXTRA_RGB, extra_depth=cfg.EXTRA_DEPTH, use_ddppo=cfg.use_ddppo,
             world_rank=self.world_rank)
         self.actor_critic.to(self.device)
-        self.actor_critic.set_action_sampling(getattr(cfg, "action_sampling", "device"))
+        self.actor_critic.set_action_sampling(getattr(cfg, "action_sampling", "fused"), seed=0x5eed0000 + seed)
         cls = DDPPO if cfg.use_ddppo else PPO
         self.agent = cls(actor_critic=self.actor_critic, clip_param=cfg.clip_param, ppo_epoch=cfg.ppo_epoch,
                          num_mini_batch=cfg.num_mini_batch, value_loss_coef=cfg.value_loss_coef,
@@ -298,7 +300,9 @@ class PPOTrainer:
             g.register_generator_state(self.envs.generator)
             with torch.no_grad(), graphs.capture(g, pool=gs.pool):
                 self._rollout_step_device(gs.cache, gs.idx, extra, done)   # (leaves the next step's separator outputs in gs.cache)
-                ops.step_index_advance(gs.idx, ro.num_steps, rs.num_steps)  # ro_step <- (ro_step + 1) % T, rs_step likewise
+                rng = self.actor_critic._rng_state    # "fused" sampling: the step's draws consumed NUM_PROCESSES x actions counters
+                ops.step_index_advance(gs.idx, ro.num_steps, rs.num_steps, rng=rng,   # ro_step <- (ro_step + 1) % T, rs_step likewise
+                                       rng_inc=self.envs.num_envs * self.actor_critic.dim_actions if rng is not None else 0)
             if gs.pool is None:
                 gs.pool = g.pool()
             gs.graphs[key] = g
@@ -538,7 +542,7 @@ class PPOTrainer:
             raise RuntimeError("checkpoint state_dict has no 'actor_critic.*' keys")
         ac.load_state_dict(sd, strict=True)
         ac = ac.to(self.device).eval()
-        ac.set_action_sampling(getattr(cfg, "action_sampling", "device"))
+        ac.set_action_sampling(getattr(cfg, "action_sampling", "fused"), seed=0x5eed1000 + cfg.SEED + self.world_rank * cfg.NUM_PROCESSES)
         return ac
 
     def eval(self, num_episodes=None, checkpoint_path=None, waveform_metrics=("si_sdr",), deterministic=None,

@@ -467,3 +467,52 @@ def test_fused_rollout_step_stats_matches_the_separate_kernels(override, extra):
         assert (dev.index, side.cuda_stream, N) in ops._step_stats_scratch and ops._step_stats_scratch[(dev.index, side.cuda_stream, N)][0].data_ptr() != \
             ops._step_stats_scratch[key][0].data_ptr()
     torch.cuda.current_stream(dev).wait_stream(side)
+
+
+def _philox_exp1(seed, counter):
+    """numpy restatement of csrc/rl_ops.hip philox_exp1 (Philox4x32-10, word 0, 24 bits -> (0, 1) -> -log)."""
+    M32 = np.uint64(0xFFFFFFFF)
+    counter = np.asarray(counter, dtype=np.uint64)
+    c0, c1 = counter & M32, counter >> np.uint64(32)
+    c2, c3 = np.full_like(c0, 0x6d32685f), np.zeros_like(c0)
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        n0, n1 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M32, p1 & M32
+        n2, n3 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & M32, p0 & M32
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M32, (k1 + np.uint64(0xBB67AE85)) & M32
+    u = ((c0 >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    return -np.log(u.astype(np.float32))
+
+
+def test_fused_action_draw_is_the_multinomial_draw_on_philox_noise():
+    """"fused" sampling (Policy.set_action_sampling): the heads kernel draws argmax(probs / Exp(1) noise) -- torch.multinomial's single-draw
+    path, common/utils.py:16-24 -- with the noise from Philox4x32-10 at (seed, counter + row A + a): equal to the same draw on the host's
+    restatement of that generator, distributed as the probabilities, and a different counter gives other draws."""
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    M, H, A = 4096, 512, 3
+    feats = torch.randn(M, H, generator=g).to(dev)
+    Wa, ba = (torch.randn(A, H, generator=g) * 0.05).to(dev), (torch.randn(A, generator=g) * 0.1).to(dev)
+    Wc, bc = (torch.randn(1, H, generator=g) * 0.05).to(dev), torch.zeros(1, device=dev)
+    seed, ctr = 0x5eed0007, 12345
+    rng = torch.tensor([seed, ctr], dtype=torch.int64, device=dev)
+    value, logp_all, probs, ent, action, logp_act = ops.policy_heads_act(feats, Wa, ba, Wc, bc, rng=rng)
+    assert int(rng[1]) == ctr                                     # the kernel reads the counter; the caller advances it
+    noise = _philox_exp1(seed, ctr + np.arange(M * A, dtype=np.uint64)).reshape(M, A)
+    want = (probs.cpu().numpy() / noise).argmax(1)
+    same = (action.cpu().numpy().reshape(-1) == want).mean()
+    assert same > 0.999, same                                     # (logf on the device vs numpy: a last-bit difference can flip a near-tie)
+    assert torch.equal(logp_act, logp_all.gather(1, action))
+    v0, lp0, p0, e0, a_mode, _ = ops.policy_heads_act(feats, Wa, ba, Wc, bc)       # the mode: same heads, no draw
+    assert torch.equal(p0, probs) and torch.equal(v0, value)
+    # distribution: per-action frequency against the mean probability (M = 4096 rows: 4 sigma of a binomial is ~0.03)
+    freq = torch.bincount(action.reshape(-1), minlength=A).float() / M
+    assert (freq.cpu() - probs.mean(0).cpu()).abs().max() < 0.035, (freq, probs.mean(0))
+    rng2 = torch.tensor([seed, ctr + M * A], dtype=torch.int64, device=dev)
+    action2 = ops.policy_heads_act(feats, Wa, ba, Wc, bc, rng=rng2)[4]
+    assert (action2 != action).float().mean() > 0.2
+    ops.step_index_advance(torch.zeros(3, dtype=torch.int64, device=dev), 4, 4, rng=rng, rng_inc=M * A)
+    assert int(rng[1]) == ctr + M * A and int(rng[0]) == seed
