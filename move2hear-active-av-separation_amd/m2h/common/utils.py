@@ -2,10 +2,12 @@
 
 ``CategoricalNet`` / ``CustomFixedCategorical`` (:16-50) keep their names and methods (sample, log_probs, mode, get_probs,
 get_log_probs, entropy).  logits, log-softmax, softmax and entropy come from one wave-per-row HIP kernel.  Sampling is the
-single-draw path of ``torch.multinomial(probs, 1, True)`` -- what the reference's ``Categorical.sample`` runs -- in one of two
+single-draw path of ``torch.multinomial(probs, 1, True)`` -- what the reference's ``Categorical.sample`` runs -- in one of three
 modes (``Policy.set_action_sampling``):
-  * ``"device"`` (throughput default): the Exp(1) noise comes from the device generator (Philox), as the reference does when its
-    policy lives on a GPU;
+  * ``"fused"`` (the trainers' default since round 5): the Exp(1) noise is made inside the heads kernel by Philox4x32-10 (the
+    generator family torch's device generator uses) keyed by the config's seed, with its counter on the device: the draw costs no
+    launch of its own (inside a HIP graph torch's generator costs three: two state fills and the exponential kernel);
+  * ``"device"``: the Exp(1) noise comes from torch's device generator (Philox), as the reference does when its policy lives on a GPU;
   * ``"cpu_generator"``: the noise comes from the CPU default generator (mt19937) at the same stream position as on the
     reference's CPU path, crosses to the device through a pinned ring, and ``m2h_sample_actions`` takes the argmax: same seed,
     same actions as the reference PyTorch-CPU run (north-star contract; tests/test_gpu_trainer_golden.py samples this way).
