@@ -1531,11 +1531,22 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
       p.Ctot % 16 == 0 && (size_t)a.N * p.Kw * (p.convT ? 4 : 1) >= (size_t)1 << 16) {
     const int phases = p.convT ? 4 : 1;
     p.MT = (int)((M + 15) / 16);
-    const long blocks = (long)phases * (a.N / 16) * ((p.MT + 1) / 2);
+    const long blocks2 = (long)phases * (a.N / 16) * ((p.MT + 1) / 2);
     const int nw = skinny_waves(p.Kw / 16);
-    if (nw == 4) M2H_LAUNCH((skinny_gather_kernel<2, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-    else if (nw == 8) M2H_LAUNCH((skinny_gather_kernel<2, 8>), dim3((unsigned)blocks), dim3(512), 0, st, p);
-    else M2H_LAUNCH((skinny_gather_kernel<2, 16>), dim3((unsigned)blocks), dim3(1024), 0, st, p);
+    // 32 pixel rows per block where that fills the chip; 16 where it would leave most CUs without a block (the deep U-Net stages at the
+    // rollout batch: 56 rows x 512 channels = 64 blocks of 32 rows): the weights stream at a per-CU rate, so twice the blocks stream them
+    // twice as fast, and their second read comes out of L2.  Same values: a row's sum does not depend on the rows beside it.
+    const bool one = g_skinny_mgb >= 0 && p.MT >= 2 && (g_skinny_mgb == 1 || blocks2 < (g_skinny_mgb > 1 ? g_skinny_mgb : 192));   // (knob 38 > 1: the block-count threshold, A/B)
+    const long blocks = one ? (long)phases * (a.N / 16) * p.MT : blocks2;
+#define M2H_SKINNY_GATHER(NW_)                                                                              \
+  do {                                                                                                      \
+    if (one) M2H_LAUNCH((skinny_gather_kernel<1, NW_>), dim3((unsigned)blocks), dim3(64 * NW_), 0, st, p);  \
+    else M2H_LAUNCH((skinny_gather_kernel<2, NW_>), dim3((unsigned)blocks), dim3(64 * NW_), 0, st, p);      \
+  } while (0)
+    if (nw == 4) M2H_SKINNY_GATHER(4);
+    else if (nw == 8) M2H_SKINNY_GATHER(8);
+    else M2H_SKINNY_GATHER(16);
+#undef M2H_SKINNY_GATHER
     return launch_status("conv_igemm_f32 (skinny gather)");
   }
   // 3x3 / stride 1 / pad 1 over 16- or 32-channel, 32-pixel-wide images in fp32 math, many rows (AcousticMem in update_sep)
