@@ -322,12 +322,18 @@ _refresh_hooks = weakref.WeakSet()   # objects with a sync() that brings derived
 def memos_of(*modules):
     """The packed-weight memos held by `modules` and their sub-modules (attributes that are a _PackMemo or a list / tuple of them)."""
     out = []
+
+    def walk(v):
+        if isinstance(v, _PackMemo):
+            out.append(v)
+        elif isinstance(v, (list, tuple)):
+            for m in v:
+                walk(m)      # (nested lists too: RNNStateEncoder keeps a pair of memos per layer)
+
     for root in modules:
         for mod in root.modules():
             for v in vars(mod).values():
-                for m in (v if isinstance(v, (list, tuple)) else (v,)):
-                    if isinstance(m, _PackMemo):
-                        out.append(m)
+                walk(v)
     return out
 
 

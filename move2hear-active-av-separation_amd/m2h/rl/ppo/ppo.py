@@ -227,6 +227,9 @@ class PPO(nn.Module):
             # conv weights re-packed in place after the previous step (the rollout's fused audio pair is rebuilt lazily, by its next user).
             # AcousticMem's packs are not this update's business -- and not its right: the trainer may be running update_sep on a second
             # stream at this moment (ppo_trainer.py, the cycle's tail), where that module re-packs its own weights in its own order.
+            # (Restricting this to the policy's own memos -- the frozen separators' look stale after every step too, their keys carry the global
+            # parameter epoch -- was measured in round 5: update_pol 42.1 / 42.4 / 42.5 against 41.6 / 42.6 / 42.3 ms per cycle: the epoch is
+            # host-bound around this point, the 108 us pack launch hides in that.)
             mem_ids = {id(m) for m in MF.memos_of(self.actor_critic.acoustic_mem)}
             MF.refresh_pack_memos(hooks=False, only=[m for m in list(MF._pack_memos) if id(m) not in mem_ids])
             if gs.graph is None:
