@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--no-far-target", action="store_true", help="skip the far-target / mixed-precision DD-PPO leg")
     ap.add_argument("--no-graph", action="store_true", help="enqueue the pair kernel by kernel instead of replaying a HIP graph")
     ap.add_argument("--ddppo-cycles", type=int, default=4, help="timed DD-PPO cycles (0 = skip); two untimed warm-up cycles precede them")
+    ap.add_argument("--force-schedule", choices=["overlap", "buckets"], default=None, help="as --force-buckets, one half of it only (A/B)")
+    ap.add_argument("--force-buckets", action="store_true",
+                    help="DD-PPO legs at one rank: run the N > 1 gradient schedule anyway (two buckets, split backward as two HIP graphs, side-stream "
+                         "steps; no collective at world size 1) -- what that schedule costs beside the one-rank one")
     ap.add_argument("--tail-overlap", action="store_true",
                     help="DD-PPO legs: enqueue the cycle's six update_sep on a second stream beside the last update_pol (overlap_update_tail; measured +0.5 %%: off)")
     ap.add_argument("--sep-update-math", choices=["fp32", "bf16x3"], default="bf16x3",
@@ -308,8 +312,11 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
     from m2h.rl.ppo.ppo_trainer import PPOTrainer, far_target_config, near_target_config
     syn = __import__("m2h.synthetic", fromlist=["x"])
     tail = bool(args.tail_overlap)
-    cfg = (far_target_config(rollout_math="fp32", overlap_update_tail=tail) if far_target
-           else near_target_config(sep_update_math=args.sep_update_math, overlap_update_tail=tail))
+    force = dict(bucketed_grad_reduce=True, overlap_grad_reduce=True) if args.force_buckets else {}
+    if args.force_schedule:
+        force = dict(overlap_grad_reduce=True) if args.force_schedule == "overlap" else dict(bucketed_grad_reduce=True)
+    cfg = (far_target_config(rollout_math="fp32", overlap_update_tail=tail, **force) if far_target
+           else near_target_config(sep_update_math=args.sep_update_math, overlap_update_tail=tail, **force))
     ops.set_math_mode(ops.MATH_BF16X3 if far_target else ops.MATH_FP32)
     try:
         tr = PPOTrainer(cfg, dev, world_rank=rank, world_size=world)
