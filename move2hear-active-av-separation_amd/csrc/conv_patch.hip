@@ -48,6 +48,9 @@
 #ifndef M2H_PATCH_P_AT
 #define M2H_PATCH_P_AT 1   // ... the patch DMAs
 #endif
+#ifndef M2H_PATCH_WT
+#define M2H_PATCH_WT 0     // 1: the tiles' 16-byte stores write-through (sc1): nothing of a layer's output stays dirty in L2 for the end-of-kernel write-back -- measured 1 % SLOWER (A/B builds)
+#endif
 #ifndef M2H_PATCH_PRIO
 #define M2H_PATCH_PRIO 0   // 1: s_setprio 1 for waves 4-7 (the younger wave of every SIMD) for the whole kernel (A/B builds)
 #endif
@@ -64,6 +67,18 @@ __device__ unsigned long long g_clock_dbg_patch[8192][16];   // [0] k-loop shade
 #endif
 
 namespace {
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// one 16-byte store per lane; write-through in M2H_PATCH_WT builds (`sc1`: the bytes go to the memory side at once and the line is not kept
+// dirty in the XCD's L2 -- MI355X_MICROARCH.md, stores of each flavour).  The s_nop keeps the data registers until the store has read
+// them (cdna_hip_programming.md 5.7: an asm store of 12 / 16 bytes).  Counted in vmcnt like any store.
+static __device__ __forceinline__ void store16(char* p, u32x4_t v) {
+#if M2H_PATCH_WT
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<u32x4_t*>(p) = v;
+#endif
+}
 
 constexpr int PNW = 8;          // waves per block
 constexpr int PHALO_ROWS = 384;  // WHOLE = 0: rows of a patch buffer
@@ -434,12 +449,12 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
           const auto l1 = __builtin_amdgcn_permlane16_swap(ula[1], ulb[1], false, false);
           const int cb = 128 * q + (16 * (half_ & 1) + 8 * (half_ >> 1)) * 2;   // byte offset of the lane's eight channels in the chunk's hi run
           if (ok) {
-            *reinterpret_cast<u32x4*>(rowp + cb) = u32x4{h0[0], h1[0], h0[1], h1[1]};
-            *reinterpret_cast<u32x4*>(rowp + 64 + cb) = u32x4{l0[0], l1[0], l0[1], l1[1]};
+            store16(rowp + cb, u32x4{h0[0], h1[0], h0[1], h1[1]});
+            store16(rowp + 64 + cb, u32x4{l0[0], l1[0], l0[1], l1[1]});
           }
         } else if (ok) {
-          *reinterpret_cast<f32x4*>(rowp + 128 * q + 16 * half_) = va;
-          *reinterpret_cast<f32x4*>(rowp + 128 * q + 64 + 16 * half_) = vb;
+          store16(rowp + 128 * q + 16 * half_, __builtin_bit_cast(u32x4_t, va));
+          store16(rowp + 128 * q + 64 + 16 * half_, __builtin_bit_cast(u32x4_t, vb));
         }
         acc[mi][2 * q] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[mi][2 * q + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
