@@ -1512,10 +1512,14 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
       const int phases = p.convT ? 4 : 1;
       const int nw = skinny_waves(p.Kw / 16);
       const bool wide = a.N * phases >= 64 * 16;
-      const dim3 grid((unsigned)(phases * (wide ? (a.N + 15) / 16 : (a.N + 3) / 4))), blk(64 * nw);
+      // two columns per block where four would leave most CUs without a block (N = 512 of one phase: 128 blocks): as the skinny gather
+      // kernel's 16-row blocks, the weights stream at a per-CU rate.  Same values (a column's sum does not depend on its neighbours).
+      const bool two = !wide && g_skinny_mgb >= 0 && a.N % 2 == 0 && (long)phases * ((a.N + 3) / 4) < 192;
+      const dim3 grid((unsigned)(phases * (wide ? (a.N + 15) / 16 : two ? (a.N + 1) / 2 : (a.N + 3) / 4))), blk(64 * nw);
 #define M2H_SKINNY_ROWS(NW_)                                                                       \
   do {                                                                                             \
     if (wide) M2H_LAUNCH((skinny_rows_kernel<16, NW_>), grid, blk, 0, st, p);              \
+    else if (two) M2H_LAUNCH((skinny_rows_kernel<2, NW_>), grid, blk, 0, st, p);           \
     else M2H_LAUNCH((skinny_rows_kernel<4, NW_>), grid, blk, 0, st, p);                    \
   } while (0)
       if (nw == 4) M2H_SKINNY_ROWS(4);
