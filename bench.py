@@ -779,10 +779,21 @@ def main():
     elapsed, _ = timed_run(args.math, args.steps, args.warmup, False)
     roofline, layers, evented_ms = None, None, None
     if not args.no_kernel_timing:
-        ev_elapsed, sink = timed_run(args.math, args.steps, 1, True)
+        # the per-kernel pass enqueues kernel by kernel with an event around each: when the host is slow (a busy box) the device idles between
+        # the kernels, clocks down, and every duration reads high (seen: 8.4 ms per evented step, kernels +15 %).  Up to three passes; the one
+        # whose wall time is closest to the graph replay's is kept, and the number of passes is reported.
+        best = None
+        for attempt in range(3):
+            ev_elapsed, sink = timed_run(args.math, args.steps, 1, True)
+            if best is None or ev_elapsed < best[0]:
+                best = (ev_elapsed, sink)
+            if ev_elapsed <= 1.25 * elapsed:
+                break
+        ev_elapsed, sink = best
         roofline, layers = account(sink, args.steps, args.math)
         evented_ms = round(1e3 * ev_elapsed / args.steps, 3)
         roofline["evented_pass_ms_per_step"] = evented_ms
+        roofline["evented_passes_run"] = attempt + 1
     other_mode, parity, bf16_mode = None, None, None
     if not args.no_other_mode:
         o_steps = max(2, args.steps // 3)
