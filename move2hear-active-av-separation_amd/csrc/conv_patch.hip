@@ -652,7 +652,9 @@ static int launch_patch_cfg(IGemmP& p, const PatchGeo& g, int S, hipStream_t st)
   const long nblk = ((long)p.MT + 7) / 8 * 8 * p.NT * (p.convT ? 4 : 1);
   if (nblk > 0x7fffffffL) return -2;
   // every tile index is a tile (MT a multiple of 8): a workgroup per CU walks them; otherwise one workgroup per index
-  const long lim = g_patch == 8 ? nblk : patch_grid_limit();   // m2h_tuning_set 36 = 8: one workgroup per tile (A/B)
+  // m2h_tuning_set 36 = 8: one workgroup per tile (A/B); m2h_tuning_set 10 = n >= 8: n workgroups (a multiple of 8; tests: other tile sequences per
+  // workgroup than this chip's CU count gives -- phase and n-tile changing from one tile of a workgroup to its next, many tiles per workgroup)
+  const long lim = g_patch == 8 ? nblk : (g_patch_grid >= 8 ? g_patch_grid / 8 * 8 : patch_grid_limit());
   const long gx = (p.MT % 8 == 0 && nblk > lim) ? lim : nblk;
   const dim3 grid((unsigned)gx, (unsigned)S), blk(64 * PNW);
   const int ntiles = (int)nblk;

@@ -166,6 +166,43 @@ def test_runner_with_the_patch_engine_matches_the_dma_engine_and_the_oracle(B, t
     assert O.rel_l1(got[0].cpu() * em, want_m * em) < 1e-4 and O.rel_l1(got[1].cpu(), want_mono) < 1e-4
 
 
+@pytest.mark.parametrize("B,H,W,C0,C1,Co,transposed", [
+    (16, 4, 32, 64, 64, 256, True),     # transposed conv, two n-tiles x four phases x 8 m-tiles = 64 tiles
+    (16, 8, 64, 64, 0, 128, False),     # conv, halo patch form, 16 m-tiles
+    (32, 8, 16, 64, 0, 64, True),       # 64-wide transposed conv on the 512 x 64 tile: 8 m-tiles x four phases
+])
+def test_patch_engine_result_does_not_depend_on_the_persistent_grid(B, H, W, C0, C1, Co, transposed):
+    """One workgroup per CU walks tiles L, L + G, ...: with G = 8 / 24 / 40 workgroups (tuning knob 10) a workgroup's consecutive tiles differ in
+    phase and n-tile (G % 32 != 0), it crosses many tile boundaries, and the last workgroups hold one tile fewer -- the values must be those of
+    one workgroup per tile, bit for bit (a tile's summation order does not depend on who computes it)."""
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + H + W + Co)
+    x = torch.randn(B, C0, H, W, generator=g)
+    x2 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    Ci = C0 + C1
+    w = torch.randn(Ci, Co, 4, 4, generator=g) * 0.05 if transposed else torch.randn(Co, Ci, 4, 4, generator=g) * 0.05
+    scale, shift = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.1
+    nhwc = lambda t: ops.split32(t.permute(0, 2, 3, 1).contiguous().to(dev))  # noqa: E731
+    wp = ops.split32(ops.pack_convT_weight(w.to(dev)) if transposed else ops.pack_conv_weight(w.to(dev)))
+    args = (nhwc(x), nhwc(x2) if C1 else None, wp, Co, transposed, scale.to(dev), shift.to(dev), 0.0 if transposed else 0.2)
+    ops.set_math_mode(ops.MATH_BF16X3)
+    outs = {}
+    try:
+        for grid in (None, 8, 24, 40):
+            ops.debug_set(36, 2)
+            ops.debug_set(10, 1 << 20 if grid is None else grid)    # (more workgroups than tiles: one workgroup per tile)
+            got, label = _layer(*args)
+            assert label.startswith("igemm_patch"), label
+            outs[grid] = got.cpu()
+    finally:
+        ops.debug_set(36, 0)
+        ops.debug_set(10, 0)
+        ops.set_math_mode(ops.MATH_FP32)
+    for grid in (8, 24, 40):
+        assert torch.equal(outs[grid], outs[None]), grid
+
+
 def test_patch_engine_two_class_halves_as_split_k():
     """Half a chip's worth of tiles and a long reduction (the fourth encoder stage at the benchmark batch; here 128 images, N = 1024):
     the engine's own dispatch (no knob) splits the window's classes into two K-halves + the ordered reduce kernel."""

@@ -51,13 +51,16 @@ def main():
         shift = torch.randn(Co, device=dev, generator=g) * 0.1
         args = (x, x2, wp, Co, transposed, scale, shift, 0.0 if transposed else 0.2)
         knob = rnd.choice((2, 3))
+        grid = rnd.choice((0, 0, 8, 16, 24, 40))   # workgroups of the engine's persistent launch (0: one per CU): other tile sequences per workgroup
         try:
             ops.debug_set(36, knob)
+            ops.debug_set(10, grid)
             got, label = _layer(*args)
             ops.debug_set(36, -1)
             ref, ref_label = _layer(*args)
         finally:
             ops.debug_set(36, 0)
+            ops.debug_set(10, 0)
         if not label.startswith("igemm_patch"):   # a shape the engine refuses (tap window, tiny images): nothing to compare
             skipped += 1
             continue
