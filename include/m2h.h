@@ -607,6 +607,9 @@ typedef struct m2h_unet_weights {
   int math_mode;              /* arithmetic of this call: 0 = the calling thread's (m2h_set_math_mode), 1 = fp32 MFMA, 2 = bf16x3 */
   const void* down0_strip;    /* first-stage weights in the strip kernel's register image (m2h_pack_strip_conv1) or NULL.  With it, split32
                                  weights and T % 64 == 0 the runner replaces the slice kernel + first encoder stage by m2h_strip_conv1_fwd */
+  int cls_kind;               /* what m2h_unet_fwd's cls_val argument points at: 0 = [B] floats holding target_class + 1 (the class plane's value,
+                                 separator_cnn.py:93-96); 1 = the raw target_class as [B] float32, 2 = as [B] int64: the ".float() + 1" of :96 then
+                                 happens inside the network's first kernel (no launch of its own) */
 } m2h_unet_weights;
 
 size_t m2h_unet_fwd_workspace_bytes(int B, int F, int T);

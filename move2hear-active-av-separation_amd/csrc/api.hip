@@ -7,6 +7,10 @@ thread_local char g_err[512] = {0};
 thread_local const char* tl_last_launch = "";
 thread_local const char* tl_unet_stage[11] = {"", "", "", "", "", "", "", "", "", "", ""};
 int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st);
+int launch_strip_conv1(const float* mix, const float* masks, const void* wreg, const float* scale, const float* shift, const float* cls_table,
+                       const float* cls_val, float* dst, int B, int T, float slope, hipStream_t st, int cls_kind);
+int sep_slice_input_cls(const float* mix, const float* masks, float* out, int B, int F, int T, int split_out, const void* cls_raw, int cls_kind,
+                        float* cls_out, hipStream_t st);
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a);
 thread_local Tuning tl_tuning = {};   // every knob 0 = automatic (m2h_internal.h)
 extern thread_local int tl_math_mode;
@@ -143,7 +147,7 @@ static const int kEnc[6] = {32, 64, 128, 256, 512, 512};
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 struct UnetLayout {
-  size_t x0, e[5], d[5], splitk, total;
+  size_t x0, e[5], d[5], splitk, cls, total;
 };
 
 static UnetLayout unet_layout(int B, int F, int T, int n_out) {
@@ -176,6 +180,7 @@ static UnetLayout unet_layout(int B, int F, int T, int n_out) {
     h *= 2; w *= 2;
   }
   L.splitk = off; off += align256(sk);
+  L.cls = off; off += align256((size_t)B * 4);   // the class plane's values when the caller hands over the raw target_class (cls_kind)
   L.total = off;
   return L;
 }
@@ -205,7 +210,7 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
     d[i] = reinterpret_cast<float*>(ws + L.d[i]);
   }
   void* sk = ws + L.splitk;
-  const size_t skb = L.total - L.splitk;
+  const size_t skb = L.cls - L.splitk;
   hipStream_t st = as_stream(stream);
   int ev = 0, stage_no = 0;
   auto mark = [&]() -> int {
@@ -227,8 +232,16 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
   // (the strip walkers index pixels with 32 bits: batches beyond that fall back to the tiled engines instead of failing)
   const bool strip_fits = (size_t)B * 512 * T * 2 < (1ull << 31);
   const bool strip0 = sp && wts->down0_strip != nullptr && T % 64 == 0 && g_strip >= 0 && strip_fits;
+  const int cls_kind = cls_val != nullptr ? wts->cls_kind : 0;
+  M2H_REQUIRE(cls_kind >= 0 && cls_kind <= 2, "unet_fwd: cls_kind must be 0, 1 or 2");
   if (!strip0) {
-    rc = m2h_sep_slice_input_fmt(mix, masks, x0, B, F, T, 2, sp, stream);
+    if (cls_kind != 0) {   // the slice launch also makes the class plane's values from the raw target_class
+      float* cls_out = reinterpret_cast<float*>(ws + L.cls);
+      rc = sep_slice_input_cls(mix, masks, x0, B, F, T, sp, cls_val, cls_kind, cls_out, st);
+      cls_val = cls_out;
+    } else {
+      rc = m2h_sep_slice_input_fmt(mix, masks, x0, B, F, T, 2, sp, stream);
+    }
     if (rc) return rc;
   }
   if ((rc = mark())) return rc;
@@ -237,8 +250,9 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
   for (int i = 0; i < 5; ++i) {
     M2H_REQUIRE(h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "unet_fwd: stage %d input %d x %d", i, h, w);
     if (i == 0 && strip0) {
-      if ((rc = m2h_strip_conv1_fwd(mix, masks, wts->down0_strip, wts->down_scale[0], wts->down_shift[0], wts->cls_table, cls_val, e[0], B, F, T,
-                                    0.2f, stream)))
+      M2H_REQUIRE(F == 512 && (wts->cls_table == nullptr) == (cls_val == nullptr), "unet_fwd: strip stage: F must be 512, class table / value mismatch");
+      if ((rc = launch_strip_conv1(mix, masks, wts->down0_strip, wts->down_scale[0], wts->down_shift[0], wts->cls_table, cls_val, e[0], B, T, 0.2f, st,
+                                   cls_kind)))
         return rc;
       if ((rc = mark())) return rc;
       cur = e[0];

@@ -110,7 +110,8 @@ struct StripConv1P {
   const float* scale;
   const float* shift;
   const float* cls_table;   // [9][64] or null
-  const float* cls_val;     // [B]
+  const float* cls_val;     // [B] (cls_kind 0: target_class + 1 as floats; 1: raw target_class, float32; 2: raw, int64)
+  int cls_kind;
   float* dst;
   int B, T, Wq, strips, jobs, jobs_padded;   // jobs_padded: linear job slots incl. the images a partial group of 8 leaves empty
   float slope;
@@ -172,7 +173,10 @@ __global__ __launch_bounds__(256, 2) void conv1_strip_kernel(const StripConv1P p
     const float* mixb = p.mix + (size_t)b * 512 * p.T * 2;     // this image (uniform); lane offsets below are 32-bit
     const float* maskb = MASKED ? p.masks + (size_t)b * 512 * p.T * 2 : nullptr;
     const bool has_l = r0 > 0, has_r = r0 + SW < p.Wq;
-    const float cv = p.cls_table != nullptr ? p.cls_val[b] : 0.f;
+    const float cv = p.cls_table == nullptr ? 0.f
+                     : p.cls_kind == 0 ? p.cls_val[b]
+                     : p.cls_kind == 1 ? p.cls_val[b] + 1.f
+                                       : (float)reinterpret_cast<const long long*>(p.cls_val)[b] + 1.f;   // separator_cnn.py:96
     int l_off[2];    // [t]: frequency row s * 32 (s = 4 wave + 2 t + sb), column pair ii of the strip
 #pragma unroll
     for (int t = 0; t < 2; ++t) l_off[t] = ((4 * wave + 2 * t + sb) * 32 * p.T + 2 * r0 + 2 * ii) * 2;
@@ -359,8 +363,9 @@ __global__ void pack_strip_conv1_kernel(const float* __restrict__ w, int Ci, f32
 }
 
 int launch_strip_conv1(const float* mix, const float* masks, const void* wreg, const float* scale, const float* shift, const float* cls_table,
-                       const float* cls_val, float* dst, int B, int T, float slope, hipStream_t st) {
+                       const float* cls_val, float* dst, int B, int T, float slope, hipStream_t st, int cls_kind) {
   StripConv1P p;
+  p.cls_kind = cls_kind;
   p.mix = mix; p.masks = masks; p.wreg = static_cast<const f32x4*>(wreg); p.scale = scale; p.shift = shift;
   p.cls_table = cls_table; p.cls_val = cls_val; p.dst = dst;
   p.B = B; p.T = T; p.Wq = T / 2; p.strips = p.Wq / SW; p.jobs = B * p.strips; p.slope = slope;
@@ -676,7 +681,7 @@ int m2h_strip_conv1_fwd(const float* mix, const float* masks, const void* wreg, 
   M2H_REQUIRE(B > 0 && F == 512 && T >= 64 && T % 64 == 0, "strip_conv1: F must be 512 and T a multiple of 64 (got %d x %d)", F, T);
   M2H_REQUIRE((cls_table == nullptr) == (cls_val == nullptr), "strip_conv1: class table / value mismatch");
   M2H_REQUIRE((size_t)B * 512 * T * 2 < (1ull << 31), "strip_conv1: input too large for 32-bit pixel arithmetic");
-  return launch_strip_conv1(mix, masks, wreg, scale, shift, cls_table, cls_val, dst, B, T, slope, as_stream(stream));
+  return launch_strip_conv1(mix, masks, wreg, scale, shift, cls_table, cls_val, dst, B, T, slope, as_stream(stream), 0);
 }
 
 int m2h_strip_last_fwd(const float* x, const float* skip, const float* wp_split32, const float* scale, const float* shift, const float* head_w,

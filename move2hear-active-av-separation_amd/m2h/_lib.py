@@ -103,7 +103,7 @@ class UnetWeights(ctypes.Structure):
         ("n_out", ctypes.c_int),
         ("weights_split32", ctypes.c_int),
         ("math_mode", ctypes.c_int),
-        ("down0_strip", ctypes.c_void_p),
+        ("down0_strip", ctypes.c_void_p), ("cls_kind", ctypes.c_int),
     ]
 
 

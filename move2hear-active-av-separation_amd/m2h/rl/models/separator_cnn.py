@@ -299,7 +299,16 @@ def unet_forward(enc, dec, mix, masks=None, target_class=None, events=None):
     w.down0_strip = _strip_conv1_of(enc, downs[0][0]).data_ptr() if (split and T % 64 == 0) else None
     cls_val = None
     if table is not None:
-        cls_val = (target_class.reshape(-1).to(torch.float32) + 1.0).contiguous()
+        # the raw target_class goes to the runner, whose first kernel makes the plane's value ".float() + 1" (reference :96) itself
+        cls_val = target_class.reshape(-1).contiguous()
+        if cls_val.dtype == torch.float32:
+            w.cls_kind = 1
+        elif cls_val.dtype == torch.int64:
+            w.cls_kind = 2
+        else:
+            cls_val, w.cls_kind = (cls_val.to(torch.float32) + 1.0).contiguous(), 0
+        if cls_val.numel() != B or not cls_val.is_cuda:
+            raise RuntimeError("m2h.unet_forward: target_class must hold one value per batch row on the GPU")
     if masks is not None:
         masks = masks.contiguous()
     lib = _lib.load()

@@ -249,6 +249,35 @@ def test_whole_network_runner_is_bitwise_the_module_chain(mode):
         ops.set_math_mode(ops.MATH_FP32)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_runner_takes_the_raw_target_class_in_every_dtype(mode):
+    """The class plane's value "target_class.float() + 1" (reference separator_cnn.py:96) is made inside the runner's first kernel from the
+    raw target_class (m2h_unet_weights.cls_kind): int64 (the simulator's dtype), float32 (the rollout storage's) and any other dtype (the
+    host-side conversion) give bit-identical masks, on the slice kernel's path (tm 32) and on the strip kernel's (tm 64, bf16x3)."""
+    from m2h import ops
+    from m2h.rl.models.separator_cnn import unet_forward
+    dev = _dev()
+    pol, _ = _policy(4, dev)
+    enc, dec = pol.binSep_enc.passive_sep_encoder, pol.binSep_dec.passive_sep_decoder
+    ops.set_math_mode(ops.MATH_BF16X3 if mode == "bf16x3" else ops.MATH_FP32)
+    try:
+        for B, tm in ((5, 32), (3, 64)):
+            mixed, tc = synthetic.make_passive_inputs(B, tm, 90 + B)
+            mix = torch.from_numpy(mixed).to(dev)
+            tcl = torch.from_numpy(tc).to(dev)
+            with torch.no_grad():
+                outs = [unet_forward(enc, dec, mix, None, tcl.to(dt)) for dt in (torch.int64, torch.float32, torch.int32, torch.float64)]
+                chain = pol.binSep_dec(*pol.binSep_enc({"mixed_bin_audio_mag": mix, "target_class": tcl}))
+            for o in outs[1:]:
+                assert torch.equal(o, outs[0])
+            if mode == "fp32":
+                assert torch.equal(outs[0], chain)
+            else:
+                assert O.rel_l1(outs[0].cpu(), chain.cpu()) < 3e-5
+    finally:
+        ops.set_math_mode(ops.MATH_FP32)
+
+
 @pytest.mark.parametrize("B,tm", [(3, 32), (1, 256), (5, 64)])
 def test_dma_engine_matches_register_engine(B, tm):
     """The LDS-DMA engine (csrc/conv_dma.hip: split32 operands DMA'd into an LDS ring, fragments read through a row permutation)
