@@ -278,6 +278,30 @@ def test_runner_takes_the_raw_target_class_in_every_dtype(mode):
         ops.set_math_mode(ops.MATH_FP32)
 
 
+def test_strip_kernels_give_the_same_values_in_either_walking_direction():
+    """The strip kernels' persistent workgroups walk the images downwards or upwards (knob 39; the last stage's default is downwards so
+    that the next U-Net finds its input in the memory-side cache): every (image, strip) job is independent, so the results are
+    bit-identical, also with a last group of fewer than 8 images (empty job slots)."""
+    from m2h import ops
+    dev = _dev()
+    pol, _ = _policy(6, dev)
+    mixed, tc = synthetic.make_passive_inputs(11, 64, 123)
+    obs = {"mixed_bin_audio_mag": torch.from_numpy(mixed).to(dev), "target_class": torch.from_numpy(tc).to(dev)}
+    ops.set_math_mode(ops.MATH_BF16X3)
+    try:
+        res = []
+        for v in (0, 1, 2, 3, 7):
+            ops.debug_set(39, v)
+            with torch.no_grad():
+                m = pol.get_binSepMasks(obs)
+                res.append((m, pol.convert_bin2mono(m, mixed_audio=obs["mixed_bin_audio_mag"])))
+        for m, mono in res[1:]:
+            assert torch.equal(m, res[0][0]) and torch.equal(mono, res[0][1])
+    finally:
+        ops.debug_set(39, 0)
+        ops.set_math_mode(ops.MATH_FP32)
+
+
 @pytest.mark.parametrize("B,tm", [(3, 32), (1, 256), (5, 64)])
 def test_dma_engine_matches_register_engine(B, tm):
     """The LDS-DMA engine (csrc/conv_dma.hip: split32 operands DMA'd into an LDS ring, fragments read through a row permutation)
