@@ -65,6 +65,7 @@ def parse():
                     help="arithmetic of the forward / input-gradient GEMMs of the passive training leg (weight gradients, BatchNorm, Adam stay fp32)")
     ap.add_argument("--train-batch", type=int, default=64, help="pretrain_passive.yaml BATCH_SIZE")
     ap.add_argument("--train-tm", type=int, default=32, help="time frames of the training clips (32 = 1 s, the reference's)")
+    ap.add_argument("--knobs", default="", help="A/B only: m2h_tuning_set pairs 'knob=value,...' (include/m2h_tuning.h: kernels that compute the same values)")
     return ap.parse_args()
 
 
@@ -590,6 +591,8 @@ def main():
         raise RuntimeError("bench.py --gpus %d but the process group has %d rank(s) (WORLD_SIZE=%s)" % (args.gpus, ranks_observed, os.environ.get("WORLD_SIZE")))
 
     from m2h import ops
+    for kv in filter(None, args.knobs.split(",")):
+        ops.debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
     pol, sd = make_policy(dev)
     mix, tc = make_inputs(dev, args.batch, args.tm, 1000 + rank)
     obs = {"mixed_bin_audio_mag": mix, "target_class": tc}

@@ -29,23 +29,33 @@ __device__ __forceinline__ Wf wf_combine(Wf a, Wf b) {
 
 // stage 1: part[split][c] = (n, mean, M2) over the split's rows
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ z, float* __restrict__ part, int M, int C, int rows_per_split) {
-  __shared__ Wf sh[4][64];
+  constexpr int NW = 4;   // waves = row lanes
+  __shared__ Wf sh[NW][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int w = threadIdx.x >> 6;
   const int m0 = blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
   Wf a = {0.f, 0.f, 0.f};
   if (c < C)
-    for (int m = m0 + w; m < m1; m += 4) {
-      const float x = z[(size_t)m * C + c];
-      a.n += 1.f;
-      const float d = x - a.mean;
-      a.mean += d / a.n;
-      a.m2 += d * (x - a.mean);
+    for (int m = m0 + w; m < m1; m += 8 * NW) {   // eight rows' loads in flight, then their updates in row order (the order of a one-row loop)
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = m + NW * j < m1 ? z[(size_t)(m + NW * j) * C + c] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (m + NW * j < m1) {
+          a.n += 1.f;
+          const float d = x[j] - a.mean;
+          a.mean += d / a.n;
+          a.m2 += d * (x[j] - a.mean);
+        }
     }
   sh[w][threadIdx.x & 63] = a;
   __syncthreads();
   if (w == 0 && c < C) {
     Wf r = wf_combine(wf_combine(sh[0][threadIdx.x], sh[1][threadIdx.x]), wf_combine(sh[2][threadIdx.x], sh[3][threadIdx.x]));
+#pragma unroll
+    for (int k = 4; k < NW; k += 4)
+      r = wf_combine(r, wf_combine(wf_combine(sh[k][threadIdx.x], sh[k + 1][threadIdx.x]), wf_combine(sh[k + 2][threadIdx.x], sh[k + 3][threadIdx.x])));
     float* p = part + ((size_t)blockIdx.y * C + c) * 3;
     p[0] = r.n;
     p[1] = r.mean;
@@ -109,18 +119,31 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ z,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd, float slope,
                                                              float* __restrict__ part, int M, int C, int rows_per_split) {
-  __shared__ float sh[2][4][64];
+  constexpr int NW = 4;
+  __shared__ float sh[2][NW][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int w = threadIdx.x >> 6;
   const int m0 = blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
   float s0 = 0.f, s1 = 0.f;
   if (c < C) {
     const float mu = mean[c], is = invstd[c];
-    for (int m = m0 + w; m < m1; m += 4) {
-      const size_t i = (size_t)m * C + c;
-      const float g = y[i] > 0.f ? dy[i] : dy[i] * slope;
-      s0 += g;
-      s1 += g * ((z[i] - mu) * is);
+    for (int m = m0 + w; m < m1; m += 4 * NW) {   // four rows' loads in flight, summed in row order
+      float vy[4], vd[4], vz[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = m + NW * j < m1;
+        const size_t i = (size_t)(ok ? m + NW * j : m) * C + c;
+        vy[j] = y[i];
+        vd[j] = dy[i];
+        vz[j] = z[i];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (m + NW * j < m1) {
+          const float g = vy[j] > 0.f ? vd[j] : vd[j] * slope;
+          s0 += g;
+          s1 += g * ((vz[j] - mu) * is);
+        }
     }
   }
   sh[0][w][threadIdx.x & 63] = s0;
@@ -128,8 +151,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   __syncthreads();
   if (w == 0 && c < C) {
     const int t = threadIdx.x;
-    part[((size_t)blockIdx.y * 2 + 0) * C + c] = sh[0][0][t] + sh[0][1][t] + sh[0][2][t] + sh[0][3][t];
-    part[((size_t)blockIdx.y * 2 + 1) * C + c] = sh[1][0][t] + sh[1][1][t] + sh[1][2][t] + sh[1][3][t];
+    float r0 = sh[0][0][t] + sh[0][1][t] + sh[0][2][t] + sh[0][3][t];
+    float r1 = sh[1][0][t] + sh[1][1][t] + sh[1][2][t] + sh[1][3][t];
+#pragma unroll
+    for (int k = 4; k < NW; ++k) {
+      r0 += sh[0][k][t];
+      r1 += sh[1][k][t];
+    }
+    part[((size_t)blockIdx.y * 2 + 0) * C + c] = r0;
+    part[((size_t)blockIdx.y * 2 + 1) * C + c] = r1;
   }
 }
 
@@ -207,9 +237,9 @@ int m2h_bn_train_fwd(const float* z, const float* gamma, const float* beta, floa
                      float* running_var, float* mean, float* invstd, float* y, int M, int C, float* workspace, m2h_stream stream) {
   M2H_REQUIRE(z && gamma && beta && mean && invstd && y && workspace && M > 1 && C > 0 && C % 4 == 0, "bn_train_fwd: bad arguments (C %% 4, M > 1)");
   M2H_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_fwd: running stats mismatch");
+  hipStream_t st = as_stream(stream);
   const int splits = bn_splits(M, C);
   const int rps = (M + splits - 1) / splits;
-  hipStream_t st = as_stream(stream);
   M2H_LAUNCH(bn_stats_partial_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, z, workspace, M, C, rps);
   M2H_LAUNCH(bn_stats_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, splits, C, eps, momentum, mean, invstd,
                      running_mean, running_var);
@@ -222,9 +252,9 @@ int m2h_bn_train_bwd(const float* dy, const float* y, const float* z, const floa
                      float* dgamma, float* dbeta, float* dz, int M, int C, float* workspace, m2h_stream stream) {
   M2H_REQUIRE(dy && y && z && mean && invstd && gamma && dgamma && dbeta && dz && workspace && M > 1 && C > 0 && C % 4 == 0,
               "bn_train_bwd: bad arguments");
+  hipStream_t st = as_stream(stream);
   const int splits = bn_splits(M, C);
   const int rps = (M + splits - 1) / splits;
-  hipStream_t st = as_stream(stream);
   M2H_LAUNCH(bn_bwd_partial_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, y, z, mean, invstd, slope, workspace, M, C, rps);
   M2H_LAUNCH(bn_bwd_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, splits, C, dgamma, dbeta);
   const size_t n4 = (size_t)M * C / 4;

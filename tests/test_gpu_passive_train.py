@@ -21,19 +21,21 @@ def _rel(a, b):
     return O.rel_l1(torch.as_tensor(a).detach().cpu(), torch.as_tensor(b).detach())
 
 
-@pytest.mark.parametrize("slope", [0.2, 0.0])
-def test_bn_act_train_forward_backward_match_torch(slope):
+@pytest.mark.parametrize("slope,shape", [(0.2, (6, 64, 8, 16)), (0.0, (6, 64, 8, 16)), (0.0, (3, 512, 1, 2)), (0.2, (64, 64, 16, 16)), (0.2, (5, 128, 8, 8)),
+                                         (0.0, (7, 256, 4, 4)), (0.2, (64, 512, 2, 2)), (0.2, (3, 12, 4, 4)), (0.0, (5, 64, 20, 20))])
+def test_bn_act_train_forward_backward_match_torch(slope, shape):
     from m2h import functional as MF
     dev = _dev()
     g = torch.Generator().manual_seed(3)
-    x = (torch.randn(6, 64, 8, 16, generator=g) * 1.7 + 0.4).requires_grad_(True)
-    bn = torch.nn.BatchNorm2d(64)
+    Cn = shape[1]
+    x = (torch.randn(*shape, generator=g) * 1.7 + 0.4).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(Cn)
     with torch.no_grad():
-        bn.weight.copy_(torch.rand(64, generator=g) + 0.5)
-        bn.bias.copy_(torch.randn(64, generator=g) * 0.2)
-        bn.running_mean.copy_(torch.randn(64, generator=g) * 0.1)
-        bn.running_var.copy_(torch.rand(64, generator=g) + 0.5)
-    bn2 = torch.nn.BatchNorm2d(64)
+        bn.weight.copy_(torch.rand(Cn, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(Cn, generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(Cn, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(Cn, generator=g) + 0.5)
+    bn2 = torch.nn.BatchNorm2d(Cn)
     bn2.load_state_dict(bn.state_dict())
     bn2 = bn2.to(dev)
     bn.train()
