@@ -49,7 +49,9 @@
 #define M2H_PATCH_P_AT 1   // ... the patch DMAs
 #endif
 #ifndef M2H_PATCH_WT
-#define M2H_PATCH_WT 0     // 1: the tiles' 16-byte stores write-through (sc1): nothing of a layer's output stays dirty in L2 for the end-of-kernel write-back -- measured 1 % SLOWER (A/B builds)
+#define M2H_PATCH_WT 2     // 2: a workgroup's LAST tile leaves write-through (sc1 stores), so the end-of-kernel write-back of the XCD L2s finds a round
+                           // of tiles less dirty data: pair minima 2.1016 / 2.1051 / 2.1040 against 2.1130 / 2.1160 / 2.1201 ms, medians -0.15 % (A/B builds,
+                           // profiles/r05_lib_ab_wt2.txt); 1: every tile (measured 1 % SLOWER); 0: none
 #endif
 #ifndef M2H_PATCH_PRIO
 #define M2H_PATCH_PRIO 0   // 1: s_setprio 1 for waves 4-7 (the younger wave of every SIMD) for the whole kernel (A/B builds)
@@ -72,12 +74,10 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // one 16-byte store per lane; write-through in M2H_PATCH_WT builds (`sc1`: the bytes go to the memory side at once and the line is not kept
 // dirty in the XCD's L2 -- MI355X_MICROARCH.md, stores of each flavour).  The s_nop keeps the data registers until the store has read
 // them (cdna_hip_programming.md 5.7: an asm store of 12 / 16 bytes).  Counted in vmcnt like any store.
+template <bool WT>
 static __device__ __forceinline__ void store16(char* p, u32x4_t v) {
-#if M2H_PATCH_WT
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#else
-  *reinterpret_cast<u32x4_t*>(p) = v;
-#endif
+  if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else *reinterpret_cast<u32x4_t*>(p) = v;
 }
 
 constexpr int PNW = 8;          // waves per block
@@ -401,7 +401,8 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   // chunk; after v_permlane16_swap (odd 16-lane rows of the first operand <-> even rows of the second) a lane of row `half` holds
   // the eight consecutive channels 16 (half & 1) + 8 (half >> 1) .. + 7 of the chunk: one 16-byte store of hi halves, one of lo
   // halves; the four lanes of a pixel cover its 64-byte hi run, then its lo run (one 128-byte line per pixel and chunk).
-  auto store_tile = [&](int m0, int n0, int phase) {
+  auto store_tile = [&](int m0, int n0, int phase, auto lastc) {   // lastc: the workgroup's last tile (M2H_PATCH_WT 2: only that one leaves write-through)
+    constexpr bool WT = M2H_PATCH_WT == 1 || (M2H_PATCH_WT == 2 && decltype(lastc)::value);
     int frow_ = frow, half_ = half;
     asm volatile("" : "+v"(frow_), "+v"(half_));   // (opaque, as in build_atab)
     if (p.S > 1) {   // raw partial sums to the slab [split][M][N], 16 bytes per lane; BN / activation / store in splitk_epilogue_kernel
@@ -449,12 +450,12 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
           const auto l1 = __builtin_amdgcn_permlane16_swap(ula[1], ulb[1], false, false);
           const int cb = 128 * q + (16 * (half_ & 1) + 8 * (half_ >> 1)) * 2;   // byte offset of the lane's eight channels in the chunk's hi run
           if (ok) {
-            store16(rowp + cb, u32x4{h0[0], h1[0], h0[1], h1[1]});
-            store16(rowp + 64 + cb, u32x4{l0[0], l1[0], l0[1], l1[1]});
+            store16<WT>(rowp + cb, u32x4{h0[0], h1[0], h0[1], h1[1]});
+            store16<WT>(rowp + 64 + cb, u32x4{l0[0], l1[0], l0[1], l1[1]});
           }
         } else if (ok) {
-          store16(rowp + 128 * q + 16 * half_, __builtin_bit_cast(u32x4_t, va));
-          store16(rowp + 128 * q + 64 + 16 * half_, __builtin_bit_cast(u32x4_t, vb));
+          store16<WT>(rowp + 128 * q + 16 * half_, __builtin_bit_cast(u32x4_t, va));
+          store16<WT>(rowp + 128 * q + 64 + 16 * half_, __builtin_bit_cast(u32x4_t, vb));
         }
         acc[mi][2 * q] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[mi][2 * q + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
 #ifdef M2H_CLOCK_DIAG
       if (gs + 1 == NS) dbg_st[0] = __builtin_amdgcn_s_memtime();
 #endif
-      store_tile(c_m0, c_n0, c_phase);
+      store_tile(c_m0, c_n0, c_phase, std::false_type{});
 #ifdef M2H_CLOCK_DIAG
       if (gs + 1 == NS) dbg_st[1] = __builtin_amdgcn_s_memtime();
 #endif
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(64 * PNW, 1) void igemm_patch_kernel(const IGemmP p
   body(T2{}, C0{}, false, N{}, P0{});
   load_a(ab, std::integral_constant<int, 3>{}, IH{}, IF{});
   for_ni([&](auto nic) { mfma_col(I0{}, IF{}, nic); });
-  store_tile(c_m0, c_n0, c_phase);
+  store_tile(c_m0, c_n0, c_phase, std::true_type{});
 
 #ifdef M2H_CLOCK_DIAG
   if (tid == 0 && blockIdx.x < 8192) {
