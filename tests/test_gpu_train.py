@@ -455,7 +455,8 @@ def test_batched_pack_equals_the_single_tensor_packs():
     dev = _dev()
     g = torch.Generator().manual_seed(12)
     items, want = [], []
-    for (Co, Ci, KH, KW, cpad) in [(64, 33, 4, 4, 36), (512, 256, 4, 4, 256), (32, 3, 8, 8, 4), (64, 32, 4, 4, 32), (512, 32, 12, 12, 32), (32, 64, 2, 2, 64)]:
+    for (Co, Ci, KH, KW, cpad) in [(64, 33, 4, 4, 36), (512, 256, 4, 4, 256), (32, 3, 8, 8, 4), (64, 32, 4, 4, 32), (512, 32, 12, 12, 32), (32, 64, 2, 2, 64),
+                                 (1536, 1536, 1, 1, 1536), (1536, 512, 1, 1, 512), (5, 512, 1, 1, 512), (130, 70, 1, 1, 72)]:   # (1 x 1: nn.Linear -- a block per 64 x 64 tile)
         w = torch.randn(Co, Ci, KH, KW, generator=g).to(dev)
         dst = torch.empty(Co, KH * KW * cpad, device=dev)
         items.append((_lib.PACK_CONV, w, dst, (Co, Ci, KH, KW, Ci, cpad)))
@@ -465,12 +466,13 @@ def test_batched_pack_equals_the_single_tensor_packs():
         dst = torch.empty(4, Co, 4 * Ci, device=dev)
         items.append((_lib.PACK_CONVT, w, dst, (Ci, Co, 0, 0, 0, 0)))
         want.append(ops.pack_convT_weight(w))
-    for (Co, Ci, K, st, pad) in [(64, 32, 4, 2, 1), (32, 32, 8, 4, 0), (32, 32, 3, 1, 1), (64, 32, 4, 2, 0), (32, 64, 2, 1, 0), (512, 64, 4, 2, 1)]:
+    for (Co, Ci, K, st, pad) in [(64, 32, 4, 2, 1), (32, 32, 8, 4, 0), (32, 32, 3, 1, 1), (64, 32, 4, 2, 0), (32, 64, 2, 1, 0), (512, 64, 4, 2, 1),
+                                (1536, 1536, 1, 1, 0), (1536, 512, 1, 1, 0), (5, 512, 1, 1, 0), (130, 70, 1, 1, 0)]:
         w = torch.randn(Co, Ci, K, K, generator=g).to(dev)
         dst = torch.empty(st * st, Ci, (K // st) * (K // st) * Co, device=dev)
         items.append((_lib.PACK_DGRAD, w, dst, (Co, Ci, K, K, st, pad)))
         want.append(MF.pack_dgrad_weight(w, st, pad))
-    for (Co, Ci, K, cpad) in [(512, 32, 12, 32), (512, 32, 1, 32), (128, 3, 2, 4)]:
+    for (Co, Ci, K, cpad) in [(512, 32, 12, 32), (512, 32, 1, 32), (128, 3, 2, 4), (1536, 1536, 1, 1536), (130, 70, 1, 72)]:
         w = torch.randn(Co, Ci, K, K, generator=g).to(dev)
         dst = torch.empty(K * K * cpad, Co, device=dev)
         items.append((_lib.PACK_FC_DGRAD, w, dst, (Co, Ci, K, K, Ci, cpad)))
