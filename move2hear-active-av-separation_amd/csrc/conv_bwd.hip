@@ -674,7 +674,9 @@ __global__ __launch_bounds__(Q4 ? 1024 : 256) void conv_wgrad_reduce_torch_kerne
   const int n = blockIdx.x / cb, ci0 = (blockIdx.x - n * cb) * 16;
   const size_t zs = (size_t)p.N * p.Kpad;
   const int el = threadIdx.x & 255;
-  for (int t0 = 0; t0 < p.ntap; t0 += 16) {
+  // gridDim.y > 1: a block takes every gridDim.y-th group of 16 taps (layers with few (n, 16-channel) blocks and many taps and splits --
+  // VisualCNN's first conv: 32 blocks summing 64 taps x 500 splits took 37-41 us at the end of the policy epoch's longest branch)
+  for (int t0 = 16 * blockIdx.y; t0 < p.ntap; t0 += 16 * gridDim.y) {
     {
       const int t = t0 + (el >> 4), ci = ci0 + (el & 15);
       const float* src = (t < p.ntap && ci < Ci) ? p.ws + (size_t)n * p.Kpad + (size_t)t * p.Ctot + ci : nullptr;
@@ -802,8 +804,10 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   if (torch_ci > 0) {   // split sum + re-layout to [N][Ci][KH][KW] in one launch
     const long gt = (long)p.N * ((torch_ci + 15) / 16);
     M2H_REQUIRE(gt < 0x7fffffffL, "conv_wgrad: reduce grid too large");
-    if (p.S >= 16) M2H_LAUNCH(conv_wgrad_reduce_torch_kernel<true>, dim3((unsigned)gt), dim3(1024), 0, st, p);
-    else M2H_LAUNCH(conv_wgrad_reduce_torch_kernel<false>, dim3((unsigned)gt), dim3(256), 0, st, p);
+    const int tgroups = (p.ntap + 15) / 16;
+    const unsigned gy = (unsigned)(gt >= 512 || tgroups == 1 ? 1 : (tgroups < 8 ? tgroups : 8));   // enough blocks for the chip before the taps are spread
+    if (p.S >= 16) M2H_LAUNCH(conv_wgrad_reduce_torch_kernel<true>, dim3((unsigned)gt, gy), dim3(1024), 0, st, p);
+    else M2H_LAUNCH(conv_wgrad_reduce_torch_kernel<false>, dim3((unsigned)gt, gy), dim3(256), 0, st, p);
     return launch_status("conv_wgrad reduce (torch layout)");
   }
   if (p.S >= 16) {
