@@ -871,10 +871,12 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 // then one thread per column sums the splits.  Lanes walk columns (coalesced 256-byte rows), the 4 waves stride the rows.
 // GATE: m2h_act_bwd_bias -- the element is first passed through the activation's backward (y > 0 ? dy : dy * slope) and written to `out`: the
 // same partition and summation order, so db has the bits of m2h_act_bwd followed by m2h_bias_grad, from one pass over dy instead of two.
-template <bool GATE>
-__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dy, float* __restrict__ part, int M, int N, int rows_per_split,
+// NW = waves per block = row lanes: 16 for the one-stage form (a few hundred rows on N / 64 blocks: with 4 waves a wave walked 70 of the update
+// batch's 280 rows, nine dependent batches of loads -- 24-37 us for the encoders' 512-wide Linear layers on 8 blocks)
+template <bool GATE, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void bias_grad_partial_kernel(const float* __restrict__ dy, float* __restrict__ part, int M, int N, int rows_per_split,
                                                                 const float* __restrict__ y = nullptr, float slope = 1.f, float* __restrict__ out = nullptr) {
-  __shared__ float sh[4][64];
+  __shared__ float sh[NW][64];
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   const int w = threadIdx.x >> 6;
   const int m0 = blockIdx.y * rows_per_split;
@@ -884,17 +886,17 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __r
     // U rows' loads in flight before the first add (the sum keeps its order, row by row: same bits as the one-load-at-a-time loop, which
     // was a chain of dependent memory round trips -- 47-51 us for the update batch's 280 rows x 512 columns on 8 blocks)
     constexpr int U = 8;
-    for (int m = m0 + w; m < m1; m += 4 * U) {
+    for (int m = m0 + w; m < m1; m += NW * U) {
       float v[U], g[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int mm = m + 4 * u;
+        const int mm = m + NW * u;
         v[u] = mm < m1 ? dy[(size_t)mm * N + n] : 0.f;
         if constexpr (GATE) g[u] = mm < m1 ? y[(size_t)mm * N + n] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int mm = m + 4 * u;
+        const int mm = m + NW * u;
         if (mm < m1) {
           float x = v[u];
           if constexpr (GATE) {
@@ -908,7 +910,12 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __r
   }
   sh[w][threadIdx.x & 63] = s;
   __syncthreads();
-  if (w == 0 && n < N) part[(size_t)blockIdx.y * N + n] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+  if (w == 0 && n < N) {
+    float r = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+#pragma unroll
+    for (int k = 4; k < NW; ++k) r += sh[k][threadIdx.x];
+    part[(size_t)blockIdx.y * N + n] = r;
+  }
 }
 
 // The same partial sums for NARROW gradients (N in {1, 2, 4, 8, 16, 32}: the U-Net heads' 2 channels over a million pixels, the encoders'
@@ -972,14 +979,15 @@ static int bias_grad_launch(const float* dy, const float* y, float slope, float*
   const int splits = bias_grad_splits(M, N);
   const int rps = (M + splits - 1) / splits;
   if (splits == 1) {   // the one split's "partial" IS the column sum
-    M2H_LAUNCH(bias_grad_partial_kernel<GATE>, dim3((N + 63) / 64, 1), dim3(256), 0, st, dy, db, M, N, rps, y, slope, out);
+    if (M > 64) M2H_LAUNCH((bias_grad_partial_kernel<GATE, 16>), dim3((N + 63) / 64, 1), dim3(1024), 0, st, dy, db, M, N, rps, y, slope, out);
+    else M2H_LAUNCH((bias_grad_partial_kernel<GATE, 4>), dim3((N + 63) / 64, 1), dim3(256), 0, st, dy, db, M, N, rps, y, slope, out);
     return launch_status(GATE ? "act_bwd_bias" : "bias_grad");
   }
   if (N <= 32 && 64 % N == 0) {   // narrow: splits of whole wave steps (64 / N rows); trailing splits may be empty (their partial is 0)
     const int rw = 64 / N, rps_n = (rps + rw - 1) / rw * rw;
     M2H_LAUNCH(bias_grad_partial_narrow_kernel<GATE>, dim3(1, splits), dim3(256), 0, st, dy, workspace, M, N, rps_n, y, slope, out);
   } else
-    M2H_LAUNCH(bias_grad_partial_kernel<GATE>, dim3((N + 63) / 64, splits), dim3(256), 0, st, dy, workspace, M, N, rps, y, slope, out);
+    M2H_LAUNCH((bias_grad_partial_kernel<GATE, 4>), dim3((N + 63) / 64, splits), dim3(256), 0, st, dy, workspace, M, N, rps, y, slope, out);
   M2H_LAUNCH(bias_grad_final_kernel, dim3((N + 3) / 4), dim3(256), 0, st, workspace, db, N, splits);
   return launch_status(GATE ? "act_bwd_bias" : "bias_grad");
 }
