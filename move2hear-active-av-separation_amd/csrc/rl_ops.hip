@@ -762,26 +762,42 @@ __global__ __launch_bounds__(64 * GB_NW) void gru_bwd_rec_kernel(const float* __
   const int j0 = blockIdx.x * GB_U, K = 3 * H;
   const float* wrow = whh_t + (size_t)(j0 + min(i, GB_U - 1)) * K + 4 * kq;
   const float* xrow = dpre + (size_t)min(i, M - 1) * K + 4 * kq;
+  // the epilogue's operands of this thread's (unit, row) pair, fetched before the dot products (as gru_step_kernel does): behind the
+  // barrier they were a second dependent round trip in every one of the 20 BPTT steps
+  const bool epi = tid < GB_U * GB_E && (tid & 15) < M;
+  const int eu = (tid >> 4) & (GB_U - 1), em = min(tid & 15, M - 1), ej = j0 + eu;
+  const size_t eo = (size_t)em * H + ej, eo3 = (size_t)em * 3 * H;
+  const float e_mk = mask != nullptr ? mask[em] : 1.f;
+  const float e_a = (epi && a != nullptr) ? a[eo] : 0.f;
+  const float e_dhp = epi ? dhp[eo] : 0.f;
+  float e_mp = 1.f, e_gir = 0.f, e_giz = 0.f, e_gin = 0.f, e_ghr = 0.f, e_ghz = 0.f, e_ghn = 0.f, e_br = 0.f, e_bz = 0.f, e_bn = 0.f, e_hp = 0.f;
+  if (gi_p != nullptr && epi) {
+    e_mp = mask_p != nullptr ? mask_p[em] : 1.f;
+    e_gir = gi_p[eo3 + ej]; e_giz = gi_p[eo3 + H + ej]; e_gin = gi_p[eo3 + 2 * H + ej];
+    e_ghr = gh_p[eo3 + ej]; e_ghz = gh_p[eo3 + H + ej]; e_ghn = gh_p[eo3 + 2 * H + ej];
+    e_br = bhh[ej]; e_bz = bhh[H + ej]; e_bn = bhh[2 * H + ej];
+    e_hp = hprev_p[eo];
+  }
   const f32x4_r acc = skinny_dot16<GB_NW>(xrow, wrow, K >> 4, wave);
 #pragma unroll
   for (int e = 0; e < 4; ++e) R[wave][kq * 4 + e][i] = acc[e];
   __syncthreads();
-  if (tid < GB_U * GB_E && (tid & 15) < M) {
+  if (epi) {
     const int u = tid >> 4, m = tid & 15;
     const float rec = wave_tile_sum<GB_NW>(R, m, u);
     const size_t o = (size_t)m * H + j0 + u;
-    const float mk = mask != nullptr ? mask[m] : 1.f;
-    const float g = (a != nullptr ? a[o] : 0.f) + mk * (rec + dhp[o]);
+    const float mk = e_mk;
+    const float g = e_a + mk * (rec + e_dhp);
     out[o] = g;
     if (gi_p != nullptr) {                 // gru_gates_bwd_kernel of the previous step at (row m, unit j), dh = g
       const int j = j0 + u;
-      const float mp = mask_p != nullptr ? mask_p[m] : 1.f;
+      const float mp = e_mp;
       const size_t o3 = (size_t)m * 3 * H;
-      const float r = sigmoidf_(gi_p[o3 + j] + (mp * gh_p[o3 + j] + bhh[j]));
-      const float z = sigmoidf_(gi_p[o3 + H + j] + (mp * gh_p[o3 + H + j] + bhh[H + j]));
-      const float hn = mp * gh_p[o3 + 2 * H + j] + bhh[2 * H + j];
-      const float n = tanhf(gi_p[o3 + 2 * H + j] + r * hn);
-      const float hp = mp * hprev_p[o];
+      const float r = sigmoidf_(e_gir + (mp * e_ghr + e_br));
+      const float z = sigmoidf_(e_giz + (mp * e_ghz + e_bz));
+      const float hn = mp * e_ghn + e_bn;
+      const float n = tanhf(e_gin + r * hn);
+      const float hp = mp * e_hp;
       const float dn = g * (1.f - z);
       const float dz = g * (hp - n);
       const float dan = dn * (1.f - n * n);
