@@ -375,17 +375,23 @@ class PPOTrainer:
         if tail:
             torch.cuda.current_stream(self.device).wait_stream(self._tail_stream)
             sep_losses = tuple(sep_pending[-1].tolist())
+        sep_dev = None
         for _sub in range(0 if tail else cfg.num_updates_per_cycle):
             if cfg.use_linear_lr_decay:
                 self.lr_scheduler_sep.step()
             e0 = self._mark(phase_events)
-            sep_losses = self._update_sep()
+            # the losses stay on the device until the cycle's last update has been enqueued: read as floats after every update (a host
+            # synchronisation each) the next update's preparation -- storage roll-over, the memory's sliced input: ~350 us of launches
+            # paced by the host -- could not be enqueued under the running epochs (rocprofv3: 470 us between two updates' epochs)
+            sep_dev = self._update_sep(as_tensor=self.device.type == "cuda")
             if phase_events is not None:
                 phase_events.append(("update_sep", e0, self._mark(phase_events)))
             if checkpoint and self.world_rank == 0 and self.num_sep_updates_done % cfg.CHECKPOINT_INTERVAL == 0 and cfg.CHECKPOINT_FOLDER:
                 self.save_checkpoint("ckpt.%d.pth" % self.count_checkpoints)
                 self.count_checkpoints += 1
             self.num_sep_updates_done += 1
+        if sep_dev is not None:
+            sep_losses = tuple(sep_dev.tolist()) if torch.is_tensor(sep_dev) else sep_dev
         if not log_stats:
             self.count_steps += steps
         return {"env_steps": steps, "seconds": time.perf_counter() - t0, "pol_losses": pol_losses, "sep_losses": sep_losses}

@@ -76,10 +76,10 @@ def run_m2h(d, flat, replay, env_kind, graphs, rank=0, world=1, pre=""):
         pol.append({"losses": np.array([out]), "lr": lr, "clip": clip, "returns": [tr.rollouts_pol.returns.cpu().clone()]})
         return out
 
-    def update_sep():
+    def update_sep(as_tensor=False):   # (train_cycle keeps the losses on the device until the cycle's last update is enqueued)
         lr = tr.agent.optimizer_sep.param_groups[0]["lr"]
-        out = orig_sep()
-        sep.append({"losses": np.array([out]), "lr": lr})
+        out = orig_sep(as_tensor=as_tensor)
+        sep.append({"losses": np.array([tuple(out.tolist()) if torch.is_tensor(out) else out]), "lr": lr})
         return out
     tr._collect_rollout_step, tr._update_pol, tr._update_sep = step, update_pol, update_sep
     tr.save_checkpoint = lambda name: saved.append((name, len(sep)))
