@@ -170,12 +170,14 @@ class PPO(nn.Module):
         feats.grad = None
         torch.autograd.backward(feats, g)
 
-    def update_pol(self, rollouts_pol):
+    def update_pol(self, rollouts_pol, as_tensor=False):
+        """as_tensor: return the three mean losses as a device tensor instead of python floats (no host synchronisation at the end of the
+        update: the trainer's next rollout steps are enqueued under the last epoch's optimizer step)."""
         advantages = self.get_advantages(rollouts_pol)
         self._pol_updates += 1
         if (self.use_hip_graphs and self._pol_updates > 1 and self.num_mini_batch == 1 and not ops.timing_enabled()
                 and getattr(rollouts_pol, "full_batch_views", False)):
-            return self._update_pol_graph(rollouts_pol, advantages)  # (the first update runs kernel by kernel: warm-up)
+            return self._update_pol_graph(rollouts_pol, advantages, as_tensor)  # (the first update runs kernel by kernel: warm-up)
         self._pol_graph = None  # an eager epoch re-binds p.grad to fresh tensors: a graph captured earlier would write stale ones
         acc = torch.zeros(4, device=self.device)
         for _e in range(self.ppo_epoch):
@@ -191,10 +193,12 @@ class PPO(nn.Module):
                 self._reduce_and_step("pol", self.optimizer_pol,  # before_step_pol + step
                                       last=_e == self.ppo_epoch - 1 and _mb == self.num_mini_batch - 1, reduced_tail=tail)
         num_updates = self.ppo_epoch * self.num_mini_batch
+        if as_tensor:
+            return (acc / num_updates)[:3]
         v, a, h, _ = (acc / num_updates).tolist()  # the only host read of the update
         return v, a, h
 
-    def _update_pol_graph(self, rollouts_pol, advantages):
+    def _update_pol_graph(self, rollouts_pol, advantages, as_tensor=False):
         """update_pol with each epoch's forward + losses + backward replayed from one HIP graph.  With one mini-batch the batch
         is the whole storage read in place (rollout_storage.py), so every address the epoch touches is fixed: storages, flat
         parameter / gradient buffers, and three static inputs -- the advantages, the clip range (device scalar, it decays per
@@ -262,6 +266,8 @@ class PPO(nn.Module):
                 self._reducers["pol"].early(self.optimizer_pol.grad_bucket(tail))
                 graphs.replay(gs.graph_rest)
             self._reduce_and_step("pol", self.optimizer_pol, last=_e == self.ppo_epoch - 1, reduced_tail=tail)
+        if as_tensor:
+            return (gs.acc / self.ppo_epoch)[:3]   # (a new tensor: the next update zeroes gs.acc)
         v, a, h, _ = (gs.acc / self.ppo_epoch).tolist()
         return v, a, h
 

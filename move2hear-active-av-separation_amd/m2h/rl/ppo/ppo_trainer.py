@@ -316,7 +316,7 @@ class PPOTrainer:
         gs.expect = ((ro.step + 1) % ro.num_steps, (rs.step + 1) % rs.num_steps)
 
     # ------------------------------------------------------------------ updates (reference :480-541)
-    def _update_pol(self):
+    def _update_pol(self, as_tensor=False):
         cfg, ro = self.config, self.rollouts_pol
         with torch.no_grad():
             last_observation = {k: v[-1] for k, v in ro.observations.items()}
@@ -324,7 +324,7 @@ class PPOTrainer:
                 last_observation, ro.recurrent_hidden_states_pol[-1], ro.masks[-1], pred_binSepMasks=ro.pred_binSepMasks[-1],
                 pred_mono=ro.pred_mono[-1], pred_monoFromMem=ro.prev_pred_monoFromMem[-1]).detach()
         ro.compute_returns(next_value, cfg.use_gae, cfg.gamma, cfg.tau)
-        out = self.agent.update_pol(ro)
+        out = self.agent.update_pol(ro, as_tensor=as_tensor)
         ro.after_update()
         return out
 
@@ -366,7 +366,9 @@ class PPOTrainer:
             tail = _sub == cfg.num_updates_per_cycle - 1 and self._tail_overlap(checkpoint)
             if tail:
                 sep_pending = self._enqueue_separator_updates(phase_events)
-            pol_losses = self._update_pol()
+            # (without the window statistics nothing on the host needs the losses before the cycle ends: they stay on the device, and the
+            # next rollout's steps are enqueued under this update's last optimizer step)
+            pol_losses = self._update_pol(as_tensor=self.device.type == "cuda" and not log_stats)
             if phase_events is not None:
                 phase_events += [("rollout", e0, e1), ("update_pol", e1, self._mark(phase_events))]
             self.num_updates_done += 1
@@ -392,6 +394,8 @@ class PPOTrainer:
             self.num_sep_updates_done += 1
         if sep_dev is not None:
             sep_losses = tuple(sep_dev.tolist()) if torch.is_tensor(sep_dev) else sep_dev
+        if torch.is_tensor(pol_losses):
+            pol_losses = tuple(pol_losses.tolist())
         if not log_stats:
             self.count_steps += steps
         return {"env_steps": steps, "seconds": time.perf_counter() - t0, "pol_losses": pol_losses, "sep_losses": sep_losses}

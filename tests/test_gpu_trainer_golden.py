@@ -70,10 +70,11 @@ def run_m2h(d, flat, replay, env_kind, graphs, rank=0, world=1, pre=""):
         return n
     pol, sep = [], []
 
-    def update_pol():
+    def update_pol(as_tensor=False):
         lr, clip = tr.agent.optimizer_pol.param_groups[0]["lr"], tr.agent.clip_param
-        out = orig_pol()
-        pol.append({"losses": np.array([out]), "lr": lr, "clip": clip, "returns": [tr.rollouts_pol.returns.cpu().clone()]})
+        out = orig_pol(as_tensor=as_tensor)
+        pol.append({"losses": np.array([tuple(out.tolist()) if torch.is_tensor(out) else out]), "lr": lr, "clip": clip,
+                    "returns": [tr.rollouts_pol.returns.cpu().clone()]})
         return out
 
     def update_sep(as_tensor=False):   # (train_cycle keeps the losses on the device until the cycle's last update is enqueued)
