@@ -994,12 +994,14 @@ __global__ __launch_bounds__(64 * NW) void skinny_rows_kernel(const IGemmP p) {
 // the walked reduction (tap window x both sources x channels) and meet through LDS in wave order; BN scale / shift, activation
 // and the NHWC store follow.  The tiled engine occupies the chip at these sizes only through split-K (slabs + a reduce launch,
 // 24-45 us per layer against 2-17 MB of weights); here the weights are streamed MG/MGB times and the activations N/16 times.
-template <int MGB, int NW>
+// NCG = 16-column groups per block (1; 2 for the update batch's wide Linear layers: the activations' share of the L2 -> CU stream, one pass per
+// column block, halves)
+template <int MGB, int NW, int NCG = 1>
 __global__ __launch_bounds__(64 * NW) void skinny_gather_kernel(const IGemmP p) {
-  __shared__ float R[NW][MGB][16][17];
+  __shared__ float R[NW][MGB * NCG][16][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  const int NB = (p.N + 15) >> 4, MS = (p.MT + MGB - 1) / MGB;     // p.MT = 16-row groups of M
+  const int NB = (p.N + 16 * NCG - 1) / (16 * NCG), MS = (p.MT + MGB - 1) / MGB;     // p.MT = 16-row groups of M
   int L = blockIdx.x;
   const int ms = L % MS;
   L /= MS;
@@ -1029,13 +1031,17 @@ __global__ __launch_bounds__(64 * NW) void skinny_gather_kernel(const IGemmP p) 
       bpix[g] = b * p.Hi * p.Wi;
     }
   }
-  const float* wrow = wbase + (size_t)min(nb * 16 + i, p.N - 1) * p.K + 4 * kq;
+  const float* wrow[NCG];
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg) wrow[cg] = wbase + (size_t)min((nb * NCG + cg) * 16 + i, p.N - 1) * p.K + 4 * kq;
   const int spt = p.Ctot >> 4;                                   // 16-float steps per tap
   const int steps = p.thn * p.twn * spt;
   const int s0 = (steps * wave) / NW, s1 = (steps * (wave + 1)) / NW;
-  f32x4 acc[MGB];
+  f32x4 acc[MGB][NCG];
 #pragma unroll
-  for (int g = 0; g < MGB; ++g) acc[g] = {0.f, 0.f, 0.f, 0.f};
+  for (int g = 0; g < MGB; ++g)
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) acc[g][cg] = {0.f, 0.f, 0.f, 0.f};
   int tap = s0 / spt, ci = (s0 - tap * spt) * 16;
   int th = p.th0 + tap / p.twn, tw = p.tw0 + tap % p.twn;
   unsigned offA[MGB];                                            // float offset of the row's pixel at the current tap, per source stride
@@ -1058,13 +1064,15 @@ __global__ __launch_bounds__(64 * NW) void skinny_gather_kernel(const IGemmP p) 
     const int nrun = min(s1 - t, (seg_end - ci) >> 4);
     const float* src = second ? p.src1 : p.src0;
     const unsigned Cs = second ? p.C1 : p.C0, c = (second ? ci - p.C0 : ci) + 4 * kq;
-    const float* wp_ = wrow + (size_t)(th * p.ntw + tw) * p.Ctot + ci;
+    const size_t wofs = (size_t)(th * p.ntw + tw) * p.Ctot + ci;
     const float* ap[MGB];
 #pragma unroll
     for (int g = 0; g < MGB; ++g) ap[g] = src + (size_t)offA[g] * Cs + c;   // (rows outside the image: pixel 0, masked below)
 #pragma unroll 4
     for (int k = 0; k < nrun; ++k) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(wp_ + 16 * k);
+      f32x4 b[NCG];
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) b[cg] = *reinterpret_cast<const f32x4*>(wrow[cg] + wofs + 16 * k);
       f32x4 a[MGB];
 #pragma unroll
       for (int g = 0; g < MGB; ++g) a[g] = *reinterpret_cast<const f32x4*>(ap[g] + 16 * k);
@@ -1072,7 +1080,9 @@ __global__ __launch_bounds__(64 * NW) void skinny_gather_kernel(const IGemmP p) 
       for (int g = 0; g < MGB; ++g) {
         const f32x4 av = okA[g] ? a[g] : zero4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b[j], acc[g], 0, 0, 0);
+        for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[g][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b[cg][j], acc[g][cg], 0, 0, 0);
       }
     }
     t += nrun;
@@ -1089,16 +1099,19 @@ __global__ __launch_bounds__(64 * NW) void skinny_gather_kernel(const IGemmP p) 
 #pragma unroll
   for (int g = 0; g < MGB; ++g)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) R[wave][g][kq * 4 + e][i] = acc[g][e];    // D[row kq*4 + e][channel i]
+    for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) R[wave][g * NCG + cg][kq * 4 + e][i] = acc[g][cg][e];    // D[row kq*4 + e][channel i]
   __syncthreads();
 #pragma unroll
-  for (int g = 0; g < MGB; ++g) {
+  for (int gc = 0; gc < MGB * NCG; ++gc) {
+    const int g = gc / NCG, cg = gc % NCG;
     const int r16 = tid >> 4, c16 = tid & 15;
-    const int m = (ms * MGB + g) * 16 + r16, n = nb * 16 + c16;
+    const int m = (ms * MGB + g) * 16 + r16, n = (nb * NCG + cg) * 16 + c16;
     if (tid < 256 && m < p.M && n < p.N) {
       float x = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) x += R[w][g][r16][c16];       // wave order
+      for (int w = 0; w < NW; ++w) x += R[w][gc][r16][c16];       // wave order
       const float sc = p.scale != nullptr ? p.scale[n] : 1.f;
       const float sh = p.shift != nullptr ? p.shift[n] : 0.f;
       x = x * sc + sh;
@@ -1541,10 +1554,22 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
     // rollout batch: 56 rows x 512 channels = 64 blocks of 32 rows): the weights stream at a per-CU rate, so twice the blocks stream them
     // twice as fast, and their second read comes out of L2.  Same values: a row's sum does not depend on the rows beside it.
     const bool one = g_skinny_mgb >= 0 && p.MT >= 2 && (g_skinny_mgb == 1 || blocks2 < (g_skinny_mgb > 1 ? g_skinny_mgb : 192));   // (knob 38 > 1: the block-count threshold, A/B)
-    const long blocks = one ? (long)phases * (a.N / 16) * p.MT : blocks2;
+    // 64 rows x 32 columns per block (eight waves) where that still gives the chip a block per CU (the update batch's 280-row Linear layers
+    // against 1536 / 4608 columns: 864 / 2592 blocks of 32 x 16): such a launch is bound by the L2 -> CU operand stream -- the weights
+    // pass once per row block, the activations once per column block -- and both shares halve
+    const long blocks4 = (long)phases * ((a.N + 31) / 32) * ((p.MT + 3) / 4);   // 64 rows x 32 columns
+    // (both wide forms for ONE-pixel outputs only -- nn.Linear and the encoders' full-spatial convs over the update batch, where they were measured:
+    // 38 -> 25, 35 -> 31, 37 -> 26, 55 -> 41 us per policy epoch; on the passive step's U-Net stages of 256-1024 pixels they measured 2 % slower)
+    const bool dense = a.Hq == 1 && a.Wq == 1 && !p.convT;
+    const bool four = dense && !one && g_skinny_mgb == 0 && p.MT >= 8 && blocks4 >= 240;
+    const long blocks2w = (long)phases * ((a.N + 31) / 32) * ((p.MT + 1) / 2);   // 32 rows x 32 columns (the 280-row layers against 512 columns)
+    const bool wide2 = dense && !one && !four && g_skinny_mgb == 0 && p.MT >= 8 && blocks2w >= 128;
+    const long blocks = four ? blocks4 : (wide2 ? blocks2w : (one ? (long)phases * (a.N / 16) * p.MT : blocks2));
 #define M2H_SKINNY_GATHER(NW_)                                                                              \
   do {                                                                                                      \
-    if (one) M2H_LAUNCH((skinny_gather_kernel<1, NW_>), dim3((unsigned)blocks), dim3(64 * NW_), 0, st, p);  \
+    if (four) M2H_LAUNCH((skinny_gather_kernel<4, (NW_ > 8 ? 8 : NW_), 2>), dim3((unsigned)blocks), dim3(64 * (NW_ > 8 ? 8 : NW_)), 0, st, p); \
+    else if (wide2) M2H_LAUNCH((skinny_gather_kernel<2, NW_, 2>), dim3((unsigned)blocks), dim3(64 * NW_), 0, st, p); \
+    else if (one) M2H_LAUNCH((skinny_gather_kernel<1, NW_>), dim3((unsigned)blocks), dim3(64 * NW_), 0, st, p);  \
     else M2H_LAUNCH((skinny_gather_kernel<2, NW_>), dim3((unsigned)blocks), dim3(64 * NW_), 0, st, p);      \
   } while (0)
     if (nw == 4) M2H_SKINNY_GATHER(4);
