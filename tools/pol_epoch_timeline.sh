@@ -1,7 +1,7 @@
 # kernel timeline of one update_pol epoch (parallel graph branches): start offset, duration, HW queue of every kernel between two ppo_loss launches
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 rm -rf gpurun_out/prof_nodes
-rocprofv3 --kernel-trace -d gpurun_out/prof_nodes -o g --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --ddppo-cycles 1 --no-far-target --train-steps 0 --feeder-steps 0 > gpurun_out/pol_timeline_log.txt 2>&1
+rocprofv3 --kernel-trace -d gpurun_out/prof_nodes -o g --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --ddppo-cycles 1 --no-far-target --train-steps 0 --feeder-steps 0 --knobs "${KNOBS:-}" > gpurun_out/pol_timeline_log.txt 2>&1
 python3 - > gpurun_out/pol_epoch_timeline.txt <<'P'
 import csv, glob
 f = glob.glob("gpurun_out/prof_nodes/*kernel_trace.csv")[0]
