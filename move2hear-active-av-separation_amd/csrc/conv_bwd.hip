@@ -696,10 +696,13 @@ __global__ __launch_bounds__(Q4 ? 1024 : 256) void conv_wgrad_reduce_torch_kerne
 // (tuning knob g_wgrad_row3x3: thread-local, m2h_internal.h) -1: never use the image-row 3x3 kernel (m2h_tuning_set 21)
 
 // block shape for (N, K): n extent, k sub-tiles per block, blocks along k
-static void wgrad_cfg(int N, int K, int& bng, int& kt, int& ktiles) {
+static void wgrad_cfg(int N, int K, int& bng, int& kt, int& ktiles, long M = 1L << 30) {
   const int kt128 = (K + WK - 1) / WK;
   bng = N > 64 ? 128 : (N > 32 ? 64 : 32);        // (64: round 4 -- a 64-channel layer on the 128-wide block spent half its MFMAs on padding)
-  kt = bng == 32 ? (kt128 >= 3 ? 3 : kt128) : (bng == 64 ? (kt128 >= 2 ? 2 : 1) : 1);  // narrow layers: up to three k sub-tiles per block share the dY operand
+  // a few hundred rows (the update batch's Linear layers: 280 x 1536 x 1536): the reduction is nine chunks long and a block's time is its
+  // MFMAs -- 64-wide blocks, twice as many, each half as long: 33 -> 28, 21 -> 14, 31 -> 27 us per policy epoch (knob 25 = -1: the 128-wide blocks)
+  if (M <= 1024 && N > 64 && g_wgrad_small_m >= 0) bng = 64;
+  kt = bng == 32 ? (kt128 >= 3 ? 3 : kt128) : (bng == 64 ? (kt128 >= 2 && N <= 64 ? 2 : 1) : 1);  // narrow layers: up to three k sub-tiles per block share the dY operand
   ktiles = (kt128 + kt - 1) / kt;
 }
 
@@ -711,7 +714,7 @@ static bool wgrad_row3x3_shape(const m2h_conv_args& a) {
 
 static int wgrad_splits(long M, int N, int K, bool row3x3 = false) {
   int bng, kt, ktiles;
-  wgrad_cfg(N, K, bng, kt, ktiles);
+  wgrad_cfg(N, K, bng, kt, ktiles, M);
   const long tiles = ((N + bng - 1) / bng) * (long)ktiles;
   const long chunks = (M + WM - 1) / WM;
   // one wave front, no tail round: 3 resident blocks per CU for the one-sub-tile kernels (40 / 64 KB LDS, <= 176 VGPRs), 2 for
@@ -768,7 +771,7 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   p.dw = dw;
   p.gate = gate; p.gate_slope = gate_slope; p.torch_ci = torch_ci;
   int bng, kt;
-  wgrad_cfg(a.N, p.K, bng, kt, p.ktiles);
+  wgrad_cfg(a.N, p.K, bng, kt, p.ktiles, M);
   p.ntiles = (a.N + bng - 1) / bng;
   const long nblk = (long)(p.S >= 8 ? (p.S + 7) / 8 * 8 : p.S) * p.ntiles * p.ktiles;
   M2H_REQUIRE(nblk < 0x7fffffffL, "conv_wgrad: grid too large");
