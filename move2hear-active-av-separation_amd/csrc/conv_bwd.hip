@@ -701,7 +701,7 @@ static void wgrad_cfg(int N, int K, int& bng, int& kt, int& ktiles, long M = 1L 
   bng = N > 64 ? 128 : (N > 32 ? 64 : 32);        // (64: round 4 -- a 64-channel layer on the 128-wide block spent half its MFMAs on padding)
   // a few hundred rows (the update batch's Linear layers: 280 x 1536 x 1536): the reduction is nine chunks long and a block's time is its
   // MFMAs -- 64-wide blocks, twice as many, each half as long: 33 -> 28, 21 -> 14, 31 -> 27 us per policy epoch (knob 25 = -1: the 128-wide blocks)
-  if (M <= 1024 && N > 64 && g_wgrad_small_m >= 0) bng = 64;
+  if (M <= 1024 && N > 64 && K <= 2048 && g_wgrad_small_m >= 0) bng = 64;   // (K <= 2048: the 4608-deep full-spatial conv re-reads its input rows once per n-block: 34 -> 54 us)
   kt = bng == 32 ? (kt128 >= 3 ? 3 : kt128) : (bng == 64 ? (kt128 >= 2 && N <= 64 ? 2 : 1) : 1);  // narrow layers: up to three k sub-tiles per block share the dY operand
   ktiles = (kt128 + kt - 1) / kt;
 }
