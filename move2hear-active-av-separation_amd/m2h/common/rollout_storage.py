@@ -197,6 +197,8 @@ class RolloutStorageSep:
         # same tensor the policy storage carried over, so re-running after_update between the 6 sub-updates of a cycle does
         # not change what is stored: compare before bumping the generation would need a sync, so track it by step instead.
         changed = self.step != getattr(self, "_last_after_update_step", None) or self.generation != getattr(self, "_last_after_update_gen", None)
+        if not changed:
+            return   # nothing was inserted since the last call: row 0 already holds the last row (the cycle's separator updates 2-6: 13 copies each)
         for sensor in self.observations:
             self.observations[sensor][0].copy_(self.observations[sensor][-1])
         self.prev_pred_monoFromMem[0].copy_(self.prev_pred_monoFromMem[-1])
