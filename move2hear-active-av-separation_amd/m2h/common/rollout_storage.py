@@ -14,6 +14,24 @@ import torch
 from .. import ops
 
 
+def _roll_rows(tensors):
+    """row[0] <- row[-1] for every storage tensor: ONE batched device copy (m2h_rows_copy) instead of one launch per tensor (13 per
+    after_update); on the CPU (tests of the host logic) the plain copies."""
+    tensors = [t for t in tensors if t is not None]
+    if tensors and all(t.is_cuda for t in tensors):
+        from .. import ops
+        idx = _roll_rows.idx.get(tensors[0].device)
+        if idx is None:
+            idx = _roll_rows.idx[tensors[0].device] = torch.zeros(1, dtype=torch.int64, device=tensors[0].device)
+        ops.rows_copy([(t[-1], t[0], -1, -1) for t in tensors], idx)
+    else:
+        for t in tensors:
+            t[0].copy_(t[-1])
+
+
+_roll_rows.idx = {}
+
+
 class RolloutStoragePol:
     def __init__(self, num_steps, num_envs, observation_space, recurrent_hidden_state_size, num_recurrent_layers=1):
         self.observations = {}
@@ -68,11 +86,7 @@ class RolloutStoragePol:
         self.step = (self.step + 1) % self.num_steps
 
     def after_update(self):
-        for sensor in self.observations:
-            self.observations[sensor][0].copy_(self.observations[sensor][-1])
-        self.recurrent_hidden_states_pol[0].copy_(self.recurrent_hidden_states_pol[-1])
-        self.prev_pred_monoFromMem[0].copy_(self.prev_pred_monoFromMem[-1])
-        self.masks[0].copy_(self.masks[-1])
+        _roll_rows(list(self.observations.values()) + [self.recurrent_hidden_states_pol, self.prev_pred_monoFromMem, self.masks])
 
     def compute_returns(self, next_value, use_gae, gamma, tau):
         ops.gae_returns(self.rewards, self.value_preds, self.masks, next_value.contiguous(), self.returns, use_gae, gamma, tau)
@@ -199,13 +213,9 @@ class RolloutStorageSep:
         changed = self.step != getattr(self, "_last_after_update_step", None) or self.generation != getattr(self, "_last_after_update_gen", None)
         if not changed:
             return   # nothing was inserted since the last call: row 0 already holds the last row (the cycle's separator updates 2-6: 13 copies each)
-        for sensor in self.observations:
-            self.observations[sensor][0].copy_(self.observations[sensor][-1])
-        self.prev_pred_monoFromMem[0].copy_(self.prev_pred_monoFromMem[-1])
-        self.masks[0].copy_(self.masks[-1])
+        _roll_rows(list(self.observations.values()) + [self.prev_pred_monoFromMem, self.masks] +
+                   ([self.pred_binSepMasks, self.pred_mono] if self.pred_mono is not None else []))
         if self.pred_mono is not None:
-            self.pred_binSepMasks[0].copy_(self.pred_binSepMasks[-1])
-            self.pred_mono[0].copy_(self.pred_mono[-1])
             self._pred_rows_valid[0] = self._pred_rows_valid[-1]
         if changed:
             # only row 0 of the stored observations changed: a cache built for generation g - 1 needs row 0 refreshed, not rebuilt
