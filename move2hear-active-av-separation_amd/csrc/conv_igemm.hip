@@ -1112,11 +1112,12 @@ __global__ __launch_bounds__(64 * NW) void skinny_gather_kernel(const IGemmP p) 
       float x = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) x += R[w][gc][r16][c16];       // wave order
+      int q, rr, b, out, bc;
+      decode_row(p, m, ph, pw, q, rr, b, out, bc);
+      if (p.cls_table != nullptr) x += p.cls_val[bc >> 4] * p.cls_table[(size_t)(bc & 15) * p.N + n];   // the class plane (as the tiled engine's epilogues)
       const float sc = p.scale != nullptr ? p.scale[n] : 1.f;
       const float sh = p.shift != nullptr ? p.shift[n] : 0.f;
       x = x * sc + sh;
-      int q, rr, b, out, bc;
-      decode_row(p, m, ph, pw, q, rr, b, out, bc);
       p.dst[(size_t)out * p.ldc + n] = x > 0.f ? x : x * p.slope;
     }
   }
@@ -1542,10 +1543,15 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
       return launch_status("conv_igemm_f32 (skinny rows)");
     }
   }
-  // small pixel counts per phase (<= 1024; knob 24 > 0 overrides the limit): 32 x 16 tiles without LDS staging or split-K
-  if (p.math == 0 && g_skinny_gather >= 0 && g_fast_loader >= 0 && p.fast_ok && M > 16 && M <= (g_skinny_gather > 0 ? g_skinny_gather : 1024) &&
-      a.N % 16 == 0 && a.out_mode == M2H_OUT_NHWC && a.cls_table == nullptr && a.head_w == nullptr && (a.operand_format & M2H_FMT_LAYOUT_BITS) == 0 &&
-      p.Ctot % 16 == 0 && (size_t)a.N * p.Kw * (p.convT ? 4 : 1) >= (size_t)1 << 16) {
+  // small pixel counts per phase (<= 1024; knob 24 > 0 overrides the limit): 32 x 16 tiles without LDS staging or split-K.
+  // Also 1024 < M <= 4096 pixels against TINY weights (< 64 K elements: the rollout batch's first encoder stage, 3584 pixels x 512 x 64, and the
+  // visual encoder's second and third convs): the tiled engine fills the chip there only through split-K slabs + a reduce launch (10 + 5 us
+  // for 0.2 GFLOP); knob 33 = -1: off
+  const bool tiny_w = (size_t)a.N * p.Kw * (p.convT ? 4 : 1) < ((size_t)1 << 16);
+  const long skinny_lim = g_skinny_gather > 0 ? g_skinny_gather : (tiny_w && g_skinny_tiny >= 0 ? 4096 : 1024);
+  if (p.math == 0 && g_skinny_gather >= 0 && g_fast_loader >= 0 && p.fast_ok && M > 16 && M <= skinny_lim &&
+      a.N % 16 == 0 && a.out_mode == M2H_OUT_NHWC && a.head_w == nullptr && (a.operand_format & M2H_FMT_LAYOUT_BITS) == 0 &&
+      p.Ctot % 16 == 0 && (tiny_w ? (M > 1024 && g_skinny_tiny >= 0) : a.cls_table == nullptr)) {
     const int phases = p.convT ? 4 : 1;
     p.MT = (int)((M + 15) / 16);
     const long blocks2 = (long)phases * (a.N / 16) * ((p.MT + 1) / 2);

@@ -54,6 +54,7 @@ extern thread_local Tuning tl_tuning;
 #define g_patch (::m2h::tl_tuning.v[36])
 #define g_skinny_mgb (::m2h::tl_tuning.v[38])
 #define g_strip_rev (::m2h::tl_tuning.v[39])
+#define g_skinny_tiny (::m2h::tl_tuning.v[33])
 #define g_wgrad_small_m (::m2h::tl_tuning.v[25])
 #define g_patch_grid (::m2h::tl_tuning.v[10])
 
