@@ -1517,7 +1517,8 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   // one output pixel; a transposed conv over a 1 x 1 image (one tap per phase).  Weight streaming on the skinny kernel.
   if (p.math == 0 && g_skinny_linear >= 0 && g_fast_loader >= 0 && p.fast_ok && M <= 16 && a.C1 == 0 && a.Hq == 1 && a.Wq == 1 && a.os >= 1 && a.N % 4 == 0 &&
       a.out_mode == M2H_OUT_NHWC && a.cls_table == nullptr && a.head_w == nullptr && (a.operand_format & M2H_FMT_LAYOUT_BITS) == 0 &&
-      (size_t)a.N * p.Kw * (p.convT ? 4 : 1) >= (size_t)1 << 18) {
+      (size_t)a.N * p.Kw * (p.convT ? 4 : 1) >= ((size_t)1 << (g_skinny_tiny >= 0 ? 14 : 18))) {   // (round 5: from 16 K weights, was 256 K: the fused audio pair's
+    // third conv and Linear at the rollout batch took a tiled launch + split-K reduce / a 32-row tile for 14 rows; knob 33 = -1: the old limit)
     bool dense;
     if (p.convT) dense = a.Hi == 1 && a.Wi == 1 && p.thn == 1 && p.twn == 1 && p.th0 == 0 && p.tw0 == 0 && a.Ho == 2 && a.Wo == 2;
     else dense = a.Ho == 1 && a.Wo == 1 && a.ph == 0 && a.pw == 0 && p.thn == a.Hi && p.twn == a.Wi && a.mulh == 1 && a.mulw == 1 &&
