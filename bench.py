@@ -394,6 +394,32 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
             dist.all_gather_object(idents, ident)
         else:
             idents = [ident]
+        # the same cycles once more with action_sampling="cpu_generator" -- the mode every reference-pinned trainer test samples in (noise from
+        # the CPU default generator at the reference's stream position: the reference PyTorch-CPU run's actions from the seed alone); the
+        # default "fused" mode is pinned end to end by the recorded-noise test of tests/test_gpu_trainer_golden.py.  Same kernels but the
+        # draw's noise source: one pinned host->device copy per step instead of the in-kernel Philox draw.
+        default_sampling = tr.actor_critic._sampling_mode
+        tr.actor_critic.set_action_sampling("cpu_generator")
+        tr.train_cycle()   # (the rollout graphs are captured anew: another draw)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        steps_cg = sum(tr.train_cycle()["env_steps"] for _ in range(args.ddppo_cycles))
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el_cg = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el_cg], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_cg = float(t.item())
+        sampling_modes = {"default": default_sampling,
+                          default_sampling: {"value": round(world * steps / el, 1), "s_per_cycle": round(el / args.ddppo_cycles, 4)},
+                          "cpu_generator": {"value": round(world * steps_cg / el_cg, 1), "s_per_cycle": round(el_cg / args.ddppo_cycles, 4)},
+                          "unit": "env-steps/s",
+                          "what": ("the headline value of this leg is the default mode's; cpu_generator = the bit-exact-from-the-seed mode of the "
+                                   "reference-pinned tests, same cycles in this same run")}
         mixed = None
         if far_target:
             # the same evaluate_actions batch (the policy storage as it stands) in both arithmetic modes
@@ -418,6 +444,7 @@ def run_ddppo(args, dev, rank, world, dist, far_target=False, with_cpu=False):
            "schedule": ("farTarget.yaml: episodes of 80 steps, navigation reward (no override), " if far_target else "nearTarget.yaml: ") +
                        "T=20, 6x(rollout+update_pol) + 6x update_sep per cycle, ppo_epoch 4, 1 minibatch, hidden 512",
            "env": "synthetic on-device env (cached 128x128 RGB-D frames + spectrogram pool), zero-cost dynamics",
+           "action_sampling": default_sampling, "action_sampling_modes": sampling_modes,
            "launch": ("HIP graphs: the rollout step (one graph per (extra-reward, episode-end) flag pair, one chain) and the update_pol epoch "
                       "(forward + losses + backward; the three encoders as parallel branches, launched onto a drained stream: DESIGN 3.2h) are "
                       "captured once and replayed, and so is the update_sep epoch (one chain); optimizer steps and collectives are enqueued kernel by kernel" if cfg.use_hip_graphs else "kernel by kernel"),

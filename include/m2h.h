@@ -240,10 +240,12 @@ int m2h_policy_heads_act(const float* feats, const float* Wa, const float* ba, c
                          int A, m2h_stream stream);
 /* Same with the draw's Exp(1) noise made INSIDE the kernel ("fused" sampling: no generator launch in the rollout step): element (row, a)
  * takes -log(u), u from Philox4x32-10 keyed by rng_state[0] (seed) at counter rng_state[1] + row A + a; rng_state: two uint64 on the
- * device, the counter is advanced by the caller (m2h_step_index_advance_rng inside a replayed step). */
+ * device, the counter is advanced by the caller (m2h_step_index_advance_rng inside a replayed step).  u = (23 random bits + 0.5) / 2^23
+ * (exact in fp32, never 0 or 1).  noise_out: NULL, or [M][A] floats that receive the noise drawn -- the record a parity test hands the CPU
+ * oracle in place of its generator's draw (common/utils.py:16-24: "same probs + same noise => same actions"). */
 int m2h_policy_heads_act_rng(const float* feats, const float* Wa, const float* ba, const float* Wc, const float* bc,
                              const unsigned long long* rng_state, float* value, float* logp_all, float* probs, float* entropy,
-                             long long* actions, float* logp_act, int M, int H, int A, m2h_stream stream);
+                             long long* actions, float* logp_act, float* noise_out, int M, int H, int A, m2h_stream stream);
 
 /* CustomFixedCategorical.sample (common/utils.py:16-24) with the noise supplied by the caller: the single-draw path of
  * torch.multinomial(probs, 1, True) is argmax(probs / q), q ~ Exp(1) drawn from the tensor's generator -- on the reference's

@@ -237,7 +237,9 @@ __global__ __launch_bounds__(64 * GC_NW) void gru_cell_kernel(const float* __res
 }
 
 // Philox4x32-10 (Salmon et al., SC'11: the counter-based generator torch's device generator is built on), one 32-bit word of the
-// block at `counter` under `seed`, as Exp(1) noise: -log(u), u = (24 random bits + 0.5) / 2^24 in (0, 1).
+// block at `counter` under `seed`, as Exp(1) noise: -log(u), u = (23 random bits + 0.5) / 2^23 in (0, 1) -- 23 bits, so that the sum
+// is exact in fp32 (with 24 bits 0xFFFFFF + 0.5 rounds to 2^24: u = 1, noise 0, probs / noise = inf and that action wins whatever its
+// probability): u in [2^-24, 1 - 2^-24], noise in [6.0e-8, 16.7].
 __device__ __forceinline__ float philox_exp1(unsigned long long seed, unsigned long long counter) {
   unsigned c0 = (unsigned)counter, c1 = (unsigned)(counter >> 32), c2 = 0x6d32685fu, c3 = 0u;   // (c2: a stream tag)
   unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
@@ -249,7 +251,7 @@ __device__ __forceinline__ float philox_exp1(unsigned long long seed, unsigned l
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
-  const float u = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u = ((float)(c0 >> 9) + 0.5f) * (1.0f / 8388608.0f);
   return -logf(u);
 }
 
@@ -262,7 +264,8 @@ __global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restri
                                                            float* __restrict__ probs, float* __restrict__ entropy,
                                                            float* __restrict__ logp_act, int M, int H, int A,
                                                            const float* __restrict__ noise = nullptr, long long* __restrict__ act_out = nullptr,
-                                                           const unsigned long long* __restrict__ rng = nullptr) {
+                                                           const unsigned long long* __restrict__ rng = nullptr,
+                                                           float* __restrict__ noise_out = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -326,8 +329,14 @@ __global__ __launch_bounds__(256) void policy_heads_kernel(const float* __restri
       // ties keep the lowest index); without noise the mode, argmax(probs) -- and its log-probability
       // rng = {seed, counter} on the device ("fused" sampling): the Exp(1) noise of element (row, a) is -log(u), u from Philox4x32-10
       // keyed by the seed at counter + row A + a -- no generator launch in the step; the counter is advanced by step_index_advance
+      // noise_out (optional, with rng): the noise drawn, [M][A] -- what the parity tests hand the CPU oracle in place of its generator's draw
       const bool draw = noise != nullptr || rng != nullptr;
-      auto nz = [&](int a) { return rng != nullptr ? philox_exp1(rng[0], rng[1] + (unsigned long long)(row * A + a)) : noise[row * A + a]; };
+      auto nz = [&](int a) {
+        if (rng == nullptr) return noise[row * A + a];
+        const float q = philox_exp1(rng[0], rng[1] + (unsigned long long)(row * A + a));
+        if (noise_out != nullptr) noise_out[row * A + a] = q;
+        return q;
+      };
       int arg = 0;
       float best = draw ? expf(acc[0] - lse) / nz(0) : expf(acc[0] - lse);
       for (int a = 1; a < A; ++a) {
@@ -1101,12 +1110,13 @@ int m2h_policy_heads_act(const float* feats, const float* Wa, const float* ba, c
 }
 
 int m2h_policy_heads_act_rng(const float* feats, const float* Wa, const float* ba, const float* Wc, const float* bc, const unsigned long long* rng_state,
-                             float* value, float* logp_all, float* probs, float* entropy, long long* actions, float* logp_act, int M, int H,
-                             int A, m2h_stream stream) {
+                             float* value, float* logp_all, float* probs, float* entropy, long long* actions, float* logp_act, float* noise_out,
+                             int M, int H, int A, m2h_stream stream) {
   M2H_REQUIRE(feats && Wa && ba && Wc && bc && rng_state && value && logp_all && probs && entropy && actions && logp_act, "policy_heads_act_rng: null pointer");
   M2H_REQUIRE(M > 0 && H > 0 && H % 64 == 0 && A > 0 && A <= 8, "policy_heads_act_rng: bad sizes (H %% 64, A <= 8)");
   M2H_LAUNCH(policy_heads_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), feats, Wa, ba, Wc, bc,
-             static_cast<const long long*>(nullptr), value, logp_all, probs, entropy, logp_act, M, H, A, static_cast<const float*>(nullptr), actions, rng_state);
+             static_cast<const long long*>(nullptr), value, logp_all, probs, entropy, logp_act, M, H, A, static_cast<const float*>(nullptr), actions, rng_state,
+             noise_out);
   return launch_status("policy_heads_act (fused draw)");
 }
 

@@ -179,7 +179,7 @@ SIGNATURES = {
     "m2h_policy_heads": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "m2h_gather_logp": [_P, _P, _P, _I, _I, _P],
     "m2h_policy_heads_act": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "m2h_policy_heads_act_rng": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "m2h_policy_heads_act_rng": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "m2h_sample_actions": [_P, _P, _P, _I, _I, _P],
     "m2h_gae_returns": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P],
     "m2h_advantages": [_P, _P, _P, _P, _I, _I, _F, _P],

@@ -555,10 +555,11 @@ def policy_heads(feats, Wa, ba, Wc, bc, actions=None):
     return value, logp_all, probs, ent, logp_act
 
 
-def policy_heads_act(feats, Wa, ba, Wc, bc, noise=None, rng=None):
+def policy_heads_act(feats, Wa, ba, Wc, bc, noise=None, rng=None, noise_out=None):
     """Heads + action + its log-probability in one launch (m2h_policy_heads_act): noise [M,A] Exp(1) -> the multinomial draw
     argmax(probs / noise); None -> the mode; rng = int64 device tensor [seed, counter] -> the noise is drawn inside the kernel
-    (m2h_policy_heads_act_rng; the caller advances the counter).  -> value [M,1], logp_all [M,A], probs [M,A], entropy [M], action [M,1] int64, logp_act [M,1]."""
+    (m2h_policy_heads_act_rng; the caller advances the counter; noise_out: optional [M,A] float tensor that receives the noise drawn).
+    -> value [M,1], logp_all [M,A], probs [M,A], entropy [M], action [M,1] int64, logp_act [M,1]."""
     for t in (feats, Wa, ba, Wc, bc, noise):
         _chk(t, "policy_heads_act")
     M, H = feats.shape
@@ -575,11 +576,17 @@ def policy_heads_act(feats, Wa, ba, Wc, bc, noise=None, rng=None):
     if rng is not None:
         if noise is not None or rng.dtype != torch.int64 or rng.numel() != 2 or not rng.is_cuda or not rng.is_contiguous():
             raise RuntimeError("m2h.policy_heads_act: rng must be a contiguous int64 device tensor [seed, counter] (and noise None)")
+        if noise_out is not None:
+            _chk(noise_out, "policy_heads_act")
+            if tuple(noise_out.shape) != (M, A):
+                raise RuntimeError("m2h.policy_heads_act: noise_out must be [%d, %d]" % (M, A))
         with torch.cuda.device(dev):
             _lib.check(_lib.load().m2h_policy_heads_act_rng(_ptr(feats), _ptr(Wa), _ptr(ba), _ptr(Wc), _ptr(bc), _ptr(rng), _ptr(value),
-                                                            _ptr(logp_all), _ptr(probs), _ptr(ent), _ptr(action), _ptr(logp_act), M, H, A,
-                                                            _stream(feats)), "m2h_policy_heads_act_rng")
+                                                            _ptr(logp_all), _ptr(probs), _ptr(ent), _ptr(action), _ptr(logp_act), _ptr(noise_out),
+                                                            M, H, A, _stream(feats)), "m2h_policy_heads_act_rng")
         return value, logp_all, probs, ent, action, logp_act
+    if noise_out is not None:
+        raise RuntimeError("m2h.policy_heads_act: noise_out records the fused draw's noise (rng); with caller-supplied noise there is nothing to record")
     with torch.cuda.device(dev):
         _lib.check(_lib.load().m2h_policy_heads_act(_ptr(feats), _ptr(Wa), _ptr(ba), _ptr(Wc), _ptr(bc), _ptr(noise), _ptr(value),
                                                     _ptr(logp_all), _ptr(probs), _ptr(ent), _ptr(action), _ptr(logp_act), M, H, A,

@@ -188,22 +188,75 @@ class Policy(nn.Module):
         return self.acoustic_mem.l1_loss_masked(pred_mono, prev_pred_monoFromMem, masks, gt_comps, off, sliced=sliced)
 
     # action sampling (common/utils.py): None = noise from the device generator; a HostNoise = noise from the CPU default generator;
-    # _rng_state = [seed, counter] on the device = noise drawn inside the heads kernel ("fused")
+    # _rng_state = [seed, counter] on the device = noise drawn inside the heads kernel ("fused").  Neither is a parameter or a buffer of
+    # the reference's state_dict (its keys are the checkpoint contract): _apply below moves them with the module, the trainer's
+    # checkpoints carry the counter beside the state_dict (sampler_state / restore_sampler_state).
     _host_noise = None
     _rng_state = None
+    _sampling_mode = "device"
+    last_action_noise = None      # record_noise_rows: [rows, actions] Exp(1) noise of the last fused draw (what a parity test hands the oracle)
 
-    def set_action_sampling(self, mode, seed=0):
+    def set_action_sampling(self, mode, seed=0, record_noise_rows=None):
         """"fused" (throughput default of the trainers): torch.multinomial's single draw, argmax(probs / Exp(1) noise), with the noise made
         inside the heads kernel by a counter-based generator (Philox4x32-10 keyed by `seed`, counter on the device): no generator launch
         in the rollout step.  "device": the same draw with torch's device generator supplying the noise (three more launches per step inside
         a HIP graph).  "cpu_generator": the noise taken from the CPU default generator, i.e. the actions of the reference PyTorch-CPU path
-        for the same seed (common/utils.py:16-24 on a CPU policy)."""
+        for the same seed (common/utils.py:16-24 on a CPU policy).
+        record_noise_rows (fused only): keep the noise of the last draw over that many rows in ``last_action_noise``.
+        A second call in "fused" mode re-seeds the EXISTING state tensor in place (captured rollout graphs hold its address); whatever a
+        call changes that a captured graph depends on shows in ``sampling_key()``, which the trainer compares before every replay."""
         from ...common.utils import HostNoise
         if mode not in ("fused", "device", "cpu_generator"):
             raise ValueError("action_sampling must be 'fused', 'device' or 'cpu_generator', got %r" % (mode,))
         dev = next(self.parameters()).device
+        self._sampling_mode = mode
         self._host_noise = HostNoise(dev) if mode == "cpu_generator" else None
-        self._rng_state = torch.tensor([int(seed) & 0x7fffffffffffffff, 0], dtype=torch.int64, device=dev) if mode == "fused" else None
+        if mode == "fused":
+            state = torch.tensor([int(seed) & 0x7fffffffffffffff, 0], dtype=torch.int64, device=dev)
+            if self._rng_state is not None and self._rng_state.device == state.device:
+                self._rng_state.copy_(state)
+            else:
+                self._rng_state = state
+        else:
+            self._rng_state = None
+        rows = int(record_noise_rows or 0)
+        if mode == "fused" and rows > 0:
+            if self.last_action_noise is None or tuple(self.last_action_noise.shape) != (rows, self.dim_actions) or self.last_action_noise.device != dev:
+                self.last_action_noise = torch.zeros(rows, self.dim_actions, device=dev)
+        else:
+            self.last_action_noise = None
+
+    def sampling_key(self):
+        """What a captured rollout step depends on besides the weights: the mode and the addresses of the sampler's device state."""
+        return (self._sampling_mode, None if self._rng_state is None else self._rng_state.data_ptr(),
+                None if self.last_action_noise is None else self.last_action_noise.data_ptr())
+
+    def sampler_state(self):
+        """[seed, counter] of the fused sampler as python ints (a host read), or None: what a checkpoint keeps so that a resumed run does
+        not replay the noise of the run's first steps."""
+        return None if self._rng_state is None else [int(v) for v in self._rng_state.tolist()]
+
+    def restore_sampler_state(self, state):
+        if state is not None and self._rng_state is not None:
+            self._rng_state.copy_(torch.tensor([int(state[0]), int(state[1])], dtype=torch.int64))
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)      # .to() / .cuda(): the sampler's device state moves with the parameters
+        for name in ("_rng_state", "last_action_noise"):
+            t = getattr(self, name)
+            if t is not None:
+                setattr(self, name, fn(t))
+        dev = next(self.parameters()).device
+        if self._host_noise is not None and self._host_noise.device != dev:
+            from ...common.utils import HostNoise
+            self._host_noise = HostNoise(dev)
+        return out
+
+    def prepare_action_sampling(self, rows):
+        """Allocates what a draw over ``rows`` rows needs outside any stream capture (cpu_generator mode: the pinned ring and the static
+        device buffer a captured step reads)."""
+        if self._host_noise is not None:
+            self._host_noise.buffer(rows, self.dim_actions)
 
     def stage_action_noise(self, rows):
         """cpu_generator mode: draw the next step's noise and enqueue its upload (called ahead of a graph replay that samples)."""
@@ -248,7 +301,8 @@ class Policy(nn.Module):
                 else:
                     noise = torch.empty((M, A), device=feats_pol.device).exponential_(1)
             value, _lpa, probs, _ent, action, action_log_probs = ops.policy_heads_act(
-                feats_pol.contiguous(), a.weight.detach(), a.bias.detach(), c.weight.detach(), c.bias.detach(), noise, rng=rng)
+                feats_pol.contiguous(), a.weight.detach(), a.bias.detach(), c.weight.detach(), c.bias.detach(), noise, rng=rng,
+                noise_out=self.last_action_noise if rng is not None and self.last_action_noise is not None and self.last_action_noise.shape[0] == M else None)
             if rng is not None and not torch.cuda.is_current_stream_capturing():
                 rng[1:2] += M * A     # kernel-by-kernel steps: the counter moves on here; a captured step advances it in its last launch (ppo_trainer.py)
             return value, action, action_log_probs, rnn_hidden_states_pol, probs

@@ -63,6 +63,8 @@ def near_target_config(**over):
     #                                     (Philox4x32-10, seed = SEED + rank offset, counter on the device: no generator launch in the step);
     #                                     "device" = the noise from torch's device generator; "cpu_generator" = from the CPU default generator:
     #                                     the reference PyTorch-CPU run's actions from the seed alone
+    c["record_action_noise"] = False   # build-side key (fused sampling): keep every step's Exp(1) noise in actor_critic.last_action_noise -- the
+    #                                     record tests/test_gpu_trainer_golden.py hands the CPU oracle's loop in place of its generator's draw
     c.update(over)
     return SimpleNamespace(**c)
 
@@ -99,7 +101,8 @@ class PPOTrainer:
             hidden_size=cfg.hidden_size, extra_rgb=cfg.EXTRA_RGB, extra_depth=cfg.EXTRA_DEPTH, use_ddppo=cfg.use_ddppo,
             world_rank=self.world_rank)
         self.actor_critic.to(self.device)
-        self.actor_critic.set_action_sampling(getattr(cfg, "action_sampling", "fused"), seed=0x5eed0000 + seed)
+        self.actor_critic.set_action_sampling(getattr(cfg, "action_sampling", "fused"), seed=0x5eed0000 + seed,
+                                              record_noise_rows=cfg.NUM_PROCESSES if getattr(cfg, "record_action_noise", False) else None)
         cls = DDPPO if cfg.use_ddppo else PPO
         self.agent = cls(actor_critic=self.actor_critic, clip_param=cfg.clip_param, ppo_epoch=cfg.ppo_epoch,
                          num_mini_batch=cfg.num_mini_batch, value_loss_coef=cfg.value_loss_coef,
@@ -280,6 +283,7 @@ class PPOTrainer:
             dev = self.device
             gs = self._graph_state = SimpleNamespace(
                 graphs={}, pool=None, where=None, idx=torch.zeros(3, dtype=torch.int64, device=dev), expect=None, epoch=None, noise_rows=None,
+                sampling=self.actor_critic.sampling_key(),
                 cache=tuple(torch.empty_like(t) for t in self._next_cache))
         if self._next_cache[0] is not gs.cache[0]:  # the previous step ran outside the graphs: hand its outputs over
             for dst, src in zip(gs.cache, self._next_cache):
@@ -299,9 +303,13 @@ class PPOTrainer:
             if where != gs.where:  # a parameter was re-allocated (first build, .to(), ...): captured addresses are stale
                 gs.graphs.clear()
                 gs.where = where
+        if gs.sampling != self.actor_critic.sampling_key():   # set_action_sampling since the capture: another draw, or its state elsewhere
+            gs.graphs.clear()
+            gs.sampling = self.actor_critic.sampling_key()
         key = (bool(extra), bool(done), ops.math_mode())   # (a graph is the kernels of ONE arithmetic: a mode change captures anew)
         g = gs.graphs.get(key)
         if g is None:
+            self.actor_critic.prepare_action_sampling(self.envs.num_envs)   # (pinned / static buffers cannot be made inside a capture)
             g = torch.cuda.CUDAGraph()
             g.register_generator_state(self.envs.generator)
             with torch.no_grad(), graphs.capture(g, pool=gs.pool):
@@ -509,6 +517,9 @@ class PPOTrainer:
 
     def save_checkpoint(self, file_name):
         ckpt = {"state_dict": {"actor_critic." + k: v for k, v in self.actor_critic.state_dict().items()}, "config": vars(self.config)}
+        sampler = self.actor_critic.sampler_state()   # build-side key beside the reference's two: the fused sampler's [seed, counter], so a run that
+        if sampler is not None:                       # continues from this file draws on from here instead of replaying the first steps' noise
+            ckpt["m2h_sampler_state"] = sampler
         os.makedirs(self.config.CHECKPOINT_FOLDER, exist_ok=True)
         torch.save(ckpt, os.path.join(self.config.CHECKPOINT_FOLDER, file_name))
 
@@ -518,8 +529,9 @@ class PPOTrainer:
         kwargs.setdefault("weights_only", False)
         return torch.load(checkpoint_path, *args, **kwargs)
 
-    def load_state_dict(self, state_dict, strict=True):
-        """Loads agent weights saved by this trainer or by the reference (keys rooted at "actor_critic.")."""
+    def load_state_dict(self, state_dict, strict=True, sampler_state=None):
+        """Loads agent weights saved by this trainer or by the reference (keys rooted at "actor_critic.").
+        sampler_state: a checkpoint's "m2h_sampler_state" ([seed, counter] of the fused action sampler), restored in place."""
         sd = {k[len("actor_critic."):]: v for k, v in state_dict.items() if k.startswith("actor_critic.")}
         if not sd:
             raise RuntimeError("checkpoint state_dict has no 'actor_critic.*' keys")
@@ -530,6 +542,7 @@ class PPOTrainer:
         self._next_cache = None
         self.rollouts_sep.invalidate_separator_outputs()
         self._drop_graphs()    # the frozen separators' packed weights / folded-BN buffers are rebuilt at new addresses
+        self.actor_critic.restore_sampler_state(sampler_state)
         return out
 
     def _drop_graphs(self):
@@ -581,7 +594,8 @@ class PPOTrainer:
         from ...common import eval_metrics as EM
         cfg, ac = self.config, self.actor_critic
         if checkpoint_path is not None:
-            self.load_state_dict(self.load_checkpoint(checkpoint_path)["state_dict"])
+            ck = self.load_checkpoint(checkpoint_path)
+            self.load_state_dict(ck["state_dict"])   # (evaluation draws from its own seed, as the reference's eval does: no sampler state)
         acs = None
         if switch_checkpoint_path is not None:
             ck = self.load_checkpoint(switch_checkpoint_path)

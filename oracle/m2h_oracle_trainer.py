@@ -167,9 +167,18 @@ def separate(sd, cfg, mix, target_class):
     return pm, O.convert_bin2mono(sd, pm, mix)
 
 
-def collect_rollout_step(sd, cfg, rk, forced_actions=None):
+def draw_actions(probs, noise=None):
+    """CustomFixedCategorical.sample (common/utils.py:16-24): torch.multinomial(probs, 1, True).  Its single-draw path is
+    argmax(probs / q), q ~ Exp(1) from the tensor's generator (pinned against the reference's own sample() by tests/golden/rl_forward.npz sample_*, tests/test_oracle_rl_golden.py); with
+    ``noise`` [N, A] given, q is that tensor instead of the generator's draw -- "same probs + same noise => same actions"."""
+    if noise is None:
+        return torch.multinomial(probs, 1, True)
+    return (probs / noise).argmax(dim=1, keepdim=True)
+
+
+def collect_rollout_step(sd, cfg, rk, forced_actions=None, action_noise=None):
     """ppo_trainer.py:253-478 for one rank.  forced_actions: [N,1] int64 to take instead of sampling (the action's log-prob
-    is still this policy's)."""
+    is still this policy's).  action_noise: [N, A] Exp(1) noise for the draw in place of the generator's (draw_actions)."""
     ro, rs, st = rk.ro, rk.rs, rk.stats
     with torch.no_grad():
         obs = {k: v[ro.step] for k, v in ro.observations.items()}                                       # :292-294
@@ -177,7 +186,7 @@ def collect_rollout_step(sd, cfg, rk, forced_actions=None):
         mem = O.acoustic_mem(sd, mono, O.mask_prev_mem(ro.prev_pred_monoFromMem[ro.step], ro.masks[ro.step]))   # :307-318
         feats, h, _ = O.policy_net(sd, obs, ro.recurrent_hidden_states_pol[ro.step], ro.masks[ro.step], pm, mono, mem)
         values, logp_all, probs = O.heads(sd, feats)                                                    # :321-335 (Policy.act)
-        actions = forced_actions if forced_actions is not None else torch.multinomial(probs, 1, True)
+        actions = forced_actions if forced_actions is not None else draw_actions(probs, action_noise)
         logp = logp_all.gather(1, actions)
     rk.last_act = (values, actions, logp, h, probs)
     outputs = rk.envs.step([a[0].item() for a in actions])                                              # :340
@@ -307,11 +316,13 @@ def window_scalars(windows, summed_stats, window_size):
     return out
 
 
-def train(cfg, envs_per_rank, sd, forced_actions=None, distributed=True, on_step=None):
+def train(cfg, envs_per_rank, sd, forced_actions=None, distributed=True, on_step=None, action_noise=None):
     """PPOTrainer.train (ppo_trainer.py:579-1013) for len(envs_per_rank) emulated ranks.
     cfg: dict with the RL.PPO keys + NUM_UPDATES, CHECKPOINT_INTERVAL, MAX_EPISODE_STEPS.
     sd: full policy state dict (reference keys, no "actor_critic." root); trainable tensors are replaced by leaf copies.
-    forced_actions: optional [rank][global step] -> [N,1] int64.  Returns a record dict shaped like the golden fixtures."""
+    forced_actions: optional [rank][global step] -> [N,1] int64.  action_noise: optional [rank][global step] -> [N, A] Exp(1) noise the
+    step's draw uses in place of the generator's (the CPU generator then only serves the epochs' randperm).
+    Returns a record dict shaped like the golden fixtures."""
     # the reference steps its LR schedulers at the START of each sub-update (:733-735, :981-982); torch warns about that order
     warnings.filterwarnings("ignore", message="Detected call of `lr_scheduler.step\\(\\)` before `optimizer.step\\(\\)`")
     sd = {k: v.clone() for k, v in sd.items()}
@@ -336,7 +347,8 @@ def train(cfg, envs_per_rank, sd, forced_actions=None, distributed=True, on_step
             clip = cfg["clip_param"] * decay(actual) if cfg["use_linear_clip_decay"] else cfg["clip_param"]   # :736-739
             for _step in range(cfg["num_steps"]):
                 for r, rk in enumerate(ranks):
-                    collect_rollout_step(sd, cfg, rk, None if forced_actions is None else forced_actions[r][k])
+                    collect_rollout_step(sd, cfg, rk, None if forced_actions is None else forced_actions[r][k],
+                                         None if action_noise is None else action_noise[r][k])
                     if on_step is not None:
                         on_step(r, k, rk)
                     count_steps += rk.envs.num_envs

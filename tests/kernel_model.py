@@ -470,3 +470,20 @@ def patch_engine_layer(x, w, transposed, whole):
                             else:
                                 out[q, r] += v @ wt
     return out
+
+
+def philox_exp1(seed, counter):
+    """numpy restatement of csrc/rl_ops.hip philox_exp1 (Philox4x32-10, word 0, 23 bits -> (0, 1) -> -log).  -> (noise, u)."""
+    M32 = np.uint64(0xFFFFFFFF)
+    counter = np.asarray(counter, dtype=np.uint64)
+    c0, c1 = counter & M32, counter >> np.uint64(32)
+    c2, c3 = np.full_like(c0, 0x6d32685f), np.zeros_like(c0)
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        n0, n1 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M32, p1 & M32
+        n2, n3 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & M32, p0 & M32
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M32, (k1 + np.uint64(0xBB67AE85)) & M32
+    u = ((c0 >> np.uint64(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+    return -np.log(u.astype(np.float32)), u

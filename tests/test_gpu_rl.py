@@ -469,21 +469,7 @@ def test_fused_rollout_step_stats_matches_the_separate_kernels(override, extra):
     torch.cuda.current_stream(dev).wait_stream(side)
 
 
-def _philox_exp1(seed, counter):
-    """numpy restatement of csrc/rl_ops.hip philox_exp1 (Philox4x32-10, word 0, 24 bits -> (0, 1) -> -log)."""
-    M32 = np.uint64(0xFFFFFFFF)
-    counter = np.asarray(counter, dtype=np.uint64)
-    c0, c1 = counter & M32, counter >> np.uint64(32)
-    c2, c3 = np.full_like(c0, 0x6d32685f), np.zeros_like(c0)
-    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
-    for _ in range(10):
-        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
-        n0, n1 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M32, p1 & M32
-        n2, n3 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & M32, p0 & M32
-        c0, c1, c2, c3 = n0, n1, n2, n3
-        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M32, (k1 + np.uint64(0xBB67AE85)) & M32
-    u = ((c0 >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
-    return -np.log(u.astype(np.float32))
+from kernel_model import philox_exp1 as _philox_exp1  # noqa: E402
 
 
 def test_fused_action_draw_is_the_multinomial_draw_on_philox_noise():
@@ -499,12 +485,24 @@ def test_fused_action_draw_is_the_multinomial_draw_on_philox_noise():
     Wc, bc = (torch.randn(1, H, generator=g) * 0.05).to(dev), torch.zeros(1, device=dev)
     seed, ctr = 0x5eed0007, 12345
     rng = torch.tensor([seed, ctr], dtype=torch.int64, device=dev)
-    value, logp_all, probs, ent, action, logp_act = ops.policy_heads_act(feats, Wa, ba, Wc, bc, rng=rng)
+    drawn = torch.zeros(M, A, device=dev)
+    value, logp_all, probs, ent, action, logp_act = ops.policy_heads_act(feats, Wa, ba, Wc, bc, rng=rng, noise_out=drawn)
     assert int(rng[1]) == ctr                                     # the kernel reads the counter; the caller advances it
-    noise = _philox_exp1(seed, ctr + np.arange(M * A, dtype=np.uint64)).reshape(M, A)
-    want = (probs.cpu().numpy() / noise).argmax(1)
-    same = (action.cpu().numpy().reshape(-1) == want).mean()
-    assert same > 0.999, same                                     # (logf on the device vs numpy: a last-bit difference can flip a near-tie)
+    # (1) the noise the kernel drew IS the generator's: -log(u) of the host restatement's u, to the device logf's last bits, and u -- 23
+    # random bits + 0.5, exact in fp32 -- never reaches 0 or 1 (0xFFFFFFFF included: the largest word gives u = 1 - 2^-24, noise 6e-8 > 0)
+    noise, u = _philox_exp1(seed, ctr + np.arange(M * A, dtype=np.uint64))
+    got = drawn.cpu().numpy().reshape(-1)
+    assert np.abs(got - noise).max() <= 4e-7 * np.abs(noise).max() and (np.abs(got - noise) <= 3e-7 * np.maximum(noise, 1e-3)).all()
+    assert u.min() >= 2.0 ** -24 and u.max() <= 1 - 2.0 ** -24 and got.min() > 0 and np.isfinite(got).all()
+    top = (np.float32(0x7FFFFF) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+    assert top < 1 and -np.log(top) > 0
+    # (2) the action IS torch.multinomial's single draw on that noise, exactly: argmax(probs / noise) in correctly rounded fp32 division
+    # on both sides, ties to the lowest index -- every one of the 4096 rows, no tolerance
+    want = (probs.cpu().numpy() / drawn.cpu().numpy()).argmax(1)
+    assert np.array_equal(action.cpu().numpy().reshape(-1), want)
+    # without the record the same draw
+    action_b = ops.policy_heads_act(feats, Wa, ba, Wc, bc, rng=rng)[4]
+    assert torch.equal(action_b, action)
     assert torch.equal(logp_act, logp_all.gather(1, action))
     v0, lp0, p0, e0, a_mode, _ = ops.policy_heads_act(feats, Wa, ba, Wc, bc)       # the mode: same heads, no draw
     assert torch.equal(p0, probs) and torch.equal(v0, value)

@@ -19,7 +19,8 @@ import pytest
 import torch
 
 import m2h_oracle_trainer as OT
-from trainer_golden_util import (check_run, check_scalars, check_updates, check_weights, load_fixture, make_env)
+from trainer_golden_util import (check_run, check_scalars, check_updates, check_weights, fixture_from_oracle_record, initial_state_dict, load_fixture,
+                                 make_env, record_step)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,8 +31,9 @@ def _passive_ckpt(seed):
     return {"actor_critic." + k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.passive_shapes(), seed).items()}
 
 
-def run_m2h(d, flat, replay, env_kind, graphs, rank=0, world=1, pre=""):
-    """Runs the product trainer over the fixture's schedule (its own sampled actions); returns a record shaped like the oracle's."""
+def run_m2h(d, flat, replay, env_kind, graphs, rank=0, world=1, pre="", sampling="cpu_generator"):
+    """Runs the product trainer over the fixture's schedule (its own sampled actions); returns a record shaped like the oracle's.
+    sampling="fused": the trainers' default draw; every step's Exp(1) noise, as the heads kernel drew it, is kept in rec["noise"]."""
     from m2h.envs.replay_env import ReplayVecEnv
     from m2h.envs.vector_env_adapter import HostVectorEnvAdapter
     from m2h.rl.ppo.ppo_trainer import PPOTrainer, near_target_config
@@ -40,7 +42,7 @@ def run_m2h(d, flat, replay, env_kind, graphs, rank=0, world=1, pre=""):
                                  "num_mini_batch", "eps", "max_grad_norm", "num_steps", "use_gae", "gamma", "tau", "use_linear_clip_decay",
                                  "use_linear_lr_decay", "sep_reward_weight", "nav_reward_weight", "extra_reward_multiplier", "reward_window_size",
                                  "use_ddppo", "NUM_UPDATES", "CHECKPOINT_INTERVAL", "MAX_EPISODE_STEPS", "SEED", "NUM_PROCESSES", "train_passive_separators")}
-    cfg = near_target_config(use_hip_graphs=graphs, action_sampling="cpu_generator", **keys)
+    cfg = near_target_config(use_hip_graphs=graphs, action_sampling=sampling, record_action_noise=sampling == "fused", **keys)
     seed = flat["SEED"] + rank * flat["NUM_PROCESSES"]
     if env_kind == "device":
         envs = ReplayVecEnv(flat["NUM_PROCESSES"], dev, seed=seed, episode_len=flat["MAX_EPISODE_STEPS"], pool=replay["pool"],
@@ -52,7 +54,7 @@ def run_m2h(d, flat, replay, env_kind, graphs, rank=0, world=1, pre=""):
         state = lambda: host.s.copy()  # noqa: E731
     tr = PPOTrainer(cfg, dev, world_rank=rank, world_size=world, envs=envs)
     tr.setup(passive_state_dict=_passive_ckpt(replay["passive_seed"]))
-    steps, saved = [], []
+    steps, saved, noise = [], [], []
     orig_step, orig_pol, orig_sep = tr._collect_rollout_step, tr._update_pol, tr._update_sep
 
     def step():
@@ -67,6 +69,8 @@ def run_m2h(d, flat, replay, env_kind, graphs, rank=0, world=1, pre=""):
         for name in OT.STAT_NAMES:
             rec["stat." + name] = getattr(tr.stats, name).cpu().numpy().copy()
         steps.append(rec)
+        if sampling == "fused":
+            noise.append(tr.actor_critic.last_action_noise.cpu().clone())
         return n
     pol, sep = [], []
 
@@ -87,7 +91,7 @@ def run_m2h(d, flat, replay, env_kind, graphs, rank=0, world=1, pre=""):
     cfg.CHECKPOINT_FOLDER = "unused"
     tr.train()
     graph_replays = 0 if tr._graph_state is None else len(tr._graph_state.graphs)
-    return {"steps": [steps], "pol": pol, "sep": sep, "ckpts": saved, "scalars": tr.scalars, "graphs": graph_replays, "trainer": tr,
+    return {"steps": [steps], "pol": pol, "sep": sep, "ckpts": saved, "scalars": tr.scalars, "graphs": graph_replays, "trainer": tr, "noise": noise,
             "state_dict": {k: v.detach().cpu() for k, v in tr.actor_critic.state_dict().items()}}
 
 
@@ -108,6 +112,53 @@ def test_near_target_training_matches_the_reference_run(env_kind, graphs):
         assert rec["graphs"] == 3 and rec["trainer"].agent._pol_graph is not None
     # the frozen separators' BatchNorm statistics are untouched by training
     assert np.array_equal(rec["state_dict"]["binSep_enc.passive_sep_encoder.cnn.0.1.running_mean"].numpy(), d["frozen_bn_running_mean0"])
+
+
+@pytest.mark.parametrize("graphs", [True, False])
+def test_near_target_training_in_the_default_fused_sampling_mode_matches_the_oracle_on_the_recorded_noise(graphs):
+    """The mode the trainers (and bench.py's DD-PPO legs) run by default, ``action_sampling="fused"``: the Exp(1) noise of
+    torch.multinomial's single draw (common/utils.py:16-24, rl/ppo/policy.py:198-225) is made inside the heads kernel, so no seed of the
+    reference's CPU generator reproduces it and the reference-run fixture's trajectory is not this run's.  The contract of SURVEY 8(d) --
+    actions bit-exact GIVEN probs and the draw's noise -- is pinned end to end instead: the kernel writes the noise it drew at every step
+    (m2h_policy_heads_act_rng noise_out), the CPU oracle's training loop (oracle/m2h_oracle_trainer.py, itself pinned to the reference's
+    own PPOTrainer.train run by tests/test_oracle_trainer_golden.py, its noise-fed draw to the reference's sample() by
+    tests/test_oracle_rl_golden.py) runs the same schedule from the same seeds with that noise in place of its generator's draw, and the
+    product's whole run must equal the oracle's: actions and env states bit for bit, rewards / values / log-probs / hidden states /
+    stored separator outputs / 17 statistics per step, losses, learning rates, clip ranges, returns, window scalars, the checkpoint
+    schedule and the weights after two cycles, at the tolerances of the reference-run tests."""
+    d, flat, replay = load_fixture("trainer_near.npz")
+    rec = run_m2h(d, flat, replay, "device", graphs, sampling="fused")
+    tr = rec["trainer"]
+    n_steps = len(rec["steps"][0])
+    assert len(rec["noise"]) == n_steps == d["step.actions"].shape[0]
+    noise = torch.stack(rec["noise"])
+    N, A = flat["NUM_PROCESSES"], 3
+    assert noise.shape == (n_steps, N, A) and bool((noise > 0).all()) and bool(torch.isfinite(noise).all())
+    # every step drew fresh noise (the device counter moved on by N x A per step, inside the replayed graphs too) ...
+    assert len({tuple(q.reshape(-1).tolist()) for q in rec["noise"]}) == n_steps
+    seed, ctr = tr.actor_critic.sampler_state()
+    assert ctr == n_steps * N * A and seed == 0x5eed0000 + flat["SEED"]
+    # ... and it is the Philox stream of the documented (seed, counter) layout
+    from kernel_model import philox_exp1 as _philox_exp1
+    want_noise, _u = _philox_exp1(seed, np.arange(n_steps * N * A, dtype=np.uint64))
+    assert np.abs(noise.numpy().reshape(-1) - want_noise).max() <= 3e-7 * np.abs(want_noise).max()
+    if graphs:
+        assert rec["graphs"] == 3
+    # the oracle's loop on the recorded noise
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    store = [[]]
+    want = OT.train(flat, [make_env(flat, replay, 0)], initial_state_dict(flat["SEED"], replay["passive_seed"]), distributed=True,
+                    on_step=record_step(store), action_noise=[list(rec["noise"])])
+    want["steps"] = store
+    d2 = fixture_from_oracle_record(want)
+    assert not np.array_equal(d2["step.actions"], d["step.actions"])      # (another noise stream than the reference run's: another trajectory)
+    check_run(d2, rec, 0, "", step_tol=5e-5, skip=("probs",), stat_tol=2e-4)
+    check_updates(d2, rec, "", 0, 1)
+    check_scalars(d2, rec, "")
+    check_weights(d2, rec, "", tol=1e-4)
+    # the draw itself, on the oracle's own CPU probabilities: argmax(probs / recorded noise) at every step, exactly
+    for k, s in enumerate(store[0]):
+        assert np.array_equal((s["probs"] / rec["noise"][k].numpy()).argmax(1).reshape(-1, 1), rec["steps"][0][k]["actions"])
 
 
 def test_train_passive_separators_key_changes_nothing_as_in_the_reference():

@@ -59,6 +59,14 @@ def test_sampling_contract_bit_exact(golden_dir):
     torch.manual_seed(int(g["sample_seed"]))
     a = torch.multinomial(torch.from_numpy(g["sample_probs"]), 1, True)
     assert torch.equal(a, torch.from_numpy(g["sample_actions"]))
+    # the draw as "argmax(probs / Exp(1) noise)" with the noise handed in (m2h_oracle_trainer.draw_actions: what the fused-sampling
+    # parity test feeds with the noise the heads kernel recorded): the generator's own Exp(1) draw at the same stream position gives the
+    # reference's actions, i.e. the noise is ALL the draw takes from the generator
+    import m2h_oracle_trainer as OT
+    torch.manual_seed(int(g["sample_seed"]))
+    probs = torch.from_numpy(g["sample_probs"])
+    q = torch.empty_like(probs).exponential_(1)
+    assert torch.equal(OT.draw_actions(probs, q), torch.from_numpy(g["sample_actions"]))
 
 
 def test_returns_advantages_generators(golden_dir):

@@ -10,25 +10,11 @@ import pytest
 import torch
 
 import m2h_oracle_trainer as OT
-from trainer_golden_util import (check_run, check_scalars, check_updates, check_weights, initial_state_dict, load_fixture, make_env)
+from trainer_golden_util import (check_run, check_scalars, check_updates, check_weights, fixture_from_oracle_record, initial_state_dict, load_fixture,
+                                 make_env, record_step)
 
 
-def record_step(store):
-    def on_step(r, k, rk):
-        values, actions, logp, h, probs = rk.last_act
-        ro = rk.ro
-        s = (ro.step - 1) % ro.num_steps
-        stats11 = OT.stats11
-        rec = {"rewards": ro.rewards[s].numpy().copy(), "values": values.numpy().copy(), "logp": logp.numpy().copy(), "probs": probs.numpy().copy(),
-               "h": h.numpy().copy(), "masks": ro.masks[s + 1].numpy().copy(), "actions": actions.numpy().copy(), "env_state": rk.envs.s.copy(),
-               "pm_stats": stats11(ro.pred_binSepMasks[s]), "mono_stats": stats11(ro.pred_mono[s]), "mem_stats": stats11(ro.prev_pred_monoFromMem[s + 1])}
-        for n in OT.STAT_NAMES:
-            rec["stat." + n] = rk.stats[n].numpy().copy()
-        store[r].append(rec)
-    return on_step
-
-
-def run_oracle(d, flat, replay, world=1, forced=True, pre=("",)):
+def run_oracle(d, flat, replay, world=1, forced=True, pre=("",), action_noise=None):
     torch.set_num_threads(4)
     sd = initial_state_dict(flat["SEED"], replay["passive_seed"])
     envs = [make_env(flat, replay, r) for r in range(world)]
@@ -36,7 +22,7 @@ def run_oracle(d, flat, replay, world=1, forced=True, pre=("",)):
     if forced:
         fa = [[torch.from_numpy(a) for a in d[p + "step.actions"]] for p in pre]
     store = [[] for _ in range(world)]
-    rec = OT.train(flat, envs, sd, forced_actions=fa, distributed=True, on_step=record_step(store))
+    rec = OT.train(flat, envs, sd, forced_actions=fa, distributed=True, on_step=record_step(store), action_noise=action_noise)
     rec["steps"] = store
     return rec
 
@@ -73,6 +59,38 @@ def test_oracle_samples_the_reference_actions_unforced():
     d, flat, replay = load_fixture("trainer_near.npz")
     rec = run_oracle(d, flat, replay, forced=False)
     assert np.array_equal(np.stack([s["actions"] for s in rec["steps"][0]]), d["step.actions"])
+
+
+def test_oracle_with_the_generators_noise_handed_in_is_the_unforced_run():
+    """OT.train(action_noise=...) -- the entry the fused-sampling parity test (tests/test_gpu_trainer_golden.py) feeds with the noise the
+    heads kernel recorded: handed the Exp(1) noise the CPU generator would have drawn at each step, it reproduces the reference's actions
+    and, re-keyed like a fixture (fixture_from_oracle_record), its own record passes the checks the reference-run fixture passes."""
+    d, flat, replay = load_fixture("trainer_near.npz")
+    # the generator's stream of the reference run: policy init, then per step one exponential_ draw of [N, 3]; per epoch one randperm.
+    # Replay it once unforced to harvest the per-step noise at the right stream positions.
+    noise = []
+    orig = OT.draw_actions
+
+    def harvesting(probs, q=None):
+        q = torch.empty_like(probs).exponential_(1)
+        noise.append(q.clone())
+        return orig(probs, q)
+    OT.draw_actions = harvesting
+    try:
+        rec0 = run_oracle(d, flat, replay, forced=False)
+    finally:
+        OT.draw_actions = orig
+    assert np.array_equal(np.stack([s["actions"] for s in rec0["steps"][0]]), d["step.actions"])
+    # the same run with that noise handed in (the generator now only serves randperm, whose values one mini-batch never uses)
+    rec = run_oracle(d, flat, replay, forced=False, action_noise=[noise])
+    check_run(d, rec, 0, "")
+    check_updates(d, rec, "", 0, 1)
+    check_weights(d, rec, "")
+    d2 = fixture_from_oracle_record(rec)
+    check_run(d2, rec, 0, "")
+    check_updates(d2, rec, "", 0, 1)
+    check_scalars(d2, rec)
+    check_weights(d2, rec, "")
 
 
 def test_oracle_two_rank_ddp_matches_reference_run():

@@ -110,3 +110,51 @@ def check_scalars(d, rec, pre=""):
         assert np.abs(got - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), (tag, got, want)
 
 
+
+
+def record_step(store):
+    """on_step hook of OT.train: one record per (rank, step), shaped like the fixtures' ``step.*`` arrays."""
+    def on_step(r, k, rk):
+        values, actions, logp, h, probs = rk.last_act
+        ro = rk.ro
+        s = (ro.step - 1) % ro.num_steps
+        stats11 = OT.stats11
+        rec = {"rewards": ro.rewards[s].numpy().copy(), "values": values.numpy().copy(), "logp": logp.numpy().copy(), "probs": probs.numpy().copy(),
+               "h": h.numpy().copy(), "masks": ro.masks[s + 1].numpy().copy(), "actions": actions.numpy().copy(), "env_state": rk.envs.s.copy(),
+               "pm_stats": stats11(ro.pred_binSepMasks[s]), "mono_stats": stats11(ro.pred_mono[s]), "mem_stats": stats11(ro.prev_pred_monoFromMem[s + 1])}
+        for n in OT.STAT_NAMES:
+            rec["stat." + n] = rk.stats[n].numpy().copy()
+        store[r].append(rec)
+    return on_step
+
+
+def fixture_from_oracle_record(rec, r=0):
+    """An oracle run (OT.train's record, steps from ``record_step``) as a dict keyed like the reference-run fixtures
+    (oracle/gen_trainer_golden.py run_reference), so that check_run / check_updates / check_scalars / check_weights compare a product
+    run with it: used where the expected values depend on inputs made at test time (the fused sampler's recorded noise)."""
+    out = {}
+    steps = rec["steps"][r]
+    for k in steps[0]:
+        out["step." + k] = np.stack([np.asarray(s[k]) for s in steps])
+    for k in ("losses", "lr", "clip"):
+        out["pol." + k] = np.stack([np.asarray(u[k][r] if k == "losses" else u[k]) for u in rec["pol"]])
+    out["pol.returns"] = np.stack([u["returns"][r].numpy() for u in rec["pol"]])
+    for k in ("losses", "lr"):
+        out["sep." + k] = np.stack([np.asarray(u[k][r] if k == "losses" else u[k]) for u in rec["sep"]])
+    tags = sorted(rec["scalars"][0][1])
+    out["scalar_tags"] = np.array(tags)
+    for t in tags:
+        out["scalar." + t] = np.array([[float(sc[t]), cs] for cs, sc in rec["scalars"]])
+    out["ckpt_names"] = np.array([c[0] for c in rec["ckpts"]])
+    out["ckpt_after_sep_updates"] = np.array([c[1] for c in rec["ckpts"]])
+    for k, t in rec["state_dict"].items():
+        if k.startswith(("pol_net", "action_dist", "critic", "acoustic_mem")):
+            if t.numel() <= 100000:
+                out["post." + k] = t.numpy().copy()
+            else:
+                flat = t.reshape(-1)
+                out["postsample." + k] = flat[torch.linspace(0, flat.numel() - 1, 64).long()].numpy().copy()
+
+    class _D(dict):
+        files = property(lambda self: list(self))
+    return _D(out)
