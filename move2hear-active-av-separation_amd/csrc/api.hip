@@ -6,13 +6,11 @@ namespace m2h {
 thread_local char g_err[512] = {0};
 thread_local const char* tl_last_launch = "";
 thread_local const char* tl_unet_stage[11] = {"", "", "", "", "", "", "", "", "", "", ""};
-int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st, unsigned* zeroed_tickets = nullptr);   // zeroed_tickets: M2H_STREAM_MAX_TILES zero words the caller
-                                                                                                    // keeps for conv_stream.hip's launches (nullptr: carved from the workspace)
+int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st);
 int launch_strip_conv1(const float* mix, const float* masks, const void* wreg, const float* scale, const float* shift, const float* cls_table,
                        const float* cls_val, float* dst, int B, int T, float slope, hipStream_t st, int cls_kind);
 int sep_slice_input_cls(const float* mix, const float* masks, float* out, int B, int F, int T, int split_out, const void* cls_raw, int cls_kind,
-                        float* cls_out, hipStream_t st, unsigned* zero_words = nullptr, int n_zero = 0);
-constexpr int kStreamTickets = 1024;   // == M2H_STREAM_MAX_TILES (igemm_common.h): ticket words of conv_stream.hip's launches
+                        float* cls_out, hipStream_t st);
 size_t conv_igemm_workspace_bytes(const m2h_conv_args& a);
 thread_local Tuning tl_tuning = {};   // every knob 0 = automatic (m2h_internal.h)
 extern thread_local int tl_math_mode;
@@ -149,7 +147,7 @@ static const int kEnc[6] = {32, 64, 128, 256, 512, 512};
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 struct UnetLayout {
-  size_t x0, e[5], d[5], splitk, cls, tickets, total;
+  size_t x0, e[5], d[5], splitk, cls, total;
 };
 
 static UnetLayout unet_layout(int B, int F, int T, int n_out) {
@@ -183,7 +181,6 @@ static UnetLayout unet_layout(int B, int F, int T, int n_out) {
   }
   L.splitk = off; off += align256(sk);
   L.cls = off; off += align256((size_t)B * 4);   // the class plane's values when the caller hands over the raw target_class (cls_kind)
-  L.tickets = off; off += align256((size_t)kStreamTickets * 4);   // conv_stream.hip's arrival counters: zeroed by the call's first kernel, left zero by every launch
   L.total = off;
   return L;
 }
@@ -237,14 +234,14 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
   const bool strip0 = sp && wts->down0_strip != nullptr && T % 64 == 0 && g_strip >= 0 && strip_fits;
   const int cls_kind = cls_val != nullptr ? wts->cls_kind : 0;
   M2H_REQUIRE(cls_kind >= 0 && cls_kind <= 2, "unet_fwd: cls_kind must be 0, 1 or 2");
-  // fp32 arithmetic (the rollout batch): the weight-streaming stages (conv_stream.hip) count their K-slices' arrivals on ticket words of the
-  // workspace, which this call's first kernel clears
-  unsigned* tickets = (!strip0 && math == 0) ? reinterpret_cast<unsigned*>(ws + L.tickets) : nullptr;
   if (!strip0) {
-    // the slice launch also makes the class plane's values from the raw target_class (cls_kind) and clears the ticket words
-    float* cls_out = reinterpret_cast<float*>(ws + L.cls);
-    rc = sep_slice_input_cls(mix, masks, x0, B, F, T, sp, cls_val, cls_kind, cls_out, st, tickets, tickets != nullptr ? kStreamTickets : 0);
-    if (cls_kind != 0) cls_val = cls_out;
+    if (cls_kind != 0) {   // the slice launch also makes the class plane's values from the raw target_class
+      float* cls_out = reinterpret_cast<float*>(ws + L.cls);
+      rc = sep_slice_input_cls(mix, masks, x0, B, F, T, sp, cls_val, cls_kind, cls_out, st);
+      cls_val = cls_out;
+    } else {
+      rc = m2h_sep_slice_input_fmt(mix, masks, x0, B, F, T, 2, sp, stream);
+    }
     if (rc) return rc;
   }
   if ((rc = mark())) return rc;
@@ -265,7 +262,7 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
     m2h_conv_args a = down_args(cur, wts->down_w[i], wts->down_scale[i], wts->down_shift[i], i == 0 ? wts->cls_table : nullptr,
                                 i == 0 ? cls_val : nullptr, e[i], B, h, w, kEnc[i], kEnc[i + 1]);
     a.workspace = sk; a.workspace_bytes = skb; a.operand_format = fmt_mid;
-    if ((rc = conv_igemm_f32(a, st, tickets))) return rc;
+    if ((rc = conv_igemm_f32(a, st))) return rc;
     if ((rc = mark())) return rc;
     cur = e[i];
     h /= 2; w /= 2;
@@ -276,7 +273,7 @@ static int unet_fwd_impl(const m2h_unet_weights* wts, const float* mix, const fl
     const float* skip = i == 0 ? nullptr : e[4 - i];
     m2h_conv_args a = up_args(cur, skip, wts->up_w[i], wts->up_scale[i], wts->up_shift[i], d[i], B, h, w, c0[i], c1[i], dco[i]);
     a.workspace = sk; a.workspace_bytes = skb; a.operand_format = fmt_mid;
-    if ((rc = conv_igemm_f32(a, st, tickets))) return rc;
+    if ((rc = conv_igemm_f32(a, st))) return rc;
     if ((rc = mark())) return rc;
     cur = d[i];
     h *= 2; w *= 2;

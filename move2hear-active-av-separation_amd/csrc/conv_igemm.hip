@@ -1370,16 +1370,6 @@ size_t conv_igemm_workspace_bytes(const m2h_conv_args& a) {
   pick_tile(M, a.N, BM, BN);
   const int S = splitk_for(M, a.N, K, phases, BM, BN);
   size_t bytes = S <= 1 ? 0 : (size_t)phases * S * M * a.N * sizeof(float);
-  {   // at most 64 rows against a weight stream: the slabs and ticket words of the streaming split-K kernel (conv_stream.hip)
-    const int Ctot = a.C0 + a.C1;
-    const int math0 = (a.operand_format & M2H_FMT_MATH_BF16X3) ? 1 : (a.operand_format & M2H_FMT_MATH_FP32) ? 0 : tl_math_mode;
-    const bool fast = a.C0 % BK == 0 && a.C1 % BK == 0 && a.C0 > 0;
-    if (a.head_w == nullptr && a.cls_table == nullptr &&
-        stream_splitk_applicable(math0, fast, M, a.N, Ctot, K, phases, a.out_mode, (a.operand_format & M2H_FMT_LAYOUT_BITS) == 0)) {
-      const size_t need = stream_splitk_workspace_bytes(M, a.N, K, phases);
-      if (need > bytes) bytes = need;
-    }
-  }
   // split32 operands in bf16x3 math: the LDS-DMA engine's two-K-halves launch of the 256 x 128 tile (conv_dma.hip) takes its slabs
   // from this workspace too -- report them, so that a caller who sizes the workspace by this function gets the same kernel (and the
   // same fp32 summation order) as the whole-network runner, whose scratch is the maximum over its stages
@@ -1399,7 +1389,7 @@ size_t conv_igemm_workspace_bytes(const m2h_conv_args& a) {
   return bytes;
 }
 
-int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st, unsigned* zeroed_tickets) {
+int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
   M2H_REQUIRE(a.src0 != nullptr && a.wp != nullptr && a.dst != nullptr, "conv_igemm: null pointer");
   M2H_REQUIRE(a.B > 0 && a.Hi > 0 && a.Wi > 0 && a.Hq > 0 && a.Wq > 0 && a.N > 0, "conv_igemm: non-positive size");
   M2H_REQUIRE(a.C0 > 0 && a.C0 % 4 == 0 && a.C1 >= 0 && a.C1 % 4 == 0, "conv_igemm: C0/C1 must be multiples of 4 (got %d, %d)", a.C0, a.C1);
@@ -1522,13 +1512,6 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st, unsigned* zeroed_tick
 #undef M2H_TAP_P
       return launch_status(w == 16 ? "igemm_convT_tap<16>" : (w == 32 ? "igemm_convT_tap<32>" : "igemm_convT_tap<64>"));
     }
-  }
-  // at most 64 rows per phase against >= 1 MB of weights (the rollout batch's deep U-Net stages, its 14-row Linear layers): every
-  // weight byte read once, a block per CU, the K-slices' partial tiles combined in the launch (conv_stream.hip)
-  if (a.head_w == nullptr && a.cls_table == nullptr &&
-      stream_splitk_applicable(p.math, p.fast_ok != 0, M, a.N, p.Ctot, p.Kw, p.convT ? 4 : 1, a.out_mode, (a.operand_format & M2H_FMT_LAYOUT_BITS) == 0)) {
-    const int rc = launch_stream_splitk(p, wsb, zeroed_tickets, st);
-    if (rc != -2) return rc;
   }
   // M <= 16 rows that are each one contiguous run of floats: Linear; a conv whose tap window covers the whole image and gives
   // one output pixel; a transposed conv over a 1 x 1 image (one tap per phase).  Weight streaming on the skinny kernel.

@@ -444,12 +444,6 @@ int launch_igemm_patch(IGemmP& p, size_t ws_bytes, hipStream_t st);   // p.S == 
 
 // convt_quad.hip: four-phase transposed-conv kernel (split32 operands, N <= 64); -2 when the launch is not one of its shapes
 int launch_convT_quad(IGemmP& p, hipStream_t st);
-// conv_stream.hip: the weight-streaming split-K kernel for at most 64 rows per phase (its rule, its scratch, its launch; -2 = workspace too small)
-constexpr int M2H_STREAM_MAX_TILES = 1024;
-constexpr int M2H_STREAM_MAX_SLICES = 16;
-bool stream_splitk_applicable(int math, bool fast, long M, int N, int Ctot, int Kw, int phases, int out_mode, bool plain_operands);
-size_t stream_splitk_workspace_bytes(long M, int N, int Kw, int phases);
-int launch_stream_splitk(IGemmP& p, size_t ws_bytes, unsigned* tickets, hipStream_t st);
 
 // conv_dma.hip: shape rule of the engine's two-way split-K launch (the fourth encoder stage at the benchmark batch)
 bool dma_split2_rule(long M, int N, int Kw, int phases, bool ws_present, size_t ws_bytes);

@@ -50,11 +50,8 @@ typedef __bf16 bf16x4_s __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void sep_slice_input_c2_kernel(const float* __restrict__ mix, const float* __restrict__ masks,
                                                                  float* __restrict__ out, int B, int F, int T, int split_out,
                                                                  const void* __restrict__ cls_raw = nullptr, int cls_kind = 0,
-                                                                 float* __restrict__ cls_out = nullptr, unsigned* __restrict__ zero_words = nullptr,
-                                                                 int n_zero = 0) {
+                                                                 float* __restrict__ cls_out = nullptr) {
   constexpr int TT = 64, LD = 132;
-  if (zero_words != nullptr && blockIdx.x == gridDim.x - 1)   // the runner's ticket words (conv_stream.hip), zeroed by its first kernel
-    for (int k = threadIdx.x; k < n_zero; k += 256) zero_words[k] = 0u;
   if (cls_out != nullptr && blockIdx.x == 0)   // the class plane's value target_class.float() + 1 (separator_cnn.py:96) for the first conv's epilogue
     for (int b = threadIdx.x; b < B; b += 256)
       cls_out[b] = (cls_kind == 2 ? (float)static_cast<const long long*>(cls_raw)[b] : static_cast<const float*>(cls_raw)[b]) + 1.f;
@@ -228,15 +225,12 @@ using namespace m2h;
 
 namespace m2h {
 // the runner's slice launch (C == 2, even T) that also turns the raw target_class into the class plane's values (m2h_unet_weights.cls_kind)
-// (cls_kind 0: no class values to make, cls_raw / cls_out unused); zero_words / n_zero: words the launch also clears (the runner's tickets)
 int sep_slice_input_cls(const float* mix, const float* masks, float* out, int B, int F, int T, int split_out, const void* cls_raw, int cls_kind,
-                        float* cls_out, hipStream_t st, unsigned* zero_words, int n_zero) {
+                        float* cls_out, hipStream_t st) {
   const long nblk = (long)B * (F / 16) * ((T + 63) / 64);
-  M2H_REQUIRE(mix && out && F % 16 == 0 && T % 2 == 0 && nblk > 0 && nblk <= 0x7fffffffL &&
-                  (cls_kind == 0 || (cls_raw && cls_out && (cls_kind == 1 || cls_kind == 2))),
+  M2H_REQUIRE(mix && out && cls_raw && cls_out && (cls_kind == 1 || cls_kind == 2) && F % 16 == 0 && T % 2 == 0 && nblk > 0 && nblk <= 0x7fffffffL,
               "sep_slice_input_cls: bad arguments");
-  M2H_LAUNCH(sep_slice_input_c2_kernel, dim3((unsigned)nblk), dim3(256), 0, st, mix, masks, out, B, F, T, split_out, cls_kind != 0 ? cls_raw : nullptr, cls_kind,
-             cls_kind != 0 ? cls_out : nullptr, zero_words, n_zero);
+  M2H_LAUNCH(sep_slice_input_c2_kernel, dim3((unsigned)nblk), dim3(256), 0, st, mix, masks, out, B, F, T, split_out, cls_raw, cls_kind, cls_out);
   return launch_status("sep_slice_input");
 }
 }  // namespace m2h

@@ -57,8 +57,6 @@ extern thread_local Tuning tl_tuning;
 #define g_skinny_tiny (::m2h::tl_tuning.v[33])
 #define g_wgrad_small_m (::m2h::tl_tuning.v[25])
 #define g_patch_grid (::m2h::tl_tuning.v[10])
-#define g_stream (::m2h::tl_tuning.v[5])
-#define g_stream_blocks (::m2h::tl_tuning.v[6])
 
 // Label of the calling thread's most recent kernel launch (the `what` of launch_status: every launch site names its kernel family):
 // read back by m2h_last_kernel / m2h_unet_fwd_stage_kernel, so that benchmark tables name the kernel that really ran.
