@@ -67,6 +67,42 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+CLOCK_DIAG_LIB = os.path.join(_HERE, "libm2h_clockdiag.so")
+CLOCK_DIAG_SOURCES = ("conv_igemm.hip", "conv_dma.hip", "conv_patch.hip")   # the units that carry M2H_CLOCK_DIAG stamps
+
+
+def build_clock_diag(force=False):
+    """DIAGNOSTIC copy of the library, never loaded by the product path: the three conv-engine units compiled with -DM2H_CLOCK_DIAG (two
+    s_memtime / s_memrealtime stamps around each block's k-loop, written to a buffer of their own), every other unit's object shared
+    with ``build()``.  tools/clock_probe.py loads it in a child process of bench.py -- one stamped run of the headline's dominant kernel
+    OUTSIDE the timed region -- to report the shader clock the chip holds inside that kernel (``roofline.clock_ghz``)."""
+    build()
+    objdir = os.path.join(CSRC, "build")
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
+    if not force and os.path.exists(CLOCK_DIAG_LIB) and os.path.getmtime(CLOCK_DIAG_LIB) > max(os.path.getmtime(d) for d in deps):
+        return CLOCK_DIAG_LIB
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DM2H_CLOCK_DIAG", "-I" + INCLUDE, "-I" + CSRC]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src + ".clockdiag.o")
+        r = subprocess.run([hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s (clock-diag build):\n%s" % (src, r.stdout))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        diag_objs = dict(zip(CLOCK_DIAG_SOURCES, ex.map(compile_one, CLOCK_DIAG_SOURCES)))
+    objs = [diag_objs.get(s, os.path.join(objdir, s + ".o")) for s in SOURCES]
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", CLOCK_DIAG_LIB + ".tmp"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc link failed (clock-diag build):\n" + r.stdout)
+    os.replace(CLOCK_DIAG_LIB + ".tmp", CLOCK_DIAG_LIB)
+    return CLOCK_DIAG_LIB
+
+
 class ConvArgs(ctypes.Structure):
     """Mirror of ``struct m2h_conv_args`` (include/m2h.h)."""
     _fields_ = [

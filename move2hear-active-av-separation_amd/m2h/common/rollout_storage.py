@@ -157,6 +157,13 @@ class RolloutStorageSep:
             self.pred_binSepMasks, self.pred_mono = self.pred_binSepMasks.to(device), self.pred_mono.to(device)
         self.generation += 1
 
+    def touch(self):
+        """Call after ANY write to the stored tensors that does not go through insert / advance / after_update / to (a direct
+        ``observations[s][row].copy_(...)``, the reference's reset pattern ppo_trainer.py:669-671): PPO's separator-output cache, the sliced
+        memory input and the after_update short-cut key on ``generation`` and would otherwise keep serving the old contents."""
+        self.generation += 1
+        self.row0_only_since = None
+
     def enable_separator_outputs(self):
         """Allocate the per-row separator outputs (see __init__); every row starts invalid."""
         ref = self.prev_pred_monoFromMem
@@ -175,6 +182,7 @@ class RolloutStorageSep:
             self.pred_binSepMasks[row].copy_(pred_binSepMasks)
             self.pred_mono[row].copy_(pred_mono)
             self._pred_rows_valid[row] = True
+            self.touch()
 
     def stored_separator_outputs(self):
         """(pred_binSepMasks, pred_mono) of rows 0 .. T-1 -- what update_sep's batch is made of -- or None when any is missing."""

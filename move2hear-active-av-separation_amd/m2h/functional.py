@@ -389,8 +389,12 @@ class Conv2dNHWC(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
         # AcousticMem's first conv over the update batch (3x3 / 1 / 1, 32 channels, 32-pixel rows, no bias, no input gradient): the
         # weight gradient is the only reader of dy, and its image-row kernel applies the activation's derivative as it loads dy
+        # (the predicate mirrors EVERY condition of the library's image-row rule, csrc/conv_bwd.hip `row3x3`: 3x3 / 1 / 1, one 32-channel source,
+        # 32-pixel rows, output grid == image (Ho x Wo == H x W: "direct"), N <= 32 and N % 4 == 0, dy rows N floats apart (contiguous NHWC: ldy % 4),
+        # one weight tile (N <= 32, K = 288 <= one k-tile group) -- a shape that passed here and failed there would raise inside backward)
         gated = (slope != 1.0 and ctx.needs_input_grad[2] and not need_x and not ctx.needs_input_grad[3] and x2 is None and
                  (KH, KW, stride, pad) == (3, 3, 1, 1) and x.shape[3] == 32 and x.shape[2] == 32 and Co <= 32 and Co % 4 == 0 and
+                 tuple(dy.shape[1:3]) == tuple(x.shape[1:3]) and dy.shape[3] == Co and dy.is_contiguous() and y.is_contiguous() and
                  x.shape[0] * x.shape[1] >= 512 and not ops.timing_enabled())
         gb = None
         if slope != 1.0 and not gated:

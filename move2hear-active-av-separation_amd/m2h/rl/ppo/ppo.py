@@ -382,7 +382,7 @@ class PPO(nn.Module):
                         # the sliced input is a function of the stored batch alone: the same tensor for every update on one generation of the
                         # storage (the cycle's updates 2-6: after_update() changes nothing once row 0 holds the last observation), as the
                         # cached separator outputs are (a 330 MB pass, 123 us, per update otherwise)
-                        skey = (id(rollouts_sep), getattr(rollouts_sep, "generation", None))
+                        skey = (id(rollouts_sep), getattr(rollouts_sep, "generation", None), rollouts_sep.prev_pred_monoFromMem.data_ptr())
                         if skey[1] is None or getattr(gs, "sliced_key", None) != skey:
                             with torch.no_grad():
                                 self.actor_critic.acoustic_mem.slice_inputs(pred_mono, prev_mem_batch, masks_batch, out=gs.sliced)

@@ -143,6 +143,7 @@ class PPOTrainer:
         for sensor in self.rollouts_pol.observations:
             self.rollouts_pol.observations[sensor][0].copy_(batch[sensor])
             self.rollouts_sep.observations[sensor][0].copy_(batch[sensor])
+        self.rollouts_sep.touch()   # (a direct row write: the caches keyed on the storage's generation must see it)
         z = lambda *s: torch.zeros(*s, device=self.device)  # noqa: E731
         self.stats = SimpleNamespace(
             episode_rewards=z(N, 1), episode_counts=z(N, 1), episode_steps=z(N, 1), episode_dist_probs=z(N, 3),
