@@ -678,6 +678,9 @@ def main():
     from m2h import ops
     for kv in filter(None, args.knobs.split(",")):
         ops.debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
+    if args.knobs:
+        from m2h import functional as MF_
+        MF_.carry_tuning(True)   # (backward passes run on autograd's thread: they take the knobs of the forward's thread along)
     pol, sd = make_policy(dev)
     mix, tc = make_inputs(dev, args.batch, args.tm, 1000 + rank)
     obs = {"mixed_bin_audio_mag": mix, "target_class": tc}

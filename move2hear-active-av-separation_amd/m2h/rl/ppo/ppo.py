@@ -328,6 +328,7 @@ class PPO(nn.Module):
             B, Fq, T, _ = pred_mono.shape
             gs = self._sep_graph = SimpleNamespace(sig=sig, graph=None, loss=None,
                                                    sliced=torch.empty((B, Fq // 16, T, 32), device=pred_mono.device, dtype=torch.float32),
+                                                   gt_plane=torch.empty((B, Fq, T, 1), device=pred_mono.device, dtype=torch.float32),
                                                    memos=MF.memos_of(self.actor_critic.acoustic_mem))
         return gs
 
@@ -386,9 +387,14 @@ class PPO(nn.Module):
                         if skey[1] is None or getattr(gs, "sliced_key", None) != skey:
                             with torch.no_grad():
                                 self.actor_critic.acoustic_mem.slice_inputs(pred_mono, prev_mem_batch, masks_batch, out=gs.sliced)
+                                # the loss's target, gt_mono_comps[..., 0] (:210-216), as a plane of its own: the stored tensor interleaves four
+                                # components per bin, so the loss kernel of every epoch fetched 440 MB of lines for 110 MB of magnitudes
+                                # (bench.py update_sep kernels: 126 us, the epoch's worst against its bytes).  Same floats, read once per
+                                # storage generation here instead of 24 x per cycle there.
+                                gs.gt_plane.copy_(gt_mono[..., 0:1])
                             gs.sliced_key = skey
                         sliced = gs.sliced
-                    monoFromMem_loss = self._sep_epoch_graph(gs, pred_mono, prev_mem_batch, masks_batch, gt_mono)
+                    monoFromMem_loss = self._sep_epoch_graph(gs, pred_mono, prev_mem_batch, masks_batch, gs.gt_plane)
                 elif cached is not None and idx is None:
                     if sliced is None:
                         with torch.no_grad():
