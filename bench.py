@@ -280,7 +280,7 @@ def ddppo_phase_rooflines(phase_ms, phase_launches, env_steps_per_cycle, sep_bf1
 
 
 def update_sep_kernel_rooflines(dev, samples, bf16x3):
-    """Each of the six conv / loss kernels of one update_sep epoch (AcousticMem forward + loss + backward over the stored samples,
+    """Each of the five conv / loss kernels of one update_sep epoch (AcousticMem forward + loss + backward over the stored samples,
     ppo.py:179-246; m2h/rl/models/memory_nets.py) launched alone on tensors of the epoch's shapes, HIP events around 5 launches in THIS run,
     bounded by what binds it: algorithmic bytes / time against the 6.3 TB/s a copy achieves, and algorithmic FLOP / time against the
     arithmetic's matrix ceiling (2500 / 3 TFLOP/s in bf16x3, 157.3 in fp32).  The phase's single MFMA fraction said nothing actionable:
@@ -291,8 +291,8 @@ def update_sep_kernel_rooflines(dev, samples, bf16x3):
     B = int(samples)
     r = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
     x, h1, dh = r(B, 32, 32, 32), r(B, 32, 32, 32).relu_(), r(B, 32, 32, 32)
-    y, dy = r(B, 32, 32, 16), r(B, 32, 32, 16)
-    gt = r(B, 512, 32, 4)
+    dy = r(B, 32, 32, 16)
+    gt_plane = r(B, 512, 32, 1)
     w0, w1 = r(32, 32, 3, 3) * 0.05, r(16, 32, 3, 3) * 0.05
     wp0, wp1 = ops.pack_conv_weight_ex(w0, 32, 32), ops.pack_conv_weight_ex(w1, 32, 32)
     wpd1 = MF.pack_dgrad_weight(w1, 1, 1)
@@ -300,8 +300,8 @@ def update_sep_kernel_rooflines(dev, samples, bf16x3):
     MB = 1e6
     cases = [
         ("forward conv 32->32 + ReLU", lambda: ops.conv2d_nhwc(x, wp0, 32, 3, 3, stride=1, pad=1, slope=0.0), 4.0 * px * (32 + 32), 2.0 * px * 32 * 288),
-        ("forward conv 32->16", lambda: ops.conv2d_nhwc(h1, wp1, 16, 3, 3, stride=1, pad=1, slope=1.0), 4.0 * px * (32 + 16), 2.0 * px * 16 * 288),
-        ("L1 loss + its gradient (NHWC, 16 bands)", lambda: ops.l1_loss_nhwc16(y, gt, 0, want_grad=True), 4.0 * px * (16 + 16 + 16), 0.0),
+        ("forward conv 32->16 + L1 loss + its gradient (one launch: the conv's output is never stored)", lambda: ops.conv3x3_l1_nhwc16(h1, wp1, gt_plane),
+         4.0 * px * (32 + 16 + 16), 2.0 * px * 16 * 288),
         ("weight gradient of conv 32->16", lambda: MF.conv_wgrad(h1, None, dy, 16, 3, 3, 1, 1, torch_ci=32), 4.0 * px * (32 + 16), 2.0 * px * 16 * 288),
         ("input gradient of conv 32->16", lambda: MF.conv_dgrad(dy, w1, (32, 32), 1, 1, wp=wpd1), 4.0 * px * (16 + 32), 2.0 * px * 32 * 144),
         ("weight gradient of conv 32->32 (ReLU gate fused)", lambda: MF.conv_wgrad(x, None, dh, 32, 3, 3, 1, 1, gate=h1, gate_slope=0.0, torch_ci=32),
@@ -326,7 +326,7 @@ def update_sep_kernel_rooflines(dev, samples, bf16x3):
             out[name] = {"kernel": label, "us": round(us, 1), "algorithmic_MB": round(nbytes / MB, 1), "achieved_GBps": round(gbps, 1), "frac_of_6300_GBps": round(f_hbm, 3),
                          "gflop": round(flops / 1e9, 2), "achieved_TFLOPs": round(tf, 1), "frac_of_matrix_ceiling": round(f_mfma, 3),
                          "bound": "hbm" if f_hbm >= f_mfma else "mfma"}
-    out["what"] = ("one launch each on tensors of the epoch's shapes (%d stored samples x 32 x 32 pixels), mean of 5 launches between two HIP events in this run; "
+    out["what"] = ("one call each (the weight gradients: kernel + their split reduce) on tensors of the epoch's shapes (%d stored samples x 32 x 32 pixels), mean of 5 launches between two HIP events in this run; "
                    "the gate-fused weight gradient also reads the forward activation (three streams)") % B
     return out
 

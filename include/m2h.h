@@ -138,6 +138,17 @@ int m2h_conv_igemm_f32(const m2h_conv_args* args /* host */, m2h_stream stream);
                           conv_strip.hip) multiply the bf16 hi halves only -- one MFMA product per product instead of three; operands,
                           accumulation and outputs unchanged (fp32 sums, split32 tensors).  Other engines compute bf16x3. */
 int m2h_set_math_mode(int mode);
+/* AcousticMem's last conv and update_sep's loss in ONE launch (rl/models/memory_nets.py:16,62-67; rl/ppo/ppo.py:206-216):
+ * loss = F.l1_loss(deslice(conv3x3(h, w)), gt) with h NHWC [B][H][T][C], wp the packed 3x3 weight [16][9 C] (m2h_pack_conv_weight_ex) and gt_plane
+ * the target as a contiguous plane [B][16 H][T] (gt_mono_comps[..., 0]); the conv's output is never stored: the image-row kernel's epilogue adds
+ * |y - g| to its block's partial sum and writes d loss / d y = sign(y - g) / n to dy NHWC [B][H][T][16] -- the layout the conv's weight- and
+ * input-gradient launches read.  partials: >= 1024 floats of scratch; loss: 1 float (sum of the partials in block order: bit-reproducible).
+ * Arithmetic: the calling thread's (m2h_set_math_mode).  Shapes: H = T = C = 32, B >= 64 (m2h_conv3x3_l1_nhwc16_supported; other shapes:
+ * m2h_conv_igemm_f32 + m2h_l1_loss_nhwc16, which this replaces where it applies: 110 MB written and read back per update_sep epoch, one launch). */
+int m2h_conv3x3_l1_nhwc16_supported(int B, int H, int T, int C);
+int m2h_conv3x3_l1_nhwc16(const float* h, const float* wp, const float* gt_plane, float* dy, float* loss, float* partials, int B, int H, int T, int C,
+                          m2h_stream stream);
+
 /* Diagnostic: kernels this process has enqueued (or captured into a HIP graph) through libm2h so far.  bench.py's per-phase launch
  * counts (a replayed graph counts its captured kernels once per replay, on the host side: m2h/graphs.py). */
 long long m2h_launch_count(void);

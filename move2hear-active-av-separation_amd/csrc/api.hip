@@ -6,7 +6,8 @@ namespace m2h {
 thread_local char g_err[512] = {0};
 thread_local const char* tl_last_launch = "";
 thread_local const char* tl_unet_stage[11] = {"", "", "", "", "", "", "", "", "", "", ""};
-int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st);
+struct ConvL1;
+int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st, const ConvL1* l1 = nullptr);
 int launch_strip_conv1(const float* mix, const float* masks, const void* wreg, const float* scale, const float* shift, const float* cls_table,
                        const float* cls_val, float* dst, int B, int T, float slope, hipStream_t st, int cls_kind);
 int sep_slice_input_cls(const float* mix, const float* masks, float* out, int B, int F, int T, int split_out, const void* cls_raw, int cls_kind,

@@ -665,6 +665,50 @@ __global__ __launch_bounds__(64 * WM, WM == 4 ? 2 : 1) void convT_tap_kernel(con
   fused_epilogue<BM, BN, WM, WN, FR, AccT, PMAX * LDK * 4>(p, acc, As, Bs, ri_out, ri_bc, 0, tid);
 }
 
+// Fused L1 epilogue of the image-row kernels' 16-channel instantiations (IGemmP::l1_gt): lane (band n = lane & 15, pixel group lane >> 4)
+// holds four consecutive time frames of band n per 16-pixel fragment -- 16 contiguous bytes of the target plane -- so the loss costs one
+// 16-byte load per fragment; the gradient sign(y - g) / n leaves in the conv's own NHWC layout, y itself is never stored (update_sep,
+// ppo.py:206-216 with memory_nets.py:16,62-67: 110 MB written and read back per epoch otherwise, and one launch).  Returns the lane's |y - g| sum.
+template <int FM, typename AccT>
+__device__ __forceinline__ float l1_row_epilogue(const IGemmP& p, const AccT (&acc)[FM], int b, int q, int lane, float sh) {
+  const int n = lane & 15;
+  float s = 0.f;
+#pragma unroll
+  for (int mi = 0; mi < FM; ++mi) {
+    const int x0 = mi * 16 + (lane >> 4) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(p.l1_gt + ((size_t)(b * 16 + n) * p.Ho + q) * p.Wo + x0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = (acc[mi][e] + sh) - g[e];
+      s += fabsf(d);
+      p.dst[((size_t)(b * p.Ho + q) * p.Wo + x0 + e) * p.ldc + n] = d > 0.f ? p.l1_inv : (d < 0.f ? -p.l1_inv : 0.f);
+    }
+  }
+  return s;
+}
+
+// the block's partial sum of the fused loss: lanes -> wave (shuffles) -> the four waves in wave order, one float per block
+__device__ __forceinline__ void l1_block_partial(const IGemmP& p, float s, float* scratch4, int tid) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  __syncthreads();                                   // (scratch4 aliases the main loop's LDS: every wave is done with it)
+  if ((tid & 63) == 0) scratch4[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) p.l1_part[blockIdx.x] = (scratch4[0] + scratch4[1]) + (scratch4[2] + scratch4[3]);
+}
+
+// loss = inv * sum of the blocks' partials, fixed order (one block of 256 threads; n <= 1024)
+__global__ __launch_bounds__(256) void l1_partials_sum_kernel(const float* __restrict__ part, int n, float inv, float* __restrict__ loss) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) * inv;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // Image-row 3x3 convolution (fp32 MFMA): Conv2d(3x3, stride 1, pad 1) over 16- or 32-channel, 32-pixel-wide images with N <= 32
 // output channels -- AcousticMem's two convs (rl/models/memory_nets.py:11-16) and the input gradient of the second one, at the
@@ -732,6 +776,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_row_kernel(const IGemmP p) {
   };
   const size_t plane = (size_t)p.Ho * p.Wo;
   const int Cc = p.N >> 4;
+  float l1_sum = 0.f;
   for (int c = blockIdx.x; c < chunks; c += gridDim.x) {
     if (c == (int)blockIdx.x) load_chunk(c);
     __syncthreads();              // the previous chunk's fragment reads (and the weight stores) are done
@@ -766,6 +811,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_row_kernel(const IGemmP p) {
     const int b = c / (p.Hq / ROWS), q = (c - b * (p.Hq / ROWS)) * ROWS + wave;
     const int n = lane & (FR - 1);
     const float sh = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
+    if constexpr (FR == 16) {
+      if (p.l1_gt != nullptr) {       // (N == 16, NHWC, slope 1: host rule) the loss instead of the store
+        l1_sum += l1_row_epilogue<FM>(p, acc, b, q, lane, sh);
+        continue;
+      }
+    }
     if (n < p.N) {
 #pragma unroll
       for (int mi = 0; mi < FM; ++mi)
@@ -782,6 +833,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_row_kernel(const IGemmP p) {
           }
         }
     }
+  }
+  if constexpr (FR == 16) {
+    if (p.l1_gt != nullptr) l1_block_partial(p, l1_sum, Pl, tid);
   }
 }
 
@@ -866,6 +920,7 @@ __global__ __launch_bounds__(256, (FR == 32 && C == 32) ? 2 : 3) void conv3x3_ro
   };
   const size_t plane = (size_t)p.Ho * p.Wo;
   const int Cc = p.N >> 4;
+  float l1_sum = 0.f;
   for (int c = blockIdx.x; c < chunks; c += gridDim.x) {
     if (c == (int)blockIdx.x) load_chunk(c);
     __syncthreads();              // the previous chunk's fragment reads (and the weight stores) are done
@@ -898,6 +953,12 @@ __global__ __launch_bounds__(256, (FR == 32 && C == 32) ? 2 : 3) void conv3x3_ro
     const int b = c / (p.Hq / ROWS), q = (c - b * (p.Hq / ROWS)) * ROWS + wave;
     const int n = lane & (FR - 1);
     const float sh = (p.shift != nullptr && n < p.N) ? p.shift[n] : 0.f;
+    if constexpr (FR == 16) {
+      if (p.l1_gt != nullptr) {       // (N == 16, NHWC, slope 1: host rule) the loss instead of the store
+        l1_sum += l1_row_epilogue<FM>(p, acc, b, q, lane, sh);
+        continue;
+      }
+    }
     if (n < p.N) {
 #pragma unroll
       for (int mi = 0; mi < FM; ++mi) {
@@ -927,6 +988,9 @@ __global__ __launch_bounds__(256, (FR == 32 && C == 32) ? 2 : 3) void conv3x3_ro
         }
       }
     }
+  }
+  if constexpr (FR == 16) {
+    if (p.l1_gt != nullptr) l1_block_partial(p, l1_sum, reinterpret_cast<float*>(Pl), tid);
   }
 }
 
@@ -1389,7 +1453,9 @@ size_t conv_igemm_workspace_bytes(const m2h_conv_args& a) {
   return bytes;
 }
 
-int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
+// l1: optional fused L1 loss (m2h_conv3x3_l1_nhwc16): honoured by the image-row 3x3 kernels' 16-channel instantiations only -- any other
+// dispatch is an error, never a silent plain conv
+int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st, const ConvL1* l1) {
   M2H_REQUIRE(a.src0 != nullptr && a.wp != nullptr && a.dst != nullptr, "conv_igemm: null pointer");
   M2H_REQUIRE(a.B > 0 && a.Hi > 0 && a.Wi > 0 && a.Hq > 0 && a.Wq > 0 && a.N > 0, "conv_igemm: non-positive size");
   M2H_REQUIRE(a.C0 > 0 && a.C0 % 4 == 0 && a.C1 >= 0 && a.C1 % 4 == 0, "conv_igemm: C0/C1 must be multiples of 4 (got %d, %d)", a.C0, a.C1);
@@ -1445,6 +1511,12 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
                 "conv_igemm: fused head needs N in {16,32}, de-sliced output, no split-K workspace, no class plane");
   }
   p.dst = a.dst; p.Ho = a.Ho; p.Wo = a.Wo; p.os = a.os; p.ph = a.ph; p.pw = a.pw; p.ldc = a.ldc; p.out_mode = a.out_mode;
+  p.l1_gt = nullptr; p.l1_part = nullptr; p.l1_inv = 0.f;
+  if (l1 != nullptr) {
+    M2H_REQUIRE(l1->gt && l1->partials && l1->loss && a.N == 16 && a.ldc == 16 && a.out_mode == M2H_OUT_NHWC && a.slope == 1.f && a.scale == nullptr,
+                "conv_igemm: the fused L1 loss needs N = 16 NHWC output without scale or activation");
+    p.l1_gt = l1->gt; p.l1_part = l1->partials; p.l1_inv = l1->inv;
+  }
   p.M = (int)M;
   {
     const size_t pix = (size_t)a.B * a.Hi * a.Wi;
@@ -1597,6 +1669,10 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
     else if (a.N <= 16) M2H_LAUNCH((conv3x3_row_kernel<16, 16>), grid, blk, 0, st, p);
     else if (a.C0 == 32) M2H_LAUNCH((conv3x3_row_kernel<32, 32>), grid, blk, 0, st, p);
     else M2H_LAUNCH((conv3x3_row_kernel<32, 16>), grid, blk, 0, st, p);
+    if (l1 != nullptr) {
+      M2H_LAUNCH(l1_partials_sum_kernel, dim3(1), dim3(256), 0, st, l1->partials, (int)grid.x, l1->inv, l1->loss);
+      return launch_status("conv_igemm_f32 (image-row 3x3 + L1 loss)");
+    }
     return launch_status("conv_igemm_f32 (image-row 3x3)");
   }
   // the same image-row shapes in bf16x3 math (update_sep with sep_update_math / the far-target leg): split operands in LDS, bf16 MFMAs
@@ -1611,8 +1687,14 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
     if (a.N <= 16) M2H_LAUNCH((conv3x3_row_bf16x3_kernel<16, 32>), grid, blk, 0, st, p);
     else if (a.C0 == 32) M2H_LAUNCH((conv3x3_row_bf16x3_kernel<32, 32>), grid, blk, 0, st, p);
     else M2H_LAUNCH((conv3x3_row_bf16x3_kernel<32, 16>), grid, blk, 0, st, p);
+    if (l1 != nullptr) {
+      M2H_LAUNCH(l1_partials_sum_kernel, dim3(1), dim3(256), 0, st, l1->partials, (int)grid.x, l1->inv, l1->loss);
+      return launch_status("conv_igemm_bf16x3 (image-row 3x3 + L1 loss)");
+    }
     return launch_status("conv_igemm_bf16x3 (image-row 3x3)");
   }
+  M2H_REQUIRE(l1 == nullptr, "conv_igemm: the fused L1 loss is built into the image-row 3x3 kernels only (3x3 / 1 / 1 over 32-channel, 32-pixel-wide images, "
+                            "N = 16, B x H / 4 >= 512)");
   // bf16x3 math, wide N, enough work for one 256 x 128 tile per CU: eight waves (4 x 2 wave tiles of 64 x 64) share one staged
   // pair of operand tiles.  The 128 x 128 kernel at two blocks per CU is bound by the chip's aggregate L2 -> LDS operand stream
   // (PMC: ~8.5 TB/s of L2 reads with the matrix pipe 36 % and the LDS 39 % busy; one block per CU is only 7 % slower than two);
@@ -1650,3 +1732,29 @@ int conv_igemm_f32(const m2h_conv_args& a, hipStream_t st) {
 }
 
 }  // namespace m2h
+
+using namespace m2h;
+
+extern "C" {
+
+// (1 iff the launch below would take an image-row 3x3 kernel for this shape: the rule of conv_igemm_f32's dispatch)
+int m2h_conv3x3_l1_nhwc16_supported(int B, int H, int T, int C) {
+  return (g_row3x3 >= 0 && B > 0 && H == 32 && T == 32 && C == 32 && (long)B * (H / 4) >= 512) ? 1 : 0;
+}
+
+int m2h_conv3x3_l1_nhwc16(const float* h, const float* wp, const float* gt_plane, float* dy, float* loss, float* partials, int B, int H, int T, int C,
+                          m2h_stream stream) {
+  M2H_REQUIRE(h && wp && gt_plane && dy && loss && partials, "conv3x3_l1_nhwc16: null pointer");
+  M2H_REQUIRE(m2h_conv3x3_l1_nhwc16_supported(B, H, T, C), "conv3x3_l1_nhwc16: needs 32-channel, 32 x 32-pixel images and B >= 64 (the image-row kernels' shapes); "
+              "use m2h_conv_igemm_f32 + m2h_l1_loss_nhwc16 otherwise");
+  m2h_conv_args a = {};
+  a.src0 = h; a.C0 = C; a.B = B; a.Hi = H; a.Wi = T; a.Hq = H; a.Wq = T;
+  a.stride = 1; a.nth = 3; a.ntw = 3; a.mulh = 1; a.offh = -1; a.mulw = 1; a.offw = -1;
+  a.wp = wp; a.N = 16; a.slope = 1.f;
+  a.dst = dy; a.Ho = H; a.Wo = T; a.os = 1; a.ldc = 16; a.out_mode = M2H_OUT_NHWC;
+  ConvL1 l1 = {gt_plane, partials, loss, 1.f / ((float)B * 16.f * (float)H * (float)T)};
+  return conv_igemm_f32(a, as_stream(stream), &l1);
+}
+
+}  // extern "C"
+

@@ -45,6 +45,20 @@ struct IGemmP {
   int th0, thn, tw0, twn, Kw;
   int S;       // split-K factor (grid y); S > 1: raw partial sums go to `ws`, the epilogue runs in splitk_epilogue_kernel
   float* ws;   // [phase][S][M][N] fp32 partial slabs (caller-owned workspace)
+  // fused L1 loss of the image-row 3x3 kernels (N == 16, NHWC; m2h_conv3x3_l1_nhwc16): l1_gt != nullptr -> the epilogue compares the conv's
+  // output with the target plane [B][16 * Ho][Wo] (band n of pixel row q = plane row n * Ho + q), adds |y - g| to the block's partial
+  // sum (l1_part[block]) and stores sign(y - g) * l1_inv -- d loss / d y -- in place of y
+  const float* l1_gt;
+  float* l1_part;
+  float l1_inv;
+};
+
+// the fused-loss arguments of an image-row launch (conv_igemm_f32's optional last parameter)
+struct ConvL1 {
+  const float* gt;
+  float* partials;   // >= 1024 floats
+  float* loss;       // 1 float: inv * sum of the partials, fixed order
+  float inv;         // 1 / number of elements
 };
 
 

@@ -668,8 +668,13 @@ class ConvL1NHWC16(torch.autograd.Function):
         if (Co, KH, KW) != (16, 3, 3) or h.shape[1] != 32:
             raise RuntimeError("m2h.conv_l1_nhwc16: a 3x3 conv to 16 bands over 32-row images expected")
         wp = memo.get(w, h.shape[3]) if memo is not None else ops.pack_conv_weight_ex(w.detach().contiguous(), Ci, h.shape[3])
-        y = ops.conv2d_nhwc(h, wp, Co, 3, 3, stride=1, pad=1, slope=1.0, name="acoustic_mem.conv1")
-        loss, dy = ops.l1_loss_nhwc16(y, gt_comps, off, want_grad=True)
+        if gt_comps.shape[-1] == 1 and off == 0 and ops.conv3x3_l1_supported(h) and not ops.timing_enabled():
+            # the target already is a plane of its own (update_sep hands it over so, ppo.py) and the shape is the image-row kernels':
+            # conv + loss + the loss's gradient in one launch, the conv's output never stored
+            loss, dy = ops.conv3x3_l1_nhwc16(h, wp, gt_comps)
+        else:
+            y = ops.conv2d_nhwc(h, wp, Co, 3, 3, stride=1, pad=1, slope=1.0, name="acoustic_mem.conv1")
+            loss, dy = ops.l1_loss_nhwc16(y, gt_comps, off, want_grad=True)
         ctx.save_for_backward(h, w, dy)
         ctx.memo = memo
         return loss

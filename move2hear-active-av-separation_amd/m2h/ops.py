@@ -958,6 +958,29 @@ def l1_loss_nhwc16(y, gt_comps, off=0, want_grad=True):
     return loss[0], dy
 
 
+def conv3x3_l1_supported(h):
+    """True when m2h_conv3x3_l1_nhwc16 takes h [B, H, T, C] (the image-row kernels' shapes: 32 x 32 x 32, B >= 64)."""
+    B, H, T, C = h.shape
+    return bool(_lib.load().m2h_conv3x3_l1_nhwc16_supported(B, H, T, C))
+
+
+def conv3x3_l1_nhwc16(h, wp, gt_plane):
+    """F.l1_loss(deslice(conv3x3(h, w)), gt) in one launch (m2h_conv3x3_l1_nhwc16): h NHWC [B, 32, 32, 32], wp packed [16, 288], gt_plane
+    [B, 512, 32, 1] contiguous -> (0-dim loss, d loss / d y in the conv's NHWC layout [B, 32, 32, 16]).  The conv's output is never stored."""
+    for t in (h, wp, gt_plane):
+        _chk(t, "conv3x3_l1_nhwc16")
+    B, H, T, C = h.shape
+    if tuple(gt_plane.shape) not in ((B, 16 * H, T, 1), (B, 16 * H, T)) or wp.numel() != 16 * 9 * C:
+        raise RuntimeError("m2h.conv3x3_l1_nhwc16: gt_plane %s must be [B, 16 H, T, 1] and wp [16, 9 C]" % (tuple(gt_plane.shape),))
+    dy = torch.empty((B, H, T, 16), device=h.device)
+    loss = torch.empty(1, device=h.device)
+    partials = torch.empty(1024, device=h.device)
+    with torch.cuda.device(h.device):
+        _lib.check(_lib.load().m2h_conv3x3_l1_nhwc16(_ptr(h), _ptr(wp), _ptr(gt_plane), _ptr(dy), _ptr(loss), _ptr(partials), B, H, T, C, _stream(h)),
+                   "m2h_conv3x3_l1_nhwc16")
+    return loss[0], dy
+
+
 def sep_slice_input_plane(mix, cls_val, ldo=36):
     """binSep stage-0 training input: slice + (target_class+1) plane as channel 32, zero padded to ldo channels."""
     _chk(mix, "sep_slice_input_plane")

@@ -399,8 +399,9 @@ class PPO(nn.Module):
                     if sliced is None:
                         with torch.no_grad():
                             sliced = self.actor_critic.acoustic_mem.slice_inputs(pred_mono, prev_mem_batch, masks_batch)
+                            gt_plane = gt_mono[..., 0:1].contiguous()   # (as the graphed epoch: the loss kernel reads the target as a plane)
                     # the memory's output is only this loss's operand here: it stays in its conv's layout (no de-slice / re-slice round trips)
-                    monoFromMem_loss = self.actor_critic.monoFromMem_l1_masked(pred_mono, prev_mem_batch, masks_batch, gt_mono, 0, sliced=sliced)
+                    monoFromMem_loss = self.actor_critic.monoFromMem_l1_masked(pred_mono, prev_mem_batch, masks_batch, gt_plane, 0, sliced=sliced)
                 else:
                     pred_monoFromMem = self.actor_critic.get_monoFromMem_masked(pred_mono, prev_mem_batch, masks_batch)
                     monoFromMem_loss = MF.l1_loss(pred_monoFromMem, gt_mono, 0)      # gt_mono_comps[..., 0::2][..., :1]

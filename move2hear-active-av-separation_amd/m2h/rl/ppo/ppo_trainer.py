@@ -517,10 +517,12 @@ class PPOTrainer:
         return ddppo_utils.all_reduce_stats(t)
 
     def save_checkpoint(self, file_name):
-        ckpt = {"state_dict": {"actor_critic." + k: v for k, v in self.actor_critic.state_dict().items()}, "config": vars(self.config)}
-        sampler = self.actor_critic.sampler_state()   # build-side key beside the reference's two: the fused sampler's [seed, counter], so a run that
-        if sampler is not None:                       # continues from this file draws on from here instead of replaying the first steps' noise
-            ckpt["m2h_sampler_state"] = sampler
+        ckpt = {"state_dict": {"actor_critic." + k: v for k, v in self.actor_critic.state_dict().items()}, "config": dict(vars(self.config))}
+        # the file keeps the reference's two keys (:223-238); the fused sampler's [seed, counter] rides in the config (a build-side key like
+        # action_sampling itself), so a run that continues from this file draws on from here instead of replaying the first steps' noise
+        sampler = self.actor_critic.sampler_state()
+        if sampler is not None:
+            ckpt["config"]["m2h_sampler_state"] = sampler
         os.makedirs(self.config.CHECKPOINT_FOLDER, exist_ok=True)
         torch.save(ckpt, os.path.join(self.config.CHECKPOINT_FOLDER, file_name))
 
@@ -532,7 +534,7 @@ class PPOTrainer:
 
     def load_state_dict(self, state_dict, strict=True, sampler_state=None):
         """Loads agent weights saved by this trainer or by the reference (keys rooted at "actor_critic.").
-        sampler_state: a checkpoint's "m2h_sampler_state" ([seed, counter] of the fused action sampler), restored in place."""
+        sampler_state: a checkpoint's config["m2h_sampler_state"] ([seed, counter] of the fused action sampler), restored in place."""
         sd = {k[len("actor_critic."):]: v for k, v in state_dict.items() if k.startswith("actor_critic.")}
         if not sd:
             raise RuntimeError("checkpoint state_dict has no 'actor_critic.*' keys")

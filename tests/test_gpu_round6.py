@@ -1,0 +1,69 @@
+"""GPU: round-6 kernels.  The fused conv + L1-loss launch of update_sep (m2h_conv3x3_l1_nhwc16: AcousticMem's last conv, its de-slice and
+F.l1_loss against gt_mono_comps[..., 0], rl/models/memory_nets.py:16,62-67 with rl/ppo/ppo.py:206-216) against the CPU oracle's layer and
+against the two launches it replaces, in both arithmetic modes; the update itself (losses, gradients, weights after the step) stays pinned by
+tests/test_gpu_rl.py / test_gpu_trainer_golden.py through the same code path."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import m2h_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_fused_conv_l1_matches_the_oracle_and_the_two_launches_it_replaces(mode):
+    from m2h import functional as MF
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    B = 72                                                  # (>= 64 samples: the image-row kernels' shapes)
+    h = torch.randn(B, 32, 32, 32, generator=g).relu()      # NHWC: the first conv's activated output
+    w = torch.randn(16, 32, 3, 3, generator=g) * 0.06
+    gt_comps = torch.rand(B, 512, 32, 4, generator=g) * 2
+    # oracle: conv2d -> de-slice [B, 16, 32, 32] -> [B, 512, 32, 1] (band n, row q -> n * 32 + q) -> mean |.|
+    y_ref = F.conv2d(h.permute(0, 3, 1, 2), w, None, 1, 1)                    # [B, 16, 32, 32]
+    pred = y_ref.reshape(B, 512, 32, 1)
+    want = F.l1_loss(pred, gt_comps[..., 0:1])
+    hd, wd, gd = h.to(dev), w.to(dev), gt_comps.to(dev)
+    plane = gd[..., 0:1].contiguous()
+    ops.set_math_mode(ops.MATH_BF16X3 if mode == "bf16x3" else ops.MATH_FP32)
+    try:
+        wp = ops.pack_conv_weight_ex(wd, 32, 32)
+        assert ops.conv3x3_l1_supported(hd) and not ops.conv3x3_l1_supported(hd[:8])
+        loss, dy = ops.conv3x3_l1_nhwc16(hd, wp, plane)
+        assert "L1 loss" in ops.last_kernel(), ops.last_kernel()
+        y = ops.conv2d_nhwc(hd, wp, 16, 3, 3, stride=1, pad=1, slope=1.0)
+        loss2, dy2 = ops.l1_loss_nhwc16(y, gd, 0, want_grad=True)
+        loss3, dy3 = ops.l1_loss_nhwc16(y, plane, 0, want_grad=True)
+        # through the autograd function update_sep uses: a plane takes the fused launch, interleaved components the two launches
+        hw = hd.clone().requires_grad_(False)
+        wq = wd.clone().requires_grad_(True)
+        lf = MF.conv_l1_nhwc16(hw, wq, plane, 0)
+        lf.backward()
+        gw_fused = wq.grad.clone()
+        wq.grad = None
+        lt = MF.conv_l1_nhwc16(hw, wq, gd, 0)
+        lt.backward()
+        gw_two = wq.grad.clone()
+    finally:
+        ops.set_math_mode(ops.MATH_FP32)
+    tol = 2e-5 if mode == "bf16x3" else 2e-6
+    assert abs(float(loss) - float(want)) <= tol * float(want), (float(loss), float(want))
+    assert abs(float(loss) - float(loss2)) <= 2e-6 * float(loss2) and float(loss2) == float(loss3)
+    # the gradient is sign(y - g) / n: identical wherever |y - g| is not within rounding of zero
+    inv = 1.0 / (B * 512 * 32)
+    assert torch.equal(dy2, dy3)
+    same = (dy == dy2).float().mean().item()
+    assert same == 1.0, same                                 # same conv values (same kernel, same accumulation), same comparison
+    assert set(np.unique(dy.cpu().numpy()).tolist()) <= {np.float32(-inv).item(), 0.0, np.float32(inv).item()}
+    d_ref = torch.sign(pred - gt_comps[..., 0:1]).reshape(B, 16, 32, 32).permute(0, 2, 3, 1) * inv      # NHWC
+    assert (dy.cpu() != d_ref.float()).float().mean().item() < (2e-3 if mode == "bf16x3" else 2e-4)     # (sign flips only where y ~ g)
+    assert abs(float(lf) - float(loss)) == 0.0 and abs(float(lt) - float(loss2)) == 0.0
+    assert O.rel_l1(gw_fused.cpu(), gw_two.cpu()) < 1e-6

@@ -170,8 +170,14 @@ def test_checkpoint_round_trip_and_eval(tmp_path):
     assert set(ck) == {"state_dict", "config"} and all(k.startswith("actor_critic.") for k in ck["state_dict"])
     assert "actor_critic.pol_net.state_encoder.rnn.weight_hh_l0" in ck["state_dict"]
     trained = {k: v.detach().cpu().clone() for k, v in tr.actor_critic.state_dict().items()}
+    # the fused action sampler's [seed, counter] rides in the config: a run continued from the file draws on, it does not replay the first steps' noise
+    seed_ctr = ck["config"]["m2h_sampler_state"]
+    assert seed_ctr == tr.actor_critic.sampler_state() and seed_ctr[1] == 2 * 4 * 3 * 3
     tr2, _ = _trainer(CHECKPOINT_FOLDER=str(tmp_path))
-    tr2.load_state_dict(ck["state_dict"])
+    assert tr2.actor_critic.sampler_state()[1] == 0
+    state_ptr = tr2.actor_critic._rng_state.data_ptr()
+    tr2.load_state_dict(ck["state_dict"], sampler_state=seed_ctr)
+    assert tr2.actor_critic.sampler_state() == seed_ctr and tr2.actor_critic._rng_state.data_ptr() == state_ptr   # (in place: graphs hold the address)
     for k, v in tr2.actor_critic.state_dict().items():
         assert torch.equal(v.cpu(), trained[k]), k
     stats = tr2.eval(num_episodes=3, waveform_metrics=("si_sdr", "si_sdri"), deterministic=True)
