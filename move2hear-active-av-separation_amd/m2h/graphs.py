@@ -30,7 +30,19 @@ class capture:
         return self.ctx.__enter__()
 
     def __exit__(self, *exc):
-        out = self.ctx.__exit__(*exc)
+        import warnings
+        # torch only WARNS when a capture recorded nothing ("The CUDA Graph is empty"): for a body that ran to its end that is how a mis-captured
+        # graph first shows (work enqueued on another stream than the capturing one), so here it is an error.  A body that raised leaves an empty
+        # graph by design (the exception is what the caller gets): that warning is dropped.
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            out = self.ctx.__exit__(*exc)
+        empty = [w for w in caught if "Graph is empty" in str(w.message)]
+        for w in caught:
+            if w not in empty:
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        if empty and exc[0] is None:
+            raise RuntimeError("m2h.graphs.capture: the capture recorded no work on the capturing stream (launches went to another stream, or nothing was launched)")
         n = _lib.load().m2h_launch_count() - self.n0
         self.graph._m2h_kernels = n
         _counts["captured"] += n
