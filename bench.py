@@ -280,7 +280,7 @@ def ddppo_phase_rooflines(phase_ms, phase_launches, env_steps_per_cycle, sep_bf1
 
 
 def update_sep_kernel_rooflines(dev, samples, bf16x3):
-    """Each of the five conv / loss kernels of one update_sep epoch (AcousticMem forward + loss + backward over the stored samples,
+    """Each of the conv / loss launches of one update_sep epoch (four in bf16x3 arithmetic, five in fp32) (AcousticMem forward + loss + backward over the stored samples,
     ppo.py:179-246; m2h/rl/models/memory_nets.py) launched alone on tensors of the epoch's shapes, HIP events around 5 launches in THIS run,
     bounded by what binds it: algorithmic bytes / time against the 6.3 TB/s a copy achieves, and algorithmic FLOP / time against the
     arithmetic's matrix ceiling (2500 / 3 TFLOP/s in bf16x3, 157.3 in fp32).  The phase's single MFMA fraction said nothing actionable:
@@ -303,10 +303,14 @@ def update_sep_kernel_rooflines(dev, samples, bf16x3):
         ("forward conv 32->16 + L1 loss + its gradient (one launch: the conv's output is never stored)", lambda: ops.conv3x3_l1_nhwc16(h1, wp1, gt_plane),
          4.0 * px * (32 + 16 + 16), 2.0 * px * 16 * 288),
         ("weight gradient of conv 32->16", lambda: MF.conv_wgrad(h1, None, dy, 16, 3, 3, 1, 1, torch_ci=32), 4.0 * px * (32 + 16), 2.0 * px * 16 * 288),
-        ("input gradient of conv 32->16", lambda: MF.conv_dgrad(dy, w1, (32, 32), 1, 1, wp=wpd1), 4.0 * px * (16 + 32), 2.0 * px * 32 * 144),
-        ("weight gradient of conv 32->32 (ReLU gate fused)", lambda: MF.conv_wgrad(x, None, dh, 32, 3, 3, 1, 1, gate=h1, gate_slope=0.0, torch_ci=32),
-         4.0 * px * (32 + 32 + 32), 2.0 * px * 32 * 288),
     ]
+    if bf16x3:   # conv0's weight gradient makes conv1's input gradient and the ReLU gate itself (m2h_conv_wgrad_dgrad_fused_f32): x + h (gate) + d loss / d y
+        cases.append(("weight gradient of conv 32->32 with conv 32->16's input gradient + ReLU gate fused (the 32-channel gradient is never stored)",
+                      lambda: MF.conv_wgrad_dgrad_fused(x, dy, wp1, h1, 0.0, 32), 4.0 * px * (32 + 32 + 16), 2.0 * px * 32 * 288 + 2.0 * px * 32 * 144))
+    else:
+        cases += [("input gradient of conv 32->16", lambda: MF.conv_dgrad(dy, w1, (32, 32), 1, 1, wp=wpd1), 4.0 * px * (16 + 32), 2.0 * px * 32 * 144),
+                  ("weight gradient of conv 32->32 (ReLU gate fused)", lambda: MF.conv_wgrad(x, None, dh, 32, 3, 3, 1, 1, gate=h1, gate_slope=0.0, torch_ci=32),
+                   4.0 * px * (32 + 32 + 32), 2.0 * px * 32 * 288)]
     peak_tf = PEAK_BF16X3_TFLOPS if bf16x3 else PEAK_F32_MFMA_TFLOPS
     out = {}
     with ops.math_scope(ops.MATH_BF16X3 if bf16x3 else ops.MATH_FP32), torch.no_grad():

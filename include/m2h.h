@@ -448,6 +448,15 @@ int m2h_conv_wgrad_gated_f32(const m2h_conv_args* args /* host */, const float* 
  * (one launch less per conv layer of every backward pass; same bits).  y: optional gate as in m2h_conv_wgrad_gated_f32 (NULL: none). */
 int m2h_conv_wgrad_torch_f32(const m2h_conv_args* args /* host */, const float* dy, int ldy, const float* y, float slope, float* dw, int Ci,
                              m2h_stream stream);
+/* m2h_conv_wgrad_torch_f32 of AcousticMem's FIRST conv with the input gradient of its SECOND conv fused in (update_sep's backward,
+ * rl/ppo/ppo.py:226 through rl/models/memory_nets.py:11-16): the gradient the weight gradient contracts with, d loss / d h (h = ReLU(conv0(x)) = y),
+ * is conv1's input gradient -- a 3x3 convolution of dy2 = d loss / d conv1-output, NHWC [B][H][W][16], with conv1's packed weight
+ * w2_packed [16][9 * 32] -- and is made row by row inside the image-row kernel instead of being written by one launch (220 MB at 1680 samples)
+ * and read back by the next.  y / slope: the ReLU gate as in m2h_conv_wgrad_gated_f32 (required).  bf16x3 arithmetic of the calling thread, args =
+ * the first conv's geometry (3x3 / 1 / 1, 32 -> 32 channels, 32-pixel rows): m2h_conv_wgrad_dgrad_fused_supported(args) tells. */
+int m2h_conv_wgrad_dgrad_fused_supported(const m2h_conv_args* args /* host */);
+int m2h_conv_wgrad_dgrad_fused_f32(const m2h_conv_args* args /* host */, const float* dy2, const float* w2_packed, const float* y, float slope, float* dw,
+                                   int Ci, m2h_stream stream);
 
 /* Input gradient = forward engine on re-laid-out weights: for a Conv2d(k, stride s, pad p) weight w [Co][Ci][KH][KW]
  * (KH, KW multiples of s) writes s*s phase matrices wp[ph*s+pw][ci][th][tw][co] = w[co][ci][(ph+p)%s + s*th][(pw+p)%s + s*tw].

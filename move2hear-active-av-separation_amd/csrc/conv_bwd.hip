@@ -46,6 +46,10 @@ struct WGradP {
   const float* gate;  // optional (image-row 3x3 kernel): the forward output y of the layer, same layout as dy: dy is read as
   float gate_slope;   // dy * (y > 0 ? 1 : gate_slope) -- the backward of the layer's fused ReLU / LeakyReLU without a pass of its own
   int torch_ci;       // > 0: dw is nn.Conv2d's own layout [N][torch_ci][KH][KW] (channels torch_ci .. Ctot-1 of the packed k axis are input padding: dropped)
+  // fused input gradient (wgrad3x3_row_dgrad_bf16x3_kernel): dy2 != nullptr -> `dy` is not read; the layer's output gradient is made in the
+  // kernel, row by row, as the input gradient of the NEXT 3x3 conv: dy[r][px][c] = sum_{tap, n} dy2[r + 1 - ty][px + 1 - tx][n] w2p[n][tap][c]
+  const float* dy2;   // [rows][32][16] NHWC gradient of the next conv's output
+  const float* w2p;   // the next conv's packed weight [16][9 * 32] (m2h_pack_conv_weight_ex)
 };
 
 // phase (ph, pw) of a quad launch: taps step by 2 ph - 1 / 2 pw - 1 (separator_cnn.py:15-24 as four sub-pixel GEMMs)
@@ -567,6 +571,232 @@ __global__ __launch_bounds__(256, 3) void wgrad3x3_row_bf16x3_kernel(const WGrad
   }
 }
 
+// The bf16x3 image-row weight gradient with the INPUT GRADIENT OF THE NEXT CONV fused in (update_sep's backward through AcousticMem,
+// memory_nets.py:11-16: conv 32 -> 32, ReLU, conv 32 -> 16): the gradient this layer's weight gradient contracts with -- d loss / d h,
+// h = ReLU(conv0(x)) -- is itself conv1's input gradient, a 3x3 convolution of d loss / d y (16 channels) with conv1's weights.  As two
+// launches that tensor (220 MB at 1680 samples) is written by the one and read back, with the ReLU gate's 220 MB, by the other; here a
+// block makes each image row of it on the matrix pipe from a ring of three staged rows of d loss / d y (110 MB in all) and conv1's
+// weights held in registers as A fragments, gates it with h and writes it -- transposed and split, as the weight-gradient MFMAs want
+// their pixel-contracted operand -- straight into the LDS stage the plain kernel fills from memory.  Per row: 15 more MFMAs per wave,
+// no second barrier (five-slot rings: row c + 3 is staged while rows c - 1 .. c + 2 are read).
+// D[c][px] = sum_k A[c][k] B[k][px], k = (tap, n): lane (row c = lane & 15, k-quarter kq) of k-step s holds tap 2 s + (kq >> 1),
+// channels 8 (kq & 1) .. + 7 of d loss / d y at pixel (r + 1 - ty, px + 1 - tx) -- one 16-byte read of the ring ([hi 16 | lo 16] bf16 per pixel).
+constexpr int WRD_PS = 80;                          // d loss / d y ring: pixel stride, bytes ([hi 32 | lo 32 | 16]: 5 x 16, odd)
+constexpr int WRD_RS = 34 * WRD_PS;                 // ring row: 32 pixels + a zero pixel on either side
+__global__ __launch_bounds__(256, 3) void wgrad3x3_row_dgrad_bf16x3_kernel(const WGradP p) {
+  constexpr int W = 32, C = 32, FR = 32;
+  __shared__ __attribute__((aligned(16))) char XT[5][C * WRB_RS];      // x rows, transposed + split (slot = row % 5)
+  __shared__ __attribute__((aligned(16))) char YT[2][FR * WRB_RS];     // rows of the fused gradient (slot = row & 1)
+  __shared__ __attribute__((aligned(16))) char DY[5][WRD_RS];          // d loss / d y rows, pixel-major + split (slot = row % 5)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x;
+  const int c0 = (int)(((long)p.chunks * split) / p.S), c1 = (int)(((long)p.chunks * (split + 1)) / p.S);
+  const int rows_total = p.B * p.Hq;
+  const int fi = lane & 15, kq = lane >> 4;
+  const int nh = wave >> 1, ch = wave & 1;           // weight-gradient role: (output-channel half, x-channel half)
+  const int dch = wave & 1, dpx = wave >> 1;         // input-gradient role: tile (channel half, pixel half) of the 32 x 32 row
+  auto slot5 = [](int r) { return (r + 5) % 5; };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // staging roles: x -- thread (pixel tid / 8, quad tid % 8); d loss / d y -- threads 0..127 (pixel tid / 4, quad tid % 4)
+  const int spx = tid >> 3, sq = tid & 7;
+  const int ypx = tid >> 2, yq = tid & 3;
+  f32x4 rx, rd, rg, rg_next;
+  bool okx = false, okd = false;
+  auto load_x = [&](int r) {
+    okx = r >= 0 && r < rows_total;
+    rx = *reinterpret_cast<const f32x4*>(p.src0 + (okx ? ((size_t)r * W + spx) * C + sq * 4 : (size_t)0));
+  };
+  auto load_d = [&](int r) {
+    okd = tid < 128 && r >= 0 && r < rows_total;
+    rd = *reinterpret_cast<const f32x4*>(p.dy2 + (okd ? ((size_t)r * W + ypx) * 16 + yq * 4 : (size_t)0));
+  };
+  auto load_g = [&](int r) {                         // the gate (this layer's forward output) at this lane's four accumulator elements of row r
+    const bool ok = r >= 0 && r < rows_total;
+    return *reinterpret_cast<const f32x4*>(p.gate + (ok ? ((size_t)r * W + dpx * 16 + fi) * C + dch * 16 + kq * 4 : (size_t)0));
+  };
+  auto split4 = [&](f32x4 v, bf16x4& hi, bf16x4& lo) {
+    hi = __builtin_convertvector(v, bf16x4);
+    const f32x4 hf = __builtin_convertvector(hi, f32x4);
+    lo = __builtin_convertvector(v - hf, bf16x4);
+  };
+  auto store_x = [&](int r) {                        // rows 4 sq .. 4 sq + 3 of the transposed stage, column spx
+    if (!okx) return;
+    bf16x4 hi, lo;
+    split4(rx, hi, lo);
+    char* base = XT[slot5(r)];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      char* d = base + (sq * 4 + e) * WRB_RS + spx * 2;
+      *reinterpret_cast<__bf16*>(d) = hi[e];
+      *reinterpret_cast<__bf16*>(d + 64) = lo[e];
+    }
+  };
+  auto store_d = [&](int r) {                        // pixel ypx + 1 of the ring row, channels 4 yq .. + 3
+    if (!okd) return;
+    bf16x4 hi, lo;
+    split4(rd, hi, lo);
+    char* d = DY[slot5(r)] + (ypx + 1) * WRD_PS + yq * 8;
+    *reinterpret_cast<bf16x4*>(d) = hi;
+    *reinterpret_cast<bf16x4*>(d + 32) = lo;
+  };
+  auto mma = [&](const f32x4& a, const f32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  };
+
+  // conv1's weights as the A fragments of the input gradient, once per block: row c = dch * 16 + fi, k-step s, this lane's eight k
+  f32x4 wa[5][2];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int tap = 2 * s + (kq >> 1), n0 = (kq & 1) * 8;
+    f32x4 v0 = zero4, v1 = zero4;
+    if (tap < 9) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v0[j] = p.w2p[(size_t)(n0 + j) * (9 * C) + tap * C + dch * 16 + fi];
+        v1[j] = p.w2p[(size_t)(n0 + 4 + j) * (9 * C) + tap * C + dch * 16 + fi];
+      }
+    }
+    bf16x4 h0, l0, h1, l1;
+    split4(v0, h0, l0);
+    split4(v1, h1, l1);
+    bf16x8 hh, ll;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hh[j] = h0[j]; hh[4 + j] = h1[j];
+      ll[j] = l0[j]; ll[4 + j] = l1[j];
+    }
+    wa[s][0] = __builtin_bit_cast(f32x4, hh);
+    wa[s][1] = __builtin_bit_cast(f32x4, ll);
+  }
+  // the ring rows' zero pixels (columns -1 and 32): never written again
+  for (int i = tid; i < 5 * 2 * (WRD_PS / 16); i += 256) {
+    const int sl = i / (2 * (WRD_PS / 16)), rem = i - sl * 2 * (WRD_PS / 16);
+    const int side = rem / (WRD_PS / 16), q16 = rem - side * (WRD_PS / 16);
+    *reinterpret_cast<f32x4*>(DY[sl] + (side ? 33 : 0) * WRD_PS + q16 * 16) = zero4;
+  }
+
+  // image row r of the fused gradient -> YT[r & 1] (gate values of the row in g)
+  auto dgrad_row = [&](int r, const f32x4& g) {
+    const int q = r % p.Hq;
+    f32x4 acc = zero4, acc_b = zero4;                 // two accumulation chains (even / odd k-steps): half the dependent MFMA latency per row
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const int tap = 2 * s + (kq >> 1);
+      const int ty = tap / 3, tx = tap - 3 * ty;
+      const int qq = q + 1 - ty;
+      const bool ok = tap < 9 && (unsigned)qq < (unsigned)p.Hq;
+      const char* bp = DY[slot5(ok ? r + 1 - ty : r)] + (dpx * 16 + fi + 2 - tx) * WRD_PS + (kq & 1) * 16;
+      f32x4 bh = *reinterpret_cast<const f32x4*>(bp), bl = *reinterpret_cast<const f32x4*>(bp + 32);
+      bh = ok ? bh : zero4;
+      bl = ok ? bl : zero4;
+      f32x4& a_ = (s & 1) ? acc_b : acc;
+      mma(wa[s][1], bh, a_);
+      mma(wa[s][0], bl, a_);
+      mma(wa[s][0], bh, a_);
+    }
+    acc += acc_b;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = g[e] > 0.f ? acc[e] : acc[e] * p.gate_slope;
+    bf16x4 hi, lo;
+    split4(v, hi, lo);
+    char* yb = YT[r & 1] + (dch * 16 + kq * 4) * WRB_RS + (dpx * 16 + fi) * 2;   // rows = channels (kq * 4 + e), column = pixel
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      *reinterpret_cast<__bf16*>(yb + e * WRB_RS) = hi[e];
+      *reinterpret_cast<__bf16*>(yb + e * WRB_RS + 64) = lo[e];
+    }
+  };
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = zero4;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  auto compute = [&](int c) {                        // the weight gradient's row step: wgrad3x3_row_bf16x3_kernel<32>::compute
+    const int q = c % p.Hq;
+    f32x4 ya[3][2];
+    const char* yb = YT[c & 1] + (nh * 16 + fi) * WRB_RS + kq * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const char* yp = yb + h * 64;
+      const u32x4 d = *reinterpret_cast<const u32x4*>(yp);
+      const unsigned before = kq > 0 ? *reinterpret_cast<const unsigned*>(yp - 4) : 0u;
+      const unsigned after = kq < 3 ? *reinterpret_cast<const unsigned*>(yp + 16) : 0u;
+      u32x4 l, r;
+      l[0] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
+      l[1] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+      l[2] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
+      l[3] = __builtin_amdgcn_alignbit(after, d[3], 16);
+      r[0] = __builtin_amdgcn_alignbit(d[0], before, 16);
+      r[1] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
+      r[2] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+      r[3] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
+      ya[0][h] = __builtin_bit_cast(f32x4, l);
+      ya[1][h] = __builtin_bit_cast(f32x4, d);
+      ya[2][h] = __builtin_bit_cast(f32x4, r);
+    }
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      const int ih = q + ty - 1;
+      if ((unsigned)ih >= (unsigned)p.Hq) continue;
+      const char* xb = XT[slot5(c + ty - 1)] + (ch * 16 + fi) * WRB_RS + kq * 16;
+      const f32x4 bh = *reinterpret_cast<const f32x4*>(xb), bl = *reinterpret_cast<const f32x4*>(xb + 64);
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        const int t = ty * 3 + tx;
+        mma(ya[tx][1], bh, acc[t]);
+        mma(ya[tx][0], bl, acc[t]);
+        mma(ya[tx][0], bh, acc[t]);
+      }
+    }
+  };
+
+  if (c0 < c1) {
+    // prologue: rows c0 - 1 .. c0 + 2 of x and of d loss / d y staged, the fused gradient's row c0 made; row c0 + 3 in registers
+#pragma unroll 1
+    for (int r = c0 - 1; r <= c0 + 2; ++r) {
+      load_x(r);
+      store_x(r);
+      load_d(r);
+      store_d(r);
+    }
+    rg = load_g(c0);
+    __syncthreads();
+    dgrad_row(c0, rg);
+    rg = load_g(c0 + 1);
+    load_x(c0 + 3);
+    load_d(c0 + 3);
+    __syncthreads();
+#pragma unroll 1
+    for (int c = c0; c < c1; ++c) {
+      // slots of row c + 3 held row c - 2: last read in step c - 1 (x: its weight-gradient step read rows c - 2 .. c; d loss / d y: the
+      // gradient row c was made from rows c - 1 .. c + 1 in step c - 1), before that step's barrier
+      store_x(c + 3);
+      store_d(c + 3);
+      if (c + 1 < c1) {
+        rg_next = load_g(c + 2);
+        load_x(c + 4);
+        load_d(c + 4);
+        dgrad_row(c + 1, rg);      // reads ring rows c .. c + 2 (staged in earlier steps) -> YT[(c + 1) & 1], read after this step's barrier
+        rg = rg_next;
+      }
+      compute(c);                  // reads YT[c & 1] (made in the previous step) and x rows c - 1 .. c + 1
+      __syncthreads();
+    }
+  }
+
+  float* slab = p.ws + (size_t)split * p.N * p.Kpad;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = nh * 16 + kq * 4 + e;
+      if (n < p.N) slab[(size_t)n * p.Kpad + t * C + ch * 16 + fi] = acc[t][e];
+    }
+  }
+}
+
 // Sum of one slab element over the splits [z0, z1): eight running sums (eight loads in flight per lane), combined pairwise -- the ONE
 // order of every many-split reduce below (wgrad_reduce_kernel and the fused re-layout kernels give the same bits).
 __device__ __forceinline__ float wgrad_quarter_sum(const float* __restrict__ src, int z0, int z1, size_t zs) {
@@ -738,10 +968,13 @@ size_t conv_wgrad_workspace_bytes(const m2h_conv_args& a) {
 
 // quad: the four phases of a ConvTranspose2d(4,2,1) in one launch (a = the geometry of one phase: taps 2x2, stride 1, os 2,
 // Ho = 2 Hi; its ph / pw / mulh / mulw are ignored), dw in the torch layout, workspace four times the single-phase size
+// dy2 / w2p: the fused input gradient (m2h_conv_wgrad_dgrad_fused_f32): `dy` is then made inside the image-row kernel from the NEXT conv's
+// output gradient dy2 [B][H][W][16] and packed weight w2p [16][9 * 32] (bf16x3 arithmetic, N = C0 = 32, gate required) and may be NULL
 int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, hipStream_t st, bool quad = false, const float* gate = nullptr,
-                   float gate_slope = 1.f, int torch_ci = 0) {
+                   float gate_slope = 1.f, int torch_ci = 0, const float* dy2 = nullptr, const float* w2p = nullptr) {
   M2H_REQUIRE(torch_ci >= 0 && torch_ci <= a.C0 + a.C1 && (!quad || torch_ci == 0), "conv_wgrad: torch_ci (%d) must lie in 1 .. C0 + C1", torch_ci);
-  M2H_REQUIRE(a.src0 != nullptr && dy != nullptr && dw != nullptr, "conv_wgrad: null pointer");
+  M2H_REQUIRE(a.src0 != nullptr && (dy != nullptr || dy2 != nullptr) && dw != nullptr, "conv_wgrad: null pointer");
+  M2H_REQUIRE((dy2 == nullptr) == (w2p == nullptr), "conv_wgrad: fused input gradient needs both dy2 and w2p");
   M2H_REQUIRE(a.conv_transpose == 0, "conv_wgrad: describe a transposed conv by its phase geometry (m2h_convT_wgrad_f32)");
   M2H_REQUIRE(!quad || (a.nth == 2 && a.ntw == 2 && a.stride == 1 && a.os == 2 && a.offh == 0 && a.offw == 0 && a.Hq == a.Hi && a.Wq == a.Wi &&
                         a.Ho == 2 * a.Hi && a.Wo == 2 * a.Wi),
@@ -749,7 +982,7 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   M2H_REQUIRE(a.C0 > 0 && a.C0 % 4 == 0 && a.C1 >= 0 && a.C1 % 4 == 0, "conv_wgrad: C0/C1 must be multiples of 4");
   M2H_REQUIRE((a.C1 == 0) == (a.src1 == nullptr), "conv_wgrad: src1/C1 mismatch");
   M2H_REQUIRE(a.B > 0 && a.Hi > 0 && a.Wi > 0 && a.Hq > 0 && a.Wq > 0 && a.N > 0 && a.nth > 0 && a.ntw > 0 && a.stride > 0, "conv_wgrad: bad sizes");
-  M2H_REQUIRE(ldy >= a.N, "conv_wgrad: ldy (%d) < N (%d)", ldy, a.N);
+  M2H_REQUIRE(ldy >= a.N || dy2 != nullptr, "conv_wgrad: ldy (%d) < N (%d)", ldy, a.N);
   const long M = (long)a.B * a.Hq * a.Wq;
   M2H_REQUIRE(M < (1L << 30) && (long)a.B * a.Hi * a.Wi < (1L << 30), "conv_wgrad: too many pixels");
   WGradP p;
@@ -770,6 +1003,7 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
   p.dwp = quad ? p.ws + slab_floats : nullptr;
   p.dw = dw;
   p.gate = gate; p.gate_slope = gate_slope; p.torch_ci = torch_ci;
+  p.dy2 = dy2; p.w2p = w2p;
   int bng, kt;
   wgrad_cfg(a.N, p.K, bng, kt, p.ktiles, M);
   p.ntiles = (a.N + bng - 1) / bng;
@@ -781,10 +1015,14 @@ int conv_wgrad_f32(const m2h_conv_args& a, const float* dy, int ldy, float* dw, 
                       a.offw == -1 && a.C0 == 32 && a.C1 == 0 && a.Wq == 32 && a.Wi == 32 && a.Hq == a.Hi && p.direct && a.N <= 32 &&
                       a.N % 4 == 0 && ldy % 4 == 0 && p.ntiles * p.ktiles == 1;
   M2H_REQUIRE(gate == nullptr || row3x3, "conv_wgrad: the activation gate is built into the image-row 3x3 kernel only (3x3 / stride 1 / pad 1, 32 channels, 32-pixel rows)");
+  M2H_REQUIRE(dy2 == nullptr || (row3x3 && tl_math_mode == 1 && a.N == 32 && gate != nullptr),
+              "conv_wgrad: the fused input gradient is built into the bf16x3 image-row 3x3 kernel only (N = 32, with the activation gate)");
   if (row3x3) {
     p.chunks = a.B * a.Hq;   // image rows
     if (p.S > p.chunks) p.S = p.chunks;
-    if (tl_math_mode == 1) {           // the calling thread computes in bf16x3 (update_sep with sep_update_math, the far-target leg)
+    if (dy2 != nullptr) {
+      M2H_LAUNCH(wgrad3x3_row_dgrad_bf16x3_kernel, dim3((unsigned)p.S), blk, 0, st, p);
+    } else if (tl_math_mode == 1) {           // the calling thread computes in bf16x3 (update_sep with sep_update_math, the far-target leg)
       if (a.N <= 16) M2H_LAUNCH((wgrad3x3_row_bf16x3_kernel<16>), dim3((unsigned)p.S), blk, 0, st, p);
       else M2H_LAUNCH((wgrad3x3_row_bf16x3_kernel<32>), dim3((unsigned)p.S), blk, 0, st, p);
     } else if (a.N <= 16) M2H_LAUNCH((wgrad3x3_row_kernel<16>), dim3((unsigned)p.S), blk, 0, st, p);
@@ -1011,6 +1249,22 @@ int m2h_conv_wgrad_f32(const m2h_conv_args* args, const float* dy, int ldy, floa
 int m2h_conv_wgrad_gated_f32(const m2h_conv_args* args, const float* dy, int ldy, const float* y, float slope, float* dw, m2h_stream stream) {
   M2H_REQUIRE(args != nullptr && y != nullptr, "conv_wgrad_gated: null pointer");
   return conv_wgrad_f32(*args, dy, ldy, dw, as_stream(stream), false, y, slope);
+}
+
+int m2h_conv_wgrad_dgrad_fused_supported(const m2h_conv_args* args) {
+  if (args == nullptr) return 0;
+  const m2h_conv_args& a = *args;
+  int bng, kt, ktiles;
+  wgrad_cfg(a.N, a.nth * a.ntw * (a.C0 + a.C1), bng, kt, ktiles, (long)a.B * a.Hq * a.Wq);
+  return (tl_math_mode == 1 && g_wgrad_row3x3 >= 0 && wgrad_row3x3_shape(a) && a.N == 32 && ((a.N + bng - 1) / bng) * ktiles == 1) ? 1 : 0;
+}
+
+int m2h_conv_wgrad_dgrad_fused_f32(const m2h_conv_args* args, const float* dy2, const float* w2_packed, const float* y, float slope, float* dw, int Ci,
+                                   m2h_stream stream) {
+  M2H_REQUIRE(args != nullptr && dy2 != nullptr && w2_packed != nullptr && y != nullptr, "conv_wgrad_dgrad_fused: null pointer");
+  M2H_REQUIRE(m2h_conv_wgrad_dgrad_fused_supported(args), "conv_wgrad_dgrad_fused: needs the bf16x3 arithmetic and the image-row shape (3x3 / 1 / 1, 32 -> 32 "
+              "channels over 32-pixel rows); use m2h_conv_igemm_f32 (input gradient) + m2h_conv_wgrad_torch_f32 otherwise");
+  return conv_wgrad_f32(*args, nullptr, args->N, dw, as_stream(stream), false, y, slope, Ci, dy2, w2_packed);
 }
 
 int m2h_conv_wgrad_torch_f32(const m2h_conv_args* args, const float* dy, int ldy, const float* y, float slope, float* dw, int Ci, m2h_stream stream) {

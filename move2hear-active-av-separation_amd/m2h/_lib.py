@@ -242,6 +242,8 @@ SIGNATURES = {
     "m2h_conv_wgrad_f32": [ctypes.POINTER(ConvArgs), _P, _I, _P, _P],
     "m2h_conv_wgrad_gated_f32": [ctypes.POINTER(ConvArgs), _P, _I, _P, _F, _P, _P],
     "m2h_conv_wgrad_torch_f32": [ctypes.POINTER(ConvArgs), _P, _I, _P, _F, _P, _I, _P],
+    "m2h_conv_wgrad_dgrad_fused_supported": [ctypes.POINTER(ConvArgs)],
+    "m2h_conv_wgrad_dgrad_fused_f32": [ctypes.POINTER(ConvArgs), _P, _P, _P, _F, _P, _I, _P],
     "m2h_pack_dgrad_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "m2h_act_bwd": [_P, _P, _F, _P, _Z, _P],
     "m2h_bias_grad_workspace_bytes": [_I, _I],

@@ -114,6 +114,35 @@ def conv_wgrad(x, x2, dy, n_out, kh, kw, stride, pad, gate=None, gate_slope=1.0,
     return dw
 
 
+def conv_wgrad_dgrad_fused_supported(x, n_out=32):
+    """True when m2h_conv_wgrad_dgrad_fused_f32 takes a 3x3 / 1 / 1 conv over x [B, H, 32, 32] -> n_out in the calling thread's arithmetic."""
+    B, H, W, _C = x.shape
+    a = _conv_args(x, None, n_out, 3, 3, 1, 1, H, W)
+    return bool(_lib.load().m2h_conv_wgrad_dgrad_fused_supported(ctypes.byref(a)))
+
+
+def conv_wgrad_dgrad_fused(x, dy2, wp_next, gate, gate_slope, torch_ci, out=None):
+    """Weight gradient [32, torch_ci, 3, 3] of a 3x3 / 1 / 1 conv (+ ReLU: gate = its forward output) whose output gradient is the INPUT gradient
+    of the next 3x3 conv, made inside the kernel from dy2 [B, H, W, 16] and that conv's packed weight wp_next [16, 288]
+    (m2h_conv_wgrad_dgrad_fused_f32: the 32-channel gradient tensor is never stored).  bf16x3 arithmetic, image-row shapes only."""
+    B, H, W, C = x.shape
+    a = _conv_args(x, None, 32, 3, 3, 1, 1, H, W)
+    lib = _lib.load()
+    shape = (32, int(torch_ci), 3, 3)
+    if out is not None and (tuple(out.shape) != shape or not out.is_contiguous() or out.dtype != torch.float32):
+        raise RuntimeError("m2h.conv_wgrad_dgrad_fused: out must be a contiguous fp32 tensor of shape %s" % (shape,))
+    if tuple(dy2.shape) != (B, H, W, 16) or not dy2.is_contiguous() or wp_next.numel() != 16 * 9 * C or tuple(gate.shape) != (B, H, W, 32):
+        raise RuntimeError("m2h.conv_wgrad_dgrad_fused: dy2 must be [B, H, W, 16] contiguous, wp_next [16, 288], gate [B, H, W, 32]")
+    dw = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        nbytes = lib.m2h_conv_wgrad_workspace_bytes(ctypes.byref(a))
+        ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+        _lib.check(lib.m2h_conv_wgrad_dgrad_fused_f32(ctypes.byref(a), ops._ptr(dy2), ops._ptr(wp_next), ops._ptr(gate), float(gate_slope), ops._ptr(dw),
+                                                      int(torch_ci), ops._stream(x)), "m2h_conv_wgrad_dgrad_fused_f32")
+    return dw
+
+
 def pack_dgrad_weight(w4d, stride, pad):
     Co, Ci, KH, KW = w4d.shape
     wp = torch.empty((stride * stride, Ci, (KH // stride) * (KW // stride) * Co), device=w4d.device, dtype=torch.float32)
@@ -699,6 +728,47 @@ class ConvL1NHWC16(torch.autograd.Function):
 
 def conv_l1_nhwc16(h, w, gt_comps, off=0, memo=None):
     return ConvL1NHWC16.apply(h, w, gt_comps.contiguous(), off, memo)
+
+
+@carries_math_mode
+class AcousticMemL1(torch.autograd.Function):
+    """loss = F.l1_loss(deslice(conv1(ReLU(conv0(x)))), gt) with gradients for the two weights only -- update_sep's whole differentiable path
+    (rl/ppo/ppo.py:206-226 through rl/models/memory_nets.py:11-16,62-67) as three forward-side and three backward-side launches at the
+    image-row shapes in bf16x3 arithmetic: conv0 + ReLU | conv1 + loss + the loss's gradient (m2h_conv3x3_l1_nhwc16: conv1's output never stored) ||
+    conv1's weight gradient | conv0's weight gradient with conv1's INPUT gradient and the ReLU gate made inside it
+    (m2h_conv_wgrad_dgrad_fused_f32: the 32-channel gradient of h never stored).  The per-layer Functions (Conv2dNHWC, ConvL1NHWC16) stay the
+    route of every other shape / arithmetic and compute the same values to fp32 summation order."""
+
+    @staticmethod
+    def forward(ctx, x, w0, w1, gt_plane, memo0, memo1):
+        wp0 = memo0.get(w0, x.shape[3]) if memo0 is not None else ops.pack_conv_weight_ex(w0.detach().contiguous(), w0.shape[1], x.shape[3])
+        wp1 = memo1.get(w1, 32) if memo1 is not None else ops.pack_conv_weight_ex(w1.detach().contiguous(), w1.shape[1], 32)
+        h = ops.conv2d_nhwc(x, wp0, 32, 3, 3, stride=1, pad=1, slope=0.0, name="acoustic_mem.conv0")
+        loss, dy = ops.conv3x3_l1_nhwc16(h, wp1, gt_plane)
+        ctx.save_for_backward(x, h, dy, w0, w1, wp1)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, h, dy, w0, w1, wp1 = ctx.saved_tensors
+        u = _unit_grads.get(g.device)
+        if u is None or g.data_ptr() != u.data_ptr():
+            dy = dy * g
+        gw1 = conv_wgrad(h, None, dy, 16, 3, 3, 1, 1, torch_ci=w1.shape[1], out=grad_slot(w1)) if ctx.needs_input_grad[2] else None
+        gw0 = None
+        if ctx.needs_input_grad[1]:
+            gw0 = conv_wgrad_dgrad_fused(x, dy, wp1, h, 0.0, w0.shape[1], out=grad_slot(w0))
+        return None, gw0, gw1, None, None, None
+
+
+def acoustic_mem_l1_supported(x):
+    """The shapes / arithmetic AcousticMemL1 runs in: both fused launches available (bf16x3, 32 x 32 x 32 images, B >= 64)."""
+    return (x.dim() == 4 and x.shape[3] == 32 and ops.math_mode() == ops.MATH_BF16X3 and not ops.timing_enabled() and ops.conv3x3_l1_supported(x)
+            and conv_wgrad_dgrad_fused_supported(x))
+
+
+def acoustic_mem_l1(x, w0, w1, gt_plane, memo0=None, memo1=None):
+    return AcousticMemL1.apply(x, w0, w1, gt_plane.contiguous(), memo0, memo1)
 
 
 _unit_grads = {}

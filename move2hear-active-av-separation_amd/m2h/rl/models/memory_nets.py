@@ -94,6 +94,10 @@ class AcousticMem(nn.Module):
             raise NotImplementedError("m2h AcousticMem: gradients w.r.t. the inputs are not built; detach the inputs")
         x = sliced if sliced is not None else self.slice_inputs(pred_mono, prev_pred_monoFromMem, masks)
         c0, c1 = self.cnn[0], self.cnn[-1]
+        if (gt_comps.shape[-1] == 1 and off == 0 and torch.is_grad_enabled() and c0.weight.requires_grad and c1.weight.requires_grad
+                and tuple(c0.weight.shape) == (32, 32, 3, 3) and MF.acoustic_mem_l1_supported(x)):
+            # update_sep at the update batch in bf16x3 arithmetic: the whole differentiable path as one Function (two convs' outputs / gradients never stored)
+            return MF.acoustic_mem_l1(x, c0.weight, c1.weight, gt_comps, self._memo[0], self._memo[1])
         x = MF.conv2d(x, c0.weight, None, 1, 1, slope=0.0, memo=self._memo[0], name="acoustic_mem.conv0")
         return MF.conv_l1_nhwc16(x, c1.weight, gt_comps, off, memo=self._memo[1])
 

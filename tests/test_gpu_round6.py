@@ -65,5 +65,52 @@ def test_fused_conv_l1_matches_the_oracle_and_the_two_launches_it_replaces(mode)
     assert set(np.unique(dy.cpu().numpy()).tolist()) <= {np.float32(-inv).item(), 0.0, np.float32(inv).item()}
     d_ref = torch.sign(pred - gt_comps[..., 0:1]).reshape(B, 16, 32, 32).permute(0, 2, 3, 1) * inv      # NHWC
     assert (dy.cpu() != d_ref.float()).float().mean().item() < (2e-3 if mode == "bf16x3" else 2e-4)     # (sign flips only where y ~ g)
-    assert abs(float(lf) - float(loss)) == 0.0 and abs(float(lt) - float(loss2)) == 0.0
+    assert abs(float(lf.detach()) - float(loss)) == 0.0 and abs(float(lt.detach()) - float(loss2)) == 0.0
     assert O.rel_l1(gw_fused.cpu(), gw_two.cpu()) < 1e-6
+
+
+def test_acoustic_mem_update_path_with_both_fusions_matches_torch_autograd():
+    """update_sep's differentiable path in bf16x3 arithmetic (functional.AcousticMemL1: conv0 + ReLU | conv1 + L1 loss + its gradient ||
+    conv1's weight gradient | conv0's weight gradient with conv1's input gradient and the ReLU gate made inside the kernel,
+    m2h_conv_wgrad_dgrad_fused_f32) against torch autograd on the CPU through the reference's ops (memory_nets.py:11-16,62-67; ppo.py:206-226),
+    and against the per-layer Functions it replaces (the unfused launches: the same values to fp32 summation order).  Batches whose row
+    ranges end inside an image, at an image edge and on a single row per block are all in the split."""
+    from m2h import functional as MF
+    from m2h import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(23)
+    for B in (64, 75):
+        x = torch.randn(B, 32, 32, 32, generator=g) * 0.7          # NHWC sliced input
+        w0 = torch.randn(32, 32, 3, 3, generator=g) * 0.06
+        w1 = torch.randn(16, 32, 3, 3, generator=g) * 0.08
+        gt = torch.rand(B, 512, 32, 1, generator=g) * 2
+        # CPU reference with torch autograd
+        w0c, w1c = w0.clone().requires_grad_(True), w1.clone().requires_grad_(True)
+        h = F.relu(F.conv2d(x.permute(0, 3, 1, 2), w0c, None, 1, 1))
+        y = F.conv2d(h, w1c, None, 1, 1)                           # [B, 16, 32, 32]: band n, row q -> de-sliced row n * 32 + q
+        want = F.l1_loss(y.reshape(B, 512, 32, 1), gt)
+        want.backward()
+        xd, gtd = x.to(dev), gt.to(dev)
+        ops.set_math_mode(ops.MATH_BF16X3)
+        try:
+            assert MF.acoustic_mem_l1_supported(xd)
+            w0d, w1d = w0.to(dev).requires_grad_(True), w1.to(dev).requires_grad_(True)
+            loss = MF.acoustic_mem_l1(xd, w0d, w1d, gtd)
+            loss.backward()
+            g0, g1 = w0d.grad.clone(), w1d.grad.clone()
+            # the per-layer Functions (no fused input gradient: dgrad launch + gated weight gradient)
+            w0e, w1e = w0.to(dev).requires_grad_(True), w1.to(dev).requires_grad_(True)
+            he = MF.conv2d(xd, w0e, None, 1, 1, slope=0.0)
+            le = MF.conv_l1_nhwc16(he, w1e, gtd, 0)
+            le.backward()
+        finally:
+            ops.set_math_mode(ops.MATH_FP32)
+        assert abs(float(loss.detach()) - float(want)) <= 3e-5 * float(want)
+        assert float(loss.detach()) == float(le.detach())
+        assert torch.equal(g1, w1e.grad)                                       # same launches for conv1's weight gradient
+        assert O.rel_l1(g0.cpu(), w0e.grad.cpu()) < 3e-5, (B, O.rel_l1(g0.cpu(), w0e.grad.cpu()))
+        # against torch autograd: the gradients of an L1 loss are sums of +-1/n signs pushed through the convs -- a sign flip where y ~ gt moves
+        # them by O(1 / n) per flipped element; 2e-3 of the gradient's L1 mass is what the unfused bf16x3 path shows too
+        e0, e1 = O.rel_l1(g0.cpu(), w0c.grad), O.rel_l1(g1.cpu(), w1c.grad)
+        u0 = O.rel_l1(w0e.grad.cpu(), w0c.grad)
+        assert e1 < 2e-3 and e0 < 2e-3 and e0 < 1.5 * u0 + 1e-5, (B, e0, e1, u0)
