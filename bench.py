@@ -823,7 +823,7 @@ def main():
         # HBM traffic of the dominant instantiation: PMC counters cannot be read from inside this process, so the per-launch
         # figure of the committed rocprofv3 --pmc passes over this same command is reported (null when the file is absent)
         traffic, traffic_src = None, None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_pmc_hbm_traffic.json" % r) for r in (5, 4, 3, 2, 1)) if os.path.exists(q)), None)
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", "r%02d_pmc_hbm_traffic.json" % r) for r in (6, 5, 4, 3, 2, 1)) if os.path.exists(q)), None)
         if tpath is not None:
             with open(tpath) as f:
                 tj = json.load(f).get(mode, {})

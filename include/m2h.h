@@ -243,6 +243,14 @@ int m2h_policy_heads(const float* feats, const float* Wa, const float* ba, const
                      const long long* actions, float* value, float* logp_all, float* probs, float* entropy, float* logp_act,
                      int M, int H, int A, m2h_stream stream);
 int m2h_gather_logp(const float* logp_all, const long long* actions, float* out, int M, int A, m2h_stream stream);
+/* LSTM cell, pointwise part -- RNNStateEncoder's rnn_type = "LSTM" variant (rl/models/rnn_state_encoder.py:10-34,49-69; nn.LSTM gate order i, f, g, o):
+ * pre = gi + gh [M][4H] (the two products with their biases); c' = sigmoid(f) (c_prev mask) + sigmoid(i) tanh(g); h' = sigmoid(o) tanh(c').
+ * mask [M]: the reset mask of the carried cell state (:63-69).  gates_out: NULL or [M][4H], the activated gates the backward reads.
+ * m2h_lstm_cell_bwd: dh / dc (either may be NULL = zero) -> dpre [M][4H] (gradient of gi and of gh) and dc_prev [M][H]. */
+int m2h_lstm_cell(const float* gi, const float* gh, const float* c_prev, const float* mask, float* h_out, float* c_out, float* gates_out, int M, int H,
+                  m2h_stream stream);
+int m2h_lstm_cell_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev, const float* mask, const float* c, float* dpre,
+                      float* dc_prev, int M, int H, m2h_stream stream);
 /* Policy.act's tail in ONE launch (rl/ppo/policy.py:217-225): m2h_policy_heads, then the action -- noise != NULL: the single draw of
  * torch.multinomial(probs, 1, True) == argmax(probs / noise) with caller-supplied Exp(1) noise [M][A] (as m2h_sample_actions);
  * noise == NULL: CustomFixedCategorical.mode() == argmax(probs) -- and logp_act[row] = logp_all[row][action]. */

@@ -236,6 +236,56 @@ __global__ __launch_bounds__(64 * GC_NW) void gru_cell_kernel(const float* __res
   }
 }
 
+// LSTM cell, pointwise part (the class's rnn_type = "LSTM" variant, rnn_state_encoder.py:10-34,49-69; nn.LSTM's gate order i, f, g, o):
+// pre = gi + gh  [M][4H] (gi = x W_ih^T + b_ih, gh = (h m) W_hh^T + b_hh);  c' = sigma(f) (c m) + sigma(i) tanh(g);  h' = sigma(o) tanh(c').
+// The reset mask m[row] multiplies the carried cell state here (the hidden state's mask is applied before its product: _mask_hidden, :63-69).
+// gates_out [M][4H] keeps the ACTIVATED gates for the backward.  One thread per (row, unit).
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ cprev,
+                                                        const float* __restrict__ mask, float* __restrict__ hout, float* __restrict__ cout,
+                                                        float* __restrict__ gates_out, int M, int H) {
+  const size_t total = (size_t)M * H;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(idx / H), j = (int)(idx - (size_t)row * H);
+    const size_t b = (size_t)row * 4 * H;
+    const float ig = sigmoidf_(gi[b + j] + gh[b + j]);
+    const float fg = sigmoidf_(gi[b + H + j] + gh[b + H + j]);
+    const float gg = tanhf(gi[b + 2 * H + j] + gh[b + 2 * H + j]);
+    const float og = sigmoidf_(gi[b + 3 * H + j] + gh[b + 3 * H + j]);
+    const float cm = cprev[idx] * mask[row];
+    const float c = fg * cm + ig * gg;
+    cout[idx] = c;
+    hout[idx] = og * tanhf(c);
+    if (gates_out != nullptr) {
+      gates_out[b + j] = ig;
+      gates_out[b + H + j] = fg;
+      gates_out[b + 2 * H + j] = gg;
+      gates_out[b + 3 * H + j] = og;
+    }
+  }
+}
+
+// Its backward: dh, dc = gradients of (h', c'); dpre [M][4H] = gradient of the pre-activations (of gi and gh alike), dcprev = gradient of the
+// carried cell state (through the mask).  dh or dc may be NULL (zero).
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc, const float* __restrict__ gates,
+                                                            const float* __restrict__ cprev, const float* __restrict__ mask, const float* __restrict__ c,
+                                                            float* __restrict__ dpre, float* __restrict__ dcprev, int M, int H) {
+  const size_t total = (size_t)M * H;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(idx / H), j = (int)(idx - (size_t)row * H);
+    const size_t b = (size_t)row * 4 * H;
+    const float ig = gates[b + j], fg = gates[b + H + j], gg = gates[b + 2 * H + j], og = gates[b + 3 * H + j];
+    const float m = mask[row];
+    const float tc = tanhf(c[idx]);
+    const float gh_ = dh != nullptr ? dh[idx] : 0.f;
+    const float dct = (dc != nullptr ? dc[idx] : 0.f) + gh_ * og * (1.f - tc * tc);
+    dpre[b + j] = dct * gg * ig * (1.f - ig);
+    dpre[b + H + j] = dct * (cprev[idx] * m) * fg * (1.f - fg);
+    dpre[b + 2 * H + j] = dct * ig * (1.f - gg * gg);
+    dpre[b + 3 * H + j] = gh_ * tc * og * (1.f - og);
+    dcprev[idx] = dct * fg * m;
+  }
+}
+
 // Philox4x32-10 (Salmon et al., SC'11: the counter-based generator torch's device generator is built on), one 32-bit word of the
 // block at `counter` under `seed`, as Exp(1) noise: -log(u), u = (23 random bits + 0.5) / 2^23 in (0, 1) -- 23 bits, so that the sum
 // is exact in fp32 (with 24 bits 0xFFFFFF + 0.5 rounds to 2^24: u = 1, noise 0, probs / noise = inf and that action wins whatever its
@@ -1087,6 +1137,24 @@ int m2h_gru_cell(const float* x, const float* wih, const float* bih, const float
               "gru_cell: needs 1 <= M <= %d rows, H %% 16 == 0 and I %% 16 == 0 (got M=%d, I=%d, H=%d)", GRU_E, M, I, H);
   M2H_LAUNCH(gru_cell_kernel, dim3(H / GRU_U), dim3(64 * GC_NW), 0, as_stream(stream), x, wih, bih, whh, bhh, hprev, mask, hout, M, I, H);
   return launch_status("gru_cell");
+}
+
+int m2h_lstm_cell(const float* gi, const float* gh, const float* c_prev, const float* mask, float* h_out, float* c_out, float* gates_out, int M, int H,
+                  m2h_stream stream) {
+  M2H_REQUIRE(gi && gh && c_prev && mask && h_out && c_out && M > 0 && H > 0, "lstm_cell: bad arguments");
+  size_t g = ((size_t)M * H + 255) / 256;
+  if (g > 4096) g = 4096;
+  M2H_LAUNCH(lstm_cell_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), gi, gh, c_prev, mask, h_out, c_out, gates_out, M, H);
+  return launch_status("lstm_cell");
+}
+
+int m2h_lstm_cell_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev, const float* mask, const float* c, float* dpre,
+                      float* dc_prev, int M, int H, m2h_stream stream) {
+  M2H_REQUIRE(gates && c_prev && mask && c && dpre && dc_prev && M > 0 && H > 0, "lstm_cell_bwd: bad arguments");
+  size_t g = ((size_t)M * H + 255) / 256;
+  if (g > 4096) g = 4096;
+  M2H_LAUNCH(lstm_cell_bwd_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), dh, dc, gates, c_prev, mask, c, dpre, dc_prev, M, H);
+  return launch_status("lstm_cell_bwd");
 }
 
 int m2h_policy_heads(const float* feats, const float* Wa, const float* ba, const float* Wc, const float* bc,

@@ -217,6 +217,8 @@ SIGNATURES = {
     "m2h_policy_heads_act": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "m2h_policy_heads_act_rng": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "m2h_sample_actions": [_P, _P, _P, _I, _I, _P],
+    "m2h_lstm_cell": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "m2h_lstm_cell_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_conv3x3_l1_nhwc16_supported": [_I, _I, _I, _I],
     "m2h_conv3x3_l1_nhwc16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "m2h_gae_returns": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P],

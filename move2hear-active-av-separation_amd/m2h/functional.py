@@ -588,6 +588,39 @@ class GRUSequence(torch.autograd.Function):
         return g_x, g_h0, None, g_wih, g_whh, g_bih, g_bhh, None, None
 
 
+class LSTMCell(torch.autograd.Function):
+    """(h', c') = LSTM cell pointwise part from the two products gi, gh [N, 4H], the carried cell state and the step's reset mask
+    (rnn_state_encoder.py:10-34, 63-69): one launch forward (m2h_lstm_cell), one backward (m2h_lstm_cell_bwd) -- in place of the ~12
+    pointwise torch kernels per step of the unfused gate math."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, c_prev, mask):
+        gi, gh, c_prev = gi.contiguous(), gh.contiguous(), c_prev.contiguous()
+        mask = mask.reshape(-1).contiguous()
+        N, H = c_prev.shape
+        h, c = torch.empty_like(c_prev), torch.empty_like(c_prev)
+        need = any(ctx.needs_input_grad[:3])
+        gates = torch.empty_like(gi) if need else None
+        with torch.cuda.device(gi.device):
+            _lib.check(_lib.load().m2h_lstm_cell(ops._ptr(gi), ops._ptr(gh), ops._ptr(c_prev), ops._ptr(mask), ops._ptr(h), ops._ptr(c), ops._ptr(gates),
+                                                 N, H, ops._stream(gi)), "m2h_lstm_cell")
+        if need:
+            ctx.save_for_backward(gates, c_prev, mask, c)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        gates, c_prev, mask, c = ctx.saved_tensors
+        N, H = c_prev.shape
+        dpre, dcp = torch.empty_like(gates), torch.empty_like(c_prev)
+        dh = dh.contiguous() if dh is not None else None
+        dc = dc.contiguous() if dc is not None else None
+        with torch.cuda.device(gates.device):
+            _lib.check(_lib.load().m2h_lstm_cell_bwd(ops._ptr(dh), ops._ptr(dc), ops._ptr(gates), ops._ptr(c_prev), ops._ptr(mask), ops._ptr(c), ops._ptr(dpre),
+                                                     ops._ptr(dcp), N, H, ops._stream(gates)), "m2h_lstm_cell_bwd")
+        return dpre, dpre, dcp, None
+
+
 class PolicyHeads(torch.autograd.Function):
     """(value [M,1], logp_act [M,1], entropy [M], probs [M,A], logp_all [M,A]) from feats and the two Linear heads
     (common/utils.py:42-50, rl/ppo/policy.py:15-23); backward for value / logp_act / entropy."""

@@ -1,5 +1,5 @@
 """Recurrent state encoder on MI355X: drop-in for audio_separation/rl/models/rnn_state_encoder.py (RNNStateEncoder, :5-143): GRU (what
-policy.py:63 constructs: fused kernels) with any number of layers, and the class's LSTM variant (library GEMMs + torch gate math).
+policy.py:63 constructs: fused kernels) with any number of layers, and the class's LSTM variant (library GEMMs + a fused cell kernel).
 
 ``nn.GRU`` is the parameter container (keys ``rnn.weight_ih_l0`` ...; orthogonal init, :36-41).  The two GEMMs of a step run on
 the MFMA engine (torch's [3H][K] weight layout is already the packed [N][K] form); the gate math and the hidden-state reset
@@ -38,8 +38,9 @@ class RNNStateEncoder(nn.Module):
     def _lstm_forward(self, x, hidden_states, masks, n, t):
         """The "LSTM" variant (:10-34, 49-61; policy.py:63 never selects it and no config key reaches it).  hidden_states packs
         (h, c) along dim 0 ([2 L, N, H], :49-61); both are multiplied by the step's reset mask (:63-69).  The four GEMMs of a step
-        run on the library's engine (the input projection batched over all T N rows); the gate math is torch's pointwise kernels with
-        torch's autograd -- no fused LSTM cell kernel is built for a variant nothing instantiates."""
+        run on the library's engine (the input projection batched over all T N rows); the gate math of a step -- sum of the two products,
+        four activations, cell update, the cell state's reset mask -- is one fused launch forward and one backward (functional.LSTMCell,
+        m2h_lstm_cell / m2h_lstm_cell_bwd; round 6: it was ~12 torch pointwise kernels per step under torch autograd)."""
         r, L, H = self.rnn, self._num_recurrent_layers, self.rnn.hidden_size
         hs, cs = hidden_states[:L], hidden_states[L:]
         m = masks.reshape(t, n, 1)
@@ -49,11 +50,8 @@ class RNNStateEncoder(nn.Module):
             gi = MF.linear(out.contiguous(), w_ih, b_ih, name="lstm.ih").reshape(t, n, 4 * H)
             h, c, steps = hs[l], cs[l], []
             for k in range(t):
-                h, c = h * m[k], c * m[k]
-                g = gi[k] + MF.linear(h.contiguous(), w_hh, b_hh, name="lstm.hh")
-                i_, f_, g_, o_ = g.split(H, dim=1)                   # nn.LSTM's gate order: input, forget, cell, output
-                c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(g_)
-                h = torch.sigmoid(o_) * torch.tanh(c)
+                gh = MF.linear((h * m[k]).contiguous(), w_hh, b_hh, name="lstm.hh")
+                h, c = MF.LSTMCell.apply(gi[k], gh, c, m[k])         # (the cell state's mask is applied inside; nn.LSTM's gate order i, f, g, o)
                 steps.append(h)
             out = torch.cat(steps, 0)
             h_out.append(h)

@@ -168,6 +168,51 @@ class GradReduceStep:
             torch.cuda.current_stream(self._dev).wait_event(ev)
 
 
+class RolloutTracker:
+    """The straggler pre-emption counter of the reference's DD-PPO loop (ppo_trainer.py:597-600, :769-782, :863): a key
+    ``rollout_tracker/num_done`` in the job's key-value store.  Every rank adds 1 when its rollout is complete (:781-782); a rank still
+    collecting stops early once it has made ``short_rollout_threshold`` of its steps AND more than ``sync_frac`` of the ranks are done
+    (:775-780); world rank 0 puts the counter back to 0 after the update's statistics all-reduce (:862-863).  The shipped configs set
+    short_rollout_threshold 1.0 (nearTarget.yaml:58): ``step >= num_steps`` never holds inside the loop, the store is then never read.
+    store: the process group's own store (one process per GPU, torch.distributed) under the reference's prefix; without a process group a
+    local counter (world size 1: nobody else to wait for)."""
+
+    def __init__(self, world_size=1, world_rank=0, store=None):
+        self.world_size, self.world_rank = int(world_size), int(world_rank)
+        if store is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from torch.distributed.distributed_c10d import _get_default_store
+            store = dist.PrefixStore("rollout_tracker", _get_default_store())
+        self._store = store
+        self._local = 0
+        self.reads = 0
+        if self._store is not None:
+            self._store.set("num_done", "0")           # :600 (every rank does, before the first rollout)
+
+    def num_done(self):
+        self.reads += 1
+        return int(self._store.get("num_done")) if self._store is not None else self._local
+
+    def rollout_done(self):
+        if self._store is not None:
+            self._store.add("num_done", 1)
+        else:
+            self._local += 1
+
+    def reset(self):
+        """World rank 0, after the update's all-reduce (:862-863)."""
+        if self.world_rank == 0:
+            if self._store is not None:
+                self._store.set("num_done", "0")
+            else:
+                self._local = 0
+
+    def should_preempt(self, step, num_steps, short_rollout_threshold, sync_frac):
+        """:775-780, evaluated after step `step` (0-based) of the rollout: the store is read only once the threshold is reached."""
+        if step < num_steps * short_rollout_threshold:
+            return False
+        return self.num_done() > sync_frac * self.world_size
+
+
 def normalize_advantages_distributed(raw_adv, local_mean, sqdiff_fn, apply_fn, eps=1e-5):
     """_get_advantages_distributed (ppo.py:275-284): global mean = mean of per-rank means, global var = mean over ranks of the
     per-rank mean((A - mean)^2) (biased), A <- (A - mean) / (sqrt(var) + eps).

@@ -15,7 +15,7 @@ tests/test_gpu_trainer_golden.py).  Changed in mechanism only:
   * the same outputs are stored beside the observation in the separator storage, where update_sep reads them instead of
     re-running the frozen U-Nets over the whole buffer (the reference does that 24 x per cycle under no_grad, ppo.py:184-195);
   * checkpoints keep the reference format {"state_dict", "config"} (:223-238).
-Out of scope: Habitat env construction, TensorBoard, the eval loop (:1015-1551).
+Out of scope: Habitat env construction, TensorBoard.
 """
 import os
 import time
@@ -44,7 +44,7 @@ def near_target_config(**over):
              extra_reward_multiplier=10.0, reward_window_size=50, use_ddppo=True, CHECKPOINT_FOLDER=None,
              switch_policy=False, time_thres_for_pol_switch=80, deterministic_eval=False,   # config/default.py:99-101
              ddppo_distrib_backend="NCCL", master_port=8738, master_addr="127.0.0.1",       # config/default.py:94-97
-             short_rollout_threshold=1.0, sync_frac=0.6,  # nearTarget.yaml:58-59: at 1.0 the preemption of :775-781 never triggers; not built
+             short_rollout_threshold=1.0, sync_frac=0.6,  # nearTarget.yaml:58-59: at 1.0 the pre-emption of :775-781 never triggers (ddppo_utils.RolloutTracker)
              use_hip_graphs=True,       # build-side key: replay the rollout step and the update_pol epoch from HIP graphs (same kernels, same results)
              bucketed_grad_reduce=None,  # build-side key: None = when distributed, the policy gradient's all-reduce in two buckets, the first under the encoders' backward
              overlap_grad_reduce=None,  # build-side key: None = overlap the last all-reduce + step of an update when distributed
@@ -157,6 +157,13 @@ class PPOTrainer:
         warnings.filterwarnings("ignore", message="Detected call of `lr_scheduler.step\\(\\)` before `optimizer.step\\(\\)`")
         self.lr_scheduler_pol = LambdaLR(self.agent.optimizer_pol, lr_lambda=lambda x: linear_decay(x, cfg.NUM_UPDATES))
         self.lr_scheduler_sep = LambdaLR(self.agent.optimizer_sep, lr_lambda=lambda x: linear_decay(x, cfg.NUM_UPDATES))
+        # straggler pre-emption (:597-600, :769-782): the "rollout_tracker/num_done" counter in the job's store; read only when
+        # short_rollout_threshold < 1 lets a rollout end early
+        from . import ddppo_utils
+        # (at the shipped threshold 1.0 the counter can never be read -- `step >= num_steps` does not occur inside the loop -- so its store
+        # traffic, two TCP round trips per rollout and rank, is not made either)
+        self.rollout_tracker = (ddppo_utils.RolloutTracker(self.world_size, self.world_rank)
+                                if cfg.use_ddppo and float(getattr(cfg, "short_rollout_threshold", 1.0)) < 1.0 else None)
         self.count_steps = 0
         self.num_updates_done = 0
         self.num_sep_updates_done = 0
@@ -379,6 +386,11 @@ class PPOTrainer:
             e0 = self._mark(phase_events)
             for _step in range(cfg.num_steps):
                 sub_steps += self._collect_rollout_step()
+                if self.rollout_tracker is not None and self.rollout_tracker.should_preempt(
+                        _step, cfg.num_steps, getattr(cfg, "short_rollout_threshold", 1.0), getattr(cfg, "sync_frac", 0.6)):
+                    break      # :775-780: enough of the other ranks are waiting at the update
+            if self.rollout_tracker is not None:
+                self.rollout_tracker.rollout_done()        # :781-782
             steps += sub_steps
             e1 = self._mark(phase_events)
             tail = _sub == cfg.num_updates_per_cycle - 1 and self._tail_overlap(checkpoint)
@@ -392,6 +404,8 @@ class PPOTrainer:
             self.num_updates_done += 1
             if log_stats:
                 self._log_window_stats(pol_losses, sub_steps)
+            if self.rollout_tracker is not None:
+                self.rollout_tracker.reset()               # :862-863 (world rank 0, behind the update's statistics all-reduce)
         if tail:
             torch.cuda.current_stream(self.device).wait_stream(self._tail_stream)
             sep_losses = tuple(sep_pending[-1].tolist())

@@ -114,3 +114,64 @@ def test_two_rank_gloo_protocol():
     assert sorted(r[0] for r in res) == [0, 1]
     for r in res:
         assert all(r[1:]), r
+
+
+def _tracker_rank(rank, port, q):
+    import torch.distributed as dist
+    from m2h.rl.ppo import ddppo_utils as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2")
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    tr = D.RolloutTracker(2, rank)
+    dist.barrier()
+    out = {}
+    # below the threshold the store is not even read
+    out["early"] = (tr.should_preempt(3, 20, 0.5, 0.4), tr.reads)
+    if rank == 1:
+        tr.rollout_done()                     # rank 1 finishes its rollout first
+    dist.barrier()
+    # rank 0, still collecting at step 10 of 20 (threshold 0.5): 1 rank done > 0.4 * 2 -> stop early; with sync_frac 0.6 (1 > 1.2 is false) go on
+    out["preempt"] = (tr.should_preempt(10, 20, 0.5, 0.4), tr.should_preempt(10, 20, 0.5, 0.6), tr.num_done())
+    dist.barrier()
+    if rank == 0:
+        tr.rollout_done()
+    dist.barrier()
+    out["both"] = tr.num_done()
+    dist.barrier()
+    tr.reset()                                # only world rank 0 writes
+    dist.barrier()
+    out["after_reset"] = tr.num_done()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rollout_tracker_preempts_stragglers_as_the_reference_counter_does():
+    """ppo_trainer.py:597-600, :769-782, :862-863 over the process group's own store, two gloo ranks: every rank adds when its rollout is
+    done, a rank still collecting stops once it is past short_rollout_threshold and more than sync_frac of the ranks wait, rank 0 resets."""
+    import multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tracker_rank, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert res[r]["early"] == (False, 0)
+        assert res[r]["preempt"] == (True, False, 1)
+        assert res[r]["both"] == 2 and res[r]["after_reset"] == 0
+    # without a process group: a local counter, world size 1 -- nobody to wait for, the own add comes after the loop
+    from m2h.rl.ppo import ddppo_utils as D
+    t = D.RolloutTracker(1, 0)
+    assert not t.should_preempt(19, 20, 0.5, 0.6)
+    t.rollout_done()
+    assert t.num_done() == 1 and t.should_preempt(10, 20, 0.5, 0.6)
+    t.reset()
+    assert t.num_done() == 0

@@ -292,3 +292,23 @@ def test_loading_weights_after_graph_capture_invalidates_the_graphs():
     torch.manual_seed(6)
     res = tr_a.train_cycle()
     assert tr_a._graph_state is not None and all(np.isfinite(res["pol_losses"]))
+
+
+def test_short_rollouts_when_enough_other_ranks_wait_at_the_update():
+    """Straggler pre-emption (ppo_trainer.py:769-782; ddppo_utils.RolloutTracker): with short_rollout_threshold 0.5 a rank that sees more than
+    sync_frac of the ranks done stops its rollout after half of its steps; the update runs on the storage as it stands (the reference does the
+    same: rollout_storage.py has no notion of a short rollout) and the HIP-graph replay picks the device step indices up again.  At the
+    shipped threshold 1.0 no tracker exists at all (no store traffic)."""
+    tr, _sd = _trainer()
+    assert tr.rollout_tracker is None
+    res = tr.train_cycle()
+    assert res["env_steps"] == 2 * 4 * 3
+    tr2, _sd = _trainer(short_rollout_threshold=0.5, sync_frac=0.6)
+    assert tr2.rollout_tracker is not None and tr2.rollout_tracker.world_size == 1
+    res = tr2.train_cycle()                     # alone in the job: nobody is ever waiting, full rollouts
+    assert res["env_steps"] == 2 * 4 * 3 and tr2.rollout_tracker.num_done() == 0
+    tr2.rollout_tracker.num_done = lambda: 1    # one (other) rank done: 1 > 0.6 x 1
+    for _ in range(2):
+        res = tr2.train_cycle()
+        assert res["env_steps"] == 2 * 3 * 3    # steps 0, 1, 2 of 4: the check after step 2 (>= 0.5 x 4) ends the rollout
+        assert all(np.isfinite(res["pol_losses"])) and all(np.isfinite(res["sep_losses"]))
