@@ -967,7 +967,10 @@ def main():
             try:
                 torch.cuda.synchronize()
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "clock_probe.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)
-                probe = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if not lines:
+                    raise RuntimeError("tools/clock_probe.py printed no result (rc %d): %s" % (r.returncode, r.stderr[-240:]))
+                probe = json.loads(lines[-1])
                 roofline["clock_probe"] = probe
                 if "layers" in probe:
                     dom = roofline["dominant_instantiation"]["name"]
