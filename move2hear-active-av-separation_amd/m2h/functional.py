@@ -8,6 +8,7 @@ Replaces torch's Conv2d/Linear autograd in audio_separation/rl/ppo/ppo.py:159-16
 """
 import contextlib
 import ctypes
+import os
 import threading
 import weakref
 
@@ -79,6 +80,125 @@ def grad_slot(w):
             opt._slots_used.add(off)
             return opt.flat_g[off:off + w.numel()].view(w.shape)
     return None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Weight gradients as a side branch of a captured step.  In a backward pass the input-gradient kernels form the dependent chain
+# (layer L's dgrad feeds layer L-1's); each layer's WEIGHT gradient hangs off that chain and nothing reads it before the optimizer.
+# Enqueued on one stream, the 10-60 us weight-gradient launches of these batch sizes sit between the chain's links.
+#
+# What this stack allows (ROCm 7.2; profiles/r06_wgrad_side_per_layer_ab.txt, tools/r06_fork_probe.py): every cross-stream edge of a
+# replayed graph costs ~19 us (one fork PER LAYER made the passive step 3.15 instead of 2.40 ms), and a side stream of a side stream may
+# only be joined by the stream the capture began on (joined by the intermediate stream: hipStreamEndCapture crashes).  Hence the form:
+# inside ``wgrad_side_branches()``, while a HIP graph is being captured, a layer whose gradient has a home in its optimizer's flat buffer
+# (grad_slot) does not launch its weight gradient, it DEFERS it (operands kept alive by the closure); ``wgrad_flush_point(x)`` -- an
+# identity in the forward, placed by a model where its backward is half done (the U-Net's bottleneck) -- launches what was deferred so
+# far on ONE side stream behind ONE event while the chain goes on; what is deferred after the last flush point is launched on the
+# chain's own stream by ``flush_deferred_wgrads()`` (the trainer calls it after backward()).  The optimizer's reads
+# (``join_wgrad_branches``: FlatAdam.captured_step / _gather) wait for the side streams.  Same kernels, same values.
+# Used by the passive training step (2.41 -> 2.37 ms, profiles/r06_wgrad_side_ab.txt).  In update_pol's epoch the same idea -- the
+# recurrent encoder's two weight gradients started on the third encoder's branch instead of the chain ahead of the fork -- returned
+# nothing (35.7 / 36.2 against 35.5 / 35.0 ms per cycle, same file) and is not built in.
+# ----------------------------------------------------------------------------------------------------------------
+_wgrad_side = {"on": False}
+_wgrad_deferred = {}    # (device index, stream id of the backward) -> [(launch, operands, arithmetic mode, tuning knobs)]
+_wgrad_pending = {}     # (device index, side stream id) -> (side stream holding weight-gradient launches nobody waited for yet, id of the stream they forked from)
+
+
+@contextlib.contextmanager
+def wgrad_side_branches(enabled=True):
+    """Inside the block (and inside a graph capture) weight-gradient launches of this module's Functions are deferred to the next
+    flush (see above); the caller flushes every stream a backward ran on, on that stream.  The flag is process-wide, not thread-local:
+    autograd runs the backward on its own thread."""
+    from . import graphs
+    prev = _wgrad_side["on"]
+    _wgrad_side["on"] = bool(enabled) and graphs.parallel_branches and os.environ.get("M2H_WGRAD_SIDE", "1") != "0"    # (the variable: A/B runs)
+    try:
+        yield
+        if _wgrad_deferred:
+            raise RuntimeError("m2h.wgrad_side_branches: weight gradients were deferred and never launched (call flush_deferred_wgrads() after backward())")
+    finally:
+        _wgrad_side["on"] = prev
+        _wgrad_deferred.clear()
+
+
+def _wgrad_launch(dev, reads, fn, slot):
+    """fn() -- one layer's weight-gradient launches, writing to `slot` -- now, or deferred to the next flush (see above: switch on, a
+    capture in progress, and the gradient has a home that exists before the launch)."""
+    if slot is None or not _wgrad_side["on"] or dev.type != "cuda" or ops.timing_enabled() or not torch.cuda.is_current_stream_capturing():
+        return fn()
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    _wgrad_deferred.setdefault(key, []).append((fn, reads, ops.math_mode(), ops.tuning_snapshot() if _carry_tuning[0] else None))
+    # A second tensor object over the same memory: autograd's AccumulateGrad keeps the tensor it is handed as .grad only when nobody else
+    # holds it (otherwise it CLONES it -- here: a copy of memory the deferred launch has not written yet); the closure holds `slot`.
+    return slot.detach()
+
+
+def flush_deferred_wgrads(device=None, side=False):
+    """Launches the weight gradients deferred by the backward that runs on the current stream: on that stream (side False), or on its
+    weight-gradient side stream behind one event (side True; the operands are handed to the side stream for the allocator --
+    ``record_stream``: inside a capture their memory is then not re-used before the capture ends)."""
+    cur = torch.cuda.current_stream(device)
+    items = _wgrad_deferred.pop((cur.device.index, cur.cuda_stream), None)
+    if not items:
+        return
+
+    def run():
+        for fn, _reads, mode, knobs in items:
+            with ops.math_scope(mode):
+                if knobs is not None:
+                    with ops.tuning_scope(knobs):
+                        fn()
+                else:
+                    fn()
+
+    if not side:
+        return run()
+    from . import graphs
+    st = graphs.side_stream(cur.device, ("wgrad", cur.cuda_stream))
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    st.wait_event(ev)
+    with torch.cuda.stream(st):
+        run()
+    for _fn, reads, _m, _k in items:
+        for t in reads:
+            if t is not None and t.numel():
+                t.record_stream(st)
+    _wgrad_pending[(cur.device.index, st.cuda_stream)] = (st, cur.cuda_stream)
+
+
+class _WgradFlushPoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        flush_deferred_wgrads(g.device, side=True)
+        return g
+
+
+def wgrad_flush_point(x):
+    """Identity.  In a backward pass captured inside ``wgrad_side_branches()``, the point where the weight gradients deferred so far are
+    launched on the side stream (nothing otherwise: no node is added when the switch is off)."""
+    if not _wgrad_side["on"] or not x.requires_grad:
+        return x
+    return _WgradFlushPoint.apply(x)
+
+
+def join_wgrad_branches(device=None, forked_from=None):
+    """The current stream waits for the weight-gradient launches forked since the last join: those forked from stream `forked_from`, or
+    (None) all of the device's -- a step that reads the whole flat gradient reads every layer's.  The caller must be on the stream the
+    capture began on whenever the launches forked from a branch (see above; the passive step does its second network's Adam there)."""
+    if _wgrad_deferred:
+        raise RuntimeError("m2h.join_wgrad_branches: weight gradients are still deferred (flush_deferred_wgrads() comes first)")
+    if not _wgrad_pending:
+        return
+    cur = torch.cuda.current_stream(device)
+    want = forked_from.cuda_stream if forked_from is not None else None
+    for key in [k for k, (_s, org) in _wgrad_pending.items() if k[0] == cur.device.index and (want is None or org == want)]:
+        cur.wait_stream(_wgrad_pending.pop(key)[0])
 
 
 def conv_wgrad(x, x2, dy, n_out, kh, kw, stride, pad, gate=None, gate_slope=1.0, torch_ci=None, out=None):
@@ -440,9 +560,10 @@ class Conv2dNHWC(torch.autograd.Function):
                 dy = act_bwd(dy, y, slope)
                 gated = False
             if gated:                       # (any failure of the gated launch is a real error: it is not swallowed)
-                gw = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, gate=y, gate_slope=slope, torch_ci=Ci, out=slot)
+                gw = _wgrad_launch(x.device, (x, dy, y), lambda: conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, gate=y, gate_slope=slope, torch_ci=Ci, out=slot), slot)
             if gw is None:
-                gw = conv_wgrad(x, x2, dy, Co, KH, KW, stride, pad, torch_ci=Ci, out=slot)
+                dyw = dy     # (the name `dy` is not rebound below, but a deferred launch must not depend on that)
+                gw = _wgrad_launch(x.device, (x, x2, dyw), lambda: conv_wgrad(x, x2, dyw, Co, KH, KW, stride, pad, torch_ci=Ci, out=slot), slot)
         if ctx.needs_input_grad[3] and gb is None:
             gb = bias_grad(dy.view(B * Ho * Wo, Co))
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
@@ -574,8 +695,13 @@ class GRUSequence(torch.autograd.Function):
         M = T * N
         I = x.shape[1]
         # (a 1x1 "conv": the packed gradient [3H][K] IS the weight's layout -- written straight into the optimizer's flat gradient buffer)
-        g_wih = conv_wgrad(x.reshape(M, 1, 1, I), None, dgi.view(M, 1, 1, 3 * H), 3 * H, 1, 1, 1, 0, out=grad_slot(w_ih)) if ctx.needs_input_grad[3] else None
-        g_whh = conv_wgrad(hpm.view(M, 1, 1, H), None, dpre.view(M, 1, 1, 3 * H), 3 * H, 1, 1, 1, 0, out=grad_slot(w_hh)) if ctx.needs_input_grad[4] else None
+        g_wih = g_whh = None
+        if ctx.needs_input_grad[3]:
+            s_ih = grad_slot(w_ih)
+            g_wih = _wgrad_launch(dev, (x, dgi), lambda: conv_wgrad(x.reshape(M, 1, 1, I), None, dgi.view(M, 1, 1, 3 * H), 3 * H, 1, 1, 1, 0, out=s_ih), s_ih)
+        if ctx.needs_input_grad[4]:
+            s_hh = grad_slot(w_hh)
+            g_whh = _wgrad_launch(dev, (hpm, dpre), lambda: conv_wgrad(hpm.view(M, 1, 1, H), None, dpre.view(M, 1, 1, 3 * H), 3 * H, 1, 1, 1, 0, out=s_hh), s_hh)
         g_bih = bias_grad(dgi) if ctx.needs_input_grad[5] else None
         g_bhh = bias_grad(dpre) if ctx.needs_input_grad[6] else None
         g_x = None
@@ -941,6 +1067,25 @@ class ConvTranspose2dNHWC(torch.autograd.Function):
         C0 = x.shape[3]
         B, H, W, _ = x.shape
         gx = gx2 = gw = None
+        if ctx.needs_input_grad[2]:
+            lib = _lib.load()
+            slot = grad_slot(w)
+
+            def wgrad():
+                with torch.cuda.device(x.device):
+                    a = _convT_phase_args(x, x2, Co, 0, 0)   # the phase geometry; the launch walks all four phases
+                    nbytes = lib.m2h_convT_wgrad_workspace_bytes(ctypes.byref(a))
+                    ws = torch.empty((nbytes + 3) // 4, device=x.device)
+                    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+                    M = B * H * W
+                    out = slot if slot is not None else torch.empty_like(w)
+                    meta = {"kernel": "wgrad_f32", "M": 4 * M, "N": Co, "K": 4 * Cin, "flops": 2.0 * 4 * M * Co * 4 * Cin}
+                    ops._timed("convT_wgrad", meta, x.device,
+                               lambda: _lib.check(lib.m2h_convT_wgrad_f32(ctypes.byref(a), ops._ptr(dz), Co, ops._ptr(out), ops._stream(x)),
+                                                  "m2h_convT_wgrad_f32"))
+                return out
+
+            gw = _wgrad_launch(x.device, (x, x2, dz), wgrad, slot)
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             # [Cin][4][4][Co]: w read as a Conv2d weight [out=Cin][in=Co]
             wconv = ctx.memo.get_bwd(w, ("convT_dgrad",)) if ctx.memo is not None else ops.pack_conv_weight(w.detach().contiguous())
@@ -948,21 +1093,6 @@ class ConvTranspose2dNHWC(torch.autograd.Function):
                 gx = ops.conv2d_nhwc(dz, wconv[:C0].contiguous(), C0, 4, 4, stride=2, pad=1, slope=1.0, name="convT.dgrad")
             if x2 is not None and ctx.needs_input_grad[1]:
                 gx2 = ops.conv2d_nhwc(dz, wconv[C0:].contiguous(), Cin - C0, 4, 4, stride=2, pad=1, slope=1.0, name="convT.dgrad")
-        if ctx.needs_input_grad[2]:
-            lib = _lib.load()
-            with torch.cuda.device(x.device):
-                a = _convT_phase_args(x, x2, Co, 0, 0)   # the phase geometry; the launch walks all four phases
-                nbytes = lib.m2h_convT_wgrad_workspace_bytes(ctypes.byref(a))
-                ws = torch.empty((nbytes + 3) // 4, device=x.device)
-                a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
-                M = B * H * W
-                gw = grad_slot(w)
-                if gw is None:
-                    gw = torch.empty_like(w)
-                meta = {"kernel": "wgrad_f32", "M": 4 * M, "N": Co, "K": 4 * Cin, "flops": 2.0 * 4 * M * Co * 4 * Cin}
-                ops._timed("convT_wgrad", meta, x.device,
-                           lambda: _lib.check(lib.m2h_convT_wgrad_f32(ctypes.byref(a), ops._ptr(dz), Co, ops._ptr(gw), ops._stream(x)),
-                                              "m2h_convT_wgrad_f32"))
         return gx, gx2, gw, None
 
 

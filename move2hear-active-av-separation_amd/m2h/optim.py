@@ -86,6 +86,8 @@ class FlatAdam(torch.optim.Optimizer):
         """p.grad of every parameter (idx: of those parameters only) -> its slice of the flat gradient buffer (one batched copy; None
         counts as zeros).  A parameter gathered once is not gathered again before the next step / zero_grad: its slice may hold an
         all-reduced sum by then (bucketed reduction, ddppo_utils.GradReduceStep.early)."""
+        from . import functional
+        functional.join_wgrad_branches(self.flat_g.device)   # weight gradients forked to a side branch of a captured step (functional.wgrad_side_branches)
         if self._gathered:
             return
         done = self._gathered_idx
@@ -184,6 +186,8 @@ class FlatAdam(torch.optim.Optimizer):
         if len(self.param_groups) != 1:
             raise RuntimeError("FlatAdam.captured_step: one parameter group only (the captured step reads param_groups[0]'s lr / betas / eps)")
         b0, b1_, idx = self.param_range(params if params is not None else self._ps)
+        from . import functional
+        functional.join_wgrad_branches(self.flat_g.device, forked_from=torch.cuda.current_stream(self.flat_g.device))   # (another branch's are its own step's business)
         items = []
         for i in idx:
             p, off = self._ps[i], self._offsets[i]

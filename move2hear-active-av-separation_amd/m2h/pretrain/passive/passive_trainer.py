@@ -25,7 +25,8 @@ def passive_config(**over):
     """Pretrain.Passive.* of config/default.py:106-111 + config/pretrain_passive.yaml (BATCH_SIZE 64)."""
     c = dict(SEED=0, lr=5.0e-4, eps=1.0e-5, max_grad_norm=0.8, NUM_EPOCHS=1000, BATCH_SIZE=64, BATCHES_PER_EPOCH=8, VAL_BATCHES=2,
              CHECKPOINT_FOLDER=None, TM=32,
-             use_hip_graphs=True)  # build-side key: replay forward + losses + backward of a training batch from a HIP graph
+             use_hip_graphs=True,  # build-side key: replay forward + losses + backward of a training batch from a HIP graph
+             wgrad_side_branches=True)   # build-side key: inside that graph the weight gradients are side branches of the backward chains (functional.wgrad_side_branches)
     c.update(over)
     return SimpleNamespace(**c)
 
@@ -115,7 +116,7 @@ class PassiveTrainer:
             gs.memos_b = MF.memos_of(ac.bin2mono_enc, ac.bin2mono_dec)
             if gs.forked:
                 MF.refresh_pack_memos()    # the first replay finds the first network's packs made (later ones: packed at the end of the step before)
-            with graphs.capture(g):
+            with graphs.capture(g), MF.wgrad_side_branches(getattr(self.config, "wgrad_side_branches", True)):
                 mix, gtb, gtm, tc = gs.inputs
                 self.optimizer.zero_grad()
                 if gs.forked:
@@ -144,14 +145,20 @@ class PassiveTrainer:
                     with torch.cuda.stream(side):
                         mono_loss = MF.l1_loss(mono, gtm, 0)
                         mono_loss.backward(MF.unit_grad(self.device))
-                        self.optimizer.captured_step(list(ac.bin2mono_enc.parameters()) + list(ac.bin2mono_dec.parameters()))
+                        MF.flush_deferred_wgrads(self.device)      # (the encoder's weight gradients: deferred behind the last flush point)
                     bin_loss = MF.bin_l1_loss(masks, mix, gtb, cstep=1)
                     bin_loss.backward(MF.unit_grad(self.device))
-                    # each network's Adam step right behind its own backward, on its own branch (FlatAdam.captured_step: lr and the
+                    MF.flush_deferred_wgrads(self.device)
+                    # the first network's Adam step right behind its own backward (FlatAdam.captured_step: lr and the
                     # bias corrections come from a device buffer the host refreshes before each replay)
                     self.optimizer.captured_step(list(ac.binSep_enc.parameters()) + list(ac.binSep_dec.parameters()))
                     MF.refresh_pack_memos(hooks=False, only=gs.memos_a, force=True)
                     main.wait_stream(side)
+                    # The second network's Adam step HERE, on the stream the capture began on: its weight gradients were forked from the side
+                    # stream to a side stream of their own (MF.wgrad_side_branches), and only the origin stream may join those (MF.join_wgrad_branches).
+                    # Nothing is lost: that branch is the step's longest chain, its Adam step ends the step either way.
+                    MF.join_wgrad_branches(self.device)
+                    self.optimizer.captured_step(list(ac.bin2mono_enc.parameters()) + list(ac.bin2mono_dec.parameters()))
                 else:
                     with MF.batched_bn_counters():
                         masks = self.actor_critic.get_binSepMasks({"mixed_bin_audio_mag": mix, "target_class": tc})
@@ -159,6 +166,7 @@ class PassiveTrainer:
                     bin_loss = MF.bin_l1_loss(masks, mix, gtb, cstep=1)
                     mono_loss = MF.l1_loss(mono, gtm, 0)
                     (bin_loss + mono_loss).backward()
+                    MF.flush_deferred_wgrads(self.device)
                     self.optimizer.captured_step()
                 gs.losses = (bin_loss.detach(), mono_loss.detach())
             gs.graph = g

@@ -217,7 +217,10 @@ class PassiveSepDecCNN(nn.Module):
     def _forward_train(self, bottleneck_feats, lst_skip_feats):
         B = bottleneck_feats.size(0)
         wb = lst_skip_feats[0].size(3) // 2
-        out = _as_nhwc(bottleneck_feats.reshape(B, -1, 1, wb))
+        # (the backward pass is half done when it reaches the bottleneck: inside MF.wgrad_side_branches() the decoder's deferred weight
+        #  gradients are launched from here on a side stream, under the encoder's backward chain.  ONE such point per network: a second
+        #  one inside the encoder made the step 2.79 instead of 2.36 ms, profiles/r06_wgrad_side_ab.txt)
+        out = MF.wgrad_flush_point(_as_nhwc(bottleneck_feats.reshape(B, -1, 1, wb)))
         if not hasattr(self, "_memo_t"):
             self._memo_t = [MF._PackMemo() for _ in range(6)]
         for idx in range(5):

@@ -105,7 +105,7 @@ def test_acoustic_mem_update_path_with_both_fusions_matches_torch_autograd():
             le.backward()
         finally:
             ops.set_math_mode(ops.MATH_FP32)
-        assert abs(float(loss.detach()) - float(want)) <= 3e-5 * float(want)
+        assert abs(float(loss.detach()) - float(want.detach())) <= 3e-5 * float(want.detach())
         assert float(loss.detach()) == float(le.detach())
         assert torch.equal(g1, w1e.grad)                                       # same launches for conv1's weight gradient
         assert O.rel_l1(g0.cpu(), w0e.grad.cpu()) < 3e-5, (B, O.rel_l1(g0.cpu(), w0e.grad.cpu()))
@@ -114,3 +114,86 @@ def test_acoustic_mem_update_path_with_both_fusions_matches_torch_autograd():
         e0, e1 = O.rel_l1(g0.cpu(), w0c.grad), O.rel_l1(g1.cpu(), w1c.grad)
         u0 = O.rel_l1(w0e.grad.cpu(), w0c.grad)
         assert e1 < 2e-3 and e0 < 2e-3 and e0 < 1.5 * u0 + 1e-5, (B, e0, e1, u0)
+
+
+def _passive_run(side, steps=4):
+    """`steps` training batches of the passive trainer from one seeded state (first one kernel by kernel, the rest replayed from the
+    step's HIP graph); returns (losses, weights, was anything deferred)."""
+    import m2h.functional as MF
+    from m2h import synthetic
+    from m2h.pretrain.passive.passive_trainer import PassiveTrainer, passive_config
+    dev = _dev()
+    tr = PassiveTrainer(passive_config(BATCH_SIZE=4, wgrad_side_branches=side), dev)
+    tr.setup()
+    tr.actor_critic.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(synthetic.passive_shapes(), 4).items()})
+    seen = []
+    orig = MF.flush_deferred_wgrads
+
+    def spy(device=None, side=False):
+        cur = torch.cuda.current_stream(device)
+        seen.append((bool(side), len(MF._wgrad_deferred.get((cur.device.index, cur.cuda_stream), []))))
+        return orig(device, side)
+
+    MF.flush_deferred_wgrads = spy
+    try:
+        tr.actor_critic.train()
+        losses = []
+        for _ in range(steps):
+            b, m = tr.train_batch(*tr.feeders["train"].batch())
+            losses.append((b.item(), m.item()))
+    finally:
+        MF.flush_deferred_wgrads = orig
+    assert not MF._wgrad_deferred and not MF._wgrad_pending and not MF._wgrad_side["on"]
+    return losses, {k: v.detach().cpu().clone() for k, v in tr.actor_critic.state_dict().items()}, seen
+
+
+def test_deferred_weight_gradients_of_the_passive_step_leave_the_same_weights():
+    """functional.wgrad_side_branches: inside the captured training step each U-Net's decoder weight gradients are launched from the
+    bottleneck's flush point on a side stream, the encoder's behind the backward -- same kernels, so losses and weights after four
+    batches equal the step captured with the switch off BIT FOR BIT; and the flushes really carried launches (5 + 5 decoder / encoder layers
+    per network + the head's 1x1 conv)."""
+    la, wa, seen_a = _passive_run(True)
+    lb, wb, seen_b = _passive_run(False)
+    assert la == lb
+    for k in wa:
+        assert torch.equal(wa[k], wb[k]), k
+    assert all(n == 0 for _s, n in seen_b)                            # switch off: nothing is ever deferred
+    side = [n for s, n in seen_a if s]
+    tail = [n for s, n in seen_a if not s]
+    assert sorted(side) == [6, 6] and sorted(tail) == [5, 5], seen_a  # per network: head + 5 transposed convs at the bottleneck, 5 encoder convs at the end
+
+
+def test_deferred_weight_gradients_must_be_flushed():
+    """A capture that defers weight gradients and never launches them is an error of the caller, reported at the end of the block (and
+    by the optimizer's join, had it been reached) -- not a silently missing gradient."""
+    import m2h.functional as MF
+    from m2h import graphs
+    from m2h.optim import FlatAdam
+    dev = _dev()
+    w = torch.nn.Parameter(torch.randn(8, 8, 3, 3, device=dev) * 0.1)
+    opt = FlatAdam([w], lr=1e-3)
+    opt.build()
+    x = torch.randn(2, 8, 8, 8, device=dev)
+    memo = MF._PackMemo()
+    opt.zero_grad()
+    MF.conv2d(x, w, None, 1, 1, memo=memo).sum().backward()   # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="deferred"):
+        with graphs.capture(g), MF.wgrad_side_branches():
+            opt.zero_grad()
+            MF.conv2d(x, w, None, 1, 1, memo=memo).sum().backward()
+    assert not MF._wgrad_deferred and not MF._wgrad_side["on"]
+    # the same capture with the flush: the gradient equals the eager one
+    opt.zero_grad()
+    MF.conv2d(x, w, None, 1, 1, memo=memo).sum().backward()
+    want = w.grad.detach().clone()
+    g = torch.cuda.CUDAGraph()
+    with graphs.capture(g), MF.wgrad_side_branches():
+        opt.zero_grad()
+        MF.conv2d(x, w, None, 1, 1, memo=memo).sum().backward()
+        MF.flush_deferred_wgrads(dev)
+    opt.flat_g.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(opt.flat_g.view_as(w), want)
