@@ -207,6 +207,157 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// One launch per direction for the layers whose channel slab fits a block's REGISTERS: a block of 256 threads owns four channels
+// (one float4 per row), thread t holds rows t, t + 256, ... -- the slab is read ONCE, the statistics meet in a fixed order
+// (thread-sequential, then a shuffle tree per wave, then the waves in order: bit-reproducible), and the block applies them to what it
+// holds.  At the passive training batch (64 clips: 64 ... 65 536 rows of 512 ... 32 channels per layer) the three launches of the
+// general path are 15 us forward + 17 us backward per layer, nearly all of it launch and dependency latency.  Which layers take this
+// path: bn_small_rows below.  m2h_tuning_set(37, -1) forces the three-launch path (tests, A/B), > 0 sets the row limit.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define g_bn_small (::m2h::tl_tuning.v[37])
+constexpr int BNS_NT = 256;    // threads per block
+constexpr int BNS_RMAX = 16;   // rows per thread at most: layers of up to 4 096 rows
+
+// sum of v over the block, the same value in every thread: shuffle tree per wave, then the four waves' partials in wave order
+__device__ __forceinline__ void block_sum4(float (&v)[4], float (*sh)[4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+    if (lane == 0) sh[wave][k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
+}
+
+// R rows per thread (1, 4 or 16: the launch picks the smallest that covers M).  Two passes over the REGISTERS: the mean, then the
+// centred sum of squares (no E[x^2] - E[x]^2 cancellation, and no per-element division as in the streaming Welford update).
+template <int R>
+__global__ __launch_bounds__(BNS_NT) void bn_fwd_small_kernel(const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float eps, float momentum, float slope, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, float* __restrict__ mean, float* __restrict__ invstd,
+                                                              float* __restrict__ y, int M, int C) {
+  __shared__ float sh[2][4][4];
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.x * 4;
+  f32x4 x[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j)               // unconditional loads (clamped row), the select afterwards: all of them in flight together
+    x[j] = *reinterpret_cast<const f32x4*>(z + (size_t)min(tid + j * BNS_NT, M - 1) * C + c0);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+    if (tid + j * BNS_NT < M) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[k] += x[j][k];
+    }
+  block_sum4(s, sh[0]);
+  const float invM = 1.f / (float)M;
+  float mu[4], q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) mu[k] = s[k] * invM;
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+    if (tid + j * BNS_NT < M) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d = x[j][k] - mu[k];
+        q[k] += d * d;
+      }
+    }
+  block_sum4(q, sh[1]);
+  float is[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) is[k] = 1.f / sqrtf(q[k] * invM + eps);
+  if (tid < 4) {
+    const int c = c0 + tid;
+    const float m2 = tid == 0 ? q[0] : tid == 1 ? q[1] : tid == 2 ? q[2] : q[3];
+    const float mk = tid == 0 ? mu[0] : tid == 1 ? mu[1] : tid == 2 ? mu[2] : mu[3];
+    mean[c] = mk;
+    invstd[c] = tid == 0 ? is[0] : tid == 1 ? is[1] : tid == 2 ? is[2] : is[3];
+    if (running_mean != nullptr) {
+      const float var_u = M > 1 ? m2 / (float)(M - 1) : m2 * invM;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mk;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * var_u;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+    if (tid + j * BNS_NT < M) {
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = (x[j][k] - mu[k]) * is[k] * ga[k] + be[k];    // bn_apply_kernel's expression
+        o[k] = v > 0.f ? v : v * slope;
+      }
+      *reinterpret_cast<f32x4*>(y + (size_t)(tid + j * BNS_NT) * C + c0) = o;
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(BNS_NT) void bn_bwd_small_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ z,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, float slope, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ dz, int M, int C) {
+  __shared__ float sh[2][4][4];
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.x * 4;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c0), is = *reinterpret_cast<const f32x4*>(invstd + c0);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
+  f32x4 g[R], xh[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const size_t o = (size_t)min(tid + j * BNS_NT, M - 1) * C + c0;
+    const f32x4 vd = *reinterpret_cast<const f32x4*>(dy + o);
+    const f32x4 vy = *reinterpret_cast<const f32x4*>(y + o);
+    const f32x4 vz = *reinterpret_cast<const f32x4*>(z + o);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      g[j][k] = vy[k] > 0.f ? vd[k] : vd[k] * slope;
+      xh[j][k] = (vz[k] - mu[k]) * is[k];
+    }
+  }
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+    if (tid + j * BNS_NT < M) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s0[k] += g[j][k];
+        s1[k] += g[j][k] * xh[j][k];
+      }
+    }
+  block_sum4(s0, sh[0]);
+  block_sum4(s1, sh[1]);
+  if (tid < 4) {
+    dbeta[c0 + tid] = tid == 0 ? s0[0] : tid == 1 ? s0[1] : tid == 2 ? s0[2] : s0[3];
+    dgamma[c0 + tid] = tid == 0 ? s1[0] : tid == 1 ? s1[1] : tid == 2 ? s1[2] : s1[3];
+  }
+  const float invM = 1.f / (float)M;
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+    if (tid + j * BNS_NT < M) {
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = ga[k] * is[k] * (g[j][k] - s0[k] * invM - xh[j][k] * s1[k] * invM);   // bn_bwd_apply_kernel's expression
+      *reinterpret_cast<f32x4*>(dz + (size_t)(tid + j * BNS_NT) * C + c0) = o;
+    }
+}
+
+// rows per thread of the one-launch kernels for M rows (0: the general path).  The row limit: knob 37 > 0, else 256 -- measured on
+// the passive training step (profiles/r06_bn_small_ab.txt): the layers of 64 and 256 rows gain, those of 1 024 rows are even, 4 096
+// and 16 384 rows lose (a block's loads touch one 128-byte line per row for 16 bytes of it).
+static int bn_small_rows(int M, int C) {
+  if (g_bn_small < 0 || C % 4 != 0) return 0;
+  const int lim = g_bn_small > 0 ? g_bn_small : 256;
+  if (M > lim || M > BNS_RMAX * BNS_NT) return 0;
+  return M <= BNS_NT ? 1 : M <= 4 * BNS_NT ? 4 : 16;
+}
+
 static int bn_splits(int M, int C) {
   const int colblocks = (C + 63) / 64;
   int splits = (1024 + colblocks - 1) / colblocks;
@@ -238,6 +389,14 @@ int m2h_bn_train_fwd(const float* z, const float* gamma, const float* beta, floa
   M2H_REQUIRE(z && gamma && beta && mean && invstd && y && workspace && M > 1 && C > 0 && C % 4 == 0, "bn_train_fwd: bad arguments (C %% 4, M > 1)");
   M2H_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_fwd: running stats mismatch");
   hipStream_t st = as_stream(stream);
+  if (const int r = bn_small_rows(M, C)) {
+#define M2H_BN_FWD(R) M2H_LAUNCH(bn_fwd_small_kernel<R>, dim3(C / 4), dim3(BNS_NT), 0, st, z, gamma, beta, eps, momentum, slope, running_mean, running_var, mean, invstd, y, M, C)
+    if (r == 1) M2H_BN_FWD(1);
+    else if (r == 4) M2H_BN_FWD(4);
+    else M2H_BN_FWD(16);
+#undef M2H_BN_FWD
+    return launch_status("bn_train_fwd (one launch)");
+  }
   const int splits = bn_splits(M, C);
   const int rps = (M + splits - 1) / splits;
   M2H_LAUNCH(bn_stats_partial_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, z, workspace, M, C, rps);
@@ -253,6 +412,14 @@ int m2h_bn_train_bwd(const float* dy, const float* y, const float* z, const floa
   M2H_REQUIRE(dy && y && z && mean && invstd && gamma && dgamma && dbeta && dz && workspace && M > 1 && C > 0 && C % 4 == 0,
               "bn_train_bwd: bad arguments");
   hipStream_t st = as_stream(stream);
+  if (const int r = bn_small_rows(M, C)) {
+#define M2H_BN_BWD(R) M2H_LAUNCH(bn_bwd_small_kernel<R>, dim3(C / 4), dim3(BNS_NT), 0, st, dy, y, z, mean, invstd, gamma, slope, dgamma, dbeta, dz, M, C)
+    if (r == 1) M2H_BN_BWD(1);
+    else if (r == 4) M2H_BN_BWD(4);
+    else M2H_BN_BWD(16);
+#undef M2H_BN_BWD
+    return launch_status("bn_train_bwd (one launch)");
+  }
   const int splits = bn_splits(M, C);
   const int rps = (M + splits - 1) / splits;
   M2H_LAUNCH(bn_bwd_partial_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, y, z, mean, invstd, slope, workspace, M, C, rps);

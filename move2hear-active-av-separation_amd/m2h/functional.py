@@ -958,8 +958,10 @@ def l1_loss(pred, gt_comps, off=0):
 # ----------------------------------------------------------------------------------------------------------------
 # passive pre-training pieces: train-mode BN + activation, transposed conv with gradients, binaural L1
 # ----------------------------------------------------------------------------------------------------------------
+@carries_math_mode
 class BNAct(torch.autograd.Function):
-    """y = act(BatchNorm2d_train(z)) on NHWC z; running statistics updated in place (momentum 0.1, unbiased variance)."""
+    """y = act(BatchNorm2d_train(z)) on NHWC z; running statistics updated in place (momentum 0.1, unbiased variance).
+    (fp32 in every arithmetic mode; the decorator is here for the tuning knobs it carries into the backward under carry_tuning(): knob 37.)"""
 
     @staticmethod
     def forward(ctx, z, gamma, beta, running_mean, running_var, eps, momentum, slope):

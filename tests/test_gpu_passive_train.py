@@ -22,10 +22,31 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("slope,shape", [(0.2, (6, 64, 8, 16)), (0.0, (6, 64, 8, 16)), (0.0, (3, 512, 1, 2)), (0.2, (64, 64, 16, 16)), (0.2, (5, 128, 8, 8)),
-                                         (0.0, (7, 256, 4, 4)), (0.2, (64, 512, 2, 2)), (0.2, (3, 12, 4, 4)), (0.0, (5, 64, 20, 20))])
-def test_bn_act_train_forward_backward_match_torch(slope, shape):
+                                         (0.0, (7, 256, 4, 4)), (0.2, (64, 512, 2, 2)), (0.2, (3, 12, 4, 4)), (0.0, (5, 64, 20, 20)),
+                                         (0.2, (17, 64, 16, 16)), (0.0, (16, 128, 16, 16)), (0.2, (65, 64, 16, 16)), (0.0, (64, 32, 32, 32))])
+@pytest.mark.parametrize("path", ["auto", "three_launches"])
+def test_bn_act_train_forward_backward_match_torch(slope, shape, path):
+    """Both routes of csrc/bn.hip: one launch per direction for layers of at most 4 096 rows (1, 4 or 16 rows per thread: the shapes here sit on
+    both sides of every limit and include ragged row counts; the default limit is 256 rows, knob 37 raises it), three launches otherwise / with
+    knob 37 = -1."""
     from m2h import functional as MF
+    from m2h import ops
     dev = _dev()
+    M = shape[0] * shape[2] * shape[3]
+    if path == "three_launches" and M > 4096:
+        pytest.skip("already the three-launch route")
+    MF.carry_tuning(True)
+    ops.debug_set(37, -1 if path == "three_launches" else 4096)    # (the one-launch kernels wherever they can run: 1, 4 and 16 rows per thread)
+    try:
+        _bn_case(MF, dev, slope, shape)
+        label = ops.last_kernel()
+    finally:
+        ops.debug_set(37, 0)
+        MF.carry_tuning(False)
+    assert ("one launch" in label) == (path == "auto" and M <= 4096), label
+
+
+def _bn_case(MF, dev, slope, shape):
     g = torch.Generator().manual_seed(3)
     Cn = shape[1]
     x = (torch.randn(*shape, generator=g) * 1.7 + 0.4).requires_grad_(True)
