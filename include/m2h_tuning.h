@@ -18,7 +18,7 @@
  * off, 1 = wherever its shape conditions hold), 34 = -1: no split-K launches of the LDS-DMA / shared-patch engines (two K-halves, K-parts of the deepest stages), 35 = -1: the whole-network
  * runner does not take the strip-walker kernels (csrc/conv_strip.hip), 36 the shared-patch LDS-DMA engine (csrc/conv_patch.hip; -1
  * off, 2 = below the tile-count threshold too, 3 = as 2 with the whole-image patch wherever it fits, 8 = one workgroup per tile instead of one per CU walking its tiles: A/B), 10 = n >= 8: the shared-patch engine's persistent launches take n workgroups instead of one per CU (tests, 25 = -1: weight gradients of layers with at most 1024 rows keep the 128-wide blocks (0: 64-wide, twice as many), 33 = -1: the skinny gather kernel does not take layers of 1024-4096 pixels with tiny weights (they go to the tiled engine's split-K launches), 39 walking direction of the strip kernels' images (bit 0: the masked first stage downwards, bit 1: the last stage upwards instead of downwards, bit 2: the unmasked first stage downwards; same values in any direction), 38 the skinny gather kernel's 16-row blocks (-1 never, 1 always; 0 = where 32-row blocks would leave most CUs empty).  Numbers of experiments that were measured and removed
- * (5, 6, 12, 13, 17, 19, 20, 29, 31, 32) are accepted and ignored.  37 = -1: train-mode BatchNorm always takes its three-launch path (0: layers of at most 256 rows take one launch per direction, > 0: layers of at most that many rows, up to 4 096; csrc/bn.hip). */
+ * (5, 6, 13, 17, 19, 20, 29, 31, 32) are accepted and ignored.  12 = -1: narrow weight-gradient blocks always take three k sub-tiles when K allows (0: two where that leaves fewer padding columns).  37 = -1: train-mode BatchNorm always takes its three-launch path (0: layers of at most 256 rows take one launch per direction, > 0: layers of at most that many rows, up to 4 096; csrc/bn.hip). */
 #ifndef M2H_TUNING_H
 #define M2H_TUNING_H
 #ifdef __cplusplus

@@ -933,6 +933,9 @@ static void wgrad_cfg(int N, int K, int& bng, int& kt, int& ktiles, long M = 1L 
   // MFMAs -- 64-wide blocks, twice as many, each half as long: 33 -> 28, 21 -> 14, 31 -> 27 us per policy epoch (knob 25 = -1: the 128-wide blocks)
   if (M <= 1024 && N > 64 && K <= 2048 && g_wgrad_small_m >= 0) bng = 64;   // (K <= 2048: the 4608-deep full-spatial conv re-reads its input rows once per n-block: 34 -> 54 us)
   kt = bng == 32 ? (kt128 >= 3 ? 3 : kt128) : (bng == 64 ? (kt128 >= 2 && N <= 64 ? 2 : 1) : 1);  // narrow layers: up to three k sub-tiles per block share the dY operand
+  // ... unless two sub-tiles per block leave fewer padding columns (K = 512: two blocks of 256 instead of two of 384 -- the last decoder
+  // stage's weight gradient, 65 536 pixels x 512 x 16 | 32, spent a third of its MFMAs and input loads on columns beyond K; knob 12 = -1: the old rule)
+  if (bng == 32 && kt == 3 && tl_tuning.v[12] >= 0 && ((kt128 + 1) / 2) * 2 < ((kt128 + 2) / 3) * 3) kt = 2;
   ktiles = (kt128 + kt - 1) / kt;
 }
 
