@@ -120,6 +120,8 @@ def wgrad_side_branches(enabled=True):
     finally:
         _wgrad_side["on"] = prev
         _wgrad_deferred.clear()
+        if not prev:
+            _wgrad_pending.clear()    # (a body that raised may leave side streams nobody joined: a later capture must not wait for them)
 
 
 def _wgrad_launch(dev, reads, fn, slot):
