@@ -510,6 +510,10 @@ int m2h_policy_heads_bwd(const float* logp_all, const float* probs, const long l
                          const float* g_ent, const float* Wa, const float* Wc, float* dz, float* dfeats, int M, int H, int A, int ZS,
                          m2h_stream stream);
 
+/* Parameter gradients of the two heads (common/utils.py:42-50, rl/ppo/policy.py:15-23 through autograd) from m2h_policy_heads_bwd's dz [M][ZS] and the
+ * features [M][H]: dw [ZS][H] = dz^T feats (rows 0..A-1: the action head's weight, row A: the critic's), db [ZS] = column sums of dz.  H % 64 == 0, ZS 4 | 8. */
+int m2h_policy_heads_wgrad(const float* feats, const float* dz, float* dw, float* db, int M, int H, int ZS, m2h_stream stream);
+
 /* F.l1_loss(pred, gt) with gt read strided from an interleaved tensor (ppo.py:212-221; passive_trainer.py:271-275):
  * loss[0] = mean |pred - gt|, grad[i] = sign(pred-gt)/n (NULL to skip).  scratch: >= 1024 floats. */
 int m2h_l1_loss(const float* pred, const float* gt, int gt_stride, int gt_off, float* loss, float* grad, float* scratch, size_t n,

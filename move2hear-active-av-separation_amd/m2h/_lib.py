@@ -236,6 +236,7 @@ SIGNATURES = {
     "m2h_gru_bwd_rec": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_gru_bwd_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "m2h_policy_heads_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "m2h_policy_heads_wgrad": [_P, _P, _P, _P, _I, _I, _I, _P],
     "m2h_l1_loss": [_P, _P, _I, _I, _P, _P, _P, _Z, _P],
     "m2h_l1_loss_nhwc16": [_P, _P, _I, _I, _P, _P, _P, _I, _I, _P],
     "m2h_bin_l1_loss": [_P, _P, _P, _I, _I, _P, _P, _P, _Z, _P],

@@ -641,6 +641,7 @@ class GRUSequence(torch.autograd.Function):
             h = ops.gru_gates(gi[sl], ght, bhh, h, masks[sl], out=out[sl])
         ctx.T = T
         ctx.save_for_backward(x, h0, masks, w_ih, w_hh, b_hh, gi, gh, out)
+        ctx.set_materialize_grads(False)      # (the update never differentiates the final state: no zero tensor, no add of it in the backward)
         return out, h
 
     @staticmethod
@@ -661,7 +662,7 @@ class GRUSequence(torch.autograd.Function):
         else:
             whh_t = pack_dgrad_weight(w_hh.detach().reshape(3 * H, H, 1, 1).contiguous(), 1, 0).view(H, 3 * H)
         fused = N <= ops.GRU_STEP_MAX_ROWS and H % 16 == 0
-        dh = g_out[(T - 1) * N:T * N].clone()
+        dh = g_out[(T - 1) * N:T * N]               # (read only below: no copy)
         if g_hT is not None:
             dh = dh + g_hT  # tiny [N,H] add; hT is rarely used downstream
         dh = dh.contiguous()
@@ -760,6 +761,7 @@ class PolicyHeads(torch.autograd.Function):
         ctx.save_for_backward(feats, wa, wc, logp_all, probs, actions if actions is not None else feats.new_empty(0))
         ctx.has_actions = actions is not None
         ctx.mark_non_differentiable(probs, logp_all)
+        ctx.set_materialize_grads(False)      # (no zero tensors -- a fill launch each -- for the outputs nobody differentiates: backward takes None)
         if logp_act is None:
             logp_act = feats.new_zeros((feats.shape[0], 1))
         return value, logp_act, ent, probs, logp_all
@@ -781,8 +783,16 @@ class PolicyHeads(torch.autograd.Function):
             _lib.check(lib.m2h_policy_heads_bwd(ops._ptr(logp_all), ops._ptr(probs), ops._ptr(actions if ctx.has_actions else None),
                                                 ops._ptr(gv), ops._ptr(gl), ops._ptr(ge), ops._ptr(wa.detach()), ops._ptr(wc.detach()), ops._ptr(dz),
                                                 ops._ptr(dfeats), M, H, A, ZS, ops._stream(feats)), "m2h_policy_heads_bwd")
-        dw = conv_wgrad(feats.detach().reshape(M, 1, 1, H), None, dz.view(M, 1, 1, ZS), ZS, 1, 1, 1, 0)  # [ZS, H]
-        db = bias_grad(dz)
+        if H % 64 == 0 and ZS in (4, 8) and feats.is_contiguous():
+            # both heads' weight and bias gradients in one small launch (the tiled weight-gradient engine + its reduce + the bias launch were 28 us here)
+            dw = torch.empty((ZS, H), device=dev)
+            db = torch.empty((ZS,), device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.m2h_policy_heads_wgrad(ops._ptr(feats.detach()), ops._ptr(dz), ops._ptr(dw), ops._ptr(db), M, H, ZS, ops._stream(feats)),
+                           "m2h_policy_heads_wgrad")
+        else:
+            dw = conv_wgrad(feats.detach().reshape(M, 1, 1, H), None, dz.view(M, 1, 1, ZS), ZS, 1, 1, 1, 0)  # [ZS, H]
+            db = bias_grad(dz)
         return dfeats, dw[:A].contiguous(), db[:A].contiguous(), dw[A:A + 1].contiguous(), db[A:A + 1].contiguous(), None
 
 
@@ -798,6 +808,7 @@ class PPOLoss(torch.autograd.Function):
         ctx.ecoef = entropy_coef
         ctx.n = values.numel()
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)
         return out[3], out
 
     @staticmethod

@@ -178,17 +178,19 @@ def test_rnn_state_encoder_variants_match_the_reference_fixture(tag, kw):
         assert _rel(y2, gold[pre + "y"]) < TOL and _rel(hT2, gold[pre + "hT"]) < TOL
 
 
-def test_policy_heads_and_ppo_loss_backward_match_torch():
+@pytest.mark.parametrize("M,H,A", [(280, 512, 3), (280, 512, 4), (37, 128, 4), (280, 512, 8)])
+def test_policy_heads_and_ppo_loss_backward_match_torch(M, H, A):
+    """(A = 3 / 4: dz rows of 4 / 8 floats through m2h_policy_heads_wgrad, 37 rows: a ragged last round; A = 8: dz rows of 12 floats, the tiled engine's route)"""
     from m2h import functional as MF
+    from m2h import ops
     dev = _dev()
     g = torch.Generator().manual_seed(21)
-    M, H = 280, 512
     feats = torch.randn(M, H, generator=g, requires_grad=True)
-    sd = {"action_dist.linear.weight": (torch.randn(3, H, generator=g) * 0.05).requires_grad_(True),
-          "action_dist.linear.bias": (torch.randn(3, generator=g) * 0.1).requires_grad_(True),
+    sd = {"action_dist.linear.weight": (torch.randn(A, H, generator=g) * 0.05).requires_grad_(True),
+          "action_dist.linear.bias": (torch.randn(A, generator=g) * 0.1).requires_grad_(True),
           "critic.fc.weight": (torch.randn(1, H, generator=g) * 0.05).requires_grad_(True),
           "critic.fc.bias": (torch.randn(1, generator=g) * 0.1).requires_grad_(True)}
-    actions = torch.randint(0, 3, (M, 1), generator=g)
+    actions = torch.randint(0, A, (M, 1), generator=g)
     old_v, ret, adv = (torch.randn(M, 1, generator=g) for _ in range(3))
     value, logp_all, probs = O.heads(sd, feats)
     logp = logp_all.gather(1, actions)
